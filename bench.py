@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (driver contract, see BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the simulation hot path -- Fluid::UpdateFrame + Fluid::Simulate = semi-Lagrangian
+advection, divergence, 40 lock-step Jacobi sweeps, projection -- over the 256^3 fp32 smoke grid of
+BASELINE.json configs[2] (zero-initialised fields, built-in Gaussian impulse, dt = 2/Y, CLAMP sampler),
+with every field resident in HBM before the timed region.  metric = voxel-updates/s.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the same 256^3 grid is cut into N z-slabs
+(strong scaling), one slab per rank, neighbour halo planes exchanged with RCCL send/recv pairs over xGMI
+inside libfluidx_hip.so; torch.distributed only carries the rendezvous (RCCL unique id), the barriers and
+the max-over-ranks reduction of the step time.
+
+The JSON line carries `roofline` (dominant kernel = the Jacobi sweep: 12 algorithmic bytes per cell-sweep,
+timed with HIP events on the kernel's own stream inside the timed region) and `cpu_baseline` (the CPU
+oracle -- a scalar C++ port of the reference shaders, OpenMP over planes -- timed on the host cores on a
+bounded sample of the same workload).  The oracle is used ONLY for that reported baseline.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+JACOBI_BYTES_PER_CELL_SWEEP = 12.0   # read p, read b, write p'  
+
+
+def step_bytes_per_voxel(iters, storage):
+    V, Cb = (12, 16) if storage == "fp32" else (6, 8)
+    return 5 * V + 2 * Cb + 2 * 4 + 12 * iters            # 5V + 2C + 2S + 12 N
+
+
+def slab_for_rank(Z, rank, world):
+    z0 = rank * Z // world
+    z1 = (rank + 1) * Z // world
+    return z0, z1 - z0
+
+
+def cpu_baseline(grid, iters, budget_s=20.0):
+    """Time the CPU oracle (port of the reference shaders) on a bounded sample of the same workload:
+    full simulation steps on a grid x grid x nz sub-volume sized for ~budget_s of CPU work."""
+    from oracle import orc                       # cpu_baseline leg only
+    ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    os.environ.setdefault("OMP_NUM_THREADS", str(ncores))
+    # calibrate on a thin slab, then pick the depth that fits the budget (>= 8 planes, <= grid)
+    nz = 8
+    sim = orc.Sim(grid, grid, nz, iters=iters)
+    sim.step(2.0 / grid)
+    t0 = time.perf_counter()
+    sim.step(2.0 / grid)
+    per_plane = (time.perf_counter() - t0) / nz
+    steps = 2
+    nz = int(max(8, min(grid, budget_s / steps / max(per_plane, 1e-9))))
+    sim = orc.Sim(grid, grid, nz, iters=iters)
+    sim.step(2.0 / grid)                         # warm-up (page faults, OpenMP pool)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sim.step(2.0 / grid)
+    dt = time.perf_counter() - t0
+    vox = float(grid) * grid * nz * steps
+    return {"value": vox / dt, "unit": "voxel-updates/s", "cores": ncores, "kind": "port",
+            "sample": "%d steps of advect+divergence+%d Jacobi+project on a %dx%dx%d sub-volume of the %d^3 workload "
+                      "(oracle/liborc.so, -O3, OpenMP over planes)" % (steps, iters, grid, grid, nz, grid)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--iters", type=int, default=40)
+    ap.add_argument("--storage", default="fp32", choices=["fp32", "fp16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="distributed plumbing only (no GPU work); used by the gloo CPU tests, never a measurement")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world != 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    N = world
+    G = args.grid
+
+    dist = None
+    if N > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.dry_run:
+            dist.init_process_group("gloo", rank=rank, world_size=N)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=N, device_id=torch.device("cuda", local_rank))
+
+    z0, nz = slab_for_rank(G, rank, N)
+
+    fluid = None
+    if not args.dry_run:
+        import fluidx12_amd as fx
+        fluid = fx.Fluid()
+        ok = fluid.Init(1920, 1080, (G, G, G), storage=args.storage, jacobi_iters=args.iters, jacobi_mode="fixed",
+                        advect_address="clamp", device=local_rank if N > 1 else -1,
+                        slab=(z0, nz) if N > 1 else None)
+        if not ok:
+            raise SystemExit("Fluid.Init failed (status %d): the HIP library needs a MI355X" % fluid.last_status)
+
+    # ---- RCCL rendezvous: rank 0 creates the unique id, torch.distributed broadcasts the bytes ----
+    if N > 1:
+        import torch
+        if args.dry_run:
+            uid = bytes(range(128)) if rank == 0 else None
+        else:
+            uid = fx.comm_unique_id() if rank == 0 else None
+        box = [uid]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+        assert isinstance(uid, (bytes, bytearray)) and len(uid) >= 128
+        if not args.dry_run:
+            fluid.comm_init_rank(uid, rank, N)
+
+    dt = 2.0 / G                                  # FluidX12.cpp:266
+
+    def one_step(k):
+        if fluid is not None:
+            fluid.UpdateFrame(dt, k % 3)
+            fluid.Simulate(k % 3)
+
+    def barrier_sync():
+        if fluid is not None:
+            fluid.Synchronize()
+        if N > 1:
+            if not args.dry_run:
+                import torch
+                torch.cuda.synchronize()
+            dist.barrier()
+
+    for k in range(args.warmup):
+        one_step(k)
+    if fluid is not None:
+        fluid.timing_enable(True)
+        fluid.timing_read(reset=True)
+    barrier_sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(args.warmup + k)
+    barrier_sync()
+    elapsed = time.perf_counter() - t0
+
+    if N > 1:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        if not args.dry_run:
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    roof = None
+    timing = None
+    if fluid is not None:
+        timing = fluid.timing_read(reset=True)
+        fluid.timing_enable(False)
+        if timing.jacobi_launches:
+            cells = float(G) * G * nz                                  # cells this rank sweeps
+            avg_launch_s = timing.jacobi_ms * 1e-3 / timing.jacobi_launches
+            sweeps_per_launch = timing.jacobi_sweeps / timing.jacobi_launches
+            achieved = JACOBI_BYTES_PER_CELL_SWEEP * cells * sweeps_per_launch / avg_launch_s / 1e9
+            roof = {"bound": "hbm", "kernel": "jacobi sweep", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "algorithmic_bytes_per_launch": JACOBI_BYTES_PER_CELL_SWEEP * cells * sweeps_per_launch,
+                    "avg_launch_us": avg_launch_s * 1e6, "launches": int(timing.jacobi_launches),
+                    "sweeps_per_launch": sweeps_per_launch,
+                    "cell_updates_per_s": cells * timing.jacobi_sweeps / (timing.jacobi_ms * 1e-3)}
+
+    if rank == 0:
+        voxels = float(G) ** 3 * args.steps
+        out = {
+            "metric": "voxel-updates/sec (advect+40 Jacobi) at 256^3; achieved HBM GB/s vs peak",
+            "value": voxels / elapsed if not args.dry_run else 0.0,
+            "unit": "voxel-updates/s",
+            "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32" if args.storage == "fp32" else "f32 arithmetic / f16 field storage",
+            "data": "synthetic",
+            "config": {"workload": "%d^3 3D smoke, %d Jacobi sweeps, %s fields, advect+divergence+Jacobi+project per step"
+                                   % (G, args.iters, args.storage),
+                       "grid": [G, G, G], "jacobi_iters": args.iters, "storage": args.storage,
+                       "parallelism": "single GPU" if N == 1 else "z-slab x%d, RCCL send/recv halo exchange" % N,
+                       "bytes_per_voxel_step": step_bytes_per_voxel(args.iters, args.storage)},
+        }
+        if args.dry_run:
+            out["dry_run"] = True
+        if timing is not None:
+            out["stage_ms_per_step"] = {k: getattr(timing, k + "_ms") / max(timing.steps, 1)
+                                        for k in ("advect", "divergence", "jacobi", "project", "exchange")}
+            sb = step_bytes_per_voxel(args.iters, args.storage) * float(G) ** 3
+            out["step_algorithmic_GBps"] = sb / (elapsed / args.steps) / 1e9
+        if roof is not None:
+            out["roofline"] = roof
+        if N == 1 and not args.no_cpu_baseline and not args.dry_run:
+            out["cpu_baseline"] = cpu_baseline(G, args.iters, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+
+    if fluid is not None:
+        fluid.Release()
+    if N > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,115 @@
+"""ctypes declarations of the C ABI in include/fluidx_hip.h (libfluidx_hip.so).
+
+The library is the product: there is no Python/CPU fallback.  `load()` raises if the HIP
+extension cannot be built or loaded.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+FX_OK = 0
+FX_E_INVALID, FX_E_DEVICE, FX_E_NOMEM, FX_E_STATE, FX_E_COMM, FX_E_HALO = -1, -2, -3, -4, -5, -6
+
+RAY_MARCH_DIRECT, RAY_MARCH_CUBEMAP, SEPARATE_LIGHT_PASS, OPTIMIZED = 0, 1, 2, 3
+FRAME_COUNT = 3
+STORAGE_FP32, STORAGE_FP16 = 0, 1
+JACOBI_FIXED, JACOBI_FAITHFUL = 0, 1
+ADDRESS_CLAMP, ADDRESS_MIRROR = 0, 1
+(FIELD_VELOCITY, FIELD_VELOCITY1, FIELD_COLOR, FIELD_COLOR_PREV, FIELD_PRESSURE, FIELD_DIVERGENCE,
+ FIELD_LIGHTMAP, FIELD_CUBEMAP) = range(8)
+
+
+class Desc(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("grid_x", C.c_uint32), ("grid_y", C.c_uint32), ("grid_z", C.c_uint32),
+                ("viewport_w", C.c_uint32), ("viewport_h", C.c_uint32), ("storage", C.c_uint32),
+                ("jacobi_iters", C.c_uint32), ("jacobi_mode", C.c_uint32), ("advect_address", C.c_uint32),
+                ("device", C.c_int32), ("slab_z0", C.c_uint32), ("slab_nz", C.c_uint32),
+                ("halo_advect", C.c_uint32), ("halo_jacobi", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class FrameInfo(C.Structure):
+    _fields_ = [("cube_lod", C.c_uint32), ("cube_size", C.c_uint32), ("ray_samples", C.c_uint32),
+                ("visibility_mask", C.c_uint32), ("frame_parity", C.c_uint32), ("edge_pixels", C.c_float),
+                ("time_step", C.c_float)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("advect_ms", C.c_double), ("divergence_ms", C.c_double), ("jacobi_ms", C.c_double),
+                ("project_ms", C.c_double), ("light_ms", C.c_double), ("view_ms", C.c_double),
+                ("exchange_ms", C.c_double), ("steps", C.c_uint64), ("jacobi_launches", C.c_uint64),
+                ("jacobi_sweeps", C.c_uint64), ("renders", C.c_uint64)]
+
+
+# every symbol include/fluidx_hip.h declares: name -> (restype, argtypes)
+_vp, _fp = C.c_void_p, C.POINTER(C.c_float)
+SYMBOLS = {
+    "fx_abi_version": (C.c_int, []),
+    "fx_error_string": (C.c_char_p, [C.c_int]),
+    "fx_create": (C.c_int, [C.POINTER(_vp), C.POINTER(Desc)]),
+    "fx_destroy": (C.c_int, [_vp]),
+    "fx_set_max_samples": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
+    "fx_set_sh": (C.c_int, [_vp, _fp]),
+    "fx_update_frame": (C.c_int, [_vp, C.c_float, C.c_uint8, _fp, _fp, _fp]),
+    "fx_simulate": (C.c_int, [_vp, _vp, C.c_uint8]),
+    "fx_render": (C.c_int, [_vp, _vp, C.c_uint8, C.c_uint8]),
+    "fx_get_frame_info": (C.c_int, [_vp, C.POINTER(FrameInfo)]),
+    "fx_synchronize": (C.c_int, [_vp]),
+    "fx_upload": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
+    "fx_download": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
+    "fx_field_bytes": (C.c_size_t, [_vp, C.c_int]),
+    "fx_advect": (C.c_int, [_vp, _vp]),
+    "fx_divergence": (C.c_int, [_vp, _vp]),
+    "fx_jacobi": (C.c_int, [_vp, _vp, C.c_uint32]),
+    "fx_project": (C.c_int, [_vp, _vp]),
+    "fx_sh_transform": (C.c_int, [_vp, _fp, C.c_uint32, _fp]),
+    "fx_timing_enable": (C.c_int, [_vp, C.c_int]),
+    "fx_timing_read": (C.c_int, [_vp, C.POINTER(Timing), C.c_int]),
+    "fx_comm_id_bytes": (C.c_size_t, []),
+    "fx_comm_get_unique_id": (C.c_int, [_vp, C.c_size_t]),
+    "fx_comm_init_rank": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_int]),
+    "fx_comm_init_local": (C.c_int, [C.POINTER(_vp), C.c_int]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load libfluidx_hip.so (building it first if a source is newer).  Raises on failure."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    try:
+        # A process that also uses torch must share ONE HIP runtime: torch bundles its own
+        # libamdhip64 and must be imported before this library resolves the same soname.
+        import torch  # noqa: F401
+    except Exception:  # torch is plumbing, not a requirement
+        pass
+    path = _build.ensure_built()
+    if not os.path.exists(path):
+        raise RuntimeError("libfluidx_hip.so is missing and could not be built")
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.fx_abi_version() != 1:
+        raise RuntimeError("fluidx ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+class FluidxError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        msg = load().fx_error_string(status).decode()
+        super().__init__("%s failed: %s (%d)" % (where, msg, status))
+
+
+def check(status, where):
+    if status != FX_OK:
+        raise FluidxError(status, where)

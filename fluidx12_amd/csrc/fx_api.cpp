@@ -1,0 +1,768 @@
+// fx_api.cpp -- implementation of the C ABI declared in include/fluidx_hip.h: the HIP re-statement
+// of class Fluid's host side (/root/reference/FluidX12/Content/Fluid.cpp).  XUSG resources become
+// hipMalloc'd fields, the command list becomes a HIP stream, the 3-slot upload constant buffers
+// (Fluid.cpp:239-252) become kernel arguments passed by value (no host/device hazard, so
+// `frame_index` only needs range-checking).
+//
+// No CPU fallback and nothing from oracle/: every field operation is a HIP kernel.
+#include "fx_context.h"
+#include "fx_hostmath.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+using namespace fx;
+
+#define FX_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+	ctx->last_error = std::string(#call) + ": " + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? FX_E_NOMEM : FX_E_DEVICE; } } while (0)
+
+namespace {
+
+const uint32_t kNumMips = 5;            // Fluid.cpp:229
+const uint32_t kDefaultAdvectHalo = 8;  // z back-trace reach <= 6 cells in practice
+const uint32_t kDefaultJacobiHalo = 4;
+
+hipStream_t pick_stream(fx_ctx* ctx, void* s) { return s ? (hipStream_t)s : ctx->stream; }
+
+size_t elem_size(const fx_ctx* c) { return c->half ? 2 : 4; }
+
+struct DeviceGuard {
+	int prev = -1;
+	bool ok = true;
+	explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) ok = hipSetDevice(dev) == hipSuccess; }
+	~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// ---- timing ---------------------------------------------------------------------------------
+enum MarkKind { MK_ADVECT, MK_DIV, MK_JACOBI, MK_PROJECT, MK_LIGHT, MK_VIEW, MK_EXCH };
+
+size_t ev_record(fx_ctx* c, hipStream_t s)
+{
+	if (c->ev_used == c->ev.size()) {
+		hipEvent_t e;
+		if (hipEventCreate(&e) != hipSuccess) return (size_t)-1;
+		c->ev.push_back(e);
+	}
+	(void)hipEventRecord(c->ev[c->ev_used], s);
+	return c->ev_used++;
+}
+
+struct ScopedMark {
+	fx_ctx* c; hipStream_t s; int kind; size_t e0; uint64_t launches, sweeps;
+	ScopedMark(fx_ctx* c_, hipStream_t s_, int kind_) : c(c_), s(s_), kind(kind_), e0((size_t)-1), launches(0), sweeps(0)
+	{
+		if (c->timing_on) e0 = ev_record(c, s);
+	}
+	~ScopedMark()
+	{
+		if (c->timing_on && e0 != (size_t)-1) {
+			const size_t e1 = ev_record(c, s);
+			if (e1 != (size_t)-1) c->marks.push_back(fx_ctx::Mark{ kind, e0, e1, launches, sweeps });
+		}
+	}
+};
+
+int drain_timing(fx_ctx* c)
+{
+	for (const auto& m : c->marks) {
+		float ms = 0.0f;
+		if (hipEventSynchronize(c->ev[m.e1]) != hipSuccess) return FX_E_DEVICE;
+		if (hipEventElapsedTime(&ms, c->ev[m.e0], c->ev[m.e1]) != hipSuccess) return FX_E_DEVICE;
+		switch (m.kind) {
+		case MK_ADVECT: c->acc.advect_ms += ms; break;
+		case MK_DIV: c->acc.divergence_ms += ms; break;
+		case MK_JACOBI: c->acc.jacobi_ms += ms; c->acc.jacobi_launches += m.launches; c->acc.jacobi_sweeps += m.sweeps; break;
+		case MK_PROJECT: c->acc.project_ms += ms; break;
+		case MK_LIGHT: c->acc.light_ms += ms; break;
+		case MK_VIEW: c->acc.view_ms += ms; break;
+		case MK_EXCH: c->acc.exchange_ms += ms; break;
+		}
+	}
+	c->marks.clear();
+	c->ev_used = 0;
+	return FX_OK;
+}
+
+// ---- staging ----------------------------------------------------------------------------------
+int ensure_stage(fx_ctx* ctx, size_t bytes)
+{
+	if (ctx->stage_bytes >= bytes) return FX_OK;
+	if (ctx->stage) { FX_HIP(hipFree(ctx->stage)); ctx->stage = nullptr; ctx->stage_bytes = 0; }
+	FX_HIP(hipMalloc((void**)&ctx->stage, bytes));
+	ctx->stage_bytes = bytes;
+	return FX_OK;
+}
+
+void free_all(fx_ctx* c)
+{
+	for (int i = 0; i < 2; ++i) {
+		if (c->vel[i]) (void)hipFree(c->vel[i]);
+		if (c->col[i]) (void)hipFree(c->col[i]);
+		if (c->p[i]) (void)hipFree(c->p[i]);
+	}
+	void* others[] = { c->b, c->frozen, c->lightmap, c->cube, c->sh_dev, c->halo_overflow, c->stage,
+		c->sh_scratch[0], c->sh_scratch[1], c->sh_scratch[2], c->sh_scratch[3] };
+	for (void* q : others) if (q) (void)hipFree(q);
+	for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+	if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
+}
+
+// planes of the local array a stage may compute / read, as global z ranges
+struct Range { int lo, hi; };   // [lo, hi)
+Range owned(const fx_ctx* c) { return Range{ c->g.z0, c->g.z0 + c->g.nz }; }
+Range grown(const fx_ctx* c, int by)
+{
+	return Range{ std::max(c->g.z0 - by, 0), std::min(c->g.z0 + c->g.nz + by, c->g.Zg) };
+}
+
+// ---- the simulation step, phase by phase, over a group of slab contexts ----------------------------
+// (Fluid::Simulate, Fluid.cpp:348-410; the phase structure is what lets one code path serve the
+// single-GPU case, the RCCL slabs and the in-process loop-back slabs)
+int for_members(fx_ctx* ctx, std::vector<fx_ctx*>& out)
+{
+	out.clear();
+	if (ctx->group && ctx->group->transport->is_local()) out = ctx->group->members;
+	else out.push_back(ctx);
+	return FX_OK;
+}
+
+int do_exchange(fx_ctx* ctx, int which_set, int k, hipStream_t s)
+{
+	if (!ctx->group || ctx->nranks <= 1 || k <= 0) return FX_OK;
+	ScopedMark mk(ctx, s, MK_EXCH);
+	return ctx->group->transport->exchange(ctx->group, which_set, k, s);
+}
+
+int advect_phase(fx_ctx* ctx, hipStream_t s)
+{
+	DeviceGuard dg(ctx->device);
+	const SimParams sp{ ctx->time_step, (int)ctx->desc.advect_address, ctx->g.Zg > 1 ? 1 : 0 };
+	const int par = ctx->frame_parity;
+	ScopedMark mk(ctx, s, MK_ADVECT);
+	const Range r = owned(ctx);
+	FX_HIP(launch_advect(ctx->g, sp, ctx->half, ctx->vel[0], ctx->col[1 - par], ctx->vel[1], ctx->col[par],
+		r.lo, r.hi, ctx->halo_overflow, s));
+	return FX_OK;
+}
+
+int divergence_phase(fx_ctx* ctx, hipStream_t s, int halo)
+{
+	DeviceGuard dg(ctx->device);
+	ScopedMark mk(ctx, s, MK_DIV);
+	const Range r = grown(ctx, ctx->nranks > 1 ? halo : 0);
+	FX_HIP(launch_divergence(ctx->g, ctx->half, ctx->vel[1], ctx->b, r.lo, r.hi, s));
+	return FX_OK;
+}
+
+// `count` lock-step sweeps whose first one may read `count` exchanged halo planes
+int jacobi_round(fx_ctx* ctx, hipStream_t s, int count, ScopedMark* mk)
+{
+	DeviceGuard dg(ctx->device);
+	int done = 0;
+	while (done < count) {
+		const int left = count - done;
+		// planes still needed after this launch shrink by one per remaining sweep
+		const int fusedMax = ctx->frozen ? 1 : jacobi_fused_max_sweeps(ctx->g);
+		const int t = std::min(left, fusedMax);
+		const Range r = grown(ctx, ctx->nranks > 1 ? left - t : 0);
+		const float* src = ctx->p[ctx->p_cur];
+		float* dst = ctx->p[ctx->p_cur ^ 1];
+		if (t > 1) {
+			FX_HIP(launch_jacobi_fused(ctx->g, src, ctx->b, dst, t, r.lo, r.hi, s));
+		} else {
+			FX_HIP(launch_jacobi_sweep(ctx->g, src, ctx->b, dst, ctx->frozen, r.lo, r.hi, s));
+		}
+		ctx->p_cur ^= 1;
+		done += t;
+		if (mk) { mk->launches += 1; mk->sweeps += t; }
+	}
+	return FX_OK;
+}
+
+int project_phase(fx_ctx* ctx, hipStream_t s)
+{
+	DeviceGuard dg(ctx->device);
+	const SimParams sp{ ctx->time_step, (int)ctx->desc.advect_address, ctx->g.Zg > 1 ? 1 : 0 };
+	ScopedMark mk(ctx, s, MK_PROJECT);
+	const Range r = owned(ctx);
+	FX_HIP(launch_project(ctx->g, sp, ctx->half, ctx->vel[1], ctx->p[ctx->p_cur], ctx->vel[0], r.lo, r.hi, s));
+	return FX_OK;
+}
+
+int jacobi_all(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t iters)
+{
+	const int k = lead->nranks > 1 ? (int)lead->desc.halo_jacobi : (int)iters;
+	uint32_t done = 0;
+	for (fx_ctx* m : M)
+		if (m->frozen) { DeviceGuard dg(m->device); if (hipMemsetAsync(m->frozen, 0, m->g.cells_local(), s) != hipSuccess) return FX_E_DEVICE; }
+	while (done < iters) {
+		const int cnt = (int)std::min<uint32_t>(k, iters - done);
+		int rc = do_exchange(lead, EX_PRESSURE, lead->nranks > 1 ? cnt : 0, s);
+		if (rc) return rc;
+		for (fx_ctx* m : M) {
+			ScopedMark mk(m, s, MK_JACOBI);
+			rc = jacobi_round(m, s, cnt, &mk);
+			if (rc) return rc;
+		}
+		done += cnt;
+	}
+	return FX_OK;
+}
+
+int simulate_impl(fx_ctx* ctx, hipStream_t s)
+{
+	std::vector<fx_ctx*> M;
+	for_members(ctx, M);
+	int rc;
+	if ((rc = do_exchange(ctx, EX_ADVECT_IN, (int)ctx->desc.halo_advect, s))) return rc;
+	for (fx_ctx* m : M) if ((rc = advect_phase(m, s))) return rc;
+	if (ctx->time_step > 0.0f) {                       // CSProject3D.hlsl:88
+		const int hj = (int)ctx->desc.halo_jacobi;
+		if ((rc = do_exchange(ctx, EX_VEL1, hj, s))) return rc;
+		for (fx_ctx* m : M) if ((rc = divergence_phase(m, s, hj - 1))) return rc;
+		if ((rc = jacobi_all(ctx, M, s, ctx->desc.jacobi_iters))) return rc;
+		if ((rc = do_exchange(ctx, EX_PRESSURE, 1, s))) return rc;
+		for (fx_ctx* m : M) if ((rc = project_phase(m, s))) return rc;
+	} else {
+		for (fx_ctx* m : M) {
+			DeviceGuard dg(m->device);
+			if (launch_copy_velocity(m->g, m->half, m->vel[1], m->vel[0], s) != hipSuccess) return FX_E_DEVICE;
+		}
+	}
+	for (fx_ctx* m : M) if (m->timing_on) m->acc.steps += 1;
+	return FX_OK;
+}
+
+bool is_driver(const fx_ctx* c) { return !c->group || !c->group->transport->is_local() || c->group->members[0] == c; }
+
+}  // namespace
+
+// ===================================================================================================
+extern "C" {
+
+int fx_abi_version(void) { return FX_ABI_VERSION; }
+
+const char* fx_error_string(int status)
+{
+	switch (status) {
+	case FX_OK: return "ok";
+	case FX_E_INVALID: return "invalid argument";
+	case FX_E_DEVICE: return "HIP device/runtime error";
+	case FX_E_NOMEM: return "out of memory";
+	case FX_E_STATE: return "invalid call order";
+	case FX_E_COMM: return "RCCL communication error";
+	case FX_E_HALO: return "advection back-trace left the exchanged halo";
+	default: return "unknown status";
+	}
+}
+
+int fx_create(fx_ctx** out, const fx_desc* d)
+{
+	if (!out || !d || d->struct_size != sizeof(fx_desc)) return FX_E_INVALID;
+	*out = nullptr;
+	if (!d->grid_x || !d->grid_y || !d->grid_z) return FX_E_INVALID;
+	if (d->grid_x != d->grid_y) return FX_E_INVALID;                         // assert at Fluid.cpp:201
+	if (d->grid_x > 65535 || d->grid_z > 65535) return FX_E_INVALID;         // Texture3D extents are uint16 (XUSG.h:1805)
+	if (d->storage > FX_STORAGE_FP16 || d->jacobi_mode > FX_JACOBI_FAITHFUL || d->advect_address > FX_ADDRESS_MIRROR) return FX_E_INVALID;
+	if (!d->jacobi_iters) return FX_E_INVALID;
+	uint32_t z0 = d->slab_z0, nz = d->slab_nz ? d->slab_nz : d->grid_z;
+	if (z0 + nz > d->grid_z) return FX_E_INVALID;
+	const bool slab = nz != d->grid_z;
+
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FX_E_DEVICE;     // fail loudly: no CPU path
+	int dev = d->device;
+	if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return FX_E_DEVICE;
+	if (dev >= ndev) return FX_E_INVALID;
+
+	fx_ctx* ctx = new (std::nothrow) fx_ctx();
+	if (!ctx) return FX_E_NOMEM;
+	ctx->desc = *d;
+	ctx->desc.slab_z0 = z0; ctx->desc.slab_nz = nz;
+	if (!ctx->desc.halo_advect) ctx->desc.halo_advect = kDefaultAdvectHalo;
+	if (!ctx->desc.halo_jacobi) ctx->desc.halo_jacobi = kDefaultJacobiHalo;
+	if (!slab) { ctx->desc.halo_advect = 0; }
+	const int H = slab ? (int)std::max(ctx->desc.halo_advect, ctx->desc.halo_jacobi) : 0;
+	if (slab && (int)nz < H) { delete ctx; return FX_E_INVALID; }             // a halo may only span the direct neighbour
+	ctx->g = Geom{ (int)d->grid_x, (int)d->grid_y, (int)d->grid_z, (int)z0, (int)nz, H,
+		std::max((int)z0 - H, 0), std::min((int)(z0 + nz) + H, (int)d->grid_z) - 1 };
+	ctx->half = d->storage == FX_STORAGE_FP16;
+	ctx->device = dev;
+	ctx->max_ray_samples = 192; ctx->max_light_samples = 64;                  // Fluid.cpp:174-175
+	ctx->rank = 0; ctx->nranks = 1;
+
+	DeviceGuard dg(dev);
+	if (!dg.ok) { delete ctx; return FX_E_DEVICE; }
+	int rc = [&]() -> int {
+		FX_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+		ctx->owns_stream = true;
+		const size_t cells = ctx->g.cells_local();
+		const size_t es = elem_size(ctx);
+		for (int i = 0; i < 2; ++i) {
+			FX_HIP(hipMalloc(&ctx->vel[i], 3 * cells * es));
+			FX_HIP(hipMalloc(&ctx->col[i], 4 * cells * es));
+			FX_HIP(hipMalloc((void**)&ctx->p[i], cells * 4));
+			FX_HIP(hipMemsetAsync(ctx->vel[i], 0, 3 * cells * es, ctx->stream));
+			FX_HIP(hipMemsetAsync(ctx->col[i], 0, 4 * cells * es, ctx->stream));
+			FX_HIP(hipMemsetAsync(ctx->p[i], 0, cells * 4, ctx->stream));
+		}
+		FX_HIP(hipMalloc((void**)&ctx->b, cells * 4));
+		FX_HIP(hipMemsetAsync(ctx->b, 0, cells * 4, ctx->stream));
+		if (d->jacobi_mode == FX_JACOBI_FAITHFUL) {
+			FX_HIP(hipMalloc((void**)&ctx->frozen, cells));
+			FX_HIP(hipMemsetAsync(ctx->frozen, 0, cells, ctx->stream));
+		}
+		FX_HIP(hipMalloc((void**)&ctx->halo_overflow, sizeof(unsigned)));
+		FX_HIP(hipMemsetAsync(ctx->halo_overflow, 0, sizeof(unsigned), ctx->stream));
+		if (d->grid_z > 1) {                                                 // rendering resources (Fluid.cpp:222-232)
+			FX_HIP(hipMalloc((void**)&ctx->lightmap, ctx->g.cells_owned() * 4));
+			FX_HIP(hipMemsetAsync(ctx->lightmap, 0, ctx->g.cells_owned() * 4, ctx->stream));
+			size_t off = 0;
+			for (uint32_t m = 0; m < kNumMips; ++m) {
+				ctx->cube_mip_offset[m] = off;
+				const size_t sz = std::max<uint32_t>(d->grid_x >> m, 1);
+				off += 6 * sz * sz * 4;
+			}
+			FX_HIP(hipMalloc((void**)&ctx->cube, off));
+			FX_HIP(hipMemsetAsync(ctx->cube, 0, off, ctx->stream));
+			FX_HIP(hipMalloc((void**)&ctx->sh_dev, 27 * sizeof(float)));
+			FX_HIP(hipMemsetAsync(ctx->sh_dev, 0, 27 * sizeof(float), ctx->stream));
+		}
+		FX_HIP(hipStreamSynchronize(ctx->stream));
+		return FX_OK;
+	}();
+	if (rc != FX_OK) { free_all(ctx); delete ctx; return rc; }
+	*out = ctx;
+	return FX_OK;
+}
+
+int fx_destroy(fx_ctx* ctx)
+{
+	if (!ctx) return FX_E_INVALID;
+	DeviceGuard dg(ctx->device);
+	(void)hipDeviceSynchronize();
+	if (ctx->group) {
+		fx_comm_group* g = ctx->group;
+		for (auto& m : g->members) if (m == ctx) m = nullptr;
+		if (--g->refs == 0) { delete g->transport; delete g; }
+	}
+	free_all(ctx);
+	delete ctx;
+	return FX_OK;
+}
+
+int fx_set_max_samples(fx_ctx* ctx, uint32_t max_ray, uint32_t max_light)
+{
+	if (!ctx || !max_ray || !max_light) return FX_E_INVALID;
+	ctx->max_ray_samples = max_ray;
+	ctx->max_light_samples = max_light;
+	return FX_OK;
+}
+
+int fx_set_sh(fx_ctx* ctx, const float* coeffs27)
+{
+	if (!ctx) return FX_E_INVALID;
+	if (!ctx->sh_dev) return FX_E_STATE;
+	if (!coeffs27) { ctx->has_sh = false; return FX_OK; }
+	DeviceGuard dg(ctx->device);
+	FX_HIP(hipMemcpy(ctx->sh_dev, coeffs27, 27 * sizeof(float), hipMemcpyHostToDevice));
+	ctx->has_sh = true;
+	return FX_OK;
+}
+
+int fx_update_frame(fx_ctx* ctx, float time_step, uint8_t frame_index,
+	const float view[16], const float proj[16], const float eye[3])
+{
+	if (!ctx || frame_index >= FX_FRAME_COUNT) return FX_E_INVALID;
+	std::vector<fx_ctx*> M;
+	for_members(ctx, M);
+	if (!is_driver(ctx)) return FX_E_STATE;
+	for (fx_ctx* c : M) {
+		if (c->g.Zg > 1 && view && proj && eye) {
+			// Fluid.cpp:296-334
+			const Mat4 world = Mat4::scaling(10.0f, 10.0f, 10.0f);              // m_volumeWorld, Fluid.cpp:182
+			const Mat4 worldI = world.inverse();
+			const Mat4 wvp = world * (Mat4::from(view) * Mat4::from(proj));
+			worldI.store3x4(c->fc.world_i);
+			world.store3x4(c->fc.world);
+			for (int a = 0; a < 3; ++a) c->fc.eye_pt[a] = eye[a];
+			const float pi = 3.141592654f;
+			const float lp[3] = { 75.0f, 75.0f, -75.0f };                        // Fluid.cpp:169-173
+			const float lc[4] = { 1.0f, 0.7f, 0.3f, pi * 3.0f }, am[4] = { 1.0f, 1.0f, 1.0f, pi * 1.5f };
+			std::memcpy(c->fc.light_pt, lp, sizeof lp);
+			std::memcpy(c->fc.light_color, lc, sizeof lc);
+			std::memcpy(c->fc.ambient, am, sizeof am);
+
+			// EstimateCubeMapLOD (Fluid.cpp:141-166)
+			static const Vec3 corners[8] = { {1,1,1},{-1,1,1},{1,-1,1},{-1,-1,1},{-1,1,-1},{1,1,-1},{-1,-1,-1},{1,-1,-1} };
+			static const uint8_t edges[12][2] = { {0,1},{3,2},{1,3},{2,0},{4,5},{7,6},{5,7},{6,4},{1,4},{6,3},{5,0},{2,7} };
+			float sx[8], sy[8];
+			for (int i = 0; i < 8; ++i) {
+				const Vec3 q = wvp.transform_coord(corners[i]);
+				sx[i] = (q.x * 0.5f + 0.5f) * (float)c->desc.viewport_w;
+				sy[i] = (q.y * -0.5f + 0.5f) * (float)c->desc.viewport_h;
+			}
+			float edge = 0.0f;
+			for (const auto& e : edges) {
+				const float ex = sx[e[1]] - sx[e[0]], ey = sy[e[1]] - sy[e[0]];
+				edge = std::max(std::sqrt(ex * ex + ey * ey), edge);
+			}
+			c->edge_pixels = edge;
+			float s = edge / 2.0f;
+			float amount = 2.0f * s / std::sqrt(3.0f);
+			const uint32_t wanted = (uint32_t)std::ceil(amount);
+			c->ray_samples = std::min(wanted, c->max_ray_samples);
+			amount = std::min(amount, (float)c->ray_samples);
+			s = amount / 2.0f * std::sqrt(3.0f);
+			const uint8_t level = (uint8_t)std::max(std::log2((float)c->g.X / s), 0.0f);
+			c->cube_lod = std::min<uint32_t>(level, kNumMips - 1);
+
+			// GenVisibilityMask (Fluid.cpp:49-61)
+			uint32_t mask = 0;
+			for (uint32_t f = 0; f < 6; ++f) {
+				const float v = worldI.transform_comp(eye, (int)(f >> 1));
+				mask |= ((f & 1u) ? v > -1.0f : v < 1.0f) ? 1u << f : 0u;
+			}
+			c->visibility_mask = mask;
+			c->view_valid = true;
+		}
+		c->time_step = time_step;
+		if (time_step > 0.0f) c->frame_parity ^= 1;                                 // Fluid.cpp:345
+		c->frame_valid = true;
+	}
+	return FX_OK;
+}
+
+int fx_simulate(fx_ctx* ctx, void* stream, uint8_t frame_index)
+{
+	if (!ctx || frame_index >= FX_FRAME_COUNT) return FX_E_INVALID;
+	if (!ctx->frame_valid) return FX_E_STATE;
+	if (!is_driver(ctx)) return FX_OK;             // loop-back group: rank 0 drives every member
+	return simulate_impl(ctx, pick_stream(ctx, stream));
+}
+
+int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags)
+{
+	if (!ctx || frame_index >= FX_FRAME_COUNT) return FX_E_INVALID;
+	if (ctx->g.Zg <= 1) return FX_E_INVALID;       // 2D visualisation is a raster pass (out of scope)
+	if (!(flags & FX_RAY_MARCH_CUBEMAP)) return FX_E_INVALID;   // direct screen-space marching: "next" row f-2
+	if (!ctx->view_valid) return FX_E_STATE;
+	if (ctx->g.nz != ctx->g.Zg) return FX_E_INVALID;            // rays cross slabs: multi-GPU rendering is row f-3
+	hipStream_t s = pick_stream(ctx, stream);
+	DeviceGuard dg(ctx->device);
+	const void* color = ctx->col[ctx->frame_parity];
+	const int size = ctx->g.X >> ctx->cube_lod;
+	uint8_t* cube = ctx->cube + ctx->cube_mip_offset[ctx->cube_lod];
+	if (flags & FX_SEPARATE_LIGHT_PASS) {
+		{
+			ScopedMark mk(ctx, s, MK_LIGHT);
+			FX_HIP(launch_raymarch_light(ctx->g, ctx->half, color, ctx->lightmap, ctx->fc,
+				ctx->has_sh ? ctx->sh_dev : nullptr, ctx->max_light_samples, s));     // Fluid.cpp:857-878
+		}
+		ScopedMark mk(ctx, s, MK_VIEW);
+		FX_HIP(launch_raymarch_view(ctx->g, ctx->half, color, ctx->lightmap, ctx->fc, nullptr, size,
+			ctx->visibility_mask, ctx->ray_samples, ctx->max_light_samples, 1, cube, s));   // Fluid.cpp:880-908
+	} else {
+		ScopedMark mk(ctx, s, MK_VIEW);
+		FX_HIP(launch_raymarch_view(ctx->g, ctx->half, color, nullptr, ctx->fc, ctx->has_sh ? ctx->sh_dev : nullptr,
+			size, ctx->visibility_mask, ctx->ray_samples, ctx->max_light_samples, 0, cube, s));   // Fluid.cpp:825-855
+	}
+	if (ctx->timing_on) ctx->acc.renders += 1;
+	return FX_OK;
+}
+
+int fx_get_frame_info(fx_ctx* ctx, fx_frame_info* out)
+{
+	if (!ctx || !out) return FX_E_INVALID;
+	out->cube_lod = ctx->cube_lod;
+	out->cube_size = (uint32_t)ctx->g.X >> ctx->cube_lod;
+	out->ray_samples = ctx->ray_samples;
+	out->visibility_mask = ctx->visibility_mask;
+	out->frame_parity = ctx->frame_parity;
+	out->edge_pixels = ctx->edge_pixels;
+	out->time_step = ctx->time_step;
+	return FX_OK;
+}
+
+int fx_synchronize(fx_ctx* ctx)
+{
+	if (!ctx) return FX_E_INVALID;
+	std::vector<fx_ctx*> M;
+	for_members(ctx, M);
+	int rc = FX_OK;
+	for (fx_ctx* c : M) {
+		DeviceGuard dg(c->device);
+		if (hipDeviceSynchronize() != hipSuccess) return FX_E_DEVICE;
+		unsigned flag = 0;
+		if (hipMemcpy(&flag, c->halo_overflow, sizeof flag, hipMemcpyDeviceToHost) != hipSuccess) return FX_E_DEVICE;
+		if (flag) {
+			(void)hipMemset(c->halo_overflow, 0, sizeof flag);
+			rc = FX_E_HALO;
+		}
+	}
+	return rc;
+}
+
+// ---- field access ----------------------------------------------------------------------------------
+static int field_info(fx_ctx* c, int field, size_t* host_bytes)
+{
+	const size_t n = c->g.cells_owned();
+	switch (field) {
+	case FX_FIELD_VELOCITY: case FX_FIELD_VELOCITY1: *host_bytes = 3 * n * 4; return FX_OK;
+	case FX_FIELD_COLOR: case FX_FIELD_COLOR_PREV: *host_bytes = 4 * n * 4; return FX_OK;
+	case FX_FIELD_PRESSURE: case FX_FIELD_DIVERGENCE: *host_bytes = n * 4; return FX_OK;
+	case FX_FIELD_LIGHTMAP: if (!c->lightmap) return FX_E_INVALID; *host_bytes = 3 * n * 4; return FX_OK;
+	case FX_FIELD_CUBEMAP: {
+		if (!c->cube) return FX_E_INVALID;
+		const size_t s = (size_t)c->g.X >> c->cube_lod;
+		*host_bytes = 6 * s * s * 4;
+		return FX_OK;
+	}
+	}
+	return FX_E_INVALID;
+}
+
+size_t fx_field_bytes(fx_ctx* ctx, int field)
+{
+	size_t b = 0;
+	if (!ctx || field_info(ctx, field, &b) != FX_OK) return 0;
+	return b;
+}
+
+int fx_upload(fx_ctx* ctx, int field, const void* host, size_t bytes)
+{
+	if (!ctx || !host) return FX_E_INVALID;
+	size_t need = 0;
+	int rc = field_info(ctx, field, &need);
+	if (rc) return rc;
+	if (bytes != need) return FX_E_INVALID;
+	DeviceGuard dg(ctx->device);
+	FX_HIP(hipDeviceSynchronize());
+	const size_t n = ctx->g.cells_owned(), off = (size_t)ctx->g.H * ctx->g.plane(), cl = ctx->g.cells_local();
+	const size_t es = elem_size(ctx);
+	switch (field) {
+	case FX_FIELD_VELOCITY: case FX_FIELD_VELOCITY1: {
+		char* dst = (char*)ctx->vel[field == FX_FIELD_VELOCITY1];
+		if ((rc = ensure_stage(ctx, need))) return rc;
+		FX_HIP(hipMemcpy(ctx->stage, host, need, hipMemcpyHostToDevice));
+		for (int a = 0; a < 3; ++a)
+			FX_HIP(launch_to_storage(ctx->stage + a * n, dst + (a * cl + off) * es, n, ctx->half, ctx->stream));
+		break;
+	}
+	case FX_FIELD_COLOR: case FX_FIELD_COLOR_PREV: {
+		char* dst = (char*)ctx->col[field == FX_FIELD_COLOR ? ctx->frame_parity : 1 - ctx->frame_parity];
+		if ((rc = ensure_stage(ctx, need))) return rc;
+		FX_HIP(hipMemcpy(ctx->stage, host, need, hipMemcpyHostToDevice));
+		FX_HIP(launch_to_storage(ctx->stage, dst + off * 4 * es, 4 * n, ctx->half, ctx->stream));
+		break;
+	}
+	case FX_FIELD_PRESSURE:
+		FX_HIP(hipMemcpy(ctx->p[ctx->p_cur] + off, host, need, hipMemcpyHostToDevice));
+		break;
+	case FX_FIELD_DIVERGENCE:
+		FX_HIP(hipMemcpy(ctx->b + off, host, need, hipMemcpyHostToDevice));
+		break;
+	default:
+		return FX_E_INVALID;     // light map / cube map are outputs
+	}
+	FX_HIP(hipStreamSynchronize(ctx->stream));
+	return FX_OK;
+}
+
+int fx_download(fx_ctx* ctx, int field, void* host, size_t bytes)
+{
+	if (!ctx || !host) return FX_E_INVALID;
+	size_t need = 0;
+	int rc = field_info(ctx, field, &need);
+	if (rc) return rc;
+	if (bytes != need) return FX_E_INVALID;
+	DeviceGuard dg(ctx->device);
+	FX_HIP(hipDeviceSynchronize());
+	const size_t n = ctx->g.cells_owned(), off = (size_t)ctx->g.H * ctx->g.plane(), cl = ctx->g.cells_local();
+	const size_t es = elem_size(ctx);
+	switch (field) {
+	case FX_FIELD_VELOCITY: case FX_FIELD_VELOCITY1: {
+		const char* src = (const char*)ctx->vel[field == FX_FIELD_VELOCITY1];
+		if ((rc = ensure_stage(ctx, need))) return rc;
+		for (int a = 0; a < 3; ++a)
+			FX_HIP(launch_from_storage(src + (a * cl + off) * es, ctx->stage + a * n, n, ctx->half, ctx->stream));
+		FX_HIP(hipStreamSynchronize(ctx->stream));
+		FX_HIP(hipMemcpy(host, ctx->stage, need, hipMemcpyDeviceToHost));
+		break;
+	}
+	case FX_FIELD_COLOR: case FX_FIELD_COLOR_PREV: {
+		const char* src = (const char*)ctx->col[field == FX_FIELD_COLOR ? ctx->frame_parity : 1 - ctx->frame_parity];
+		if ((rc = ensure_stage(ctx, need))) return rc;
+		FX_HIP(launch_from_storage(src + off * 4 * es, ctx->stage, 4 * n, ctx->half, ctx->stream));
+		FX_HIP(hipStreamSynchronize(ctx->stream));
+		FX_HIP(hipMemcpy(host, ctx->stage, need, hipMemcpyDeviceToHost));
+		break;
+	}
+	case FX_FIELD_PRESSURE:
+		FX_HIP(hipMemcpy(host, ctx->p[ctx->p_cur] + off, need, hipMemcpyDeviceToHost));
+		break;
+	case FX_FIELD_DIVERGENCE:
+		FX_HIP(hipMemcpy(host, ctx->b + off, need, hipMemcpyDeviceToHost));
+		break;
+	case FX_FIELD_LIGHTMAP:
+		if ((rc = ensure_stage(ctx, need))) return rc;
+		FX_HIP(launch_lightmap_decode(ctx->lightmap, ctx->stage, n, ctx->stream));
+		FX_HIP(hipStreamSynchronize(ctx->stream));
+		FX_HIP(hipMemcpy(host, ctx->stage, need, hipMemcpyDeviceToHost));
+		break;
+	case FX_FIELD_CUBEMAP:
+		FX_HIP(hipMemcpy(host, ctx->cube + ctx->cube_mip_offset[ctx->cube_lod], need, hipMemcpyDeviceToHost));
+		break;
+	default:
+		return FX_E_INVALID;
+	}
+	return FX_OK;
+}
+
+// ---- individual stages (parity tests, micro-benchmarks) ---------------------------------------------
+int fx_advect(fx_ctx* ctx, void* stream)
+{
+	if (!ctx) return FX_E_INVALID;
+	if (!ctx->frame_valid) return FX_E_STATE;
+	if (ctx->nranks > 1) return FX_E_INVALID;
+	return advect_phase(ctx, pick_stream(ctx, stream));
+}
+
+int fx_divergence(fx_ctx* ctx, void* stream)
+{
+	if (!ctx || ctx->nranks > 1) return FX_E_INVALID;
+	return divergence_phase(ctx, pick_stream(ctx, stream), 0);
+}
+
+int fx_jacobi(fx_ctx* ctx, void* stream, uint32_t iters)
+{
+	if (!ctx || !iters || ctx->nranks > 1) return FX_E_INVALID;
+	std::vector<fx_ctx*> M{ ctx };
+	return jacobi_all(ctx, M, pick_stream(ctx, stream), iters);
+}
+
+int fx_project(fx_ctx* ctx, void* stream)
+{
+	if (!ctx || ctx->nranks > 1) return FX_E_INVALID;
+	if (!ctx->frame_valid) return FX_E_STATE;
+	return project_phase(ctx, pick_stream(ctx, stream));
+}
+
+// ---- SH light probe -----------------------------------------------------------------------------------
+int fx_sh_transform(fx_ctx* ctx, const float* cube, uint32_t n, float* out27)
+{
+	if (!ctx || !cube || !out27 || !n || n > 4096) return FX_E_INVALID;
+	DeviceGuard dg(ctx->device);
+	FX_HIP(hipDeviceSynchronize());
+	const size_t cubeBytes = (size_t)6 * n * n * 3 * sizeof(float);
+	int rc = ensure_stage(ctx, cubeBytes);
+	if (rc) return rc;
+	if (ctx->sh_scratch_n != n) {
+		for (int i = 0; i < 4; ++i) {
+			if (ctx->sh_scratch[i]) { FX_HIP(hipFree(ctx->sh_scratch[i])); ctx->sh_scratch[i] = nullptr; }
+			FX_HIP(hipMalloc((void**)&ctx->sh_scratch[i], sh_scratch_floats((int)n, i) * sizeof(float)));
+		}
+		ctx->sh_scratch_n = n;
+	}
+	float* d_out = nullptr;
+	FX_HIP(hipMalloc((void**)&d_out, 27 * sizeof(float)));
+	FX_HIP(hipMemcpy(ctx->stage, cube, cubeBytes, hipMemcpyHostToDevice));
+	hipError_t e = launch_sh_transform(ctx->stage, (int)n, ctx->sh_scratch[0], ctx->sh_scratch[1], ctx->sh_scratch[2],
+		ctx->sh_scratch[3], d_out, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	if (e == hipSuccess) e = hipMemcpy(out27, d_out, 27 * sizeof(float), hipMemcpyDeviceToHost);
+	(void)hipFree(d_out);
+	if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return FX_E_DEVICE; }
+	return FX_OK;
+}
+
+// ---- timing ---------------------------------------------------------------------------------------------
+int fx_timing_enable(fx_ctx* ctx, int enable)
+{
+	if (!ctx) return FX_E_INVALID;
+	std::vector<fx_ctx*> M;
+	for_members(ctx, M);
+	for (fx_ctx* c : M) c->timing_on = enable != 0;
+	return FX_OK;
+}
+
+int fx_timing_read(fx_ctx* ctx, fx_timing* out, int reset)
+{
+	if (!ctx || !out) return FX_E_INVALID;
+	DeviceGuard dg(ctx->device);
+	int rc = drain_timing(ctx);
+	if (rc) return rc;
+	*out = ctx->acc;
+	if (reset) std::memset(&ctx->acc, 0, sizeof ctx->acc);
+	return FX_OK;
+}
+
+// ---- multi-GPU ---------------------------------------------------------------------------------------------
+size_t fx_comm_id_bytes(void) { return rccl_id_bytes(); }
+
+int fx_comm_get_unique_id(void* id_out, size_t bytes)
+{
+	if (!id_out) return FX_E_INVALID;
+	std::string err;
+	const int rc = rccl_get_unique_id(id_out, bytes, &err);
+	if (rc) std::fprintf(stderr, "fluidx: %s\n", err.c_str());
+	return rc;
+}
+
+static int check_slab_chain(fx_ctx* c, int rank, int nranks)
+{
+	if (nranks < 1 || rank < 0 || rank >= nranks) return FX_E_INVALID;
+	if (c->group) return FX_E_STATE;
+	if (nranks > 1 && c->g.nz == c->g.Zg) return FX_E_INVALID;     // a slab context is required
+	if (rank == 0 && c->g.z0 != 0) return FX_E_INVALID;
+	if (rank == nranks - 1 && c->g.z0 + c->g.nz != c->g.Zg) return FX_E_INVALID;
+	return FX_OK;
+}
+
+int fx_comm_init_rank(fx_ctx* ctx, const void* id, size_t bytes, int rank, int nranks)
+{
+	if (!ctx || !id) return FX_E_INVALID;
+	int rc = check_slab_chain(ctx, rank, nranks);
+	if (rc) return rc;
+	Transport* t = make_rccl_transport(id, bytes, rank, nranks, ctx->device, &ctx->last_error);
+	if (!t) { std::fprintf(stderr, "fluidx: %s\n", ctx->last_error.c_str()); return FX_E_COMM; }
+	fx_comm_group* g = new fx_comm_group();
+	g->members.push_back(ctx);
+	g->transport = t;
+	g->refs = 1;
+	ctx->group = g; ctx->rank = rank; ctx->nranks = nranks;
+	return FX_OK;
+}
+
+int fx_comm_init_local(fx_ctx** ctxs, int nranks)
+{
+	if (!ctxs || nranks < 1) return FX_E_INVALID;
+	int zexp = 0;
+	for (int r = 0; r < nranks; ++r) {
+		if (!ctxs[r]) return FX_E_INVALID;
+		int rc = check_slab_chain(ctxs[r], r, nranks);
+		if (rc) return rc;
+		if (ctxs[r]->g.z0 != zexp || ctxs[r]->device != ctxs[0]->device) return FX_E_INVALID;   // contiguous chain, one device
+		if (ctxs[r]->desc.halo_advect != ctxs[0]->desc.halo_advect || ctxs[r]->desc.halo_jacobi != ctxs[0]->desc.halo_jacobi)
+			return FX_E_INVALID;
+		zexp += ctxs[r]->g.nz;
+	}
+	fx_comm_group* g = new fx_comm_group();
+	g->transport = make_local_transport();
+	g->refs = nranks;
+	for (int r = 0; r < nranks; ++r) {
+		g->members.push_back(ctxs[r]);
+		ctxs[r]->group = g; ctxs[r]->rank = r; ctxs[r]->nranks = nranks;
+		// one stream for the whole loop-back group: phases of different members are ordered by it
+		if (r > 0) {
+			if (ctxs[r]->owns_stream) (void)hipStreamDestroy(ctxs[r]->stream);
+			ctxs[r]->stream = ctxs[0]->stream;
+			ctxs[r]->owns_stream = false;
+		}
+	}
+	return FX_OK;
+}
+
+}  // extern "C"

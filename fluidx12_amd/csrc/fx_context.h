@@ -1,0 +1,91 @@
+// fx_context.h -- the state behind `fx_ctx` (the HIP re-statement of class Fluid's members,
+// /root/reference/FluidX12/Content/Fluid.h:79-127): fields in HBM, frame constants, streams,
+// timing events and the slab-exchange transport.
+#pragma once
+#include "fx_internal.h"
+#include <vector>
+#include <string>
+
+struct fx_comm_group;
+
+struct fx_ctx {
+	fx_desc desc;
+	fx::Geom g;
+	int half;                       // 1 = fp16 velocity/colour storage
+	int device;
+	hipStream_t stream;             // context-owned stream (used when the caller passes NULL)
+	bool owns_stream;
+
+	// ---- fields (XUSG textures of Fluid.h:93-97 -> hipMalloc) --------------------------------
+	void* vel[2];                   // 3 component planes each, local extent incl. halo
+	void* col[2];                   // rgba texels
+	float* p[2];                    // pressure ping-pong (m_incompress); p[p_cur] is current
+	int p_cur;
+	float* b;                       // divergence
+	uint8_t* frozen;                // faithful-mode freeze mask (null in fixed mode)
+	uint32_t* lightmap;             // R11G11B10F packed (m_lightMap), owned planes only
+	uint8_t* cube;                  // RGBA8 cube map, 5 mips back to back (m_cubeMap)
+	size_t cube_mip_offset[5];
+	float* sh_dev;                  // 27 floats
+	bool has_sh;
+	unsigned* halo_overflow;        // device flag set when a back-trace leaves the halo
+	float* stage;                   // fp32 staging for upload/download conversion
+	size_t stage_bytes;
+	float* sh_scratch[4];
+	size_t sh_scratch_n;
+
+	// ---- frame state (Fluid.h:108-127) --------------------------------------------------------
+	uint32_t max_ray_samples, max_light_samples;
+	uint32_t ray_samples, cube_lod, visibility_mask;
+	uint8_t frame_parity;
+	float time_step;
+	float edge_pixels;
+	bool frame_valid, view_valid;
+	fx::FrameConsts fc;
+
+	// ---- timing ---------------------------------------------------------------------------------
+	bool timing_on;
+	std::vector<hipEvent_t> ev;     // ring of events, 8 per recorded step/render
+	size_t ev_used;
+	struct Mark { int kind; size_t e0, e1; uint64_t launches, sweeps; };
+	std::vector<Mark> marks;
+	fx_timing acc;
+
+	// ---- multi-GPU ------------------------------------------------------------------------------
+	fx_comm_group* group;           // null = single context
+	int rank, nranks;
+	std::string last_error;
+};
+
+namespace fx {
+
+// one array taking part in a halo exchange: `count` back-to-back sub-arrays (velocity = 3
+// component planes) of nzl planes each, plane_bytes per plane
+struct ExchArray { char* base; size_t plane_bytes; int count; };
+
+// transport behind a group of slab contexts
+struct Transport {
+	virtual ~Transport() {}
+	// exchange the k boundary planes of every array between z-neighbours, for the given member
+	// (RCCL: the only member; local: called once per exchange with member == null -> all members)
+	virtual int exchange(fx_comm_group* grp, int which_set, int k, hipStream_t s) = 0;
+	virtual bool is_local() const = 0;
+};
+
+}  // namespace fx
+
+struct fx_comm_group {
+	std::vector<fx_ctx*> members;   // local transport: every rank; RCCL: just this rank
+	fx::Transport* transport;
+	int refs;
+};
+
+namespace fx {
+enum ExchSet { EX_ADVECT_IN = 0, EX_VEL1 = 1, EX_PRESSURE = 2 };
+// arrays of one member for an exchange set
+int exchange_arrays(fx_ctx* c, int which_set, ExchArray out[4]);
+Transport* make_local_transport();
+Transport* make_rccl_transport(const void* id, size_t bytes, int rank, int nranks, int device, std::string* err);
+size_t rccl_id_bytes();
+int rccl_get_unique_id(void* out, size_t bytes, std::string* err);
+}  // namespace fx

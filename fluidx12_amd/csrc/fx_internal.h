@@ -1,0 +1,80 @@
+// fx_internal.h -- context layout and kernel launcher declarations shared by the C-ABI
+// implementation (fx_api.cpp) and the HIP kernels (fx_sim.hip, fx_render.hip, fx_sh.hip).
+// Product code: never includes or links anything from oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/fluidx_hip.h"
+
+namespace fx {
+
+// Geometry of one z-slab as the kernels see it.  Local plane l <-> global z = z0 - H + l.
+struct Geom {
+	int X, Y;        // plane extent
+	int Zg;          // global depth
+	int z0;          // first owned global plane
+	int nz;          // owned planes
+	int H;           // allocated halo planes on each side (0 for a single-GPU context)
+	int zlo, zhi;    // inclusive range of global planes whose data is present locally
+	__host__ __device__ size_t plane() const { return (size_t)X * Y; }
+	__host__ __device__ int nzl() const { return nz + 2 * H; }
+	__host__ __device__ size_t cells_local() const { return plane() * (size_t)nzl(); }
+	__host__ __device__ size_t cells_owned() const { return plane() * (size_t)nz; }
+	// local plane index of global plane z (must be present)
+	__host__ __device__ int lz(int z) const { return z - z0 + H; }
+};
+
+// frame constants of the ray-march kernels (Common.hlsli:15-30 cbPerObject/cbPerFrame)
+struct FrameConsts {
+	float world_i[12];     // XMFLOAT3X4: rows of the transposed inverse world
+	float world[12];
+	float eye_pt[3];
+	float light_pt[3];
+	float light_color[4];
+	float ambient[4];
+};
+
+struct SimParams {
+	float dt;
+	int address;           // fx_address
+	int is3d;
+};
+
+// ---- simulation launchers (fx_sim.hip); `half_store` selects __half storage of velocity/colour
+// z_begin/z_end: global plane range to compute (within the locally present range)
+hipError_t launch_advect(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const void* col_in,
+	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, hipStream_t s);
+hipError_t launch_divergence(const Geom& g, int half_store, const void* vel, float* b, int z_begin, int z_end, hipStream_t s);
+// one lock-step sweep p_in -> p_out on planes [z_begin, z_end); frozen may be null
+hipError_t launch_jacobi_sweep(const Geom& g, const float* p_in, const float* b, float* p_out, uint8_t* frozen,
+	int z_begin, int z_end, hipStream_t s);
+// `sweeps` lock-step sweeps fused in one launch (temporal blocking); result in p_out.  Planes [z_begin, z_end)
+// of p_out are valid afterwards provided p_in/b are valid on [z_begin - sweeps, z_end + sweeps) (or the
+// global boundary).  Returns hipErrorNotSupported when the geometry has no fused path.
+hipError_t launch_jacobi_fused(const Geom& g, const float* p_in, const float* b, float* p_out, int sweeps,
+	int z_begin, int z_end, hipStream_t s);
+int jacobi_fused_max_sweeps(const Geom& g);
+hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const float* p,
+	void* vel_out, int z_begin, int z_end, hipStream_t s);
+hipError_t launch_copy_velocity(const Geom& g, int half_store, const void* vel_in, void* vel_out, hipStream_t s);
+
+// ---- layout conversion between dense fp32 host layouts and device storage (fx_sim.hip)
+// scalar planes: nplanes x cells fp32 <-> T ; colour: cells x 4
+hipError_t launch_to_storage(const float* src, void* dst, size_t n, int half_store, hipStream_t s);
+hipError_t launch_from_storage(const void* src, float* dst, size_t n, int half_store, hipStream_t s);
+
+// ---- ray march launchers (fx_render.hip)
+hipError_t launch_raymarch_light(const Geom& g, int half_store, const void* color, uint32_t* lightmap,
+	const FrameConsts& fc, const float* sh, uint32_t num_samples, hipStream_t s);
+hipError_t launch_raymarch_view(const Geom& g, int half_store, const void* color, const uint32_t* lightmap,
+	const FrameConsts& fc, const float* sh, int cube_size, uint32_t mask, uint32_t num_samples,
+	uint32_t num_light_samples, int separate, uint8_t* cube, hipStream_t s);
+hipError_t launch_lightmap_decode(const uint32_t* lightmap, float* out, size_t n, hipStream_t s);
+
+// ---- SH light probe (fx_sh.hip): cube float[6][n][n][3] (device) -> out float[27] (device)
+hipError_t launch_sh_transform(const float* cube, int n, float* scratch0, float* scratch1, float* w0, float* w1,
+	float* out27, hipStream_t s);
+size_t sh_scratch_floats(int n, int which);
+
+}  // namespace fx

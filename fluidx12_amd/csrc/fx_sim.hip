@@ -1,0 +1,412 @@
+// fx_sim.hip -- gfx950 kernels of the simulation step.
+//
+//   k_advect      <- CSAdvect.hlsl:41-79          (semi-Lagrangian velocity + colour advection, impulse)
+//   k_divergence  <- CSProject3D.hlsl:39-50,75-83 (CSProject2D.hlsl:37-46)
+//   k_jacobi_*    <- CSPoisson.hlsli:8-26         (lock-step schedule: synchronous ping-pong Jacobi)
+//   k_project     <- CSProject3D.hlsl:55-63,105-112 (CSProject2D.hlsl:51-59,99-105)
+// (paths relative to /root/reference/FluidX12/Content/Shaders/).  The reference fuses divergence,
+// relaxation and projection in one dispatch whose relaxation races by design; here they are separate
+// launches on one HIP stream and the relaxation is a deterministic sweep.
+//
+// Numerics contract: fp32 arithmetic in the association order of the reference's
+// shipped DXBC; a DXBC `mad` is fmaf(); nothing else is contracted (-ffp-contract=off).
+// Layout: velocity = 3 component planes (SoA), colour = interleaved rgba texels, pressure and
+// divergence = fp32 planes; x fastest, one wave64 = 64 consecutive x.  All memory-bound: no MFMA.
+#include "fx_internal.h"
+
+namespace fx {
+
+typedef _Float16 h16;
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+
+template <bool HALF> struct Store;
+template <> struct Store<false> {
+	typedef float S;
+	typedef float4 S4;
+	static __device__ __forceinline__ float ld(const S* p, size_t i) { return p[i]; }
+	static __device__ __forceinline__ void st(S* p, size_t i, float v) { p[i] = v; }
+	static __device__ __forceinline__ float4 ld4(const S4* p, size_t i) { return p[i]; }
+	static __device__ __forceinline__ void st4(S4* p, size_t i, float4 v) { p[i] = v; }
+};
+template <> struct Store<true> {
+	typedef h16 S;
+	typedef h16x4 S4;
+	static __device__ __forceinline__ float ld(const S* p, size_t i) { return (float)p[i]; }
+	static __device__ __forceinline__ void st(S* p, size_t i, float v) { p[i] = (h16)v; }   // RNE
+	static __device__ __forceinline__ float4 ld4(const S4* p, size_t i)
+	{
+		const h16x4 h = p[i];
+		return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+	}
+	static __device__ __forceinline__ void st4(S4* p, size_t i, float4 v)
+	{
+		h16x4 h;
+		h.x = (h16)v.x; h.y = (h16)v.y; h.z = (h16)v.z; h.w = (h16)v.w;
+		p[i] = h;
+	}
+};
+
+__device__ __forceinline__ float lerpf(float a, float b, float f) { return fmaf(f, b - a, a); }
+__device__ __forceinline__ float saturatef(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+
+// D3D addressing of an integer tap (CLAMP / MIRROR)
+__device__ __forceinline__ int addr_tap(int i, int n, int mode)
+{
+	if (mode == FX_ADDRESS_MIRROR) {
+		const int period = 2 * n;
+		int m = i % period;
+		if (m < 0) m += period;
+		return m < n ? m : period - 1 - m;
+	}
+	return min(max(i, 0), n - 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// advection
+// ---------------------------------------------------------------------------------------------
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_advect(const Geom g, const SimParams sp,
+	const typename Store<HALF>::S* __restrict__ vel_in, const typename Store<HALF>::S4* __restrict__ col_in,
+	typename Store<HALF>::S* __restrict__ vel_out, typename Store<HALF>::S4* __restrict__ col_out,
+	int z_begin, unsigned* halo_overflow)
+{
+	typedef Store<HALF> St;
+	const int x = blockIdx.x * 64 + threadIdx.x;
+	const int y = blockIdx.y * 4 + threadIdx.y;
+	const int z = z_begin + blockIdx.z;
+	if (x >= g.X || y >= g.Y) return;
+
+	const size_t plane = g.plane();
+	const size_t stride = g.cells_local();                  // distance between velocity component planes
+	const size_t id = (size_t)g.lz(z) * plane + (size_t)y * g.X + x;
+	const float dt = sp.dt;
+
+	const float px = ((float)x + 0.5f) / (float)g.X;        // Simulation.hlsli:10
+	const float py = ((float)y + 0.5f) / (float)g.Y;
+	const float pz = ((float)z + 0.5f) / (float)g.Zg;
+	const float dx = px + -0.5f, dy = py + -0.100000001f, dz = pz + -0.5f;   // Impulse.hlsli:14
+	const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+	const float rr = sp.is3d ? 0.00390625f : 0.0009765625f;
+	const float basis = exp2f(((d2 * -4.0f) / rr) * 1.44269502f);           // CSAdvect.hlsl:33-36,59
+	float Fx, Fy, Fz;
+	if (sp.is3d) {                                                           // :63-65
+		Fx = fmaf(basis, 0.0f, dz * -200.0f);
+		Fy = fmaf(basis, 192.0f, 0.0f);
+		Fz = fmaf(basis, 0.0f, dx * 200.0f);
+	} else {
+		Fx = 0.0f; Fy = basis * 48.0f; Fz = 0.0f;
+	}
+
+	const float u0x = St::ld(vel_in, id), u0y = St::ld(vel_in, stride + id), u0z = St::ld(vel_in, 2 * stride + id);   // :47
+	const float ax = fmaf(-u0x, dt, px), ay = fmaf(-u0y, dt, py), az = fmaf(-u0z, dt, pz);                             // :52
+
+	// trilinear taps: t = u*N - 0.5, i0 = floor(t), f = t - i0
+	const float tx = ax * (float)g.X - 0.5f, ty = ay * (float)g.Y - 0.5f, tz = az * (float)g.Zg - 0.5f;
+	const float flx = floorf(tx), fly = floorf(ty), flz = floorf(tz);
+	const float fx = tx - flx, fy = ty - fly, fz = tz - flz;
+	const int ix = (int)flx, iy = (int)fly, iz = (int)flz;
+	const int x0 = addr_tap(ix, g.X, sp.address), x1 = addr_tap(ix + 1, g.X, sp.address);
+	const int y0 = addr_tap(iy, g.Y, sp.address), y1 = addr_tap(iy + 1, g.Y, sp.address);
+	int z0 = addr_tap(iz, g.Zg, sp.address), z1 = addr_tap(iz + 1, g.Zg, sp.address);
+	if (z0 < g.zlo || z0 > g.zhi || z1 < g.zlo || z1 > g.zhi) {             // back-trace left the exchanged halo
+		atomicOr(halo_overflow, 1u);
+		z0 = min(max(z0, g.zlo), g.zhi);
+		z1 = min(max(z1, g.zlo), g.zhi);
+	}
+	const size_t r00 = (size_t)g.lz(z0) * plane + (size_t)y0 * g.X, r10 = (size_t)g.lz(z0) * plane + (size_t)y1 * g.X;
+	const size_t r01 = (size_t)g.lz(z1) * plane + (size_t)y0 * g.X, r11 = (size_t)g.lz(z1) * plane + (size_t)y1 * g.X;
+
+	float u[3];
+#pragma unroll
+	for (int a = 0; a < 3; ++a) {                                            // :53
+		const typename St::S* f = vel_in + a * stride;
+		const float c00 = lerpf(St::ld(f, r00 + x0), St::ld(f, r00 + x1), fx);
+		const float c10 = lerpf(St::ld(f, r10 + x0), St::ld(f, r10 + x1), fx);
+		const float c01 = lerpf(St::ld(f, r01 + x0), St::ld(f, r01 + x1), fx);
+		const float c11 = lerpf(St::ld(f, r11 + x0), St::ld(f, r11 + x1), fx);
+		u[a] = lerpf(lerpf(c00, c10, fy), lerpf(c01, c11, fy), fz);
+	}
+	float c[4];
+	{                                                                        // :54
+		const float4 t000 = St::ld4(col_in, r00 + x0), t100 = St::ld4(col_in, r00 + x1);
+		const float4 t010 = St::ld4(col_in, r10 + x0), t110 = St::ld4(col_in, r10 + x1);
+		const float4 t001 = St::ld4(col_in, r01 + x0), t101 = St::ld4(col_in, r01 + x1);
+		const float4 t011 = St::ld4(col_in, r11 + x0), t111 = St::ld4(col_in, r11 + x1);
+#define FX_TRI(m) lerpf(lerpf(lerpf(t000.m, t100.m, fx), lerpf(t010.m, t110.m, fx), fy), \
+	lerpf(lerpf(t001.m, t101.m, fx), lerpf(t011.m, t111.m, fx), fy), fz)
+		c[0] = FX_TRI(x); c[1] = FX_TRI(y); c[2] = FX_TRI(z); c[3] = FX_TRI(w);
+#undef FX_TRI
+	}
+
+	if (basis >= 0.0183156393f) {                                            // :60
+		u[0] = fmaf(Fx, dt, u[0]); u[1] = fmaf(Fy, dt, u[1]); u[2] = fmaf(Fz, dt, u[2]);   // :66
+		const float bdt = basis * dt;
+		c[0] = saturatef(fmaf(bdt, 8.0f, c[0]));                             // :67, g_impulse = (.2,.4,1,1)*40
+		c[1] = saturatef(fmaf(bdt, 16.0f, c[1]));
+		c[2] = saturatef(fmaf(bdt, 40.0f, c[2]));
+		c[3] = saturatef(fmaf(bdt, 40.0f, c[3]));
+	}
+	const float atten = fmaxf(fmaf(-dt, 0.200000003f, 1.0f), 0.0f);          // :74
+	St::st(vel_out, id, u[0] * atten);                                       // :77
+	St::st(vel_out, stride + id, u[1] * atten);
+	St::st(vel_out, 2 * stride + id, u[2] * atten);
+	St::st4(col_out, id, make_float4(c[0] * atten, c[1] * atten, c[2] * atten, c[3] * atten));   // :78
+}
+
+// ---------------------------------------------------------------------------------------------
+// divergence  b = 0.5 * ((fB - fF) + ((fD - fU) + (fR - fL)))   (2D: (fR - fL) + (fD - fU))
+// ---------------------------------------------------------------------------------------------
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_divergence(const Geom g, const typename Store<HALF>::S* __restrict__ vel,
+	float* __restrict__ b, int z_begin)
+{
+	typedef Store<HALF> St;
+	const int x = blockIdx.x * 64 + threadIdx.x;
+	const int y = blockIdx.y * 4 + threadIdx.y;
+	const int z = z_begin + blockIdx.z;
+	if (x >= g.X || y >= g.Y) return;
+	const size_t plane = g.plane(), stride = g.cells_local();
+	const size_t row = (size_t)g.lz(z) * plane + (size_t)y * g.X;
+	const int xl = max(x, 1) - 1, xr = min(x + 1, g.X - 1);
+	const int yu = max(y, 1) - 1, yd = min(y + 1, g.Y - 1);
+	const float ddx = -St::ld(vel, row + xl) + St::ld(vel, row + xr);
+	const float ddy = -St::ld(vel, stride + (size_t)g.lz(z) * plane + (size_t)yu * g.X + x)
+		+ St::ld(vel, stride + (size_t)g.lz(z) * plane + (size_t)yd * g.X + x);
+	float S;
+	if (g.Zg > 1) {
+		const int zf = max(z, 1) - 1, zb = min(z + 1, g.Zg - 1);
+		const float ddz = -St::ld(vel, 2 * stride + (size_t)g.lz(zf) * plane + (size_t)y * g.X + x)
+			+ St::ld(vel, 2 * stride + (size_t)g.lz(zb) * plane + (size_t)y * g.X + x);
+		S = ddz + (ddy + ddx);
+	} else {
+		S = ddx + ddy;
+	}
+	b[row + x] = 0.5f * S;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Jacobi sweep, generic: any extent, 2D/3D, optional freeze mask (faithful early-out)
+//   x = ((((((qL - b) + qR) + qU) + qD) + qF) + qB) * (1/6)     2D: (((qL - b) + qR) + qU) + qD) * 1/4
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_jacobi_generic(const Geom g, const float* __restrict__ p_in,
+	const float* __restrict__ b, float* __restrict__ p_out, uint8_t* __restrict__ frozen, int z_begin)
+{
+	const int x = blockIdx.x * 64 + threadIdx.x;
+	const int y = blockIdx.y * 4 + threadIdx.y;
+	const int z = z_begin + blockIdx.z;
+	if (x >= g.X || y >= g.Y) return;
+	const size_t plane = g.plane();
+	const size_t zrow = (size_t)g.lz(z) * plane;
+	const size_t id = zrow + (size_t)y * g.X + x;
+	const float x0 = p_in[id];
+	if (frozen && frozen[id]) { p_out[id] = x0; return; }
+	const int xl = max(x, 1) - 1, xr = min(x + 1, g.X - 1);
+	const int yu = max(y, 1) - 1, yd = min(y + 1, g.Y - 1);
+	float s = p_in[zrow + (size_t)y * g.X + xl] - b[id];
+	s = p_in[zrow + (size_t)y * g.X + xr] + s;
+	s = p_in[zrow + (size_t)yu * g.X + x] + s;
+	s = p_in[zrow + (size_t)yd * g.X + x] + s;
+	float inv = 0.25f;
+	if (g.Zg > 1) {
+		const int zf = max(z, 1) - 1, zb = min(z + 1, g.Zg - 1);
+		s = p_in[(size_t)g.lz(zf) * plane + (size_t)y * g.X + x] + s;
+		s = p_in[(size_t)g.lz(zb) * plane + (size_t)y * g.X + x] + s;
+		inv = __uint_as_float(0x3e2aaaabu);
+	}
+	p_out[id] = s * inv;
+	if (frozen && fabsf(fmaf(s, inv, -x0)) < 0.00100000005f) frozen[id] = 1;     // CSPoisson.hlsli:24
+}
+
+// ---------------------------------------------------------------------------------------------
+// Jacobi sweep, 3D fast path: one thread = 4 consecutive x (16 B loads/stores), X % 4 == 0.
+// Neighbour rows/planes come through L1/L2 (each line is re-read by the 5 stencil partners).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_jacobi_v4(const Geom g, const float* __restrict__ p_in,
+	const float* __restrict__ b, float* __restrict__ p_out, int z_begin, int rows_per_block)
+{
+	const int X4 = g.X >> 2;
+	const int lane = threadIdx.x;                       // float4 column
+	const int x4 = blockIdx.x * blockDim.x + lane;
+	const int y = blockIdx.y * rows_per_block + threadIdx.y;
+	const int z = z_begin + blockIdx.z;
+	if (x4 >= X4 || y >= g.Y) return;
+	const size_t plane = g.plane();
+	const int yu = max(y, 1) - 1, yd = min(y + 1, g.Y - 1);
+	const int zf = max(z, 1) - 1, zb = min(z + 1, g.Zg - 1);
+	const size_t zrow = (size_t)g.lz(z) * plane;
+	const size_t c_off = zrow + (size_t)y * g.X + 4 * x4;
+	const float4 c = *reinterpret_cast<const float4*>(p_in + c_off);
+	const float4 U = *reinterpret_cast<const float4*>(p_in + zrow + (size_t)yu * g.X + 4 * x4);
+	const float4 D = *reinterpret_cast<const float4*>(p_in + zrow + (size_t)yd * g.X + 4 * x4);
+	const float4 F = *reinterpret_cast<const float4*>(p_in + (size_t)g.lz(zf) * plane + (size_t)y * g.X + 4 * x4);
+	const float4 B = *reinterpret_cast<const float4*>(p_in + (size_t)g.lz(zb) * plane + (size_t)y * g.X + 4 * x4);
+	const float4 bb = *reinterpret_cast<const float4*>(b + c_off);
+	const float L = x4 > 0 ? p_in[c_off - 1] : c.x;
+	const float R = x4 < X4 - 1 ? p_in[c_off + 4] : c.w;
+	const float inv = __uint_as_float(0x3e2aaaabu);
+	float4 o;
+	o.x = ((((((L - bb.x) + c.y) + U.x) + D.x) + F.x) + B.x) * inv;
+	o.y = ((((((c.x - bb.y) + c.z) + U.y) + D.y) + F.y) + B.y) * inv;
+	o.z = ((((((c.y - bb.z) + c.w) + U.z) + D.z) + F.z) + B.z) * inv;
+	o.w = ((((((c.z - bb.w) + R) + U.w) + D.w) + F.w) + B.w) * inv;
+	*reinterpret_cast<float4*>(p_out + c_off) = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// projection + wall damping
+// ---------------------------------------------------------------------------------------------
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_project(const Geom g, const SimParams sp,
+	const typename Store<HALF>::S* __restrict__ vel_in, const float* __restrict__ p,
+	typename Store<HALF>::S* __restrict__ vel_out, int z_begin)
+{
+	typedef Store<HALF> St;
+	const int x = blockIdx.x * 64 + threadIdx.x;
+	const int y = blockIdx.y * 4 + threadIdx.y;
+	const int z = z_begin + blockIdx.z;
+	if (x >= g.X || y >= g.Y) return;
+	const size_t plane = g.plane(), stride = g.cells_local();
+	const size_t zrow = (size_t)g.lz(z) * plane;
+	const size_t id = zrow + (size_t)y * g.X + x;
+	const int xl = max(x, 1) - 1, xr = min(x + 1, g.X - 1);
+	const int yu = max(y, 1) - 1, yd = min(y + 1, g.Y - 1);
+	float u[3] = { St::ld(vel_in, id), St::ld(vel_in, stride + id), St::ld(vel_in, 2 * stride + id) };
+	float grad[3];
+	grad[0] = -p[zrow + (size_t)y * g.X + xl] + p[zrow + (size_t)y * g.X + xr];
+	grad[1] = -p[zrow + (size_t)yu * g.X + x] + p[zrow + (size_t)yd * g.X + x];
+	grad[2] = 0.0f;
+	float k = 0.5f;
+	if (sp.is3d) {
+		const int zf = max(z, 1) - 1, zb = min(z + 1, g.Zg - 1);
+		grad[2] = -p[(size_t)g.lz(zf) * plane + (size_t)y * g.X + x] + p[(size_t)g.lz(zb) * plane + (size_t)y * g.X + x];
+		k = __uint_as_float(0x3f855556u);                                  // 0.5f / 0.48f (g_density, CSProject3D.hlsl:26)
+		u[2] = fmaf(-grad[2], k, u[2]);
+	}
+	u[0] = fmaf(-grad[0], k, u[0]);                                        // CSProject3D.hlsl:62
+	u[1] = fmaf(-grad[1], k, u[1]);
+	const int cell[3] = { x, y, z };
+	const float dims[3] = { (float)g.X, (float)g.Y, (float)g.Zg };
+#pragma unroll
+	for (int a = 0; a < 3; ++a) {                                          // :106-108
+		float pos = ((float)cell[a] + 0.5f) / dims[a];
+		if (sp.is3d || a < 2) pos = fmaf(pos, 2.0f, -1.0f);
+		float f = (-fabsf(pos) + 0.970000029f) * 33.3333359f;
+		f = fminf(fmaxf(f, -1.0f), 1.0f);
+		const float w = (0.0f < u[a] * pos) ? f : 1.0f;
+		St::st(vel_out, a * stride + id, u[a] * w);
+	}
+}
+
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_copy_owned(const Geom g, const typename Store<HALF>::S* __restrict__ src,
+	typename Store<HALF>::S* __restrict__ dst)
+{
+	// copies the owned planes of the three component planes (dt <= 0 path, CSProject3D.hlsl:88,112)
+	const size_t n = g.cells_owned();
+	const size_t off = (size_t)g.H * g.plane();
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n; i += (size_t)gridDim.x * blockDim.x) {
+		const size_t a = i / n, r = i - a * n;
+		dst[a * g.cells_local() + off + r] = src[a * g.cells_local() + off + r];
+	}
+}
+
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_to_storage(const float* __restrict__ src, typename Store<HALF>::S* __restrict__ dst, size_t n)
+{
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+		Store<HALF>::st(dst, i, src[i]);
+}
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_from_storage(const typename Store<HALF>::S* __restrict__ src, float* __restrict__ dst, size_t n)
+{
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+		dst[i] = Store<HALF>::ld(src, i);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static inline dim3 grid_xyz(const Geom& g, int nzp) { return dim3((g.X + 63) / 64, (g.Y + 3) / 4, nzp); }
+static inline unsigned grid_1d(size_t n) { return (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
+
+hipError_t launch_advect(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const void* col_in,
+	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, hipStream_t s)
+{
+	if (z_end <= z_begin) return hipSuccess;
+	const dim3 grid = grid_xyz(g, z_end - z_begin), block(64, 4, 1);
+	if (half_store)
+		hipLaunchKernelGGL(k_advect<true>, grid, block, 0, s, g, sp, (const h16*)vel_in, (const h16x4*)col_in,
+			(h16*)vel_out, (h16x4*)col_out, z_begin, halo_overflow);
+	else
+		hipLaunchKernelGGL(k_advect<false>, grid, block, 0, s, g, sp, (const float*)vel_in, (const float4*)col_in,
+			(float*)vel_out, (float4*)col_out, z_begin, halo_overflow);
+	return hipGetLastError();
+}
+
+hipError_t launch_divergence(const Geom& g, int half_store, const void* vel, float* b, int z_begin, int z_end, hipStream_t s)
+{
+	if (z_end <= z_begin) return hipSuccess;
+	const dim3 grid = grid_xyz(g, z_end - z_begin), block(64, 4, 1);
+	if (half_store) hipLaunchKernelGGL(k_divergence<true>, grid, block, 0, s, g, (const h16*)vel, b, z_begin);
+	else hipLaunchKernelGGL(k_divergence<false>, grid, block, 0, s, g, (const float*)vel, b, z_begin);
+	return hipGetLastError();
+}
+
+hipError_t launch_jacobi_sweep(const Geom& g, const float* p_in, const float* b, float* p_out, uint8_t* frozen,
+	int z_begin, int z_end, hipStream_t s)
+{
+	if (z_end <= z_begin) return hipSuccess;
+	const int nzp = z_end - z_begin;
+	if (!frozen && g.Zg > 1 && (g.X & 3) == 0) {
+		const int X4 = g.X >> 2;
+		const int bx = X4 < 64 ? X4 : 64;               // float4 columns per block row
+		int by = 256 / bx; if (by < 1) by = 1; if (by > g.Y) by = g.Y;
+		const dim3 block(bx, by, 1), grid((X4 + bx - 1) / bx, (g.Y + by - 1) / by, nzp);
+		hipLaunchKernelGGL(k_jacobi_v4, grid, block, 0, s, g, p_in, b, p_out, z_begin, by);
+	} else {
+		hipLaunchKernelGGL(k_jacobi_generic, grid_xyz(g, nzp), dim3(64, 4, 1), 0, s, g, p_in, b, p_out, frozen, z_begin);
+	}
+	return hipGetLastError();
+}
+
+int jacobi_fused_max_sweeps(const Geom&) { return 1; }
+hipError_t launch_jacobi_fused(const Geom&, const float*, const float*, float*, int, int, int, hipStream_t)
+{
+	return hipErrorNotSupported;
+}
+
+hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const float* p,
+	void* vel_out, int z_begin, int z_end, hipStream_t s)
+{
+	if (z_end <= z_begin) return hipSuccess;
+	const dim3 grid = grid_xyz(g, z_end - z_begin), block(64, 4, 1);
+	if (half_store) hipLaunchKernelGGL(k_project<true>, grid, block, 0, s, g, sp, (const h16*)vel_in, p, (h16*)vel_out, z_begin);
+	else hipLaunchKernelGGL(k_project<false>, grid, block, 0, s, g, sp, (const float*)vel_in, p, (float*)vel_out, z_begin);
+	return hipGetLastError();
+}
+
+hipError_t launch_copy_velocity(const Geom& g, int half_store, const void* vel_in, void* vel_out, hipStream_t s)
+{
+	const unsigned grid = grid_1d(3 * g.cells_owned());
+	if (half_store) hipLaunchKernelGGL(k_copy_owned<true>, dim3(grid), dim3(256), 0, s, g, (const h16*)vel_in, (h16*)vel_out);
+	else hipLaunchKernelGGL(k_copy_owned<false>, dim3(grid), dim3(256), 0, s, g, (const float*)vel_in, (float*)vel_out);
+	return hipGetLastError();
+}
+
+hipError_t launch_to_storage(const float* src, void* dst, size_t n, int half_store, hipStream_t s)
+{
+	if (!n) return hipSuccess;
+	if (half_store) hipLaunchKernelGGL(k_to_storage<true>, dim3(grid_1d(n)), dim3(256), 0, s, src, (h16*)dst, n);
+	else hipLaunchKernelGGL(k_to_storage<false>, dim3(grid_1d(n)), dim3(256), 0, s, src, (float*)dst, n);
+	return hipGetLastError();
+}
+
+hipError_t launch_from_storage(const void* src, float* dst, size_t n, int half_store, hipStream_t s)
+{
+	if (!n) return hipSuccess;
+	if (half_store) hipLaunchKernelGGL(k_from_storage<true>, dim3(grid_1d(n)), dim3(256), 0, s, (const h16*)src, dst, n);
+	else hipLaunchKernelGGL(k_from_storage<false>, dim3(grid_1d(n)), dim3(256), 0, s, (const float*)src, dst, n);
+	return hipGetLastError();
+}
+
+}  // namespace fx

@@ -1,0 +1,158 @@
+/* fluidx_hip.h -- C ABI of the MI355X-native smoke solver + cube-map-space ray marcher.
+ *
+ * Drop-in boundary for the reference's `class Fluid` operator (StarsX/FluidX12,
+ * FluidX12/Content/Fluid.h:20-35) and the SH side of `LightProbe` (Content/LightProbe.h:16-26):
+ * every entry point below names the reference interface it replaces.  Plain C types only
+ * (pointers + sizes); `void* stream` is a `hipStream_t` (the reference's `XUSG::CommandList*`
+ * becomes the HIP stream work is enqueued on; NULL = the context's own stream).
+ *
+ * All functions return 0 (FX_OK) or a negative FX_E_* code and never throw across the ABI.
+ * A context is not thread-safe (single caller thread, like the reference's UI thread).
+ * There is no CPU fallback: without a HIP device fx_create fails with FX_E_DEVICE.
+ */
+#ifndef FLUIDX_HIP_H
+#define FLUIDX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FX_ABI_VERSION 1
+
+enum fx_status {
+	FX_OK = 0,
+	FX_E_INVALID = -1,      /* bad argument / unsupported combination          */
+	FX_E_DEVICE = -2,       /* HIP runtime error (no device, launch failure)   */
+	FX_E_NOMEM = -3,        /* device or host allocation failed                */
+	FX_E_STATE = -4,        /* call order violation (e.g. render before update) */
+	FX_E_COMM = -5,         /* RCCL error / library unavailable                */
+	FX_E_HALO = -6          /* back-trace left the exchanged halo (multi-GPU)  */
+};
+
+/* Fluid::RenderFlags (Fluid.h:12-18) */
+enum fx_render_flags {
+	FX_RAY_MARCH_DIRECT = 0,
+	FX_RAY_MARCH_CUBEMAP = 1,
+	FX_SEPARATE_LIGHT_PASS = 2,
+	FX_OPTIMIZED = 3
+};
+#define FX_FRAME_COUNT 3            /* Fluid::FrameCount (Fluid.h:35) */
+
+enum fx_storage { FX_STORAGE_FP32 = 0, FX_STORAGE_FP16 = 1 };   /* velocity/colour texel storage; the
+                                                                  reference is RGBA16F (Fluid.cpp:207,213) */
+enum fx_jacobi_mode { FX_JACOBI_FIXED = 0,      /* N lock-step sweeps, no early-out (BASELINE configs)     */
+                      FX_JACOBI_FAITHFUL = 1 }; /* cap N (reference: 64) + per-cell freeze at |dx| < 1e-3
+                                                   (CSPoisson.hlsli:11,24)                                  */
+enum fx_address { FX_ADDRESS_CLAMP = 0,         /* FluidEZ.cpp:406 (default path of the reference)          */
+                  FX_ADDRESS_MIRROR = 1 };      /* Fluid.cpp:452                                            */
+
+/* fields for fx_upload / fx_download; host layouts are dense fp32 regardless of device storage:
+ *   VELOCITY  float[3][Z][Y][X]  (component planes; the texture advect reads = m_velocities[0])
+ *   VELOCITY1 float[3][Z][Y][X]  (m_velocities[1], advect output / project input)
+ *   COLOR     float[Z][Y][X][4]  (m_colors[parity], the one every renderer reads)
+ *   COLOR_PREV float[Z][Y][X][4] (m_colors[!parity])
+ *   PRESSURE  float[Z][Y][X]     (m_incompress)      DIVERGENCE float[Z][Y][X] (scratch b)
+ *   LIGHTMAP  float[Z][Y][X][3]  (m_lightMap decoded from R11G11B10F)
+ *   CUBEMAP   uint8[6][S][S][4]  (mip `lod` of m_cubeMap, S = X >> lod, R8G8B8A8_UNORM)
+ * Z = the context's own slab (slab_nz planes), never the halo. */
+enum fx_field {
+	FX_FIELD_VELOCITY = 0, FX_FIELD_VELOCITY1 = 1, FX_FIELD_COLOR = 2, FX_FIELD_COLOR_PREV = 3,
+	FX_FIELD_PRESSURE = 4, FX_FIELD_DIVERGENCE = 5, FX_FIELD_LIGHTMAP = 6, FX_FIELD_CUBEMAP = 7
+};
+
+typedef struct fx_ctx fx_ctx;
+
+/* replaces the arguments of Fluid::Init (Fluid.cpp:189-270) */
+typedef struct fx_desc {
+	uint32_t struct_size;       /* = sizeof(fx_desc)                                        */
+	uint32_t grid_x, grid_y, grid_z;    /* global grid; grid_x == grid_y (Fluid.cpp:201); grid_z == 1 -> 2D */
+	uint32_t viewport_w, viewport_h;    /* Init(width, height)                              */
+	uint32_t storage;           /* fx_storage                                               */
+	uint32_t jacobi_iters;      /* N (BASELINE: 20/40/80; reference faithful: 64)           */
+	uint32_t jacobi_mode;       /* fx_jacobi_mode                                           */
+	uint32_t advect_address;    /* fx_address                                               */
+	int32_t  device;            /* HIP device ordinal, -1 = current                         */
+	uint32_t slab_z0, slab_nz;  /* z-slab owned by this context; {0, 0} = whole grid        */
+	uint32_t halo_advect;       /* planes exchanged before advection (0 = default 8)        */
+	uint32_t halo_jacobi;       /* sweeps per pressure halo exchange (0 = default)          */
+	uint32_t flags;             /* reserved, 0                                              */
+} fx_desc;
+
+/* values Fluid::UpdateFrame derives (Fluid.cpp:324-333) */
+typedef struct fx_frame_info {
+	uint32_t cube_lod;          /* m_cubeMapLOD                         */
+	uint32_t cube_size;         /* grid_x >> cube_lod                   */
+	uint32_t ray_samples;       /* m_raySampleCount                     */
+	uint32_t visibility_mask;   /* m_visibilityMask                     */
+	uint32_t frame_parity;      /* m_frameParity                        */
+	float    edge_pixels;       /* EstimateCubeEdgePixelSize            */
+	float    time_step;
+} fx_frame_info;
+
+/* HIP-event timings accumulated by fx_simulate / fx_render while enabled (milliseconds, launch counts) */
+typedef struct fx_timing {
+	double   advect_ms, divergence_ms, jacobi_ms, project_ms, light_ms, view_ms, exchange_ms;
+	uint64_t steps, jacobi_launches, jacobi_sweeps, renders;
+} fx_timing;
+
+int fx_abi_version(void);
+const char* fx_error_string(int status);
+
+/* Fluid::Fluid + Fluid::Init (Fluid.cpp:168-270): allocates all fields zero-initialised */
+int fx_create(fx_ctx** out, const fx_desc* desc);
+/* Fluid::~Fluid */
+int fx_destroy(fx_ctx* ctx);
+/* Fluid::SetMaxSamples (Fluid.cpp:272-276) */
+int fx_set_max_samples(fx_ctx* ctx, uint32_t max_ray_samples, uint32_t max_light_samples);
+/* Fluid::SetSH (Fluid.cpp:278-281): 9 x float3 host coefficients, NULL detaches the probe */
+int fx_set_sh(fx_ctx* ctx, const float* coeffs27);
+/* Fluid::UpdateFrame (Fluid.cpp:283-346); matrices row-major, row-vector convention (DirectXMath).
+ * view/proj/eye may be NULL for a pure simulation context (no rendering state is updated). */
+int fx_update_frame(fx_ctx* ctx, float time_step, uint8_t frame_index,
+	const float view[16], const float proj[16], const float eye[3]);
+/* Fluid::Simulate (Fluid.cpp:348-410): enqueues advect + divergence + N sweeps + project */
+int fx_simulate(fx_ctx* ctx, void* stream, uint8_t frame_index);
+/* Fluid::Render (Fluid.cpp:412-446): cube-map-space paths (flags & FX_RAY_MARCH_CUBEMAP);
+ * writes the cube map (and light map); the raster resolve to a back buffer is out of scope. */
+int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags);
+int fx_get_frame_info(fx_ctx* ctx, fx_frame_info* out);
+
+/* blocks until everything enqueued by this context has finished; reports FX_E_HALO if the advection
+ * back-trace of a multi-GPU step left the exchanged halo */
+int fx_synchronize(fx_ctx* ctx);
+
+/* checkpoint / parity access (no reference counterpart; the reference cannot read fields back) */
+int fx_upload(fx_ctx* ctx, int field, const void* host, size_t bytes);
+int fx_download(fx_ctx* ctx, int field, void* host, size_t bytes);
+size_t fx_field_bytes(fx_ctx* ctx, int field);
+
+/* individual stages of Simulate, exposed for per-kernel parity tests and micro-benchmarks */
+int fx_advect(fx_ctx* ctx, void* stream);
+int fx_divergence(fx_ctx* ctx, void* stream);
+int fx_jacobi(fx_ctx* ctx, void* stream, uint32_t iters);
+int fx_project(fx_ctx* ctx, void* stream);
+
+/* LightProbe::TransformSH + GetSH (LightProbe.h:22,26; LightProbeEZ.cpp:117-123,183-278):
+ * order-3 SH of a radiance cube float[6][N][N][3] (host), coefficients to out27 (host) */
+int fx_sh_transform(fx_ctx* ctx, const float* cube, uint32_t n, float* out27);
+
+/* timing */
+int fx_timing_enable(fx_ctx* ctx, int enable);
+int fx_timing_read(fx_ctx* ctx, fx_timing* out, int reset);
+
+/* ---- multi-GPU z-slabs (no reference counterpart) --------------------------------
+ * One context per rank.  RCCL transport: fx_comm_id_bytes/fx_comm_get_unique_id on rank 0, broadcast
+ * the bytes out of band, fx_comm_init_rank on every rank (rank r owns slab r).  Loop-back transport
+ * (one process, one GPU, several slab contexts -- used by the tests): fx_comm_init_local. */
+size_t fx_comm_id_bytes(void);
+int fx_comm_get_unique_id(void* id_out, size_t bytes);
+int fx_comm_init_rank(fx_ctx* ctx, const void* id, size_t bytes, int rank, int nranks);
+int fx_comm_init_local(fx_ctx** ctxs, int nranks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUIDX_HIP_H */

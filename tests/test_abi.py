@@ -1,0 +1,83 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol
+include/fluidx_hip.h declares; without a GPU the product fails loudly instead of falling back."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "fluidx_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_operator_surface():
+    names = header_functions()
+    for need in ("fx_create", "fx_destroy", "fx_set_max_samples", "fx_set_sh", "fx_update_frame", "fx_simulate",
+                 "fx_render", "fx_sh_transform", "fx_upload", "fx_download", "fx_comm_init_rank"):
+        assert need in names
+
+
+def test_library_exports_every_declared_symbol():
+    from fluidx12_amd import capi
+    lib = capi.load()
+    names = header_functions()
+    assert set(names) == set(capi.SYMBOLS), "capi.SYMBOLS and include/fluidx_hip.h disagree"
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.fx_abi_version() == 1
+    assert lib.fx_error_string(-6).decode().startswith("advection")
+
+
+def test_no_torch_types_in_the_abi():
+    src = open(os.path.join(ROOT, "include", "fluidx_hip.h")).read()
+    assert "torch" not in src and "at::" not in src and "#include <hip" not in src
+
+
+def test_product_does_not_reference_the_oracle():
+    pkg = os.path.join(ROOT, "fluidx12_amd")
+    for dp, _, fns in os.walk(pkg):
+        if os.path.basename(dp) == "build":
+            continue
+        for fn in fns:
+            if fn.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dp, fn)).read()
+                for line in txt.splitlines():
+                    code = line.split("//")[0].split("#")[0] if not fn.endswith(".py") else line.split("#")[0]
+                    assert "liborc" not in code and "fx_oracle.h" not in code, (fn, line)
+                    assert not re.search(r"^\s*(from|import)\s+oracle", code), (fn, line)
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.device_count() > 0
+    except Exception:
+        return os.path.exists("/dev/kfd")
+
+
+@pytest.mark.skipif(_have_gpu(), reason="checks the no-GPU failure mode")
+def test_create_fails_loudly_without_gpu():
+    import fluidx12_amd as fx
+    from fluidx12_amd import capi
+    f = fx.Fluid()
+    assert f.Init(800, 800, (32, 32, 32)) is False          # the reference's Init also reports failure as false
+    assert f.last_status == capi.FX_E_DEVICE
+    with pytest.raises(fx.FluidxError):
+        f.Simulate(0)
+
+
+def test_create_rejects_bad_descriptors():
+    from fluidx12_amd import capi
+    lib = capi.load()
+    ctx = C.c_void_p()
+    d = capi.Desc()
+    assert lib.fx_create(C.byref(ctx), C.byref(d)) == capi.FX_E_INVALID      # struct_size 0
+    d.struct_size = C.sizeof(capi.Desc)
+    d.grid_x, d.grid_y, d.grid_z, d.jacobi_iters = 32, 16, 8, 4              # x != y (Fluid.cpp:201)
+    assert lib.fx_create(C.byref(ctx), C.byref(d)) == capi.FX_E_INVALID
+    assert lib.fx_destroy(None) == capi.FX_E_INVALID

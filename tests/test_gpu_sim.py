@@ -1,0 +1,217 @@
+"""GPU parity tests of the simulation hot path: HIP kernels (through the C ABI) vs the CPU oracle on
+identical inputs.  Bar: velocity/colour within 1e-4 rel-L2 of the oracle (north_star); in practice the
+kernels that contain no transcendental (divergence, Jacobi, projection) are asserted BIT-EXACT and
+advection (one exp2 per voxel inside the impulse ball) to 1e-6."""
+import numpy as np
+import pytest
+
+import fluidx12_amd as fx
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+TOL = 1e-4          # north_star: fields within 1e-4 rel-L2 of the reference replay
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    n = np.sqrt((b ** 2).sum())
+    d = np.sqrt(((a - b) ** 2).sum())
+    return d / n if n > 0 else d
+
+
+def rand_state(X, Y, Z, seed=0, scale=0.5):
+    rng = np.random.default_rng(seed)
+    vel = (rng.standard_normal((3, Z, Y, X)) * scale).astype(f32)
+    col = rng.random((Z, Y, X, 4)).astype(f32)
+    p = rng.standard_normal((Z, Y, X)).astype(f32)
+    return vel, col, p
+
+
+def make(dims, **kw):
+    f = fx.Fluid()
+    assert f.Init(800, 800, dims, **kw), f.last_status
+    return f
+
+
+DIMS = [(32, 32, 32), (64, 64, 16), (20, 20, 12), (150, 150, 6), (64, 64, 1), (36, 36, 1)]
+
+
+@pytest.mark.parametrize("dims", DIMS)
+@pytest.mark.parametrize("address", ["clamp", "mirror"])
+def test_advect_matches_oracle(dims, address):
+    X, Y, Z = dims
+    vel, col, _ = rand_state(X, Y, Z, 11, scale=1.5)
+    f = make(dims, advect_address=address)
+    dt = f32(f.default_time_step())
+    f.upload(fx.FIELD_VELOCITY, vel)
+    f.upload(fx.FIELD_COLOR, col)               # parity 0 -> UpdateFrame flips: advect reads colour[!p] = this one
+    f.UpdateFrame(dt, 0)
+    f.Advect()
+    f.Synchronize()
+    vo, co = orc.advect(vel, col, dt, address=int(address == "mirror"))
+    gv, gc = f.download(fx.FIELD_VELOCITY1), f.download(fx.FIELD_COLOR)
+    assert rel_l2(gv, vo) < 1e-6 and rel_l2(gc, co) < 1e-6
+    # outside the impulse ball there is no transcendental on the path: bit-exact
+    z, y, x = np.meshgrid(np.arange(Z), np.arange(Y), np.arange(X), indexing="ij")
+    d2 = ((x + .5) / X - .5) ** 2 + ((y + .5) / Y - .1) ** 2 + ((z + .5) / Z - .5) ** 2
+    far = d2 > (1.5 / 16) ** 2
+    assert np.array_equal(gv[:, far], vo[:, far])
+    assert np.array_equal(gc[far], co[far])
+
+
+@pytest.mark.parametrize("dims", DIMS)
+def test_divergence_jacobi_project_bit_exact(dims):
+    X, Y, Z = dims
+    vel, col, p = rand_state(X, Y, Z, 12)
+    f = make(dims, jacobi_iters=7)
+    f.upload(fx.FIELD_VELOCITY1, vel)
+    f.upload(fx.FIELD_PRESSURE, p)
+    f.UpdateFrame(f32(f.default_time_step()), 0)
+    f.Divergence()
+    b = orc.divergence(vel)
+    assert np.array_equal(f.download(fx.FIELD_DIVERGENCE), b)
+    f.Jacobi(7)
+    q, _ = orc.jacobi(p, b, 7)
+    assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
+    f.Project()
+    assert np.array_equal(f.download(fx.FIELD_VELOCITY), orc.project(vel, q))
+
+
+@pytest.mark.parametrize("iters", [1, 2, 3, 5, 8, 20, 40])
+def test_jacobi_sweep_counts(iters):
+    X = 64
+    _, _, p = rand_state(X, X, X, 13)
+    b = np.random.default_rng(14).uniform(-1, 1, (X, X, X)).astype(f32)
+    f = make((X, X, X), jacobi_iters=iters)
+    f.upload(fx.FIELD_PRESSURE, p)
+    f.upload(fx.FIELD_DIVERGENCE, b)
+    f.Jacobi(iters)
+    q, _ = orc.jacobi(p, b, iters)
+    assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
+
+
+def test_jacobi_faithful_mode_matches_oracle():
+    X = 32
+    s = orc.Sim(X, X, X, iters=64, mode=1)
+    f = make((X, X, X), jacobi_iters=64, jacobi_mode="faithful")
+    for _ in range(3):
+        s.step()
+        f.UpdateFrame(f32(f.default_time_step()), 0)
+        f.Simulate(0)
+    f.Synchronize()
+    assert rel_l2(f.download(fx.FIELD_PRESSURE), s.p) < 1e-5
+    assert rel_l2(f.download(fx.FIELD_VELOCITY), s.velocity) < TOL
+
+
+@pytest.mark.parametrize("dims,iters,steps", [((64, 64, 1), 20, 8), ((32, 32, 32), 40, 8), ((48, 48, 24), 40, 4)])
+@pytest.mark.parametrize("address", ["clamp", "mirror"])
+def test_rollout_matches_oracle(dims, iters, steps, address):
+    """config 1 (64^2, 20 sweeps) and small 3D grids: <= 8 steps from the zero state (the flow is chaotic,
+    rounding noise grows ~1.7x per step -- SURVEY.md hard part 3)."""
+    X, Y, Z = dims
+    s = orc.Sim(X, Y, Z, iters=iters, address=int(address == "mirror"))
+    f = make(dims, jacobi_iters=iters, advect_address=address)
+    for k in range(steps):
+        s.step()
+        f.UpdateFrame(f32(f.default_time_step()), k % 3)
+        f.Simulate(k % 3)
+    f.Synchronize()
+    assert rel_l2(f.download(fx.FIELD_VELOCITY), s.velocity) < TOL
+    assert rel_l2(f.download(fx.FIELD_COLOR), s.color) < TOL
+    assert rel_l2(f.download(fx.FIELD_PRESSURE), s.p) < TOL
+    assert f.frame_info().frame_parity == s.parity
+
+
+def test_fp16_storage_rollout():
+    X = 32
+    s = orc.Sim(X, X, X, iters=40, half=True)
+    f = make((X, X, X), jacobi_iters=40, storage="fp16")
+    for k in range(4):
+        s.step()
+        f.UpdateFrame(f32(f.default_time_step()), 0)
+        f.Simulate(0)
+    f.Synchronize()
+    gv, gc = f.download(fx.FIELD_VELOCITY), f.download(fx.FIELD_COLOR)
+    assert rel_l2(gv, s.velocity) < 2e-3 and rel_l2(gc, s.color) < 2e-3      # half ulp = 2^-11: rounding flips amplify
+    # stored values are exactly representable in binary16
+    assert np.array_equal(gv.astype(np.float16).astype(f32), gv)
+
+
+def test_fp16_single_step_kernels():
+    X = 32
+    vel, col, p = rand_state(X, X, X, 15)
+    vel = vel.astype(np.float16).astype(f32); col = col.astype(np.float16).astype(f32)
+    f = make((X, X, X), storage="fp16")
+    dt = f32(f.default_time_step())
+    f.upload(fx.FIELD_VELOCITY, vel); f.upload(fx.FIELD_COLOR, col)
+    f.UpdateFrame(dt, 0)
+    f.Advect()
+    vo, co = orc.advect(vel, col, dt, half=True)
+    gv, gc = f.download(fx.FIELD_VELOCITY1), f.download(fx.FIELD_COLOR)
+    # same fp32 arithmetic then RNE to half: at most a rare 1-ulp(half) flip from the exp2 difference
+    assert np.mean(gv != vo) < 1e-4 and np.mean(gc != co) < 1e-4
+    f.upload(fx.FIELD_VELOCITY1, vo); f.upload(fx.FIELD_PRESSURE, p)
+    f.Project()
+    assert np.array_equal(f.download(fx.FIELD_VELOCITY), orc.project(vo, p, half=True))
+
+
+def test_paused_step_copies_velocity():
+    X = 16
+    vel, col, p = rand_state(X, X, X, 16)
+    f = make((X, X, X))
+    f.upload(fx.FIELD_VELOCITY, vel); f.upload(fx.FIELD_COLOR, col); f.upload(fx.FIELD_PRESSURE, p)
+    f.UpdateFrame(0.0, 0)                        # dt = 0: parity does not flip (Fluid.cpp:345)
+    f.Simulate(0)
+    f.Synchronize()
+    assert np.array_equal(f.download(fx.FIELD_VELOCITY), vel)      # CSProject3D.hlsl:88,112
+    assert np.array_equal(f.download(fx.FIELD_PRESSURE), p)
+    assert f.frame_info().frame_parity == 0
+
+
+def test_errors_and_call_order():
+    f = fx.Fluid()
+    assert f.Init(800, 800, (32, 16, 8)) is False                  # x != y, Fluid.cpp:201
+    f = make((16, 16, 16))
+    with pytest.raises(fx.FluidxError):
+        f.Simulate(0)                                              # UpdateFrame first
+    with pytest.raises(fx.FluidxError):
+        f.UpdateFrame(0.1, 3)                                      # frameIndex < FrameCount
+    with pytest.raises(ValueError):
+        f.upload(fx.FIELD_PRESSURE, np.zeros((4, 4, 4), f32))
+
+
+# ---- full BASELINE sizes: size-independent properties --------------------------------------------------
+@pytest.mark.parametrize("X", [128, 256])
+def test_full_size_properties(X):
+    f = make((X, X, X), jacobi_iters=40)
+    dt = f32(f.default_time_step())
+    for k in range(2):
+        f.UpdateFrame(dt, 0)
+        f.Simulate(0)
+    f.Synchronize()
+    u = f.download(fx.FIELD_VELOCITY)
+    c = f.download(fx.FIELD_COLOR)
+    assert np.isfinite(u).all() and np.isfinite(c).all()
+    ux, uy, uz = u
+    scale = np.abs(u).max()
+    assert scale > 0
+    # 180-degree rotational symmetry about the vertical axis through (0.5, ., 0.5)
+    assert np.abs(ux + ux[::-1, :, ::-1]).max() < 2e-4 * scale
+    assert np.abs(uy - uy[::-1, :, ::-1]).max() < 2e-4 * scale
+    assert np.abs(c[..., 3] - c[::-1, :, ::-1, 3]).max() < 1e-4
+    assert (c >= 0).all() and (c <= 1).all()                       # saturate + dissipation
+    # linearity of the sweep: J(p1 + p2, b1 + b2) == J(p1, b1) + J(p2, b2) up to rounding
+    rng = np.random.default_rng(21)
+    p1, p2, b1, b2 = (rng.standard_normal((X, X, X)).astype(f32) for _ in range(4))
+
+    def J(p, b):
+        f.upload(fx.FIELD_PRESSURE, p); f.upload(fx.FIELD_DIVERGENCE, b)
+        f.Jacobi(8)
+        return f.download(fx.FIELD_PRESSURE)
+    lhs, rhs = J(p1 + p2, b1 + b2), J(p1, b1) + J(p2, b2)
+    assert rel_l2(lhs, rhs) < 1e-6
+    # a slab of the full-size sweep agrees bit-for-bit with the oracle run on that slab's dependency cone
+    zs = slice(0, 12)
+    q, _ = orc.jacobi(p1[:12 + 8], b1[:12 + 8], 8)
+    assert np.array_equal(J(p1, b1)[0:12], q[0:12])
