@@ -1,0 +1,199 @@
+"""GPU parity tests of the cube-map-space ray march and the SH light probe vs the CPU oracle.
+Bars: light map = packed R11G11B10F -> decoded values equal the oracle's except where a 1-ulp
+difference of rsq/division flips a rounding (rare; asserted as a fraction); cube map = RGBA8 ->
+at most +-1 LSB (compare renders with an 8-bit tolerance); SH = 1e-5."""
+import numpy as np
+import pytest
+
+import fluidx12_amd as fx
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def smoke_state(X, steps=10, seed=None):
+    """a density field with structure: a few simulation steps of the oracle (+ optional noise blob)"""
+    s = orc.Sim(X, X, X, iters=20)
+    for _ in range(steps):
+        s.step()
+    col = s.color.copy()
+    if seed is not None:
+        rng = np.random.default_rng(seed)
+        z, y, x = np.meshgrid(*(np.arange(X),) * 3, indexing="ij")
+        blob = np.exp(-(((x - X * .55) ** 2 + (y - X * .5) ** 2 + (z - X * .45) ** 2) / (X * .22) ** 2)).astype(f32)
+        col += (blob[..., None] * rng.random((X, X, X, 4)) * np.array([.3, .5, .8, .6])).astype(f32)
+        col = np.clip(col, 0, 1).astype(f32)
+    return col
+
+
+def setup(X, col, vw=640, vh=480, storage="fp32", sh=None, max_samples=(192, 64)):
+    f = fx.Fluid()
+    assert f.Init(vw, vh, (X, X, X), storage=storage)
+    f.SetMaxSamples(*max_samples)
+    if sh is not None:
+        f.SetSH(sh)
+    view, proj, eye = fx.default_camera(vw, vh)
+    f.upload(fx.FIELD_COLOR, col)
+    f.UpdateFrame(0.0, 0, view, proj, eye)          # dt = 0: parity stays, colour[parity] is what we uploaded
+    fr, lod, rs, mask, _ = orc.update_frame(view, proj, eye, vw, vh, X, max_samples[0])
+    fi = f.frame_info()
+    assert (fi.cube_lod, fi.ray_samples, fi.visibility_mask) == (lod, rs, mask)
+    if sh is not None:
+        for i, v in enumerate(np.asarray(sh, f32).reshape(27)):
+            fr.sh[i] = v
+    return f, fr, lod, rs, mask
+
+
+def cube_close(gpu, ref, max_lsb=1, frac=0.02):
+    d = np.abs(gpu.astype(np.int32) - ref.astype(np.int32))
+    assert d.max() <= max_lsb, int(d.max())
+    assert (d > 0).mean() <= frac, float((d > 0).mean())
+
+
+@pytest.mark.parametrize("X,vp", [(32, (640, 480)), (48, (1920, 1080)), (64, (200, 150))])
+def test_update_frame_matches_oracle(X, vp):
+    f, fr, lod, rs, mask = setup(X, np.zeros((X, X, X, 4), f32), *vp)
+    assert f.frame_info().cube_size == X >> lod
+
+
+@pytest.mark.parametrize("X", [32, 40])
+def test_separate_light_pass(X):
+    col = smoke_state(X, 8, seed=3)
+    f, fr, lod, rs, mask = setup(X, col)
+    f.Render(0, fx.Fluid.OPTIMIZED)
+    f.Synchronize()
+    lm_ref = orc.raymarch_light(col, fr, 64, False, 2)
+    lm = f.download(fx.FIELD_LIGHTMAP)
+    assert (lm != lm_ref).mean() < 1e-3                      # rare R11G11B10 rounding flips only
+    assert np.abs(lm - lm_ref).max() <= np.abs(lm_ref).max() * 2.0 ** -5
+    cf, cu = orc.raymarch_view(col, lm_ref, fr, X >> lod, mask, rs, 64, False, True)
+    cube = f.download(fx.FIELD_CUBEMAP)
+    assert cu[..., 3].max() > 50                             # the test volume is actually visible
+    cube_close(cube, cu)
+    # culled faces are never written (CSRayMarch.hlsl:102): they stay at their cleared value
+    for face in range(6):
+        if not (mask >> face) & 1:
+            assert not cube[face].any()
+
+
+def test_merged_march():
+    X = 32
+    col = smoke_state(X, 8, seed=4)
+    f, fr, lod, rs, mask = setup(X, col, max_samples=(96, 24))
+    f.Render(0, fx.Fluid.RAY_MARCH_CUBEMAP)
+    f.Synchronize()
+    _, cu = orc.raymarch_view(col, None, fr, X >> lod, mask, rs, 24, False, False)
+    cube_close(f.download(fx.FIELD_CUBEMAP), cu)
+
+
+def synthetic_radiance(N):
+    """L(dir) = max(dir.y, 0) * (1, .9, .8) + 0.1"""
+    cube = np.empty((6, N, N, 3), f32)
+    idx = np.arange(N, dtype=f32)
+    px, py = np.meshgrid(idx - N / 2 + 0.5, -(idx - N / 2 + 0.5))     # x varies along columns, y along rows
+    pz = np.full_like(px, N / 2)
+    dirs = [(pz, py, -px), (-pz, py, px), (px, pz, -py), (px, -pz, py), (px, py, pz), (-px, py, -pz)]
+    for f_, (dx, dy, dz) in enumerate(dirs):
+        n = dy / np.sqrt(dx * dx + dy * dy + dz * dz)
+        cube[f_] = np.maximum(n, 0)[..., None] * np.array([1, .9, .8], f32) + f32(0.1)
+    return cube
+
+
+@pytest.mark.parametrize("N", [16, 64, 256])
+def test_sh_transform(N):
+    cube = synthetic_radiance(N)
+    f = fx.Fluid()
+    assert f.Init(640, 480, (16, 16, 16))
+    lp = fx.LightProbe(f)
+    assert lp.Init(cube)
+    lp.TransformSH()
+    sh = lp.GetSH()
+    ref = orc.sh_transform(cube)
+    assert np.allclose(sh, ref, rtol=1e-5, atol=1e-6)
+    # the up direction is brighter than down for this sky
+    assert orc.sh_irradiance(sh, [0, 1, 0])[0] > orc.sh_irradiance(sh, [0, -1, 0])[0]
+
+
+def test_sh_constant_radiance_known_answer():
+    N = 32
+    c = np.array([0.3, 0.6, 0.9], f32)
+    cube = np.broadcast_to(c, (6, N, N, 3)).copy()
+    f = fx.Fluid()
+    assert f.Init(640, 480, (16, 16, 16))
+    lp = fx.LightProbe(f)
+    lp.Init(cube)
+    lp.TransformSH()
+    sh = lp.GetSH()
+    assert np.allclose(sh[0], c * 0.2820948 * 4 * np.pi, rtol=2e-5)
+    assert np.abs(sh[1:]).max() < 2e-4
+
+
+@pytest.mark.parametrize("flags", [fx.Fluid.OPTIMIZED, fx.Fluid.RAY_MARCH_CUBEMAP])
+def test_gi_with_light_probe(flags):
+    X = 32
+    col = smoke_state(X, 8, seed=5)
+    sh = orc.sh_transform(synthetic_radiance(32))
+    f, fr, lod, rs, mask = setup(X, col, sh=sh, max_samples=(96, 24))
+    f.Render(0, flags)
+    f.Synchronize()
+    if flags == fx.Fluid.OPTIMIZED:
+        lm_ref = orc.raymarch_light(col, fr, 24, True, 2)
+        lm = f.download(fx.FIELD_LIGHTMAP)
+        assert (lm != lm_ref).mean() < 5e-3
+        _, cu = orc.raymarch_view(col, lm_ref, fr, X >> lod, mask, rs, 24, True, True)
+    else:
+        _, cu = orc.raymarch_view(col, None, fr, X >> lod, mask, rs, 24, True, False)
+    cube_close(f.download(fx.FIELD_CUBEMAP), cu)
+
+
+def test_fp16_colour_render():
+    X = 32
+    col = smoke_state(X, 8, seed=6).astype(np.float16).astype(f32)
+    f, fr, lod, rs, mask = setup(X, col, storage="fp16")
+    f.Render(0, fx.Fluid.OPTIMIZED)
+    f.Synchronize()
+    lm_ref = orc.raymarch_light(col, fr, 64, False, 2)
+    _, cu = orc.raymarch_view(col, lm_ref, fr, X >> lod, mask, rs, 64, False, True)
+    cube_close(f.download(fx.FIELD_CUBEMAP), cu)
+
+
+def test_render_errors():
+    f = fx.Fluid()
+    assert f.Init(640, 480, (16, 16, 16))
+    with pytest.raises(fx.FluidxError):
+        f.Render(0, fx.Fluid.OPTIMIZED)                  # UpdateFrame with a camera first
+    f2 = fx.Fluid()
+    assert f2.Init(640, 480, (32, 32, 1))
+    f2.UpdateFrame(0.1, 0)
+    with pytest.raises(fx.FluidxError):
+        f2.Render(0, fx.Fluid.OPTIMIZED)                 # 2D has no ray march
+
+
+def test_config3_render_properties():
+    """256^3, default camera at 1920x1080: LOD 0, 192 samples, faces {+X,-X,-Y,+Z};
+    full-size checks are properties, not an oracle replay."""
+    X = 256
+    f = fx.Fluid()
+    assert f.Init(1920, 1080, (X, X, X))
+    view, proj, eye = fx.default_camera(1920, 1080)
+    for k in range(24):
+        f.UpdateFrame(f32(f.default_time_step()), k % 3, view, proj, eye)
+        f.Simulate(k % 3)
+    f.Render(0, fx.Fluid.OPTIMIZED)
+    f.Synchronize()
+    fi = f.frame_info()
+    assert (fi.cube_lod, fi.ray_samples, fi.visibility_mask) == (0, 192, 0x1B)
+    cube = f.download(fx.FIELD_CUBEMAP)
+    assert cube.shape == (6, X, X, 4)
+    assert not cube[2].any() and not cube[5].any()       # +Y and -Z are culled
+    assert cube[..., 3].max() > 0                        # smoke is visible
+    lm = f.download(fx.FIELD_LIGHTMAP)
+    amb = np.float32(1.5 * np.pi)
+    # empty voxels receive exactly light colour + ambient (shadow = 1): (1,.7,.3)*3pi + 1.5pi, R11G11B10-rounded
+    corner = lm[0, 0, 0]
+    assert np.allclose(corner, np.array([1, .7, .3]) * 3 * np.pi + amb, rtol=2 ** -5)
+    # idempotence: rendering the same state twice gives the same cube map
+    f.Render(0, fx.Fluid.OPTIMIZED)
+    f.Synchronize()
+    assert np.array_equal(cube, f.download(fx.FIELD_CUBEMAP))
