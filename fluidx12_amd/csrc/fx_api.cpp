@@ -164,7 +164,7 @@ int jacobi_round(fx_ctx* ctx, hipStream_t s, int count, ScopedMark* mk)
 	while (done < count) {
 		const int left = count - done;
 		// planes still needed after this launch shrink by one per remaining sweep
-		const int fusedMax = ctx->frozen ? 1 : jacobi_fused_max_sweeps(ctx->g);
+		const int fusedMax = ctx->frozen ? 1 : jacobi_fused_max_sweeps(ctx->g, (int)(ctx->desc.flags & FX_FLAG_JACOBI_FUSE_MASK));
 		const int t = std::min(left, fusedMax);
 		const Range r = grown(ctx, ctx->nranks > 1 ? left - t : 0);
 		const float* src = ctx->p[ctx->p_cur];

@@ -78,8 +78,12 @@ typedef struct fx_desc {
 	uint32_t slab_z0, slab_nz;  /* z-slab owned by this context; {0, 0} = whole grid        */
 	uint32_t halo_advect;       /* planes exchanged before advection (0 = default 8)        */
 	uint32_t halo_jacobi;       /* sweeps per pressure halo exchange (0 = default)          */
-	uint32_t flags;             /* reserved, 0                                              */
+	uint32_t flags;             /* FX_FLAG_*                                                */
 } fx_desc;
+
+/* fx_desc.flags: bits 0-3 = Jacobi sweeps fused per launch (temporal blocking), 0 = library default,
+ * 1 = one launch per sweep; results are bit-identical for every setting */
+#define FX_FLAG_JACOBI_FUSE_MASK 0xFu
 
 /* values Fluid::UpdateFrame derives (Fluid.cpp:324-333) */
 typedef struct fx_frame_info {

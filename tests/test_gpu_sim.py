@@ -91,6 +91,21 @@ def test_jacobi_sweep_counts(iters):
     assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
 
 
+@pytest.mark.parametrize("dims", [(64, 64, 40), (128, 128, 24), (256, 256, 20)])
+@pytest.mark.parametrize("fuse", [1, 2, 3, 4])
+def test_jacobi_temporal_blocking_bit_exact(dims, fuse):
+    """T sweeps fused in one launch (register/LDS temporal blocking) == T single sweeps == oracle, bit for bit"""
+    X, Y, Z = dims
+    _, _, p = rand_state(X, Y, Z, 17)
+    b = np.random.default_rng(18).uniform(-1, 1, (Z, Y, X)).astype(f32)
+    f = make(dims, jacobi_iters=9, jacobi_fuse=fuse)
+    f.upload(fx.FIELD_PRESSURE, p)
+    f.upload(fx.FIELD_DIVERGENCE, b)
+    f.Jacobi(9)                                  # 9 = 4+4+1 = 3+3+3 = 2*4+1: exercises remainders
+    q, _ = orc.jacobi(p, b, 9)
+    assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
+
+
 def test_jacobi_faithful_mode_matches_oracle():
     X = 32
     s = orc.Sim(X, X, X, iters=64, mode=1)

@@ -54,6 +54,15 @@ def test_slabs_equal_single_domain(nranks, iters, hj):
     assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
 
 
+@pytest.mark.parametrize("fuse", [2, 4])
+def test_slabs_with_temporal_blocking(fuse):
+    dims = (64, 64, 96)
+    ref = run_single(dims, 4, jacobi_iters=12, jacobi_fuse=1)
+    fl = run_slabs(dims, 4, 3, jacobi_iters=12, halo_jacobi=4, halo_advect=8, jacobi_fuse=fuse)
+    assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
+    assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
+
+
 def test_uneven_slabs_and_fp16():
     dims = (48, 48, 40)
     ref = run_single(dims, 4, jacobi_iters=12, storage="fp16")
