@@ -51,6 +51,29 @@ template <> struct Store<true> {
 __device__ __forceinline__ float lerpf(float a, float b, float f) { return fmaf(f, b - a, a); }
 __device__ __forceinline__ float saturatef(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 
+// ---- XCD-aware workgroup -> tile mapping ----------------------------------------------------------
+// MI355X dispatches workgroup L to XCD L % 8 and every XCD has a private 4 MiB L2.  With the natural order
+// (tile = L) the eight XCDs interleave at tile granularity, so every stencil halo row/plane is fetched by two
+// L2s.  Here XCD k instead walks the k-th contiguous eighth of the tile sequence (tiles ordered x, then y,
+// then z): its halo traffic shrinks to the two ends of its z range.  Speed only, never correctness.
+struct Tile3 { int x, y, z; };
+__device__ __forceinline__ Tile3 xcd_tile(int gx, int gy, int gz, int remap)
+{
+	const int n = gx * gy * gz;
+	int t = (int)blockIdx.x;
+	if (remap) {
+		const int q = n >> 3, r = n & 7;
+		const int xcd = t & 7, j = t >> 3;
+		t = xcd * q + min(xcd, r) + j;
+	}
+	Tile3 o;
+	o.x = t % gx;
+	const int u = t / gx;
+	o.y = u % gy;
+	o.z = u / gy;
+	return o;
+}
+
 // D3D addressing of an integer tap (CLAMP / MIRROR)
 __device__ __forceinline__ int addr_tap(int i, int n, int mode)
 {
@@ -70,13 +93,15 @@ template <bool HALF>
 __global__ __launch_bounds__(256) void k_advect(const Geom g, const SimParams sp,
 	const typename Store<HALF>::S* __restrict__ vel_in, const typename Store<HALF>::S4* __restrict__ col_in,
 	typename Store<HALF>::S* __restrict__ vel_out, typename Store<HALF>::S4* __restrict__ col_out,
-	int z_begin, unsigned* halo_overflow)
+	int z_begin, int nzp, int remap, unsigned* halo_overflow)
 {
 	typedef Store<HALF> St;
-	const int x = blockIdx.x * 64 + threadIdx.x;
-	const int y = blockIdx.y * 4 + threadIdx.y;
-	const int z = z_begin + blockIdx.z;
-	if (x >= g.X || y >= g.Y) return;
+	const int BX = blockDim.x, BY = blockDim.y, BZ = blockDim.z;
+	const Tile3 tile = xcd_tile((g.X + BX - 1) / BX, (g.Y + BY - 1) / BY, (nzp + BZ - 1) / BZ, remap);
+	const int x = tile.x * BX + threadIdx.x;
+	const int y = tile.y * BY + threadIdx.y;
+	const int z = z_begin + tile.z * BZ + threadIdx.z;
+	if (x >= g.X || y >= g.Y || z >= z_begin + nzp) return;
 
 	const size_t plane = g.plane();
 	const size_t stride = g.cells_local();                  // distance between velocity component planes
@@ -160,12 +185,13 @@ __global__ __launch_bounds__(256) void k_advect(const Geom g, const SimParams sp
 // ---------------------------------------------------------------------------------------------
 template <bool HALF>
 __global__ __launch_bounds__(256) void k_divergence(const Geom g, const typename Store<HALF>::S* __restrict__ vel,
-	float* __restrict__ b, int z_begin)
+	float* __restrict__ b, int z_begin, int nzp, int remap)
 {
 	typedef Store<HALF> St;
-	const int x = blockIdx.x * 64 + threadIdx.x;
-	const int y = blockIdx.y * 4 + threadIdx.y;
-	const int z = z_begin + blockIdx.z;
+	const Tile3 tile = xcd_tile((g.X + 63) >> 6, (g.Y + 3) >> 2, nzp, remap);
+	const int x = tile.x * 64 + threadIdx.x;
+	const int y = tile.y * 4 + threadIdx.y;
+	const int z = z_begin + tile.z;
 	if (x >= g.X || y >= g.Y) return;
 	const size_t plane = g.plane(), stride = g.cells_local();
 	const size_t row = (size_t)g.lz(z) * plane + (size_t)y * g.X;
@@ -191,11 +217,12 @@ __global__ __launch_bounds__(256) void k_divergence(const Geom g, const typename
 //   x = ((((((qL - b) + qR) + qU) + qD) + qF) + qB) * (1/6)     2D: (((qL - b) + qR) + qU) + qD) * 1/4
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_jacobi_generic(const Geom g, const float* __restrict__ p_in,
-	const float* __restrict__ b, float* __restrict__ p_out, uint8_t* __restrict__ frozen, int z_begin)
+	const float* __restrict__ b, float* __restrict__ p_out, uint8_t* __restrict__ frozen, int z_begin, int nzp, int remap)
 {
-	const int x = blockIdx.x * 64 + threadIdx.x;
-	const int y = blockIdx.y * 4 + threadIdx.y;
-	const int z = z_begin + blockIdx.z;
+	const Tile3 tile = xcd_tile((g.X + 63) >> 6, (g.Y + 3) >> 2, nzp, remap);
+	const int x = tile.x * 64 + threadIdx.x;
+	const int y = tile.y * 4 + threadIdx.y;
+	const int z = z_begin + tile.z;
 	if (x >= g.X || y >= g.Y) return;
 	const size_t plane = g.plane();
 	const size_t zrow = (size_t)g.lz(z) * plane;
@@ -224,13 +251,14 @@ __global__ __launch_bounds__(256) void k_jacobi_generic(const Geom g, const floa
 // Neighbour rows/planes come through L1/L2 (each line is re-read by the 5 stencil partners).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_jacobi_v4(const Geom g, const float* __restrict__ p_in,
-	const float* __restrict__ b, float* __restrict__ p_out, int z_begin, int rows_per_block)
+	const float* __restrict__ b, float* __restrict__ p_out, int z_begin, int nzp, int remap, int rows_per_block)
 {
 	const int X4 = g.X >> 2;
 	const int lane = threadIdx.x;                       // float4 column
-	const int x4 = blockIdx.x * blockDim.x + lane;
-	const int y = blockIdx.y * rows_per_block + threadIdx.y;
-	const int z = z_begin + blockIdx.z;
+	const Tile3 tile = xcd_tile((X4 + (int)blockDim.x - 1) / (int)blockDim.x, (g.Y + rows_per_block - 1) / rows_per_block, nzp, remap);
+	const int x4 = tile.x * blockDim.x + lane;
+	const int y = tile.y * rows_per_block + threadIdx.y;
+	const int z = z_begin + tile.z;
 	if (x4 >= X4 || y >= g.Y) return;
 	const size_t plane = g.plane();
 	const int yu = max(y, 1) - 1, yd = min(y + 1, g.Y - 1);
@@ -372,12 +400,13 @@ __global__ __launch_bounds__(NT, MINW) void k_jacobi_tb(const Geom g, const floa
 template <bool HALF>
 __global__ __launch_bounds__(256) void k_project(const Geom g, const SimParams sp,
 	const typename Store<HALF>::S* __restrict__ vel_in, const float* __restrict__ p,
-	typename Store<HALF>::S* __restrict__ vel_out, int z_begin)
+	typename Store<HALF>::S* __restrict__ vel_out, int z_begin, int nzp, int remap)
 {
 	typedef Store<HALF> St;
-	const int x = blockIdx.x * 64 + threadIdx.x;
-	const int y = blockIdx.y * 4 + threadIdx.y;
-	const int z = z_begin + blockIdx.z;
+	const Tile3 tile = xcd_tile((g.X + 63) >> 6, (g.Y + 3) >> 2, nzp, remap);
+	const int x = tile.x * 64 + threadIdx.x;
+	const int y = tile.y * 4 + threadIdx.y;
+	const int z = z_begin + tile.z;
 	if (x >= g.X || y >= g.Y) return;
 	const size_t plane = g.plane(), stride = g.cells_local();
 	const size_t zrow = (size_t)g.lz(z) * plane;
@@ -440,20 +469,40 @@ __global__ __launch_bounds__(256) void k_from_storage(const typename Store<HALF>
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-static inline dim3 grid_xyz(const Geom& g, int nzp) { return dim3((g.X + 63) / 64, (g.Y + 3) / 4, nzp); }
+static inline dim3 grid_xyz(const Geom& g, int nzp) { return dim3(((g.X + 63) / 64) * ((g.Y + 3) / 4) * nzp, 1, 1); }
+static int env_int(const char* name, int dflt);
+// bit 0 Jacobi, bit 1 advect, bit 2 divergence, bit 3 project.  Default: Jacobi only -- measured on MI355X at
+// 256^3 (profiles/r01_xcd_remap.txt): Jacobi -11% time / -18% fetch; the gather-heavy advect and the short
+// divergence/project kernels got slower with it.  FLUIDX_XCD_REMAP overrides (measurement knob).
+enum { REMAP_JACOBI = 1, REMAP_ADVECT = 2, REMAP_DIV = 4, REMAP_PROJECT = 8 };
+static int xcd_remap_on(int which)
+{
+	static const int mask = env_int("FLUIDX_XCD_REMAP", REMAP_JACOBI);
+	return (mask & which) ? 1 : 0;
+}
 static inline unsigned grid_1d(size_t n) { return (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
 
 hipError_t launch_advect(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const void* col_in,
 	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, hipStream_t s)
 {
 	if (z_end <= z_begin) return hipSuccess;
-	const dim3 grid = grid_xyz(g, z_end - z_begin), block(64, 4, 1);
+	// workgroup shape: FLUIDX_ADVECT_BLOCK="bx,by,bz" overrides (measurement knob)
+	static int bx = 0, by = 0, bz = 0;
+	if (!bx) {
+		bx = 64; by = 4; bz = 1;
+		const char* e = getenv("FLUIDX_ADVECT_BLOCK");
+		int a, b_, c;
+		if (e && sscanf(e, "%d,%d,%d", &a, &b_, &c) == 3 && a > 0 && b_ > 0 && c > 0 && a * b_ * c <= 256) { bx = a; by = b_; bz = c; }
+	}
+	const int nzp = z_end - z_begin;
+	const int cbz = g.Zg > 1 ? bz : 1;
+	const dim3 block(bx, by, cbz), grid(((g.X + bx - 1) / bx) * ((g.Y + by - 1) / by) * ((nzp + cbz - 1) / cbz), 1, 1);
 	if (half_store)
 		hipLaunchKernelGGL(k_advect<true>, grid, block, 0, s, g, sp, (const h16*)vel_in, (const h16x4*)col_in,
-			(h16*)vel_out, (h16x4*)col_out, z_begin, halo_overflow);
+			(h16*)vel_out, (h16x4*)col_out, z_begin, nzp, xcd_remap_on(REMAP_ADVECT), halo_overflow);
 	else
 		hipLaunchKernelGGL(k_advect<false>, grid, block, 0, s, g, sp, (const float*)vel_in, (const float4*)col_in,
-			(float*)vel_out, (float4*)col_out, z_begin, halo_overflow);
+			(float*)vel_out, (float4*)col_out, z_begin, nzp, xcd_remap_on(REMAP_ADVECT), halo_overflow);
 	return hipGetLastError();
 }
 
@@ -461,8 +510,8 @@ hipError_t launch_divergence(const Geom& g, int half_store, const void* vel, flo
 {
 	if (z_end <= z_begin) return hipSuccess;
 	const dim3 grid = grid_xyz(g, z_end - z_begin), block(64, 4, 1);
-	if (half_store) hipLaunchKernelGGL(k_divergence<true>, grid, block, 0, s, g, (const h16*)vel, b, z_begin);
-	else hipLaunchKernelGGL(k_divergence<false>, grid, block, 0, s, g, (const float*)vel, b, z_begin);
+	if (half_store) hipLaunchKernelGGL(k_divergence<true>, grid, block, 0, s, g, (const h16*)vel, b, z_begin, z_end - z_begin, xcd_remap_on(REMAP_DIV));
+	else hipLaunchKernelGGL(k_divergence<false>, grid, block, 0, s, g, (const float*)vel, b, z_begin, z_end - z_begin, xcd_remap_on(REMAP_DIV));
 	return hipGetLastError();
 }
 
@@ -475,10 +524,10 @@ hipError_t launch_jacobi_sweep(const Geom& g, const float* p_in, const float* b,
 		const int X4 = g.X >> 2;
 		const int bx = X4 < 64 ? X4 : 64;               // float4 columns per block row
 		int by = 256 / bx; if (by < 1) by = 1; if (by > g.Y) by = g.Y;
-		const dim3 block(bx, by, 1), grid((X4 + bx - 1) / bx, (g.Y + by - 1) / by, nzp);
-		hipLaunchKernelGGL(k_jacobi_v4, grid, block, 0, s, g, p_in, b, p_out, z_begin, by);
+		const dim3 block(bx, by, 1), grid(((X4 + bx - 1) / bx) * ((g.Y + by - 1) / by) * nzp, 1, 1);
+		hipLaunchKernelGGL(k_jacobi_v4, grid, block, 0, s, g, p_in, b, p_out, z_begin, nzp, xcd_remap_on(REMAP_JACOBI), by);
 	} else {
-		hipLaunchKernelGGL(k_jacobi_generic, grid_xyz(g, nzp), dim3(64, 4, 1), 0, s, g, p_in, b, p_out, frozen, z_begin);
+		hipLaunchKernelGGL(k_jacobi_generic, grid_xyz(g, nzp), dim3(64, 4, 1), 0, s, g, p_in, b, p_out, frozen, z_begin, nzp, xcd_remap_on(REMAP_JACOBI));
 	}
 	return hipGetLastError();
 }
@@ -591,8 +640,8 @@ hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, co
 {
 	if (z_end <= z_begin) return hipSuccess;
 	const dim3 grid = grid_xyz(g, z_end - z_begin), block(64, 4, 1);
-	if (half_store) hipLaunchKernelGGL(k_project<true>, grid, block, 0, s, g, sp, (const h16*)vel_in, p, (h16*)vel_out, z_begin);
-	else hipLaunchKernelGGL(k_project<false>, grid, block, 0, s, g, sp, (const float*)vel_in, p, (float*)vel_out, z_begin);
+	if (half_store) hipLaunchKernelGGL(k_project<true>, grid, block, 0, s, g, sp, (const h16*)vel_in, p, (h16*)vel_out, z_begin, z_end - z_begin, xcd_remap_on(REMAP_PROJECT));
+	else hipLaunchKernelGGL(k_project<false>, grid, block, 0, s, g, sp, (const float*)vel_in, p, (float*)vel_out, z_begin, z_end - z_begin, xcd_remap_on(REMAP_PROJECT));
 	return hipGetLastError();
 }
 
