@@ -1,0 +1,74 @@
+// fluidx_demo.cpp -- the frame loop of the reference's demo driver (FluidX12/FluidX12.cpp) on the C++ shim:
+// OnUpdate's time-step rule (:266) and default camera (:243-253), PopulateCommandList's Simulate + Render
+// (:465,489-490), minus the window.  Build (after `python -m fluidx12_amd.build`):
+//   hipcc -std=c++17 examples/fluidx_demo.cpp -o fluidx_demo -Lfluidx12_amd -lfluidx_hip -Wl,-rpath,$PWD/fluidx12_amd
+// Usage: fluidx_demo [-gridSize X Y Z] [-maxRaySamples N] [-maxLightSamples N] [-frames N]   (FluidX12.cpp:398-433)
+#include "../fluidx12_amd/csrc/Fluid.hpp"
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+using namespace fluidx;
+
+static XMFLOAT4X4 LookAtLH(const float eye[3], const float at[3], const float up[3])
+{
+	float z[3] = { at[0] - eye[0], at[1] - eye[1], at[2] - eye[2] };
+	float l = std::sqrt(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]);
+	for (float& v : z) v /= l;
+	float x[3] = { up[1] * z[2] - up[2] * z[1], up[2] * z[0] - up[0] * z[2], up[0] * z[1] - up[1] * z[0] };
+	l = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+	for (float& v : x) v /= l;
+	const float y[3] = { z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0] };
+	auto dot = [&](const float* a) { return a[0] * eye[0] + a[1] * eye[1] + a[2] * eye[2]; };
+	XMFLOAT4X4 m = { { { x[0], y[0], z[0], 0 }, { x[1], y[1], z[1], 0 }, { x[2], y[2], z[2], 0 }, { -dot(x), -dot(y), -dot(z), 1 } } };
+	return m;
+}
+
+static XMFLOAT4X4 PerspectiveFovLH(float fovy, float aspect, float zn, float zf)
+{
+	const float h = std::cos(0.5f * fovy) / std::sin(0.5f * fovy), w = h / aspect, q = zf / (zf - zn);
+	XMFLOAT4X4 m = { { { w, 0, 0, 0 }, { 0, h, 0, 0 }, { 0, 0, q, 1 }, { 0, 0, -q * zn, 0 } } };
+	return m;
+}
+
+int main(int argc, char** argv)
+{
+	XMUINT3 grid = { 128, 128, 128 };                  // FluidX12.cpp:44
+	uint32_t maxRay = 192, maxLight = 64, frames = 100; // FluidX12.cpp:38-39
+	const uint32_t width = 800, height = 800;           // Main.cpp:17
+	for (int i = 1; i < argc; ++i) {
+		if (!std::strcmp(argv[i], "-gridSize") && i + 3 < argc) { grid.x = atoi(argv[++i]); grid.y = atoi(argv[++i]); grid.z = atoi(argv[++i]); }
+		else if (!std::strcmp(argv[i], "-maxRaySamples") && i + 1 < argc) maxRay = atoi(argv[++i]);
+		else if (!std::strcmp(argv[i], "-maxLightSamples") && i + 1 < argc) maxLight = atoi(argv[++i]);
+		else if (!std::strcmp(argv[i], "-frames") && i + 1 < argc) frames = atoi(argv[++i]);
+	}
+	Fluid fluid;
+	if (!fluid.Init(nullptr, width, height, grid)) {   // ThrowIfFailed(E_FAIL) in the reference (FluidX12.cpp:198-200)
+		std::fprintf(stderr, "Fluid::Init failed: %s\n", fx_error_string(fluid.LastStatus()));
+		return 1;
+	}
+	fluid.SetMaxSamples(maxRay, maxLight);
+	const float eye[3] = { 4.0f, 16.0f, -40.0f }, at[3] = { 0, 0, 0 }, up[3] = { 0, 1, 0 };
+	const XMFLOAT4X4 view = LookAtLH(eye, at, up);
+	const XMFLOAT4X4 proj = PerspectiveFovLH(3.141592654f / 4.0f, width / (float)height, 1.0f, 1000.0f);
+	const XMFLOAT3 eyePt = { eye[0], eye[1], eye[2] };
+	const float timeStep = (grid.z > 1 ? 2.0f : 1.0f) / grid.y;    // FluidX12.cpp:266
+
+	const auto t0 = std::chrono::steady_clock::now();
+	for (uint32_t f = 0; f < frames; ++f) {
+		const uint8_t frameIndex = f % Fluid::FrameCount;
+		fluid.UpdateFrame(timeStep, frameIndex, view, proj, eyePt);
+		fluid.Simulate(nullptr, frameIndex);
+		if (grid.z > 1) fluid.Render(nullptr, frameIndex, Fluid::OPTIMIZED);
+		if (fluid.LastStatus() != FX_OK) { std::fprintf(stderr, "frame %u: %s\n", f, fx_error_string(fluid.LastStatus())); return 1; }
+	}
+	if (fx_synchronize(fluid.Handle()) != FX_OK) return 1;
+	const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	fx_frame_info fi;
+	fx_get_frame_info(fluid.Handle(), &fi);
+	std::printf("%u frames of %ux%ux%u in %.3f s (%.1f fps); cube LOD %u (%u^2), %u ray samples, mask 0x%x\n",
+		frames, grid.x, grid.y, grid.z, s, frames / s, fi.cube_lod, fi.cube_size, fi.ray_samples, fi.visibility_mask);
+	return 0;
+}

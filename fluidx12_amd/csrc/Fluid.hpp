@@ -1,0 +1,96 @@
+// Fluid.hpp -- C++ host-side mirror of the reference's operator classes over the C ABI
+// (include/fluidx_hip.h).  Same method names, argument meaning and error behaviour as
+// /root/reference/FluidX12/Content/Fluid.h:20-35 and Content/LightProbe.h:16-26, so a caller written
+// against the reference (FluidX12/FluidX12.cpp:197-201, 277, 465, 484-500) ports by dropping the XUSG
+// arguments: CommandList* -> hipStream_t (void*), descriptor-table lib / uploaders / formats -> gone.
+// Header-only; links against libfluidx_hip.so.
+#pragma once
+#include "../../include/fluidx_hip.h"
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace fluidx {
+
+struct XMUINT3 { uint32_t x, y, z; };
+struct XMFLOAT3 { float x, y, z; };
+struct XMFLOAT4X4 { float m[4][4]; };      // row-major, row-vector convention (DirectXMath)
+
+struct FluidOptions {                       // knobs the reference fixes at compile time / in FluidX12.cpp
+	uint32_t storage = FX_STORAGE_FP16;            // the reference stores RGBA16F (Fluid.cpp:207,213)
+	uint32_t jacobiIters = 64;                     // ITER (CSProject3D.hlsl:13)
+	uint32_t jacobiMode = FX_JACOBI_FAITHFUL;      // per-cell early-out (CSPoisson.hlsli:24)
+	uint32_t advectAddress = FX_ADDRESS_CLAMP;     // FluidEZ.cpp:406 (Fluid.cpp:452 uses MIRROR)
+	int32_t device = -1;
+};
+
+class Fluid {
+public:
+	typedef FluidOptions Options;
+	enum RenderFlags : uint8_t {           // Fluid.h:12-18
+		RAY_MARCH_DIRECT = 0,
+		RAY_MARCH_CUBEMAP = (1 << 0),
+		SEPARATE_LIGHT_PASS = (1 << 1),
+		OPTIMIZED = RAY_MARCH_CUBEMAP | SEPARATE_LIGHT_PASS
+	};
+	static const uint8_t FrameCount = FX_FRAME_COUNT;   // Fluid.h:35
+
+	Fluid() : m_ctx(nullptr) {}
+	virtual ~Fluid() { if (m_ctx) fx_destroy(m_ctx); }
+	Fluid(const Fluid&) = delete;
+	Fluid& operator=(const Fluid&) = delete;
+
+	// Fluid::Init (Fluid.cpp:189-270): false on failure, like XUSG_N_RETURN(..., false)
+	bool Init(void* /*pCommandList*/, uint32_t width, uint32_t height, const XMUINT3& gridSize, const Options& opt = Options())
+	{
+		if (m_ctx) { fx_destroy(m_ctx); m_ctx = nullptr; }
+		fx_desc d;
+		std::memset(&d, 0, sizeof d);
+		d.struct_size = sizeof d;
+		d.grid_x = gridSize.x; d.grid_y = gridSize.y; d.grid_z = gridSize.z;
+		d.viewport_w = width; d.viewport_h = height;
+		d.storage = opt.storage; d.jacobi_iters = opt.jacobiIters; d.jacobi_mode = opt.jacobiMode;
+		d.advect_address = opt.advectAddress; d.device = opt.device;
+		m_status = fx_create(&m_ctx, &d);
+		return m_status == FX_OK;
+	}
+	void SetMaxSamples(uint32_t maxRaySamples, uint32_t maxLightSamples) { m_status = fx_set_max_samples(m_ctx, maxRaySamples, maxLightSamples); }
+	void SetSH(const float* coeffSH /* 9 x float3, or nullptr */) { m_status = fx_set_sh(m_ctx, coeffSH); }
+	void UpdateFrame(float timeStep, uint8_t frameIndex, const XMFLOAT4X4& view, const XMFLOAT4X4& proj, const XMFLOAT3& eyePt)
+	{
+		const float eye[3] = { eyePt.x, eyePt.y, eyePt.z };
+		m_status = fx_update_frame(m_ctx, timeStep, frameIndex, &view.m[0][0], &proj.m[0][0], eye);
+	}
+	void Simulate(void* pCommandList /* hipStream_t */, uint8_t frameIndex) { m_status = fx_simulate(m_ctx, pCommandList, frameIndex); }
+	void Render(void* pCommandList /* hipStream_t */, uint8_t frameIndex, uint8_t flags) { m_status = fx_render(m_ctx, pCommandList, frameIndex, flags); }
+
+	// not in the reference: the void methods above cannot report failure there either (debug layer only)
+	int LastStatus() const { return m_status; }
+	fx_ctx* Handle() const { return m_ctx; }
+
+protected:
+	fx_ctx* m_ctx;
+	int m_status = FX_OK;
+};
+
+// SH side of class LightProbe (LightProbe.h:16-26); the DDS loader and the sky pass are out of scope
+class LightProbe {
+public:
+	bool Init(const float* radianceCube /* float[6][n][n][3] */, uint32_t n)
+	{
+		if (!radianceCube || !n) return false;
+		m_cube.assign(radianceCube, radianceCube + (size_t)6 * n * n * 3);
+		m_n = n;
+		return true;
+	}
+	void TransformSH(Fluid& fluid) { m_status = fx_sh_transform(fluid.Handle(), m_cube.data(), m_n, m_sh); }   // LightProbeEZ.cpp:117-123
+	const float* GetSH() const { return m_sh; }
+	int LastStatus() const { return m_status; }
+private:
+	std::vector<float> m_cube;
+	uint32_t m_n = 0;
+	float m_sh[27] = {};
+	int m_status = FX_OK;
+};
+
+}  // namespace fluidx

@@ -1,0 +1,47 @@
+"""world_size-2 CPU test (gloo) of bench.py's multi-rank plumbing: torch.distributed rendezvous on 127.0.0.1,
+z-slab assignment, broadcast of the RCCL unique-id bytes, barriers, max-over-ranks reduction and the single JSON
+line from rank 0.  `--dry-run` skips all GPU work (and says so in the JSON), so this is never a measurement.
+The slab arithmetic itself is verified on the GPU by tests/test_gpu_slabs.py (loop-back transport)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bench_two_ranks_gloo_dry_run():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--dry-run"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["dry_run"] is True
+    assert d["scaling"] == "strong" and d["unit"] == "voxel-updates/s" and d["higher_is_better"] is True
+    assert d["config"]["parallelism"].startswith("z-slab x2")
+    assert "cpu_baseline" not in d                        # rank 0 at N = 1 only
+
+
+def test_slab_partition_covers_the_grid():
+    sys.path.insert(0, ROOT)
+    import bench
+    for Z in (256, 250, 64):
+        for n in (1, 2, 3, 4, 8):
+            slabs = [bench.slab_for_rank(Z, r, n) for r in range(n)]
+            assert slabs[0][0] == 0 and sum(s[1] for s in slabs) == Z
+            for (a, na), (b, _) in zip(slabs, slabs[1:]):
+                assert a + na == b
+    assert bench.step_bytes_per_voxel(40, "fp32") == 580 and bench.step_bytes_per_voxel(40, "fp16") == 534
