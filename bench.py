@@ -36,6 +36,22 @@ def step_bytes_per_voxel(iters, storage):
     return 5 * V + 2 * Cb + 2 * 4 + 12 * iters            # 5V + 2C + 2S + 12 N
 
 
+def pmc_traffic(kernel, grid, iters, storage):
+    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (tools/pmc_summary.py),
+    or None when no summary matches this workload.  bench.py cannot run the profiler on itself; the summary is
+    produced by the same command under rocprofv3 --pmc and committed under profiles/."""
+    import glob
+    best = None
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
+        try:
+            d = json.load(open(fn))
+        except Exception:
+            continue
+        if (d.get("grid"), d.get("iters"), d.get("storage")) == (grid, iters, storage) and kernel in d.get("kernels", {}):
+            best = (d["kernels"][kernel]["traffic"], os.path.basename(fn))
+    return best
+
+
 def slab_for_rank(Z, rank, world):
     z0 = rank * Z // world
     z1 = (rank + 1) * Z // world
@@ -179,8 +195,11 @@ def main():
             avg_launch_s = timing.jacobi_ms * 1e-3 / timing.jacobi_launches
             sweeps_per_launch = timing.jacobi_sweeps / timing.jacobi_launches
             achieved = JACOBI_BYTES_PER_CELL_SWEEP * cells * sweeps_per_launch / avg_launch_s / 1e9
-            roof = {"bound": "hbm", "kernel": "jacobi sweep", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            tr = pmc_traffic("k_jacobi_v4", G, args.iters, args.storage) if (N == 1 and sweeps_per_launch == 1) else None
+            roof = {"bound": "hbm", "kernel": "k_jacobi_v4 (one lock-step Jacobi sweep)" if sweeps_per_launch == 1 else "k_jacobi_tb",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
+                    "traffic_source": tr[1] if tr else None,
                     "algorithmic_bytes_per_launch": JACOBI_BYTES_PER_CELL_SWEEP * cells * sweeps_per_launch,
                     "avg_launch_us": avg_launch_s * 1e6, "launches": int(timing.jacobi_launches),
                     "sweeps_per_launch": sweeps_per_launch,
