@@ -99,6 +99,20 @@ def test_thread_groups_and_shape_of_the_shipped_shaders():
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/Bin"), reason="reference not mounted (GPU box)")
+def test_golden_vectors_regenerate_from_the_mounted_binaries():
+    """re-run two of the shipped shaders in the interpreter and compare with the committed golden vectors"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_dxbc_golden as mk
+    g = np.load(os.path.join(ROOT, "tests", "golden", "dxbc_sim.npz"))
+    dt = np.float32(2.0 / 16)
+    vo, co = mk.run_advect(g["advect_3d_f16_mirror_vel_in"], g["advect_3d_f16_mirror_col_in"], dt, "MIRROR", "R16G16B16A16_FLOAT")
+    assert np.array_equal(vo, g["advect_3d_f16_mirror_vel_out"]) and np.array_equal(co, g["advect_3d_f16_mirror_col_out"])
+    v0, p, _ = mk.run_project(g["project_3d_f32_vel_in"], g["project_3d_f32_p_in"], dt, "R32G32B32A32_FLOAT")
+    assert np.array_equal(v0, g["project_3d_f32_vel_out"]) and np.array_equal(p, g["project_3d_f32_p_out"])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/Bin"), reason="reference not mounted (GPU box)")
 def test_fixture_matches_the_mounted_reference_and_decoder_self_checks():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import dxbc

@@ -1,0 +1,114 @@
+"""The HIP kernels (through the C ABI) against golden vectors produced by the reference's OWN shipped shader
+binaries (tests/golden/dxbc_*.npz; see tests/test_dxbc_golden.py and tools/make_dxbc_golden.py).
+This is the product checked against the reference itself, with no oracle in between."""
+import os
+
+import numpy as np
+import pytest
+
+import fluidx12_amd as fx
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SIM = np.load(os.path.join(GOLD, "dxbc_sim.npz"))
+REN = np.load(os.path.join(GOLD, "dxbc_render.npz"))
+SH = np.load(os.path.join(GOLD, "dxbc_sh.npz"))
+f32 = np.float32
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    n = np.sqrt((b ** 2).sum())
+    return np.sqrt(((a - b) ** 2).sum()) / (n if n > 0 else 1.0)
+
+
+def make(dims, **kw):
+    f = fx.Fluid()
+    assert f.Init(640, 480, dims, **kw), f.last_status
+    return f
+
+
+@pytest.mark.parametrize("tag,dims", [("3d", (16, 16, 8)), ("2d", (16, 16, 1))])
+@pytest.mark.parametrize("fmt", ["f32", "f16"])
+@pytest.mark.parametrize("address", ["clamp", "mirror"])
+def test_advect_vs_reference_binary(tag, dims, fmt, address):
+    k = "advect_%s_%s_%s" % (tag, fmt, address)
+    f = make(dims, storage="fp16" if fmt == "f16" else "fp32", advect_address=address)
+    f.upload(fx.FIELD_VELOCITY, SIM[k + "_vel_in"])
+    f.upload(fx.FIELD_COLOR, SIM[k + "_col_in"])
+    f.UpdateFrame(f32(f.default_time_step()), 0)
+    f.Advect()
+    f.Synchronize()
+    gv, gc = f.download(fx.FIELD_VELOCITY1), f.download(fx.FIELD_COLOR)
+    # one exp2 per voxel (device v_exp_f32 vs correctly rounded): everything else is bit-exact
+    assert rel_l2(gv, SIM[k + "_vel_out"]) < 1e-6 and rel_l2(gc, SIM[k + "_col_out"]) < 1e-6
+    assert np.mean(gv != SIM[k + "_vel_out"]) < 2e-3 and np.mean(gc != SIM[k + "_col_out"]) < 2e-3
+
+
+@pytest.mark.parametrize("tag,dims", [("3d", (16, 16, 8)), ("2d", (16, 16, 1))])
+@pytest.mark.parametrize("fmt", ["f32", "f16"])
+def test_project_vs_reference_binary(tag, dims, fmt):
+    """CSProject3D/2D.cso (lock-step schedule) == divergence + faithful 64-sweep Jacobi + projection kernels, bit-exact"""
+    k = "project_%s_%s" % (tag, fmt)
+    f = make(dims, storage="fp16" if fmt == "f16" else "fp32", jacobi_iters=64, jacobi_mode="faithful")
+    f.upload(fx.FIELD_VELOCITY1, SIM[k + "_vel_in"])
+    f.upload(fx.FIELD_PRESSURE, SIM[k + "_p_in"])
+    f.UpdateFrame(f32(f.default_time_step()), 0)
+    f.Divergence()
+    f.Jacobi(64)
+    f.Project()
+    f.Synchronize()
+    assert np.array_equal(f.download(fx.FIELD_PRESSURE), SIM[k + "_p_out"])
+    assert np.array_equal(f.download(fx.FIELD_VELOCITY), SIM[k + "_vel_out"])
+
+
+@pytest.mark.parametrize("tag,dims,address", [("3d", (16, 16, 16), "mirror"), ("3d_ez", (16, 16, 16), "clamp"), ("2d", (32, 32, 1), "clamp")])
+def test_rollout_vs_reference_binaries(tag, dims, address):
+    """4 frames in the reference's own configuration: RGBA16F fields, ITER 64 + early-out, Fluid (MIRROR) / FluidEZ (CLAMP)"""
+    f = make(dims, storage="fp16", jacobi_iters=64, jacobi_mode="faithful", advect_address=address)
+    for st in range(1, 5):
+        f.UpdateFrame(f32(f.default_time_step()), (st - 1) % 3)
+        f.Simulate((st - 1) % 3)
+        f.Synchronize()
+        for field, key in ((fx.FIELD_VELOCITY, "vel"), (fx.FIELD_COLOR, "col"), (fx.FIELD_PRESSURE, "p")):
+            got, ref = f.download(field), SIM["rollout_%s_step%d_%s" % (tag, st, key)]
+            assert rel_l2(got, ref) < 1e-4, (st, key)                  # north_star tolerance
+            assert np.mean(got != ref) < 5e-3, (st, key)               # in practice (almost) every value is identical
+
+
+@pytest.mark.parametrize("has_sh", [0, 1])
+def test_ray_march_vs_reference_binaries(has_sh):
+    X, S, nl, ns, nml, mask, vw, vh = (int(v) for v in REN["params"])
+    col = REN["color"]
+    f = make((X, X, X), storage="fp16")                                # the golden volume is RGBA16F-exact
+    view, proj, eye = fx.default_camera(vw, vh)
+    f.upload(fx.FIELD_COLOR, col)
+    if has_sh:
+        f.SetSH(REN["sh"])
+
+    def cube_close(got, ref):
+        d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 0.01, (int(d.max()), float((d > 0).mean()))
+
+    f.SetMaxSamples(ns, nl)
+    f.UpdateFrame(0.0, 0, view, proj, eye)
+    fi = f.frame_info()
+    assert (fi.cube_lod, fi.ray_samples, fi.visibility_mask, fi.cube_size) == (0, ns, mask, S)
+    f.Render(0, fx.Fluid.OPTIMIZED)
+    f.Synchronize()
+    lm, ref = f.download(fx.FIELD_LIGHTMAP), REN["lightmap_sh%d" % has_sh]
+    assert np.mean(lm != ref) < 2e-3 and np.abs(lm - ref).max() <= np.abs(ref).max() * 2.0 ** -5     # CSRayMarchL.cso
+    cube_close(f.download(fx.FIELD_CUBEMAP), REN["cube_separate_sh%d" % has_sh])                     # CSRayMarchV.cso
+    f.SetMaxSamples(ns, nml)
+    f.UpdateFrame(0.0, 0, view, proj, eye)
+    f.Render(0, fx.Fluid.RAY_MARCH_CUBEMAP)
+    f.Synchronize()
+    cube_close(f.download(fx.FIELD_CUBEMAP), REN["cube_merged_sh%d" % has_sh])                       # CSRayMarch.cso
+
+
+def test_sh_transform_vs_reference_binaries():
+    f = make((16, 16, 16))
+    lp = fx.LightProbe(f)
+    assert lp.Init(SH["cube"])
+    lp.TransformSH()
+    assert np.allclose(lp.GetSH(), SH["sh"], rtol=1e-5, atol=1e-6)

@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Golden vectors from the reference's OWN shipped shader binaries.
+
+Runs /root/reference/Bin/CS*.cso (the DXBC the reference executes) in the lock-step interpreter
+tools/dxbc_interp.py on small seeded inputs and writes inputs + outputs to tests/golden/dxbc_*.npz.
+Only runs in the authoring container (needs /root/reference); the fixtures are data (arrays in / arrays out).
+
+    python tools/make_dxbc_golden.py            # regenerates every fixture (about a minute)
+
+Resource bindings and constant-buffer layouts follow the reference's host code: Fluid.cpp:12-33 (CB structs),
+:729-770 (SRV/UAV pairing), :825-908 (root constants of the three ray-march dispatches), LightProbeEZ.cpp:183-278.
+Nothing in here calls the oracle or the HIP library.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import dxbc_interp as di  # noqa: E402
+
+BIN = "/root/reference/Bin"
+OUT = os.path.join(ROOT, "tests", "golden")
+F32 = np.float32
+U32 = np.uint32
+
+
+def cb_floats(rows):
+    a = np.zeros((len(rows), 4), F32)
+    for i, r in enumerate(rows):
+        a[i, :len(r)] = r
+    return a.view(U32)
+
+
+def divup(a, b):
+    return (a + b - 1) // b
+
+
+# ---------------------------------------------------------------------------------------------------------
+# simulation
+# ---------------------------------------------------------------------------------------------------------
+def run_advect(vel, col, dt, address, fmt):
+    """vel (3,Z,Y,X), col (Z,Y,X,4) -> (vel_out, col_out) through CSAdvect.cso (dispatch Fluid.cpp:374)"""
+    _, Z, Y, X = vel.shape
+    tv = di.Texture(np.moveaxis(vel, 0, -1), fmt)                 # Texture3D<float3> view of the RGBA16F texture
+    tc = di.Texture(col, fmt)
+    uv = di.Texture(np.zeros((Z, Y, X, 3), F32), fmt)
+    uc = di.Texture(np.zeros((Z, Y, X, 4), F32), fmt)
+    cb = {0: np.array([[np.float32(dt).view(U32), 12345, 0, 0]], U32)}    # CBSimulation {TimeStep, BaseSeed}
+    di.run_shader(os.path.join(BIN, "CSAdvect.cso"), (divup(X, 8), divup(Y, 8), Z),
+                  {"t0": tv, "t1": tc, "u0": uv, "u1": uc}, cb, {"s0": di.Sampler(address)})
+    return np.moveaxis(uv.data, -1, 0).copy(), uc.data.copy()
+
+
+def run_project(vel1, p, dt, fmt):
+    """vel1 (3,Z,Y,X), pressure (Z,Y,X) -> (vel0, pressure) through CSProject3D/2D.cso (Fluid.cpp:394-408)"""
+    _, Z, Y, X = vel1.shape
+    tv = di.Texture(np.moveaxis(vel1, 0, -1), fmt)
+    uv = di.Texture(np.zeros((Z, Y, X, 3), F32), fmt)
+    up = di.Texture(p[..., None].copy(), "R32_FLOAT")
+    cb = {0: np.array([[np.float32(dt).view(U32), 0, 0, 0]], U32)}
+    if Z > 1:
+        m = di.run_shader(os.path.join(BIN, "CSProject3D.cso"), (divup(X, 4), divup(Y, 4), divup(Z, 4)),
+                          {"t0": tv, "u0": uv, "u1": up}, cb)
+    else:
+        m = di.run_shader(os.path.join(BIN, "CSProject2D.cso"), (divup(X, 8), divup(Y, 8), Z),
+                          {"t0": tv, "u0": uv, "u1": up}, cb)
+    return np.moveaxis(uv.data, -1, 0).copy(), up.data[..., 0].copy(), m.executed
+
+
+def rand_state(X, Y, Z, seed, scale):
+    rng = np.random.default_rng(seed)
+    vel = (rng.standard_normal((3, Z, Y, X)) * scale).astype(F32)
+    col = rng.random((Z, Y, X, 4)).astype(F32)
+    p = (rng.standard_normal((Z, Y, X)) * 0.05).astype(F32)
+    return vel, col, p
+
+
+def make_sim():
+    out = {}
+    for tag, dims in (("3d", (16, 16, 8)), ("2d", (16, 16, 1))):
+        X, Y, Z = dims
+        dt = F32((2.0 if Z > 1 else 1.0) / Y)
+        for fmt_tag, fmt in (("f32", "R32G32B32A32_FLOAT"), ("f16", "R16G16B16A16_FLOAT")):
+            vel, col, p = rand_state(X, Y, Z, 101, 1.2)
+            if fmt_tag == "f16":
+                vel, col = di.half_round(vel), di.half_round(col)
+            for address in ("CLAMP", "MIRROR"):
+                vo, co = run_advect(vel, col, dt, address, fmt)
+                k = "advect_%s_%s_%s" % (tag, fmt_tag, address.lower())
+                out[k + "_vel_in"], out[k + "_col_in"], out[k + "_vel_out"], out[k + "_col_out"] = vel, col, vo, co
+            v0, pp, n = run_project(vel, p, dt, fmt)
+            k = "project_%s_%s" % (tag, fmt_tag)
+            out[k + "_vel_in"], out[k + "_p_in"], out[k + "_vel_out"], out[k + "_p_out"] = vel, p, v0, pp
+            print(k, "instructions executed:", n)
+    # dt = 0: the projection block is skipped (CSProject3D.hlsl:88)
+    vel, col, p = rand_state(16, 16, 8, 102, 0.5)
+    v0, pp, _ = run_project(vel, p, 0.0, "R32G32B32A32_FLOAT")
+    out["project_3d_paused_vel_in"], out["project_3d_paused_p_in"] = vel, p
+    out["project_3d_paused_vel_out"], out["project_3d_paused_p_out"] = v0, pp
+
+    # ---- 4-step rollout from the zero state with the reference's own formats (RGBA16F fields, R32F pressure,
+    #      ITER 64 + early-out) and host sequencing (Fluid.cpp:345,360-384): advect vel0->vel1, colour[!p]->colour[p];
+    #      project vel1->vel0, pressure in place
+    for tag, dims, address in (("3d", (16, 16, 16), "MIRROR"), ("3d_ez", (16, 16, 16), "CLAMP"), ("2d", (32, 32, 1), "CLAMP")):
+        X, Y, Z = dims
+        dt = F32((2.0 if Z > 1 else 1.0) / Y)
+        vel0 = np.zeros((3, Z, Y, X), F32)
+        cols = [np.zeros((Z, Y, X, 4), F32), np.zeros((Z, Y, X, 4), F32)]
+        p = np.zeros((Z, Y, X), F32)
+        parity = 0
+        for step in range(4):
+            parity ^= 1
+            vel1, cols[parity] = run_advect(vel0, cols[1 - parity], dt, address, "R16G16B16A16_FLOAT")
+            vel0, p, _ = run_project(vel1, p, dt, "R16G16B16A16_FLOAT")
+            out["rollout_%s_step%d_vel" % (tag, step + 1)] = vel0
+            out["rollout_%s_step%d_col" % (tag, step + 1)] = cols[parity]
+            out["rollout_%s_step%d_p" % (tag, step + 1)] = p
+        print("rollout", tag, "max|u|", float(np.abs(vel0).max()), "sum alpha", float(cols[parity][..., 3].sum()))
+    np.savez_compressed(os.path.join(OUT, "dxbc_sim.npz"), **out)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# ray march
+# ---------------------------------------------------------------------------------------------------------
+def frame_constants(X, vw, vh):
+    """what Fluid::UpdateFrame writes (Fluid.cpp:296-334) for the demo's default camera (FluidX12.cpp:243-253),
+    in float64 numpy then rounded -- these are INPUTS of the golden vectors and are stored with them."""
+    eye = np.array([4.0, 16.0, -40.0])
+    z = -eye / np.linalg.norm(eye)
+    x = np.cross([0, 1.0, 0], z); x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    view = np.eye(4); view[:3, 0], view[:3, 1], view[:3, 2] = x, y, z
+    view[3, :3] = [-x @ eye, -y @ eye, -z @ eye]
+    h = 1.0 / np.tan(np.pi / 8); w = h / (vw / vh); q = 1000.0 / 999.0
+    proj = np.zeros((4, 4)); proj[0, 0], proj[1, 1], proj[2, 2], proj[2, 3], proj[3, 2] = w, h, q, 1.0, -q
+    world = np.diag([10.0, 10.0, 10.0, 1.0])
+    wvp = world @ view @ proj
+    rows = np.zeros((14, 4))
+    rows[0:4] = np.linalg.inv(wvp).T
+    rows[4:8] = wvp.T
+    rows[8:11] = np.linalg.inv(world).T[:3]
+    rows[11:14] = world.T[:3]
+    cb0 = rows.astype(F32)
+    pi = np.float32(3.141592654)
+    cb1 = np.array([[4, 16, -40, 1], [75, 75, -75, 1], [1, .7, .3, pi * F32(3)], [1, 1, 1, pi * F32(1.5)]], F32)
+    return cb0, cb1
+
+
+def smoke_volume(X, seed):
+    rng = np.random.default_rng(seed)
+    z, y, x = np.meshgrid(*(np.arange(X),) * 3, indexing="ij")
+    blob = np.exp(-(((x - X * .55) ** 2 + (y - X * .45) ** 2 + (z - X * .5) ** 2) / (X * .28) ** 2))
+    col = (blob[..., None] * (0.35 + 0.65 * rng.random((X, X, X, 4))) * np.array([.4, .6, .9, .8])).astype(F32)
+    col[col[..., 3] < 0.02] = 0
+    return di.half_round(col)
+
+
+def make_render():
+    out = {}
+    X, S = 16, 16
+    cb0, cb1 = frame_constants(X, 640, 480)
+    col = smoke_volume(X, 7)
+    sh = (np.random.default_rng(8).random((9, 3)) * np.array([[2.0]] + [[0.6]] * 8)).astype(F32)
+    out["color"], out["cb_per_object"], out["cb_per_frame"], out["sh"] = col, cb0, cb1, sh
+    mask = 0x1B
+    for has_sh in (0, 1):
+        # light pass (Fluid.cpp:857-878): cb2 = {maxLightSamples, hasSH}
+        nl = 16
+        lm = di.Texture(np.zeros((X, X, X, 3), F32), "R11G11B10_FLOAT")
+        di.run_shader(os.path.join(BIN, "CSRayMarchL.cso"), (X // 4, X // 4, X // 4),
+                      {"t0": di.Texture(col), "t1": di.Structured(9, 12, sh), "u0": lm},
+                      {0: cb0.view(U32), 1: cb1.view(U32), 2: np.array([[nl, has_sh, 0, 0]], U32)}, {"s0": di.Sampler("CLAMP")})
+        out["lightmap_sh%d" % has_sh] = lm.data.copy()
+        # view pass with the light map (Fluid.cpp:880-908): cb2 = {raySampleCount}, cb3 = mask
+        ns = 24
+        cube = di.Texture(np.zeros((6, S, S, 4), F32), "R8G8B8A8_UNORM")
+        di.run_shader(os.path.join(BIN, "CSRayMarchV.cso"), (S // 8, S // 8, 6),
+                      {"t0": di.Texture(col), "t1": di.Texture(lm.data), "u0": cube},
+                      {0: cb0.view(U32), 1: cb1.view(U32), 2: np.array([[ns, 0, 0, 0]], U32), 3: np.array([[mask, 0, 0, 0]], U32)},
+                      {"s0": di.Sampler("CLAMP")})
+        out["cube_separate_sh%d" % has_sh] = np.rint(cube.data * 255).astype(np.uint8)
+        # merged march (Fluid.cpp:825-855): cb2 = {raySampleCount, hasSH, maxLightSamples}
+        cube = di.Texture(np.zeros((6, S, S, 4), F32), "R8G8B8A8_UNORM")
+        di.run_shader(os.path.join(BIN, "CSRayMarch.cso"), (S // 8, S // 8, 6),
+                      {"t0": di.Texture(col), "t1": di.Structured(9, 12, sh), "u0": cube},
+                      {0: cb0.view(U32), 1: cb1.view(U32), 2: np.array([[ns, has_sh, 8, 0]], U32), 3: np.array([[mask, 0, 0, 0]], U32)},
+                      {"s0": di.Sampler("CLAMP")})
+        out["cube_merged_sh%d" % has_sh] = np.rint(cube.data * 255).astype(np.uint8)
+        print("render sh=%d: lightmap range %.3f..%.3f, cube alpha max %d" % (
+            has_sh, lm.data.min(), lm.data.max(), out["cube_separate_sh%d" % has_sh][..., 3].max()))
+    out["params"] = np.array([X, S, 16, 24, 8, mask, 640, 480], np.int64)     # grid, cube, light samples, view, merged light, mask, vp
+    np.savez_compressed(os.path.join(OUT, "dxbc_render.npz"), **out)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# spherical harmonics
+# ---------------------------------------------------------------------------------------------------------
+def make_sh():
+    out = {}
+    N, order = 16, 3
+    rng = np.random.default_rng(9)
+    cube = (rng.random((6, N, N, 3)) * np.array([1.0, 0.8, 0.6])).astype(F32)
+    total = 6 * N * N
+    groups = divup(total, 32)
+    sh0, w0 = di.Structured(groups * 9, 12), di.Structured(groups, 4)
+    sums = divup(groups, 32)
+    sh1, w1 = di.Structured(max(sums, 1) * 9 + 9, 12), di.Structured(max(sums, 1) + 1, 4)
+    di.run_shader(os.path.join(BIN, "CSSHCubeMap.cso"), (groups, 1, 1),
+                  {"t0": di.CubePoint(cube), "u0": sh0, "u1": w0}, {0: np.array([[order, N, 0, 0]], U32)}, {"s0": di.Sampler("WRAP")})
+    out["partials_sh"], out["partials_w"] = sh0.words.view(F32).copy(), w0.words.view(F32).copy()
+    S, W = [sh0, sh1], [w0, w1]
+    src, n = 0, groups
+    while n > 1:                                                       # LightProbeEZ.cpp:213-252 with the intended per-pass count
+        di.run_shader(os.path.join(BIN, "CSSHSum.cso"), (divup(n, 32), order * order, 1),
+                      {"t0": S[src], "t1": W[src], "u0": S[src ^ 1], "u1": W[src ^ 1]}, {0: np.array([[order, n, 0, 0]], U32)})
+        src ^= 1
+        n = divup(n, 32)
+    res = di.Structured(32, 12)
+    di.run_shader(os.path.join(BIN, "CSSHNormalize.cso"), (1, 1, 1), {"t0": S[src], "t1": W[src], "u0": res}, {})
+    out["cube"], out["sh"] = cube, res.words.view(F32)[:9].copy()
+    print("SH[0] =", out["sh"][0], " weight sum ->", float(W[src].words.view(F32)[0, 0]), "(4 pi = 12.566)")
+    np.savez_compressed(os.path.join(OUT, "dxbc_sh.npz"), **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["sim", "render", "sh"]
+    if "sim" in which:
+        make_sim()
+    if "render" in which:
+        make_render()
+    if "sh" in which:
+        make_sh()
