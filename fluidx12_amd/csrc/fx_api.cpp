@@ -22,7 +22,7 @@ namespace {
 
 const uint32_t kNumMips = 5;            // Fluid.cpp:229
 const uint32_t kDefaultAdvectHalo = 8;  // z back-trace reach <= 6 cells in practice
-const uint32_t kDefaultJacobiHalo = 4;
+const uint32_t kDefaultJacobiHalo = 8;   // sweeps per pressure exchange: 5 messages per 40 sweeps, +11% halo sweeps at 64 planes/rank
 
 hipStream_t pick_stream(fx_ctx* ctx, void* s) { return s ? (hipStream_t)s : ctx->stream; }
 
@@ -164,7 +164,7 @@ int jacobi_round(fx_ctx* ctx, hipStream_t s, int count, ScopedMark* mk)
 	while (done < count) {
 		const int left = count - done;
 		// planes still needed after this launch shrink by one per remaining sweep
-		const int fusedMax = ctx->frozen ? 1 : jacobi_fused_max_sweeps(ctx->g, (int)(ctx->desc.flags & FX_FLAG_JACOBI_FUSE_MASK));
+		const int fusedMax = ctx->frozen ? 1 : jacobi_fused_max_sweeps(ctx->g, (int)(ctx->desc.flags & FX_FLAG_JACOBI_FUSE_MASK), ctx->g.nz);
 		const int t = std::min(left, fusedMax);
 		const Range r = grown(ctx, ctx->nranks > 1 ? left - t : 0);
 		const float* src = ctx->p[ctx->p_cur];

@@ -54,8 +54,11 @@ hipError_t launch_jacobi_sweep(const Geom& g, const float* p_in, const float* b,
 // global boundary).  Returns hipErrorNotSupported when the geometry has no fused path.
 hipError_t launch_jacobi_fused(const Geom& g, const float* p_in, const float* b, float* p_out, int sweeps,
 	int z_begin, int z_end, hipStream_t s);
+// two or three sweeps per launch, register-resident strips (fx_jacobi_strip.hip)
+bool jacobi_strip_supported(const Geom& g);
+hipError_t launch_jacobi_strip(const Geom& g, const float* p_in, const float* b, float* p_out, int sweeps, int z_begin, int z_end, hipStream_t s);
 // sweeps fused per launch for this geometry (1 = no fused path); requested > 0 overrides the default
-int jacobi_fused_max_sweeps(const Geom& g, int requested);
+int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp);
 hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const float* p,
 	void* vel_out, int z_begin, int z_end, hipStream_t s);
 hipError_t launch_copy_velocity(const Geom& g, int half_store, const void* vel_in, void* vel_out, hipStream_t s);

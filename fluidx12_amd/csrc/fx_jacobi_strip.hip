@@ -1,0 +1,187 @@
+// fx_jacobi_strip.hip -- two lock-step Jacobi sweeps per launch, register-resident ("strip" kernel).
+//
+// Restates CSPoisson.hlsli:8-26 (/root/reference/FluidX12/Content/Shaders/) like k_jacobi_v4, two sweeps
+// at a time.  Design for CDNA4's 512-VGPR waves rather than for LDS:
+//   * one wave64 = one strip of R consecutive full-x rows (thread = 4 x-cells x R rows); it streams along z and
+//     keeps a 3-plane window of the input (R+4 rows: a 2-row halo on each side) and of the first sweep's result
+//     (R+2 rows) in registers -- about 330 VGPRs, one wave per SIMD;
+//   * the halo rows are recomputed, not exchanged: no LDS, no barrier, every wave is independent;
+//   * x neighbours come from wave shuffles, y neighbours from the thread's own registers, z neighbours from the
+//     register window; p and b are read once (halo rows hit L2) and p'' is written once per TWO sweeps, so the
+//     HBM / Infinity-Cache traffic per sweep is roughly halved.
+// Per-cell arithmetic and association order are those of k_jacobi_v4: results are bit-identical to two single
+// sweeps (tests/test_gpu_sim.py).
+#include "fx_internal.h"
+#include <cstdlib>
+
+namespace fx {
+
+namespace {
+
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// one Jacobi update of a float4 column: ((((((L - b) + R) + U) + D) + F) + B) * (1/6)
+__device__ __forceinline__ float4 relax4(float4 c, float4 U, float4 D, float4 F, float4 Bk, float4 bb, bool x_first, bool x_last)
+{
+	float L = __shfl_up(c.w, 1), Rr = __shfl_down(c.x, 1);
+	if (x_first) L = c.x;
+	if (x_last) Rr = c.w;
+	const float4 Lv = make_float4(L, c.x, c.y, c.z), Rv = make_float4(c.y, c.z, c.w, Rr);
+	float4 x = add4(add4(add4(add4(add4(sub4(Lv, bb), Rv), U), D), F), Bk);
+	const float inv = __uint_as_float(0x3e2aaaabu);
+	x.x *= inv; x.y *= inv; x.z *= inv; x.w *= inv;
+	return x;
+}
+
+// same XCD-aware tile order as fx_sim.hip (see xcd_tile there)
+__device__ __forceinline__ int xcd_index(int n, int remap)
+{
+	int t = (int)blockIdx.x;
+	if (remap) {
+		const int q = n >> 3, r = n & 7;
+		const int xcd = t & 7, j = t >> 3;
+		t = xcd * q + min(xcd, r) + j;
+	}
+	return t;
+}
+
+// T sweeps per launch, R output rows per strip.  Level l (0 = input, T = output) carries R + 2(T - l) rows; row i of
+// level l is global row y0 - (T - l) + i, i.e. row i + 1 of level l - 1.
+template <int T, int R>
+__global__ __launch_bounds__(256, 1) void k_jacobi_strip(const Geom g, const float* __restrict__ p_in,
+	const float* __restrict__ b, float* __restrict__ p_out, int z_begin, int z_end, int zchunk, int ngroups, int nchunks, int remap)
+{
+	constexpr int NR0 = R + 2 * T;                   // input rows per strip
+	constexpr int NRB = R + 2 * (T - 1);             // rows of b the first sweep needs
+	const int LX = g.X >> 2;                         // lanes per row
+	const int SPW = 64 / LX;                         // strips per wave (1 at X = 256)
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int lx = lane % LX, sub = lane / LX;
+	const int tile = xcd_index(ngroups * nchunks, remap);
+	const int grp = tile % ngroups, chunk = tile / ngroups;
+	const int strip = (grp * 4 + wave) * SPW + sub;
+	const int y0 = strip * R;
+	const int zb = z_begin + chunk * zchunk, ze = min(zb + zchunk, z_end);
+	const int qs = max(zb - T, g.zlo), q_last = ze - 1 + T, q_load_last = min(q_last, g.zhi);
+	const bool x_first = lx == 0, x_last = lx == LX - 1;
+	const size_t plane = g.plane();
+
+	size_t roff[NR0];                                // clamped row offsets (clamp = the clamp-to-edge stencil of the input level)
+#pragma unroll
+	for (int i = 0; i < NR0; ++i) roff[i] = (size_t)min(max(y0 - T + i, 0), g.Y - 1) * g.X + 4 * lx;
+
+	const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	float4 P[T][3][NR0];                             // level l uses the first R + 2(T - l) rows; the rest is never touched
+	float4 Bq[T + 1][NRB];                           // Bq[k] = b of plane q - k, rows y0 - (T-1) ...
+	float4 NP[NR0], NB[NRB];
+#pragma unroll
+	for (int l = 0; l < T; ++l)
+#pragma unroll
+		for (int k = 0; k < 3; ++k)
+#pragma unroll
+			for (int i = 0; i < NR0; ++i) P[l][k][i] = zero;
+#pragma unroll
+	for (int k = 0; k <= T; ++k)
+#pragma unroll
+		for (int i = 0; i < NRB; ++i) Bq[k][i] = zero;
+#pragma unroll
+	for (int i = 0; i < NR0; ++i) NP[i] = zero;
+#pragma unroll
+	for (int i = 0; i < NRB; ++i) NB[i] = zero;
+
+	if (qs <= q_load_last) {
+		const size_t zo = (size_t)g.lz(qs) * plane;
+#pragma unroll
+		for (int i = 0; i < NR0; ++i) NP[i] = *reinterpret_cast<const float4*>(p_in + zo + roff[i]);
+#pragma unroll
+		for (int i = 0; i < NRB; ++i) NB[i] = *reinterpret_cast<const float4*>(b + zo + roff[i + 1]);
+	}
+
+	for (int q = qs; q <= q_last; ++q) {
+		// ---- take input plane q, rotate the input window and the b delay line ----------------------------------------
+#pragma unroll
+		for (int i = 0; i < NR0; ++i) { P[0][0][i] = P[0][1][i]; P[0][1][i] = P[0][2][i]; P[0][2][i] = NP[i]; }
+#pragma unroll
+		for (int k = T; k >= 1; --k)
+#pragma unroll
+			for (int i = 0; i < NRB; ++i) Bq[k][i] = Bq[k - 1][i];
+#pragma unroll
+		for (int i = 0; i < NRB; ++i) Bq[0][i] = NB[i];
+		if (q + 1 <= q_load_last) {                 // prefetch plane q+1 (one whole z-step of latency cover)
+			const size_t zo = (size_t)g.lz(q + 1) * plane;
+#pragma unroll
+			for (int i = 0; i < NR0; ++i) NP[i] = *reinterpret_cast<const float4*>(p_in + zo + roff[i]);
+#pragma unroll
+			for (int i = 0; i < NRB; ++i) NB[i] = *reinterpret_cast<const float4*>(b + zo + roff[i + 1]);
+		}
+
+		// ---- sweep s produces level s, plane q - s, from level s - 1 (planes q-s-1, q-s, q-s+1) ---------------------------
+#pragma unroll
+		for (int sw = 1; sw <= T; ++sw) {
+			constexpr int dummy = 0; (void)dummy;
+			const int m = q - sw;
+			const bool m_first = m == 0, m_last = m == g.Zg - 1;
+			const bool store_plane = sw == T && m >= zb && m < ze;
+			const size_t zo2 = store_plane ? (size_t)g.lz(m) * plane : 0;
+			const int nr = R + 2 * (T - sw);
+			if (sw < T) {
+#pragma unroll
+				for (int i = 0; i < NR0; ++i)
+					if (i < nr) { P[sw < T ? sw : 0][0][i] = P[sw < T ? sw : 0][1][i]; P[sw < T ? sw : 0][1][i] = P[sw < T ? sw : 0][2][i]; }
+			}
+#pragma unroll
+			for (int i = 0; i < NR0; ++i) {
+				if (i < nr) {
+					const int y = y0 - (T - sw) + i;
+					const float4 c = P[sw - 1][1][i + 1];
+					const float4 U = y <= 0 ? c : P[sw - 1][1][i];            // rows outside the domain never hold data
+					const float4 D = y >= g.Y - 1 ? c : P[sw - 1][1][i + 2];
+					const float4 x = relax4(c, U, D, m_first ? c : P[sw - 1][0][i + 1], m_last ? c : P[sw - 1][2][i + 1],
+						Bq[sw][i + sw - 1], x_first, x_last);
+					if (sw < T) P[sw < T ? sw : 0][2][i] = x;
+					else if (store_plane && y < g.Y) *reinterpret_cast<float4*>(p_out + zo2 + (size_t)y * g.X + 4 * lx) = x;
+				}
+			}
+		}
+	}
+}
+
+int env_i(const char* n, int d) { const char* v = getenv(n); return v && *v ? atoi(v) : d; }
+
+}  // namespace
+
+bool jacobi_strip_supported(const Geom& g)
+{
+	const int LX = g.X >> 2;
+	return g.Zg > 1 && (g.X & 3) == 0 && (LX == 16 || LX == 32 || LX == 64) && g.Y >= 8;
+}
+
+hipError_t launch_jacobi_strip(const Geom& g, const float* p_in, const float* b, float* p_out, int sweeps, int z_begin, int z_end, hipStream_t s)
+{
+	if (z_end <= z_begin) return hipSuccess;
+	if (!jacobi_strip_supported(g)) return hipErrorNotSupported;
+	static const int forced_chunk = env_i("FLUIDX_STRIP_ZCHUNK", 0);   // measurement knobs
+	static const int remap = env_i("FLUIDX_STRIP_REMAP", 1);
+	static const int Rsel = env_i("FLUIDX_STRIP_R", 0);
+	const int rows = Rsel == 2 || Rsel == 4 ? Rsel : (sweeps == 3 ? 2 : 4);
+	const int R = rows;
+	const int LX = g.X >> 2, SPW = 64 / LX;
+	const int nstrips = (g.Y + R - 1) / R;
+	const int ngroups = (nstrips + 4 * SPW - 1) / (4 * SPW);            // 4 waves per workgroup
+	const int nzp = z_end - z_begin;
+	int nchunks = (256 + ngroups - 1) / ngroups;                        // one workgroup (= 1 wave per SIMD) per CU
+	int zchunk = forced_chunk > 0 ? forced_chunk : (nzp + nchunks - 1) / nchunks;
+	if (zchunk < 8) zchunk = 8;
+	if (zchunk > nzp) zchunk = nzp;
+	nchunks = (nzp + zchunk - 1) / zchunk;
+	const dim3 grid(ngroups * nchunks), block(256);
+#define FX_STRIP(T_, R_) hipLaunchKernelGGL((k_jacobi_strip<T_, R_>), grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap)
+	if (sweeps == 2) { if (R == 2) FX_STRIP(2, 2); else FX_STRIP(2, 4); }
+	else if (sweeps == 3) { if (R == 4) FX_STRIP(3, 4); else FX_STRIP(3, 2); }
+	else return hipErrorNotSupported;
+#undef FX_STRIP
+	return hipGetLastError();
+}
+
+}  // namespace fx

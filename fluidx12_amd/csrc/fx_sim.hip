@@ -547,13 +547,25 @@ static bool tb_supported(const Geom& g)
 	return g.Zg > 1 && (g.X & 3) == 0 && (LX == 16 || LX == 32 || LX == 64) && g.Y >= 16;
 }
 
-int jacobi_fused_max_sweeps(const Geom& g, int requested)
+// the strip kernel needs ~256 workgroups of >= 16 planes each to beat the one-sweep kernel: measured on MI355X,
+// 256^3 wins (20 vs 30 us/sweep) while 128^3 and the 256x256x{32,64} slabs lose (profiles/r01c_jacobi_strip.txt)
+static bool strip_profitable(const Geom& g, int nzp)
+{
+	if (!jacobi_strip_supported(g)) return false;
+	const int SPW = 64 / (g.X >> 2);
+	const int ngroups = ((g.Y + 3) / 4 + 4 * SPW - 1) / (4 * SPW);
+	const int nchunks = (256 + ngroups - 1) / ngroups;
+	return nzp / nchunks >= 16;
+}
+
+int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp)
 {
 	static const int forced = env_int("FLUIDX_JACOBI_T", 0);
 	if (!tb_supported(g)) return 1;
-	// default 1: on MI355X the one-sweep kernel (served from the 256 MB Infinity Cache at 256^3) beats every
-	// fused tile shape measured so far (profiles/r01_jacobi_tile_sweep.txt)
-	const int t = requested > 0 ? requested : (forced > 0 ? forced : 1);
+	// default: two sweeps per launch in the register-strip kernel (fx_jacobi_strip.hip) where the geometry allows it,
+	// else one sweep per launch; the LDS kernel k_jacobi_tb<T> lost to both in every shape measured
+	// (profiles/r01_jacobi_tile_sweep.txt)
+	const int t = requested > 0 ? requested : (forced > 0 ? forced : (strip_profitable(g, nzp) ? 2 : 1));
 	return t < 1 ? 1 : (t > 4 ? 4 : t);
 }
 
@@ -628,8 +640,16 @@ hipError_t launch_jacobi_fused(const Geom& g, const float* p_in, const float* b,
 	if (z_end <= z_begin) return hipSuccess;
 	if (!tb_supported(g)) return hipErrorNotSupported;
 	switch (sweeps) {
-	case 2: return launch_tb<2>(g, p_in, b, p_out, z_begin, z_end, s);
-	case 3: return launch_tb<3>(g, p_in, b, p_out, z_begin, z_end, s);
+	case 2: {
+		static const int use_tb = env_int("FLUIDX_FUSE2_TB", 0);      // 1 = the LDS kernel instead of the register strips
+		if (!use_tb && jacobi_strip_supported(g)) return launch_jacobi_strip(g, p_in, b, p_out, 2, z_begin, z_end, s);
+		return launch_tb<2>(g, p_in, b, p_out, z_begin, z_end, s);
+	}
+	case 3: {
+		static const int use_tb3 = env_int("FLUIDX_FUSE2_TB", 0);
+		if (!use_tb3 && jacobi_strip_supported(g)) return launch_jacobi_strip(g, p_in, b, p_out, 3, z_begin, z_end, s);
+		return launch_tb<3>(g, p_in, b, p_out, z_begin, z_end, s);
+	}
 	case 4: return launch_tb<4>(g, p_in, b, p_out, z_begin, z_end, s);
 	default: return hipErrorNotSupported;
 	}

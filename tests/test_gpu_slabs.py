@@ -91,6 +91,23 @@ def test_halo_overflow_is_reported():
     assert e.value.status == capi.FX_E_HALO
 
 
+def test_rccl_transport_single_rank():
+    """the RCCL transport on the one GPU we have: librccl is dlopen()ed, a unique id is created, ncclCommInitRank
+    succeeds for a 1-rank world and a step runs through the same phase code (no neighbour => no send/recv)"""
+    uid = fx.comm_unique_id()
+    assert len(uid) >= 128
+    dims = (32, 32, 32)
+    ref = run_single(dims, 2, jacobi_iters=8)
+    f = fx.Fluid()
+    assert f.Init(800, 800, dims, jacobi_iters=8)
+    f.comm_init_rank(uid, 0, 1)
+    for k in range(2):
+        f.UpdateFrame(f32(f.default_time_step()), k)
+        f.Simulate(k)
+    f.Synchronize()
+    assert np.array_equal(f.download(fx.FIELD_VELOCITY), ref.download(fx.FIELD_VELOCITY))
+
+
 def test_slab_descriptor_validation():
     f = fx.Fluid()
     assert f.Init(800, 800, (32, 32, 32), slab=(0, 4), halo_advect=8) is False     # halo wider than the slab

@@ -25,8 +25,8 @@ WIDE = {"k_jacobi_v4": True, "k_jacobi_tb": True, "k_advect": True, "k_divergenc
 
 
 def short(name):
-    n = name.split("(")[0].replace("void ", "")
-    n = n.split("<")[0]
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    n = n.split("(")[0].split("<")[0]
     return n.split("::")[-1]
 
 
@@ -53,9 +53,9 @@ def main():
     for k in sorted(set(f) | set(w)):
         fr = sum(f[k]) / max(len(f[k]), 1) * 1024.0
         wr = sum(w[k]) / max(len(w[k]), 1) * 1024.0
-        fc = fr * (2.0 if WIDE.get(k, False) else 1.0)
+        fc = fr * (2.0 if WIDE.get(k, True) else 1.0)
         out["kernels"][k] = {"dispatches": len(f[k]), "fetch_raw": fr, "fetch_corrected": fc, "write": wr, "traffic": fc + wr,
-                             "wide_loads": bool(WIDE.get(k, False))}
+                             "wide_loads": bool(WIDE.get(k, True))}
     print(json.dumps(out, indent=1))
 
 
