@@ -21,10 +21,19 @@ namespace fx {
 typedef _Float16 h16;
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
+// two x-adjacent texels of one plane in ONE load (4-byte / 2-byte aligned: global memory allows it on gfx950)
+struct __attribute__((packed, aligned(4))) F32Pair { float a, b; };
+struct __attribute__((packed, aligned(2))) F16Pair { _Float16 a, b; };
+
 template <bool HALF> struct Store;
 template <> struct Store<false> {
 	typedef float S;
 	typedef float4 S4;
+	static __device__ __forceinline__ void ld2(const S* p, size_t i, float& a, float& b)
+	{
+		const F32Pair v = *reinterpret_cast<const F32Pair*>(p + i);
+		a = v.a; b = v.b;
+	}
 	static __device__ __forceinline__ float ld(const S* p, size_t i) { return p[i]; }
 	static __device__ __forceinline__ void st(S* p, size_t i, float v) { p[i] = v; }
 	static __device__ __forceinline__ float4 ld4(const S4* p, size_t i) { return p[i]; }
@@ -33,6 +42,11 @@ template <> struct Store<false> {
 template <> struct Store<true> {
 	typedef h16 S;
 	typedef h16x4 S4;
+	static __device__ __forceinline__ void ld2(const S* p, size_t i, float& a, float& b)
+	{
+		const F16Pair v = *reinterpret_cast<const F16Pair*>(p + i);
+		a = (float)v.a; b = (float)v.b;
+	}
 	static __device__ __forceinline__ float ld(const S* p, size_t i) { return (float)p[i]; }
 	static __device__ __forceinline__ void st(S* p, size_t i, float v) { p[i] = (h16)v; }   // RNE
 	static __device__ __forceinline__ float4 ld4(const S4* p, size_t i)
@@ -57,16 +71,28 @@ __device__ __forceinline__ float saturatef(float x) { return fminf(fmaxf(x, 0.0f
 // L2s.  Here XCD k instead walks the k-th contiguous eighth of the tile sequence (tiles ordered x, then y,
 // then z): its halo traffic shrinks to the two ends of its z range.  Speed only, never correctness.
 struct Tile3 { int x, y, z; };
+// remap: 0 = natural order; 1 = XCD k walks the k-th contiguous eighth of the (x, y, z)-ordered tile sequence (a z range);
+// 2 = XCD k owns the k-th y-band of EVERY plane and walks it plane by plane (needs gy % 8 == 0, else natural order):
+// the per-XCD working set per plane is 1/8 plane, so z-neighbour planes stay in its L2 even when a plane of all fields
+// exceeds 4 MiB (advection: 1.75 MiB of velocity + colour per 256^2 plane).
 __device__ __forceinline__ Tile3 xcd_tile(int gx, int gy, int gz, int remap)
 {
 	const int n = gx * gy * gz;
 	int t = (int)blockIdx.x;
-	if (remap) {
+	Tile3 o;
+	if (remap == 2 && (gy & 7) == 0) {
+		const int band = gy >> 3, xcd = t & 7, j = t >> 3;
+		o.x = j % gx;
+		const int u = j / gx;
+		o.y = xcd * band + u % band;
+		o.z = u / band;
+		return o;
+	}
+	if (remap == 1) {
 		const int q = n >> 3, r = n & 7;
 		const int xcd = t & 7, j = t >> 3;
 		t = xcd * q + min(xcd, r) + j;
 	}
-	Tile3 o;
 	o.x = t % gx;
 	const int u = t / gx;
 	o.y = u % gy;
@@ -144,14 +170,33 @@ __global__ __launch_bounds__(256) void k_advect(const Geom g, const SimParams sp
 	const size_t r01 = (size_t)g.lz(z1) * plane + (size_t)y0 * g.X, r11 = (size_t)g.lz(z1) * plane + (size_t)y1 * g.X;
 
 	float u[3];
+	if (g.X >= 2) {
+		// the two x-taps of a row are adjacent (or equal, at a clamped/mirrored border): fetch them as one 8-byte
+		// (4-byte for fp16) load at xa = min(x0, x1) and select -- 12 gathers instead of 24 (the kernel is TA-issue bound)
+		const int xa = min(min(x0, x1), g.X - 2);
+		const bool lo0 = x0 == xa, lo1 = x1 == xa;
 #pragma unroll
-	for (int a = 0; a < 3; ++a) {                                            // :53
-		const typename St::S* f = vel_in + a * stride;
-		const float c00 = lerpf(St::ld(f, r00 + x0), St::ld(f, r00 + x1), fx);
-		const float c10 = lerpf(St::ld(f, r10 + x0), St::ld(f, r10 + x1), fx);
-		const float c01 = lerpf(St::ld(f, r01 + x0), St::ld(f, r01 + x1), fx);
-		const float c11 = lerpf(St::ld(f, r11 + x0), St::ld(f, r11 + x1), fx);
-		u[a] = lerpf(lerpf(c00, c10, fy), lerpf(c01, c11, fy), fz);
+		for (int a = 0; a < 3; ++a) {                                        // :53
+			const typename St::S* f = vel_in + a * stride;
+			float l00, h00, l10, h10, l01, h01, l11, h11;
+			St::ld2(f, r00 + xa, l00, h00); St::ld2(f, r10 + xa, l10, h10);
+			St::ld2(f, r01 + xa, l01, h01); St::ld2(f, r11 + xa, l11, h11);
+			const float c00 = lerpf(lo0 ? l00 : h00, lo1 ? l00 : h00, fx);
+			const float c10 = lerpf(lo0 ? l10 : h10, lo1 ? l10 : h10, fx);
+			const float c01 = lerpf(lo0 ? l01 : h01, lo1 ? l01 : h01, fx);
+			const float c11 = lerpf(lo0 ? l11 : h11, lo1 ? l11 : h11, fx);
+			u[a] = lerpf(lerpf(c00, c10, fy), lerpf(c01, c11, fy), fz);
+		}
+	} else {
+#pragma unroll
+		for (int a = 0; a < 3; ++a) {
+			const typename St::S* f = vel_in + a * stride;
+			const float c00 = lerpf(St::ld(f, r00 + x0), St::ld(f, r00 + x1), fx);
+			const float c10 = lerpf(St::ld(f, r10 + x0), St::ld(f, r10 + x1), fx);
+			const float c01 = lerpf(St::ld(f, r01 + x0), St::ld(f, r01 + x1), fx);
+			const float c11 = lerpf(St::ld(f, r11 + x0), St::ld(f, r11 + x1), fx);
+			u[a] = lerpf(lerpf(c00, c10, fy), lerpf(c01, c11, fy), fz);
+		}
 	}
 	float c[4];
 	{                                                                        // :54
@@ -470,17 +515,21 @@ __global__ __launch_bounds__(256) void k_from_storage(const typename Store<HALF>
 // launchers
 // ---------------------------------------------------------------------------------------------
 static inline dim3 grid_xyz(const Geom& g, int nzp) { return dim3(((g.X + 63) / 64) * ((g.Y + 3) / 4) * nzp, 1, 1); }
+static inline unsigned grid_1d(size_t n) { return (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
 static int env_int(const char* name, int dflt);
-// bit 0 Jacobi, bit 1 advect, bit 2 divergence, bit 3 project.  Default: Jacobi only -- measured on MI355X at
-// 256^3 (profiles/r01_xcd_remap.txt): Jacobi -11% time / -18% fetch; the gather-heavy advect and the short
-// divergence/project kernels got slower with it.  FLUIDX_XCD_REMAP overrides (measurement knob).
-enum { REMAP_JACOBI = 1, REMAP_ADVECT = 2, REMAP_DIV = 4, REMAP_PROJECT = 8 };
+enum { REMAP_JACOBI = 0, REMAP_ADVECT = 1, REMAP_DIV = 2, REMAP_PROJECT = 3 };
+// per-kernel mapping mode (see xcd_tile).  FLUIDX_XCD_REMAP="j,a,d,p" overrides (measurement knob).
 static int xcd_remap_on(int which)
 {
-	static const int mask = env_int("FLUIDX_XCD_REMAP", REMAP_JACOBI);
-	return (mask & which) ? 1 : 0;
+	static int mode[4] = { -1, 0, 0, 0 };
+	if (mode[0] < 0) {
+		mode[0] = 1; mode[1] = 0; mode[2] = 0; mode[3] = 0;   // measured: only the Jacobi sweeps gain (profiles/r01_xcd_remap.txt)
+		const char* e = getenv("FLUIDX_XCD_REMAP");
+		int a, b_, c, d;
+		if (e && sscanf(e, "%d,%d,%d,%d", &a, &b_, &c, &d) == 4) { mode[0] = a; mode[1] = b_; mode[2] = c; mode[3] = d; }
+	}
+	return mode[which];
 }
-static inline unsigned grid_1d(size_t n) { return (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
 
 hipError_t launch_advect(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const void* col_in,
 	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, hipStream_t s)
