@@ -147,6 +147,100 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip(const Geom g, const flo
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Two sweeps, tuned: the generic kernel above spends most of its VALU issue on rotating the register windows
+// (v_mov / v_accvgpr) and on per-use boundary selects (rocprofv3: SQ_ACTIVE_INST_VALU = 64 % of wave cycles, only a
+// quarter of it arithmetic).  Here the three window slots rotate by NAME (the z loop is unrolled by three, slot
+// indices are compile-time), and the z boundaries are handled by duplicating a plane into the neighbouring slot once,
+// under a wave-uniform branch, instead of a select at every use.  Needs Y % R == 0.
+// ---------------------------------------------------------------------------------------------------------------
+// one z step with the window slots named at compile time (expanded three times in the kernel: plain local arrays with
+// constant indices stay in registers; a struct passed by reference was demoted to scratch by the compiler)
+#define FX_STRIP2_STEP(PH) do { \
+	constexpr int NEW = (PH) % 3, CTR = ((PH) + 2) % 3, OLD = ((PH) + 1) % 3; \
+	_Pragma("unroll") for (int i = 0; i < R + 4; ++i) P0[NEW][i] = NP[i]; \
+	_Pragma("unroll") for (int i = 0; i < R + 2; ++i) Bq[NEW][i] = NB[i]; \
+	if (q == 0) {                                   /* plane -1 := plane 0 (clamped front neighbour), once */ \
+		_Pragma("unroll") for (int i = 0; i < R + 4; ++i) P0[CTR][i] = NP[i]; \
+	} \
+	if (q + 1 <= q_load_last) {                     /* prefetch plane q+1; past the last plane NP keeps plane zhi (clamped back) */ \
+		const size_t zo = (size_t)g.lz(q + 1) * plane; \
+		_Pragma("unroll") for (int i = 0; i < R + 4; ++i) NP[i] = *reinterpret_cast<const float4*>(p_in + zo + roff[i]); \
+		_Pragma("unroll") for (int i = 0; i < R + 2; ++i) NB[i] = *reinterpret_cast<const float4*>(b + zo + roff[i + 1]); \
+	} \
+	/* sweep 1: plane q-1, rows y0-1 .. y0+R; the clamped row loads already encode the y boundary */ \
+	if (q - 1 == g.Zg) {                            /* plane Zg := plane Zg-1 of the first sweep's result */ \
+		_Pragma("unroll") for (int i = 0; i < R + 2; ++i) P1[NEW][i] = P1[CTR][i]; \
+	} else { \
+		_Pragma("unroll") for (int i = 0; i < R + 2; ++i) \
+			P1[NEW][i] = relax4(P0[CTR][i + 1], P0[CTR][i], P0[CTR][i + 2], P0[OLD][i + 1], P0[NEW][i + 1], Bq[CTR][i], x_first, x_last); \
+		if (q - 1 == 0) { \
+			_Pragma("unroll") for (int i = 0; i < R + 2; ++i) P1[CTR][i] = P1[NEW][i]; \
+		} \
+	} \
+	/* sweep 2: plane q-2, rows y0 .. y0+R-1 */ \
+	if (q - 2 >= zb && q - 2 < ze) { \
+		const size_t zo2 = (size_t)g.lz(q - 2) * plane; \
+		_Pragma("unroll") for (int j = 0; j < R; ++j) { \
+			const float4 c = P1[CTR][j + 1]; \
+			float4 U = P1[CTR][j], D = P1[CTR][j + 2]; \
+			if (j == 0 && y0 == 0) U = c;                                /* rows outside the domain hold no data */ \
+			if (j == R - 1 && y0 + R >= g.Y) D = c; \
+			const float4 x = relax4(c, U, D, P1[OLD][j + 1], P1[NEW][j + 1], Bq[OLD][j + 1], x_first, x_last); \
+			if (strip_live) *reinterpret_cast<float4*>(p_out + zo2 + (size_t)(y0 + j) * g.X + 4 * lx) = x; \
+		} \
+	} \
+} while (0)
+
+template <int R>
+__global__ __launch_bounds__(256, 1) void k_jacobi_strip2u(const Geom g, const float* __restrict__ p_in,
+	const float* __restrict__ b, float* __restrict__ p_out, int z_begin, int z_end, int zchunk, int ngroups, int nchunks, int remap)
+{
+	const int LX = g.X >> 2, SPW = 64 / LX;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int lx = lane % LX, sub = lane / LX;
+	const int tile = xcd_index(ngroups * nchunks, remap);
+	const int grp = tile % ngroups, chunk = tile / ngroups;
+	const int strip = (grp * 4 + wave) * SPW + sub;
+	const int y0 = strip * R;
+	const bool strip_live = y0 < g.Y;
+	const int zb = z_begin + chunk * zchunk, ze = min(zb + zchunk, z_end);
+	const int qs = max(zb - 2, g.zlo), q_last = ze - 1 + 2, q_load_last = min(q_last, g.zhi);
+	const bool x_first = lx == 0, x_last = lx == LX - 1;
+	const size_t plane = g.plane();
+
+	size_t roff[R + 4];
+#pragma unroll
+	for (int i = 0; i < R + 4; ++i) roff[i] = (size_t)min(max(y0 - 2 + i, 0), g.Y - 1) * g.X + 4 * lx;
+
+	float4 P0[3][R + 4], P1[3][R + 2], Bq[3][R + 2], NP[R + 4], NB[R + 2];
+	const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+#pragma unroll
+		for (int i = 0; i < R + 4; ++i) P0[k][i] = zero;
+#pragma unroll
+		for (int i = 0; i < R + 2; ++i) { P1[k][i] = zero; Bq[k][i] = zero; }
+	}
+	{
+		const size_t zo = (size_t)g.lz(min(qs, q_load_last)) * plane;
+#pragma unroll
+		for (int i = 0; i < R + 4; ++i) NP[i] = *reinterpret_cast<const float4*>(p_in + zo + roff[i]);
+#pragma unroll
+		for (int i = 0; i < R + 2; ++i) NB[i] = *reinterpret_cast<const float4*>(b + zo + roff[i + 1]);
+	}
+	int q = qs;
+	for (;;) {
+		FX_STRIP2_STEP(0);
+		if (++q > q_last) break;
+		FX_STRIP2_STEP(1);
+		if (++q > q_last) break;
+		FX_STRIP2_STEP(2);
+		if (++q > q_last) break;
+	}
+}
+#undef FX_STRIP2_STEP
+
 int env_i(const char* n, int d) { const char* v = getenv(n); return v && *v ? atoi(v) : d; }
 
 }  // namespace
@@ -177,7 +271,10 @@ hipError_t launch_jacobi_strip(const Geom& g, const float* p_in, const float* b,
 	nchunks = (nzp + zchunk - 1) / zchunk;
 	const dim3 grid(ngroups * nchunks), block(256);
 #define FX_STRIP(T_, R_) hipLaunchKernelGGL((k_jacobi_strip<T_, R_>), grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap)
-	if (sweeps == 2) { if (R == 2) FX_STRIP(2, 2); else FX_STRIP(2, 4); }
+	static const int generic = env_i("FLUIDX_STRIP_GENERIC", 0);
+	if (sweeps == 2 && R == 4 && (g.Y & 3) == 0 && !generic)
+		hipLaunchKernelGGL(k_jacobi_strip2u<4>, grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
+	else if (sweeps == 2) { if (R == 2) FX_STRIP(2, 2); else FX_STRIP(2, 4); }
 	else if (sweeps == 3) { if (R == 4) FX_STRIP(3, 4); else FX_STRIP(3, 2); }
 	else return hipErrorNotSupported;
 #undef FX_STRIP
