@@ -196,7 +196,10 @@ def main():
             sweeps_per_launch = timing.jacobi_sweeps / timing.jacobi_launches
             achieved = JACOBI_BYTES_PER_CELL_SWEEP * cells * sweeps_per_launch / avg_launch_s / 1e9
             kname = "k_jacobi_v4" if sweeps_per_launch == 1 else "k_jacobi_strip"
-            tr = pmc_traffic(kname, G, args.iters, args.storage) if N == 1 else None
+            tr = None
+            if N == 1:
+                for cand in ([kname] if sweeps_per_launch == 1 else ["k_jacobi_strip2u", "k_jacobi_strip"]):
+                    tr = tr or pmc_traffic(cand, G, args.iters, args.storage)
             roof = {"bound": "hbm",
                     "kernel": "k_jacobi_v4 (one lock-step Jacobi sweep per launch)" if sweeps_per_launch == 1 else
                               "k_jacobi_strip (%g lock-step Jacobi sweeps per launch, register-resident temporal blocking: "
