@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--storage", default="fp32", choices=["fp32", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-render", action="store_true", help="skip the (untimed-for-value) ray-march measurement")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--dry-run", action="store_true",
                     help="distributed plumbing only (no GPU work); used by the gloo CPU tests, never a measurement")
@@ -187,8 +188,30 @@ def main():
 
     roof = None
     timing = None
+    render = None
     if fluid is not None:
         timing = fluid.timing_read(reset=True)
+        if N == 1 and G > 1 and not args.no_render:
+            # config 3's second half, reported beside (never inside) `value`: the cube-map-space ray march of the state the
+            # timed steps left behind -- default camera at 1920x1080 (FluidX12.cpp:243-253), OPTIMIZED = light volume + view pass
+            import fluidx12_amd as fx
+            view, proj, eye = fx.default_camera(1920, 1080)
+            fluid.UpdateFrame(0.0, 0, view, proj, eye)
+            fluid.Render(0, fx.Fluid.OPTIMIZED)
+            fluid.Synchronize()
+            fluid.timing_read(reset=True)
+            nr = 5
+            for _ in range(nr):
+                fluid.Render(0, fx.Fluid.OPTIMIZED)
+            fluid.Synchronize()
+            tr_ = fluid.timing_read(reset=True)
+            fi = fluid.frame_info()
+            rays = bin(fi.visibility_mask).count("1") * fi.cube_size ** 2
+            render = {"mode": "OPTIMIZED (CSRayMarchL + CSRayMarchV)", "viewport": [1920, 1080], "cube_lod": fi.cube_lod,
+                      "cube_size": fi.cube_size, "ray_samples": fi.ray_samples, "light_samples": 64, "rays": rays,
+                      "light_pass_ms": tr_.light_ms / nr, "view_pass_ms": tr_.view_ms / nr,
+                      "rays_per_s": rays / (tr_.view_ms / nr * 1e-3) if tr_.view_ms > 0 else None,
+                      "light_voxels_per_s": float(G) ** 3 / (tr_.light_ms / nr * 1e-3) if tr_.light_ms > 0 else None}
         fluid.timing_enable(False)
         if timing.jacobi_launches:
             cells = float(G) * G * nz                                  # cells this rank sweeps
@@ -240,6 +263,8 @@ def main():
             out["step_algorithmic_GBps"] = sb / (elapsed / args.steps) / 1e9
         if roof is not None:
             out["roofline"] = roof
+        if render is not None:
+            out["render"] = render
         if N == 1 and not args.no_cpu_baseline and not args.dry_run:
             out["cpu_baseline"] = cpu_baseline(G, args.iters, args.cpu_budget)
         print(json.dumps(out), flush=True)
