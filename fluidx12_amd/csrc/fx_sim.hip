@@ -257,6 +257,35 @@ __global__ __launch_bounds__(256) void k_divergence(const Geom g, const typename
 	b[row + x] = 0.5f * S;
 }
 
+// fp32 3-D fast path: one thread = 4 consecutive x (16-B loads of the y and z neighbour rows, 16-B store of b)
+__global__ __launch_bounds__(256) void k_divergence_v4(const Geom g, const float* __restrict__ vel, float* __restrict__ b,
+	int z_begin, int nzp, int remap, int rows_per_block)
+{
+	const int X4 = g.X >> 2;
+	const Tile3 tile = xcd_tile((X4 + (int)blockDim.x - 1) / (int)blockDim.x, (g.Y + rows_per_block - 1) / rows_per_block, nzp, remap);
+	const int x4 = tile.x * blockDim.x + threadIdx.x;
+	const int y = tile.y * rows_per_block + threadIdx.y;
+	const int z = z_begin + tile.z;
+	if (x4 >= X4 || y >= g.Y) return;
+	const size_t plane = g.plane(), stride = g.cells_local();
+	const int yu = max(y, 1) - 1, yd = min(y + 1, g.Y - 1);
+	const int zf = max(z, 1) - 1, zb = min(z + 1, g.Zg - 1);
+	const size_t zrow = (size_t)g.lz(z) * plane, off = zrow + (size_t)y * g.X + 4 * x4;
+	const float4 cx = *reinterpret_cast<const float4*>(vel + off);
+	const float L = x4 > 0 ? vel[off - 1] : cx.x;
+	const float R = x4 < X4 - 1 ? vel[off + 4] : cx.w;
+	const float4 U = *reinterpret_cast<const float4*>(vel + stride + zrow + (size_t)yu * g.X + 4 * x4);
+	const float4 D = *reinterpret_cast<const float4*>(vel + stride + zrow + (size_t)yd * g.X + 4 * x4);
+	const float4 F = *reinterpret_cast<const float4*>(vel + 2 * stride + (size_t)g.lz(zf) * plane + (size_t)y * g.X + 4 * x4);
+	const float4 B = *reinterpret_cast<const float4*>(vel + 2 * stride + (size_t)g.lz(zb) * plane + (size_t)y * g.X + 4 * x4);
+	float4 o;
+	o.x = 0.5f * ((-F.x + B.x) + ((-U.x + D.x) + (-L + cx.y)));
+	o.y = 0.5f * ((-F.y + B.y) + ((-U.y + D.y) + (-cx.x + cx.z)));
+	o.z = 0.5f * ((-F.z + B.z) + ((-U.z + D.z) + (-cx.y + cx.w)));
+	o.w = 0.5f * ((-F.w + B.w) + ((-U.w + D.w) + (-cx.z + R)));
+	*reinterpret_cast<float4*>(b + off) = o;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Jacobi sweep, generic: any extent, 2D/3D, optional freeze mask (faithful early-out)
 //   x = ((((((qL - b) + qR) + qU) + qD) + qF) + qB) * (1/6)     2D: (((qL - b) + qR) + qU) + qD) * 1/4
@@ -558,6 +587,14 @@ hipError_t launch_advect(const Geom& g, const SimParams& sp, int half_store, con
 hipError_t launch_divergence(const Geom& g, int half_store, const void* vel, float* b, int z_begin, int z_end, hipStream_t s)
 {
 	if (z_end <= z_begin) return hipSuccess;
+	if (!half_store && g.Zg > 1 && (g.X & 3) == 0) {
+		const int nzp = z_end - z_begin, X4 = g.X >> 2;
+		const int bx = X4 < 64 ? X4 : 64;
+		int by = 256 / bx; if (by > g.Y) by = g.Y;
+		const dim3 block(bx, by, 1), grid(((X4 + bx - 1) / bx) * ((g.Y + by - 1) / by) * nzp, 1, 1);
+		hipLaunchKernelGGL(k_divergence_v4, grid, block, 0, s, g, (const float*)vel, b, z_begin, nzp, xcd_remap_on(REMAP_DIV), by);
+		return hipGetLastError();
+	}
 	const dim3 grid = grid_xyz(g, z_end - z_begin), block(64, 4, 1);
 	if (half_store) hipLaunchKernelGGL(k_divergence<true>, grid, block, 0, s, g, (const h16*)vel, b, z_begin, z_end - z_begin, xcd_remap_on(REMAP_DIV));
 	else hipLaunchKernelGGL(k_divergence<false>, grid, block, 0, s, g, (const float*)vel, b, z_begin, z_end - z_begin, xcd_remap_on(REMAP_DIV));
