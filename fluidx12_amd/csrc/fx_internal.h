@@ -56,6 +56,7 @@ hipError_t launch_jacobi_fused(const Geom& g, const float* p_in, const float* b,
 	int z_begin, int z_end, hipStream_t s);
 // two or three sweeps per launch, register-resident strips (fx_jacobi_strip.hip)
 bool jacobi_strip_supported(const Geom& g);
+bool jacobi_strip_wide(const Geom& g);       // X = 512: only the two-sweep wide kernel exists
 hipError_t launch_jacobi_strip(const Geom& g, const float* p_in, const float* b, float* p_out, int sweeps, int z_begin, int z_end, hipStream_t s);
 // sweeps fused per launch for this geometry (1 = no fused path); requested > 0 overrides the default
 int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp);

@@ -241,6 +241,125 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip2u(const Geom g, const f
 }
 #undef FX_STRIP2_STEP
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same two-sweep kernel for X = 512: a row is two coalesced 1-KiB halves, lane l owns float4 l of the left half
+// (A) and float4 l of the right half (B).  The x neighbours across the middle of the row travel by v_readlane
+// (lane 63's A.w <-> lane 0's B.x), everything else is as above.  R = 2 rows per strip keeps the windows at ~420
+// registers; 512^2 planes still give 256 strips, i.e. long z chunks.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 relax4_lr(float4 c, float L, float Rr, float4 U, float4 D, float4 F, float4 Bk, float4 bb)
+{
+	const float4 Lv = make_float4(L, c.x, c.y, c.z), Rv = make_float4(c.y, c.z, c.w, Rr);
+	float4 x = add4(add4(add4(add4(add4(sub4(Lv, bb), Rv), U), D), F), Bk);
+	const float inv = __uint_as_float(0x3e2aaaabu);
+	x.x *= inv; x.y *= inv; x.z *= inv; x.w *= inv;
+	return x;
+}
+
+// relax both halves of one row: inputs are [2]-arrays (A, B)
+#define FX_RELAX_W(out, c, U, D, F, Bk, bb) do { \
+	const float4 cA = (c)[0], cB = (c)[1]; \
+	float LA = __shfl_up(cA.w, 1), RA = __shfl_down(cA.x, 1), LB = __shfl_up(cB.w, 1), RB = __shfl_down(cB.x, 1); \
+	const float midA = __shfl(cA.w, 63), midB = __shfl(cB.x, 0); \
+	if (lane == 0) { LA = cA.x; LB = midA; } \
+	if (lane == 63) { RA = midB; RB = cB.w; } \
+	(out)[0] = relax4_lr(cA, LA, RA, (U)[0], (D)[0], (F)[0], (Bk)[0], (bb)[0]); \
+	(out)[1] = relax4_lr(cB, LB, RB, (U)[1], (D)[1], (F)[1], (Bk)[1], (bb)[1]); \
+} while (0)
+
+#define FX_STRIPW_STEP(PH) do { \
+	constexpr int NEW = (PH) % 3, CTR = ((PH) + 2) % 3, OLD = ((PH) + 1) % 3; \
+	_Pragma("unroll") for (int i = 0; i < R + 4; ++i) { P0[NEW][i][0] = NP[i][0]; P0[NEW][i][1] = NP[i][1]; } \
+	_Pragma("unroll") for (int i = 0; i < R + 2; ++i) { Bq[NEW][i][0] = NB[i][0]; Bq[NEW][i][1] = NB[i][1]; } \
+	if (q == 0) { \
+		_Pragma("unroll") for (int i = 0; i < R + 4; ++i) { P0[CTR][i][0] = NP[i][0]; P0[CTR][i][1] = NP[i][1]; } \
+	} \
+	if (q + 1 <= q_load_last) { \
+		const size_t zo = (size_t)g.lz(q + 1) * plane; \
+		_Pragma("unroll") for (int i = 0; i < R + 4; ++i) { \
+			NP[i][0] = *reinterpret_cast<const float4*>(p_in + zo + roff[i]); \
+			NP[i][1] = *reinterpret_cast<const float4*>(p_in + zo + roff[i] + 256); } \
+		_Pragma("unroll") for (int i = 0; i < R + 2; ++i) { \
+			NB[i][0] = *reinterpret_cast<const float4*>(b + zo + roff[i + 1]); \
+			NB[i][1] = *reinterpret_cast<const float4*>(b + zo + roff[i + 1] + 256); } \
+	} \
+	if (q - 1 == g.Zg) { \
+		_Pragma("unroll") for (int i = 0; i < R + 2; ++i) { P1[NEW][i][0] = P1[CTR][i][0]; P1[NEW][i][1] = P1[CTR][i][1]; } \
+	} else { \
+		_Pragma("unroll") for (int i = 0; i < R + 2; ++i) \
+			FX_RELAX_W(P1[NEW][i], P0[CTR][i + 1], P0[CTR][i], P0[CTR][i + 2], P0[OLD][i + 1], P0[NEW][i + 1], Bq[CTR][i]); \
+		if (q - 1 == 0) { \
+			_Pragma("unroll") for (int i = 0; i < R + 2; ++i) { P1[CTR][i][0] = P1[NEW][i][0]; P1[CTR][i][1] = P1[NEW][i][1]; } \
+		} \
+	} \
+	if (q - 2 >= zb && q - 2 < ze) { \
+		const size_t zo2 = (size_t)g.lz(q - 2) * plane; \
+		_Pragma("unroll") for (int j = 0; j < R; ++j) { \
+			float4 U[2] = { P1[CTR][j][0], P1[CTR][j][1] }, D[2] = { P1[CTR][j + 2][0], P1[CTR][j + 2][1] }, x[2]; \
+			if (j == 0 && y0 == 0) { U[0] = P1[CTR][j + 1][0]; U[1] = P1[CTR][j + 1][1]; } \
+			if (j == R - 1 && y0 + R >= g.Y) { D[0] = P1[CTR][j + 1][0]; D[1] = P1[CTR][j + 1][1]; } \
+			FX_RELAX_W(x, P1[CTR][j + 1], U, D, P1[OLD][j + 1], P1[NEW][j + 1], Bq[OLD][j + 1]); \
+			if (strip_live) { \
+				float* dst = p_out + zo2 + (size_t)(y0 + j) * g.X + 4 * lane; \
+				*reinterpret_cast<float4*>(dst) = x[0]; \
+				*reinterpret_cast<float4*>(dst + 256) = x[1]; \
+			} \
+		} \
+	} \
+} while (0)
+
+template <int R>
+__global__ __launch_bounds__(256, 1) void k_jacobi_strip2w(const Geom g, const float* __restrict__ p_in,
+	const float* __restrict__ b, float* __restrict__ p_out, int z_begin, int z_end, int zchunk, int ngroups, int nchunks, int remap)
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int tile = xcd_index(ngroups * nchunks, remap);
+	const int grp = tile % ngroups, chunk = tile / ngroups;
+	const int y0 = (grp * 4 + wave) * R;
+	const bool strip_live = y0 < g.Y;
+	const int zb = z_begin + chunk * zchunk, ze = min(zb + zchunk, z_end);
+	const int qs = max(zb - 2, g.zlo), q_last = ze - 1 + 2, q_load_last = min(q_last, g.zhi);
+	const size_t plane = g.plane();
+
+	size_t roff[R + 4];
+#pragma unroll
+	for (int i = 0; i < R + 4; ++i) roff[i] = (size_t)min(max(y0 - 2 + i, 0), g.Y - 1) * g.X + 4 * lane;
+
+	float4 P0[3][R + 4][2], P1[3][R + 2][2], Bq[3][R + 2][2], NP[R + 4][2], NB[R + 2][2];
+	const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+#pragma unroll
+		for (int i = 0; i < R + 4; ++i) { P0[k][i][0] = zero; P0[k][i][1] = zero; }
+#pragma unroll
+		for (int i = 0; i < R + 2; ++i) { P1[k][i][0] = zero; P1[k][i][1] = zero; Bq[k][i][0] = zero; Bq[k][i][1] = zero; }
+	}
+	{
+		const size_t zo = (size_t)g.lz(min(qs, q_load_last)) * plane;
+#pragma unroll
+		for (int i = 0; i < R + 4; ++i) {
+			NP[i][0] = *reinterpret_cast<const float4*>(p_in + zo + roff[i]);
+			NP[i][1] = *reinterpret_cast<const float4*>(p_in + zo + roff[i] + 256);
+		}
+#pragma unroll
+		for (int i = 0; i < R + 2; ++i) {
+			NB[i][0] = *reinterpret_cast<const float4*>(b + zo + roff[i + 1]);
+			NB[i][1] = *reinterpret_cast<const float4*>(b + zo + roff[i + 1] + 256);
+		}
+	}
+	int q = qs;
+	for (;;) {
+		FX_STRIPW_STEP(0);
+		if (++q > q_last) break;
+		FX_STRIPW_STEP(1);
+		if (++q > q_last) break;
+		FX_STRIPW_STEP(2);
+		if (++q > q_last) break;
+	}
+}
+#undef FX_STRIPW_STEP
+#undef FX_RELAX_W
+
 int env_i(const char* n, int d) { const char* v = getenv(n); return v && *v ? atoi(v) : d; }
 
 }  // namespace
@@ -248,8 +367,11 @@ int env_i(const char* n, int d) { const char* v = getenv(n); return v && *v ? at
 bool jacobi_strip_supported(const Geom& g)
 {
 	const int LX = g.X >> 2;
+	if (g.Zg > 1 && g.X == 512 && (g.Y & 1) == 0) return true;        // wide kernel: two sweeps only (k_jacobi_strip2w)
 	return g.Zg > 1 && (g.X & 3) == 0 && (LX == 16 || LX == 32 || LX == 64) && g.Y >= 8;
 }
+
+bool jacobi_strip_wide(const Geom& g) { return g.X == 512; }
 
 hipError_t launch_jacobi_strip(const Geom& g, const float* p_in, const float* b, float* p_out, int sweeps, int z_begin, int z_end, hipStream_t s)
 {
@@ -258,9 +380,11 @@ hipError_t launch_jacobi_strip(const Geom& g, const float* p_in, const float* b,
 	static const int forced_chunk = env_i("FLUIDX_STRIP_ZCHUNK", 0);   // measurement knobs
 	static const int remap = env_i("FLUIDX_STRIP_REMAP", 1);
 	static const int Rsel = env_i("FLUIDX_STRIP_R", 0);
-	const int rows = Rsel == 2 || Rsel == 4 ? Rsel : (sweeps == 3 ? 2 : 4);
+	const bool wide = jacobi_strip_wide(g);
+	if (wide && sweeps != 2) return hipErrorNotSupported;
+	const int rows = wide ? 2 : (Rsel == 2 || Rsel == 4 ? Rsel : (sweeps == 3 ? 2 : 4));
 	const int R = rows;
-	const int LX = g.X >> 2, SPW = 64 / LX;
+	const int LX = g.X >> 2, SPW = wide ? 1 : 64 / LX;
 	const int nstrips = (g.Y + R - 1) / R;
 	const int ngroups = (nstrips + 4 * SPW - 1) / (4 * SPW);            // 4 waves per workgroup
 	const int nzp = z_end - z_begin;
@@ -272,7 +396,9 @@ hipError_t launch_jacobi_strip(const Geom& g, const float* p_in, const float* b,
 	const dim3 grid(ngroups * nchunks), block(256);
 #define FX_STRIP(T_, R_) hipLaunchKernelGGL((k_jacobi_strip<T_, R_>), grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap)
 	static const int generic = env_i("FLUIDX_STRIP_GENERIC", 0);
-	if (sweeps == 2 && R == 4 && (g.Y & 3) == 0 && !generic)
+	if (wide)
+		hipLaunchKernelGGL(k_jacobi_strip2w<2>, grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
+	else if (sweeps == 2 && R == 4 && (g.Y & 3) == 0 && !generic)
 		hipLaunchKernelGGL(k_jacobi_strip2u<4>, grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
 	else if (sweeps == 2) { if (R == 2) FX_STRIP(2, 2); else FX_STRIP(2, 4); }
 	else if (sweeps == 3) { if (R == 4) FX_STRIP(3, 4); else FX_STRIP(3, 2); }

@@ -638,8 +638,9 @@ static bool tb_supported(const Geom& g)
 static bool strip_profitable(const Geom& g, int nzp)
 {
 	if (!jacobi_strip_supported(g)) return false;
-	const int SPW = 64 / (g.X >> 2);
-	const int ngroups = ((g.Y + 3) / 4 + 4 * SPW - 1) / (4 * SPW);
+	const bool wide = jacobi_strip_wide(g);
+	const int SPW = wide ? 1 : 64 / (g.X >> 2), R = wide ? 2 : 4;
+	const int ngroups = ((g.Y + R - 1) / R + 4 * SPW - 1) / (4 * SPW);
 	const int nchunks = (256 + ngroups - 1) / ngroups;
 	return nzp / nchunks >= 16;
 }
@@ -647,6 +648,10 @@ static bool strip_profitable(const Geom& g, int nzp)
 int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp)
 {
 	static const int forced = env_int("FLUIDX_JACOBI_T", 0);
+	if (jacobi_strip_supported(g) && jacobi_strip_wide(g)) {            // X = 512: one fused shape (two sweeps, wide strips)
+		const int want = requested > 0 ? requested : (forced > 0 ? forced : (strip_profitable(g, nzp) ? 2 : 1));
+		return want >= 2 ? 2 : 1;
+	}
 	if (!tb_supported(g)) return 1;
 	// default: two sweeps per launch in the register-strip kernel (fx_jacobi_strip.hip) where the geometry allows it,
 	// else one sweep per launch; the LDS kernel k_jacobi_tb<T> lost to both in every shape measured
@@ -724,6 +729,8 @@ hipError_t launch_jacobi_fused(const Geom& g, const float* p_in, const float* b,
 	int z_begin, int z_end, hipStream_t s)
 {
 	if (z_end <= z_begin) return hipSuccess;
+	if (jacobi_strip_supported(g) && jacobi_strip_wide(g))
+		return sweeps == 2 ? launch_jacobi_strip(g, p_in, b, p_out, 2, z_begin, z_end, s) : hipErrorNotSupported;
 	if (!tb_supported(g)) return hipErrorNotSupported;
 	switch (sweeps) {
 	case 2: {

@@ -91,6 +91,20 @@ def test_jacobi_sweep_counts(iters):
     assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
 
 
+def test_jacobi_wide_strips_x512_bit_exact():
+    """X = 512: the two-sweep strip kernel with two float4 per lane (k_jacobi_strip2w) == oracle, bit for bit"""
+    X, Y, Z = 512, 512, 20
+    _, _, p = rand_state(X, Y, Z, 19)
+    b = np.random.default_rng(20).uniform(-1, 1, (Z, Y, X)).astype(f32)
+    q, _ = orc.jacobi(p, b, 5)
+    for fuse in (1, 2):
+        f = make((X, Y, Z), jacobi_iters=5, jacobi_fuse=fuse)
+        f.upload(fx.FIELD_PRESSURE, p)
+        f.upload(fx.FIELD_DIVERGENCE, b)
+        f.Jacobi(5)                              # 2 + 2 + 1
+        assert np.array_equal(f.download(fx.FIELD_PRESSURE), q), fuse
+
+
 @pytest.mark.parametrize("dims", [(64, 64, 40), (128, 128, 24), (256, 256, 20)])
 @pytest.mark.parametrize("fuse", [1, 2, 3, 4])
 def test_jacobi_temporal_blocking_bit_exact(dims, fuse):
