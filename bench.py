@@ -8,9 +8,10 @@ advection, divergence, 40 lock-step Jacobi sweeps, projection -- over the 256^3 
 BASELINE.json configs[2] (zero-initialised fields, built-in Gaussian impulse, dt = 2/Y, CLAMP sampler),
 with every field resident in HBM before the timed region.  metric = voxel-updates/s.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the same 256^3 grid is cut into N z-slabs
-(strong scaling), one slab per rank, neighbour halo planes exchanged with RCCL send/recv pairs over xGMI
-inside libfluidx_hip.so; torch.distributed only carries the rendezvous (RCCL unique id), the barriers and
+N > 1 (launched by torch.distributed.run, one rank per GPU): the grid is cut into N z-slabs, one per rank, neighbour
+halo planes exchanged with RCCL send/recv pairs over xGMI inside libfluidx_hip.so.  Default = weak scaling: 16.8 M
+voxels per GPU (256^3, 256x256x512, 512x512x256, 512^3 for N = 1, 2, 4, 8 -- see workload_grid); --scaling strong
+keeps 256^3 for every N. torch.distributed only carries the rendezvous (RCCL unique id), the barriers and
 the max-over-ranks reduction of the step time.
 
 The JSON line carries `roofline` (dominant kernel = the Jacobi sweep: 12 algorithmic bytes per cell-sweep,
@@ -50,6 +51,17 @@ def pmc_traffic(kernel, grid, iters, storage):
         if (d.get("grid"), d.get("iters"), d.get("storage")) == (grid, iters, storage) and kernel in d.get("kernels", {}):
             best = (d["kernels"][kernel]["traffic"], os.path.basename(fn))
     return best
+
+
+def workload_grid(G, N, scaling):
+    """Grid of the N-rank run.  strong: the same G^3 for every N.  weak (default): 16.8 M voxels per GPU at G = 256 --
+    the grid doubles along z, then along x and y, alternately: 1: G^3, 2: G x G x 2G, 4: 2G x 2G x G, 8: (2G)^3 (= BASELINE
+    configs[3]'s 512^3 on 8 GPUs); other N stack along z.  Returns ((X, Y, Z), advect halo planes): the halo covers the
+    z back-trace reach measured with tools/reach_probe.py over 200 steps (9.9 / 2.3 / 4.4 cells for N = 2 / 4 / 8) + margin."""
+    if N == 1 or scaling == "strong":
+        return (G, G, G), 0
+    table = {2: ((G, G, 2 * G), 14), 4: ((2 * G, 2 * G, G), 6), 8: ((2 * G, 2 * G, 2 * G), 8)}
+    return table.get(N, ((G, G, G * N), 6 * N + 2))
 
 
 def slab_for_rank(Z, rank, world):
@@ -97,6 +109,7 @@ def main():
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--storage", default="fp32", choices=["fp32", "fp16"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="how the grid grows with --gpus (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-render", action="store_true", help="skip the (untimed-for-value) ray-march measurement")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -124,15 +137,16 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=N, device_id=torch.device("cuda", local_rank))
 
-    z0, nz = slab_for_rank(G, rank, N)
+    (GX, GY, GZ), halo_adv = workload_grid(G, N, args.scaling)
+    z0, nz = slab_for_rank(GZ, rank, N)
 
     fluid = None
     if not args.dry_run:
         import fluidx12_amd as fx
         fluid = fx.Fluid()
-        ok = fluid.Init(1920, 1080, (G, G, G), storage=args.storage, jacobi_iters=args.iters, jacobi_mode="fixed",
+        ok = fluid.Init(1920, 1080, (GX, GY, GZ), storage=args.storage, jacobi_iters=args.iters, jacobi_mode="fixed",
                         advect_address="clamp", device=local_rank if N > 1 else -1,
-                        slab=(z0, nz) if N > 1 else None)
+                        slab=(z0, nz) if N > 1 else None, halo_advect=halo_adv)
         if not ok:
             raise SystemExit("Fluid.Init failed (status %d): the HIP library needs a MI355X" % fluid.last_status)
 
@@ -150,7 +164,7 @@ def main():
         if not args.dry_run:
             fluid.comm_init_rank(uid, rank, N)
 
-    dt = 2.0 / G                                  # FluidX12.cpp:266
+    dt = 2.0 / GY                                 # FluidX12.cpp:266
 
     def one_step(k):
         if fluid is not None:
@@ -214,7 +228,7 @@ def main():
                       "light_voxels_per_s": float(G) ** 3 / (tr_.light_ms / nr * 1e-3) if tr_.light_ms > 0 else None}
         fluid.timing_enable(False)
         if timing.jacobi_launches:
-            cells = float(G) * G * nz                                  # cells this rank sweeps
+            cells = float(GX) * GY * nz                                # cells this rank sweeps
             avg_launch_s = timing.jacobi_ms * 1e-3 / timing.jacobi_launches
             sweeps_per_launch = timing.jacobi_sweeps / timing.jacobi_launches
             achieved = JACOBI_BYTES_PER_CELL_SWEEP * cells * sweeps_per_launch / avg_launch_s / 1e9
@@ -236,7 +250,7 @@ def main():
                     "cell_updates_per_s": cells * timing.jacobi_sweeps / (timing.jacobi_ms * 1e-3)}
 
     if rank == 0:
-        voxels = float(G) ** 3 * args.steps
+        voxels = float(GX) * GY * GZ * args.steps
         out = {
             "metric": "voxel-updates/sec (advect+40 Jacobi) at 256^3; achieved HBM GB/s vs peak",
             "value": voxels / elapsed if not args.dry_run else 0.0,
@@ -244,14 +258,14 @@ def main():
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling if N > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.storage == "fp32" else "f32 arithmetic / f16 field storage",
             "data": "synthetic",
-            "config": {"workload": "%d^3 3D smoke, %d Jacobi sweeps, %s fields, advect+divergence+Jacobi+project per step"
-                                   % (G, args.iters, args.storage),
-                       "grid": [G, G, G], "jacobi_iters": args.iters, "storage": args.storage,
-                       "parallelism": "single GPU" if N == 1 else "z-slab x%d, RCCL send/recv halo exchange" % N,
+            "config": {"workload": "%dx%dx%d 3D smoke (%.1f M voxels per GPU), %d Jacobi sweeps, %s fields, "
+                                   "advect+divergence+Jacobi+project per step" % (GX, GY, GZ, GX * GY * GZ / N / 1e6, args.iters, args.storage),
+                       "grid": [GX, GY, GZ], "jacobi_iters": args.iters, "storage": args.storage,
+                       "parallelism": "single GPU" if N == 1 else "z-slab x%d (%d planes per rank), RCCL send/recv halo exchange" % (N, GZ // N),
                        "bytes_per_voxel_step": step_bytes_per_voxel(args.iters, args.storage)},
         }
         if args.dry_run:
@@ -259,7 +273,7 @@ def main():
         if timing is not None:
             out["stage_ms_per_step"] = {k: getattr(timing, k + "_ms") / max(timing.steps, 1)
                                         for k in ("advect", "divergence", "jacobi", "project", "exchange")}
-            sb = step_bytes_per_voxel(args.iters, args.storage) * float(G) ** 3
+            sb = step_bytes_per_voxel(args.iters, args.storage) * float(GX) * GY * GZ
             out["step_algorithmic_GBps"] = sb / (elapsed / args.steps) / 1e9
         if roof is not None:
             out["roofline"] = roof

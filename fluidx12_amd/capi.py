@@ -16,6 +16,7 @@ FRAME_COUNT = 3
 STORAGE_FP32, STORAGE_FP16 = 0, 1
 JACOBI_FIXED, JACOBI_FAITHFUL = 0, 1
 ADDRESS_CLAMP, ADDRESS_MIRROR = 0, 1
+FLAG_JACOBI_FUSE_MASK, FLAG_NO_OVERLAP = 0xF, 0x10
 (FIELD_VELOCITY, FIELD_VELOCITY1, FIELD_COLOR, FIELD_COLOR_PREV, FIELD_PRESSURE, FIELD_DIVERGENCE,
  FIELD_LIGHTMAP, FIELD_CUBEMAP) = range(8)
 

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -120,6 +121,18 @@ Range grown(const fx_ctx* c, int by)
 // ---- the simulation step, phase by phase, over a group of slab contexts ----------------------------
 // (Fluid::Simulate, Fluid.cpp:348-410; the phase structure is what lets one code path serve the
 // single-GPU case, the RCCL slabs and the in-process loop-back slabs)
+//
+// Multi-rank schedule of one step (k = sweeps per pressure exchange, Ha = advect halo):
+//   1  [comm] exchange Ha planes of velocity + colour      || [compute] advect the planes >= Ha away from a slab face
+//      then advect the 2 x Ha face planes
+//   2  exchange 1 plane of the advected uz ; divergence on the owned planes
+//   3  exchange k-1 planes of b and k planes of p (one message group)
+//   4  per round of k sweeps: the k planes next to each face are brought to the round's last level first
+//      ("face tasks", from the exchanged halo), [comm] they travel to the neighbour || [compute] the interior
+//      follows.  A round is one or two fused launches (k <= 2 x sweeps-per-launch), which is what keeps the
+//      ping-pong buffers free of read/write conflicts between the face tasks and the interior (see jacobi_overlapped)
+//   5  projection (reads the 1st halo plane of the last exchange)
+// Every cell is computed with the arithmetic of the single-domain run, so results are bit-identical.
 int for_members(fx_ctx* ctx, std::vector<fx_ctx*>& out)
 {
 	out.clear();
@@ -128,57 +141,246 @@ int for_members(fx_ctx* ctx, std::vector<fx_ctx*>& out)
 	return FX_OK;
 }
 
-int do_exchange(fx_ctx* ctx, int which_set, int k, hipStream_t s)
+bool multi_rank(const fx_ctx* c) { return c->group && c->nranks > 1; }
+
+bool overlap_enabled(const fx_ctx* lead)
 {
-	if (!ctx->group || ctx->nranks <= 1 || k <= 0) return FX_OK;
-	ScopedMark mk(ctx, s, MK_EXCH);
-	return ctx->group->transport->exchange(ctx->group, which_set, k, s);
+	if (!multi_rank(lead) || !lead->group->comm_stream) return false;
+	if (lead->desc.flags & FX_FLAG_NO_OVERLAP) return false;
+	const char* e = std::getenv("FLUIDX_OVERLAP");
+	return !(e && e[0] == '0');
 }
 
-int advect_phase(fx_ctx* ctx, hipStream_t s)
+struct ExchSpec { int set, k, pidx; };
+
+int do_exchange(fx_ctx* ctx, const std::vector<fx_ctx*>& M, const ExchSpec* specs, int nspec, hipStream_t s)
 {
+	if (!multi_rank(ctx)) return FX_OK;
+	DeviceGuard dg(ctx->device);
+	ScopedMark mk(ctx, s, MK_EXCH);
+	std::vector<std::vector<Seg>> segs(M.size());
+	size_t total = 0;
+	for (size_t i = 0; i < M.size(); ++i) {
+		for (int j = 0; j < nspec; ++j) {
+			if (specs[j].k <= 0) continue;
+			ExchItem it[4];
+			const int n = exchange_items(M[i], specs[j].set, specs[j].k, specs[j].pidx, it);
+			halo_segments(M[i], it, n, segs[i]);
+		}
+		total += segs[i].size();
+	}
+	if (!total) return FX_OK;
+	return ctx->group->transport->exchange(ctx->group, segs, s);
+}
+
+// comm stream picks up after everything queued on the compute stream so far
+int comm_fork(fx_ctx* ctx, hipStream_t s)
+{
+	fx_comm_group* g = ctx->group;
+	FX_HIP(hipEventRecord(g->ev_ready, s));
+	FX_HIP(hipStreamWaitEvent(g->comm_stream, g->ev_ready, 0));
+	return FX_OK;
+}
+int comm_mark_done(fx_ctx* ctx) { FX_HIP(hipEventRecord(ctx->group->ev_done, ctx->group->comm_stream)); return FX_OK; }
+int comm_join(fx_ctx* ctx, hipStream_t s) { FX_HIP(hipStreamWaitEvent(s, ctx->group->ev_done, 0)); return FX_OK; }
+
+bool has_lower(const fx_ctx* c) { return c->nranks > 1 && c->rank > 0; }
+bool has_upper(const fx_ctx* c) { return c->nranks > 1 && c->rank + 1 < c->nranks; }
+
+// advect planes [r.lo, r.hi); own_only: back-traces must stay inside the owned planes (the halo is still in flight)
+int advect_range(fx_ctx* ctx, hipStream_t s, Range r, bool own_only)
+{
+	if (r.hi <= r.lo) return FX_OK;
 	DeviceGuard dg(ctx->device);
 	const SimParams sp{ ctx->time_step, (int)ctx->desc.advect_address, ctx->g.Zg > 1 ? 1 : 0 };
 	const int par = ctx->frame_parity;
-	ScopedMark mk(ctx, s, MK_ADVECT);
-	const Range r = owned(ctx);
-	FX_HIP(launch_advect(ctx->g, sp, ctx->half, ctx->vel[0], ctx->col[1 - par], ctx->vel[1], ctx->col[par],
+	Geom g = ctx->g;
+	if (own_only) { g.zlo = std::max(g.zlo, g.z0); g.zhi = std::min(g.zhi, g.z0 + g.nz - 1); }
+	FX_HIP(launch_advect(g, sp, ctx->half, ctx->vel[0], ctx->col[1 - par], ctx->vel[1], ctx->col[par],
 		r.lo, r.hi, ctx->halo_overflow, s));
 	return FX_OK;
 }
 
-int divergence_phase(fx_ctx* ctx, hipStream_t s, int halo)
+int advect_all(fx_ctx* ctx, std::vector<fx_ctx*>& M, hipStream_t s)
+{
+	int rc;
+	const int Ha = (int)ctx->desc.halo_advect;
+	const ExchSpec spec{ EX_ADVECT_IN, Ha, 0 };
+	bool ov = overlap_enabled(ctx);
+	for (fx_ctx* m : M) if (m->g.nz <= 2 * Ha) ov = false;
+	if (!ov) {
+		if ((rc = do_exchange(ctx, M, &spec, 1, s))) return rc;
+		for (fx_ctx* m : M) { ScopedMark mk(m, s, MK_ADVECT); if ((rc = advect_range(m, s, owned(m), false))) return rc; }
+		return FX_OK;
+	}
+	if ((rc = comm_fork(ctx, s))) return rc;
+	if ((rc = do_exchange(ctx, M, &spec, 1, ctx->group->comm_stream))) return rc;
+	if ((rc = comm_mark_done(ctx))) return rc;
+	for (fx_ctx* m : M) {
+		ScopedMark mk(m, s, MK_ADVECT);
+		const Range o = owned(m);
+		if ((rc = advect_range(m, s, Range{ o.lo + (has_lower(m) ? Ha : 0), o.hi - (has_upper(m) ? Ha : 0) }, true))) return rc;
+	}
+	if ((rc = comm_join(ctx, s))) return rc;
+	for (fx_ctx* m : M) {
+		ScopedMark mk(m, s, MK_ADVECT);
+		const Range o = owned(m);
+		if (has_lower(m) && (rc = advect_range(m, s, Range{ o.lo, o.lo + Ha }, false))) return rc;
+		if (has_upper(m) && (rc = advect_range(m, s, Range{ o.hi - Ha, o.hi }, false))) return rc;
+	}
+	return FX_OK;
+}
+
+int divergence_phase(fx_ctx* ctx, hipStream_t s)
 {
 	DeviceGuard dg(ctx->device);
 	ScopedMark mk(ctx, s, MK_DIV);
-	const Range r = grown(ctx, ctx->nranks > 1 ? halo : 0);
+	const Range r = owned(ctx);
 	FX_HIP(launch_divergence(ctx->g, ctx->half, ctx->vel[1], ctx->b, r.lo, r.hi, s));
 	return FX_OK;
 }
 
-// `count` lock-step sweeps whose first one may read `count` exchanged halo planes
+// t lock-step sweeps p[src] -> p[src ^ 1] on planes [r.lo, r.hi) in ONE launch
+int jacobi_launch(fx_ctx* ctx, hipStream_t s, int src, int t, Range r, ScopedMark* mk)
+{
+	r.lo = std::max(r.lo, 0); r.hi = std::min(r.hi, ctx->g.Zg);
+	if (r.hi <= r.lo) return FX_OK;
+	DeviceGuard dg(ctx->device);
+	if (t > 1) {
+		FX_HIP(launch_jacobi_fused(ctx->g, ctx->p[src], ctx->b, ctx->p[src ^ 1], t, r.lo, r.hi, s));
+	} else {
+		FX_HIP(launch_jacobi_sweep(ctx->g, ctx->p[src], ctx->b, ctx->p[src ^ 1], ctx->frozen, r.lo, r.hi, s));
+	}
+	if (mk) { mk->launches += 1; mk->sweeps += t; }
+	return FX_OK;
+}
+
+int fused_sweeps(const fx_ctx* c)
+{
+	return c->frozen ? 1 : jacobi_fused_max_sweeps(c->g, (int)(c->desc.flags & FX_FLAG_JACOBI_FUSE_MASK), c->g.nz);
+}
+
+// `count` lock-step sweeps whose first one may read `count` exchanged halo planes; the planes swept shrink by
+// one per sweep towards the owned range (redundant halo work instead of an exchange per sweep)
 int jacobi_round(fx_ctx* ctx, hipStream_t s, int count, ScopedMark* mk)
 {
-	DeviceGuard dg(ctx->device);
 	int done = 0;
 	while (done < count) {
 		const int left = count - done;
-		// planes still needed after this launch shrink by one per remaining sweep
-		const int fusedMax = ctx->frozen ? 1 : jacobi_fused_max_sweeps(ctx->g, (int)(ctx->desc.flags & FX_FLAG_JACOBI_FUSE_MASK), ctx->g.nz);
-		const int t = std::min(left, fusedMax);
-		const Range r = grown(ctx, ctx->nranks > 1 ? left - t : 0);
-		const float* src = ctx->p[ctx->p_cur];
-		float* dst = ctx->p[ctx->p_cur ^ 1];
-		if (t > 1) {
-			FX_HIP(launch_jacobi_fused(ctx->g, src, ctx->b, dst, t, r.lo, r.hi, s));
-		} else {
-			FX_HIP(launch_jacobi_sweep(ctx->g, src, ctx->b, dst, ctx->frozen, r.lo, r.hi, s));
-		}
+		const int t = std::min(left, fused_sweeps(ctx));
+		const int rc = jacobi_launch(ctx, s, ctx->p_cur, t, grown(ctx, multi_rank(ctx) ? left - t : 0), mk);
+		if (rc) return rc;
 		ctx->p_cur ^= 1;
 		done += t;
-		if (mk) { mk->launches += 1; mk->sweeps += t; }
 	}
 	return FX_OK;
+}
+
+int clear_freeze_masks(std::vector<fx_ctx*>& M, hipStream_t s)
+{
+	for (fx_ctx* m : M)
+		if (m->frozen) { DeviceGuard dg(m->device); if (hipMemsetAsync(m->frozen, 0, m->g.cells_local(), s) != hipSuccess) return FX_E_DEVICE; }
+	return FX_OK;
+}
+
+// exchange, then k sweeps, exchange, ... on one stream
+int jacobi_serial(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t iters)
+{
+	const bool multi = multi_rank(lead);
+	const int k = multi ? (int)lead->desc.halo_jacobi : (int)iters;
+	int rc;
+	if ((rc = clear_freeze_masks(M, s))) return rc;
+	const ExchSpec bspec{ EX_DIV, k - 1, 0 };
+	if ((rc = do_exchange(lead, M, &bspec, 1, s))) return rc;
+	uint32_t done = 0;
+	while (done < iters) {
+		const int cnt = (int)std::min<uint32_t>(k, iters - done);
+		const ExchSpec pspec{ EX_PRESSURE, cnt, lead->p_cur };
+		if ((rc = do_exchange(lead, M, &pspec, 1, s))) return rc;
+		for (fx_ctx* m : M) {
+			ScopedMark mk(m, s, MK_JACOBI);
+			if ((rc = jacobi_round(m, s, cnt, &mk))) return rc;
+		}
+		done += cnt;
+	}
+	const ExchSpec last{ EX_PRESSURE, 1, lead->p_cur };          // the projection's z-gradient reads one plane across the face
+	return do_exchange(lead, M, &last, 1, s);
+}
+
+// Rounds of k = t1 + t2 sweeps (t1, t2 <= sweeps per launch) with the pressure exchange of round r hidden behind
+// the interior sweeps of rounds r and r+1.  With src = the buffer holding the round's level 0 (halo k planes valid):
+//   two launches per round:
+//     I1  src -> dst, t1 sweeps, planes [lo + k + t2, hi - k - t2)        reads owned planes only
+//     (wait: the halo of src has arrived)
+//     L1  src -> dst, t1 sweeps, planes [lo - t2, lo + k + t2)            level t1 next to the face (U1 mirrored)
+//     L2  dst -> src, t2 sweeps, planes [lo, lo + k)                      the k planes the neighbour needs, final level
+//     [comm] send src[lo, lo + k), receive src[lo - k, lo)               || I2  dst -> src, t2 sweeps, [lo + k, hi - k)
+//   one launch per round: L (src -> dst on [lo, lo + k)), [comm] exchange dst || I (src -> dst on [lo + k, hi - k)).
+// Ordering on the compute stream makes I1 read src before L2 overwrites part of it; the comm stream only ever
+// touches the buffer that is `src` of the NEXT round: its k face planes (read) and its halo planes (written), which the
+// interior launches of this round (writing [lo + k, hi - k) of it) and I1 of the next round (reading owned planes
+// of it, writing the other buffer) do not touch.  No plane is swept twice at the same level by one rank, so the
+// freeze mask of the faithful mode stays exact as well.
+int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t iters, int t, int k)
+{
+	int rc;
+	if ((rc = clear_freeze_masks(M, s))) return rc;
+	const ExchSpec first[2] = { { EX_DIV, k - 1, 0 }, { EX_PRESSURE, k, lead->p_cur } };
+	if ((rc = do_exchange(lead, M, first, 2, s))) return rc;
+	bool in_flight = false;
+	uint32_t done = 0;
+	while (done < iters) {
+		const int cnt = (int)std::min<uint32_t>(k, iters - done);
+		const int t1 = std::min(t, cnt), t2 = cnt - t1;
+		const int src = lead->p_cur, fin = t2 ? src : src ^ 1;
+		if (t2)
+			for (fx_ctx* m : M) {
+				ScopedMark mk(m, s, MK_JACOBI);
+				const Range o = owned(m);
+				if ((rc = jacobi_launch(m, s, src, t1, Range{ has_lower(m) ? o.lo + k + t2 : o.lo, has_upper(m) ? o.hi - k - t2 : o.hi }, &mk))) return rc;
+			}
+		if (in_flight) { if ((rc = comm_join(lead, s))) return rc; in_flight = false; }
+		for (fx_ctx* m : M) {
+			ScopedMark mk(m, s, MK_JACOBI);
+			const Range o = owned(m);
+			if (has_lower(m)) {
+				if ((rc = jacobi_launch(m, s, src, t1, Range{ o.lo - t2, o.lo + k + t2 }, nullptr))) return rc;
+				if (t2 && (rc = jacobi_launch(m, s, src ^ 1, t2, Range{ o.lo, o.lo + k }, nullptr))) return rc;
+			}
+			if (has_upper(m)) {
+				if ((rc = jacobi_launch(m, s, src, t1, Range{ o.hi - k - t2, o.hi + t2 }, nullptr))) return rc;
+				if (t2 && (rc = jacobi_launch(m, s, src ^ 1, t2, Range{ o.hi - k, o.hi }, nullptr))) return rc;
+			}
+		}
+		if ((rc = comm_fork(lead, s))) return rc;
+		const ExchSpec pspec{ EX_PRESSURE, k, fin };
+		if ((rc = do_exchange(lead, M, &pspec, 1, lead->group->comm_stream))) return rc;
+		if ((rc = comm_mark_done(lead))) return rc;
+		in_flight = true;
+		for (fx_ctx* m : M) {
+			ScopedMark mk(m, s, MK_JACOBI);
+			const Range o = owned(m);
+			const Range in{ has_lower(m) ? o.lo + k : o.lo, has_upper(m) ? o.hi - k : o.hi };
+			if ((rc = jacobi_launch(m, s, t2 ? src ^ 1 : src, t2 ? t2 : t1, in, &mk))) return rc;
+			m->p_cur = fin;
+		}
+		done += cnt;
+	}
+	if (in_flight) rc = comm_join(lead, s);
+	return rc;
+}
+
+int jacobi_all(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t iters)
+{
+	if (overlap_enabled(lead)) {
+		int t = fused_sweeps(lead);
+		for (fx_ctx* m : M) t = std::min(t, fused_sweeps(m));
+		const int k = std::min((int)lead->desc.halo_jacobi, 2 * t);
+		bool ok = true;
+		for (fx_ctx* m : M) if (m->g.nz < 3 * k + 2) ok = false;      // room for two face zones and an interior
+		if (ok) return jacobi_overlapped(lead, M, s, iters, t, k);
+	}
+	return jacobi_serial(lead, M, s, iters);
 }
 
 int project_phase(fx_ctx* ctx, hipStream_t s)
@@ -191,39 +393,17 @@ int project_phase(fx_ctx* ctx, hipStream_t s)
 	return FX_OK;
 }
 
-int jacobi_all(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t iters)
-{
-	const int k = lead->nranks > 1 ? (int)lead->desc.halo_jacobi : (int)iters;
-	uint32_t done = 0;
-	for (fx_ctx* m : M)
-		if (m->frozen) { DeviceGuard dg(m->device); if (hipMemsetAsync(m->frozen, 0, m->g.cells_local(), s) != hipSuccess) return FX_E_DEVICE; }
-	while (done < iters) {
-		const int cnt = (int)std::min<uint32_t>(k, iters - done);
-		int rc = do_exchange(lead, EX_PRESSURE, lead->nranks > 1 ? cnt : 0, s);
-		if (rc) return rc;
-		for (fx_ctx* m : M) {
-			ScopedMark mk(m, s, MK_JACOBI);
-			rc = jacobi_round(m, s, cnt, &mk);
-			if (rc) return rc;
-		}
-		done += cnt;
-	}
-	return FX_OK;
-}
-
 int simulate_impl(fx_ctx* ctx, hipStream_t s)
 {
 	std::vector<fx_ctx*> M;
 	for_members(ctx, M);
 	int rc;
-	if ((rc = do_exchange(ctx, EX_ADVECT_IN, (int)ctx->desc.halo_advect, s))) return rc;
-	for (fx_ctx* m : M) if ((rc = advect_phase(m, s))) return rc;
+	if ((rc = advect_all(ctx, M, s))) return rc;
 	if (ctx->time_step > 0.0f) {                       // CSProject3D.hlsl:88
-		const int hj = (int)ctx->desc.halo_jacobi;
-		if ((rc = do_exchange(ctx, EX_VEL1, hj, s))) return rc;
-		for (fx_ctx* m : M) if ((rc = divergence_phase(m, s, hj - 1))) return rc;
+		const ExchSpec uz{ EX_UZ1, 1, 0 };
+		if ((rc = do_exchange(ctx, M, &uz, 1, s))) return rc;
+		for (fx_ctx* m : M) if ((rc = divergence_phase(m, s))) return rc;
 		if ((rc = jacobi_all(ctx, M, s, ctx->desc.jacobi_iters))) return rc;
-		if ((rc = do_exchange(ctx, EX_PRESSURE, 1, s))) return rc;
 		for (fx_ctx* m : M) if ((rc = project_phase(m, s))) return rc;
 	} else {
 		for (fx_ctx* m : M) {
@@ -346,7 +526,13 @@ int fx_destroy(fx_ctx* ctx)
 	if (ctx->group) {
 		fx_comm_group* g = ctx->group;
 		for (auto& m : g->members) if (m == ctx) m = nullptr;
-		if (--g->refs == 0) { delete g->transport; delete g; }
+		if (--g->refs == 0) {
+			if (g->comm_stream) (void)hipStreamDestroy(g->comm_stream);
+			if (g->ev_ready) (void)hipEventDestroy(g->ev_ready);
+			if (g->ev_done) (void)hipEventDestroy(g->ev_done);
+			delete g->transport;
+			delete g;
+		}
 	}
 	free_all(ctx);
 	delete ctx;
@@ -627,13 +813,15 @@ int fx_advect(fx_ctx* ctx, void* stream)
 	if (!ctx) return FX_E_INVALID;
 	if (!ctx->frame_valid) return FX_E_STATE;
 	if (ctx->nranks > 1) return FX_E_INVALID;
-	return advect_phase(ctx, pick_stream(ctx, stream));
+	hipStream_t s = pick_stream(ctx, stream);
+	ScopedMark mk(ctx, s, MK_ADVECT);
+	return advect_range(ctx, s, owned(ctx), false);
 }
 
 int fx_divergence(fx_ctx* ctx, void* stream)
 {
 	if (!ctx || ctx->nranks > 1) return FX_E_INVALID;
-	return divergence_phase(ctx, pick_stream(ctx, stream), 0);
+	return divergence_phase(ctx, pick_stream(ctx, stream));
 }
 
 int fx_jacobi(fx_ctx* ctx, void* stream, uint32_t iters)
@@ -721,6 +909,19 @@ static int check_slab_chain(fx_ctx* c, int rank, int nranks)
 	return FX_OK;
 }
 
+// side stream (highest priority: the exchange kernels must get CUs while the interior sweeps fill the chip) + ordering events
+static int make_comm_stream(fx_comm_group* g, int device)
+{
+	g->comm_stream = nullptr; g->ev_ready = nullptr; g->ev_done = nullptr;
+	DeviceGuard dg(device);
+	int lo = 0, hi = 0;
+	if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
+	if (hipStreamCreateWithPriority(&g->comm_stream, hipStreamNonBlocking, hi) != hipSuccess) return FX_E_DEVICE;
+	if (hipEventCreateWithFlags(&g->ev_ready, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;
+	if (hipEventCreateWithFlags(&g->ev_done, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;
+	return FX_OK;
+}
+
 int fx_comm_init_rank(fx_ctx* ctx, const void* id, size_t bytes, int rank, int nranks)
 {
 	if (!ctx || !id) return FX_E_INVALID;
@@ -732,6 +933,7 @@ int fx_comm_init_rank(fx_ctx* ctx, const void* id, size_t bytes, int rank, int n
 	g->members.push_back(ctx);
 	g->transport = t;
 	g->refs = 1;
+	if ((rc = make_comm_stream(g, ctx->device))) { delete t; delete g; return rc; }
 	ctx->group = g; ctx->rank = rank; ctx->nranks = nranks;
 	return FX_OK;
 }
@@ -752,6 +954,7 @@ int fx_comm_init_local(fx_ctx** ctxs, int nranks)
 	fx_comm_group* g = new fx_comm_group();
 	g->transport = make_local_transport();
 	g->refs = nranks;
+	if (int rc = make_comm_stream(g, ctxs[0]->device)) { delete g->transport; delete g; return rc; }
 	for (int r = 0; r < nranks; ++r) {
 		g->members.push_back(ctxs[r]);
 		ctxs[r]->group = g; ctxs[r]->rank = r; ctxs[r]->nranks = nranks;

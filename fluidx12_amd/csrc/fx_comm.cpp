@@ -15,50 +15,68 @@
 
 namespace fx {
 
-int exchange_arrays(fx_ctx* c, int which_set, ExchArray out[4])
+int exchange_items(fx_ctx* c, int which_set, int k, int pidx, ExchItem out[4])
 {
 	const size_t plane = c->g.plane();
 	const size_t es = c->half ? 2 : 4;
 	switch (which_set) {
-	case EX_ADVECT_IN:      // what advection gathers from: velocity[0] and colour[!parity]
-		out[0] = ExchArray{ (char*)c->vel[0], plane * es, 3 };
-		out[1] = ExchArray{ (char*)c->col[1 - c->frame_parity], plane * es * 4, 1 };
+	case EX_ADVECT_IN:
+		out[0] = ExchItem{ (char*)c->vel[0], plane * es, 3, k };
+		out[1] = ExchItem{ (char*)c->col[1 - c->frame_parity], plane * es * 4, 1, k };
 		return 2;
-	case EX_VEL1:           // advected velocity, read by the divergence on the halo planes
-		out[0] = ExchArray{ (char*)c->vel[1], plane * es, 3 };
+	case EX_UZ1:
+		out[0] = ExchItem{ (char*)c->vel[1] + 2 * (size_t)c->g.nzl() * plane * es, plane * es, 1, k };
+		return 1;
+	case EX_DIV:
+		out[0] = ExchItem{ (char*)c->b, plane * 4, 1, k };
 		return 1;
 	case EX_PRESSURE:
-		out[0] = ExchArray{ (char*)c->p[c->p_cur], plane * 4, 1 };
-		return 1;
+		out[0] = ExchItem{ (char*)c->p[pidx & 1], plane * 4, 1, k };
+		if (!c->frozen) return 1;
+		out[1] = ExchItem{ (char*)c->frozen, plane, 1, k };      // the neighbour's freeze state travels with its pressure
+		return 2;
 	}
 	return 0;
+}
+
+void halo_segments(const fx_ctx* c, const ExchItem* items, int n, std::vector<Seg>& out)
+{
+	const Geom& g = c->g;
+	for (int i = 0; i < n; ++i) {
+		const ExchItem& it = items[i];
+		if (it.k <= 0) continue;
+		const size_t pb = it.plane_bytes, bytes = (size_t)it.k * pb;
+		for (int cpt = 0; cpt < it.ncomp; ++cpt) {
+			char* base = it.base + (size_t)cpt * g.nzl() * pb;
+			if (c->rank > 0)                     // bottom k owned planes go down, the lower halo fills from below
+				out.push_back(Seg{ base + (size_t)g.H * pb, base + (size_t)(g.H - it.k) * pb, bytes, -1 });
+			if (c->rank + 1 < c->nranks)         // top k owned planes go up, the upper halo fills from above
+				out.push_back(Seg{ base + (size_t)(g.H + g.nz - it.k) * pb, base + (size_t)(g.H + g.nz) * pb, bytes, +1 });
+		}
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
 struct LocalTransport : Transport {
 	bool is_local() const override { return true; }
-	int exchange(fx_comm_group* grp, int which_set, int k, hipStream_t s) override
+	int exchange(fx_comm_group* grp, const std::vector<std::vector<Seg>>& segs, hipStream_t s) override
 	{
 		const int n = (int)grp->members.size();
-		for (int r = 0; r + 1 < n; ++r) {
-			fx_ctx* lo = grp->members[r];
-			fx_ctx* hi = grp->members[r + 1];
-			ExchArray a[4], bb[4];
-			const int na = exchange_arrays(lo, which_set, a);
-			exchange_arrays(hi, which_set, bb);
-			for (int i = 0; i < na; ++i)
-				for (int cpt = 0; cpt < a[i].count; ++cpt) {
-					const size_t pb = a[i].plane_bytes;
-					char* lob = a[i].base + (size_t)cpt * lo->g.nzl() * pb;
-					char* hib = bb[i].base + (size_t)cpt * hi->g.nzl() * pb;
-					// lo's top k owned planes -> hi's lower halo
-					if (hipMemcpyAsync(hib + (size_t)(hi->g.H - k) * pb, lob + (size_t)(lo->g.H + lo->g.nz - k) * pb,
-							(size_t)k * pb, hipMemcpyDeviceToDevice, s) != hipSuccess) return FX_E_DEVICE;
-					// hi's bottom k owned planes -> lo's upper halo
-					if (hipMemcpyAsync(lob + (size_t)(lo->g.H + lo->g.nz) * pb, hib + (size_t)hi->g.H * pb,
-							(size_t)k * pb, hipMemcpyDeviceToDevice, s) != hipSuccess) return FX_E_DEVICE;
+		if ((int)segs.size() != n) return FX_E_STATE;
+		// every member "receives": its j-th segment from direction d pairs with the peer's j-th segment towards -d
+		for (int r = 0; r < n; ++r)
+			for (int d = -1; d <= 1; d += 2) {
+				const int peer = r + d;
+				if (peer < 0 || peer >= n) continue;
+				size_t jp = 0;
+				for (const Seg& mine : segs[r]) {
+					if (mine.dir != d) continue;
+					while (jp < segs[peer].size() && segs[peer][jp].dir != -d) ++jp;
+					if (jp == segs[peer].size() || segs[peer][jp].bytes != mine.bytes) return FX_E_STATE;   // the lists must mirror
+					if (hipMemcpyAsync(mine.recv, segs[peer][jp].send, mine.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return FX_E_DEVICE;
+					++jp;
 				}
-		}
+			}
 		return FX_OK;
 	}
 };
@@ -120,26 +138,18 @@ struct RcclTransport : Transport {
 	int rank, nranks;
 	bool is_local() const override { return false; }
 	~RcclTransport() override { if (comm) api->CommDestroy(comm); }
-	int exchange(fx_comm_group* grp, int which_set, int k, hipStream_t s) override
+	int exchange(fx_comm_group* grp, const std::vector<std::vector<Seg>>& segs, hipStream_t s) override
 	{
 		fx_ctx* c = grp->members[0];
-		ExchArray a[4];
-		const int na = exchange_arrays(c, which_set, a);
-		const Geom& g = c->g;
+		if (segs.size() != 1) return FX_E_STATE;
 		ncclResult_t r = api->GroupStart();
-		for (int i = 0; i < na && r == ncclSuccess; ++i)
-			for (int cpt = 0; cpt < a[i].count && r == ncclSuccess; ++cpt) {
-				const size_t pb = a[i].plane_bytes, n = (size_t)k * pb;
-				char* base = a[i].base + (size_t)cpt * g.nzl() * pb;
-				if (rank > 0) {          // lower z-neighbour
-					r = api->Send(base + (size_t)g.H * pb, n, ncclInt8, rank - 1, comm, s);
-					if (r == ncclSuccess) r = api->Recv(base + (size_t)(g.H - k) * pb, n, ncclInt8, rank - 1, comm, s);
-				}
-				if (rank + 1 < nranks && r == ncclSuccess) {   // upper z-neighbour
-					r = api->Send(base + (size_t)(g.H + g.nz - k) * pb, n, ncclInt8, rank + 1, comm, s);
-					if (r == ncclSuccess) r = api->Recv(base + (size_t)(g.H + g.nz) * pb, n, ncclInt8, rank + 1, comm, s);
-				}
-			}
+		for (const Seg& sg : segs[0]) {
+			if (r != ncclSuccess) break;
+			const int peer = rank + sg.dir;
+			if (peer < 0 || peer >= nranks) { r = ncclInvalidArgument; break; }
+			r = api->Send(sg.send, sg.bytes, ncclInt8, peer, comm, s);
+			if (r == ncclSuccess) r = api->Recv(sg.recv, sg.bytes, ncclInt8, peer, comm, s);
+		}
 		const ncclResult_t e = api->GroupEnd();
 		if (r == ncclSuccess) r = e;
 		if (r != ncclSuccess) { c->last_error = std::string("rccl: ") + api->GetErrorString(r); return FX_E_COMM; }

@@ -59,16 +59,21 @@ struct fx_ctx {
 
 namespace fx {
 
-// one array taking part in a halo exchange: `count` back-to-back sub-arrays (velocity = 3
-// component planes) of nzl planes each, plane_bytes per plane
-struct ExchArray { char* base; size_t plane_bytes; int count; };
+// one array taking part in a halo exchange: `ncomp` back-to-back sub-arrays (velocity = 3 component
+// planes) of nzl planes each, plane_bytes per plane, k boundary planes travelling to each z-neighbour
+struct ExchItem { char* base; size_t plane_bytes; int ncomp; int k; };
+
+// a run of whole planes travelling between z-neighbours: `send` goes to rank + dir, `recv` comes from it.
+// Both sides of a pair build their lists from the same items in the same order, so the j-th segment a rank
+// sends upwards is the j-th segment its upper neighbour receives from below (RCCL matches send/recv of a
+// pair in issue order; the loop-back transport pairs them by the same index).
+struct Seg { char* send; char* recv; size_t bytes; int dir; };
 
 // transport behind a group of slab contexts
 struct Transport {
 	virtual ~Transport() {}
-	// exchange the k boundary planes of every array between z-neighbours, for the given member
-	// (RCCL: the only member; local: called once per exchange with member == null -> all members)
-	virtual int exchange(fx_comm_group* grp, int which_set, int k, hipStream_t s) = 0;
+	// segs[i] = segments of grp->members[i] (RCCL: one member = this rank; loop-back: every rank)
+	virtual int exchange(fx_comm_group* grp, const std::vector<std::vector<Seg>>& segs, hipStream_t s) = 0;
 	virtual bool is_local() const = 0;
 };
 
@@ -78,12 +83,23 @@ struct fx_comm_group {
 	std::vector<fx_ctx*> members;   // local transport: every rank; RCCL: just this rank
 	fx::Transport* transport;
 	int refs;
+	// side stream the overlapped exchanges run on, and the two events that order it against the compute
+	// stream: ev_ready = "the planes to send are final" (compute -> comm), ev_done = "halos have arrived"
+	hipStream_t comm_stream;
+	hipEvent_t ev_ready, ev_done;
 };
 
 namespace fx {
-enum ExchSet { EX_ADVECT_IN = 0, EX_VEL1 = 1, EX_PRESSURE = 2 };
-// arrays of one member for an exchange set
-int exchange_arrays(fx_ctx* c, int which_set, ExchArray out[4]);
+enum ExchSet {
+	EX_ADVECT_IN = 0,   // what advection gathers from: velocity[0] (3 components) and colour[!parity]
+	EX_UZ1 = 1,         // z-component of the advected velocity: all the divergence reads across a slab face
+	EX_DIV = 2,         // divergence b
+	EX_PRESSURE = 3     // pressure buffer `pidx` (+ the freeze mask in faithful mode)
+};
+// items of one member for an exchange set; returns their number (<= 4)
+int exchange_items(fx_ctx* c, int which_set, int k, int pidx, ExchItem out[4]);
+// append the segments of `items` for the neighbours this member has
+void halo_segments(const fx_ctx* c, const ExchItem* items, int n, std::vector<Seg>& out);
 Transport* make_local_transport();
 Transport* make_rccl_transport(const void* id, size_t bytes, int rank, int nranks, int device, std::string* err);
 size_t rccl_id_bytes();

@@ -70,7 +70,7 @@ class Fluid:
 
     # ---- Fluid::Init (Fluid.cpp:189-270) ----------------------------------------------------------
     def Init(self, width, height, gridSize, *, storage="fp32", jacobi_iters=40, jacobi_mode="fixed",
-             advect_address="clamp", device=-1, slab=None, halo_advect=0, halo_jacobi=0, jacobi_fuse=0):
+             advect_address="clamp", device=-1, slab=None, halo_advect=0, halo_jacobi=0, jacobi_fuse=0, overlap=True):
         if self._ctx:
             self.Release()
         X, Y, Z = (int(v) for v in gridSize)
@@ -86,7 +86,7 @@ class Fluid:
         if slab is not None:
             d.slab_z0, d.slab_nz = int(slab[0]), int(slab[1])
         d.halo_advect, d.halo_jacobi = int(halo_advect), int(halo_jacobi)
-        d.flags = int(jacobi_fuse) & 0xF
+        d.flags = (int(jacobi_fuse) & 0xF) | (0 if overlap else capi.FLAG_NO_OVERLAP)
         self.last_status = self._lib.fx_create(C.byref(self._ctx), C.byref(d))
         if self.last_status != capi.FX_OK:      # the reference's Init returns false (XUSG_N_RETURN)
             self._ctx = C.c_void_p()

@@ -84,6 +84,9 @@ typedef struct fx_desc {
 /* fx_desc.flags: bits 0-3 = Jacobi sweeps fused per launch (temporal blocking), 0 = library default,
  * 1 = one launch per sweep; results are bit-identical for every setting */
 #define FX_FLAG_JACOBI_FUSE_MASK 0xFu
+/* multi-rank contexts: keep every halo exchange on the compute stream (no side comm stream, no face-first
+ * ordering); results are bit-identical either way -- the switch exists to measure what the overlap buys */
+#define FX_FLAG_NO_OVERLAP 0x10u
 
 /* values Fluid::UpdateFrame derives (Fluid.cpp:324-333) */
 typedef struct fx_frame_info {

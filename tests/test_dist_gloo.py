@@ -30,7 +30,7 @@ def test_bench_two_ranks_gloo_dry_run():
     assert len(lines) == 1, r.stdout                      # rank 0 prints ONE line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["dry_run"] is True
-    assert d["scaling"] == "strong" and d["unit"] == "voxel-updates/s" and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["unit"] == "voxel-updates/s" and d["higher_is_better"] is True
     assert d["config"]["parallelism"].startswith("z-slab x2")
     assert "cpu_baseline" not in d                        # rank 0 at N = 1 only
 

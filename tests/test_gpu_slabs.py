@@ -42,23 +42,50 @@ def gather(fl, field, axis):
     return np.concatenate([f.download(field) for f in fl], axis=axis)
 
 
+@pytest.mark.parametrize("overlap", [True, False])
 @pytest.mark.parametrize("nranks", [2, 4])
-@pytest.mark.parametrize("iters,hj", [(40, 4), (10, 3), (7, 8)])
-def test_slabs_equal_single_domain(nranks, iters, hj):
+@pytest.mark.parametrize("iters,hj", [(40, 4), (10, 3), (7, 8), (5, 1)])
+def test_slabs_equal_single_domain(nranks, iters, hj, overlap):
+    """overlap=True: exchanges on the side stream behind interior work (face planes first); False: everything on one stream"""
     dims = (64, 64, 64)
     steps = 6
     ref = run_single(dims, steps, jacobi_iters=iters)
-    fl = run_slabs(dims, steps, nranks, jacobi_iters=iters, halo_jacobi=hj, halo_advect=8)
+    fl = run_slabs(dims, steps, nranks, jacobi_iters=iters, halo_jacobi=hj, halo_advect=6, overlap=overlap)
     assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
     assert np.array_equal(gather(fl, fx.FIELD_COLOR, 0), ref.download(fx.FIELD_COLOR))
     assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
 
 
-@pytest.mark.parametrize("fuse", [2, 4])
-def test_slabs_with_temporal_blocking(fuse):
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("fuse,iters", [(2, 12), (4, 12), (2, 11), (3, 13)])
+def test_slabs_with_temporal_blocking(fuse, iters, overlap):
     dims = (64, 64, 96)
-    ref = run_single(dims, 4, jacobi_iters=12, jacobi_fuse=1)
-    fl = run_slabs(dims, 4, 3, jacobi_iters=12, halo_jacobi=4, halo_advect=8, jacobi_fuse=fuse)
+    ref = run_single(dims, 4, jacobi_iters=iters, jacobi_fuse=1)
+    fl = run_slabs(dims, 4, 3, jacobi_iters=iters, halo_jacobi=4, halo_advect=8, jacobi_fuse=fuse, overlap=overlap)
+    assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
+    assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("dims,nranks,hj", [((512, 512, 48), 3, 8), ((512, 512, 32), 2, 6), ((256, 256, 64), 2, 8)])
+def test_slabs_with_register_strips(dims, nranks, hj, overlap):
+    """the two-sweep register-strip Jacobi kernels (X = 512: the wide two-float4-per-lane kernel; X = 256: the
+    float4-per-lane one) inside the slab schedule: shrinking ranges, odd remainders and slab boundaries equal the
+    one-sweep-per-launch single-domain run bit-for-bit"""
+    ref = run_single(dims, 3, jacobi_iters=14, jacobi_fuse=1)
+    fl = run_slabs(dims, 3, nranks, jacobi_iters=14, halo_jacobi=hj, halo_advect=8, jacobi_fuse=2, overlap=overlap)
+    assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
+    assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
+    assert np.array_equal(gather(fl, fx.FIELD_COLOR, 0), ref.download(fx.FIELD_COLOR))
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_slabs_faithful_mode(overlap):
+    """reference-faithful Jacobi (64-sweep cap, per-cell freeze at |delta| < 1e-3): the freeze mask of the face planes
+    travels with the pressure halo, so the decomposed run freezes exactly the cells the single domain freezes"""
+    dims = (48, 48, 48)
+    ref = run_single(dims, 5, jacobi_mode="faithful", jacobi_iters=64)
+    fl = run_slabs(dims, 5, 3, jacobi_mode="faithful", jacobi_iters=64, halo_jacobi=2, halo_advect=6, overlap=overlap)
     assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
     assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
 
