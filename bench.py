@@ -64,6 +64,11 @@ def workload_grid(G, N, scaling):
     return table.get(N, ((G, G, G * N), 6 * N + 2))
 
 
+# (FX_OPT_OVERLAP, FX_OPT_JACOBI_ROUND): advection halo behind the interior advection + serial pressure rounds of 8 sweeps;
+# pressure exchanges behind the interior sweeps of rounds of 8 and of 4 sweeps (face planes first); nothing overlapped
+SCHEDULE_CANDIDATES = [(1, 8), (2, 8), (2, 4), (0, 8)]
+
+
 def slab_for_rank(Z, rank, world):
     z0 = rank * Z // world
     z1 = (rank + 1) * Z // world
@@ -110,6 +115,8 @@ def main():
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--storage", default="fp32", choices=["fp32", "fp16"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="how the grid grows with --gpus (N > 1)")
+    ap.add_argument("--schedule", default="auto", help="N > 1: 'auto' times the slab schedules below for 3 steps each before the "
+                    "warm-up and keeps the fastest, or 'OVERLAP,ROUND' (fx_set_option values) to pin one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-render", action="store_true", help="skip the (untimed-for-value) ray-march measurement")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -179,6 +186,41 @@ def main():
                 import torch
                 torch.cuda.synchronize()
             dist.barrier()
+
+    # ---- N > 1: which slab schedule (what travels behind what; results are bit-identical for all of them) -------------------
+    # Link bandwidth, RCCL launch latency and cross-stream event latency decide this, none of which a 1-GPU box can
+    # measure, so the bench measures it where it runs: every candidate gets 1 settling + 3 timed steps (untimed region).
+    schedule = None
+    if N > 1 and fluid is not None:
+        from fluidx12_amd import capi
+        import torch
+
+        def apply(ov, rnd):
+            fluid.set_option(capi.OPT_OVERLAP, ov)
+            fluid.set_option(capi.OPT_JACOBI_ROUND, rnd)
+
+        if args.schedule != "auto":
+            ov, rnd = (int(v) for v in args.schedule.split(","))
+            apply(ov, rnd)
+            schedule = {"overlap": ov, "jacobi_round": rnd, "picked": "pinned by --schedule"}
+        else:
+            tried = []
+            kk = 0
+            for ov, rnd in SCHEDULE_CANDIDATES:
+                apply(ov, rnd)
+                one_step(kk); kk += 1
+                barrier_sync()
+                t_ = time.perf_counter()
+                for _ in range(3):
+                    one_step(kk); kk += 1
+                barrier_sync()
+                el = torch.tensor([time.perf_counter() - t_], dtype=torch.float64).cuda()
+                dist.all_reduce(el, op=dist.ReduceOp.MAX)          # identical on every rank => identical pick
+                tried.append({"overlap": ov, "jacobi_round": rnd, "ms_per_step": float(el.item()) / 3 * 1e3})
+            best = min(tried, key=lambda c: c["ms_per_step"])
+            apply(best["overlap"], best["jacobi_round"])
+            schedule = {"overlap": best["overlap"], "jacobi_round": best["jacobi_round"],
+                        "picked": "fastest of the candidates timed before the warm-up", "candidates": tried}
 
     for k in range(args.warmup):
         one_step(k)
@@ -266,6 +308,7 @@ def main():
                                    "advect+divergence+Jacobi+project per step" % (GX, GY, GZ, GX * GY * GZ / N / 1e6, args.iters, args.storage),
                        "grid": [GX, GY, GZ], "jacobi_iters": args.iters, "storage": args.storage,
                        "parallelism": "single GPU" if N == 1 else "z-slab x%d (%d planes per rank), RCCL send/recv halo exchange" % (N, GZ // N),
+                       "schedule": schedule,
                        "bytes_per_voxel_step": step_bytes_per_voxel(args.iters, args.storage)},
         }
         if args.dry_run:

@@ -17,6 +17,7 @@ STORAGE_FP32, STORAGE_FP16 = 0, 1
 JACOBI_FIXED, JACOBI_FAITHFUL = 0, 1
 ADDRESS_CLAMP, ADDRESS_MIRROR = 0, 1
 FLAG_JACOBI_FUSE_MASK, FLAG_NO_OVERLAP = 0xF, 0x10
+OPT_OVERLAP, OPT_JACOBI_ROUND = 1, 2
 (FIELD_VELOCITY, FIELD_VELOCITY1, FIELD_COLOR, FIELD_COLOR_PREV, FIELD_PRESSURE, FIELD_DIVERGENCE,
  FIELD_LIGHTMAP, FIELD_CUBEMAP) = range(8)
 
@@ -65,6 +66,7 @@ SYMBOLS = {
     "fx_project": (C.c_int, [_vp, _vp]),
     "fx_sh_transform": (C.c_int, [_vp, _fp, C.c_uint32, _fp]),
     "fx_timing_enable": (C.c_int, [_vp, C.c_int]),
+    "fx_set_option": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "fx_timing_read": (C.c_int, [_vp, C.POINTER(Timing), C.c_int]),
     "fx_comm_id_bytes": (C.c_size_t, []),
     "fx_comm_get_unique_id": (C.c_int, [_vp, C.c_size_t]),

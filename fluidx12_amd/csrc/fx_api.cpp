@@ -103,7 +103,7 @@ void free_all(fx_ctx* c)
 		if (c->col[i]) (void)hipFree(c->col[i]);
 		if (c->p[i]) (void)hipFree(c->p[i]);
 	}
-	void* others[] = { c->b, c->frozen, c->lightmap, c->cube, c->sh_dev, c->halo_overflow, c->stage,
+	void* others[] = { c->p_face[0], c->p_face[1], c->b, c->frozen, c->lightmap, c->cube, c->sh_dev, c->halo_overflow, c->stage,
 		c->sh_scratch[0], c->sh_scratch[1], c->sh_scratch[2], c->sh_scratch[3] };
 	for (void* q : others) if (q) (void)hipFree(q);
 	for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -128,9 +128,8 @@ Range grown(const fx_ctx* c, int by)
 //   2  exchange 1 plane of the advected uz ; divergence on the owned planes
 //   3  exchange k-1 planes of b and k planes of p (one message group)
 //   4  per round of k sweeps: the k planes next to each face are brought to the round's last level first
-//      ("face tasks", from the exchanged halo), [comm] they travel to the neighbour || [compute] the interior
-//      follows.  A round is one or two fused launches (k <= 2 x sweeps-per-launch), which is what keeps the
-//      ping-pong buffers free of read/write conflicts between the face tasks and the interior (see jacobi_overlapped)
+//      (thin single-sweep launches over both face zones, from the exchanged halo), [comm] they travel to the
+//      neighbour || [compute] the interior follows with the fused-sweep kernels (see jacobi_overlapped)
 //   5  projection (reads the 1st halo plane of the last exchange)
 // Every cell is computed with the arithmetic of the single-domain run, so results are bit-identical.
 int for_members(fx_ctx* ctx, std::vector<fx_ctx*>& out)
@@ -143,12 +142,11 @@ int for_members(fx_ctx* ctx, std::vector<fx_ctx*>& out)
 
 bool multi_rank(const fx_ctx* c) { return c->group && c->nranks > 1; }
 
-bool overlap_enabled(const fx_ctx* lead)
+// 0 = no side stream, 1 = advection halo overlapped, 2 = pressure rounds overlapped as well (fx_set_option)
+int overlap_level(const fx_ctx* lead)
 {
-	if (!multi_rank(lead) || !lead->group->comm_stream) return false;
-	if (lead->desc.flags & FX_FLAG_NO_OVERLAP) return false;
-	const char* e = std::getenv("FLUIDX_OVERLAP");
-	return !(e && e[0] == '0');
+	if (!multi_rank(lead) || !lead->group->comm_stream) return 0;
+	return lead->opt_overlap;
 }
 
 struct ExchSpec { int set, k, pidx; };
@@ -206,7 +204,7 @@ int advect_all(fx_ctx* ctx, std::vector<fx_ctx*>& M, hipStream_t s)
 	int rc;
 	const int Ha = (int)ctx->desc.halo_advect;
 	const ExchSpec spec{ EX_ADVECT_IN, Ha, 0 };
-	bool ov = overlap_enabled(ctx);
+	bool ov = overlap_level(ctx) >= 1;
 	for (fx_ctx* m : M) if (m->g.nz <= 2 * Ha) ov = false;
 	if (!ov) {
 		if ((rc = do_exchange(ctx, M, &spec, 1, s))) return rc;
@@ -287,7 +285,7 @@ int clear_freeze_masks(std::vector<fx_ctx*>& M, hipStream_t s)
 int jacobi_serial(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t iters)
 {
 	const bool multi = multi_rank(lead);
-	const int k = multi ? (int)lead->desc.halo_jacobi : (int)iters;
+	const int k = multi ? lead->opt_round : (int)iters;
 	int rc;
 	if ((rc = clear_freeze_masks(M, s))) return rc;
 	const ExchSpec bspec{ EX_DIV, k - 1, 0 };
@@ -307,20 +305,20 @@ int jacobi_serial(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t
 	return do_exchange(lead, M, &last, 1, s);
 }
 
-// Rounds of k = t1 + t2 sweeps (t1, t2 <= sweeps per launch) with the pressure exchange of round r hidden behind
-// the interior sweeps of rounds r and r+1.  With src = the buffer holding the round's level 0 (halo k planes valid):
-//   two launches per round:
-//     I1  src -> dst, t1 sweeps, planes [lo + k + t2, hi - k - t2)        reads owned planes only
-//     (wait: the halo of src has arrived)
-//     L1  src -> dst, t1 sweeps, planes [lo - t2, lo + k + t2)            level t1 next to the face (U1 mirrored)
-//     L2  dst -> src, t2 sweeps, planes [lo, lo + k)                      the k planes the neighbour needs, final level
-//     [comm] send src[lo, lo + k), receive src[lo - k, lo)               || I2  dst -> src, t2 sweeps, [lo + k, hi - k)
-//   one launch per round: L (src -> dst on [lo, lo + k)), [comm] exchange dst || I (src -> dst on [lo + k, hi - k)).
-// Ordering on the compute stream makes I1 read src before L2 overwrites part of it; the comm stream only ever
-// touches the buffer that is `src` of the NEXT round: its k face planes (read) and its halo planes (written), which the
-// interior launches of this round (writing [lo + k, hi - k) of it) and I1 of the next round (reading owned planes
-// of it, writing the other buffer) do not touch.  No plane is swept twice at the same level by one rank, so the
-// freeze mask of the faithful mode stays exact as well.
+// Rounds of up to k sweeps with the pressure exchange of a round hidden behind its interior sweeps.
+// With lo/hi = the owned planes, src = the buffer holding the round's level 0 (k halo planes valid), cnt <= k sweeps
+// in the round, done as m launches of t_1 <= t_2 = ... = t_m fused sweeps (c_j = t_1 + ... + t_j):
+//   face chain   cnt single sweeps over BOTH face zones per launch, level s on [lo - (cnt - s), lo + k + (cnt - s))
+//                (mirrored at hi).  Levels live in two scratch buffers, except level c_j, which goes into the real
+//                buffer interior launch j + 1 reads, and level cnt (planes [lo, lo + k)), which goes into the
+//                buffer that ends the round -- the k planes the neighbour needs, ready before the interior starts.
+//   [comm]       send those k planes, receive the neighbour's into the halo        ||
+//   interior     launch j: level c_(j-1) -> c_j on [lo + k + (cnt - c_j), hi - k - (cnt - c_j))
+// The zone the face chain writes at level c_j ends exactly where the reads of interior launch j - 1 in the same
+// buffer begin (t_j >= t_(j-1): the short launch comes first), and the comm stream touches only the k face planes and
+// the halo planes of the round's last buffer, which no interior launch reads or writes.  Every (cell, level) is
+// computed once per rank, so the freeze mask of the faithful mode stays exact, and each with the arithmetic of the
+// single-domain sweep.
 int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t iters, int t, int k)
 {
 	int rc;
@@ -331,25 +329,24 @@ int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint
 	uint32_t done = 0;
 	while (done < iters) {
 		const int cnt = (int)std::min<uint32_t>(k, iters - done);
-		const int t1 = std::min(t, cnt), t2 = cnt - t1;
-		const int src = lead->p_cur, fin = t2 ? src : src ^ 1;
-		if (t2)
-			for (fx_ctx* m : M) {
-				ScopedMark mk(m, s, MK_JACOBI);
-				const Range o = owned(m);
-				if ((rc = jacobi_launch(m, s, src, t1, Range{ has_lower(m) ? o.lo + k + t2 : o.lo, has_upper(m) ? o.hi - k - t2 : o.hi }, &mk))) return rc;
-			}
+		const int m = (cnt + t - 1) / t, t_first = cnt - (m - 1) * t;
+		const int src = lead->p_cur, fin = src ^ (m & 1);
 		if (in_flight) { if ((rc = comm_join(lead, s))) return rc; in_flight = false; }
-		for (fx_ctx* m : M) {
-			ScopedMark mk(m, s, MK_JACOBI);
-			const Range o = owned(m);
-			if (has_lower(m)) {
-				if ((rc = jacobi_launch(m, s, src, t1, Range{ o.lo - t2, o.lo + k + t2 }, nullptr))) return rc;
-				if (t2 && (rc = jacobi_launch(m, s, src ^ 1, t2, Range{ o.lo, o.lo + k }, nullptr))) return rc;
-			}
-			if (has_upper(m)) {
-				if ((rc = jacobi_launch(m, s, src, t1, Range{ o.hi - k - t2, o.hi + t2 }, nullptr))) return rc;
-				if (t2 && (rc = jacobi_launch(m, s, src ^ 1, t2, Range{ o.hi - k, o.hi }, nullptr))) return rc;
+		for (fx_ctx* ctx : M) {                            // face chain
+			if (!has_lower(ctx) && !has_upper(ctx)) continue;
+			DeviceGuard dg(ctx->device);
+			ScopedMark mk(ctx, s, MK_JACOBI);
+			const Range o = owned(ctx);
+			const float* in = ctx->p[src];
+			for (int lvl = 1; lvl <= cnt; ++lvl) {
+				const int rem = cnt - lvl;
+				float* out = ctx->p_face[lvl & 1];
+				if (lvl == cnt) out = ctx->p[fin];
+				else if (lvl >= t_first && (lvl - t_first) % t == 0) out = ctx->p[src ^ (((lvl - t_first) / t + 1) & 1)];   // level c_j -> input of launch j + 1
+				const Range lo{ o.lo - rem, has_lower(ctx) ? o.lo + k + rem : o.lo - rem };
+				const Range hi{ has_upper(ctx) ? o.hi - k - rem : o.hi + rem, o.hi + rem };
+				FX_HIP(launch_jacobi_sweep2(ctx->g, in, ctx->b, out, ctx->frozen, lo.lo, lo.hi, hi.lo, hi.hi, s));
+				in = out;
 			}
 		}
 		if ((rc = comm_fork(lead, s))) return rc;
@@ -357,12 +354,19 @@ int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint
 		if ((rc = do_exchange(lead, M, &pspec, 1, lead->group->comm_stream))) return rc;
 		if ((rc = comm_mark_done(lead))) return rc;
 		in_flight = true;
-		for (fx_ctx* m : M) {
-			ScopedMark mk(m, s, MK_JACOBI);
-			const Range o = owned(m);
-			const Range in{ has_lower(m) ? o.lo + k : o.lo, has_upper(m) ? o.hi - k : o.hi };
-			if ((rc = jacobi_launch(m, s, t2 ? src ^ 1 : src, t2 ? t2 : t1, in, &mk))) return rc;
-			m->p_cur = fin;
+		for (fx_ctx* ctx : M) {                            // interior
+			ScopedMark mk(ctx, s, MK_JACOBI);
+			const Range o = owned(ctx);
+			int lvl = 0, cur = src;
+			for (int j = 0; j < m; ++j) {
+				const int tj = j == 0 ? t_first : t;
+				lvl += tj;
+				const int rem = cnt - lvl;
+				const Range in{ has_lower(ctx) ? o.lo + k + rem : o.lo, has_upper(ctx) ? o.hi - k - rem : o.hi };
+				if ((rc = jacobi_launch(ctx, s, cur, tj, in, &mk))) return rc;
+				cur ^= 1;
+			}
+			ctx->p_cur = fin;
 		}
 		done += cnt;
 	}
@@ -372,12 +376,12 @@ int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint
 
 int jacobi_all(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t iters)
 {
-	if (overlap_enabled(lead)) {
+	if (overlap_level(lead) >= 2) {
 		int t = fused_sweeps(lead);
 		for (fx_ctx* m : M) t = std::min(t, fused_sweeps(m));
-		const int k = std::min((int)lead->desc.halo_jacobi, 2 * t);
+		const int k = lead->opt_round;
 		bool ok = true;
-		for (fx_ctx* m : M) if (m->g.nz < 3 * k + 2) ok = false;      // room for two face zones and an interior
+		for (fx_ctx* m : M) if (m->g.nz < 4 * k || !m->p_face[0]) ok = false;    // two face zones (<= 2k - 1 planes each) and an interior
 		if (ok) return jacobi_overlapped(lead, M, s, iters, t, k);
 	}
 	return jacobi_serial(lead, M, s, iters);
@@ -472,6 +476,8 @@ int fx_create(fx_ctx** out, const fx_desc* d)
 	ctx->device = dev;
 	ctx->max_ray_samples = 192; ctx->max_light_samples = 64;                  // Fluid.cpp:174-175
 	ctx->rank = 0; ctx->nranks = 1;
+	ctx->opt_overlap = (d->flags & FX_FLAG_NO_OVERLAP) ? 0 : 2;
+	ctx->opt_round = (int)ctx->desc.halo_jacobi;
 
 	DeviceGuard dg(dev);
 	if (!dg.ok) { delete ctx; return FX_E_DEVICE; }
@@ -488,6 +494,11 @@ int fx_create(fx_ctx** out, const fx_desc* d)
 			FX_HIP(hipMemsetAsync(ctx->col[i], 0, 4 * cells * es, ctx->stream));
 			FX_HIP(hipMemsetAsync(ctx->p[i], 0, cells * 4, ctx->stream));
 		}
+		if (slab)                                                            // scratch levels of the face chains (jacobi_overlapped)
+			for (int i = 0; i < 2; ++i) {
+				FX_HIP(hipMalloc((void**)&ctx->p_face[i], cells * 4));
+				FX_HIP(hipMemsetAsync(ctx->p_face[i], 0, cells * 4, ctx->stream));
+			}
 		FX_HIP(hipMalloc((void**)&ctx->b, cells * 4));
 		FX_HIP(hipMemsetAsync(ctx->b, 0, cells * 4, ctx->stream));
 		if (d->jacobi_mode == FX_JACOBI_FAITHFUL) {
@@ -916,6 +927,8 @@ static int make_comm_stream(fx_comm_group* g, int device)
 	DeviceGuard dg(device);
 	int lo = 0, hi = 0;
 	if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
+	const char* pe = std::getenv("FLUIDX_COMM_PRIORITY");           // 0 = default priority
+	if (pe && pe[0] == '0') hi = 0;
 	if (hipStreamCreateWithPriority(&g->comm_stream, hipStreamNonBlocking, hi) != hipSuccess) return FX_E_DEVICE;
 	if (hipEventCreateWithFlags(&g->ev_ready, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;
 	if (hipEventCreateWithFlags(&g->ev_done, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;
@@ -936,6 +949,22 @@ int fx_comm_init_rank(fx_ctx* ctx, const void* id, size_t bytes, int rank, int n
 	if ((rc = make_comm_stream(g, ctx->device))) { delete t; delete g; return rc; }
 	ctx->group = g; ctx->rank = rank; ctx->nranks = nranks;
 	return FX_OK;
+}
+
+int fx_set_option(fx_ctx* ctx, uint32_t option, uint32_t value)
+{
+	if (!ctx) return FX_E_INVALID;
+	switch (option) {
+	case FX_OPT_OVERLAP:
+		if (value > 2) return FX_E_INVALID;
+		ctx->opt_overlap = (int)value;
+		return FX_OK;
+	case FX_OPT_JACOBI_ROUND:
+		if (value < 1 || value > ctx->desc.halo_jacobi) return FX_E_INVALID;
+		ctx->opt_round = (int)value;
+		return FX_OK;
+	}
+	return FX_E_INVALID;
 }
 
 int fx_comm_init_local(fx_ctx** ctxs, int nranks)

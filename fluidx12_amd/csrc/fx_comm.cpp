@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace fx {
@@ -63,6 +64,9 @@ struct LocalTransport : Transport {
 	{
 		const int n = (int)grp->members.size();
 		if ((int)segs.size() != n) return FX_E_STATE;
+		// timing experiments only (results become wrong): keep the streams/events of the schedule, drop the copies
+		static const bool no_copy = [] { const char* e = std::getenv("FLUIDX_DEBUG_NO_COPY"); return e && e[0] == '1'; }();
+		if (no_copy) return FX_OK;
 		// every member "receives": its j-th segment from direction d pairs with the peer's j-th segment towards -d
 		for (int r = 0; r < n; ++r)
 			for (int d = -1; d <= 1; d += 2) {

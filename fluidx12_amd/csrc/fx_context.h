@@ -21,6 +21,7 @@ struct fx_ctx {
 	void* col[2];                   // rgba texels
 	float* p[2];                    // pressure ping-pong (m_incompress); p[p_cur] is current
 	int p_cur;
+	float* p_face[2];               // slab contexts: scratch levels of the Jacobi face chains (same geometry as p)
 	float* b;                       // divergence
 	uint8_t* frozen;                // faithful-mode freeze mask (null in fixed mode)
 	uint32_t* lightmap;             // R11G11B10F packed (m_lightMap), owned planes only
@@ -54,6 +55,8 @@ struct fx_ctx {
 	// ---- multi-GPU ------------------------------------------------------------------------------
 	fx_comm_group* group;           // null = single context
 	int rank, nranks;
+	int opt_overlap;                // FX_OPT_OVERLAP
+	int opt_round;                  // FX_OPT_JACOBI_ROUND
 	std::string last_error;
 };
 

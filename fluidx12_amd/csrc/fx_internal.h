@@ -49,6 +49,9 @@ hipError_t launch_divergence(const Geom& g, int half_store, const void* vel, flo
 // one lock-step sweep p_in -> p_out on planes [z_begin, z_end); frozen may be null
 hipError_t launch_jacobi_sweep(const Geom& g, const float* p_in, const float* b, float* p_out, uint8_t* frozen,
 	int z_begin, int z_end, hipStream_t s);
+// the same sweep over two disjoint plane ranges in one launch (the two face zones of a slab)
+hipError_t launch_jacobi_sweep2(const Geom& g, const float* p_in, const float* b, float* p_out, uint8_t* frozen,
+	int z_begin, int z_end, int z_begin2, int z_end2, hipStream_t s);
 // `sweeps` lock-step sweeps fused in one launch (temporal blocking); result in p_out.  Planes [z_begin, z_end)
 // of p_out are valid afterwards provided p_in/b are valid on [z_begin - sweeps, z_end + sweeps) (or the
 // global boundary).  Returns hipErrorNotSupported when the geometry has no fused path.

@@ -291,12 +291,13 @@ __global__ __launch_bounds__(256) void k_divergence_v4(const Geom g, const float
 //   x = ((((((qL - b) + qR) + qU) + qD) + qF) + qB) * (1/6)     2D: (((qL - b) + qR) + qU) + qD) * 1/4
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_jacobi_generic(const Geom g, const float* __restrict__ p_in,
-	const float* __restrict__ b, float* __restrict__ p_out, uint8_t* __restrict__ frozen, int z_begin, int nzp, int remap)
+	const float* __restrict__ b, float* __restrict__ p_out, uint8_t* __restrict__ frozen, int z_begin, int nzp, int remap,
+	int split, int z_begin2)
 {
 	const Tile3 tile = xcd_tile((g.X + 63) >> 6, (g.Y + 3) >> 2, nzp, remap);
 	const int x = tile.x * 64 + threadIdx.x;
 	const int y = tile.y * 4 + threadIdx.y;
-	const int z = z_begin + tile.z;
+	const int z = tile.z < split ? z_begin + tile.z : z_begin2 + (tile.z - split);    // two plane ranges in one launch
 	if (x >= g.X || y >= g.Y) return;
 	const size_t plane = g.plane();
 	const size_t zrow = (size_t)g.lz(z) * plane;
@@ -325,14 +326,15 @@ __global__ __launch_bounds__(256) void k_jacobi_generic(const Geom g, const floa
 // Neighbour rows/planes come through L1/L2 (each line is re-read by the 5 stencil partners).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_jacobi_v4(const Geom g, const float* __restrict__ p_in,
-	const float* __restrict__ b, float* __restrict__ p_out, int z_begin, int nzp, int remap, int rows_per_block)
+	const float* __restrict__ b, float* __restrict__ p_out, int z_begin, int nzp, int remap, int rows_per_block,
+	int split, int z_begin2)
 {
 	const int X4 = g.X >> 2;
 	const int lane = threadIdx.x;                       // float4 column
 	const Tile3 tile = xcd_tile((X4 + (int)blockDim.x - 1) / (int)blockDim.x, (g.Y + rows_per_block - 1) / rows_per_block, nzp, remap);
 	const int x4 = tile.x * blockDim.x + lane;
 	const int y = tile.y * rows_per_block + threadIdx.y;
-	const int z = z_begin + tile.z;
+	const int z = tile.z < split ? z_begin + tile.z : z_begin2 + (tile.z - split);    // two plane ranges in one launch
 	if (x4 >= X4 || y >= g.Y) return;
 	const size_t plane = g.plane();
 	const int yu = max(y, 1) - 1, yd = min(y + 1, g.Y - 1);
@@ -604,16 +606,27 @@ hipError_t launch_divergence(const Geom& g, int half_store, const void* vel, flo
 hipError_t launch_jacobi_sweep(const Geom& g, const float* p_in, const float* b, float* p_out, uint8_t* frozen,
 	int z_begin, int z_end, hipStream_t s)
 {
-	if (z_end <= z_begin) return hipSuccess;
-	const int nzp = z_end - z_begin;
+	return launch_jacobi_sweep2(g, p_in, b, p_out, frozen, z_begin, z_end, 0, 0, s);
+}
+
+// one sweep over two disjoint plane ranges (the two face zones of a slab) in a single launch
+hipError_t launch_jacobi_sweep2(const Geom& g, const float* p_in, const float* b, float* p_out, uint8_t* frozen,
+	int z_begin, int z_end, int z_begin2, int z_end2, hipStream_t s)
+{
+	if (z_end < z_begin) z_end = z_begin;
+	if (z_end2 < z_begin2) z_end2 = z_begin2;
+	const int split = z_end - z_begin;
+	const int nzp = split + (z_end2 - z_begin2);
+	if (nzp <= 0) return hipSuccess;
 	if (!frozen && g.Zg > 1 && (g.X & 3) == 0) {
 		const int X4 = g.X >> 2;
 		const int bx = X4 < 64 ? X4 : 64;               // float4 columns per block row
 		int by = 256 / bx; if (by < 1) by = 1; if (by > g.Y) by = g.Y;
 		const dim3 block(bx, by, 1), grid(((X4 + bx - 1) / bx) * ((g.Y + by - 1) / by) * nzp, 1, 1);
-		hipLaunchKernelGGL(k_jacobi_v4, grid, block, 0, s, g, p_in, b, p_out, z_begin, nzp, xcd_remap_on(REMAP_JACOBI), by);
+		hipLaunchKernelGGL(k_jacobi_v4, grid, block, 0, s, g, p_in, b, p_out, z_begin, nzp, xcd_remap_on(REMAP_JACOBI), by, split, z_begin2);
 	} else {
-		hipLaunchKernelGGL(k_jacobi_generic, grid_xyz(g, nzp), dim3(64, 4, 1), 0, s, g, p_in, b, p_out, frozen, z_begin, nzp, xcd_remap_on(REMAP_JACOBI));
+		hipLaunchKernelGGL(k_jacobi_generic, grid_xyz(g, nzp), dim3(64, 4, 1), 0, s, g, p_in, b, p_out, frozen, z_begin, nzp, xcd_remap_on(REMAP_JACOBI),
+			split, z_begin2);
 	}
 	return hipGetLastError();
 }

@@ -70,7 +70,7 @@ class Fluid:
 
     # ---- Fluid::Init (Fluid.cpp:189-270) ----------------------------------------------------------
     def Init(self, width, height, gridSize, *, storage="fp32", jacobi_iters=40, jacobi_mode="fixed",
-             advect_address="clamp", device=-1, slab=None, halo_advect=0, halo_jacobi=0, jacobi_fuse=0, overlap=True):
+             advect_address="clamp", device=-1, slab=None, halo_advect=0, halo_jacobi=0, jacobi_fuse=0, overlap=2):
         if self._ctx:
             self.Release()
         X, Y, Z = (int(v) for v in gridSize)
@@ -86,13 +86,16 @@ class Fluid:
         if slab is not None:
             d.slab_z0, d.slab_nz = int(slab[0]), int(slab[1])
         d.halo_advect, d.halo_jacobi = int(halo_advect), int(halo_jacobi)
-        d.flags = (int(jacobi_fuse) & 0xF) | (0 if overlap else capi.FLAG_NO_OVERLAP)
+        level = 2 if overlap is True else int(overlap)        # 0 none, 1 advection halo only, 2 (default) + pressure rounds
+        d.flags = (int(jacobi_fuse) & 0xF) | (0 if level else capi.FLAG_NO_OVERLAP)
         self.last_status = self._lib.fx_create(C.byref(self._ctx), C.byref(d))
         if self.last_status != capi.FX_OK:      # the reference's Init returns false (XUSG_N_RETURN)
             self._ctx = C.c_void_p()
             return False
         self.grid = (X, Y, Z)
         self.slab = (d.slab_z0, d.slab_nz if d.slab_nz else Z)
+        if level == 1:
+            self.set_option(capi.OPT_OVERLAP, 1)
         return True
 
     def Release(self):
@@ -205,6 +208,11 @@ class Fluid:
         t = capi.Timing()
         capi.check(self._lib.fx_timing_read(self._ctx, C.byref(t), int(reset)), "timing_read")
         return t
+
+    def set_option(self, option, value):
+        """slab schedule knobs (capi.OPT_OVERLAP 0/1/2, capi.OPT_JACOBI_ROUND 1..halo_jacobi); same on every rank"""
+        self._need()
+        capi.check(self._lib.fx_set_option(self._ctx, int(option), int(value)), "set_option")
 
     # ---- multi-GPU slabs ---------------------------------------------------------------------------------
     def comm_init_rank(self, unique_id, rank, nranks):

@@ -159,6 +159,16 @@ int fx_comm_get_unique_id(void* id_out, size_t bytes);
 int fx_comm_init_rank(fx_ctx* ctx, const void* id, size_t bytes, int rank, int nranks);
 int fx_comm_init_local(fx_ctx** ctxs, int nranks);
 
+/* How the slab schedule hides the exchanges; results are bit-identical for every setting, and every rank of a
+ * group must use the same values (a loop-back group reads those of its first context).
+ *   FX_OPT_OVERLAP       0 = every exchange on the compute stream;
+ *                        1 = the advection halo travels on a side stream behind the interior advection;
+ *                        2 = (default) additionally each pressure exchange travels behind the interior sweeps
+ *                            of its round (the face planes are swept first)
+ *   FX_OPT_JACOBI_ROUND  sweeps per pressure exchange, 1 .. fx_desc.halo_jacobi (default = halo_jacobi) */
+enum fx_option { FX_OPT_OVERLAP = 1, FX_OPT_JACOBI_ROUND = 2 };
+int fx_set_option(fx_ctx* ctx, uint32_t option, uint32_t value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,7 +42,7 @@ def gather(fl, field, axis):
     return np.concatenate([f.download(field) for f in fl], axis=axis)
 
 
-@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("overlap", [2, 1, 0])
 @pytest.mark.parametrize("nranks", [2, 4])
 @pytest.mark.parametrize("iters,hj", [(40, 4), (10, 3), (7, 8), (5, 1)])
 def test_slabs_equal_single_domain(nranks, iters, hj, overlap):
@@ -133,6 +133,30 @@ def test_rccl_transport_single_rank():
         f.Simulate(k)
     f.Synchronize()
     assert np.array_equal(f.download(fx.FIELD_VELOCITY), ref.download(fx.FIELD_VELOCITY))
+
+
+def test_schedule_options_at_run_time():
+    """fx_set_option switches the schedule between steps; every setting continues the same bit-exact trajectory"""
+    dims = (64, 64, 96)
+    ref = run_single(dims, 6, jacobi_iters=16)
+    fl = []
+    for r in range(3):
+        f = fx.Fluid()
+        assert f.Init(800, 800, dims, slab=(r * 32, 32), jacobi_iters=16, halo_jacobi=8, halo_advect=6)
+        fl.append(f)
+    fx.comm_init_local(fl)
+    settings = [(2, 8), (1, 8), (2, 4), (0, 3), (2, 2), (2, 1)]
+    for k, (ov, rnd) in enumerate(settings):
+        for f in fl:
+            f.set_option(capi.OPT_OVERLAP, ov)
+            f.set_option(capi.OPT_JACOBI_ROUND, rnd)
+        fl[0].UpdateFrame(f32(fl[0].default_time_step()), k % 3)
+        fl[0].Simulate(k % 3)
+    fl[0].Synchronize()
+    assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
+    assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
+    with pytest.raises(fx.FluidxError):
+        fl[0].set_option(capi.OPT_JACOBI_ROUND, 9)
 
 
 def test_slab_descriptor_validation():
