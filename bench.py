@@ -257,15 +257,17 @@ def main():
             fluid.Synchronize()
             fluid.timing_read(reset=True)
             nr = 5
+            fluid.ClearRenderTarget()
             for _ in range(nr):
-                fluid.Render(0, fx.Fluid.OPTIMIZED)
+                fluid.Render(0, fx.Fluid.OPTIMIZED, to_target=True)     # + renderCube: cube map -> 1920x1080 RGBA8 target
             fluid.Synchronize()
             tr_ = fluid.timing_read(reset=True)
             fi = fluid.frame_info()
             rays = bin(fi.visibility_mask).count("1") * fi.cube_size ** 2
-            render = {"mode": "OPTIMIZED (CSRayMarchL + CSRayMarchV)", "viewport": [1920, 1080], "cube_lod": fi.cube_lod,
+            render = {"mode": "OPTIMIZED (CSRayMarchL + CSRayMarchV) + renderCube (PSRayCastCube, raster-free)", "viewport": [1920, 1080], "cube_lod": fi.cube_lod,
                       "cube_size": fi.cube_size, "ray_samples": fi.ray_samples, "light_samples": 64, "rays": rays,
                       "light_pass_ms": tr_.light_ms / nr, "view_pass_ms": tr_.view_ms / nr,
+                      "cube_resolve_ms": tr_.resolve_ms / nr,
                       "rays_per_s": rays / (tr_.view_ms / nr * 1e-3) if tr_.view_ms > 0 else None,
                       "light_voxels_per_s": float(G) ** 3 / (tr_.light_ms / nr * 1e-3) if tr_.light_ms > 0 else None}
         fluid.timing_enable(False)

@@ -18,8 +18,9 @@ JACOBI_FIXED, JACOBI_FAITHFUL = 0, 1
 ADDRESS_CLAMP, ADDRESS_MIRROR = 0, 1
 FLAG_JACOBI_FUSE_MASK, FLAG_NO_OVERLAP = 0xF, 0x10
 OPT_OVERLAP, OPT_JACOBI_ROUND = 1, 2
+ABI_VERSION = 2                      # FX_ABI_VERSION of include/fluidx_hip.h
 (FIELD_VELOCITY, FIELD_VELOCITY1, FIELD_COLOR, FIELD_COLOR_PREV, FIELD_PRESSURE, FIELD_DIVERGENCE,
- FIELD_LIGHTMAP, FIELD_CUBEMAP) = range(8)
+ FIELD_LIGHTMAP, FIELD_CUBEMAP, FIELD_TARGET, FIELD_TARGET_FLOAT) = range(10)
 
 
 class Desc(C.Structure):
@@ -33,14 +34,14 @@ class Desc(C.Structure):
 class FrameInfo(C.Structure):
     _fields_ = [("cube_lod", C.c_uint32), ("cube_size", C.c_uint32), ("ray_samples", C.c_uint32),
                 ("visibility_mask", C.c_uint32), ("frame_parity", C.c_uint32), ("edge_pixels", C.c_float),
-                ("time_step", C.c_float)]
+                ("time_step", C.c_float), ("world_view_proj_i", C.c_float * 16)]
 
 
 class Timing(C.Structure):
     _fields_ = [("advect_ms", C.c_double), ("divergence_ms", C.c_double), ("jacobi_ms", C.c_double),
                 ("project_ms", C.c_double), ("light_ms", C.c_double), ("view_ms", C.c_double),
                 ("exchange_ms", C.c_double), ("steps", C.c_uint64), ("jacobi_launches", C.c_uint64),
-                ("jacobi_sweeps", C.c_uint64), ("renders", C.c_uint64)]
+                ("jacobi_sweeps", C.c_uint64), ("renders", C.c_uint64), ("resolve_ms", C.c_double)]
 
 
 # every symbol include/fluidx_hip.h declares: name -> (restype, argtypes)
@@ -65,6 +66,8 @@ SYMBOLS = {
     "fx_jacobi": (C.c_int, [_vp, _vp, C.c_uint32]),
     "fx_project": (C.c_int, [_vp, _vp]),
     "fx_sh_transform": (C.c_int, [_vp, _fp, C.c_uint32, _fp]),
+    "fx_clear_render_target": (C.c_int, [_vp, _vp, _fp]),
+    "fx_render_cube": (C.c_int, [_vp, _vp, C.c_uint8]),
     "fx_timing_enable": (C.c_int, [_vp, C.c_int]),
     "fx_set_option": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "fx_timing_read": (C.c_int, [_vp, C.POINTER(Timing), C.c_int]),
@@ -100,7 +103,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.fx_abi_version() != 1:
+    if lib.fx_abi_version() != ABI_VERSION:
         raise RuntimeError("fluidx ABI version mismatch")
     _lib = lib
     return lib

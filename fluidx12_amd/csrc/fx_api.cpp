@@ -37,7 +37,7 @@ struct DeviceGuard {
 };
 
 // ---- timing ---------------------------------------------------------------------------------
-enum MarkKind { MK_ADVECT, MK_DIV, MK_JACOBI, MK_PROJECT, MK_LIGHT, MK_VIEW, MK_EXCH };
+enum MarkKind { MK_ADVECT, MK_DIV, MK_JACOBI, MK_PROJECT, MK_LIGHT, MK_VIEW, MK_EXCH, MK_RESOLVE };
 
 size_t ev_record(fx_ctx* c, hipStream_t s)
 {
@@ -79,6 +79,7 @@ int drain_timing(fx_ctx* c)
 		case MK_LIGHT: c->acc.light_ms += ms; break;
 		case MK_VIEW: c->acc.view_ms += ms; break;
 		case MK_EXCH: c->acc.exchange_ms += ms; break;
+		case MK_RESOLVE: c->acc.resolve_ms += ms; break;
 		}
 	}
 	c->marks.clear();
@@ -103,7 +104,7 @@ void free_all(fx_ctx* c)
 		if (c->col[i]) (void)hipFree(c->col[i]);
 		if (c->p[i]) (void)hipFree(c->p[i]);
 	}
-	void* others[] = { c->p_face[0], c->p_face[1], c->b, c->frozen, c->lightmap, c->cube, c->sh_dev, c->halo_overflow, c->stage,
+	void* others[] = { c->target, c->target_float, c->p_face[0], c->p_face[1], c->b, c->frozen, c->lightmap, c->cube, c->sh_dev, c->halo_overflow, c->stage,
 		c->sh_scratch[0], c->sh_scratch[1], c->sh_scratch[2], c->sh_scratch[3] };
 	for (void* q : others) if (q) (void)hipFree(q);
 	for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -584,6 +585,9 @@ int fx_update_frame(fx_ctx* ctx, float time_step, uint8_t frame_index,
 			const Mat4 wvp = world * (Mat4::from(view) * Mat4::from(proj));
 			worldI.store3x4(c->fc.world_i);
 			world.store3x4(c->fc.world);
+			const Mat4 wvpI = wvp.inverse();                                    // stored transposed (Fluid.cpp:318)
+			for (int r = 0; r < 4; ++r)
+				for (int q = 0; q < 4; ++q) c->fc.wvp_i[r * 4 + q] = wvpI.m[q][r];
 			for (int a = 0; a < 3; ++a) c->fc.eye_pt[a] = eye[a];
 			const float pi = 3.141592654f;
 			const float lp[3] = { 75.0f, 75.0f, -75.0f };                        // Fluid.cpp:169-173
@@ -670,6 +674,44 @@ int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags)
 	return FX_OK;
 }
 
+static int ensure_target(fx_ctx* ctx)
+{
+	if (ctx->target) return FX_OK;
+	const size_t n = (size_t)ctx->desc.viewport_w * ctx->desc.viewport_h;
+	if (!n) return FX_E_INVALID;
+	FX_HIP(hipMalloc((void**)&ctx->target, n * 4));
+	FX_HIP(hipMemset(ctx->target, 0, n * 4));
+	FX_HIP(hipMalloc((void**)&ctx->target_float, n * 16));
+	FX_HIP(hipMemset(ctx->target_float, 0, n * 16));
+	return FX_OK;
+}
+
+int fx_clear_render_target(fx_ctx* ctx, void* stream, const float rgba[4])
+{
+	if (!ctx || !rgba) return FX_E_INVALID;
+	DeviceGuard dg(ctx->device);
+	int rc = ensure_target(ctx);
+	if (rc) return rc;
+	FX_HIP(launch_clear_target(ctx->target, (int)ctx->desc.viewport_w, (int)ctx->desc.viewport_h, rgba, pick_stream(ctx, stream)));
+	return FX_OK;
+}
+
+int fx_render_cube(fx_ctx* ctx, void* stream, uint8_t frame_index)
+{
+	if (!ctx || frame_index >= FX_FRAME_COUNT) return FX_E_INVALID;
+	if (ctx->g.Zg <= 1 || !ctx->cube) return FX_E_INVALID;
+	if (!ctx->view_valid) return FX_E_STATE;
+	if (ctx->g.nz != ctx->g.Zg) return FX_E_INVALID;
+	DeviceGuard dg(ctx->device);
+	int rc = ensure_target(ctx);
+	if (rc) return rc;
+	hipStream_t s = pick_stream(ctx, stream);
+	ScopedMark mk(ctx, s, MK_RESOLVE);
+	FX_HIP(launch_resolve_cube(ctx->cube + ctx->cube_mip_offset[ctx->cube_lod], ctx->g.X >> ctx->cube_lod, ctx->fc,
+		(int)ctx->desc.viewport_w, (int)ctx->desc.viewport_h, ctx->target, ctx->target_float, s));
+	return FX_OK;
+}
+
 int fx_get_frame_info(fx_ctx* ctx, fx_frame_info* out)
 {
 	if (!ctx || !out) return FX_E_INVALID;
@@ -680,6 +722,7 @@ int fx_get_frame_info(fx_ctx* ctx, fx_frame_info* out)
 	out->frame_parity = ctx->frame_parity;
 	out->edge_pixels = ctx->edge_pixels;
 	out->time_step = ctx->time_step;
+	std::memcpy(out->world_view_proj_i, ctx->fc.wvp_i, sizeof out->world_view_proj_i);
 	return FX_OK;
 }
 
@@ -717,6 +760,10 @@ static int field_info(fx_ctx* c, int field, size_t* host_bytes)
 		*host_bytes = 6 * s * s * 4;
 		return FX_OK;
 	}
+	case FX_FIELD_TARGET: case FX_FIELD_TARGET_FLOAT:
+		if (!c->target) return FX_E_STATE;
+		*host_bytes = (size_t)c->desc.viewport_w * c->desc.viewport_h * (field == FX_FIELD_TARGET ? 4 : 16);
+		return FX_OK;
 	}
 	return FX_E_INVALID;
 }
@@ -761,8 +808,11 @@ int fx_upload(fx_ctx* ctx, int field, const void* host, size_t bytes)
 	case FX_FIELD_DIVERGENCE:
 		FX_HIP(hipMemcpy(ctx->b + off, host, need, hipMemcpyHostToDevice));
 		break;
+	case FX_FIELD_CUBEMAP:       // mip `cube_lod`: lets the resolve be driven with a known cube map (parity tests, replays)
+		FX_HIP(hipMemcpy(ctx->cube + ctx->cube_mip_offset[ctx->cube_lod], host, need, hipMemcpyHostToDevice));
+		break;
 	default:
-		return FX_E_INVALID;     // light map / cube map are outputs
+		return FX_E_INVALID;     // light map / render target are outputs
 	}
 	FX_HIP(hipStreamSynchronize(ctx->stream));
 	return FX_OK;
@@ -811,6 +861,12 @@ int fx_download(fx_ctx* ctx, int field, void* host, size_t bytes)
 		break;
 	case FX_FIELD_CUBEMAP:
 		FX_HIP(hipMemcpy(host, ctx->cube + ctx->cube_mip_offset[ctx->cube_lod], need, hipMemcpyDeviceToHost));
+		break;
+	case FX_FIELD_TARGET:
+		FX_HIP(hipMemcpy(host, ctx->target, need, hipMemcpyDeviceToHost));
+		break;
+	case FX_FIELD_TARGET_FLOAT:
+		FX_HIP(hipMemcpy(host, ctx->target_float, need, hipMemcpyDeviceToHost));
 		break;
 	default:
 		return FX_E_INVALID;

@@ -27,6 +27,8 @@ struct fx_ctx {
 	uint32_t* lightmap;             // R11G11B10F packed (m_lightMap), owned planes only
 	uint8_t* cube;                  // RGBA8 cube map, 5 mips back to back (m_cubeMap)
 	size_t cube_mip_offset[5];
+	uint8_t* target;                // W x H RGBA8 render target of the cube resolve (lazily allocated)
+	float* target_float;            // the resolve's SV_TARGET before the output merger (parity tests; lazily allocated)
 	float* sh_dev;                  // 27 floats
 	bool has_sh;
 	unsigned* halo_overflow;        // device flag set when a back-trace leaves the halo

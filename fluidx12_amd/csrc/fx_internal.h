@@ -33,6 +33,7 @@ struct FrameConsts {
 	float light_pt[3];
 	float light_color[4];
 	float ambient[4];
+	float wvp_i[16];       // CBPerObject.WorldViewProjI as its four constant-buffer rows (Fluid.cpp:318)
 };
 
 struct SimParams {
@@ -79,6 +80,11 @@ hipError_t launch_raymarch_view(const Geom& g, int half_store, const void* color
 	const FrameConsts& fc, const float* sh, int cube_size, uint32_t mask, uint32_t num_samples,
 	uint32_t num_light_samples, int separate, uint8_t* cube, hipStream_t s);
 hipError_t launch_lightmap_decode(const uint32_t* lightmap, float* out, size_t n, hipStream_t s);
+
+// ---- cube map -> screen resolve (fx_resolve.hip; row f-1)
+hipError_t launch_resolve_cube(const uint8_t* cube_mip, int N, const FrameConsts& fc, int W, int H, uint8_t* target,
+	float* out_float, hipStream_t s);
+hipError_t launch_clear_target(uint8_t* target, int W, int H, const float rgba[4], hipStream_t s);
 
 // ---- SH light probe (fx_sh.hip): cube float[6][n][n][3] (device) -> out float[27] (device)
 hipError_t launch_sh_transform(const float* cube, int n, float* scratch0, float* scratch1, float* w0, float* w1,

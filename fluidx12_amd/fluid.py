@@ -93,6 +93,7 @@ class Fluid:
             self._ctx = C.c_void_p()
             return False
         self.grid = (X, Y, Z)
+        self.viewport = (int(width), int(height))
         self.slab = (d.slab_z0, d.slab_nz if d.slab_nz else Z)
         if level == 1:
             self.set_option(capi.OPT_OVERLAP, 1)
@@ -140,9 +141,24 @@ class Fluid:
         self._need()
         capi.check(self._lib.fx_simulate(self._ctx, stream, frameIndex), "Simulate")
 
-    def Render(self, frameIndex=0, flags=capi.OPTIMIZED, stream=None):
+    def Render(self, frameIndex=0, flags=capi.OPTIMIZED, stream=None, to_target=False):
+        """Fluid::Render (Fluid.cpp:412-446).  to_target=True also runs renderCube (Fluid.cpp:430), which the reference
+        always does: the cube map is resolved onto the render target (ClearRenderTarget first, as the caller does)."""
         self._need()
         capi.check(self._lib.fx_render(self._ctx, stream, frameIndex, flags), "Render")
+        if to_target:
+            self.RenderCube(frameIndex, stream)
+
+    def ClearRenderTarget(self, rgba=(0.2, 0.2, 0.2, 0.0), stream=None):
+        """ClearRenderTargetView with the demo's clear colour (FluidX12.cpp:471-472)"""
+        self._need()
+        c = (C.c_float * 4)(*[float(v) for v in rgba])
+        capi.check(self._lib.fx_clear_render_target(self._ctx, stream, c), "ClearRenderTarget")
+
+    def RenderCube(self, frameIndex=0, stream=None):
+        """Fluid::renderCube (Fluid.cpp:910-931), raster-free: PSRayCastCube per pixel + PREMULTIPLIED blend"""
+        self._need()
+        capi.check(self._lib.fx_render_cube(self._ctx, stream, frameIndex), "RenderCube")
 
     # ---- the demo driver's time-step rule (FluidX12.cpp:266) ---------------------------------------
     def default_time_step(self):
@@ -183,6 +199,10 @@ class Fluid:
             return (nz, Y, X), np.float32
         if field == capi.FIELD_LIGHTMAP:
             return (nz, Y, X, 3), np.float32
+        if field == capi.FIELD_TARGET:
+            return (self.viewport[1], self.viewport[0], 4), np.uint8
+        if field == capi.FIELD_TARGET_FLOAT:
+            return (self.viewport[1], self.viewport[0], 4), np.float32
         s = self.frame_info().cube_size
         return (6, s, s, 4), np.uint8
 

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 1
+#define FX_ABI_VERSION 2
 
 enum fx_status {
 	FX_OK = 0,
@@ -60,7 +60,9 @@ enum fx_address { FX_ADDRESS_CLAMP = 0,         /* FluidEZ.cpp:406 (default path
  * Z = the context's own slab (slab_nz planes), never the halo. */
 enum fx_field {
 	FX_FIELD_VELOCITY = 0, FX_FIELD_VELOCITY1 = 1, FX_FIELD_COLOR = 2, FX_FIELD_COLOR_PREV = 3,
-	FX_FIELD_PRESSURE = 4, FX_FIELD_DIVERGENCE = 5, FX_FIELD_LIGHTMAP = 6, FX_FIELD_CUBEMAP = 7
+	FX_FIELD_PRESSURE = 4, FX_FIELD_DIVERGENCE = 5, FX_FIELD_LIGHTMAP = 6, FX_FIELD_CUBEMAP = 7,
+	FX_FIELD_TARGET = 8,        /* render target of fx_render_cube: uint8 [viewport_h][viewport_w][4] (download only) */
+	FX_FIELD_TARGET_FLOAT = 9   /* the resolve's output before the blend: float [h][w][4], zeros where discarded     */
 };
 
 typedef struct fx_ctx fx_ctx;
@@ -97,12 +99,14 @@ typedef struct fx_frame_info {
 	uint32_t frame_parity;      /* m_frameParity                        */
 	float    edge_pixels;       /* EstimateCubeEdgePixelSize            */
 	float    time_step;
+	float    world_view_proj_i[16];  /* CBPerObject.WorldViewProjI as its 4 constant-buffer rows (Fluid.cpp:318; ABI 2) */
 } fx_frame_info;
 
 /* HIP-event timings accumulated by fx_simulate / fx_render while enabled (milliseconds, launch counts) */
 typedef struct fx_timing {
 	double   advect_ms, divergence_ms, jacobi_ms, project_ms, light_ms, view_ms, exchange_ms;
 	uint64_t steps, jacobi_launches, jacobi_sweeps, renders;
+	double   resolve_ms;        /* fx_render_cube (ABI 2) */
 } fx_timing;
 
 int fx_abi_version(void);
@@ -125,6 +129,14 @@ int fx_simulate(fx_ctx* ctx, void* stream, uint8_t frame_index);
 /* Fluid::Render (Fluid.cpp:412-446): cube-map-space paths (flags & FX_RAY_MARCH_CUBEMAP);
  * writes the cube map (and light map); the raster resolve to a back buffer is out of scope. */
 int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags);
+/* The caller-side half of the cube path (row f-1 of SURVEY.md 8): the render target the reference's caller binds.
+ * fx_clear_render_target = ClearRenderTargetView (FluidX12.cpp:471-472; the demo clears to (0.2, 0.2, 0.2, 0));
+ * fx_render_cube = Fluid::renderCube (Fluid.cpp:910-931) in its raster-free per-pixel form (PSRayCastCube.hlsl):
+ * resolves mip `cube_lod` of the cube map the last fx_render wrote onto the viewport_w x viewport_h RGBA8 target with
+ * the PREMULTIPLIED blend (Fluid.cpp:653).  Read the result with fx_download(FX_FIELD_TARGET). */
+int fx_clear_render_target(fx_ctx* ctx, void* stream, const float rgba[4]);
+int fx_render_cube(fx_ctx* ctx, void* stream, uint8_t frame_index);
+
 int fx_get_frame_info(fx_ctx* ctx, fx_frame_info* out);
 
 /* blocks until everything enqueued by this context has finished; reports FX_E_HALO if the advection

@@ -57,6 +57,15 @@ void orc_raymarch_view(const float* color, const float* lightmap, int X, int Y, 
 uint32_t orc_pack_r11g11b10(float r, float g, float b);
 void orc_unpack_r11g11b10(uint32_t v, float* rgb);
 
+// ---- cube map -> screen resolve (orc_resolve.cpp; PSRayCastCube.hlsl:20-113, PSCube.hlsli:41-122) ----------
+// cube: RGBA8 [6][N][N][4] (the mip the view pass wrote); wvp_i: orc_world_view_proj_inverse; out_rgba float[H][W][4]
+// premultiplied (zeros where discarded), covered uint8[H][W]
+void orc_world_view_proj_inverse(const float view[16], const float proj[16], float out16[16]);
+void orc_resolve_cube(const uint8_t* cube, int N, const orc_frame* fc, const float* wvp_i, int W, int H,
+	float* out_rgba, uint8_t* covered);
+// PREMULTIPLIED blend (Fluid.cpp:653) of a resolve result over an R8G8B8A8_UNORM target (FluidX12.cpp:31), in place
+void orc_blend_premultiplied(const float* src_rgba, const uint8_t* covered, uint8_t* target_rgba8, int W, int H);
+
 // ---- spherical harmonics light probe (orc_sh.cpp) -----------------------------------------
 // cube float[6][N][N][3]; out float[9][3].  quirk != 0 reproduces LightProbeEZ.cpp:245-246
 // (every sum pass sees the first pass's element count, so pass 3 re-adds 20 stale partials).

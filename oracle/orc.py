@@ -60,6 +60,9 @@ def lib():
                                           C.POINTER(u), fp]
         _lib.orc_raymarch_light.argtypes = [fp, fp, i, i, i, C.POINTER(Frame), u, i, i]
         _lib.orc_raymarch_view.argtypes = [fp, fp, i, i, i, C.POINTER(Frame), i, u, u, u, i, i, fp, u8p]
+        _lib.orc_world_view_proj_inverse.argtypes = [fp, fp, fp]
+        _lib.orc_resolve_cube.argtypes = [u8p, i, C.POINTER(Frame), fp, i, i, fp, u8p]
+        _lib.orc_blend_premultiplied.argtypes = [fp, u8p, u8p, i, i]
         _lib.orc_pack_r11g11b10.argtypes = [f, f, f]
         _lib.orc_pack_r11g11b10.restype = u
         _lib.orc_unpack_r11g11b10.argtypes = [u, fp]
@@ -190,6 +193,33 @@ def raymarch_view(col, lightmap, frame, size, mask, num_samples, num_light_sampl
     lib().orc_raymarch_view(_fp(col), lmp, X, Y, Z, C.byref(frame), size, mask, num_samples, num_light_samples,
                             int(has_sh), int(separate), _fp(cf), cu.ctypes.data_as(C.POINTER(C.c_uint8)))
     return cf, cu
+
+
+def world_view_proj_inverse(view, proj):
+    """CBPerObject.WorldViewProjI as its four constant-buffer rows (Fluid.cpp:318)"""
+    out = np.empty((4, 4), np.float32)
+    lib().orc_world_view_proj_inverse(_fp(_f32(view)), _fp(_f32(proj)), _fp(out))
+    return out
+
+
+def resolve_cube(cube_u8, frame, wvp_i, width, height):
+    """PSRayCastCube per screen pixel: (premultiplied float[H][W][4], covered uint8[H][W])"""
+    cube_u8 = np.ascontiguousarray(cube_u8, np.uint8)
+    N = cube_u8.shape[1]
+    out = np.empty((height, width, 4), np.float32)
+    cov = np.empty((height, width), np.uint8)
+    u8 = C.POINTER(C.c_uint8)
+    lib().orc_resolve_cube(cube_u8.ctypes.data_as(u8), N, C.byref(frame), _fp(_f32(wvp_i)), width, height, _fp(out), cov.ctypes.data_as(u8))
+    return out, cov
+
+
+def blend_premultiplied(src, covered, target_u8):
+    """PREMULTIPLIED blend over an RGBA8 target; returns the new target"""
+    t = np.ascontiguousarray(target_u8, np.uint8).copy()
+    H, W = covered.shape
+    u8 = C.POINTER(C.c_uint8)
+    lib().orc_blend_premultiplied(_fp(_f32(src)), np.ascontiguousarray(covered, np.uint8).ctypes.data_as(u8), t.ctypes.data_as(u8), W, H)
+    return t
 
 
 def sh_transform(cube, quirk=False):

@@ -86,6 +86,19 @@ void orc_look_at_lh(const float eye[3], const float focus[3], const float up[3],
 	std::memcpy(out16, m, sizeof m);
 }
 
+// CBPerObject.WorldViewProjI (Fluid.cpp:318): transpose(inverse(world * view * proj)), world = scale 10 (Fluid.cpp:182);
+// out16 = the four float4 rows of the constant buffer
+void orc_world_view_proj_inverse(const float view[16], const float proj[16], float out16[16])
+{
+	M4 V, P, W{};
+	std::memcpy(V.m, view, 64);
+	std::memcpy(P.m, proj, 64);
+	W.m[0][0] = W.m[1][1] = W.m[2][2] = 10.0f; W.m[3][3] = 1.0f;
+	const M4 I = inverse(mul(W, mul(V, P)));
+	for (int r = 0; r < 4; ++r)
+		for (int c = 0; c < 4; ++c) out16[r * 4 + c] = I.m[c][r];
+}
+
 void orc_perspective_fov_lh(float fovy, float aspect, float zn, float zf, float out16[16])
 {
 	const float h = std::cos(0.5f * fovy) / std::sin(0.5f * fovy);

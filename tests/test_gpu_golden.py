@@ -13,6 +13,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SIM = np.load(os.path.join(GOLD, "dxbc_sim.npz"))
 REN = np.load(os.path.join(GOLD, "dxbc_render.npz"))
 SH = np.load(os.path.join(GOLD, "dxbc_sh.npz"))
+RES = np.load(os.path.join(GOLD, "dxbc_resolve.npz"))
 f32 = np.float32
 
 
@@ -104,6 +105,32 @@ def test_ray_march_vs_reference_binaries(has_sh):
     f.Render(0, fx.Fluid.RAY_MARCH_CUBEMAP)
     f.Synchronize()
     cube_close(f.download(fx.FIELD_CUBEMAP), REN["cube_merged_sh%d" % has_sh])                       # CSRayMarch.cso
+
+
+@pytest.mark.parametrize("name", ["rendered16", "random8"])
+def test_cube_resolve_vs_reference_binary(name):
+    """k_resolve_cube against PSRayCastCube.cso's own output (row f-1).  The library derives its frame constants itself
+    (fp32 DirectXMath restatement, the golden ones were rounded from float64), so a silhouette pixel may flip and values
+    agree to ~1e-5; tests/test_gpu_render.py holds the bit-exact comparison with identical constants."""
+    W, H, vw, vh = (int(v) for v in RES["params"])
+    cube = RES["cube_" + name]
+    N = cube.shape[1]
+    f = fx.Fluid()
+    assert f.Init(W, H, (N, N, N))
+    view, proj, eye = fx.default_camera(vw, vh)
+    f.UpdateFrame(0.0, 0, view, proj, eye)
+    assert f.frame_info().cube_size == N
+    f.upload(fx.FIELD_CUBEMAP, cube)
+    f.ClearRenderTarget()
+    f.RenderCube(0)
+    f.Synchronize()
+    got = f.download(fx.FIELD_TARGET_FLOAT)
+    ref, disc = RES["target_" + name], RES["discard_" + name]
+    cov = got[..., 3] > 0
+    assert np.mean(cov != ~disc) < 2e-3
+    both = cov & ~disc
+    d = np.abs(got[both] - ref[both])
+    assert np.mean(d > 1e-4) < 2e-3 and np.median(d) < 2e-5
 
 
 def test_sh_transform_vs_reference_binaries():

@@ -197,3 +197,80 @@ def test_config3_render_properties():
     f.Render(0, fx.Fluid.OPTIMIZED)
     f.Synchronize()
     assert np.array_equal(cube, f.download(fx.FIELD_CUBEMAP))
+
+
+# ---- cube map -> screen resolve (row f-1: Fluid::renderCube, PSRayCastCube.hlsl, PSCube.hlsli) ---------------------------
+def oracle_frame_of(f, view, proj, eye, X):
+    """the oracle's frame constants + the library's own WorldViewProjI, so that both run on identical inputs"""
+    vw, vh = f.viewport
+    fr = orc.update_frame(view, proj, eye, vw, vh, X, 192)[0]
+    fi = f.frame_info()
+    wvp_i = np.array(list(fi.world_view_proj_i), f32).reshape(4, 4)
+    ref = orc.world_view_proj_inverse(view, proj)
+    assert np.abs(wvp_i - ref).max() <= 1e-5 * np.abs(ref).max()       # two fp32 restatements of XMMatrixInverse
+    return fr, wvp_i
+
+
+@pytest.mark.parametrize("N,vp,seed", [(16, (160, 120), 1), (8, (96, 72), 2), (32, (320, 200), 3)])
+def test_cube_resolve_equals_oracle(N, vp, seed):
+    """k_resolve_cube on a fully random cube map (every face, seamless edge and corner carries data):
+    SV_TARGET and the blended RGBA8 target equal the oracle bit for bit"""
+    rng = np.random.default_rng(seed)
+    cube = rng.integers(0, 256, (6, N, N, 4), dtype=np.uint8)
+    f = fx.Fluid()
+    assert f.Init(vp[0], vp[1], (N, N, N))
+    view, proj, eye = fx.default_camera(*vp)
+    f.UpdateFrame(0.0, 0, view, proj, eye)
+    assert f.frame_info().cube_size == N
+    f.upload(fx.FIELD_CUBEMAP, cube)
+    assert np.array_equal(f.download(fx.FIELD_CUBEMAP), cube)
+    fr, wvp_i = oracle_frame_of(f, view, proj, eye, N)
+    out, cov = orc.resolve_cube(cube, fr, wvp_i, vp[0], vp[1])
+    f.ClearRenderTarget((0.2, 0.2, 0.2, 0.0))
+    f.RenderCube(0)
+    f.Synchronize()
+    got = f.download(fx.FIELD_TARGET_FLOAT)
+    assert cov.mean() > 0.1
+    assert np.array_equal(got.view(np.uint32), out.view(np.uint32))
+    target = np.empty((vp[1], vp[0], 4), np.uint8)
+    target[...] = (51, 51, 51, 0)
+    assert np.array_equal(f.download(fx.FIELD_TARGET), orc.blend_premultiplied(out, cov, target))
+    # the blend accumulates: a second resolve composites over the first (the caller clears once per frame)
+    f.RenderCube(0)
+    f.Synchronize()
+    twice = orc.blend_premultiplied(out, cov, orc.blend_premultiplied(out, cov, target))
+    assert np.array_equal(f.download(fx.FIELD_TARGET), twice)
+
+
+def test_render_to_target_pipeline():
+    """simulate -> Render(OPTIMIZED) -> renderCube at the demo's 640x480: the whole Fluid::Render of the cube path.
+    The resolved image equals the oracle's resolve of the downloaded cube map; uncovered pixels keep the clear colour."""
+    X, vp = 32, (640, 480)
+    f, fr, lod, rs, mask = setup(X, smoke_state(X, 8, seed=5), *vp)
+    view, proj, eye = fx.default_camera(*vp)
+    f.ClearRenderTarget()
+    f.Render(0, fx.Fluid.OPTIMIZED, to_target=True)
+    f.Synchronize()
+    cube = f.download(fx.FIELD_CUBEMAP)
+    fr2, wvp_i = oracle_frame_of(f, view, proj, eye, X)
+    out, cov = orc.resolve_cube(cube, fr2, wvp_i, *vp)
+    img = f.download(fx.FIELD_TARGET)
+    target = np.empty((vp[1], vp[0], 4), np.uint8)
+    target[...] = (51, 51, 51, 0)
+    assert np.array_equal(img, orc.blend_premultiplied(out, cov, target))
+    assert 0.02 < cov.mean() < 0.9 and (img[~cov.astype(bool)] == (51, 51, 51, 0)).all()
+    assert img[cov.astype(bool)][:, 3].max() > 50
+
+
+def test_render_cube_errors():
+    f = fx.Fluid()
+    assert f.Init(64, 64, (16, 16, 16))
+    with pytest.raises(fx.FluidxError):
+        f.RenderCube(0)                                   # no view yet
+    with pytest.raises(fx.FluidxError):
+        f.download(fx.FIELD_TARGET)                       # no target yet
+    f2 = fx.Fluid()
+    assert f2.Init(64, 64, (16, 16, 1))
+    f2.UpdateFrame(0.0, 0)
+    with pytest.raises(fx.FluidxError):
+        f2.RenderCube(0)                                  # 2D has no cube map

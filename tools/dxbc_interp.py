@@ -233,6 +233,110 @@ class CubePoint:
         return out
 
 
+class CubeSeamless:
+    """TextureCube of RGBA8_UNORM texels [6][N][N][4] with D3D11 addressing, used by the pixel shaders that resolve the
+    cube map (gather4 / sample_l): major axis with ties Z > Y > X, per-face (sc, tc) table, bilinear footprint at
+    floor(u*N - 0.5), seamless edges.  A footprint texel that falls off one edge is found by FOLDING its centre over the
+    cube edge onto the adjacent face (geometric, no adjacency table); a texel off a corner is the mean of the other
+    three."""
+
+    def __init__(self, cube_u8):
+        self.t = np.ascontiguousarray(cube_u8, np.uint8)
+        self.N = self.t.shape[1]
+
+    @property
+    def dims(self):
+        return (self.N, self.N, 6)
+
+    @staticmethod
+    def _select(d):
+        x, y, z = d[:, 0], d[:, 1], d[:, 2]
+        ax, ay, az = np.abs(x), np.abs(y), np.abs(z)
+        mz = (az >= ax) & (az >= ay)
+        my = ~mz & (ay >= ax)
+        mx = ~mz & ~my
+        face = np.zeros(len(d), np.int64)
+        sc = np.zeros(len(d), F32); tc = np.zeros(len(d), F32); ma = np.ones(len(d), F32)
+        for m, comp, fpos, s_p, t_p, s_n, t_n, mag in ((mx, x, 0, -z, -y, z, -y, ax), (my, y, 2, x, z, x, -z, ay), (mz, z, 4, x, -y, -x, -y, az)):
+            p = m & ~(comp < 0); n_ = m & (comp < 0)
+            face[p] = fpos; face[n_] = fpos + 1
+            sc[p] = s_p[p]; tc[p] = t_p[p]; sc[n_] = s_n[n_]; tc[n_] = t_n[n_]
+            ma[m] = mag[m]
+        return face, sc, tc, ma
+
+    @staticmethod
+    def _point(face, sc, tc):
+        one = np.ones_like(sc)
+        P = np.zeros((len(sc), 3), F32)
+        for f, (a, b, c) in enumerate(((one, -tc, -sc), (-one, -tc, sc), (sc, one, tc), (sc, -one, -tc), (sc, -tc, one), (-sc, -tc, -one))):
+            k = face == f
+            P[k, 0] = a[k]; P[k, 1] = b[k]; P[k, 2] = c[k]
+        return P
+
+    def _texels(self, face, i, j):
+        """[n][4] float texels at integer (i, j) of `face`; i/j may be -1 or N (one of them: folded; both: NaN marker)"""
+        N = self.N
+        out = np.zeros((len(face), 4), F32)
+        oi = (i < 0) | (i >= N); oj = (j < 0) | (j >= N)
+        inside = ~oi & ~oj
+        out[inside] = self.t[face[inside], j[inside], i[inside]].astype(F32) / F32(255.0)
+        edge = oi ^ oj
+        if edge.any():
+            f = face[edge]
+            sc = ((2 * i[edge] + 1).astype(F32) / F32(N) - F32(1.0)).astype(F32)      # texel centre on the extended face plane
+            tc = ((2 * j[edge] + 1).astype(F32) / F32(N) - F32(1.0)).astype(F32)
+            P = self._point(f, sc, tc)
+            ax = f >> 1
+            rows = np.arange(len(f))
+            P = np.nan_to_num(P, nan=0.0, posinf=4.0, neginf=-4.0)  # lanes whose pixel was discarded carry garbage
+            oa = np.argmax(np.abs(P), axis=1)                     # the one coordinate beyond the cube
+            excess = np.abs(P[rows, oa]) - 1
+            sign_f = np.sign(P[rows, ax])
+            P[rows, oa] = np.sign(P[rows, oa])                    # back onto the cube ...
+            P[rows, ax] = sign_f * (1 - excess)                   # ... and down the adjacent face by the same distance
+            g, s2, t2, _ = self._select(P.astype(F32))
+            i2 = np.clip(np.floor((s2 * F32(0.5) + F32(0.5)) * N).astype(np.int64), 0, N - 1)
+            j2 = np.clip(np.floor((t2 * F32(0.5) + F32(0.5)) * N).astype(np.int64), 0, N - 1)
+            out[edge] = self.t[g, j2, i2].astype(F32) / F32(255.0)
+        corner = oi & oj
+        out[corner] = np.nan
+        return out, corner
+
+    def footprint(self, d):
+        N = self.N
+        face, sc, tc, ma = self._select(d.astype(F32))
+        u = (F32(0.5) * (sc / ma) + F32(0.5)).astype(F32)
+        v = (F32(0.5) * (tc / ma) + F32(0.5)).astype(F32)
+        tu = fma32(u, F32(N), F32(-0.5)); tv = fma32(v, F32(N), F32(-0.5))
+        i0 = np.floor(tu).astype(np.int64); j0 = np.floor(tv).astype(np.int64)
+        fu = (tu - np.floor(tu)).astype(F32); fv = (tv - np.floor(tv)).astype(F32)
+        taps = []
+        corners = []
+        for di, dj in ((0, 1), (1, 1), (1, 0), (0, 0)):          # gather order x, y, z, w
+            t, c = self._texels(face, i0 + di, j0 + dj)
+            taps.append(t); corners.append(c)
+        taps = np.stack(taps, 1)                                  # [n][4 taps][4 channels]
+        for k in range(4):
+            c = corners[k]
+            if c.any():
+                others = [q for q in range(4) if q != k]
+                acc = taps[c][:, others[0]] + taps[c][:, others[1]]
+                acc = (acc + taps[c][:, others[2]]).astype(F32)
+                taps[c, k] = (acc / F32(3.0)).astype(F32)
+        return taps, fu, fv
+
+    def gather(self, d, channel):
+        taps, _, _ = self.footprint(d)
+        return np.ascontiguousarray(taps[:, :, channel])
+
+    def sample(self, d):
+        taps, fu, fv = self.footprint(d)
+
+        def lerp(a, b, f):
+            return fma32(f[:, None], (b - a).astype(F32), a)
+        return lerp(lerp(taps[:, 3], taps[:, 2], fu), lerp(taps[:, 0], taps[:, 1], fu), fv)
+
+
 class Machine:
     def __init__(self, blob, groups, resources, cbs, samplers=None):
         """groups = (gx, gy, gz) thread groups; resources: {'t0': Texture|Structured|CubePoint, 'u0': ...};
@@ -296,6 +400,8 @@ class Machine:
             val = cb[i] if isinstance(i, np.ndarray) else np.broadcast_to(cb[i], (self.N, 4))
         elif t in self.v:
             val = self.v[t]
+        elif t == "v":                                    # pixel-shader input register
+            val = self.inputs[o.indices[0]]
         elif t == "null":
             return None
         else:
@@ -328,6 +434,10 @@ class Machine:
         comps = [c for c in range(4) if (o.mask >> c) & 1] if o.ncomp == 4 else [0]
         if o.type == "r":
             dst = self.r[o.indices[0]]
+            for c in comps:
+                dst[mask, c] = val[mask, c]
+        elif o.type == "o":                                  # pixel-shader output register
+            dst = self.outputs.setdefault(o.indices[0], np.zeros((self.N, 4), U32))
             for c in comps:
                 dst[mask, c] = val[mask, c]
         elif o.type == "x":
@@ -445,8 +555,14 @@ class Machine:
                 frames.pop()
                 pc += 1
                 continue
-            if op in ("RET", "RETC"):
+            if op in ("RET", "RETC", "DISCARD"):
                 t = m
+                if op == "DISCARD":
+                    c = self.read(i.operands[0])[:, 0] != 0
+                    if not i.test_nz:
+                        c = ~c
+                    t = m & c
+                    self.discarded = getattr(self, "discarded", np.zeros(N, bool)) | t
                 if op == "RETC":
                     c = self.read(i.operands[0])[:, 0] != 0
                     if not i.test_nz:
@@ -469,7 +585,7 @@ class Machine:
     def exec_alu(self, i, m):
         op = i.op
         O = i.operands
-        INT_OPS = ("IADD", "IMAD", "IMUL", "ISHL", "UDIV", "UMAX", "UMIN", "ULT", "UGE", "AND", "OR", "UTOF", "ITOF")
+        INT_OPS = ("IADD", "IMAD", "IMUL", "ISHL", "UDIV", "UMAX", "UMIN", "ULT", "UGE", "AND", "OR", "UTOF", "ITOF", "INEG")
 
         def R(o):
             return self.read(o, integer=op in INT_OPS)
@@ -557,6 +673,16 @@ class Machine:
                 wf(R(O[1]).astype(F32))
             elif op == "ITOF":
                 wf(R(O[1]).view(np.int32).astype(F32))
+            elif op == "INEG":
+                wu((~R(O[1]).astype(np.uint64) + 1) & 0xFFFFFFFF)
+            elif op == "FRC":
+                a = F(1)
+                wf(a - np.floor(a))
+            elif op == "GATHER4":
+                res = self.res["t" + str(O[2].indices[0])]
+                chan = O[3].swizzle[0]                            # sampler operand carries the channel select
+                g = res.gather(F(1)[:, :3], chan)
+                self.write(O[0], f2u(g)[:, list(O[2].swizzle)], m)
             elif op == "RESINFO":
                 res = self.res[O[2].type + str(O[2].indices[0])]
                 X, Y, Z = res.dims
@@ -581,8 +707,8 @@ class Machine:
             elif op == "SAMPLE_L":
                 res = self.res["t" + str(O[2].indices[0])]
                 c = F(1)
-                if isinstance(res, CubePoint):
-                    t = res.sample(c)
+                if isinstance(res, (CubePoint, CubeSeamless)):
+                    t = res.sample(c[:, :3]) if isinstance(res, CubeSeamless) else res.sample(c)
                 else:
                     t = sample_trilinear(res, self.smp["s" + str(O[3].indices[0])], c[:, 0], c[:, 1], c[:, 2], i.offsets)
                 self.write(O[0], f2u(t)[:, list(O[2].swizzle)], m)
@@ -627,6 +753,32 @@ class Machine:
                         words[idx[ok], off[ok] + k] = val[ok, c]
             else:
                 raise NotImplementedError(op)
+
+
+class PixelMachine(Machine):
+    """ps_5_0: one lane per pixel; `inputs` = {register index: float32[N][4]} (the interpolants at the pixel centres),
+    outputs in self.outputs[index] (uint32 bit patterns), self.discarded marks lanes that executed a discard."""
+
+    def __init__(self, blob, inputs, resources, cbs, samplers=None):
+        self.version, self.ins = dxbc.decode(blob)
+        self.res = resources
+        self.cbs = {k: np.ascontiguousarray(v, U32) for k, v in cbs.items()}
+        self.smp = samplers or {}
+        self.inputs = {k: f2u(np.ascontiguousarray(v, F32)) for k, v in inputs.items()}
+        self.N = len(next(iter(inputs.values())))
+        self.v = {}
+        self.outputs = {}
+        self.discarded = np.zeros(self.N, bool)
+        ntemps = [i for i in self.ins if i.op == "DCL_TEMPS"]
+        self.r = np.zeros(((ntemps[0].extra[0] if ntemps else 0) + 1, self.N, 4), U32)
+        self.x = {}
+        self.gsm = {}
+        self.executed = 0
+
+
+def run_pixel_shader(path, inputs, resources, cbs, samplers=None, **kw):
+    m = PixelMachine(open(path, "rb").read(), inputs, resources, cbs, samplers)
+    return m.run(**kw)
 
 
 def run_shader(path, groups, resources, cbs, samplers=None, **kw):

@@ -196,6 +196,38 @@ def make_render():
 
 
 # ---------------------------------------------------------------------------------------------------------
+# cube map -> screen resolve (row f-1): PSRayCastCube.cso per screen pixel
+# ---------------------------------------------------------------------------------------------------------
+def make_resolve():
+    """inputs: a cube map (the view pass's own golden output, and a fully random one that exercises every seamless edge),
+    the frame constants and the screen-quad interpolant UV = (pixel + 0.5) / size (VSScreenQuad.hlsl:17-26);
+    outputs: SV_TARGET (premultiplied RGBA, fp32) and the discard mask."""
+    out = {}
+    X = 16
+    W, H = 160, 120                                                   # same aspect as the 640x480 of the frame constants
+    cb0, cb1 = frame_constants(X, 640, 480)
+    out["cb_per_object"], out["cb_per_frame"] = cb0, cb1
+    py, px = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    uv = np.zeros((H * W, 4), F32)
+    uv[:, 0] = ((px.ravel().astype(F32) + F32(0.5)) / F32(W)).astype(F32)
+    uv[:, 1] = ((py.ravel().astype(F32) + F32(0.5)) / F32(H)).astype(F32)
+    rendered = np.load(os.path.join(OUT, "dxbc_render.npz"))["cube_separate_sh0"]
+    rng = np.random.default_rng(11)
+    random8 = rng.integers(0, 256, (6, 8, 8, 4), dtype=np.uint8)
+    random8[..., 3] = np.maximum(random8[..., 3], 1)
+    for name, cube in (("rendered16", rendered), ("random8", random8)):
+        m = di.run_pixel_shader(os.path.join(BIN, "PSRayCastCube.cso"), {1: uv}, {"t0": di.CubeSeamless(cube)},
+                                {0: cb0.view(U32), 1: cb1.view(U32)}, {"s0": di.Sampler("CLAMP")})
+        res = m.outputs[0].view(F32).reshape(H, W, 4).copy()
+        disc = m.discarded.reshape(H, W)
+        res[disc] = 0
+        out["cube_" + name], out["target_" + name], out["discard_" + name] = cube, res, disc
+        print("resolve %s: %d of %d pixels covered, alpha max %.3f" % (name, (~disc).sum(), disc.size, res[..., 3].max()))
+    out["params"] = np.array([W, H, 640, 480], np.int64)
+    np.savez_compressed(os.path.join(OUT, "dxbc_resolve.npz"), **out)
+
+
+# ---------------------------------------------------------------------------------------------------------
 # spherical harmonics
 # ---------------------------------------------------------------------------------------------------------
 def make_sh():
@@ -226,10 +258,12 @@ def make_sh():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sim", "render", "sh"]
+    which = sys.argv[1:] or ["sim", "render", "sh", "resolve"]
     if "sim" in which:
         make_sim()
     if "render" in which:
         make_render()
     if "sh" in which:
         make_sh()
+    if "resolve" in which:
+        make_resolve()
