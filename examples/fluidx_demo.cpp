@@ -2,13 +2,15 @@
 // OnUpdate's time-step rule (:266) and default camera (:243-253), PopulateCommandList's Simulate + Render
 // (:465,489-490), minus the window.  Build (after `python -m fluidx12_amd.build`):
 //   hipcc -std=c++17 examples/fluidx_demo.cpp -o fluidx_demo -Lfluidx12_amd -lfluidx_hip -Wl,-rpath,$PWD/fluidx12_amd
-// Usage: fluidx_demo [-gridSize X Y Z] [-maxRaySamples N] [-maxLightSamples N] [-frames N]   (FluidX12.cpp:398-433)
+// Usage: fluidx_demo [-gridSize X Y Z] [-maxRaySamples N] [-maxLightSamples N] [-frames N] [-screenshot out.ppm]
+// (FluidX12.cpp:398-433; the screen shot replaces the stb_image_write path of FluidX12.cpp:640-660 with a binary PPM)
 #include "../fluidx12_amd/csrc/Fluid.hpp"
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 using namespace fluidx;
 
@@ -38,11 +40,13 @@ int main(int argc, char** argv)
 	XMUINT3 grid = { 128, 128, 128 };                  // FluidX12.cpp:44
 	uint32_t maxRay = 192, maxLight = 64, frames = 100; // FluidX12.cpp:38-39
 	const uint32_t width = 800, height = 800;           // Main.cpp:17
+	const char* screenshot = nullptr;
 	for (int i = 1; i < argc; ++i) {
 		if (!std::strcmp(argv[i], "-gridSize") && i + 3 < argc) { grid.x = atoi(argv[++i]); grid.y = atoi(argv[++i]); grid.z = atoi(argv[++i]); }
 		else if (!std::strcmp(argv[i], "-maxRaySamples") && i + 1 < argc) maxRay = atoi(argv[++i]);
 		else if (!std::strcmp(argv[i], "-maxLightSamples") && i + 1 < argc) maxLight = atoi(argv[++i]);
 		else if (!std::strcmp(argv[i], "-frames") && i + 1 < argc) frames = atoi(argv[++i]);
+		else if (!std::strcmp(argv[i], "-screenshot") && i + 1 < argc) screenshot = argv[++i];
 	}
 	Fluid fluid;
 	if (!fluid.Init(nullptr, width, height, grid)) {   // ThrowIfFailed(E_FAIL) in the reference (FluidX12.cpp:198-200)
@@ -61,10 +65,23 @@ int main(int argc, char** argv)
 		const uint8_t frameIndex = f % Fluid::FrameCount;
 		fluid.UpdateFrame(timeStep, frameIndex, view, proj, eyePt);
 		fluid.Simulate(nullptr, frameIndex);
-		if (grid.z > 1) fluid.Render(nullptr, frameIndex, Fluid::OPTIMIZED);
+		const float clearColor[4] = { 0.2f, 0.2f, 0.2f, 0.0f };                    // FluidX12.cpp:471-472
+		if (grid.z > 1) {
+			fluid.ClearRenderTarget(nullptr, clearColor);
+			fluid.Render(nullptr, frameIndex, Fluid::OPTIMIZED);                    // marches + renderCube onto the target
+		}
 		if (fluid.LastStatus() != FX_OK) { std::fprintf(stderr, "frame %u: %s\n", f, fx_error_string(fluid.LastStatus())); return 1; }
 	}
 	if (fx_synchronize(fluid.Handle()) != FX_OK) return 1;
+	if (screenshot && grid.z > 1) {
+		std::vector<uint8_t> rgba;
+		if (!fluid.ReadRenderTarget(rgba)) { std::fprintf(stderr, "read-back failed\n"); return 1; }
+		FILE* fp = std::fopen(screenshot, "wb");
+		if (!fp) { std::perror(screenshot); return 1; }
+		std::fprintf(fp, "P6\n%u %u\n255\n", width, height);
+		for (size_t p = 0; p < (size_t)width * height; ++p) std::fwrite(&rgba[4 * p], 1, 3, fp);
+		std::fclose(fp);
+	}
 	const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	fx_frame_info fi;
 	fx_get_frame_info(fluid.Handle(), &fi);

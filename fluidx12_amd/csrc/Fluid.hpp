@@ -62,7 +62,27 @@ public:
 		m_status = fx_update_frame(m_ctx, timeStep, frameIndex, &view.m[0][0], &proj.m[0][0], eye);
 	}
 	void Simulate(void* pCommandList /* hipStream_t */, uint8_t frameIndex) { m_status = fx_simulate(m_ctx, pCommandList, frameIndex); }
-	void Render(void* pCommandList /* hipStream_t */, uint8_t frameIndex, uint8_t flags) { m_status = fx_render(m_ctx, pCommandList, frameIndex, flags); }
+	// Fluid::Render (Fluid.cpp:412-446).  With a render target in use (ClearRenderTarget called at least once) the
+	// cube path ends in renderCube like the reference's (Fluid.cpp:430); without one only the cube map is produced.
+	void Render(void* pCommandList /* hipStream_t */, uint8_t frameIndex, uint8_t flags)
+	{
+		m_status = fx_render(m_ctx, pCommandList, frameIndex, flags);
+		if (m_status == FX_OK && m_hasTarget && (flags & RAY_MARCH_CUBEMAP)) m_status = fx_render_cube(m_ctx, pCommandList, frameIndex);
+	}
+	// the caller's ClearRenderTargetView on the swap-chain target (FluidX12.cpp:471-472)
+	void ClearRenderTarget(void* pCommandList, const float clearColor[4])
+	{
+		m_status = fx_clear_render_target(m_ctx, pCommandList, clearColor);
+		m_hasTarget = m_status == FX_OK;
+	}
+	// read the RGBA8 target back (the reference's screen-shot path reads the back buffer, FluidX12.cpp:640-660)
+	bool ReadRenderTarget(std::vector<uint8_t>& rgba)
+	{
+		rgba.resize(fx_field_bytes(m_ctx, FX_FIELD_TARGET));
+		if (rgba.empty()) return false;
+		m_status = fx_download(m_ctx, FX_FIELD_TARGET, rgba.data(), rgba.size());
+		return m_status == FX_OK;
+	}
 
 	// not in the reference: the void methods above cannot report failure there either (debug layer only)
 	int LastStatus() const { return m_status; }
@@ -71,6 +91,7 @@ public:
 protected:
 	fx_ctx* m_ctx;
 	int m_status = FX_OK;
+	bool m_hasTarget = false;
 };
 
 // SH side of class LightProbe (LightProbe.h:16-26); the DDS loader and the sky pass are out of scope
