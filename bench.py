@@ -262,12 +262,21 @@ def main():
                 fluid.Render(0, fx.Fluid.OPTIMIZED, to_target=True)     # + renderCube: cube map -> 1920x1080 RGBA8 target
             fluid.Synchronize()
             tr_ = fluid.timing_read(reset=True)
+            # the paper's comparison (row f-2): the direct screen-space march of every pixel with the same light volume
+            fluid.Render(0, fx.Fluid.SEPARATE_LIGHT_PASS)
+            fluid.Synchronize()
+            fluid.timing_read(reset=True)
+            for _ in range(nr):
+                fluid.Render(0, fx.Fluid.SEPARATE_LIGHT_PASS)
+            fluid.Synchronize()
+            td_ = fluid.timing_read(reset=True)
             fi = fluid.frame_info()
             rays = bin(fi.visibility_mask).count("1") * fi.cube_size ** 2
             render = {"mode": "OPTIMIZED (CSRayMarchL + CSRayMarchV) + renderCube (PSRayCastCube, raster-free)", "viewport": [1920, 1080], "cube_lod": fi.cube_lod,
                       "cube_size": fi.cube_size, "ray_samples": fi.ray_samples, "light_samples": 64, "rays": rays,
                       "light_pass_ms": tr_.light_ms / nr, "view_pass_ms": tr_.view_ms / nr,
                       "cube_resolve_ms": tr_.resolve_ms / nr,
+                      "direct_march_ms": td_.view_ms / nr, "direct_rays": 1920 * 1080,
                       "rays_per_s": rays / (tr_.view_ms / nr * 1e-3) if tr_.view_ms > 0 else None,
                       "light_voxels_per_s": float(G) ** 3 / (tr_.light_ms / nr * 1e-3) if tr_.light_ms > 0 else None}
         fluid.timing_enable(False)

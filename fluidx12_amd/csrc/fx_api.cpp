@@ -644,13 +644,51 @@ int fx_simulate(fx_ctx* ctx, void* stream, uint8_t frame_index)
 	return simulate_impl(ctx, pick_stream(ctx, stream));
 }
 
+// the zero fill is ordered on the stream the target is about to be used on (the context's streams do not synchronise
+// with the NULL stream)
+static int ensure_target(fx_ctx* ctx, hipStream_t s)
+{
+	if (ctx->target) return FX_OK;
+	const size_t n = (size_t)ctx->desc.viewport_w * ctx->desc.viewport_h;
+	if (!n) return FX_E_INVALID;
+	FX_HIP(hipMalloc((void**)&ctx->target, n * 4));
+	FX_HIP(hipMemsetAsync(ctx->target, 0, n * 4, s));
+	FX_HIP(hipMalloc((void**)&ctx->target_float, n * 16));
+	FX_HIP(hipMemsetAsync(ctx->target_float, 0, n * 16, s));
+	return FX_OK;
+}
+
 int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags)
 {
 	if (!ctx || frame_index >= FX_FRAME_COUNT) return FX_E_INVALID;
 	if (ctx->g.Zg <= 1) return FX_E_INVALID;       // 2D visualisation is a raster pass (out of scope)
-	if (!(flags & FX_RAY_MARCH_CUBEMAP)) return FX_E_INVALID;   // direct screen-space marching: "next" row f-2
 	if (!ctx->view_valid) return FX_E_STATE;
 	if (ctx->g.nz != ctx->g.Zg) return FX_E_INVALID;            // rays cross slabs: multi-GPU rendering is row f-3
+	if (!(flags & FX_RAY_MARCH_CUBEMAP)) {
+		// direct screen-space marching (Fluid.cpp:432-443): one ray per pixel, straight onto the render target
+		DeviceGuard dgd(ctx->device);
+		hipStream_t sd = pick_stream(ctx, stream);
+		int rc = ensure_target(ctx, sd);
+		if (rc) return rc;
+		const void* colord = ctx->col[ctx->frame_parity];
+		const int W = (int)ctx->desc.viewport_w, H = (int)ctx->desc.viewport_h;
+		if (flags & FX_SEPARATE_LIGHT_PASS) {
+			{
+				ScopedMark mk(ctx, sd, MK_LIGHT);
+				FX_HIP(launch_raymarch_light(ctx->g, ctx->half, colord, ctx->lightmap, ctx->fc,
+					ctx->has_sh ? ctx->sh_dev : nullptr, ctx->max_light_samples, sd));
+			}
+			ScopedMark mk(ctx, sd, MK_VIEW);
+			FX_HIP(launch_raycast_direct(ctx->g, ctx->half, colord, ctx->lightmap, ctx->fc, nullptr, W, H,
+				ctx->ray_samples, ctx->max_light_samples, 1, ctx->target, ctx->target_float, sd));       // rayCastVDirect :953-972
+		} else {
+			ScopedMark mk(ctx, sd, MK_VIEW);
+			FX_HIP(launch_raycast_direct(ctx->g, ctx->half, colord, nullptr, ctx->fc, ctx->has_sh ? ctx->sh_dev : nullptr, W, H,
+				ctx->max_ray_samples, ctx->max_light_samples, 0, ctx->target, ctx->target_float, sd));   // rayCastDirect :932-951
+		}
+		if (ctx->timing_on) ctx->acc.renders += 1;
+		return FX_OK;
+	}
 	hipStream_t s = pick_stream(ctx, stream);
 	DeviceGuard dg(ctx->device);
 	const void* color = ctx->col[ctx->frame_parity];
@@ -674,23 +712,11 @@ int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags)
 	return FX_OK;
 }
 
-static int ensure_target(fx_ctx* ctx)
-{
-	if (ctx->target) return FX_OK;
-	const size_t n = (size_t)ctx->desc.viewport_w * ctx->desc.viewport_h;
-	if (!n) return FX_E_INVALID;
-	FX_HIP(hipMalloc((void**)&ctx->target, n * 4));
-	FX_HIP(hipMemset(ctx->target, 0, n * 4));
-	FX_HIP(hipMalloc((void**)&ctx->target_float, n * 16));
-	FX_HIP(hipMemset(ctx->target_float, 0, n * 16));
-	return FX_OK;
-}
-
 int fx_clear_render_target(fx_ctx* ctx, void* stream, const float rgba[4])
 {
 	if (!ctx || !rgba) return FX_E_INVALID;
 	DeviceGuard dg(ctx->device);
-	int rc = ensure_target(ctx);
+	int rc = ensure_target(ctx, pick_stream(ctx, stream));
 	if (rc) return rc;
 	FX_HIP(launch_clear_target(ctx->target, (int)ctx->desc.viewport_w, (int)ctx->desc.viewport_h, rgba, pick_stream(ctx, stream)));
 	return FX_OK;
@@ -703,9 +729,9 @@ int fx_render_cube(fx_ctx* ctx, void* stream, uint8_t frame_index)
 	if (!ctx->view_valid) return FX_E_STATE;
 	if (ctx->g.nz != ctx->g.Zg) return FX_E_INVALID;
 	DeviceGuard dg(ctx->device);
-	int rc = ensure_target(ctx);
-	if (rc) return rc;
 	hipStream_t s = pick_stream(ctx, stream);
+	int rc = ensure_target(ctx, s);
+	if (rc) return rc;
 	ScopedMark mk(ctx, s, MK_RESOLVE);
 	FX_HIP(launch_resolve_cube(ctx->cube + ctx->cube_mip_offset[ctx->cube_lod], ctx->g.X >> ctx->cube_lod, ctx->fc,
 		(int)ctx->desc.viewport_w, (int)ctx->desc.viewport_h, ctx->target, ctx->target_float, s));
@@ -739,6 +765,7 @@ int fx_synchronize(fx_ctx* ctx)
 		if (hipMemcpy(&flag, c->halo_overflow, sizeof flag, hipMemcpyDeviceToHost) != hipSuccess) return FX_E_DEVICE;
 		if (flag) {
 			(void)hipMemset(c->halo_overflow, 0, sizeof flag);
+			(void)hipDeviceSynchronize();      // the context's streams do not order against the NULL stream
 			rc = FX_E_HALO;
 		}
 	}

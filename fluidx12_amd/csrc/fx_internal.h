@@ -79,6 +79,10 @@ hipError_t launch_raymarch_light(const Geom& g, int half_store, const void* colo
 hipError_t launch_raymarch_view(const Geom& g, int half_store, const void* color, const uint32_t* lightmap,
 	const FrameConsts& fc, const float* sh, int cube_size, uint32_t mask, uint32_t num_samples,
 	uint32_t num_light_samples, int separate, uint8_t* cube, hipStream_t s);
+// direct screen-space march (row f-2): one ray per pixel, blended into the RGBA8 target (and/or kept as float4)
+hipError_t launch_raycast_direct(const Geom& g, int half_store, const void* color, const uint32_t* lightmap,
+	const FrameConsts& fc, const float* sh, int W, int H, uint32_t num_samples, uint32_t num_light_samples, int separate,
+	uint8_t* target, float* out_float, hipStream_t s);
 hipError_t launch_lightmap_decode(const uint32_t* lightmap, float* out, size_t n, hipStream_t s);
 
 // ---- cube map -> screen resolve (fx_resolve.hip; row f-1)

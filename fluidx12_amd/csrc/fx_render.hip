@@ -287,46 +287,19 @@ __device__ __forceinline__ uint32_t to_unorm8(float v)
 	return (uint32_t)(v * 255.0f + 0.5f);
 }
 
+// the march of one view ray (CSRayMarch.hlsl:140-190 == PSRayCast.hlsl:72-122): o = origin on/in the cube, d = unit
+// direction, tMax = ray parameter at the cube-map target (the direct pixel march has none: FLT_MAX)
 template <bool HALF, bool SEPARATE>
-__global__ __launch_bounds__(64) void k_raymarch_view(const Geom g, const typename ColTex<HALF>::T* __restrict__ col,
-	const uint32_t* __restrict__ lightmap, const FrameConsts fc, const float* __restrict__ sh, int size, uint32_t mask,
-	uint32_t numSamples, uint32_t numLightSamples, uint32_t* __restrict__ cube)
+__device__ __forceinline__ void march_ray(const Geom& g, const typename ColTex<HALF>::T* __restrict__ col,
+	const uint32_t* __restrict__ lightmap, const FrameConsts& fc, const float* __restrict__ sh, const float o[3], const float d[3],
+	float tMax, uint32_t numSamples, uint32_t numLightSamples, float& sr, float& sg, float& sb, float& sa)
 {
-	const int face = blockIdx.z;
-	if (!((mask >> face) & 1u)) return;                                            // CSRayMarch.hlsl:102
-	const int x = blockIdx.x * 8 + threadIdx.x, y = blockIdx.y * 8 + threadIdx.y;
-	if (x >= size || y >= size) return;
-
-	float o[3];
-#pragma unroll
-	for (int a = 0; a < 3; ++a) {                                                  // :107
-		const float* r = fc.world_i + 4 * a;
-		o[a] = fmaf(r[3], 1.0f, fmaf(fc.eye_pt[2], r[2], fmaf(fc.eye_pt[1], r[1], fc.eye_pt[0] * r[0])));
-	}
-	// GetLocalPos (:39-64)
-	const float px = fmaf(((float)x + 0.5f) / (float)size, 2.0f, -1.0f);
-	const float py = -fmaf(((float)y + 0.5f) / (float)size, 2.0f, -1.0f);
-	float tg[3];
-	switch (face) {
-	case 0: tg[0] = 1.0f;  tg[1] = py;    tg[2] = -px;   break;
-	case 1: tg[0] = -1.0f; tg[1] = py;    tg[2] = px;    break;
-	case 2: tg[0] = px;    tg[1] = 1.0f;  tg[2] = -py;   break;
-	case 3: tg[0] = px;    tg[1] = -1.0f; tg[2] = py;    break;
-	case 4: tg[0] = px;    tg[1] = py;    tg[2] = 1.0f;  break;
-	default: tg[0] = -px;  tg[1] = py;    tg[2] = -1.0f; break;
-	}
-	float d[3] = { -o[0] + tg[0], -o[1] + tg[1], -o[2] + tg[2] };
-	const float rl = rsqf(dot3(d[0], d[1], d[2], d[0], d[1], d[2]));               // :115
-	d[0] *= rl; d[1] *= rl; d[2] *= rl;
-	if (!compute_ray_origin(o, d)) return;                                         // :116
-	const float tMax = fmaxf((tg[2] + -o[2]) / d[2], fmaxf((tg[1] + -o[1]) / d[1], (tg[0] + -o[0]) / d[0]));   // :118
-
 	const float stepScale = 3.46410155f / (float)numSamples;
 	const float lightStep = 3.46410155f / (float)numLightSamples;
 	float lx = 0.0f, ly = 0.0f, lz = 0.0f;
 	if (!SEPARATE) light_dir_local(fc, lx, ly, lz);
 
-	float sr = 0.0f, sg = 0.0f, sb = 0.0f, sa = 0.0f;
+	sr = 0.0f; sg = 0.0f; sb = 0.0f; sa = 0.0f;
 	float t = 0.0f, prev = 0.0f;
 	for (uint32_t i = 0; i < numSamples; ++i) {                                    // :146
 		const float qx = fmaf(d[0], t, o[0]), qy = fmaf(d[1], t, o[1]), qz = fmaf(d[2], t, o[2]);
@@ -362,9 +335,90 @@ __global__ __launch_bounds__(64) void k_raymarch_view(const Geom g, const typena
 		t = t + newStep;                                                           // :187-188
 		if (tMax < t) break;                                                       // :189
 	}
+}
+
+template <bool HALF, bool SEPARATE>
+__global__ __launch_bounds__(64) void k_raymarch_view(const Geom g, const typename ColTex<HALF>::T* __restrict__ col,
+	const uint32_t* __restrict__ lightmap, const FrameConsts fc, const float* __restrict__ sh, int size, uint32_t mask,
+	uint32_t numSamples, uint32_t numLightSamples, uint32_t* __restrict__ cube)
+{
+	const int face = blockIdx.z;
+	if (!((mask >> face) & 1u)) return;                                            // CSRayMarch.hlsl:102
+	const int x = blockIdx.x * 8 + threadIdx.x, y = blockIdx.y * 8 + threadIdx.y;
+	if (x >= size || y >= size) return;
+
+	float o[3];
+#pragma unroll
+	for (int a = 0; a < 3; ++a) {                                                  // :107
+		const float* r = fc.world_i + 4 * a;
+		o[a] = fmaf(r[3], 1.0f, fmaf(fc.eye_pt[2], r[2], fmaf(fc.eye_pt[1], r[1], fc.eye_pt[0] * r[0])));
+	}
+	// GetLocalPos (:39-64)
+	const float px = fmaf(((float)x + 0.5f) / (float)size, 2.0f, -1.0f);
+	const float py = -fmaf(((float)y + 0.5f) / (float)size, 2.0f, -1.0f);
+	float tg[3];
+	switch (face) {
+	case 0: tg[0] = 1.0f;  tg[1] = py;    tg[2] = -px;   break;
+	case 1: tg[0] = -1.0f; tg[1] = py;    tg[2] = px;    break;
+	case 2: tg[0] = px;    tg[1] = 1.0f;  tg[2] = -py;   break;
+	case 3: tg[0] = px;    tg[1] = -1.0f; tg[2] = py;    break;
+	case 4: tg[0] = px;    tg[1] = py;    tg[2] = 1.0f;  break;
+	default: tg[0] = -px;  tg[1] = py;    tg[2] = -1.0f; break;
+	}
+	float d[3] = { -o[0] + tg[0], -o[1] + tg[1], -o[2] + tg[2] };
+	const float rl = rsqf(dot3(d[0], d[1], d[2], d[0], d[1], d[2]));               // :115
+	d[0] *= rl; d[1] *= rl; d[2] *= rl;
+	if (!compute_ray_origin(o, d)) return;                                         // :116
+	const float tMax = fmaxf((tg[2] + -o[2]) / d[2], fmaxf((tg[1] + -o[1]) / d[1], (tg[0] + -o[0]) / d[0]));   // :118
+
+	float sr, sg, sb, sa;
+	march_ray<HALF, SEPARATE>(g, col, lightmap, fc, sh, o, d, tMax, numSamples, numLightSamples, sr, sg, sb, sa);
 	sr *= 0.159154937f; sg *= 0.159154937f; sb *= 0.159154937f;                    // :192
 	cube[((size_t)face * size + y) * size + x] =
 		to_unorm8(sr) | (to_unorm8(sg) << 8) | (to_unorm8(sb) << 16) | (to_unorm8(sa) << 24);   // :195
+}
+
+// ---------------------------------------------------------------------------------------------------
+// direct screen-space march (row f-2): PSRayCast.hlsl:44-127 (merged) / PSRayCastV.hlsl (SEPARATE: light-map fetch),
+// Fluid::rayCastDirect / rayCastVDirect (Fluid.cpp:932-972).  One thread per pixel, 8x8-pixel tile per wave so that the
+// taps of a wave stay spatially coherent; output = the shader's premultiplied SV_TARGET, merged into the RGBA8 target
+// with the PREMULTIPLIED blend (Fluid.cpp:670,685) and optionally kept as float4 (parity tests).
+// ---------------------------------------------------------------------------------------------------
+template <bool HALF, bool SEPARATE>
+__global__ __launch_bounds__(64) void k_raycast_direct(const Geom g, const typename ColTex<HALF>::T* __restrict__ col,
+	const uint32_t* __restrict__ lightmap, const FrameConsts fc, const float* __restrict__ sh, int W, int H,
+	uint32_t numSamples, uint32_t numLightSamples, uint32_t* __restrict__ target, float4* __restrict__ out_float)
+{
+	const int px = blockIdx.x * 8 + threadIdx.x, py = blockIdx.y * 8 + threadIdx.y;
+	if (px >= W || py >= H) return;
+	const size_t pix = (size_t)py * W + px;
+	if (out_float) out_float[pix] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	// TexcoordToLocalPos (PSRayCast.hlsl:17-26)
+	const float u = ((float)px + 0.5f) / (float)W, v = ((float)py + 0.5f) / (float)H;
+	const float qx = fmaf(u, 2.0f, -1.0f), qy = fmaf(v, -2.0f, 1.0f);
+	const float* M = fc.wvp_i;
+	const float h0 = dot3(qx, qy, 1.0f, M[0], M[1], M[3]), h1 = dot3(qx, qy, 1.0f, M[4], M[5], M[7]);
+	const float h2 = dot3(qx, qy, 1.0f, M[8], M[9], M[11]), h3 = dot3(qx, qy, 1.0f, M[12], M[13], M[15]);
+	float o[3] = { h0 / h3, h1 / h3, h2 / h3 }, d[3];
+#pragma unroll
+	for (int a = 0; a < 3; ++a) {                                                  // :47-49
+		const float* r = fc.world_i + 4 * a;
+		const float e = fmaf(r[3], 1.0f, fmaf(fc.eye_pt[2], r[2], fmaf(fc.eye_pt[1], r[1], fc.eye_pt[0] * r[0])));
+		d[a] = o[a] + -e;
+	}
+	const float rl = rsqf(dot3(d[0], d[1], d[2], d[0], d[1], d[2]));
+	d[0] *= rl; d[1] *= rl; d[2] *= rl;
+	if (!compute_ray_origin(o, d)) return;                                         // :50 discard
+	float sr, sg, sb, sa;
+	march_ray<HALF, SEPARATE>(g, col, lightmap, fc, sh, o, d, 3.40282347e+38f, numSamples, numLightSamples, sr, sg, sb, sa);
+	sr *= 0.159154937f; sg *= 0.159154937f; sb *= 0.159154937f;                    // :124
+	if (out_float) out_float[pix] = make_float4(sr, sg, sb, sa);
+	if (target) {
+		const uint32_t dd = target[pix];
+		const float ia = 1.0f - sa;
+		target[pix] = to_unorm8(fmaf((float)(dd & 255u) / 255.0f, ia, sr)) | (to_unorm8(fmaf((float)((dd >> 8) & 255u) / 255.0f, ia, sg)) << 8)
+			| (to_unorm8(fmaf((float)((dd >> 16) & 255u) / 255.0f, ia, sb)) << 16) | (to_unorm8(fmaf((float)(dd >> 24) / 255.0f, ia, sa)) << 24);
+	}
 }
 
 __global__ __launch_bounds__(256) void k_lightmap_decode(const uint32_t* __restrict__ lm, float* __restrict__ out, size_t n)
@@ -393,6 +447,20 @@ hipError_t launch_raymarch_view(const Geom& g, int half_store, const void* color
 	uint32_t* out = reinterpret_cast<uint32_t*>(cube);
 #define FX_LAUNCH(H, S) hipLaunchKernelGGL((k_raymarch_view<H, S>), grid, block, 0, s, g, \
 	(const typename ColTex<H>::T*)color, lightmap, fc, sh, cube_size, mask, num_samples, num_light_samples, out)
+	if (half_store) { if (separate) FX_LAUNCH(true, true); else FX_LAUNCH(true, false); }
+	else { if (separate) FX_LAUNCH(false, true); else FX_LAUNCH(false, false); }
+#undef FX_LAUNCH
+	return hipGetLastError();
+}
+
+hipError_t launch_raycast_direct(const Geom& g, int half_store, const void* color, const uint32_t* lightmap,
+	const FrameConsts& fc, const float* sh, int W, int H, uint32_t num_samples, uint32_t num_light_samples, int separate,
+	uint8_t* target, float* out_float, hipStream_t s)
+{
+	const dim3 grid((W + 7) / 8, (H + 7) / 8, 1), block(8, 8, 1);
+#define FX_LAUNCH(HF, S) hipLaunchKernelGGL((k_raycast_direct<HF, S>), grid, block, 0, s, g, \
+	(const typename ColTex<HF>::T*)color, lightmap, fc, sh, W, H, num_samples, num_light_samples, \
+	reinterpret_cast<uint32_t*>(target), reinterpret_cast<float4*>(out_float))
 	if (half_store) { if (separate) FX_LAUNCH(true, true); else FX_LAUNCH(true, false); }
 	else { if (separate) FX_LAUNCH(false, true); else FX_LAUNCH(false, false); }
 #undef FX_LAUNCH

@@ -146,7 +146,7 @@ class Fluid:
         always does: the cube map is resolved onto the render target (ClearRenderTarget first, as the caller does)."""
         self._need()
         capi.check(self._lib.fx_render(self._ctx, stream, frameIndex, flags), "Render")
-        if to_target:
+        if to_target and (flags & capi.RAY_MARCH_CUBEMAP):     # the direct modes write the target themselves
             self.RenderCube(frameIndex, stream)
 
     def ClearRenderTarget(self, rgba=(0.2, 0.2, 0.2, 0.0), stream=None):

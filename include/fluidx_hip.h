@@ -126,8 +126,11 @@ int fx_update_frame(fx_ctx* ctx, float time_step, uint8_t frame_index,
 	const float view[16], const float proj[16], const float eye[3]);
 /* Fluid::Simulate (Fluid.cpp:348-410): enqueues advect + divergence + N sweeps + project */
 int fx_simulate(fx_ctx* ctx, void* stream, uint8_t frame_index);
-/* Fluid::Render (Fluid.cpp:412-446): cube-map-space paths (flags & FX_RAY_MARCH_CUBEMAP);
- * writes the cube map (and light map); the raster resolve to a back buffer is out of scope. */
+/* Fluid::Render (Fluid.cpp:412-446), all four flag combinations:
+ *   flags & FX_RAY_MARCH_CUBEMAP   cube-map-space march (merged, or light volume + view pass with FX_SEPARATE_LIGHT_PASS):
+ *                                  writes the cube map (and light map); fx_render_cube below puts it on the screen
+ *   otherwise                      direct screen-space march, one ray per pixel of the viewport (PSRayCast / PSRayCastV,
+ *                                  Fluid.cpp:932-972), blended straight into the render target (PREMULTIPLIED) */
 int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags);
 /* The caller-side half of the cube path (row f-1 of SURVEY.md 8): the render target the reference's caller binds.
  * fx_clear_render_target = ClearRenderTargetView (FluidX12.cpp:471-472; the demo clears to (0.2, 0.2, 0.2, 0));

@@ -54,6 +54,10 @@ void orc_raymarch_light(const float* color, float* lightmap, int X, int Y, int Z
 void orc_raymarch_view(const float* color, const float* lightmap, int X, int Y, int Z, const orc_frame* fc,
 	int size, uint32_t mask, uint32_t numSamples, uint32_t numLightSamples, int hasSH, int separate,
 	float* cube_f32, uint8_t* cube_u8);
+// direct screen-space march (row f-2; PSRayCast.hlsl / PSRayCastV.hlsl), one ray per pixel
+void orc_raycast_direct(const float* color, const float* lightmap, int X, int Y, int Z, const orc_frame* fc,
+	const float* wvp_i, int W, int H, uint32_t numSamples, uint32_t numLightSamples, int hasSH, int separate,
+	float* out_rgba, uint8_t* covered);
 uint32_t orc_pack_r11g11b10(float r, float g, float b);
 void orc_unpack_r11g11b10(uint32_t v, float* rgb);
 

@@ -60,6 +60,7 @@ def lib():
                                           C.POINTER(u), fp]
         _lib.orc_raymarch_light.argtypes = [fp, fp, i, i, i, C.POINTER(Frame), u, i, i]
         _lib.orc_raymarch_view.argtypes = [fp, fp, i, i, i, C.POINTER(Frame), i, u, u, u, i, i, fp, u8p]
+        _lib.orc_raycast_direct.argtypes = [fp, fp, i, i, i, C.POINTER(Frame), fp, i, i, u, u, i, i, fp, u8p]
         _lib.orc_world_view_proj_inverse.argtypes = [fp, fp, fp]
         _lib.orc_resolve_cube.argtypes = [u8p, i, C.POINTER(Frame), fp, i, i, fp, u8p]
         _lib.orc_blend_premultiplied.argtypes = [fp, u8p, u8p, i, i]
@@ -193,6 +194,18 @@ def raymarch_view(col, lightmap, frame, size, mask, num_samples, num_light_sampl
     lib().orc_raymarch_view(_fp(col), lmp, X, Y, Z, C.byref(frame), size, mask, num_samples, num_light_samples,
                             int(has_sh), int(separate), _fp(cf), cu.ctypes.data_as(C.POINTER(C.c_uint8)))
     return cf, cu
+
+
+def raycast_direct(col, lightmap, frame, wvp_i, width, height, num_samples, num_light_samples=64, has_sh=False, separate=True):
+    """PSRayCast / PSRayCastV per screen pixel: (premultiplied float[H][W][4], covered uint8[H][W])"""
+    col = _f32(col)
+    Z, Y, X, _ = col.shape
+    out = np.empty((height, width, 4), np.float32)
+    cov = np.empty((height, width), np.uint8)
+    lmp = _fp(_f32(lightmap)) if lightmap is not None else None
+    lib().orc_raycast_direct(_fp(col), lmp, X, Y, Z, C.byref(frame), _fp(_f32(wvp_i)), width, height, num_samples,
+                             num_light_samples, int(has_sh), int(separate), _fp(out), cov.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out, cov
 
 
 def world_view_proj_inverse(view, proj):

@@ -194,6 +194,49 @@ bool compute_ray_origin(float o[3], const float d[3])
 	return hit;
 }
 
+// the march of one view ray (CSRayMarch.hlsl:140-190 == PSRayCast.hlsl:72-122): o = ray origin on/in the cube, d = unit
+// direction, tMax = parameter at the cube-map target (the direct pixel-shader march has none: pass FLT_MAX)
+void march(float scatter[4], const Vol& v, const orc_frame* fc, const float o[3], const float d[3], float tMax,
+	const float ldir[3], const float lightColor[3], const float ambient[3], float stepScale, float lightStep,
+	uint32_t numSamples, uint32_t numLightSamples, int hasSH, int separate)
+{
+	scatter[0] = scatter[1] = scatter[2] = scatter[3] = 0.0f;
+	float t = 0.0f, prevDensity = 0.0f;
+	for (uint32_t i = 0; i < numSamples; ++i) {            // :146
+		float pos[3], uvw[3];
+		for (int a = 0; a < 3; ++a) pos[a] = std::fmaf(d[a], t, o[a]);
+		if (outside(pos)) break;                          // :149
+		for (int a = 0; a < 3; ++a) uvw[a] = std::fmaf(pos[a], 0.5f, 0.5f);
+		const Taps tp = make_taps(uvw, v.dims, ADDR_CLAMP);
+		float c[4];
+		for (int a = 0; a < 4; ++a) c[a] = sample_chan(v.color, 4, a, v.dims, tp);   // :157
+		float newStep = stepScale;
+		if (0.00999999978f < c[3]) {                      // :161
+			float light[3];
+			if (separate) {
+				for (int a = 0; a < 3; ++a) light[a] = sample_chan(v.light, 3, a, v.dims, tp);
+			} else {
+				float shadow = 1.0f, ao = 1.0f, irr[3] = { 0, 0, 0 };
+				cast_light_ray(shadow, v, pos, ldir, lightStep, numLightSamples);        // RayMarch.hlsli:270
+				if (hasSH) gi_term(irr, ao, v, fc, pos, uvw, lightStep, numLightSamples);   // :275-283
+				for (int a = 0; a < 3; ++a) {
+					const float amb = hasSH ? ao * irr[a] : ambient[a];
+					light[a] = std::fmaf(lightColor[a], shadow, amb);                   // :293
+				}
+			}
+			const float transm = -scatter[3] + 1.0f;                                    // :170
+			newStep = step_factor(-prevDensity + c[3], transm, c[3]) * stepScale;       // :172
+			for (int a = 0; a < 3; ++a)
+				scatter[a] = std::fmaf(transm * (light[a] * c[a]), 0.800000012f, scatter[a]);   // :180-181
+			scatter[3] = std::fmaf(0.800000012f * c[3], transm, scatter[3]);
+			if (transm < 0.00999999978f) break;           // :183
+			prevDensity = c[3];                           // :174
+		}
+		t = t + newStep;                                  // :187-188
+		if (tMax < t) break;                              // :189
+	}
+}
+
 inline uint8_t to_unorm8(float v)
 {
 	if (!(v > 0.0f)) return 0;                     // NaN, negatives
@@ -293,41 +336,8 @@ void orc_raymarch_view(const float* color, const float* lightmap, int X, int Y, 
 				for (int a = 0; a < 3; ++a) tq[a] = (target[a] + -o[a]) / d[a];   // ComputeTargetHit :178-183
 				const float tMax = std::fmax(tq[2], std::fmax(tq[1], tq[0]));
 
-				float scatter[4] = { 0, 0, 0, 0 };
-				float t = 0.0f, prevDensity = 0.0f;
-				for (uint32_t i = 0; i < numSamples; ++i) {            // :146
-					float pos[3], uvw[3];
-					for (int a = 0; a < 3; ++a) pos[a] = std::fmaf(d[a], t, o[a]);
-					if (outside(pos)) break;                          // :149
-					for (int a = 0; a < 3; ++a) uvw[a] = std::fmaf(pos[a], 0.5f, 0.5f);
-					const Taps tp = make_taps(uvw, v.dims, ADDR_CLAMP);
-					float c[4];
-					for (int a = 0; a < 4; ++a) c[a] = sample_chan(color, 4, a, v.dims, tp);   // :157
-					float newStep = stepScale;
-					if (0.00999999978f < c[3]) {                      // :161
-						float light[3];
-						if (separate) {
-							for (int a = 0; a < 3; ++a) light[a] = sample_chan(lightmap, 3, a, v.dims, tp);
-						} else {
-							float shadow = 1.0f, ao = 1.0f, irr[3] = { 0, 0, 0 };
-							cast_light_ray(shadow, v, pos, ldir, lightStep, numLightSamples);        // RayMarch.hlsli:270
-							if (hasSH) gi_term(irr, ao, v, fc, pos, uvw, lightStep, numLightSamples);   // :275-283
-							for (int a = 0; a < 3; ++a) {
-								const float amb = hasSH ? ao * irr[a] : ambient[a];
-								light[a] = std::fmaf(lightColor[a], shadow, amb);                   // :293
-							}
-						}
-						const float transm = -scatter[3] + 1.0f;                                    // :170
-						newStep = step_factor(-prevDensity + c[3], transm, c[3]) * stepScale;       // :172
-						for (int a = 0; a < 3; ++a)
-							scatter[a] = std::fmaf(transm * (light[a] * c[a]), 0.800000012f, scatter[a]);   // :180-181
-						scatter[3] = std::fmaf(0.800000012f * c[3], transm, scatter[3]);
-						if (transm < 0.00999999978f) break;           // :183
-						prevDensity = c[3];                           // :174
-					}
-					t = t + newStep;                                  // :187-188
-					if (tMax < t) break;                              // :189
-				}
+				float scatter[4];
+				march(scatter, v, fc, o, d, tMax, ldir, lightColor, ambient, stepScale, lightStep, numSamples, numLightSamples, hasSH, separate);
 				const size_t o4 = (((size_t)face * size + y) * size + x) * 4;
 				for (int a = 0; a < 3; ++a) scatter[a] *= 0.159154937f;                    // :192
 				for (int a = 0; a < 4; ++a) {
@@ -335,6 +345,54 @@ void orc_raymarch_view(const float* color, const float* lightmap, int X, int Y, 
 					if (cube_u8) cube_u8[o4 + a] = to_unorm8(scatter[a]);                  // :195
 				}
 			}
+		}
+}
+
+// ---------------------------------------------------------------------------------------------
+// PSRayCast.hlsl:44-127 (separate == 0: nested light march, cb2 = {maxRaySamples, hasSH, maxLightSamples},
+// Fluid.cpp:932-951) and PSRayCastV.hlsl (separate != 0: light-map fetch, cb2 = {raySampleCount}, Fluid.cpp:953-972):
+// the direct screen-space march, one ray per pixel from the near plane through the volume; the pixel's UV is the
+// screen-quad interpolant (px + .5) / W.  out_rgba float[H][W][4] premultiplied, zeros + covered = 0 where discarded.
+// ---------------------------------------------------------------------------------------------
+void orc_raycast_direct(const float* color, const float* lightmap, int X, int Y, int Z, const orc_frame* fc,
+	const float* wvp_i, int W, int H, uint32_t numSamples, uint32_t numLightSamples, int hasSH, int separate,
+	float* out_rgba, uint8_t* covered)
+{
+	const Vol v{ color, lightmap, { X, Y, Z } };
+	float eye[3];
+	for (int a = 0; a < 3; ++a) {
+		const float* r = fc->world_i + 4 * a;
+		eye[a] = std::fmaf(r[3], 1.0f, std::fmaf(fc->eye_pt[2], r[2], std::fmaf(fc->eye_pt[1], r[1], fc->eye_pt[0] * r[0])));
+	}
+	float ldir[3];
+	light_dir_local(ldir, fc);
+	float lightColor[3], ambient[3];
+	for (int a = 0; a < 3; ++a) { lightColor[a] = fc->light_color[3] * fc->light_color[a]; ambient[a] = fc->ambient[3] * fc->ambient[a]; }
+	const float stepScale = 3.46410155f / (float)numSamples;
+	const float lightStep = 3.46410155f / (float)numLightSamples;
+#pragma omp parallel for schedule(dynamic, 1)
+	for (int py = 0; py < H; ++py)
+		for (int px = 0; px < W; ++px) {
+			float* out = out_rgba + ((size_t)py * W + px) * 4;
+			out[0] = out[1] = out[2] = out[3] = 0.0f;
+			covered[(size_t)py * W + px] = 0;
+			const float u = ((float)px + 0.5f) / (float)W, vv = ((float)py + 0.5f) / (float)H;
+			const float q[3] = { std::fmaf(u, 2.0f, -1.0f), std::fmaf(vv, -2.0f, 1.0f), 1.0f };   // TexcoordToLocalPos :17-26
+			float h[4];
+			for (int r = 0; r < 4; ++r) {
+				const float col[3] = { wvp_i[4 * r + 0], wvp_i[4 * r + 1], wvp_i[4 * r + 3] };
+				h[r] = dp3(q, col);
+			}
+			float o[3] = { h[0] / h[3], h[1] / h[3], h[2] / h[3] }, d[3];
+			for (int a = 0; a < 3; ++a) d[a] = o[a] + -eye[a];
+			normalize3(d);                                                     // :49
+			if (!compute_ray_origin(o, d)) continue;                          // :50 discard
+			float scatter[4];
+			march(scatter, v, fc, o, d, 3.40282347e+38f, ldir, lightColor, ambient, stepScale, lightStep, numSamples,
+				numLightSamples, hasSH, separate);
+			for (int a = 0; a < 3; ++a) out[a] = scatter[a] * 0.159154937f;   // :124
+			out[3] = scatter[3];
+			covered[(size_t)py * W + px] = 1;
 		}
 }
 

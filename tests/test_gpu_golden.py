@@ -14,6 +14,7 @@ SIM = np.load(os.path.join(GOLD, "dxbc_sim.npz"))
 REN = np.load(os.path.join(GOLD, "dxbc_render.npz"))
 SH = np.load(os.path.join(GOLD, "dxbc_sh.npz"))
 RES = np.load(os.path.join(GOLD, "dxbc_resolve.npz"))
+DIR = np.load(os.path.join(GOLD, "dxbc_direct.npz"))
 f32 = np.float32
 
 
@@ -131,6 +132,41 @@ def test_cube_resolve_vs_reference_binary(name):
     both = cov & ~disc
     d = np.abs(got[both] - ref[both])
     assert np.mean(d > 1e-4) < 2e-3 and np.median(d) < 2e-5
+
+
+@pytest.mark.parametrize("has_sh", [0, 1])
+def test_direct_ray_cast_vs_reference_binaries(has_sh):
+    """k_raycast_direct against PSRayCastV.cso / PSRayCast.cso (row f-2); own frame constants as in the resolve test"""
+    W, H, ns, nml, vw, vh = (int(v) for v in DIR["params"])
+    X = int(REN["params"][0])
+    f = fx.Fluid()
+    assert f.Init(W, H, (X, X, X), storage="fp16")
+    view, proj, eye = fx.default_camera(vw, vh)
+    f.upload(fx.FIELD_COLOR, REN["color"])
+    if has_sh:
+        f.SetSH(REN["sh"])
+
+    def close(key):
+        got = f.download(fx.FIELD_TARGET_FLOAT)
+        ref = DIR[key]                                      # zeros where discarded or where the ray met no smoke
+        lit = (ref[..., 3] > 0) | (got[..., 3] > 0)
+        assert lit.mean() > 0.1
+        d = np.abs(got[lit] - ref[lit])
+        assert np.mean(d > 2e-3) < 5e-3 and np.median(d) < 1e-4, (float(np.mean(d > 2e-3)), float(np.median(d)))
+
+    f.SetMaxSamples(ns, int(REN["params"][2]))
+    f.UpdateFrame(0.0, 0, view, proj, eye)
+    assert f.frame_info().ray_samples == ns
+    f.ClearRenderTarget()
+    f.Render(0, fx.Fluid.SEPARATE_LIGHT_PASS)               # rayMarchL + rayCastVDirect
+    f.Synchronize()
+    close("separate_sh%d" % has_sh)
+    f.SetMaxSamples(ns, nml)
+    f.UpdateFrame(0.0, 0, view, proj, eye)
+    f.ClearRenderTarget()
+    f.Render(0, fx.Fluid.RAY_MARCH_DIRECT)                  # rayCastDirect
+    f.Synchronize()
+    close("merged_sh%d" % has_sh)
 
 
 def test_sh_transform_vs_reference_binaries():

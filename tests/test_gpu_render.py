@@ -274,3 +274,58 @@ def test_render_cube_errors():
     f2.UpdateFrame(0.0, 0)
     with pytest.raises(fx.FluidxError):
         f2.RenderCube(0)                                  # 2D has no cube map
+
+
+# ---- direct screen-space march (row f-2: Fluid::rayCastDirect / rayCastVDirect, PSRayCast.hlsl, PSRayCastV.hlsl) ----------
+def rgba8_close(got, ref, frac=0.002):
+    d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() <= frac, (int(d.max()), float((d > 0).mean()))
+
+
+@pytest.mark.parametrize("flags,use_sh", [(fx.Fluid.SEPARATE_LIGHT_PASS, False), (fx.Fluid.RAY_MARCH_DIRECT, False),
+                                          (fx.Fluid.RAY_MARCH_DIRECT, True)])
+def test_direct_ray_cast_equals_oracle(flags, use_sh):
+    """Render() without RAY_MARCH_CUBEMAP: one ray per screen pixel.  SV_TARGET equals the oracle (bit for bit up to the
+    light map's rare R11G11B10 rounding flips in the separate mode) and the blended target equals the oracle's blend."""
+    X, vp = 32, (200, 150)
+    sh = (np.random.default_rng(4).random((9, 3)) * np.array([[2.0]] + [[0.5]] * 8)).astype(f32) if use_sh else None
+    col = smoke_state(X, 8, seed=6)
+    f, fr, lod, rs, mask = setup(X, col, *vp, sh=sh, max_samples=(48, 16))
+    view, proj, eye = fx.default_camera(*vp)
+    fr2, wvp_i = oracle_frame_of(f, view, proj, eye, X)
+    separate = bool(flags & fx.Fluid.SEPARATE_LIGHT_PASS)
+    if separate:
+        lm = orc.raymarch_light(col, fr, 16, use_sh, 2)
+        out, cov = orc.raycast_direct(col, lm, fr, wvp_i, vp[0], vp[1], rs, 16, use_sh, True)
+    else:
+        out, cov = orc.raycast_direct(col, None, fr, wvp_i, vp[0], vp[1], 48, 16, use_sh, False)
+    f.ClearRenderTarget()
+    f.Render(0, flags)
+    f.Synchronize()
+    got = f.download(fx.FIELD_TARGET_FLOAT)
+    assert 0.05 < cov.mean() < 0.9 and out[..., 3].max() > 0.3
+    if separate:
+        assert np.mean(got != out) < 2e-3 and np.abs(got - out).max() < 0.05
+    else:
+        assert np.array_equal(got.view(np.uint32), out.view(np.uint32))
+    target = np.empty((vp[1], vp[0], 4), np.uint8)
+    target[...] = (51, 51, 51, 0)
+    rgba8_close(f.download(fx.FIELD_TARGET), orc.blend_premultiplied(out, cov, target))
+
+
+def test_direct_and_cube_paths_show_the_same_picture():
+    """the paper's comparison: the cube-map-space path (march 4 x N^2 texels, then resolve) approximates the direct
+    march of every pixel -- same silhouette, close colours"""
+    X, vp = 48, (320, 240)
+    f, fr, lod, rs, mask = setup(X, smoke_state(X, 10, seed=7), *vp)
+    f.ClearRenderTarget()
+    f.Render(0, fx.Fluid.SEPARATE_LIGHT_PASS)
+    f.Synchronize()
+    direct = f.download(fx.FIELD_TARGET).astype(np.int32)
+    f.ClearRenderTarget()
+    f.Render(0, fx.Fluid.OPTIMIZED, to_target=True)
+    f.Synchronize()
+    cube = f.download(fx.FIELD_TARGET).astype(np.int32)
+    covered = (direct[..., 3] > 8) | (cube[..., 3] > 8)
+    assert covered.mean() > 0.05
+    assert np.abs(direct - cube)[covered].mean() < 6.0          # of 255

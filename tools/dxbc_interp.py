@@ -673,6 +673,8 @@ class Machine:
                 wf(R(O[1]).astype(F32))
             elif op == "ITOF":
                 wf(R(O[1]).view(np.int32).astype(F32))
+            elif op == "NOT":
+                wu(~R(O[1]))
             elif op == "INEG":
                 wu((~R(O[1]).astype(np.uint64) + 1) & 0xFFFFFFFF)
             elif op == "FRC":
@@ -772,6 +774,10 @@ class PixelMachine(Machine):
         ntemps = [i for i in self.ins if i.op == "DCL_TEMPS"]
         self.r = np.zeros(((ntemps[0].extra[0] if ntemps else 0) + 1, self.N, 4), U32)
         self.x = {}
+        for i in self.ins:
+            if i.op == "DCL_INDEXABLE_TEMP":
+                idx, size, _ = i.extra
+                self.x[int(idx)] = np.zeros((self.N, int(size), 4), U32)
         self.gsm = {}
         self.executed = 0
 

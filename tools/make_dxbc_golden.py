@@ -228,6 +228,39 @@ def make_resolve():
 
 
 # ---------------------------------------------------------------------------------------------------------
+# direct screen-space march (row f-2): PSRayCast.cso / PSRayCastV.cso per screen pixel
+# ---------------------------------------------------------------------------------------------------------
+def make_direct():
+    """the volume, SH and light maps of the cube-map goldens marched per screen pixel instead of per cube texel:
+    rayCastVDirect binds {colour, light map}, cb2 = {raySampleCount} (Fluid.cpp:953-972); rayCastDirect binds
+    {colour, SH buffer}, cb2 = {maxRaySamples, hasSH, maxLightSamples} (Fluid.cpp:932-951)."""
+    ren = np.load(os.path.join(OUT, "dxbc_render.npz"))
+    col, sh, cb0, cb1 = ren["color"], ren["sh"], ren["cb_per_object"], ren["cb_per_frame"]
+    W, H = 96, 72
+    py, px = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    uv = np.zeros((H * W, 4), F32)
+    uv[:, 0] = ((px.ravel().astype(F32) + F32(0.5)) / F32(W)).astype(F32)
+    uv[:, 1] = ((py.ravel().astype(F32) + F32(0.5)) / F32(H)).astype(F32)
+    out = {"params": np.array([W, H, 24, 8, 640, 480], np.int64)}       # target size, view samples, merged light samples, vp
+    ns, nml = 24, 8
+    for has_sh in (0, 1):
+        lm = ren["lightmap_sh%d" % has_sh]
+        m = di.run_pixel_shader(os.path.join(BIN, "PSRayCastV.cso"), {1: uv},
+                                {"t0": di.Texture(col), "t1": di.Texture(lm)},
+                                {0: cb0.view(U32), 1: cb1.view(U32), 2: np.array([[ns, 0, 0, 0]], U32)}, {"s0": di.Sampler("CLAMP")})
+        res = m.outputs[0].view(F32).reshape(H, W, 4).copy(); res[m.discarded.reshape(H, W)] = 0
+        out["separate_sh%d" % has_sh], out["discard_separate_sh%d" % has_sh] = res, m.discarded.reshape(H, W)
+        m = di.run_pixel_shader(os.path.join(BIN, "PSRayCast.cso"), {1: uv},
+                                {"t0": di.Texture(col), "t1": di.Structured(9, 12, sh)},
+                                {0: cb0.view(U32), 1: cb1.view(U32), 2: np.array([[ns, has_sh, nml, 0]], U32)}, {"s0": di.Sampler("CLAMP")})
+        res = m.outputs[0].view(F32).reshape(H, W, 4).copy(); res[m.discarded.reshape(H, W)] = 0
+        out["merged_sh%d" % has_sh], out["discard_merged_sh%d" % has_sh] = res, m.discarded.reshape(H, W)
+        print("direct sh=%d: separate alpha max %.3f (%d px covered), merged alpha max %.3f" % (
+            has_sh, out["separate_sh%d" % has_sh][..., 3].max(), (~m.discarded).sum(), res[..., 3].max()))
+    np.savez_compressed(os.path.join(OUT, "dxbc_direct.npz"), **out)
+
+
+# ---------------------------------------------------------------------------------------------------------
 # spherical harmonics
 # ---------------------------------------------------------------------------------------------------------
 def make_sh():
@@ -258,7 +291,7 @@ def make_sh():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sim", "render", "sh", "resolve"]
+    which = sys.argv[1:] or ["sim", "render", "sh", "resolve", "direct"]
     if "sim" in which:
         make_sim()
     if "render" in which:
@@ -267,3 +300,5 @@ if __name__ == "__main__":
         make_sh()
     if "resolve" in which:
         make_resolve()
+    if "direct" in which:
+        make_direct()
