@@ -661,7 +661,18 @@ static int ensure_target(fx_ctx* ctx, hipStream_t s)
 int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags)
 {
 	if (!ctx || frame_index >= FX_FRAME_COUNT) return FX_E_INVALID;
-	if (ctx->g.Zg <= 1) return FX_E_INVALID;       // 2D visualisation is a raster pass (out of scope)
+	if (ctx->g.Zg <= 1) {                          // Fluid.cpp:445: else visualizeColor(pCommandList)
+		if (!ctx->frame_valid) return FX_E_STATE;
+		DeviceGuard dg2(ctx->device);
+		hipStream_t s2 = pick_stream(ctx, stream);
+		int rc = ensure_target(ctx, s2);
+		if (rc) return rc;
+		ScopedMark mk(ctx, s2, MK_VIEW);
+		FX_HIP(launch_visualize_color(ctx->g, ctx->half, ctx->col[ctx->frame_parity], (int)ctx->desc.viewport_w,
+			(int)ctx->desc.viewport_h, ctx->target, ctx->target_float, s2));
+		if (ctx->timing_on) ctx->acc.renders += 1;
+		return FX_OK;
+	}
 	if (!ctx->view_valid) return FX_E_STATE;
 	if (ctx->g.nz != ctx->g.Zg) return FX_E_INVALID;            // rays cross slabs: multi-GPU rendering is row f-3
 	if (!(flags & FX_RAY_MARCH_CUBEMAP)) {

@@ -83,6 +83,8 @@ hipError_t launch_raymarch_view(const Geom& g, int half_store, const void* color
 hipError_t launch_raycast_direct(const Geom& g, int half_store, const void* color, const uint32_t* lightmap,
 	const FrameConsts& fc, const float* sh, int W, int H, uint32_t num_samples, uint32_t num_light_samples, int separate,
 	uint8_t* target, float* out_float, hipStream_t s);
+// 2-D visualiser (PSVisualizeColor): colour[parity] of a Z = 1 grid onto the render target
+hipError_t launch_visualize_color(const Geom& g, int half_store, const void* color, int W, int H, uint8_t* target, float* out_float, hipStream_t s);
 hipError_t launch_lightmap_decode(const uint32_t* lightmap, float* out, size_t n, hipStream_t s);
 
 // ---- cube map -> screen resolve (fx_resolve.hip; row f-1)

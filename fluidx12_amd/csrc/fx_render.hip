@@ -421,6 +421,27 @@ __global__ __launch_bounds__(64) void k_raycast_direct(const Geom g, const typen
 	}
 }
 
+// 2-D visualiser: PSVisualizeColor.hlsl:24-33 (Fluid::visualizeColor, Fluid.cpp:811-823), PREMULTIPLIED blend
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_visualize_color(const Geom g, const typename ColTex<HALF>::T* __restrict__ col, int W, int H,
+	uint32_t* __restrict__ target, float4* __restrict__ out_float)
+{
+	const int px = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y * blockDim.y + threadIdx.y;
+	if (px >= W || py >= H) return;
+	const size_t pix = (size_t)py * W + px;
+	const float u = ((float)px + 0.5f) / (float)W, v = ((float)py + 0.5f) / (float)H;
+	const Taps tp = make_taps(g, fmaf(u, 1.0f, 0.0f), fmaf(v, -1.0f, 1.0f), 0.5f);
+	float4 c = sample_color<HALF>(col, tp);
+	c.x = c.x / (c.x + 0.5f); c.y = c.y / (c.y + 0.5f); c.z = c.z / (c.z + 0.5f);
+	if (out_float) out_float[pix] = c;
+	if (target) {
+		const uint32_t dd = target[pix];
+		const float ia = 1.0f - c.w;
+		target[pix] = to_unorm8(fmaf((float)(dd & 255u) / 255.0f, ia, c.x)) | (to_unorm8(fmaf((float)((dd >> 8) & 255u) / 255.0f, ia, c.y)) << 8)
+			| (to_unorm8(fmaf((float)((dd >> 16) & 255u) / 255.0f, ia, c.z)) << 16) | (to_unorm8(fmaf((float)(dd >> 24) / 255.0f, ia, c.w)) << 24);
+	}
+}
+
 __global__ __launch_bounds__(256) void k_lightmap_decode(const uint32_t* __restrict__ lm, float* __restrict__ out, size_t n)
 {
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -464,6 +485,16 @@ hipError_t launch_raycast_direct(const Geom& g, int half_store, const void* colo
 	if (half_store) { if (separate) FX_LAUNCH(true, true); else FX_LAUNCH(true, false); }
 	else { if (separate) FX_LAUNCH(false, true); else FX_LAUNCH(false, false); }
 #undef FX_LAUNCH
+	return hipGetLastError();
+}
+
+hipError_t launch_visualize_color(const Geom& g, int half_store, const void* color, int W, int H, uint8_t* target, float* out_float, hipStream_t s)
+{
+	const dim3 grid((W + 63) / 64, (H + 3) / 4, 1), block(64, 4, 1);
+	if (half_store) hipLaunchKernelGGL(k_visualize_color<true>, grid, block, 0, s, g, (const h16x4*)color, W, H,
+		reinterpret_cast<uint32_t*>(target), reinterpret_cast<float4*>(out_float));
+	else hipLaunchKernelGGL(k_visualize_color<false>, grid, block, 0, s, g, (const float4*)color, W, H,
+		reinterpret_cast<uint32_t*>(target), reinterpret_cast<float4*>(out_float));
 	return hipGetLastError();
 }
 

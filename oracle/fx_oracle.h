@@ -58,6 +58,8 @@ void orc_raymarch_view(const float* color, const float* lightmap, int X, int Y, 
 void orc_raycast_direct(const float* color, const float* lightmap, int X, int Y, int Z, const orc_frame* fc,
 	const float* wvp_i, int W, int H, uint32_t numSamples, uint32_t numLightSamples, int hasSH, int separate,
 	float* out_rgba, uint8_t* covered);
+// 2-D visualiser (PSVisualizeColor.hlsl:24-33): color float[Y][X][4] -> premultiplied float[H][W][4]
+void orc_visualize_color(const float* color, int X, int Y, int W, int H, float* out_rgba);
 uint32_t orc_pack_r11g11b10(float r, float g, float b);
 void orc_unpack_r11g11b10(uint32_t v, float* rgb);
 

@@ -61,6 +61,7 @@ def lib():
         _lib.orc_raymarch_light.argtypes = [fp, fp, i, i, i, C.POINTER(Frame), u, i, i]
         _lib.orc_raymarch_view.argtypes = [fp, fp, i, i, i, C.POINTER(Frame), i, u, u, u, i, i, fp, u8p]
         _lib.orc_raycast_direct.argtypes = [fp, fp, i, i, i, C.POINTER(Frame), fp, i, i, u, u, i, i, fp, u8p]
+        _lib.orc_visualize_color.argtypes = [fp, i, i, i, i, fp]
         _lib.orc_world_view_proj_inverse.argtypes = [fp, fp, fp]
         _lib.orc_resolve_cube.argtypes = [u8p, i, C.POINTER(Frame), fp, i, i, fp, u8p]
         _lib.orc_blend_premultiplied.argtypes = [fp, u8p, u8p, i, i]
@@ -206,6 +207,15 @@ def raycast_direct(col, lightmap, frame, wvp_i, width, height, num_samples, num_
     lib().orc_raycast_direct(_fp(col), lmp, X, Y, Z, C.byref(frame), _fp(_f32(wvp_i)), width, height, num_samples,
                              num_light_samples, int(has_sh), int(separate), _fp(out), cov.ctypes.data_as(C.POINTER(C.c_uint8)))
     return out, cov
+
+
+def visualize_color(col, width, height):
+    """PSVisualizeColor per screen pixel of a 2-D grid: col (1, Y, X, 4) or (Y, X, 4) -> premultiplied float[H][W][4]"""
+    col = _f32(col).reshape(col.shape[-3], col.shape[-2], 4)
+    Y, X, _ = col.shape
+    out = np.empty((height, width, 4), np.float32)
+    lib().orc_visualize_color(_fp(col), X, Y, width, height, _fp(out))
+    return out
 
 
 def world_view_proj_inverse(view, proj):

@@ -396,4 +396,23 @@ void orc_raycast_direct(const float* color, const float* lightmap, int X, int Y,
 		}
 }
 
+// ---------------------------------------------------------------------------------------------
+// PSVisualizeColor.hlsl:24-33 (Fluid::visualizeColor, Fluid.cpp:811-823): the 2-D grid on the screen.  uvw = (u, 1 - v, .5),
+// linear CLAMP fetch of colour[parity], rgb / (rgb + .5); premultiplied SV_TARGET float[H][W][4].
+// ---------------------------------------------------------------------------------------------
+void orc_visualize_color(const float* color, int X, int Y, int W, int H, float* out_rgba)
+{
+	const int dims[3] = { X, Y, 1 };
+#pragma omp parallel for schedule(static)
+	for (int py = 0; py < H; ++py)
+		for (int px = 0; px < W; ++px) {
+			const float u = ((float)px + 0.5f) / (float)W, vv = ((float)py + 0.5f) / (float)H;
+			const float uvw[3] = { std::fmaf(u, 1.0f, 0.0f), std::fmaf(vv, -1.0f, 1.0f), 0.5f };
+			const Taps tp = make_taps(uvw, dims, ADDR_CLAMP);
+			float* o = out_rgba + ((size_t)py * W + px) * 4;
+			for (int a = 0; a < 4; ++a) o[a] = sample_chan(color, 4, a, dims, tp);
+			for (int a = 0; a < 3; ++a) o[a] = o[a] / (o[a] + 0.5f);
+		}
+}
+
 }  // extern "C"

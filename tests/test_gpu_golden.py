@@ -169,6 +169,17 @@ def test_direct_ray_cast_vs_reference_binaries(has_sh):
     close("merged_sh%d" % has_sh)
 
 
+def test_2d_visualiser_vs_reference_binary():
+    col = DIR["visualize_color"]
+    f = fx.Fluid()
+    assert f.Init(40, 30, (24, 24, 1), storage="fp16")
+    f.upload(fx.FIELD_COLOR, col)
+    f.UpdateFrame(0.0, 0)
+    f.Render(0, 0)
+    f.Synchronize()
+    assert np.array_equal(f.download(fx.FIELD_TARGET_FLOAT).view(np.uint32), DIR["visualize_target"].view(np.uint32))
+
+
 def test_sh_transform_vs_reference_binaries():
     f = make((16, 16, 16))
     lp = fx.LightProbe(f)

@@ -165,9 +165,8 @@ def test_render_errors():
         f.Render(0, fx.Fluid.OPTIMIZED)                  # UpdateFrame with a camera first
     f2 = fx.Fluid()
     assert f2.Init(640, 480, (32, 32, 1))
-    f2.UpdateFrame(0.1, 0)
     with pytest.raises(fx.FluidxError):
-        f2.Render(0, fx.Fluid.OPTIMIZED)                 # 2D has no ray march
+        f2.Render(0, fx.Fluid.OPTIMIZED)                 # no frame yet
 
 
 def test_config3_render_properties():
@@ -329,3 +328,25 @@ def test_direct_and_cube_paths_show_the_same_picture():
     covered = (direct[..., 3] > 8) | (cube[..., 3] > 8)
     assert covered.mean() > 0.05
     assert np.abs(direct - cube)[covered].mean() < 6.0          # of 255
+
+
+@pytest.mark.parametrize("storage", ["fp32", "fp16"])
+def test_2d_visualiser_equals_oracle(storage):
+    """Render() of a 2-D grid = Fluid::visualizeColor (PSVisualizeColor.hlsl): tone-mapped colour[parity] on the target"""
+    X, vp = 64, (200, 120)
+    f = fx.Fluid()
+    assert f.Init(vp[0], vp[1], (X, X, 1), storage=storage, jacobi_iters=20)
+    for k in range(12):
+        f.UpdateFrame(f32(f.default_time_step()), k % 3)
+        f.Simulate(k % 3)
+    f.ClearRenderTarget()
+    f.Render(0, fx.Fluid.OPTIMIZED)
+    f.Synchronize()
+    col = f.download(fx.FIELD_COLOR)
+    assert col[..., 3].max() > 0.2
+    out = orc.visualize_color(col, *vp)
+    got = f.download(fx.FIELD_TARGET_FLOAT)
+    assert np.array_equal(got.view(np.uint32), out.view(np.uint32))
+    target = np.empty((vp[1], vp[0], 4), np.uint8)
+    target[...] = (51, 51, 51, 0)
+    assert np.array_equal(f.download(fx.FIELD_TARGET), orc.blend_premultiplied(out, np.ones(vp[::-1], np.uint8), target))

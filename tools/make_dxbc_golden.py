@@ -257,6 +257,16 @@ def make_direct():
         out["merged_sh%d" % has_sh], out["discard_merged_sh%d" % has_sh] = res, m.discarded.reshape(H, W)
         print("direct sh=%d: separate alpha max %.3f (%d px covered), merged alpha max %.3f" % (
             has_sh, out["separate_sh%d" % has_sh][..., 3].max(), (~m.discarded).sum(), res[..., 3].max()))
+    # 2-D visualiser (PSVisualizeColor.cso, Fluid.cpp:811-823): a 24 x 24 fp16-exact colour field on a 40 x 30 target
+    rng = np.random.default_rng(12)
+    col2d = di.half_round((rng.random((1, 24, 24, 4)) * np.array([1.5, 1.0, 0.5, 1.0])).astype(F32))
+    W2, H2 = 40, 30
+    py, px = np.meshgrid(np.arange(H2), np.arange(W2), indexing="ij")
+    uv2 = np.zeros((H2 * W2, 4), F32)
+    uv2[:, 0] = ((px.ravel().astype(F32) + F32(0.5)) / F32(W2)).astype(F32)
+    uv2[:, 1] = ((py.ravel().astype(F32) + F32(0.5)) / F32(H2)).astype(F32)
+    m = di.run_pixel_shader(os.path.join(BIN, "PSVisualizeColor.cso"), {1: uv2}, {"t0": di.Texture(col2d)}, {}, {"s0": di.Sampler("CLAMP")})
+    out["visualize_color"], out["visualize_target"] = col2d, m.outputs[0].view(F32).reshape(H2, W2, 4).copy()
     np.savez_compressed(os.path.join(OUT, "dxbc_direct.npz"), **out)
 
 
