@@ -16,7 +16,7 @@ FRAME_COUNT = 3
 STORAGE_FP32, STORAGE_FP16 = 0, 1
 JACOBI_FIXED, JACOBI_FAITHFUL = 0, 1
 ADDRESS_CLAMP, ADDRESS_MIRROR = 0, 1
-FLAG_JACOBI_FUSE_MASK, FLAG_NO_OVERLAP = 0xF, 0x10
+FLAG_JACOBI_FUSE_MASK, FLAG_NO_OVERLAP, FLAG_RENDER_ONLY = 0xF, 0x10, 0x20
 OPT_OVERLAP, OPT_JACOBI_ROUND = 1, 2
 ABI_VERSION = 2                      # FX_ABI_VERSION of include/fluidx_hip.h
 (FIELD_VELOCITY, FIELD_VELOCITY1, FIELD_COLOR, FIELD_COLOR_PREV, FIELD_PRESSURE, FIELD_DIVERGENCE,
@@ -70,6 +70,7 @@ SYMBOLS = {
     "fx_render_cube": (C.c_int, [_vp, _vp, C.c_uint8]),
     "fx_timing_enable": (C.c_int, [_vp, C.c_int]),
     "fx_set_option": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
+    "fx_comm_gather_color": (C.c_int, [_vp, _vp, _vp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "fx_timing_read": (C.c_int, [_vp, C.POINTER(Timing), C.c_int]),
     "fx_comm_id_bytes": (C.c_size_t, []),
     "fx_comm_get_unique_id": (C.c_int, [_vp, C.c_size_t]),

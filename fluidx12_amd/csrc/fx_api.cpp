@@ -471,6 +471,7 @@ int fx_create(fx_ctx** out, const fx_desc* d)
 	if (!slab) { ctx->desc.halo_advect = 0; }
 	const int H = slab ? (int)std::max(ctx->desc.halo_advect, ctx->desc.halo_jacobi) : 0;
 	if (slab && (int)nz < H) { delete ctx; return FX_E_INVALID; }             // a halo may only span the direct neighbour
+	if (slab && (d->flags & FX_FLAG_RENDER_ONLY)) { delete ctx; return FX_E_INVALID; }   // rays cross slabs: render contexts are whole grids
 	ctx->g = Geom{ (int)d->grid_x, (int)d->grid_y, (int)d->grid_z, (int)z0, (int)nz, H,
 		std::max((int)z0 - H, 0), std::min((int)(z0 + nz) + H, (int)d->grid_z) - 1 };
 	ctx->half = d->storage == FX_STORAGE_FP16;
@@ -487,7 +488,11 @@ int fx_create(fx_ctx** out, const fx_desc* d)
 		ctx->owns_stream = true;
 		const size_t cells = ctx->g.cells_local();
 		const size_t es = elem_size(ctx);
-		for (int i = 0; i < 2; ++i) {
+		if (d->flags & FX_FLAG_RENDER_ONLY) {                                // colour only; parity never flips
+			FX_HIP(hipMalloc(&ctx->col[0], 4 * cells * es));
+			FX_HIP(hipMemsetAsync(ctx->col[0], 0, 4 * cells * es, ctx->stream));
+		}
+		for (int i = 0; i < 2 && !(d->flags & FX_FLAG_RENDER_ONLY); ++i) {
 			FX_HIP(hipMalloc(&ctx->vel[i], 3 * cells * es));
 			FX_HIP(hipMalloc(&ctx->col[i], 4 * cells * es));
 			FX_HIP(hipMalloc((void**)&ctx->p[i], cells * 4));
@@ -495,14 +500,16 @@ int fx_create(fx_ctx** out, const fx_desc* d)
 			FX_HIP(hipMemsetAsync(ctx->col[i], 0, 4 * cells * es, ctx->stream));
 			FX_HIP(hipMemsetAsync(ctx->p[i], 0, cells * 4, ctx->stream));
 		}
-		if (slab)                                                            // scratch levels of the face chains (jacobi_overlapped)
+		if (slab && !(d->flags & FX_FLAG_RENDER_ONLY))                       // scratch levels of the face chains (jacobi_overlapped)
 			for (int i = 0; i < 2; ++i) {
 				FX_HIP(hipMalloc((void**)&ctx->p_face[i], cells * 4));
 				FX_HIP(hipMemsetAsync(ctx->p_face[i], 0, cells * 4, ctx->stream));
 			}
-		FX_HIP(hipMalloc((void**)&ctx->b, cells * 4));
-		FX_HIP(hipMemsetAsync(ctx->b, 0, cells * 4, ctx->stream));
-		if (d->jacobi_mode == FX_JACOBI_FAITHFUL) {
+		if (!(d->flags & FX_FLAG_RENDER_ONLY)) {
+			FX_HIP(hipMalloc((void**)&ctx->b, cells * 4));
+			FX_HIP(hipMemsetAsync(ctx->b, 0, cells * 4, ctx->stream));
+		}
+		if (d->jacobi_mode == FX_JACOBI_FAITHFUL && !(d->flags & FX_FLAG_RENDER_ONLY)) {
 			FX_HIP(hipMalloc((void**)&ctx->frozen, cells));
 			FX_HIP(hipMemsetAsync(ctx->frozen, 0, cells, ctx->stream));
 		}
@@ -630,7 +637,7 @@ int fx_update_frame(fx_ctx* ctx, float time_step, uint8_t frame_index,
 			c->view_valid = true;
 		}
 		c->time_step = time_step;
-		if (time_step > 0.0f) c->frame_parity ^= 1;                                 // Fluid.cpp:345
+		if (time_step > 0.0f && !(c->desc.flags & FX_FLAG_RENDER_ONLY)) c->frame_parity ^= 1;   // Fluid.cpp:345
 		c->frame_valid = true;
 	}
 	return FX_OK;
@@ -639,7 +646,7 @@ int fx_update_frame(fx_ctx* ctx, float time_step, uint8_t frame_index,
 int fx_simulate(fx_ctx* ctx, void* stream, uint8_t frame_index)
 {
 	if (!ctx || frame_index >= FX_FRAME_COUNT) return FX_E_INVALID;
-	if (!ctx->frame_valid) return FX_E_STATE;
+	if (!ctx->frame_valid || (ctx->desc.flags & FX_FLAG_RENDER_ONLY)) return FX_E_STATE;
 	if (!is_driver(ctx)) return FX_OK;             // loop-back group: rank 0 drives every member
 	return simulate_impl(ctx, pick_stream(ctx, stream));
 }
@@ -788,9 +795,10 @@ static int field_info(fx_ctx* c, int field, size_t* host_bytes)
 {
 	const size_t n = c->g.cells_owned();
 	switch (field) {
-	case FX_FIELD_VELOCITY: case FX_FIELD_VELOCITY1: *host_bytes = 3 * n * 4; return FX_OK;
-	case FX_FIELD_COLOR: case FX_FIELD_COLOR_PREV: *host_bytes = 4 * n * 4; return FX_OK;
-	case FX_FIELD_PRESSURE: case FX_FIELD_DIVERGENCE: *host_bytes = n * 4; return FX_OK;
+	case FX_FIELD_VELOCITY: case FX_FIELD_VELOCITY1: if (!c->vel[0]) return FX_E_STATE; *host_bytes = 3 * n * 4; return FX_OK;
+	case FX_FIELD_COLOR_PREV: if (!c->col[1]) return FX_E_STATE;   /* fall through */
+	case FX_FIELD_COLOR: *host_bytes = 4 * n * 4; return FX_OK;
+	case FX_FIELD_PRESSURE: case FX_FIELD_DIVERGENCE: if (!c->b) return FX_E_STATE; *host_bytes = n * 4; return FX_OK;
 	case FX_FIELD_LIGHTMAP: if (!c->lightmap) return FX_E_INVALID; *host_bytes = 3 * n * 4; return FX_OK;
 	case FX_FIELD_CUBEMAP: {
 		if (!c->cube) return FX_E_INVALID;
@@ -916,6 +924,7 @@ int fx_download(fx_ctx* ctx, int field, void* host, size_t bytes)
 int fx_advect(fx_ctx* ctx, void* stream)
 {
 	if (!ctx) return FX_E_INVALID;
+	if (ctx->desc.flags & FX_FLAG_RENDER_ONLY) return FX_E_STATE;
 	if (!ctx->frame_valid) return FX_E_STATE;
 	if (ctx->nranks > 1) return FX_E_INVALID;
 	hipStream_t s = pick_stream(ctx, stream);
@@ -926,12 +935,14 @@ int fx_advect(fx_ctx* ctx, void* stream)
 int fx_divergence(fx_ctx* ctx, void* stream)
 {
 	if (!ctx || ctx->nranks > 1) return FX_E_INVALID;
+	if (ctx->desc.flags & FX_FLAG_RENDER_ONLY) return FX_E_STATE;
 	return divergence_phase(ctx, pick_stream(ctx, stream));
 }
 
 int fx_jacobi(fx_ctx* ctx, void* stream, uint32_t iters)
 {
 	if (!ctx || !iters || ctx->nranks > 1) return FX_E_INVALID;
+	if (ctx->desc.flags & FX_FLAG_RENDER_ONLY) return FX_E_STATE;
 	std::vector<fx_ctx*> M{ ctx };
 	return jacobi_all(ctx, M, pick_stream(ctx, stream), iters);
 }
@@ -939,7 +950,7 @@ int fx_jacobi(fx_ctx* ctx, void* stream, uint32_t iters)
 int fx_project(fx_ctx* ctx, void* stream)
 {
 	if (!ctx || ctx->nranks > 1) return FX_E_INVALID;
-	if (!ctx->frame_valid) return FX_E_STATE;
+	if (!ctx->frame_valid || (ctx->desc.flags & FX_FLAG_RENDER_ONLY)) return FX_E_STATE;
 	return project_phase(ctx, pick_stream(ctx, stream));
 }
 
@@ -1042,6 +1053,41 @@ int fx_comm_init_rank(fx_ctx* ctx, const void* id, size_t bytes, int rank, int n
 	g->refs = 1;
 	if ((rc = make_comm_stream(g, ctx->device))) { delete t; delete g; return rc; }
 	ctx->group = g; ctx->rank = rank; ctx->nranks = nranks;
+	return FX_OK;
+}
+
+int fx_comm_gather_color(fx_ctx* ctx, void* stream, fx_ctx* full, int root, const uint32_t* slab_z0, const uint32_t* slab_nz)
+{
+	if (!ctx || !ctx->group || root < 0 || root >= ctx->nranks) return FX_E_INVALID;
+	if (!is_driver(ctx)) return FX_OK;
+	const bool local = ctx->group->transport->is_local();
+	const bool am_root = local || ctx->rank == root;
+	if (am_root) {
+		if (!full || full->g.X != ctx->g.X || full->g.Y != ctx->g.Y || full->g.Zg != ctx->g.Zg || full->g.nz != full->g.Zg ||
+			full->half != ctx->half) return FX_E_INVALID;
+		if (!local && full->device != ctx->device) return FX_E_INVALID;
+	}
+	if (!local && (!slab_z0 || !slab_nz)) return FX_E_INVALID;
+	const size_t plane_bytes = ctx->g.plane() * 4 * elem_size(ctx);
+	std::vector<GatherPart> parts((size_t)ctx->nranks);
+	for (int r = 0; r < ctx->nranks; ++r) {
+		const fx_ctx* m = local ? ctx->group->members[r] : (r == ctx->rank ? ctx : nullptr);
+		const uint32_t z0 = local ? (uint32_t)m->g.z0 : slab_z0[r], nz = local ? (uint32_t)m->g.nz : slab_nz[r];
+		if (z0 + nz > (uint32_t)ctx->g.Zg) return FX_E_INVALID;
+		parts[r].rank = r;
+		parts[r].bytes = (size_t)nz * plane_bytes;
+		parts[r].src = m ? (const char*)m->col[m->frame_parity] + (size_t)m->g.H * plane_bytes : nullptr;
+		parts[r].dst = am_root ? (char*)full->col[full->frame_parity] + (size_t)z0 * plane_bytes : nullptr;
+	}
+	DeviceGuard dg(ctx->device);
+	hipStream_t s = pick_stream(ctx, stream);
+	ScopedMark mk(ctx, s, MK_EXCH);
+	int rc = ctx->group->transport->gather(ctx->group, parts, root, s);
+	if (rc) return rc;
+	if (am_root && full->stream != s) {                // the render context's own stream must see the planes
+		FX_HIP(hipEventRecord(ctx->group->ev_done, s));
+		FX_HIP(hipStreamWaitEvent(full->stream, ctx->group->ev_done, 0));
+	}
 	return FX_OK;
 }
 

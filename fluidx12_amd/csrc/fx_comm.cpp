@@ -83,6 +83,12 @@ struct LocalTransport : Transport {
 			}
 		return FX_OK;
 	}
+	int gather(fx_comm_group*, const std::vector<GatherPart>& parts, int, hipStream_t s) override
+	{
+		for (const GatherPart& p : parts)
+			if (p.bytes && hipMemcpyAsync(p.dst, p.src, p.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return FX_E_DEVICE;
+		return FX_OK;
+	}
 };
 
 Transport* make_local_transport() { return new LocalTransport(); }
@@ -157,6 +163,25 @@ struct RcclTransport : Transport {
 		const ncclResult_t e = api->GroupEnd();
 		if (r == ncclSuccess) r = e;
 		if (r != ncclSuccess) { c->last_error = std::string("rccl: ") + api->GetErrorString(r); return FX_E_COMM; }
+		return FX_OK;
+	}
+	int gather(fx_comm_group* grp, const std::vector<GatherPart>& parts, int root, hipStream_t s) override
+	{
+		fx_ctx* c = grp->members[0];
+		if ((int)parts.size() != nranks || root < 0 || root >= nranks) return FX_E_INVALID;
+		ncclResult_t r = api->GroupStart();
+		if (rank == root) {
+			for (const GatherPart& p : parts) {
+				if (r != ncclSuccess || !p.bytes) continue;
+				if (p.rank == root) { if (hipMemcpyAsync(p.dst, p.src, p.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) r = ncclUnhandledCudaError; }
+				else r = api->Recv(p.dst, p.bytes, ncclInt8, p.rank, comm, s);
+			}
+		} else if (parts[rank].bytes) {
+			r = api->Send(parts[rank].src, parts[rank].bytes, ncclInt8, root, comm, s);
+		}
+		const ncclResult_t e = api->GroupEnd();
+		if (r == ncclSuccess) r = e;
+		if (r != ncclSuccess) { c->last_error = std::string("rccl gather: ") + api->GetErrorString(r); return FX_E_COMM; }
 		return FX_OK;
 	}
 };

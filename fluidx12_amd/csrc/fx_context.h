@@ -74,11 +74,16 @@ struct ExchItem { char* base; size_t plane_bytes; int ncomp; int k; };
 // pair in issue order; the loop-back transport pairs them by the same index).
 struct Seg { char* send; char* recv; size_t bytes; int dir; };
 
+// one rank's contribution to a gather onto `root`: `src` lives on rank `rank`, `dst` on the root
+struct GatherPart { int rank; const char* src; char* dst; size_t bytes; };
+
 // transport behind a group of slab contexts
 struct Transport {
 	virtual ~Transport() {}
 	// segs[i] = segments of grp->members[i] (RCCL: one member = this rank; loop-back: every rank)
 	virtual int exchange(fx_comm_group* grp, const std::vector<std::vector<Seg>>& segs, hipStream_t s) = 0;
+	// parts[r] for every rank r of the chain (RCCL: only this rank's src and, on the root, every dst are meaningful)
+	virtual int gather(fx_comm_group* grp, const std::vector<GatherPart>& parts, int root, hipStream_t s) = 0;
 	virtual bool is_local() const = 0;
 };
 

@@ -70,7 +70,8 @@ class Fluid:
 
     # ---- Fluid::Init (Fluid.cpp:189-270) ----------------------------------------------------------
     def Init(self, width, height, gridSize, *, storage="fp32", jacobi_iters=40, jacobi_mode="fixed",
-             advect_address="clamp", device=-1, slab=None, halo_advect=0, halo_jacobi=0, jacobi_fuse=0, overlap=2):
+             advect_address="clamp", device=-1, slab=None, halo_advect=0, halo_jacobi=0, jacobi_fuse=0, overlap=2,
+             render_only=False):
         if self._ctx:
             self.Release()
         X, Y, Z = (int(v) for v in gridSize)
@@ -87,7 +88,7 @@ class Fluid:
             d.slab_z0, d.slab_nz = int(slab[0]), int(slab[1])
         d.halo_advect, d.halo_jacobi = int(halo_advect), int(halo_jacobi)
         level = 2 if overlap is True else int(overlap)        # 0 none, 1 advection halo only, 2 (default) + pressure rounds
-        d.flags = (int(jacobi_fuse) & 0xF) | (0 if level else capi.FLAG_NO_OVERLAP)
+        d.flags = (int(jacobi_fuse) & 0xF) | (0 if level else capi.FLAG_NO_OVERLAP) | (capi.FLAG_RENDER_ONLY if render_only else 0)
         self.last_status = self._lib.fx_create(C.byref(self._ctx), C.byref(d))
         if self.last_status != capi.FX_OK:      # the reference's Init returns false (XUSG_N_RETURN)
             self._ctx = C.c_void_p()
@@ -233,6 +234,17 @@ class Fluid:
         """slab schedule knobs (capi.OPT_OVERLAP 0/1/2, capi.OPT_JACOBI_ROUND 1..halo_jacobi); same on every rank"""
         self._need()
         capi.check(self._lib.fx_set_option(self._ctx, int(option), int(value)), "set_option")
+
+    def gather_color(self, full=None, root=0, slabs=None, stream=None):
+        """multi-GPU rendering, exact: every rank's colour planes travel to `root`'s whole-grid context `full` (pass it on
+        the root, None elsewhere); slabs = [(z0, nz)] * nranks for RCCL groups (a loop-back group knows its members)."""
+        self._need()
+        z0 = nz = None
+        if slabs is not None:
+            z0 = (C.c_uint32 * len(slabs))(*[int(a) for a, _ in slabs])
+            nz = (C.c_uint32 * len(slabs))(*[int(b) for _, b in slabs])
+        capi.check(self._lib.fx_comm_gather_color(self._ctx, stream, full._ctx if full is not None else None, int(root), z0, nz),
+                   "gather_color")
 
     # ---- multi-GPU slabs ---------------------------------------------------------------------------------
     def comm_init_rank(self, unique_id, rank, nranks):

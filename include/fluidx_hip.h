@@ -89,6 +89,9 @@ typedef struct fx_desc {
 /* multi-rank contexts: keep every halo exchange on the compute stream (no side comm stream, no face-first
  * ordering); results are bit-identical either way -- the switch exists to measure what the overlap buys */
 #define FX_FLAG_NO_OVERLAP 0x10u
+/* a context that only renders: one colour buffer + light map / cube map / target, no velocity, pressure or divergence.
+ * It receives its colour from fx_upload or fx_comm_gather_color; fx_simulate and the stage calls return FX_E_STATE. */
+#define FX_FLAG_RENDER_ONLY 0x20u
 
 /* values Fluid::UpdateFrame derives (Fluid.cpp:324-333) */
 typedef struct fx_frame_info {
@@ -173,6 +176,14 @@ size_t fx_comm_id_bytes(void);
 int fx_comm_get_unique_id(void* id_out, size_t bytes);
 int fx_comm_init_rank(fx_ctx* ctx, const void* id, size_t bytes, int rank, int nranks);
 int fx_comm_init_local(fx_ctx** ctxs, int nranks);
+
+/* Multi-GPU rendering (row f-3 of SURVEY.md 8), the exact way: rays cross slabs, so the colour field is gathered.  Every
+ * rank of the slab group sends its owned planes of colour[parity] to rank `root`, where they land in `full`, a whole-grid
+ * context on the root's device (same grid and storage; FX_FLAG_RENDER_ONLY keeps it small) that then runs
+ * fx_update_frame(dt = 0, camera) + fx_render like any single-GPU context -- the picture is bit-identical to the
+ * single-domain one.  Call on every rank; `full` is read on the root only (NULL elsewhere).  slab_z0 / slab_nz list the
+ * nranks slabs (the root places the planes by them; a loop-back group knows its members and accepts NULL). */
+int fx_comm_gather_color(fx_ctx* ctx, void* stream, fx_ctx* full, int root, const uint32_t* slab_z0, const uint32_t* slab_nz);
 
 /* How the slab schedule hides the exchanges; results are bit-identical for every setting, and every rank of a
  * group must use the same values (a loop-back group reads those of its first context).

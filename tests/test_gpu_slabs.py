@@ -159,6 +159,65 @@ def test_schedule_options_at_run_time():
         fl[0].set_option(capi.OPT_JACOBI_ROUND, 9)
 
 
+def test_multi_gpu_render_by_colour_gather():
+    """row f-3, the exact way: the slabs' colour planes are gathered into a render-only whole-grid context, which then
+    renders the very picture of the single-domain run (light map, cube map and resolved target bit-identical)"""
+    dims, vp, steps = (48, 48, 48), (320, 240), 8
+    view, proj, eye = fx.default_camera(*vp)
+
+    def render(f):
+        f.UpdateFrame(0.0, 0, view, proj, eye)
+        f.ClearRenderTarget()
+        f.Render(0, fx.Fluid.OPTIMIZED, to_target=True)
+        f.Synchronize()
+        return f.download(fx.FIELD_LIGHTMAP), f.download(fx.FIELD_CUBEMAP), f.download(fx.FIELD_TARGET)
+
+    ref = fx.Fluid()
+    assert ref.Init(vp[0], vp[1], dims, jacobi_iters=16)
+    for k in range(steps):
+        ref.UpdateFrame(f32(ref.default_time_step()), k % 3)
+        ref.Simulate(k % 3)
+    want = render(ref)
+    assert want[1][..., 3].max() > 20
+
+    fl = run_slabs(dims, steps, 3, jacobi_iters=16, halo_jacobi=4, halo_advect=6)
+    full = fx.Fluid()
+    assert full.Init(vp[0], vp[1], dims, render_only=True)
+    fl[0].gather_color(full, root=1)
+    got = render(full)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    assert np.array_equal(full.download(fx.FIELD_COLOR), ref.download(fx.FIELD_COLOR))
+    # a render-only context holds no simulation state
+    with pytest.raises(fx.FluidxError):
+        full.Simulate(0)
+    with pytest.raises(fx.FluidxError):
+        full.download(fx.FIELD_PRESSURE)
+    # mismatching target
+    other = fx.Fluid()
+    assert other.Init(vp[0], vp[1], (48, 48, 24), render_only=True)
+    with pytest.raises(fx.FluidxError):
+        fl[0].gather_color(other)
+    assert fx.Fluid().Init(64, 64, (32, 32, 32), slab=(0, 16), render_only=True) is False
+
+
+def test_rccl_gather_single_rank():
+    """the RCCL transport's gather on the one GPU we have (1-rank communicator: the root's own part is a device copy)"""
+    dims = (32, 32, 32)
+    f = fx.Fluid()
+    assert f.Init(200, 150, dims, jacobi_iters=8)
+    f.comm_init_rank(fx.comm_unique_id(), 0, 1)
+    for k in range(4):
+        f.UpdateFrame(f32(f.default_time_step()), k % 3)
+        f.Simulate(k % 3)
+    full = fx.Fluid()
+    assert full.Init(200, 150, dims, render_only=True)
+    f.gather_color(full, root=0, slabs=[(0, 32)])
+    f.Synchronize()
+    full.Synchronize()
+    assert np.array_equal(full.download(fx.FIELD_COLOR), f.download(fx.FIELD_COLOR))
+
+
 def test_slab_descriptor_validation():
     f = fx.Fluid()
     assert f.Init(800, 800, (32, 32, 32), slab=(0, 4), halo_advect=8) is False     # halo wider than the slab
