@@ -2,7 +2,7 @@
 // OnUpdate's time-step rule (:266) and default camera (:243-253), PopulateCommandList's Simulate + Render
 // (:465,489-490), minus the window.  Build (after `python -m fluidx12_amd.build`):
 //   hipcc -std=c++17 examples/fluidx_demo.cpp -o fluidx_demo -Lfluidx12_amd -lfluidx_hip -Wl,-rpath,$PWD/fluidx12_amd
-// Usage: fluidx_demo [-gridSize X Y Z] [-maxRaySamples N] [-maxLightSamples N] [-frames N] [-screenshot out.ppm]
+// Usage: fluidx_demo [-gridSize X Y Z] [-maxRaySamples N] [-maxLightSamples N] [-radiance cube.dds] [-frames N] [-screenshot out.ppm]
 // (FluidX12.cpp:398-433; the screen shot replaces the stb_image_write path of FluidX12.cpp:640-660 with a binary PPM)
 #include "../fluidx12_amd/csrc/Fluid.hpp"
 #include <chrono>
@@ -41,12 +41,14 @@ int main(int argc, char** argv)
 	uint32_t maxRay = 192, maxLight = 64, frames = 100; // FluidX12.cpp:38-39
 	const uint32_t width = 800, height = 800;           // Main.cpp:17
 	const char* screenshot = nullptr;
+	const char* radiance = nullptr;                     // FluidGI.bat: -radiance Assets/rnl_cross.dds
 	for (int i = 1; i < argc; ++i) {
 		if (!std::strcmp(argv[i], "-gridSize") && i + 3 < argc) { grid.x = atoi(argv[++i]); grid.y = atoi(argv[++i]); grid.z = atoi(argv[++i]); }
 		else if (!std::strcmp(argv[i], "-maxRaySamples") && i + 1 < argc) maxRay = atoi(argv[++i]);
 		else if (!std::strcmp(argv[i], "-maxLightSamples") && i + 1 < argc) maxLight = atoi(argv[++i]);
 		else if (!std::strcmp(argv[i], "-frames") && i + 1 < argc) frames = atoi(argv[++i]);
 		else if (!std::strcmp(argv[i], "-screenshot") && i + 1 < argc) screenshot = argv[++i];
+		else if (!std::strcmp(argv[i], "-radiance") && i + 1 < argc) radiance = argv[++i];
 	}
 	Fluid fluid;
 	if (!fluid.Init(nullptr, width, height, grid)) {   // ThrowIfFailed(E_FAIL) in the reference (FluidX12.cpp:198-200)
@@ -54,6 +56,13 @@ int main(int argc, char** argv)
 		return 1;
 	}
 	fluid.SetMaxSamples(maxRay, maxLight);
+	LightProbe probe;                                   // FluidX12.cpp:189-195, 205-210: load, TransformSH, SetSH
+	if (radiance) {
+		if (!probe.Init(fluid, radiance)) { std::fprintf(stderr, "cannot load %s as a BC6H_UF16 DDS cube map\n", radiance); return 1; }
+		probe.TransformSH(fluid);
+		fluid.SetSH(probe.GetSH());
+		std::printf("light probe %s: SH L00 = (%.3f, %.3f, %.3f)\n", radiance, probe.GetSH()[0], probe.GetSH()[1], probe.GetSH()[2]);
+	}
 	const float eye[3] = { 4.0f, 16.0f, -40.0f }, at[3] = { 0, 0, 0 }, up[3] = { 0, 1, 0 };
 	const XMFLOAT4X4 view = LookAtLH(eye, at, up);
 	const XMFLOAT4X4 proj = PerspectiveFovLH(3.141592654f / 4.0f, width / (float)height, 1.0f, 1000.0f);

@@ -68,6 +68,8 @@ SYMBOLS = {
     "fx_sh_transform": (C.c_int, [_vp, _fp, C.c_uint32, _fp]),
     "fx_clear_render_target": (C.c_int, [_vp, _vp, _fp]),
     "fx_render_cube": (C.c_int, [_vp, _vp, C.c_uint8]),
+    "fx_dds_cube_info": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "fx_dds_decode_cube": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, _fp, C.c_size_t]),
     "fx_timing_enable": (C.c_int, [_vp, C.c_int]),
     "fx_set_option": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "fx_comm_gather_color": (C.c_int, [_vp, _vp, _vp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

@@ -7,6 +7,7 @@
 #pragma once
 #include "../../include/fluidx_hip.h"
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -103,6 +104,23 @@ public:
 		m_cube.assign(radianceCube, radianceCube + (size_t)6 * n * n * 3);
 		m_n = n;
 		return true;
+	}
+	// LightProbe::Init(..., fileName) (LightProbe.cpp:41-46): a DDS cube map in BC6H_UF16 such as Bin/Assets/rnl_cross.dds
+	bool Init(Fluid& fluid, const char* fileName, uint32_t mip = 0)
+	{
+		FILE* fp = std::fopen(fileName, "rb");
+		if (!fp) return false;
+		std::vector<uint8_t> dds;
+		uint8_t buf[65536];
+		for (size_t got; (got = std::fread(buf, 1, sizeof buf, fp)) > 0;) dds.insert(dds.end(), buf, buf + got);
+		std::fclose(fp);
+		uint32_t size = 0, mips = 0;
+		m_status = fx_dds_cube_info(dds.data(), dds.size(), &size, &mips);
+		if (m_status != FX_OK || mip >= mips) return false;
+		m_n = (size >> mip) ? size >> mip : 1;
+		m_cube.resize((size_t)6 * m_n * m_n * 3);
+		m_status = fx_dds_decode_cube(fluid.Handle(), dds.data(), dds.size(), mip, m_cube.data(), m_cube.size());
+		return m_status == FX_OK;
 	}
 	void TransformSH(Fluid& fluid) { m_status = fx_sh_transform(fluid.Handle(), m_cube.data(), m_n, m_sh); }   // LightProbeEZ.cpp:117-123
 	const float* GetSH() const { return m_sh; }

@@ -983,6 +983,39 @@ int fx_sh_transform(fx_ctx* ctx, const float* cube, uint32_t n, float* out27)
 }
 
 // ---- timing ---------------------------------------------------------------------------------------------
+int fx_dds_cube_info(const void* dds, size_t bytes, uint32_t* size, uint32_t* mips)
+{
+	size_t fo[6], mo[16];
+	uint32_t sz = 0, nm = 0;
+	if (!dds_bc6h_cube_layout(dds, bytes, &sz, &nm, fo, mo)) return FX_E_INVALID;
+	if (size) *size = sz;
+	if (mips) *mips = nm;
+	return FX_OK;
+}
+
+int fx_dds_decode_cube(fx_ctx* ctx, const void* dds, size_t bytes, uint32_t mip, float* out_cube, size_t out_floats)
+{
+	if (!ctx || !out_cube) return FX_E_INVALID;
+	size_t fo[6], mo[16];
+	uint32_t sz = 0, nm = 0;
+	if (!dds_bc6h_cube_layout(dds, bytes, &sz, &nm, fo, mo) || mip >= nm) return FX_E_INVALID;
+	const uint32_t n = std::max<uint32_t>(sz >> mip, 1), nb = (n + 3) / 4;
+	const size_t face_floats = (size_t)n * n * 3, face_blocks = (size_t)nb * nb * 16;
+	if (out_floats != 6 * face_floats) return FX_E_INVALID;
+	DeviceGuard dg(ctx->device);
+	const size_t float_bytes = (6 * face_floats * 4 + 15) & ~(size_t)15;     // the blocks are read as 16-byte words
+	int rc = ensure_stage(ctx, float_bytes + 6 * face_blocks);
+	if (rc) return rc;
+	char* blocks_dev = reinterpret_cast<char*>(ctx->stage) + float_bytes;
+	for (int f = 0; f < 6; ++f)
+		FX_HIP(hipMemcpyAsync(blocks_dev + f * face_blocks, static_cast<const char*>(dds) + fo[f] + mo[mip], face_blocks, hipMemcpyHostToDevice, ctx->stream));
+	for (int f = 0; f < 6; ++f)
+		FX_HIP(launch_bc6h_decode(blocks_dev + f * face_blocks, (int)nb, (int)nb, (int)n, ctx->stage + f * face_floats, ctx->stream));
+	FX_HIP(hipMemcpyAsync(out_cube, ctx->stage, 6 * face_floats * 4, hipMemcpyDeviceToHost, ctx->stream));
+	FX_HIP(hipStreamSynchronize(ctx->stream));
+	return FX_OK;
+}
+
 int fx_timing_enable(fx_ctx* ctx, int enable)
 {
 	if (!ctx) return FX_E_INVALID;

@@ -92,6 +92,10 @@ hipError_t launch_resolve_cube(const uint8_t* cube_mip, int N, const FrameConsts
 	float* out_float, hipStream_t s);
 hipError_t launch_clear_target(uint8_t* target, int W, int H, const float rgba[4], hipStream_t s);
 
+// ---- BC6H_UF16 / DDS cube (fx_bc6h.hip; row f-4)
+hipError_t launch_bc6h_decode(const void* blocks_dev, int nbx, int nby, int n, float* out_dev, hipStream_t s);
+bool dds_bc6h_cube_layout(const void* dds, size_t bytes, uint32_t* size, uint32_t* mips, size_t face_offset[6], size_t mip_offset[16]);
+
 // ---- SH light probe (fx_sh.hip): cube float[6][n][n][3] (device) -> out float[27] (device)
 hipError_t launch_sh_transform(const float* cube, int n, float* scratch0, float* scratch1, float* w0, float* w1,
 	float* out27, hipStream_t s);

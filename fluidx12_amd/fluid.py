@@ -275,13 +275,32 @@ class LightProbe:
         self._radiance = None
         self._sh = None
 
-    def Init(self, radiance_cube):
-        """radiance cube float[6][N][N][3] (the reference loads a DDS cube map, LightProbe.cpp:41-46)."""
+    def Init(self, radiance_cube, mip=0):
+        """radiance: a float cube [6][N][N][3], or -- like the reference (LightProbe.cpp:41-46) -- a DDS cube map in
+        BC6H_UF16 given as a file name or its bytes (mip `mip` is decoded on the device)."""
+        if isinstance(radiance_cube, (str, bytes, bytearray)):
+            data = open(radiance_cube, "rb").read() if isinstance(radiance_cube, str) else bytes(radiance_cube)
+            radiance_cube = self.decode_dds(data, mip)
+            if radiance_cube is None:
+                return False
         a = np.ascontiguousarray(radiance_cube, np.float32)
         if a.ndim != 4 or a.shape[0] != 6 or a.shape[1] != a.shape[2] or a.shape[3] != 3:
             return False
         self._radiance = a
         return True
+
+    def decode_dds(self, data, mip=0):
+        """DDS (BC6H_UF16 cube) bytes -> float32[6][n][n][3], or None if the container is something else"""
+        f = self._fluid
+        f._need()
+        size, mips = C.c_uint32(), C.c_uint32()
+        buf = (C.c_char * len(data)).from_buffer_copy(data)
+        if f._lib.fx_dds_cube_info(buf, len(data), C.byref(size), C.byref(mips)) != capi.FX_OK or mip >= mips.value:
+            return None
+        n = max(size.value >> mip, 1)
+        out = np.empty((6, n, n, 3), np.float32)
+        capi.check(f._lib.fx_dds_decode_cube(f._ctx, buf, len(data), mip, _fp(out), out.size), "decode_dds")
+        return out
 
     def TransformSH(self):
         f = self._fluid

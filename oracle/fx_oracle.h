@@ -6,6 +6,7 @@
 // product (fluidx12_amd/, include/fluidx_hip.h) never does.
 #pragma once
 #include <stdint.h>
+#include <stddef.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -71,6 +72,10 @@ void orc_resolve_cube(const uint8_t* cube, int N, const orc_frame* fc, const flo
 	float* out_rgba, uint8_t* covered);
 // PREMULTIPLIED blend (Fluid.cpp:653) of a resolve result over an R8G8B8A8_UNORM target (FluidX12.cpp:31), in place
 void orc_blend_premultiplied(const float* src_rgba, const uint8_t* covered, uint8_t* target_rgba8, int W, int H);
+
+// ---- BC6H_UF16 + DDS cube container (orc_bc6h.cpp): the radiance asset path of LightProbe::Init (LightProbe.cpp:41-46) ----
+int orc_bc6h_decode_block(const uint8_t* block16, uint16_t* out_half_rgb /* [16][3] */);
+int orc_dds_bc6h_cube_face(const uint8_t* dds, size_t bytes, int face, int mip, float* out_rgb, int* mode_hist);
 
 // ---- spherical harmonics light probe (orc_sh.cpp) -----------------------------------------
 // cube float[6][N][N][3]; out float[9][3].  quirk != 0 reproduces LightProbeEZ.cpp:245-246

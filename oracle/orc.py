@@ -62,6 +62,8 @@ def lib():
         _lib.orc_raymarch_view.argtypes = [fp, fp, i, i, i, C.POINTER(Frame), i, u, u, u, i, i, fp, u8p]
         _lib.orc_raycast_direct.argtypes = [fp, fp, i, i, i, C.POINTER(Frame), fp, i, i, u, u, i, i, fp, u8p]
         _lib.orc_visualize_color.argtypes = [fp, i, i, i, i, fp]
+        _lib.orc_bc6h_decode_block.argtypes = [u8p, C.POINTER(C.c_uint16)]
+        _lib.orc_dds_bc6h_cube_face.argtypes = [u8p, C.c_size_t, i, i, fp, C.POINTER(C.c_int)]
         _lib.orc_world_view_proj_inverse.argtypes = [fp, fp, fp]
         _lib.orc_resolve_cube.argtypes = [u8p, i, C.POINTER(Frame), fp, i, i, fp, u8p]
         _lib.orc_blend_premultiplied.argtypes = [fp, u8p, u8p, i, i]
@@ -216,6 +218,37 @@ def visualize_color(col, width, height):
     out = np.empty((height, width, 4), np.float32)
     lib().orc_visualize_color(_fp(col), X, Y, width, height, _fp(out))
     return out
+
+
+def bc6h_decode_blocks(blocks):
+    """blocks uint8[n][16] -> (half bit patterns uint16[n][16][3], modes int[n]) (mode 0 = reserved)"""
+    blocks = np.ascontiguousarray(blocks, np.uint8).reshape(-1, 16)
+    out = np.empty((len(blocks), 16, 3), np.uint16)
+    modes = np.empty(len(blocks), np.int32)
+    u8 = C.POINTER(C.c_uint8)
+    for k in range(len(blocks)):
+        modes[k] = lib().orc_bc6h_decode_block(blocks[k].ctypes.data_as(u8), out[k].ctypes.data_as(C.POINTER(C.c_uint16)))
+    return out, modes
+
+
+def dds_bc6h_cube(dds_bytes, mip=0):
+    """DDS cube map (BC6H_UF16, DX10 header) -> (float32[6][n][n][3], mode histogram[15])"""
+    buf = np.frombuffer(dds_bytes, np.uint8)
+    u8 = C.POINTER(C.c_uint8)
+    hist = (C.c_int * 15)()
+    faces = []
+    for f in range(6):
+        tmp = np.zeros((4096 * 4096 * 3,), np.float32) if f == 0 else None
+        if f == 0:
+            n = lib().orc_dds_bc6h_cube_face(buf.ctypes.data_as(u8), len(buf), 0, mip, _fp(tmp), hist)
+            if n <= 0:
+                raise ValueError("not a BC6H_UF16 DDS cube map (or no such mip)")
+            faces.append(tmp[:n * n * 3].reshape(n, n, 3).copy())
+        else:
+            a = np.empty((n, n, 3), np.float32)
+            assert lib().orc_dds_bc6h_cube_face(buf.ctypes.data_as(u8), len(buf), f, mip, _fp(a), hist) == n
+            faces.append(a)
+    return np.stack(faces), np.array(list(hist))
 
 
 def world_view_proj_inverse(view, proj):
