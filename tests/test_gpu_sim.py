@@ -244,3 +244,26 @@ def test_full_size_properties(X):
     zs = slice(0, 12)
     q, _ = orc.jacobi(p1[:12 + 8], b1[:12 + 8], 8)
     assert np.array_equal(J(p1, b1)[0:12], q[0:12])
+
+
+@pytest.mark.parametrize("dims,storage,address", [((64, 64, 32), "fp32", "clamp"), ((32, 32, 64), "fp16", "mirror"),
+                                                   ((128, 128, 1), "fp32", "clamp"), ((8, 8, 4), "fp32", "mirror"),
+                                                   ((256, 256, 8), "fp32", "clamp")])
+def test_advect_fast_path_bit_identical(dims, storage, address, monkeypatch):
+    """k_advect_fast (power-of-two grids: reciprocal multiplies, 32-bit tap offsets, shifts) against the general kernel"""
+    import fluidx12_amd as fx
+
+    def run(fast):
+        monkeypatch.setenv("FLUIDX_ADVECT_FAST", "1" if fast else "0")
+        f = fx.Fluid()
+        assert f.Init(320, 240, dims, storage=storage, advect_address=address, jacobi_iters=6)
+        for k in range(5):
+            f.UpdateFrame(np.float32(f.default_time_step()), k % 3)
+            f.Simulate(k % 3)
+        f.Synchronize()
+        return f.download(fx.FIELD_VELOCITY), f.download(fx.FIELD_COLOR)
+
+    v0, c0 = run(False)
+    v1, c1 = run(True)
+    assert np.abs(c0).max() > 0
+    assert np.array_equal(v0.view(np.uint32), v1.view(np.uint32)) and np.array_equal(c0.view(np.uint32), c1.view(np.uint32))
