@@ -247,8 +247,8 @@ def test_full_size_properties(X):
 
 
 @pytest.mark.parametrize("dims,storage,address", [((64, 64, 32), "fp32", "clamp"), ((32, 32, 64), "fp16", "mirror"),
-                                                   ((128, 128, 1), "fp32", "clamp"), ((8, 8, 4), "fp32", "mirror"),
-                                                   ((256, 256, 8), "fp32", "clamp")])
+                                                   ((128, 128, 1), "fp32", "clamp"), ((32, 32, 16), "fp32", "mirror"),
+                                                   ((256, 256, 16), "fp32", "clamp")])
 def test_advect_fast_path_bit_identical(dims, storage, address, monkeypatch):
     """k_advect_fast (power-of-two grids: reciprocal multiplies, 32-bit tap offsets, shifts) against the general kernel"""
     import fluidx12_amd as fx
