@@ -62,6 +62,9 @@ hipError_t launch_jacobi_fused(const Geom& g, const float* p_in, const float* b,
 bool jacobi_strip_supported(const Geom& g);
 bool jacobi_strip_wide(const Geom& g);       // X = 512: only the two-sweep wide kernel exists
 hipError_t launch_jacobi_strip(const Geom& g, const float* p_in, const float* b, float* p_out, int sweeps, int z_begin, int z_end, hipStream_t s);
+// three sweeps per launch, register strips + the LDS as a second register file (fx_jacobi_strip3.hip; X = 256)
+bool jacobi_strip3_supported(const Geom& g);
+hipError_t launch_jacobi_strip3(const Geom& g, const float* p_in, const float* b, float* p_out, int z_begin, int z_end, hipStream_t s);
 // sweeps fused per launch for this geometry (1 = no fused path); requested > 0 overrides the default
 int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp);
 hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const float* p,

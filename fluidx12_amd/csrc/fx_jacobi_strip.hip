@@ -192,8 +192,8 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip(const Geom g, const flo
 	} \
 } while (0)
 
-template <int R>
-__global__ __launch_bounds__(256, 1) void k_jacobi_strip2u(const Geom g, const float* __restrict__ p_in,
+template <int R, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_jacobi_strip2u(const Geom g, const float* __restrict__ p_in,
 	const float* __restrict__ b, float* __restrict__ p_out, int z_begin, int z_end, int zchunk, int ngroups, int nchunks, int remap)
 {
 	const int LX = g.X >> 2, SPW = 64 / LX;
@@ -388,7 +388,8 @@ hipError_t launch_jacobi_strip(const Geom& g, const float* p_in, const float* b,
 	const int nstrips = (g.Y + R - 1) / R;
 	const int ngroups = (nstrips + 4 * SPW - 1) / (4 * SPW);            // 4 waves per workgroup
 	const int nzp = z_end - z_begin;
-	int nchunks = (256 + ngroups - 1) / ngroups;                        // one workgroup (= 1 wave per SIMD) per CU
+	static const int wg_target = env_i("FLUIDX_STRIP_WGS", 256);
+	int nchunks = (wg_target + ngroups - 1) / ngroups;                  // one workgroup (= 1 wave per SIMD) per CU
 	int zchunk = forced_chunk > 0 ? forced_chunk : (nzp + nchunks - 1) / nchunks;
 	if (zchunk < 8) zchunk = 8;
 	if (zchunk > nzp) zchunk = nzp;
@@ -399,7 +400,9 @@ hipError_t launch_jacobi_strip(const Geom& g, const float* p_in, const float* b,
 	if (wide)
 		hipLaunchKernelGGL(k_jacobi_strip2w<2>, grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
 	else if (sweeps == 2 && R == 4 && (g.Y & 3) == 0 && !generic)
-		hipLaunchKernelGGL(k_jacobi_strip2u<4>, grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
+		hipLaunchKernelGGL((k_jacobi_strip2u<4, 1>), grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
+	else if (sweeps == 2 && R == 2 && (g.Y & 1) == 0 && !generic)   // two waves per SIMD (<= 256 registers): FLUIDX_STRIP_R=2
+		hipLaunchKernelGGL((k_jacobi_strip2u<2, 2>), grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
 	else if (sweeps == 2) { if (R == 2) FX_STRIP(2, 2); else FX_STRIP(2, 4); }
 	else if (sweeps == 3) { if (R == 4) FX_STRIP(3, 4); else FX_STRIP(3, 2); }
 	else return hipErrorNotSupported;

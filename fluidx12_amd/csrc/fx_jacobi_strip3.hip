@@ -1,0 +1,222 @@
+// fx_jacobi_strip3.hip -- THREE lock-step Jacobi sweeps per launch: the strip kernel of fx_jacobi_strip.hip with the LDS
+// as a second register file.
+//
+// Restates CSPoisson.hlsli:8-26 (/root/reference/FluidX12/Content/Shaders/) like k_jacobi_v4; per-cell arithmetic and
+// association order are unchanged, so three fused sweeps are bit-identical to three single ones.
+//
+// Why LDS now: a wave64 = one strip of R = 4 full-x rows streaming along z.  Level l (0 = input ... 3 = output) needs a
+// 3-plane window of R + 2(3 - l) rows, plus the b planes of three different z offsets: 116 float4 rows = 464 registers per
+// lane before temporaries -- the all-register version spilled and ran slower than two sweeps (profiles/r01c_jacobi_strip.txt).
+// Here only the windows of levels 1 and 2 (8 + 6 rows x 3 planes, rotated by NAME as in k_jacobi_strip2u) and the plane
+// in flight live in registers; the input window's older two planes (2 x 10 rows) and the b planes waiting for sweeps 2
+// and 3 (3 x 6 rows) live in the wave's private 38-KiB slice of the LDS (4 waves x 38 KiB = 152 of the CU's 160 KiB; no
+// barrier, no sharing: each wave only ever touches its own slice).  A ds_read_b128 / ds_write_b128 moves a whole row
+// (16 B per lane) per instruction, where an AGPR spill moves 4 B per instruction.  The LDS slots rotate at run time (three
+// byte offsets swapped per step), so the z loop still unrolls by three only.
+//
+// Per z step q (plane q of the input arrives in registers, prefetched during step q - 1):
+//   sweep 1  level-1 plane q-1, rows y0-2 .. y0+R+1, from input planes q-2 (LDS), q-1 (LDS), q (registers) and b[q-1] (registers)
+//            then the input plane and rows 1..6 of b[q-1] go to their LDS slots and the prefetch of plane q+1 / b[q] is issued
+//   sweep 2  level-2 plane q-2, rows y0-1 .. y0+R, from the level-1 window and b[q-2] (LDS)
+//   sweep 3  output plane q-3, rows y0 .. y0+R-1, from the level-2 window and b[q-3] (LDS); stored if inside the chunk
+// Traffic: p and b are read once and p''' written once per THREE sweeps.
+//
+// What it measures (256^3, MI355X): 19.2 us per sweep against 18.5 for the two-sweep kernel -- no gain, and that is the
+// instructive part.  Both kernels hold ONE plane in flight per wave (14 / 18 KiB) and their z step lasts about one loaded
+// memory round trip: two sweeps 1.85 us per step = exactly the 6.4 TB/s the fabric sustains with 1024 such waves; here the
+// prefetch can only be issued after sweep 1 has consumed the arrived plane, so a step costs sweep 1 + a round trip = 2.6 us.
+// Issuing it at the top of the step (arrived plane parked in the LDS first, sweep 1 reading it back) needs the in-flight
+// 18 rows live across the whole step: 330 registers, and the compiler then keeps that plane in SCRATCH, whose reloads
+// serialise with the prefetch (33 us per sweep).  A third input slot in the LDS would fix it and does not fit: 48 rows
+// against the 40 a wave can have.  So this kernel serves jacobi_fuse = 3 (23 us -> 19.2 us against the all-register
+// version) and the default stays at two sweeps.
+#include "fx_internal.h"
+#include <cstdlib>
+
+namespace fx {
+
+namespace {
+
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// ((((((L - b) + R) + U) + D) + F) + B) * (1/6) on a float4 column; x neighbours by wave shuffle
+__device__ __forceinline__ float4 relax4(float4 c, float4 U, float4 D, float4 F, float4 Bk, float4 bb, bool x_first, bool x_last)
+{
+	float L = __shfl_up(c.w, 1), Rr = __shfl_down(c.x, 1);
+	if (x_first) L = c.x;
+	if (x_last) Rr = c.w;
+	const float4 Lv = make_float4(L, c.x, c.y, c.z), Rv = make_float4(c.y, c.z, c.w, Rr);
+	float4 x = add4(add4(add4(add4(add4(sub4(Lv, bb), Rv), U), D), F), Bk);
+	const float inv = __uint_as_float(0x3e2aaaabu);
+	x.x *= inv; x.y *= inv; x.z *= inv; x.w *= inv;
+	return x;
+}
+
+__device__ __forceinline__ int xcd_index3(int n, int remap)
+{
+	int t = (int)blockIdx.x;
+	if (remap) {
+		const int q = n >> 3, r = n & 7;
+		const int xcd = t & 7, j = t >> 3;
+		t = xcd * q + min(xcd, r) + j;
+	}
+	return t;
+}
+
+constexpr int R3 = 4;                       // output rows per strip
+constexpr int LDS_P0_ROWS = R3 + 6;         // one input plane: rows y0-3 .. y0+R+2
+constexpr int LDS_B_ROWS = R3 + 2;          // one stored b plane: rows y0-1 .. y0+R
+constexpr int LDS_ROWS_PER_WAVE = 2 * LDS_P0_ROWS + 3 * LDS_B_ROWS;   // 38 rows of 1 KiB
+
+// row `r` of an LDS slot whose first row starts `slot` float4s into the wave's slice
+#define FX_LDS(slot, r) lds[(slot) + (r) * 64]
+
+#define FX_STRIP3_STEP(PH) do { \
+	constexpr int NEW = (PH) % 3, CTR = ((PH) + 2) % 3, OLD = ((PH) + 1) % 3; \
+	/* ---- sweep 1: level-1 plane q-1, rows j <-> y0-2+j; input rows i <-> y0-3+i ------------------------------- */ \
+	if (q == 0) {                                   /* input plane -1 := plane 0, once (clamped front neighbour) */ \
+		_Pragma("unroll") for (int i = 0; i < R3 + 6; ++i) FX_LDS(s_ctr, i) = NP[i]; \
+	} \
+	if (q - 1 == g.Zg) {                            /* level-1 plane Zg := plane Zg-1 */ \
+		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) P1[NEW][j] = P1[CTR][j]; \
+	} else { \
+		float4 u_ = FX_LDS(s_ctr, 0), c_ = FX_LDS(s_ctr, 1); \
+		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) { \
+			const float4 d_ = FX_LDS(s_ctr, j + 2); \
+			const float4 f_ = FX_LDS(s_old, j + 1); \
+			P1[NEW][j] = relax4(c_, u_, d_, f_, NP[j + 1], NB[j], x_first, x_last); \
+			u_ = c_; c_ = d_; \
+		} \
+		if (q - 1 == 0) { \
+			_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) P1[CTR][j] = P1[NEW][j]; \
+		} \
+	} \
+	/* ---- the plane in flight moves to the LDS (over the input plane q-2, dead now); b[q-1] rows 1..6 to the free b slot ---- */ \
+	_Pragma("unroll") for (int i = 0; i < R3 + 6; ++i) FX_LDS(s_old, i) = NP[i]; \
+	_Pragma("unroll") for (int i = 0; i < R3 + 2; ++i) FX_LDS(s_bfree, i) = NB[i + 1]; \
+	{ const int t_ = s_old; s_old = s_ctr; s_ctr = t_; }            /* plane q is next step's centre */ \
+	{ const int t_ = s_bfree; s_bfree = s_b3; s_b3 = s_b2; s_b2 = t_; } /* after this: s_b2 = b[q-1], s_b3 = b[q-2], s_bfree = b[q-3] */ \
+	if (q + 1 <= q_load_last) {                     /* prefetch input plane q+1; past the last plane NP keeps plane zhi */ \
+		const size_t zo = (size_t)g.lz(q + 1) * plane; \
+		_Pragma("unroll") for (int i = 0; i < R3 + 6; ++i) NP[i] = *reinterpret_cast<const float4*>(p_in + zo + roff[i]); \
+	} \
+	if (q <= b_load_last) {                         /* b[q] for the next step's sweep 1 */ \
+		const size_t zo = (size_t)g.lz(q) * plane; \
+		_Pragma("unroll") for (int i = 0; i < R3 + 4; ++i) NB[i] = *reinterpret_cast<const float4*>(b + zo + roff[i + 1]); \
+	} \
+	/* ---- sweep 2: level-2 plane q-2, rows k <-> y0-1+k; b[q-2] is s_b3 (rows y0-1 ..) ------------------------------- */ \
+	if (q - 2 == g.Zg) { \
+		_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) P2[NEW][k] = P2[CTR][k]; \
+	} else { \
+		_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) { \
+			const float4 c_ = P1[CTR][k + 1]; \
+			float4 u_ = P1[CTR][k], d_ = P1[CTR][k + 2]; \
+			if (k == 1 && y0 == 0) u_ = c_;                             /* rows outside the domain hold no data */ \
+			if (k == R3 && y0 + R3 >= g.Y) d_ = c_; \
+			P2[NEW][k] = relax4(c_, u_, d_, P1[OLD][k + 1], P1[NEW][k + 1], FX_LDS(s_b3, k), x_first, x_last); \
+		} \
+		if (q - 2 == 0) { \
+			_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) P2[CTR][k] = P2[NEW][k]; \
+		} \
+	} \
+	/* ---- sweep 3: output plane q-3, rows m <-> y0+m; b[q-3] is s_bfree (its rows 1..4) ------------------------------- */ \
+	if (q - 3 >= zb && q - 3 < ze) { \
+		const size_t zo3 = (size_t)g.lz(q - 3) * plane; \
+		_Pragma("unroll") for (int m = 0; m < R3; ++m) { \
+			const float4 c_ = P2[CTR][m + 1]; \
+			float4 u_ = P2[CTR][m], d_ = P2[CTR][m + 2]; \
+			if (m == 0 && y0 == 0) u_ = c_; \
+			if (m == R3 - 1 && y0 + R3 >= g.Y) d_ = c_; \
+			const float4 x_ = relax4(c_, u_, d_, P2[OLD][m + 1], P2[NEW][m + 1], FX_LDS(s_bfree, m + 1), x_first, x_last); \
+			if (strip_live) *reinterpret_cast<float4*>(p_out + zo3 + (size_t)(y0 + m) * g.X + 4 * lx) = x_; \
+		} \
+	} \
+} while (0)
+
+__global__ __launch_bounds__(256, 1) void k_jacobi_strip3(const Geom g, const float* __restrict__ p_in,
+	const float* __restrict__ b, float* __restrict__ p_out, int z_begin, int z_end, int zchunk, int ngroups, int nchunks, int remap)
+{
+	__shared__ float4 lds_all[4 * LDS_ROWS_PER_WAVE * 64];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int lx = lane;                                              // X = 256: one row = one wave
+	float4* lds = lds_all + wave * (LDS_ROWS_PER_WAVE * 64) + lane;
+	const int tile = xcd_index3(ngroups * nchunks, remap);
+	const int grp = tile % ngroups, chunk = tile / ngroups;
+	const int y0 = (grp * 4 + wave) * R3;
+	const bool strip_live = y0 < g.Y;
+	const int zb = z_begin + chunk * zchunk, ze = min(zb + zchunk, z_end);
+	const int qs = max(zb - 3, g.zlo), q_last = ze - 1 + 3, q_load_last = min(q_last, g.zhi);
+	const int b_load_last = min(q_last - 1, g.zhi);
+	const bool x_first = lx == 0, x_last = lx == 63;
+	const size_t plane = g.plane();
+
+	size_t roff[R3 + 6];
+#pragma unroll
+	for (int i = 0; i < R3 + 6; ++i) roff[i] = (size_t)min(max(y0 - 3 + i, 0), g.Y - 1) * g.X + 4 * lx;
+
+	// LDS slots (float4 offsets into the wave's slice): two input planes, three b planes
+	int s_ctr = 0, s_old = LDS_P0_ROWS * 64;
+	int s_b2 = 2 * LDS_P0_ROWS * 64, s_b3 = s_b2 + LDS_B_ROWS * 64, s_bfree = s_b3 + LDS_B_ROWS * 64;
+
+	float4 P1[3][R3 + 4], P2[3][R3 + 2], NP[R3 + 6], NB[R3 + 4];
+	const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+#pragma unroll
+		for (int i = 0; i < R3 + 4; ++i) P1[k][i] = zero;
+#pragma unroll
+		for (int i = 0; i < R3 + 2; ++i) P2[k][i] = zero;
+	}
+#pragma unroll
+	for (int i = 0; i < LDS_ROWS_PER_WAVE; ++i) lds[i * 64] = zero;
+	{
+		const size_t zo = (size_t)g.lz(min(qs, q_load_last)) * plane;
+#pragma unroll
+		for (int i = 0; i < R3 + 6; ++i) NP[i] = *reinterpret_cast<const float4*>(p_in + zo + roff[i]);
+		// b[qs - 1] for the first step's sweep 1 (clamped into the present planes: its level-1 plane is never used when qs - 1 < zlo)
+		const size_t zob = (size_t)g.lz(min(max(qs - 1, g.zlo), g.zhi)) * plane;
+#pragma unroll
+		for (int i = 0; i < R3 + 4; ++i) NB[i] = *reinterpret_cast<const float4*>(b + zob + roff[i + 1]);
+	}
+	int q = qs;
+	for (;;) {
+		FX_STRIP3_STEP(0);
+		if (++q > q_last) break;
+		FX_STRIP3_STEP(1);
+		if (++q > q_last) break;
+		FX_STRIP3_STEP(2);
+		if (++q > q_last) break;
+	}
+}
+#undef FX_STRIP3_STEP
+#undef FX_LDS
+
+}  // namespace
+
+bool jacobi_strip3_supported(const Geom& g)
+{
+	return g.Zg > 1 && g.X == 256 && (g.Y & 3) == 0 && g.Y >= 8;
+}
+
+hipError_t launch_jacobi_strip3(const Geom& g, const float* p_in, const float* b, float* p_out, int z_begin, int z_end, hipStream_t s)
+{
+	if (z_end <= z_begin) return hipSuccess;
+	if (!jacobi_strip3_supported(g)) return hipErrorNotSupported;
+	const char* ce = getenv("FLUIDX_STRIP3_ZCHUNK");
+	const char* re = getenv("FLUIDX_STRIP_REMAP");
+	const int forced_chunk = ce && *ce ? atoi(ce) : 0;
+	const int remap = re && *re ? atoi(re) : 1;
+	const int nstrips = g.Y / R3;
+	const int ngroups = (nstrips + 3) / 4;                              // 4 waves (strips) per workgroup
+	const int nzp = z_end - z_begin;
+	int nchunks = (256 + ngroups - 1) / ngroups;                        // one workgroup per CU
+	int zchunk = forced_chunk > 0 ? forced_chunk : (nzp + nchunks - 1) / nchunks;
+	if (zchunk < 8) zchunk = 8;
+	if (zchunk > nzp) zchunk = nzp;
+	nchunks = (nzp + zchunk - 1) / zchunk;
+	hipLaunchKernelGGL(k_jacobi_strip3, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
+	return hipGetLastError();
+}
+
+}  // namespace fx

@@ -897,6 +897,8 @@ hipError_t launch_jacobi_fused(const Geom& g, const float* p_in, const float* b,
 	}
 	case 3: {
 		static const int use_tb3 = env_int("FLUIDX_FUSE2_TB", 0);
+		static const int no_lds3 = env_int("FLUIDX_STRIP3_OFF", 0);    // 1 = the all-register three-sweep strips (spills)
+		if (!use_tb3 && !no_lds3 && jacobi_strip3_supported(g)) return launch_jacobi_strip3(g, p_in, b, p_out, z_begin, z_end, s);
 		if (!use_tb3 && jacobi_strip_supported(g)) return launch_jacobi_strip(g, p_in, b, p_out, 3, z_begin, z_end, s);
 		return launch_tb<3>(g, p_in, b, p_out, z_begin, z_end, s);
 	}
