@@ -81,3 +81,27 @@ def test_create_rejects_bad_descriptors():
     d.grid_x, d.grid_y, d.grid_z, d.jacobi_iters = 32, 16, 8, 4              # x != y (Fluid.cpp:201)
     assert lib.fx_create(C.byref(ctx), C.byref(d)) == capi.FX_E_INVALID
     assert lib.fx_destroy(None) == capi.FX_E_INVALID
+
+
+def test_header_is_plain_c99_and_cxx11(tmp_path):
+    """the boundary is a C ABI: the header must compile as C99 and as C++11 on its own (no HIP, no torch, no C++-only syntax)"""
+    import shutil
+    import subprocess
+    src = tmp_path / "abi_probe.c"
+    src.write_text('#include "fluidx_hip.h"\nint main(void) { fx_desc d; fx_frame_info fi; fx_timing t; d.struct_size = sizeof d;\n'
+                   '  (void)fi; (void)t; return FX_ABI_VERSION > 0 && FX_OPT_OVERLAP == 1 ? 0 : 1; }\n')
+    inc = os.path.join(ROOT, "include")
+    if shutil.which("gcc"):
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)], check=True)
+    if shutil.which("g++"):
+        subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc, "-x", "c++", str(src)], check=True)
+
+
+def test_cxx_shim_and_demo_compile():
+    """the C++ mirror of class Fluid (csrc/Fluid.hpp) and the demo driver build against the header with a host compiler
+    (syntax only: linking needs the HIP runtime)"""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-fsyntax-only", os.path.join(ROOT, "examples", "fluidx_demo.cpp")], check=True)
