@@ -136,8 +136,8 @@ Range grown(const fx_ctx* c, int by)
 int for_members(fx_ctx* ctx, std::vector<fx_ctx*>& out)
 {
 	out.clear();
-	if (ctx->group && ctx->group->transport->is_local()) out = ctx->group->members;
-	else out.push_back(ctx);
+	if (ctx->group && ctx->group->transport->is_local() && !ctx->group->broken) out = ctx->group->members;
+	else out.push_back(ctx);                           // (a broken loop-back group: only this context, and only for teardown)
 	return FX_OK;
 }
 
@@ -421,6 +421,7 @@ int simulate_impl(fx_ctx* ctx, hipStream_t s)
 }
 
 bool is_driver(const fx_ctx* c) { return !c->group || !c->group->transport->is_local() || c->group->members[0] == c; }
+bool group_broken(const fx_ctx* c) { return c->group && c->group->transport->is_local() && c->group->broken; }
 
 }  // namespace
 
@@ -545,7 +546,9 @@ int fx_destroy(fx_ctx* ctx)
 	if (ctx->group) {
 		fx_comm_group* g = ctx->group;
 		for (auto& m : g->members) if (m == ctx) m = nullptr;
+		g->broken = true;
 		if (--g->refs == 0) {
+			if (g->shared_stream) (void)hipStreamDestroy(g->shared_stream);
 			if (g->comm_stream) (void)hipStreamDestroy(g->comm_stream);
 			if (g->ev_ready) (void)hipEventDestroy(g->ev_ready);
 			if (g->ev_done) (void)hipEventDestroy(g->ev_done);
@@ -583,7 +586,7 @@ int fx_update_frame(fx_ctx* ctx, float time_step, uint8_t frame_index,
 	if (!ctx || frame_index >= FX_FRAME_COUNT) return FX_E_INVALID;
 	std::vector<fx_ctx*> M;
 	for_members(ctx, M);
-	if (!is_driver(ctx)) return FX_E_STATE;
+	if (!is_driver(ctx) || group_broken(ctx)) return FX_E_STATE;
 	for (fx_ctx* c : M) {
 		if (c->g.Zg > 1 && view && proj && eye) {
 			// Fluid.cpp:296-334
@@ -646,7 +649,7 @@ int fx_update_frame(fx_ctx* ctx, float time_step, uint8_t frame_index,
 int fx_simulate(fx_ctx* ctx, void* stream, uint8_t frame_index)
 {
 	if (!ctx || frame_index >= FX_FRAME_COUNT) return FX_E_INVALID;
-	if (!ctx->frame_valid || (ctx->desc.flags & FX_FLAG_RENDER_ONLY)) return FX_E_STATE;
+	if (!ctx->frame_valid || (ctx->desc.flags & FX_FLAG_RENDER_ONLY) || group_broken(ctx)) return FX_E_STATE;
 	if (!is_driver(ctx)) return FX_OK;             // loop-back group: rank 0 drives every member
 	return simulate_impl(ctx, pick_stream(ctx, stream));
 }
@@ -1062,6 +1065,7 @@ static int check_slab_chain(fx_ctx* c, int rank, int nranks)
 static int make_comm_stream(fx_comm_group* g, int device)
 {
 	g->comm_stream = nullptr; g->ev_ready = nullptr; g->ev_done = nullptr;
+	g->shared_stream = nullptr; g->broken = false;
 	DeviceGuard dg(device);
 	int lo = 0, hi = 0;
 	if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
@@ -1092,6 +1096,7 @@ int fx_comm_init_rank(fx_ctx* ctx, const void* id, size_t bytes, int rank, int n
 int fx_comm_gather_color(fx_ctx* ctx, void* stream, fx_ctx* full, int root, const uint32_t* slab_z0, const uint32_t* slab_nz)
 {
 	if (!ctx || !ctx->group || root < 0 || root >= ctx->nranks) return FX_E_INVALID;
+	if (group_broken(ctx)) return FX_E_STATE;
 	if (!is_driver(ctx)) return FX_OK;
 	const bool local = ctx->group->transport->is_local();
 	const bool am_root = local || ctx->rank == root;
@@ -1160,12 +1165,14 @@ int fx_comm_init_local(fx_ctx** ctxs, int nranks)
 	for (int r = 0; r < nranks; ++r) {
 		g->members.push_back(ctxs[r]);
 		ctxs[r]->group = g; ctxs[r]->rank = r; ctxs[r]->nranks = nranks;
-		// one stream for the whole loop-back group: phases of different members are ordered by it
+		// one stream for the whole loop-back group: phases of different members are ordered by it.  The group owns it, so
+		// that the members can be destroyed in any order.
 		if (r > 0) {
 			if (ctxs[r]->owns_stream) (void)hipStreamDestroy(ctxs[r]->stream);
 			ctxs[r]->stream = ctxs[0]->stream;
-			ctxs[r]->owns_stream = false;
 		}
+		ctxs[r]->owns_stream = false;
+		g->shared_stream = ctxs[0]->stream;
 	}
 	return FX_OK;
 }

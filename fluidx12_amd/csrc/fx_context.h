@@ -97,6 +97,8 @@ struct fx_comm_group {
 	// stream: ev_ready = "the planes to send are final" (compute -> comm), ev_done = "halos have arrived"
 	hipStream_t comm_stream;
 	hipEvent_t ev_ready, ev_done;
+	hipStream_t shared_stream;      // loop-back groups: the one compute stream of all members (owned by the group)
+	bool broken;                    // a member was destroyed: the survivors can only be destroyed
 };
 
 namespace fx {

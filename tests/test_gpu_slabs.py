@@ -218,6 +218,25 @@ def test_rccl_gather_single_rank():
     assert np.array_equal(full.download(fx.FIELD_COLOR), f.download(fx.FIELD_COLOR))
 
 
+def test_loopback_group_survives_any_destruction_order():
+    """the members of a loop-back group share one compute stream owned by the group: destroying the driver first must
+    neither crash nor leave the others usable by accident"""
+    dims = (32, 32, 32)
+    fl = run_slabs(dims, 2, 2, jacobi_iters=4, halo_jacobi=2, halo_advect=4)
+    fl[0].Release()                                      # the driver goes first
+    with pytest.raises(fx.FluidxError):
+        fl[1].UpdateFrame(f32(0.01), 0)
+    with pytest.raises(fx.FluidxError):
+        fl[1].Simulate(0)
+    assert fl[1].download(fx.FIELD_PRESSURE).shape == (16, 32, 32)    # read-back of what it holds still works
+    fl[1].Release()
+    fl = run_slabs(dims, 2, 3, jacobi_iters=4, halo_jacobi=2, halo_advect=4)
+    fl[2].Release(); fl[1].Release()
+    with pytest.raises(fx.FluidxError):
+        fl[0].Simulate(0)
+    fl[0].Release()
+
+
 def test_slab_descriptor_validation():
     f = fx.Fluid()
     assert f.Init(800, 800, (32, 32, 32), slab=(0, 4), halo_advect=8) is False     # halo wider than the slab
