@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-render", action="store_true", help="skip the (untimed-for-value) ray-march measurement")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--loopback", type=int, default=0,
+                    help="run the N-rank code path (grid, slabs, halos, schedule selection) with N slab contexts in THIS process on "
+                         "one GPU through the loop-back transport: a functional check of the multi-rank path, never a scaling number")
     ap.add_argument("--dry-run", action="store_true",
                     help="distributed plumbing only (no GPU work); used by the gloo CPU tests, never a measurement")
     args = ap.parse_args()
@@ -131,9 +134,12 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     N = world
     G = args.grid
+    loop = args.loopback if (world == 1 and args.loopback > 1 and not args.dry_run) else 0
+    if loop:
+        N = loop                                  # logical ranks; still one process, one GPU, no torch.distributed
 
     dist = None
-    if N > 1:
+    if N > 1 and not loop:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -148,17 +154,24 @@ def main():
     z0, nz = slab_for_rank(GZ, rank, N)
 
     fluid = None
+    members = []
     if not args.dry_run:
         import fluidx12_amd as fx
-        fluid = fx.Fluid()
-        ok = fluid.Init(1920, 1080, (GX, GY, GZ), storage=args.storage, jacobi_iters=args.iters, jacobi_mode="fixed",
-                        advect_address="clamp", device=local_rank if N > 1 else -1,
-                        slab=(z0, nz) if N > 1 else None, halo_advect=halo_adv)
-        if not ok:
-            raise SystemExit("Fluid.Init failed (status %d): the HIP library needs a MI355X" % fluid.last_status)
+        for r in ([rank] if not loop else range(N)):
+            z0r, nzr = slab_for_rank(GZ, r, N)
+            f_ = fx.Fluid()
+            ok = f_.Init(1920, 1080, (GX, GY, GZ), storage=args.storage, jacobi_iters=args.iters, jacobi_mode="fixed",
+                         advect_address="clamp", device=local_rank if (N > 1 and not loop) else -1,
+                         slab=(z0r, nzr) if N > 1 else None, halo_advect=halo_adv)
+            if not ok:
+                raise SystemExit("Fluid.Init failed (status %d): the HIP library needs a MI355X" % f_.last_status)
+            members.append(f_)
+        fluid = members[0]                        # loop-back: the first context drives the group
+        if loop:
+            fx.comm_init_local(members)
 
     # ---- RCCL rendezvous: rank 0 creates the unique id, torch.distributed broadcasts the bytes ----
-    if N > 1:
+    if N > 1 and not loop:
         import torch
         if args.dry_run:
             uid = bytes(range(128)) if rank == 0 else None
@@ -181,11 +194,21 @@ def main():
     def barrier_sync():
         if fluid is not None:
             fluid.Synchronize()
-        if N > 1:
+        if dist is not None:
             if not args.dry_run:
                 import torch
                 torch.cuda.synchronize()
             dist.barrier()
+
+    def max_over_ranks(seconds):
+        if dist is None:
+            return seconds
+        import torch
+        t_ = torch.tensor([seconds], dtype=torch.float64)
+        if not args.dry_run:
+            t_ = t_.cuda()
+        dist.all_reduce(t_, op=dist.ReduceOp.MAX)      # identical on every rank afterwards
+        return float(t_.item())
 
     # ---- N > 1: which slab schedule (what travels behind what; results are bit-identical for all of them) -------------------
     # Link bandwidth, RCCL launch latency and cross-stream event latency decide this, none of which a 1-GPU box can
@@ -193,11 +216,11 @@ def main():
     schedule = None
     if N > 1 and fluid is not None:
         from fluidx12_amd import capi
-        import torch
 
         def apply(ov, rnd):
-            fluid.set_option(capi.OPT_OVERLAP, ov)
-            fluid.set_option(capi.OPT_JACOBI_ROUND, rnd)
+            for m_ in members:
+                m_.set_option(capi.OPT_OVERLAP, ov)
+                m_.set_option(capi.OPT_JACOBI_ROUND, rnd)
 
         if args.schedule != "auto":
             ov, rnd = (int(v) for v in args.schedule.split(","))
@@ -214,9 +237,8 @@ def main():
                 for _ in range(3):
                     one_step(kk); kk += 1
                 barrier_sync()
-                el = torch.tensor([time.perf_counter() - t_], dtype=torch.float64).cuda()
-                dist.all_reduce(el, op=dist.ReduceOp.MAX)          # identical on every rank => identical pick
-                tried.append({"overlap": ov, "jacobi_round": rnd, "ms_per_step": float(el.item()) / 3 * 1e3})
+                el = max_over_ranks(time.perf_counter() - t_)      # identical on every rank => identical pick
+                tried.append({"overlap": ov, "jacobi_round": rnd, "ms_per_step": el / 3 * 1e3})
             best = min(tried, key=lambda c: c["ms_per_step"])
             apply(best["overlap"], best["jacobi_round"])
             schedule = {"overlap": best["overlap"], "jacobi_round": best["jacobi_round"],
@@ -225,8 +247,9 @@ def main():
     for k in range(args.warmup):
         one_step(k)
     if fluid is not None:
-        fluid.timing_enable(True)
-        fluid.timing_read(reset=True)
+        for m_ in members:
+            m_.timing_enable(True)
+            m_.timing_read(reset=True)
     barrier_sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -234,19 +257,13 @@ def main():
     barrier_sync()
     elapsed = time.perf_counter() - t0
 
-    if N > 1:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        if not args.dry_run:
-            t = t.cuda()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed)
 
     roof = None
     timing = None
     render = None
     if fluid is not None:
-        timing = fluid.timing_read(reset=True)
+        timing = (members[len(members) // 2] if loop else fluid).timing_read(reset=True)   # loop-back: an inner rank's stages
         if N == 1 and G > 1 and not args.no_render:
             # config 3's second half, reported beside (never inside) `value`: the cube-map-space ray march of the state the
             # timed steps left behind -- default camera at 1920x1080 (FluidX12.cpp:243-253), OPTIMIZED = light volume + view pass
@@ -308,17 +325,17 @@ def main():
             "metric": "voxel-updates/sec (advect+40 Jacobi) at 256^3; achieved HBM GB/s vs peak",
             "value": voxels / elapsed if not args.dry_run else 0.0,
             "unit": "voxel-updates/s",
-            "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": 1 if loop else N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
             "higher_is_better": True,
             "scaling": args.scaling if N > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.storage == "fp32" else "f32 arithmetic / f16 field storage",
-            "data": "synthetic",
+            "data": "synthetic" if not loop else "synthetic; LOOP-BACK: %d slab ranks share ONE GPU (functional check of the multi-rank path, not a scaling measurement)" % loop,
             "config": {"workload": "%dx%dx%d 3D smoke (%.1f M voxels per GPU), %d Jacobi sweeps, %s fields, "
                                    "advect+divergence+Jacobi+project per step" % (GX, GY, GZ, GX * GY * GZ / N / 1e6, args.iters, args.storage),
                        "grid": [GX, GY, GZ], "jacobi_iters": args.iters, "storage": args.storage,
-                       "parallelism": "single GPU" if N == 1 else "z-slab x%d (%d planes per rank), RCCL send/recv halo exchange" % (N, GZ // N),
+                       "parallelism": "single GPU" if N == 1 else ("z-slab x%d (%d planes per rank), " % (N, GZ // N)) + ("loop-back copies on one GPU" if loop else "RCCL send/recv halo exchange"),
                        "schedule": schedule,
                        "bytes_per_voxel_step": step_bytes_per_voxel(args.iters, args.storage)},
         }
@@ -337,9 +354,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(G, args.iters, args.cpu_budget)
         print(json.dumps(out), flush=True)
 
-    if fluid is not None:
-        fluid.Release()
-    if N > 1:
+    for m_ in members:
+        m_.Release()
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1067,11 +1067,13 @@ static int make_comm_stream(fx_comm_group* g, int device)
 	g->comm_stream = nullptr; g->ev_ready = nullptr; g->ev_done = nullptr;
 	g->shared_stream = nullptr; g->broken = false;
 	DeviceGuard dg(device);
-	int lo = 0, hi = 0;
-	if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
-	const char* pe = std::getenv("FLUIDX_COMM_PRIORITY");           // 0 = default priority
-	if (pe && pe[0] == '0') hi = 0;
-	if (hipStreamCreateWithPriority(&g->comm_stream, hipStreamNonBlocking, hi) != hipSuccess) return FX_E_DEVICE;
+	// DEFAULT priority.  A high-priority side stream made every dependency between it and the compute stream cost about a
+	// millisecond for the first group of a process (18 ms per step instead of 7.7, profiles/r01d_slab_schedule_loopback.txt);
+	// FLUIDX_COMM_PRIORITY=1 asks for the highest priority anyway (measurement knob).
+	int lo = 0, hi = 0, prio = 0;
+	const char* pe = std::getenv("FLUIDX_COMM_PRIORITY");
+	if (pe && pe[0] == '1' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) prio = hi;
+	if (hipStreamCreateWithPriority(&g->comm_stream, hipStreamNonBlocking, prio) != hipSuccess) return FX_E_DEVICE;
 	if (hipEventCreateWithFlags(&g->ev_ready, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;
 	if (hipEventCreateWithFlags(&g->ev_done, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;
 	return FX_OK;

@@ -77,7 +77,7 @@ struct LocalTransport : Transport {
 					if (mine.dir != d) continue;
 					while (jp < segs[peer].size() && segs[peer][jp].dir != -d) ++jp;
 					if (jp == segs[peer].size() || segs[peer][jp].bytes != mine.bytes) return FX_E_STATE;   // the lists must mirror
-					if (hipMemcpyAsync(mine.recv, segs[peer][jp].send, mine.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return FX_E_DEVICE;
+					if (launch_copy_bytes(mine.recv, segs[peer][jp].send, mine.bytes, s) != hipSuccess) return FX_E_DEVICE;
 					++jp;
 				}
 			}
@@ -86,7 +86,7 @@ struct LocalTransport : Transport {
 	int gather(fx_comm_group*, const std::vector<GatherPart>& parts, int, hipStream_t s) override
 	{
 		for (const GatherPart& p : parts)
-			if (p.bytes && hipMemcpyAsync(p.dst, p.src, p.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return FX_E_DEVICE;
+			if (p.bytes && launch_copy_bytes(p.dst, p.src, p.bytes, s) != hipSuccess) return FX_E_DEVICE;
 		return FX_OK;
 	}
 };

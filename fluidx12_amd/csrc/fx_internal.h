@@ -69,6 +69,7 @@ hipError_t launch_jacobi_strip3(const Geom& g, const float* p_in, const float* b
 int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp);
 hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const float* p,
 	void* vel_out, int z_begin, int z_end, hipStream_t s);
+hipError_t launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t s);   // device-to-device, as a kernel
 hipError_t launch_copy_velocity(const Geom& g, int half_store, const void* vel_in, void* vel_out, hipStream_t s);
 
 // ---- layout conversion between dense fp32 host layouts and device storage (fx_sim.hip)

@@ -907,6 +907,24 @@ hipError_t launch_jacobi_fused(const Geom& g, const float* p_in, const float* b,
 	}
 }
 
+// device-to-device copy of whole planes as a kernel (16-byte words): the loop-back transport's stand-in for a link.  A
+// hipMemcpyAsync on a side stream took the SDMA path here (~50 GB/s inside one device) and made the overlapped schedules
+// look 2-3x slower than the serial one on a 1-GPU box.
+__global__ __launch_bounds__(256) void k_copy16(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n)
+{
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+hipError_t launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t s)
+{
+	if (!bytes) return hipSuccess;
+	if ((bytes & 15) || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+	const size_t n = bytes / 16;
+	const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+	hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, s, static_cast<uint4*>(dst), static_cast<const uint4*>(src), n);
+	return hipGetLastError();
+}
+
 hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const float* p,
 	void* vel_out, int z_begin, int z_end, hipStream_t s)
 {
