@@ -241,3 +241,20 @@ def test_slab_descriptor_validation():
     f = fx.Fluid()
     assert f.Init(800, 800, (32, 32, 32), slab=(0, 4), halo_advect=8) is False     # halo wider than the slab
     assert f.Init(800, 800, (32, 32, 32), slab=(16, 32)) is False                  # slab leaves the grid
+
+
+def test_bench_multi_rank_path_in_loopback():
+    """bench.py's N-rank code path (grid choice, slabs, halos, schedule timing, JSON) on one GPU via --loopback"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--loopback", "2", "--grid", "64", "--iters", "8",
+                          "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and "LOOP-BACK" in d["data"] and d["config"]["grid"] == [64, 64, 128]
+    sched = d["config"]["schedule"]
+    assert len(sched["candidates"]) == 4 and (sched["overlap"], sched["jacobi_round"]) in [(1, 8), (2, 8), (2, 4), (0, 8)]
+    assert d["value"] > 0 and d["scaling"] == "weak"
