@@ -306,69 +306,90 @@ int jacobi_serial(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t
 	return do_exchange(lead, M, &last, 1, s);
 }
 
-// Rounds of up to k sweeps with the pressure exchange of a round hidden behind its interior sweeps.
-// With lo/hi = the owned planes, src = the buffer holding the round's level 0 (k halo planes valid), cnt <= k sweeps
-// in the round, done as m launches of t_1 <= t_2 = ... = t_m fused sweeps (c_j = t_1 + ... + t_j):
-//   face chain   cnt single sweeps over BOTH face zones per launch, level s on [lo - (cnt - s), lo + k + (cnt - s))
-//                (mirrored at hi).  Levels live in two scratch buffers, except level c_j, which goes into the real
-//                buffer interior launch j + 1 reads, and level cnt (planes [lo, lo + k)), which goes into the
-//                buffer that ends the round -- the k planes the neighbour needs, ready before the interior starts.
-//   [comm]       send those k planes, receive the neighbour's into the halo        ||
-//   interior     launch j: level c_(j-1) -> c_j on [lo + k + (cnt - c_j), hi - k - (cnt - c_j))
-// The zone the face chain writes at level c_j ends exactly where the reads of interior launch j - 1 in the same
-// buffer begin (t_j >= t_(j-1): the short launch comes first), and the comm stream touches only the k face planes and
-// the halo planes of the round's last buffer, which no interior launch reads or writes.  Every (cell, level) is
-// computed once per rank, so the freeze mask of the faithful mode stays exact, and each with the arithmetic of the
-// single-domain sweep.
+// Rounds of up to k sweeps with the pressure exchange of a round hidden behind its interior sweeps, on three streams.
+// With lo/hi = the owned planes, src = the buffer holding the round's level 0 (k halo planes valid), cnt <= k sweeps in the
+// round, done as m launches of t_1 <= t_2 = ... = t_m fused sweeps (c_j = t_1 + ... + t_j, rem_j = cnt - c_j):
+//   face stream   the FACE CHAIN: cnt single sweeps over both face zones per launch, level s on [lo - (cnt - s), lo + k + (cnt - s))
+//                 (mirrored at hi), entirely in two scratch buffers (only its first sweep reads src): thin, latency-bound
+//                 launches that run BESIDE the interior instead of in front of it.  Its last level holds the k planes the
+//                 neighbour needs.
+//   comm stream   after the chain: those k planes leave from the scratch buffer, the neighbour's land in the halo of the
+//                 round's last buffer (which no interior launch touches)
+//   compute       the INTERIOR, self-sufficient: launch j brings [lo + k - rem_j, hi - k + rem_j) from level c_(j-1) to c_j,
+//                 i.e. it recomputes the rem_j planes per side the chain also computes instead of waiting for them (it never
+//                 reads below lo + k - cnt >= lo, so it needs no halo).  Launch 2 overwrites src and therefore waits until
+//                 the chain's first sweep has read it; after the last launch the chain's k final planes are copied from the
+//                 scratch buffer into [lo, lo + k) of the round's last buffer, which completes the owned planes.
+// Per round the critical path is max(interior, chain + link) instead of chain + max(interior, link).  Every cell gets the
+// arithmetic of the single-domain sweep; (cell, level) pairs of the zone borders are computed twice, which is why the
+// faithful mode (its freeze mask is a side effect) takes the serial schedule instead.
 int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t iters, int t, int k)
 {
+	fx_comm_group* grp = lead->group;
+	hipStream_t fs = grp->face_stream, cs = grp->comm_stream;
 	int rc;
-	if ((rc = clear_freeze_masks(M, s))) return rc;
+	fx_ctx* ctx = lead;                                    // FX_HIP reports through `ctx`
 	const ExchSpec first[2] = { { EX_DIV, k - 1, 0 }, { EX_PRESSURE, k, lead->p_cur } };
 	if ((rc = do_exchange(lead, M, first, 2, s))) return rc;
+	FX_HIP(hipEventRecord(grp->ev_int, s));
 	bool in_flight = false;
 	uint32_t done = 0;
 	while (done < iters) {
 		const int cnt = (int)std::min<uint32_t>(k, iters - done);
 		const int m = (cnt + t - 1) / t, t_first = cnt - (m - 1) * t;
-		const int src = lead->p_cur, fin = src ^ (m & 1);
-		if (in_flight) { if ((rc = comm_join(lead, s))) return rc; in_flight = false; }
-		for (fx_ctx* ctx : M) {                            // face chain
-			if (!has_lower(ctx) && !has_upper(ctx)) continue;
-			DeviceGuard dg(ctx->device);
-			ScopedMark mk(ctx, s, MK_JACOBI);
-			const Range o = owned(ctx);
-			const float* in = ctx->p[src];
-			for (int lvl = 1; lvl <= cnt; ++lvl) {
-				const int rem = cnt - lvl;
-				float* out = ctx->p_face[lvl & 1];
-				if (lvl == cnt) out = ctx->p[fin];
-				else if (lvl >= t_first && (lvl - t_first) % t == 0) out = ctx->p[src ^ (((lvl - t_first) / t + 1) & 1)];   // level c_j -> input of launch j + 1
-				const Range lo{ o.lo - rem, has_lower(ctx) ? o.lo + k + rem : o.lo - rem };
-				const Range hi{ has_upper(ctx) ? o.hi - k - rem : o.hi + rem, o.hi + rem };
-				FX_HIP(launch_jacobi_sweep2(ctx->g, in, ctx->b, out, ctx->frozen, lo.lo, lo.hi, hi.lo, hi.hi, s));
-				in = out;
+		const int src = lead->p_cur, fin = src ^ (m & 1), fbuf = cnt & 1;   // the chain's level s lives in p_face[s & 1]
+		// ---- face stream: the chain (needs the previous round's interior + face copy, and its exchange)
+		FX_HIP(hipStreamWaitEvent(fs, grp->ev_int, 0));
+		if (in_flight) FX_HIP(hipStreamWaitEvent(fs, grp->ev_done, 0));
+		for (int lvl = 1; lvl <= cnt; ++lvl) {
+			const int rem = cnt - lvl;
+			for (fx_ctx* mctx : M) {
+				if (!has_lower(mctx) && !has_upper(mctx)) continue;
+				DeviceGuard dg(mctx->device);
+				ScopedMark mk(mctx, fs, MK_JACOBI);
+				const Range o = owned(mctx);
+				const float* in = lvl == 1 ? mctx->p[src] : mctx->p_face[(lvl - 1) & 1];
+				const Range lo{ o.lo - rem, has_lower(mctx) ? o.lo + k + rem : o.lo - rem };
+				const Range hi{ has_upper(mctx) ? o.hi - k - rem : o.hi + rem, o.hi + rem };
+				FX_HIP(launch_jacobi_sweep2(mctx->g, in, mctx->b, mctx->p_face[lvl & 1], nullptr, lo.lo, lo.hi, hi.lo, hi.hi, fs));
 			}
+			if (lvl == 1) FX_HIP(hipEventRecord(grp->ev_face1, fs));
 		}
-		if ((rc = comm_fork(lead, s))) return rc;
-		const ExchSpec pspec{ EX_PRESSURE, k, fin };
-		if ((rc = do_exchange(lead, M, &pspec, 1, lead->group->comm_stream))) return rc;
+		FX_HIP(hipEventRecord(grp->ev_ready, fs));
+		// ---- comm stream: the k final planes of the chain travel, the neighbour's land in the halo of p[fin]
+		FX_HIP(hipStreamWaitEvent(cs, grp->ev_ready, 0));
+		const ExchSpec pspec{ EX_PRESSURE_FACE, k, (fbuf << 1) | fin };
+		if ((rc = do_exchange(lead, M, &pspec, 1, cs))) return rc;
 		if ((rc = comm_mark_done(lead))) return rc;
 		in_flight = true;
-		for (fx_ctx* ctx : M) {                            // interior
-			ScopedMark mk(ctx, s, MK_JACOBI);
-			const Range o = owned(ctx);
+		// ---- compute stream: the interior
+		for (fx_ctx* mctx : M) {
+			ScopedMark mk(mctx, s, MK_JACOBI);
+			const Range o = owned(mctx);
 			int lvl = 0, cur = src;
 			for (int j = 0; j < m; ++j) {
 				const int tj = j == 0 ? t_first : t;
 				lvl += tj;
 				const int rem = cnt - lvl;
-				const Range in{ has_lower(ctx) ? o.lo + k + rem : o.lo, has_upper(ctx) ? o.hi - k - rem : o.hi };
-				if ((rc = jacobi_launch(ctx, s, cur, tj, in, &mk))) return rc;
+				const Range in{ has_lower(mctx) ? o.lo + k - rem : o.lo, has_upper(mctx) ? o.hi - k + rem : o.hi };
+				if (j == 1 && mctx == M.front()) FX_HIP(hipStreamWaitEvent(s, grp->ev_face1, 0));   // launch 2 overwrites the chain's input
+				if ((rc = jacobi_launch(mctx, s, cur, tj, in, &mk))) return rc;
 				cur ^= 1;
 			}
-			ctx->p_cur = fin;
 		}
+		// the chain's final planes complete the owned range of p[fin]
+		FX_HIP(hipStreamWaitEvent(s, grp->ev_ready, 0));
+		for (fx_ctx* mctx : M) {
+			DeviceGuard dg(mctx->device);
+			const size_t pl = mctx->g.plane(), kb = (size_t)k * pl * 4;
+			const Range o = owned(mctx);
+			if (has_lower(mctx))
+				FX_HIP(launch_copy_bytes(mctx->p[fin] + (size_t)mctx->g.lz(o.lo) * pl, mctx->p_face[fbuf] + (size_t)mctx->g.lz(o.lo) * pl, kb, s));
+			if (has_upper(mctx))
+				FX_HIP(launch_copy_bytes(mctx->p[fin] + (size_t)mctx->g.lz(o.hi - k) * pl, mctx->p_face[fbuf] + (size_t)mctx->g.lz(o.hi - k) * pl, kb, s));
+			mctx->p_cur = fin;
+		}
+		FX_HIP(hipEventRecord(grp->ev_int, s));
 		done += cnt;
 	}
 	if (in_flight) rc = comm_join(lead, s);
@@ -381,8 +402,8 @@ int jacobi_all(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t it
 		int t = fused_sweeps(lead);
 		for (fx_ctx* m : M) t = std::min(t, fused_sweeps(m));
 		const int k = lead->opt_round;
-		bool ok = true;
-		for (fx_ctx* m : M) if (m->g.nz < 4 * k || !m->p_face[0]) ok = false;    // two face zones (<= 2k - 1 planes each) and an interior
+		bool ok = lead->group->face_stream != nullptr;
+		for (fx_ctx* m : M) if (m->g.nz < 4 * k || !m->p_face[0] || m->frozen) ok = false;   // two face zones (<= 2k - 1 planes each) and an interior
 		if (ok) return jacobi_overlapped(lead, M, s, iters, t, k);
 	}
 	return jacobi_serial(lead, M, s, iters);
@@ -550,6 +571,9 @@ int fx_destroy(fx_ctx* ctx)
 		if (--g->refs == 0) {
 			if (g->shared_stream) (void)hipStreamDestroy(g->shared_stream);
 			if (g->comm_stream) (void)hipStreamDestroy(g->comm_stream);
+			if (g->face_stream) (void)hipStreamDestroy(g->face_stream);
+			if (g->ev_int) (void)hipEventDestroy(g->ev_int);
+			if (g->ev_face1) (void)hipEventDestroy(g->ev_face1);
 			if (g->ev_ready) (void)hipEventDestroy(g->ev_ready);
 			if (g->ev_done) (void)hipEventDestroy(g->ev_done);
 			delete g->transport;
@@ -1066,6 +1090,7 @@ static int make_comm_stream(fx_comm_group* g, int device)
 {
 	g->comm_stream = nullptr; g->ev_ready = nullptr; g->ev_done = nullptr;
 	g->shared_stream = nullptr; g->broken = false;
+	g->face_stream = nullptr; g->ev_int = nullptr; g->ev_face1 = nullptr;
 	DeviceGuard dg(device);
 	// DEFAULT priority.  A high-priority side stream made every dependency between it and the compute stream cost about a
 	// millisecond for the first group of a process (18 ms per step instead of 7.7, profiles/r01d_slab_schedule_loopback.txt);
@@ -1076,6 +1101,9 @@ static int make_comm_stream(fx_comm_group* g, int device)
 	if (hipStreamCreateWithPriority(&g->comm_stream, hipStreamNonBlocking, prio) != hipSuccess) return FX_E_DEVICE;
 	if (hipEventCreateWithFlags(&g->ev_ready, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;
 	if (hipEventCreateWithFlags(&g->ev_done, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;
+	if (hipStreamCreateWithFlags(&g->face_stream, hipStreamNonBlocking) != hipSuccess) return FX_E_DEVICE;
+	if (hipEventCreateWithFlags(&g->ev_int, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;
+	if (hipEventCreateWithFlags(&g->ev_face1, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;
 	return FX_OK;
 }
 

@@ -22,20 +22,23 @@ int exchange_items(fx_ctx* c, int which_set, int k, int pidx, ExchItem out[4])
 	const size_t es = c->half ? 2 : 4;
 	switch (which_set) {
 	case EX_ADVECT_IN:
-		out[0] = ExchItem{ (char*)c->vel[0], plane * es, 3, k };
-		out[1] = ExchItem{ (char*)c->col[1 - c->frame_parity], plane * es * 4, 1, k };
+		out[0] = ExchItem{ (char*)c->vel[0], plane * es, 3, k, nullptr };
+		out[1] = ExchItem{ (char*)c->col[1 - c->frame_parity], plane * es * 4, 1, k, nullptr };
 		return 2;
 	case EX_UZ1:
-		out[0] = ExchItem{ (char*)c->vel[1] + 2 * (size_t)c->g.nzl() * plane * es, plane * es, 1, k };
+		out[0] = ExchItem{ (char*)c->vel[1] + 2 * (size_t)c->g.nzl() * plane * es, plane * es, 1, k, nullptr };
 		return 1;
 	case EX_DIV:
-		out[0] = ExchItem{ (char*)c->b, plane * 4, 1, k };
+		out[0] = ExchItem{ (char*)c->b, plane * 4, 1, k, nullptr };
 		return 1;
 	case EX_PRESSURE:
-		out[0] = ExchItem{ (char*)c->p[pidx & 1], plane * 4, 1, k };
+		out[0] = ExchItem{ (char*)c->p[pidx & 1], plane * 4, 1, k, nullptr };
 		if (!c->frozen) return 1;
-		out[1] = ExchItem{ (char*)c->frozen, plane, 1, k };      // the neighbour's freeze state travels with its pressure
+		out[1] = ExchItem{ (char*)c->frozen, plane, 1, k, nullptr };      // the neighbour's freeze state travels with its pressure
 		return 2;
+	case EX_PRESSURE_FACE:
+		out[0] = ExchItem{ (char*)c->p_face[(pidx >> 1) & 1], plane * 4, 1, k, (char*)c->p[pidx & 1] };
+		return 1;
 	}
 	return 0;
 }
@@ -49,10 +52,11 @@ void halo_segments(const fx_ctx* c, const ExchItem* items, int n, std::vector<Se
 		const size_t pb = it.plane_bytes, bytes = (size_t)it.k * pb;
 		for (int cpt = 0; cpt < it.ncomp; ++cpt) {
 			char* base = it.base + (size_t)cpt * g.nzl() * pb;
+			char* rbase = (it.recv_base ? it.recv_base : it.base) + (size_t)cpt * g.nzl() * pb;
 			if (c->rank > 0)                     // bottom k owned planes go down, the lower halo fills from below
-				out.push_back(Seg{ base + (size_t)g.H * pb, base + (size_t)(g.H - it.k) * pb, bytes, -1 });
+				out.push_back(Seg{ base + (size_t)g.H * pb, rbase + (size_t)(g.H - it.k) * pb, bytes, -1 });
 			if (c->rank + 1 < c->nranks)         // top k owned planes go up, the upper halo fills from above
-				out.push_back(Seg{ base + (size_t)(g.H + g.nz - it.k) * pb, base + (size_t)(g.H + g.nz) * pb, bytes, +1 });
+				out.push_back(Seg{ base + (size_t)(g.H + g.nz - it.k) * pb, rbase + (size_t)(g.H + g.nz) * pb, bytes, +1 });
 		}
 	}
 }

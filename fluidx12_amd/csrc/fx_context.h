@@ -66,7 +66,8 @@ namespace fx {
 
 // one array taking part in a halo exchange: `ncomp` back-to-back sub-arrays (velocity = 3 component
 // planes) of nzl planes each, plane_bytes per plane, k boundary planes travelling to each z-neighbour
-struct ExchItem { char* base; size_t plane_bytes; int ncomp; int k; };
+// recv_base (optional): the halo planes land in another array of the same geometry than the one the face planes leave from
+struct ExchItem { char* base; size_t plane_bytes; int ncomp; int k; char* recv_base; };
 
 // a run of whole planes travelling between z-neighbours: `send` goes to rank + dir, `recv` comes from it.
 // Both sides of a pair build their lists from the same items in the same order, so the j-th segment a rank
@@ -97,6 +98,9 @@ struct fx_comm_group {
 	// stream: ev_ready = "the planes to send are final" (compute -> comm), ev_done = "halos have arrived"
 	hipStream_t comm_stream;
 	hipEvent_t ev_ready, ev_done;
+	// the face chains of the overlapped pressure rounds run on their own stream, beside the interior sweeps
+	hipStream_t face_stream;
+	hipEvent_t ev_int, ev_face1;    // "interior + face copy of the round done" (compute -> face), "the chain has read its input" (face -> compute)
 	hipStream_t shared_stream;      // loop-back groups: the one compute stream of all members (owned by the group)
 	bool broken;                    // a member was destroyed: the survivors can only be destroyed
 };
@@ -106,7 +110,8 @@ enum ExchSet {
 	EX_ADVECT_IN = 0,   // what advection gathers from: velocity[0] (3 components) and colour[!parity]
 	EX_UZ1 = 1,         // z-component of the advected velocity: all the divergence reads across a slab face
 	EX_DIV = 2,         // divergence b
-	EX_PRESSURE = 3     // pressure buffer `pidx` (+ the freeze mask in faithful mode)
+	EX_PRESSURE = 3,    // pressure buffer `pidx` (+ the freeze mask in faithful mode)
+	EX_PRESSURE_FACE = 4 // face planes leave from scratch buffer p_face[pidx >> 1], halos land in pressure buffer pidx & 1
 };
 // items of one member for an exchange set; returns their number (<= 4)
 int exchange_items(fx_ctx* c, int which_set, int k, int pidx, ExchItem out[4]);
