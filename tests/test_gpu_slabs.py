@@ -258,3 +258,14 @@ def test_bench_multi_rank_path_in_loopback():
     sched = d["config"]["schedule"]
     assert len(sched["candidates"]) == 4 and (sched["overlap"], sched["jacobi_round"]) in [(1, 8), (2, 8), (2, 4), (0, 8)]
     assert d["value"] > 0 and d["scaling"] == "weak"
+
+
+@pytest.mark.parametrize("overlap", [2, 0])
+def test_slabs_mirror_addressing(overlap):
+    """the reference's `Fluid` sampler mode (MIRROR, Fluid.cpp:452) in slabs: mirrored taps only exist at the GLOBAL z faces"""
+    dims = (64, 64, 64)
+    ref = run_single(dims, 6, jacobi_iters=10, advect_address="mirror", storage="fp16")
+    fl = run_slabs(dims, 6, 4, jacobi_iters=10, advect_address="mirror", storage="fp16", halo_jacobi=4, halo_advect=6, overlap=overlap)
+    assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
+    assert np.array_equal(gather(fl, fx.FIELD_COLOR, 0), ref.download(fx.FIELD_COLOR))
+    assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
