@@ -206,7 +206,7 @@ int advect_all(fx_ctx* ctx, std::vector<fx_ctx*>& M, hipStream_t s)
 	const int Ha = (int)ctx->desc.halo_advect;
 	const ExchSpec spec{ EX_ADVECT_IN, Ha, 0 };
 	bool ov = overlap_level(ctx) >= 1;
-	for (fx_ctx* m : M) if (m->g.nz <= 2 * Ha) ov = false;
+	if (ov && ctx->group->min_nz <= 2 * Ha) ov = false;        // decided on the thinnest slab of the chain: the same on every rank
 	if (!ov) {
 		if ((rc = do_exchange(ctx, M, &spec, 1, s))) return rc;
 		for (fx_ctx* m : M) { ScopedMark mk(m, s, MK_ADVECT); if ((rc = advect_range(m, s, owned(m), false))) return rc; }
@@ -402,8 +402,9 @@ int jacobi_all(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t it
 		int t = fused_sweeps(lead);
 		for (fx_ctx* m : M) t = std::min(t, fused_sweeps(m));
 		const int k = lead->opt_round;
-		bool ok = lead->group->face_stream != nullptr;
-		for (fx_ctx* m : M) if (m->g.nz < 4 * k || !m->p_face[0] || m->frozen) ok = false;   // two face zones (<= 2k - 1 planes each) and an interior
+		// two face zones (<= 2k - 1 planes each) and an interior; decided on the thinnest slab of the chain and on the (chain-wide)
+		// Jacobi mode, so that every rank takes the same branch -- the two schedules exchange different things
+		const bool ok = lead->group->face_stream != nullptr && lead->group->min_nz >= 4 * k && lead->p_face[0] && !lead->frozen;
 		if (ok) return jacobi_overlapped(lead, M, s, iters, t, k);
 	}
 	return jacobi_serial(lead, M, s, iters);
@@ -1119,6 +1120,22 @@ int fx_comm_init_rank(fx_ctx* ctx, const void* id, size_t bytes, int rank, int n
 	g->transport = t;
 	g->refs = 1;
 	if ((rc = make_comm_stream(g, ctx->device))) { delete t; delete g; return rc; }
+	if ((rc = t->min_over_ranks(ctx->g.nz, ctx->stream, &g->min_nz))) { delete t; delete g; return rc; }
+	{	// every rank must run the same schedule: same grid, halos, sweep count, Jacobi mode and storage (min == max of a digest)
+		const fx_desc& d = ctx->desc;
+		uint32_t h = 2166136261u;
+		for (uint32_t v : { d.grid_x, d.grid_y, d.grid_z, d.halo_advect, d.halo_jacobi, d.jacobi_iters, d.jacobi_mode, d.storage, d.advect_address, (uint32_t)nranks })
+			h = (h ^ v) * 16777619u;
+		const int digest = (int)(h & 0x3FFFFFFFu);
+		int lo = 0, hi = 0;
+		if ((rc = t->min_over_ranks(digest, ctx->stream, &lo)) || (rc = t->min_over_ranks(-digest, ctx->stream, &hi))) { delete t; delete g; return rc; }
+		if (lo != digest || -hi != digest) {
+			ctx->last_error = "fx_comm_init_rank: the ranks were created with different descriptors";
+			std::fprintf(stderr, "fluidx: %s\n", ctx->last_error.c_str());
+			delete t; delete g;
+			return FX_E_INVALID;
+		}
+	}
 	ctx->group = g; ctx->rank = rank; ctx->nranks = nranks;
 	return FX_OK;
 }
@@ -1192,6 +1209,8 @@ int fx_comm_init_local(fx_ctx** ctxs, int nranks)
 	g->transport = make_local_transport();
 	g->refs = nranks;
 	if (int rc = make_comm_stream(g, ctxs[0]->device)) { delete g->transport; delete g; return rc; }
+	g->min_nz = ctxs[0]->g.nz;
+	for (int r = 1; r < nranks; ++r) g->min_nz = std::min(g->min_nz, ctxs[r]->g.nz);
 	for (int r = 0; r < nranks; ++r) {
 		g->members.push_back(ctxs[r]);
 		ctxs[r]->group = g; ctxs[r]->rank = r; ctxs[r]->nranks = nranks;

@@ -64,6 +64,7 @@ void halo_segments(const fx_ctx* c, const ExchItem* items, int n, std::vector<Se
 // ------------------------------------------------------------------------------------------------
 struct LocalTransport : Transport {
 	bool is_local() const override { return true; }
+	int min_over_ranks(int v, hipStream_t, int* out) override { *out = v; return FX_OK; }   // the caller sees every member
 	int exchange(fx_comm_group* grp, const std::vector<std::vector<Seg>>& segs, hipStream_t s) override
 	{
 		const int n = (int)grp->members.size();
@@ -107,6 +108,7 @@ struct RcclApi {
 	decltype(&ncclRecv) Recv = nullptr;
 	decltype(&ncclGroupStart) GroupStart = nullptr;
 	decltype(&ncclGroupEnd) GroupEnd = nullptr;
+	decltype(&ncclAllReduce) AllReduce = nullptr;
 	decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 
@@ -127,7 +129,7 @@ static RcclApi* rccl(std::string* err)
 #define FX_SYM(f) api.f = (decltype(api.f))dlsym(api.handle, "nccl" #f); \
 	if (!api.f) { if (err) *err = "librccl lacks nccl" #f; api.handle = nullptr; return nullptr; }
 	FX_SYM(GetUniqueId) FX_SYM(CommInitRank) FX_SYM(CommDestroy) FX_SYM(Send) FX_SYM(Recv)
-	FX_SYM(GroupStart) FX_SYM(GroupEnd) FX_SYM(GetErrorString)
+	FX_SYM(GroupStart) FX_SYM(GroupEnd) FX_SYM(AllReduce) FX_SYM(GetErrorString)
 #undef FX_SYM
 	return &api;
 }
@@ -152,6 +154,18 @@ struct RcclTransport : Transport {
 	int rank, nranks;
 	bool is_local() const override { return false; }
 	~RcclTransport() override { if (comm) api->CommDestroy(comm); }
+	// smallest value of `v` over the ranks (one-time set-up traffic: the ranks must take the same schedule decisions)
+	int min_over_ranks(int v, hipStream_t s, int* out) override
+	{
+		int* d = nullptr;
+		if (hipMalloc((void**)&d, sizeof(int)) != hipSuccess) return FX_E_NOMEM;
+		int rc = FX_OK;
+		if (hipMemcpyAsync(d, &v, sizeof v, hipMemcpyHostToDevice, s) != hipSuccess) rc = FX_E_DEVICE;
+		if (rc == FX_OK && api->AllReduce(d, d, 1, ncclInt32, ncclMin, comm, s) != ncclSuccess) rc = FX_E_COMM;
+		if (rc == FX_OK && (hipMemcpyAsync(out, d, sizeof v, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) rc = FX_E_DEVICE;
+		(void)hipFree(d);
+		return rc;
+	}
 	int exchange(fx_comm_group* grp, const std::vector<std::vector<Seg>>& segs, hipStream_t s) override
 	{
 		fx_ctx* c = grp->members[0];

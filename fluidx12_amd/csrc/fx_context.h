@@ -86,6 +86,8 @@ struct Transport {
 	// parts[r] for every rank r of the chain (RCCL: only this rank's src and, on the root, every dst are meaningful)
 	virtual int gather(fx_comm_group* grp, const std::vector<GatherPart>& parts, int root, hipStream_t s) = 0;
 	virtual bool is_local() const = 0;
+	// min of `v` over the ranks of the chain (RCCL: an all-reduce; loop-back: the caller combines its members itself)
+	virtual int min_over_ranks(int v, hipStream_t s, int* out) = 0;
 };
 
 }  // namespace fx
@@ -101,6 +103,7 @@ struct fx_comm_group {
 	// the face chains of the overlapped pressure rounds run on their own stream, beside the interior sweeps
 	hipStream_t face_stream;
 	hipEvent_t ev_int, ev_face1;    // "interior + face copy of the round done" (compute -> face), "the chain has read its input" (face -> compute)
+	int min_nz;                     // thinnest slab of the chain: every rank takes the same schedule decisions from it
 	hipStream_t shared_stream;      // loop-back groups: the one compute stream of all members (owned by the group)
 	bool broken;                    // a member was destroyed: the survivors can only be destroyed
 };
