@@ -341,12 +341,12 @@ int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint
 		// ---- face stream: the chain (needs the previous round's interior + face copy, and its exchange)
 		FX_HIP(hipStreamWaitEvent(fs, grp->ev_int, 0));
 		if (in_flight) FX_HIP(hipStreamWaitEvent(fs, grp->ev_done, 0));
+		ScopedMark chain_mark(lead, fs, MK_JACOBI);        // one mark per chain (loop-back: all members' chains, booked on the first)
 		for (int lvl = 1; lvl <= cnt; ++lvl) {
 			const int rem = cnt - lvl;
 			for (fx_ctx* mctx : M) {
 				if (!has_lower(mctx) && !has_upper(mctx)) continue;
 				DeviceGuard dg(mctx->device);
-				ScopedMark mk(mctx, fs, MK_JACOBI);
 				const Range o = owned(mctx);
 				const float* in = lvl == 1 ? mctx->p[src] : mctx->p_face[(lvl - 1) & 1];
 				const Range lo{ o.lo - rem, has_lower(mctx) ? o.lo + k + rem : o.lo - rem };
@@ -1049,7 +1049,17 @@ int fx_timing_enable(fx_ctx* ctx, int enable)
 	if (!ctx) return FX_E_INVALID;
 	std::vector<fx_ctx*> M;
 	for_members(ctx, M);
-	for (fx_ctx* c : M) c->timing_on = enable != 0;
+	for (fx_ctx* c : M) {
+		c->timing_on = enable != 0;
+		if (enable) {                                  // the events of a few hundred steps exist before the timed region starts
+			DeviceGuard dg(c->device);
+			while (c->ev.size() < 4096) {
+				hipEvent_t e;
+				if (hipEventCreate(&e) != hipSuccess) return FX_E_DEVICE;
+				c->ev.push_back(e);
+			}
+		}
+	}
 	return FX_OK;
 }
 
