@@ -104,7 +104,7 @@ void free_all(fx_ctx* c)
 		if (c->col[i]) (void)hipFree(c->col[i]);
 		if (c->p[i]) (void)hipFree(c->p[i]);
 	}
-	void* others[] = { c->target, c->target_float, c->p_face[0], c->p_face[1], c->b, c->frozen, c->lightmap, c->cube, c->sh_dev, c->halo_overflow, c->stage,
+	void* others[] = { c->occ, c->target, c->target_float, c->p_face[0], c->p_face[1], c->b, c->frozen, c->lightmap, c->cube, c->sh_dev, c->halo_overflow, c->stage,
 		c->sh_scratch[0], c->sh_scratch[1], c->sh_scratch[2], c->sh_scratch[3] };
 	for (void* q : others) if (q) (void)hipFree(q);
 	for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -549,6 +549,8 @@ int fx_create(fx_ctx** out, const fx_desc* d)
 			}
 			FX_HIP(hipMalloc((void**)&ctx->cube, off));
 			FX_HIP(hipMemsetAsync(ctx->cube, 0, off, ctx->stream));
+			const size_t ncell = (size_t)((d->grid_x + 3) / 4) * ((d->grid_y + 3) / 4) * ((d->grid_z + 3) / 4);
+			FX_HIP(hipMalloc((void**)&ctx->occ, ncell * sizeof(float)));
 			FX_HIP(hipMalloc((void**)&ctx->sh_dev, 27 * sizeof(float)));
 			FX_HIP(hipMemsetAsync(ctx->sh_dev, 0, 27 * sizeof(float), ctx->stream));
 		}
@@ -693,6 +695,16 @@ static int ensure_target(fx_ctx* ctx, hipStream_t s)
 	return FX_OK;
 }
 
+// the occupancy grid of this frame's colour field (FLUIDX_RENDER_OCCUPANCY=0 switches the empty-space skipping off: A/B runs);
+// its cost is booked on the light/view pass that follows
+static const float* render_occupancy(fx_ctx* ctx, const void* color, hipStream_t s)
+{
+	const char* e = std::getenv("FLUIDX_RENDER_OCCUPANCY");
+	if ((e && e[0] == '0') || !ctx->occ) return nullptr;
+	if (launch_occupancy(ctx->g, ctx->half, color, ctx->occ, s) != hipSuccess) return nullptr;
+	return ctx->occ;
+}
+
 int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags)
 {
 	if (!ctx || frame_index >= FX_FRAME_COUNT) return FX_E_INVALID;
@@ -718,19 +730,20 @@ int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags)
 		if (rc) return rc;
 		const void* colord = ctx->col[ctx->frame_parity];
 		const int W = (int)ctx->desc.viewport_w, H = (int)ctx->desc.viewport_h;
+		const float* occd = render_occupancy(ctx, colord, sd);
 		if (flags & FX_SEPARATE_LIGHT_PASS) {
 			{
 				ScopedMark mk(ctx, sd, MK_LIGHT);
 				FX_HIP(launch_raymarch_light(ctx->g, ctx->half, colord, ctx->lightmap, ctx->fc,
-					ctx->has_sh ? ctx->sh_dev : nullptr, ctx->max_light_samples, sd));
+					ctx->has_sh ? ctx->sh_dev : nullptr, ctx->max_light_samples, occd, sd));
 			}
 			ScopedMark mk(ctx, sd, MK_VIEW);
 			FX_HIP(launch_raycast_direct(ctx->g, ctx->half, colord, ctx->lightmap, ctx->fc, nullptr, W, H,
-				ctx->ray_samples, ctx->max_light_samples, 1, ctx->target, ctx->target_float, sd));       // rayCastVDirect :953-972
+				ctx->ray_samples, ctx->max_light_samples, 1, ctx->target, ctx->target_float, occd, sd));   // rayCastVDirect :953-972
 		} else {
 			ScopedMark mk(ctx, sd, MK_VIEW);
 			FX_HIP(launch_raycast_direct(ctx->g, ctx->half, colord, nullptr, ctx->fc, ctx->has_sh ? ctx->sh_dev : nullptr, W, H,
-				ctx->max_ray_samples, ctx->max_light_samples, 0, ctx->target, ctx->target_float, sd));   // rayCastDirect :932-951
+				ctx->max_ray_samples, ctx->max_light_samples, 0, ctx->target, ctx->target_float, occd, sd));   // rayCastDirect :932-951
 		}
 		if (ctx->timing_on) ctx->acc.renders += 1;
 		return FX_OK;
@@ -740,19 +753,20 @@ int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags)
 	const void* color = ctx->col[ctx->frame_parity];
 	const int size = ctx->g.X >> ctx->cube_lod;
 	uint8_t* cube = ctx->cube + ctx->cube_mip_offset[ctx->cube_lod];
+	const float* occ = render_occupancy(ctx, color, s);
 	if (flags & FX_SEPARATE_LIGHT_PASS) {
 		{
 			ScopedMark mk(ctx, s, MK_LIGHT);
 			FX_HIP(launch_raymarch_light(ctx->g, ctx->half, color, ctx->lightmap, ctx->fc,
-				ctx->has_sh ? ctx->sh_dev : nullptr, ctx->max_light_samples, s));     // Fluid.cpp:857-878
+				ctx->has_sh ? ctx->sh_dev : nullptr, ctx->max_light_samples, occ, s));     // Fluid.cpp:857-878
 		}
 		ScopedMark mk(ctx, s, MK_VIEW);
 		FX_HIP(launch_raymarch_view(ctx->g, ctx->half, color, ctx->lightmap, ctx->fc, nullptr, size,
-			ctx->visibility_mask, ctx->ray_samples, ctx->max_light_samples, 1, cube, s));   // Fluid.cpp:880-908
+			ctx->visibility_mask, ctx->ray_samples, ctx->max_light_samples, 1, cube, occ, s));   // Fluid.cpp:880-908
 	} else {
 		ScopedMark mk(ctx, s, MK_VIEW);
 		FX_HIP(launch_raymarch_view(ctx->g, ctx->half, color, nullptr, ctx->fc, ctx->has_sh ? ctx->sh_dev : nullptr,
-			size, ctx->visibility_mask, ctx->ray_samples, ctx->max_light_samples, 0, cube, s));   // Fluid.cpp:825-855
+			size, ctx->visibility_mask, ctx->ray_samples, ctx->max_light_samples, 0, cube, occ, s));   // Fluid.cpp:825-855
 	}
 	if (ctx->timing_on) ctx->acc.renders += 1;
 	return FX_OK;

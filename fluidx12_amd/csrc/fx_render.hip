@@ -73,7 +73,9 @@ __device__ __forceinline__ float3 unpack_r11g11b10(uint32_t v)
 }
 
 // ---- trilinear taps (LINEAR_CLAMP, Fluid.cpp:475) ---------------------------------------------------
-struct Taps { size_t i[8]; float fx, fy, fz; };
+// `cell` = the 4^3 occupancy block of the base tap; the block's entry in the occupancy grid is the largest alpha of voxels
+// [4c, 4c + 4] per axis, which contains all eight taps whatever the clamping did
+struct Taps { size_t i[8]; float fx, fy, fz; uint32_t cell; };
 
 __device__ __forceinline__ Taps make_taps(const Geom& g, float u, float v, float w, int ox = 0, int oy = 0, int oz = 0)
 {
@@ -90,6 +92,7 @@ __device__ __forceinline__ Taps make_taps(const Geom& g, float u, float v, float
 	t.i[2] = z0 * XY + y1 * X + x0; t.i[3] = z0 * XY + y1 * X + x1;
 	t.i[4] = z1 * XY + y0 * X + x0; t.i[5] = z1 * XY + y0 * X + x1;
 	t.i[6] = z1 * XY + y1 * X + x0; t.i[7] = z1 * XY + y1 * X + x1;
+	t.cell = (uint32_t)(((z0 >> 2) * ((g.Y + 3) >> 2) + (y0 >> 2)) * ((g.X + 3) >> 2) + (x0 >> 2));
 	return t;
 }
 
@@ -99,18 +102,24 @@ __device__ __forceinline__ float blend8(const float q[8], const Taps& t)
 		lerp1(lerp1(q[4], q[5], t.fx), lerp1(q[6], q[7], t.fx), t.fy), t.fz);
 }
 
+// Empty-space skipping that changes no bit: where the occupancy grid says every tap has alpha == 0 the trilinear result IS +0
+// (lerp(0, 0, f) = fma(f, 0, 0)), so the eight gathers are replaced by one 4-byte look-up of an L2-resident 1/64-size grid.
 template <bool HALF>
-__device__ __forceinline__ float sample_density(const typename ColTex<HALF>::T* col, const Taps& t)
+__device__ __forceinline__ float sample_density(const typename ColTex<HALF>::T* col, const Taps& t, const float* __restrict__ occ = nullptr)
 {
+	if (occ && occ[t.cell] == 0.0f) return 0.0f;
 	float q[8];
 #pragma unroll
 	for (int k = 0; k < 8; ++k) q[k] = ColTex<HALF>::ldw(col, t.i[k]);
 	return blend8(q, t);
 }
 
+// The view march only looks at a sample whose alpha exceeds 0.01 (CSRayMarch.hlsl:161): if no tap does, neither does their
+// convex combination (round-to-nearest is monotonic), and the sample can be reported as empty without fetching it.
 template <bool HALF>
-__device__ __forceinline__ float4 sample_color(const typename ColTex<HALF>::T* col, const Taps& t)
+__device__ __forceinline__ float4 sample_color(const typename ColTex<HALF>::T* col, const Taps& t, const float* __restrict__ occ = nullptr)
 {
+	if (occ && occ[t.cell] <= 0.00999999978f) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	float4 c[8];
 #pragma unroll
 	for (int k = 0; k < 8; ++k) c[k] = ColTex<HALF>::ld(col, t.i[k]);
@@ -149,14 +158,14 @@ __device__ __forceinline__ float step_factor(float dDensity, float transm, float
 // CastLightRay (RayMarch.hlsli:215-247)
 template <bool HALF>
 __device__ void cast_light_ray(float& transm, const Geom& g, const typename ColTex<HALF>::T* col,
-	float ox, float oy, float oz, float dx, float dy, float dz, float stepScale, uint32_t numSamples)
+	float ox, float oy, float oz, float dx, float dy, float dz, float stepScale, uint32_t numSamples, const float* __restrict__ occ = nullptr)
 {
 	float t = stepScale, prev = 0.0f;
 	for (uint32_t i = 0; i < numSamples; ++i) {
 		const float px = fmaf(dx, t, ox), py = fmaf(dy, t, oy), pz = fmaf(dz, t, oz);
 		if (outside(px, py, pz)) break;
 		const Taps tp = make_taps(g, fmaf(px, 0.5f, 0.5f), fmaf(py, 0.5f, 0.5f), fmaf(pz, 0.5f, 0.5f));
-		const float density = sample_density<HALF>(col, tp);
+		const float density = sample_density<HALF>(col, tp, occ);
 		const float nt = fmaf(-density, 0.800000012f, 1.0f) * transm;
 		if (nt < 0.00999999978f) { transm = nt; break; }
 		const float fac = step_factor(-prev + density, transm, density);
@@ -194,15 +203,16 @@ __device__ void sh_irradiance(float out[3], const float* __restrict__ sh, float 
 // GI branch of CSRayMarchL.hlsl:59-68 / RayMarch.hlsli:275-283
 template <bool HALF>
 __device__ void gi_term(float irr[3], float& ao, const Geom& g, const typename ColTex<HALF>::T* col, const FrameConsts& fc,
-	const float* __restrict__ sh, float px, float py, float pz, float u, float v, float w, float stepScale, uint32_t numSamples)
+	const float* __restrict__ sh, float px, float py, float pz, float u, float v, float w, float stepScale, uint32_t numSamples,
+	const float* __restrict__ occ = nullptr)
 {
 	// GetDensityGradient (RayMarch.hlsli:73-95)
-	const float qxm = sample_density<HALF>(col, make_taps(g, u, v, w, -1, 0, 0));
-	const float qxp = sample_density<HALF>(col, make_taps(g, u, v, w, 1, 0, 0));
-	const float qym = sample_density<HALF>(col, make_taps(g, u, v, w, 0, -1, 0));
-	const float qyp = sample_density<HALF>(col, make_taps(g, u, v, w, 0, 1, 0));
-	const float qzm = sample_density<HALF>(col, make_taps(g, u, v, w, 0, 0, -1));
-	const float qzp = sample_density<HALF>(col, make_taps(g, u, v, w, 0, 0, 1));
+	const float qxm = sample_density<HALF>(col, make_taps(g, u, v, w, -1, 0, 0), occ);
+	const float qxp = sample_density<HALF>(col, make_taps(g, u, v, w, 1, 0, 0), occ);
+	const float qym = sample_density<HALF>(col, make_taps(g, u, v, w, 0, -1, 0), occ);
+	const float qyp = sample_density<HALF>(col, make_taps(g, u, v, w, 0, 1, 0), occ);
+	const float qzm = sample_density<HALF>(col, make_taps(g, u, v, w, 0, 0, -1), occ);
+	const float qzp = sample_density<HALF>(col, make_taps(g, u, v, w, 0, 0, 1), occ);
 	const float gx = -qxm + qxp, gy = -qym + qyp, gz = -qzm + qzp;
 	const bool any = fabsf(gx) > 0.0f || fabsf(gy) > 0.0f || fabsf(gz) > 0.0f;
 	float dx = any ? -gx : px, dy = any ? -gy : py, dz = any ? -gz : pz;
@@ -215,7 +225,7 @@ __device__ void gi_term(float irr[3], float& ao, const Geom& g, const typename C
 	const float rd = rsqf(dot3(dx, dy, dz, dx, dy, dz));
 	dx *= rd; dy *= rd; dz *= rd;
 	ao = 1.0f;
-	cast_light_ray<HALF>(ao, g, col, px, py, pz, dx, dy, dz, stepScale, numSamples);
+	cast_light_ray<HALF>(ao, g, col, px, py, pz, dx, dy, dz, stepScale, numSamples, occ);
 }
 
 __device__ __forceinline__ void light_dir_local(const FrameConsts& fc, float& lx, float& ly, float& lz)
@@ -230,7 +240,7 @@ __device__ __forceinline__ void light_dir_local(const FrameConsts& fc, float& lx
 // ---------------------------------------------------------------------------------------------------
 template <bool HALF>
 __global__ __launch_bounds__(256) void k_raymarch_light(const Geom g, const typename ColTex<HALF>::T* __restrict__ col,
-	uint32_t* __restrict__ lightmap, const FrameConsts fc, const float* __restrict__ sh, uint32_t numSamples)
+	uint32_t* __restrict__ lightmap, const FrameConsts fc, const float* __restrict__ sh, uint32_t numSamples, const float* __restrict__ occ)
 {
 	const int x = blockIdx.x * 64 + threadIdx.x;
 	const int y = blockIdx.y * 4 + threadIdx.y;
@@ -240,14 +250,14 @@ __global__ __launch_bounds__(256) void k_raymarch_light(const Geom g, const type
 	const float oy = fmaf(((float)y + 0.5f) / (float)g.Y, 2.0f, -1.0f);
 	const float oz = fmaf(((float)z + 0.5f) / (float)g.Zg, 2.0f, -1.0f);
 	const float u = fmaf(ox, 0.5f, 0.5f), v = fmaf(oy, 0.5f, 0.5f), w = fmaf(oz, 0.5f, 0.5f);   // :36
-	const float density = sample_density<HALF>(col, make_taps(g, u, v, w));        // :37
+	const float density = sample_density<HALF>(col, make_taps(g, u, v, w), occ);   // :37
 	float shadow = 1.0f, ao = 1.0f, irr[3] = { 0.0f, 0.0f, 0.0f };
 	if (density >= 0.00999999978f) {                                               // :44
 		const float stepScale = 3.46410155f / (float)numSamples;                   // RayMarch.hlsli:29-30
 		float lx, ly, lz;
 		light_dir_local(fc, lx, ly, lz);
-		cast_light_ray<HALF>(shadow, g, col, ox, oy, oz, lx, ly, lz, stepScale, numSamples);   // :55
-		if (sh) gi_term<HALF>(irr, ao, g, col, fc, sh, ox, oy, oz, u, v, w, stepScale, numSamples);   // :59-68
+		cast_light_ray<HALF>(shadow, g, col, ox, oy, oz, lx, ly, lz, stepScale, numSamples, occ);   // :55
+		if (sh) gi_term<HALF>(irr, ao, g, col, fc, sh, ox, oy, oz, u, v, w, stepScale, numSamples, occ);   // :59-68
 	}
 	float out[3];
 #pragma unroll
@@ -292,7 +302,7 @@ __device__ __forceinline__ uint32_t to_unorm8(float v)
 template <bool HALF, bool SEPARATE>
 __device__ __forceinline__ void march_ray(const Geom& g, const typename ColTex<HALF>::T* __restrict__ col,
 	const uint32_t* __restrict__ lightmap, const FrameConsts& fc, const float* __restrict__ sh, const float o[3], const float d[3],
-	float tMax, uint32_t numSamples, uint32_t numLightSamples, float& sr, float& sg, float& sb, float& sa)
+	float tMax, uint32_t numSamples, uint32_t numLightSamples, float& sr, float& sg, float& sb, float& sa, const float* __restrict__ occ)
 {
 	const float stepScale = 3.46410155f / (float)numSamples;
 	const float lightStep = 3.46410155f / (float)numLightSamples;
@@ -306,7 +316,7 @@ __device__ __forceinline__ void march_ray(const Geom& g, const typename ColTex<H
 		if (outside(qx, qy, qz)) break;                                            // :149
 		const float u = fmaf(qx, 0.5f, 0.5f), v = fmaf(qy, 0.5f, 0.5f), w = fmaf(qz, 0.5f, 0.5f);
 		const Taps tp = make_taps(g, u, v, w);
-		const float4 c = sample_color<HALF>(col, tp);                              // :157
+		const float4 c = sample_color<HALF>(col, tp, occ);                         // :157
 		float newStep = stepScale;
 		if (0.00999999978f < c.w) {                                                // :161
 			float light[3];
@@ -315,8 +325,8 @@ __device__ __forceinline__ void march_ray(const Geom& g, const typename ColTex<H
 				light[0] = l.x; light[1] = l.y; light[2] = l.z;
 			} else {                                                               // RayMarch.hlsli:260-294
 				float shadow = 1.0f, ao = 1.0f, irr[3] = { 0.0f, 0.0f, 0.0f };
-				cast_light_ray<HALF>(shadow, g, col, qx, qy, qz, lx, ly, lz, lightStep, numLightSamples);
-				if (sh) gi_term<HALF>(irr, ao, g, col, fc, sh, qx, qy, qz, u, v, w, lightStep, numLightSamples);
+				cast_light_ray<HALF>(shadow, g, col, qx, qy, qz, lx, ly, lz, lightStep, numLightSamples, occ);
+				if (sh) gi_term<HALF>(irr, ao, g, col, fc, sh, qx, qy, qz, u, v, w, lightStep, numLightSamples, occ);
 #pragma unroll
 				for (int a = 0; a < 3; ++a) {
 					const float amb = sh ? ao * irr[a] : fc.ambient[3] * fc.ambient[a];
@@ -340,7 +350,7 @@ __device__ __forceinline__ void march_ray(const Geom& g, const typename ColTex<H
 template <bool HALF, bool SEPARATE>
 __global__ __launch_bounds__(64) void k_raymarch_view(const Geom g, const typename ColTex<HALF>::T* __restrict__ col,
 	const uint32_t* __restrict__ lightmap, const FrameConsts fc, const float* __restrict__ sh, int size, uint32_t mask,
-	uint32_t numSamples, uint32_t numLightSamples, uint32_t* __restrict__ cube)
+	uint32_t numSamples, uint32_t numLightSamples, uint32_t* __restrict__ cube, const float* __restrict__ occ)
 {
 	const int face = blockIdx.z;
 	if (!((mask >> face) & 1u)) return;                                            // CSRayMarch.hlsl:102
@@ -372,7 +382,7 @@ __global__ __launch_bounds__(64) void k_raymarch_view(const Geom g, const typena
 	const float tMax = fmaxf((tg[2] + -o[2]) / d[2], fmaxf((tg[1] + -o[1]) / d[1], (tg[0] + -o[0]) / d[0]));   // :118
 
 	float sr, sg, sb, sa;
-	march_ray<HALF, SEPARATE>(g, col, lightmap, fc, sh, o, d, tMax, numSamples, numLightSamples, sr, sg, sb, sa);
+	march_ray<HALF, SEPARATE>(g, col, lightmap, fc, sh, o, d, tMax, numSamples, numLightSamples, sr, sg, sb, sa, occ);
 	sr *= 0.159154937f; sg *= 0.159154937f; sb *= 0.159154937f;                    // :192
 	cube[((size_t)face * size + y) * size + x] =
 		to_unorm8(sr) | (to_unorm8(sg) << 8) | (to_unorm8(sb) << 16) | (to_unorm8(sa) << 24);   // :195
@@ -387,7 +397,7 @@ __global__ __launch_bounds__(64) void k_raymarch_view(const Geom g, const typena
 template <bool HALF, bool SEPARATE>
 __global__ __launch_bounds__(64) void k_raycast_direct(const Geom g, const typename ColTex<HALF>::T* __restrict__ col,
 	const uint32_t* __restrict__ lightmap, const FrameConsts fc, const float* __restrict__ sh, int W, int H,
-	uint32_t numSamples, uint32_t numLightSamples, uint32_t* __restrict__ target, float4* __restrict__ out_float)
+	uint32_t numSamples, uint32_t numLightSamples, uint32_t* __restrict__ target, float4* __restrict__ out_float, const float* __restrict__ occ)
 {
 	const int px = blockIdx.x * 8 + threadIdx.x, py = blockIdx.y * 8 + threadIdx.y;
 	if (px >= W || py >= H) return;
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(64) void k_raycast_direct(const Geom g, const typen
 	d[0] *= rl; d[1] *= rl; d[2] *= rl;
 	if (!compute_ray_origin(o, d)) return;                                         // :50 discard
 	float sr, sg, sb, sa;
-	march_ray<HALF, SEPARATE>(g, col, lightmap, fc, sh, o, d, 3.40282347e+38f, numSamples, numLightSamples, sr, sg, sb, sa);
+	march_ray<HALF, SEPARATE>(g, col, lightmap, fc, sh, o, d, 3.40282347e+38f, numSamples, numLightSamples, sr, sg, sb, sa, occ);
 	sr *= 0.159154937f; sg *= 0.159154937f; sb *= 0.159154937f;                    // :124
 	if (out_float) out_float[pix] = make_float4(sr, sg, sb, sa);
 	if (target) {
@@ -450,24 +460,50 @@ __global__ __launch_bounds__(256) void k_lightmap_decode(const uint32_t* __restr
 	}
 }
 
+// occupancy grid of the ray marches: entry c = largest alpha of the voxels [4c, 4c + 4] per axis (5^3, clipped to the grid),
+// i.e. of everything a trilinear sample whose base tap lies in block c can touch
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_occupancy(const Geom g, const typename ColTex<HALF>::T* __restrict__ col, float* __restrict__ occ)
+{
+	const int CX = (g.X + 3) >> 2, CY = (g.Y + 3) >> 2, CZ = (g.Zg + 3) >> 2;
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= CX * CY * CZ) return;
+	const int cx = c % CX, cy = (c / CX) % CY, cz = c / (CX * CY);
+	float m = 0.0f;
+	for (int z = 4 * cz; z <= min(4 * cz + 4, g.Zg - 1); ++z)
+		for (int y = 4 * cy; y <= min(4 * cy + 4, g.Y - 1); ++y) {
+			const size_t row = ((size_t)z * g.Y + y) * g.X;
+			for (int x = 4 * cx; x <= min(4 * cx + 4, g.X - 1); ++x) m = fmaxf(m, ColTex<HALF>::ldw(col, row + x));
+		}
+	occ[c] = m;
+}
+
+hipError_t launch_occupancy(const Geom& g, int half_store, const void* color, float* occ, hipStream_t s)
+{
+	const int n = ((g.X + 3) >> 2) * ((g.Y + 3) >> 2) * ((g.Zg + 3) >> 2);
+	if (half_store) hipLaunchKernelGGL(k_occupancy<true>, dim3((n + 255) / 256), dim3(256), 0, s, g, (const h16x4*)color, occ);
+	else hipLaunchKernelGGL(k_occupancy<false>, dim3((n + 255) / 256), dim3(256), 0, s, g, (const float4*)color, occ);
+	return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------
 hipError_t launch_raymarch_light(const Geom& g, int half_store, const void* color, uint32_t* lightmap,
-	const FrameConsts& fc, const float* sh, uint32_t num_samples, hipStream_t s)
+	const FrameConsts& fc, const float* sh, uint32_t num_samples, const float* occ, hipStream_t s)
 {
 	const dim3 grid((g.X + 63) / 64, (g.Y + 3) / 4, g.Zg), block(64, 4, 1);
-	if (half_store) hipLaunchKernelGGL(k_raymarch_light<true>, grid, block, 0, s, g, (const h16x4*)color, lightmap, fc, sh, num_samples);
-	else hipLaunchKernelGGL(k_raymarch_light<false>, grid, block, 0, s, g, (const float4*)color, lightmap, fc, sh, num_samples);
+	if (half_store) hipLaunchKernelGGL(k_raymarch_light<true>, grid, block, 0, s, g, (const h16x4*)color, lightmap, fc, sh, num_samples, occ);
+	else hipLaunchKernelGGL(k_raymarch_light<false>, grid, block, 0, s, g, (const float4*)color, lightmap, fc, sh, num_samples, occ);
 	return hipGetLastError();
 }
 
 hipError_t launch_raymarch_view(const Geom& g, int half_store, const void* color, const uint32_t* lightmap,
 	const FrameConsts& fc, const float* sh, int cube_size, uint32_t mask, uint32_t num_samples,
-	uint32_t num_light_samples, int separate, uint8_t* cube, hipStream_t s)
+	uint32_t num_light_samples, int separate, uint8_t* cube, const float* occ, hipStream_t s)
 {
 	const dim3 grid((cube_size + 7) / 8, (cube_size + 7) / 8, 6), block(8, 8, 1);
 	uint32_t* out = reinterpret_cast<uint32_t*>(cube);
 #define FX_LAUNCH(H, S) hipLaunchKernelGGL((k_raymarch_view<H, S>), grid, block, 0, s, g, \
-	(const typename ColTex<H>::T*)color, lightmap, fc, sh, cube_size, mask, num_samples, num_light_samples, out)
+	(const typename ColTex<H>::T*)color, lightmap, fc, sh, cube_size, mask, num_samples, num_light_samples, out, occ)
 	if (half_store) { if (separate) FX_LAUNCH(true, true); else FX_LAUNCH(true, false); }
 	else { if (separate) FX_LAUNCH(false, true); else FX_LAUNCH(false, false); }
 #undef FX_LAUNCH
@@ -476,12 +512,12 @@ hipError_t launch_raymarch_view(const Geom& g, int half_store, const void* color
 
 hipError_t launch_raycast_direct(const Geom& g, int half_store, const void* color, const uint32_t* lightmap,
 	const FrameConsts& fc, const float* sh, int W, int H, uint32_t num_samples, uint32_t num_light_samples, int separate,
-	uint8_t* target, float* out_float, hipStream_t s)
+	uint8_t* target, float* out_float, const float* occ, hipStream_t s)
 {
 	const dim3 grid((W + 7) / 8, (H + 7) / 8, 1), block(8, 8, 1);
 #define FX_LAUNCH(HF, S) hipLaunchKernelGGL((k_raycast_direct<HF, S>), grid, block, 0, s, g, \
 	(const typename ColTex<HF>::T*)color, lightmap, fc, sh, W, H, num_samples, num_light_samples, \
-	reinterpret_cast<uint32_t*>(target), reinterpret_cast<float4*>(out_float))
+	reinterpret_cast<uint32_t*>(target), reinterpret_cast<float4*>(out_float), occ)
 	if (half_store) { if (separate) FX_LAUNCH(true, true); else FX_LAUNCH(true, false); }
 	else { if (separate) FX_LAUNCH(false, true); else FX_LAUNCH(false, false); }
 #undef FX_LAUNCH

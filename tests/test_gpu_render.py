@@ -350,3 +350,32 @@ def test_2d_visualiser_equals_oracle(storage):
     target = np.empty((vp[1], vp[0], 4), np.uint8)
     target[...] = (51, 51, 51, 0)
     assert np.array_equal(f.download(fx.FIELD_TARGET), orc.blend_premultiplied(out, np.ones(vp[::-1], np.uint8), target))
+
+
+@pytest.mark.parametrize("storage,use_sh", [("fp32", False), ("fp16", True)])
+def test_empty_space_skipping_changes_no_bit(storage, use_sh, monkeypatch):
+    """the occupancy grid only replaces gathers whose result is known (all taps 0, or all taps <= the 0.01 threshold of the
+    view march): light map, both cube-map marches and the direct marches are bit-identical with and without it"""
+    X, vp = 48, (240, 180)
+    col = smoke_state(X, 10, seed=11)
+    sh = (np.random.default_rng(5).random((9, 3)) * np.array([[2.0]] + [[0.5]] * 8)).astype(f32) if use_sh else None
+
+    def run(on):
+        monkeypatch.setenv("FLUIDX_RENDER_OCCUPANCY", "1" if on else "0")
+        f, fr, lod, rs, mask = setup(X, col, *vp, storage=storage, sh=sh, max_samples=(64, 24))
+        out = []
+        for flags in (fx.Fluid.OPTIMIZED, fx.Fluid.RAY_MARCH_CUBEMAP):
+            f.Render(0, flags)
+            f.Synchronize()
+            out += [f.download(fx.FIELD_LIGHTMAP), f.download(fx.FIELD_CUBEMAP)]
+        for flags in (fx.Fluid.SEPARATE_LIGHT_PASS, fx.Fluid.RAY_MARCH_DIRECT):
+            f.ClearRenderTarget()
+            f.Render(0, flags)
+            f.Synchronize()
+            out.append(f.download(fx.FIELD_TARGET_FLOAT))
+        return out
+
+    a, b = run(False), run(True)
+    assert a[1][..., 3].max() > 30 and a[4][..., 3].max() > 0.2
+    for u, v in zip(a, b):
+        assert np.array_equal(u.view(np.uint8), v.view(np.uint8))
