@@ -550,7 +550,7 @@ int fx_create(fx_ctx** out, const fx_desc* d)
 			FX_HIP(hipMalloc((void**)&ctx->cube, off));
 			FX_HIP(hipMemsetAsync(ctx->cube, 0, off, ctx->stream));
 			const size_t ncell = (size_t)((d->grid_x + 3) / 4) * ((d->grid_y + 3) / 4) * ((d->grid_z + 3) / 4);
-			FX_HIP(hipMalloc((void**)&ctx->occ, ncell * sizeof(float)));
+			FX_HIP(hipMalloc((void**)&ctx->occ, 2 * ncell * sizeof(float)));       // the grid + the per-block maxima it is dilated from
 			FX_HIP(hipMalloc((void**)&ctx->sh_dev, 27 * sizeof(float)));
 			FX_HIP(hipMemsetAsync(ctx->sh_dev, 0, 27 * sizeof(float), ctx->stream));
 		}
@@ -730,10 +730,11 @@ int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags)
 		if (rc) return rc;
 		const void* colord = ctx->col[ctx->frame_parity];
 		const int W = (int)ctx->desc.viewport_w, H = (int)ctx->desc.viewport_h;
-		const float* occd = render_occupancy(ctx, colord, sd);
+		const float* occd = nullptr;                        // built inside the first pass's timing mark: its cost belongs to the frame
 		if (flags & FX_SEPARATE_LIGHT_PASS) {
 			{
 				ScopedMark mk(ctx, sd, MK_LIGHT);
+				occd = render_occupancy(ctx, colord, sd);
 				FX_HIP(launch_raymarch_light(ctx->g, ctx->half, colord, ctx->lightmap, ctx->fc,
 					ctx->has_sh ? ctx->sh_dev : nullptr, ctx->max_light_samples, occd, sd));
 			}
@@ -742,6 +743,7 @@ int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags)
 				ctx->ray_samples, ctx->max_light_samples, 1, ctx->target, ctx->target_float, occd, sd));   // rayCastVDirect :953-972
 		} else {
 			ScopedMark mk(ctx, sd, MK_VIEW);
+			occd = render_occupancy(ctx, colord, sd);
 			FX_HIP(launch_raycast_direct(ctx->g, ctx->half, colord, nullptr, ctx->fc, ctx->has_sh ? ctx->sh_dev : nullptr, W, H,
 				ctx->max_ray_samples, ctx->max_light_samples, 0, ctx->target, ctx->target_float, occd, sd));   // rayCastDirect :932-951
 		}
@@ -753,10 +755,11 @@ int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags)
 	const void* color = ctx->col[ctx->frame_parity];
 	const int size = ctx->g.X >> ctx->cube_lod;
 	uint8_t* cube = ctx->cube + ctx->cube_mip_offset[ctx->cube_lod];
-	const float* occ = render_occupancy(ctx, color, s);
+	const float* occ = nullptr;
 	if (flags & FX_SEPARATE_LIGHT_PASS) {
 		{
 			ScopedMark mk(ctx, s, MK_LIGHT);
+			occ = render_occupancy(ctx, color, s);
 			FX_HIP(launch_raymarch_light(ctx->g, ctx->half, color, ctx->lightmap, ctx->fc,
 				ctx->has_sh ? ctx->sh_dev : nullptr, ctx->max_light_samples, occ, s));     // Fluid.cpp:857-878
 		}
@@ -765,6 +768,7 @@ int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags)
 			ctx->visibility_mask, ctx->ray_samples, ctx->max_light_samples, 1, cube, occ, s));   // Fluid.cpp:880-908
 	} else {
 		ScopedMark mk(ctx, s, MK_VIEW);
+		occ = render_occupancy(ctx, color, s);
 		FX_HIP(launch_raymarch_view(ctx->g, ctx->half, color, nullptr, ctx->fc, ctx->has_sh ? ctx->sh_dev : nullptr,
 			size, ctx->visibility_mask, ctx->ray_samples, ctx->max_light_samples, 0, cube, occ, s));   // Fluid.cpp:825-855
 	}

@@ -460,29 +460,52 @@ __global__ __launch_bounds__(256) void k_lightmap_decode(const uint32_t* __restr
 	}
 }
 
-// occupancy grid of the ray marches: entry c = largest alpha of the voxels [4c, 4c + 4] per axis (5^3, clipped to the grid),
-// i.e. of everything a trilinear sample whose base tap lies in block c can touch
+// occupancy grid of the ray marches: entry c bounds the alpha of the voxels [4c, 4c + 4] per axis -- everything a trilinear
+// sample whose base tap lies in block c can touch.  Two passes: k_occupancy_blocks reads every alpha once, coalesced along
+// x (lane = x, each thread folds a 1 x 4 x 4 column, four lanes fold into one 4^3 block: no atomics), k_occupancy_dilate
+// takes the max over the 2 x 2 x 2 blocks c .. c + 1 (a superset of [4c, 4c + 4]: conservative, which only skips less).
 template <bool HALF>
-__global__ __launch_bounds__(256) void k_occupancy(const Geom g, const typename ColTex<HALF>::T* __restrict__ col, float* __restrict__ occ)
+__global__ __launch_bounds__(256) void k_occupancy_blocks(const Geom g, const typename ColTex<HALF>::T* __restrict__ col, float* __restrict__ blk)
 {
-	const int CX = (g.X + 3) >> 2, CY = (g.Y + 3) >> 2, CZ = (g.Zg + 3) >> 2;
+	const int CX = (g.X + 3) >> 2, CY = (g.Y + 3) >> 2;
+	const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+	const int cy = blockIdx.y * 4 + (threadIdx.x >> 6), cz = blockIdx.z;
+	float m = 0.0f;
+	if (x < g.X && cy < CY) {
+		for (int z = 4 * cz; z < min(4 * cz + 4, g.Zg); ++z)
+			for (int y = 4 * cy; y < min(4 * cy + 4, g.Y); ++y)
+				m = fmaxf(m, ColTex<HALF>::ldw(col, ((size_t)z * g.Y + y) * g.X + x));
+	}
+	m = fmaxf(m, __shfl_xor(m, 1));
+	m = fmaxf(m, __shfl_xor(m, 2));
+	if (x < g.X && cy < CY && (x & 3) == 0) blk[((size_t)cz * CY + cy) * CX + (x >> 2)] = m;
+}
+
+__global__ __launch_bounds__(256) void k_occupancy_dilate(int CX, int CY, int CZ, const float* __restrict__ blk, float* __restrict__ occ)
+{
 	const int c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= CX * CY * CZ) return;
 	const int cx = c % CX, cy = (c / CX) % CY, cz = c / (CX * CY);
+	const int x1 = min(cx + 1, CX - 1), y1 = min(cy + 1, CY - 1), z1 = min(cz + 1, CZ - 1);
 	float m = 0.0f;
-	for (int z = 4 * cz; z <= min(4 * cz + 4, g.Zg - 1); ++z)
-		for (int y = 4 * cy; y <= min(4 * cy + 4, g.Y - 1); ++y) {
-			const size_t row = ((size_t)z * g.Y + y) * g.X;
-			for (int x = 4 * cx; x <= min(4 * cx + 4, g.X - 1); ++x) m = fmaxf(m, ColTex<HALF>::ldw(col, row + x));
-		}
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		const int xx = (k & 1) ? x1 : cx, yy = (k & 2) ? y1 : cy, zz = (k & 4) ? z1 : cz;
+		m = fmaxf(m, blk[((size_t)zz * CY + yy) * CX + xx]);
+	}
 	occ[c] = m;
 }
 
+// occ: CX*CY*CZ floats, scratch: as many again
 hipError_t launch_occupancy(const Geom& g, int half_store, const void* color, float* occ, hipStream_t s)
 {
-	const int n = ((g.X + 3) >> 2) * ((g.Y + 3) >> 2) * ((g.Zg + 3) >> 2);
-	if (half_store) hipLaunchKernelGGL(k_occupancy<true>, dim3((n + 255) / 256), dim3(256), 0, s, g, (const h16x4*)color, occ);
-	else hipLaunchKernelGGL(k_occupancy<false>, dim3((n + 255) / 256), dim3(256), 0, s, g, (const float4*)color, occ);
+	const int CX = (g.X + 3) >> 2, CY = (g.Y + 3) >> 2, CZ = (g.Zg + 3) >> 2;
+	const int n = CX * CY * CZ;
+	float* blk = occ + n;
+	const dim3 grid((g.X + 63) / 64, (CY + 3) / 4, CZ), block(256);
+	if (half_store) hipLaunchKernelGGL(k_occupancy_blocks<true>, grid, block, 0, s, g, (const h16x4*)color, blk);
+	else hipLaunchKernelGGL(k_occupancy_blocks<false>, grid, block, 0, s, g, (const float4*)color, blk);
+	hipLaunchKernelGGL(k_occupancy_dilate, dim3((n + 255) / 256), dim3(256), 0, s, CX, CY, CZ, blk, occ);
 	return hipGetLastError();
 }
 
