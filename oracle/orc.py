@@ -12,7 +12,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "liborc.so")
-_SRCS = ["orc_sim.cpp", "orc_render.cpp", "orc_host.cpp", "orc_sh.cpp", "orc_common.h", "fx_oracle.h", "Makefile"]
+_SRCS = ["orc_sim.cpp", "orc_render.cpp", "orc_host.cpp", "orc_sh.cpp", "orc_resolve.cpp", "orc_bc6h.cpp", "orc_common.h", "fx_oracle.h",
+         "Makefile"]
 
 
 def build(force=False):
