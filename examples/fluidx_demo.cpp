@@ -77,6 +77,7 @@ int main(int argc, char** argv)
 		const float clearColor[4] = { 0.2f, 0.2f, 0.2f, 0.0f };                    // FluidX12.cpp:471-472
 		if (grid.z > 1) {
 			fluid.ClearRenderTarget(nullptr, clearColor);
+			if (radiance) probe.RenderEnvironment(fluid, nullptr, frameIndex);      // FluidX12.cpp:483: the sky first
 			fluid.Render(nullptr, frameIndex, Fluid::OPTIMIZED);                    // marches + renderCube onto the target
 		}
 		if (fluid.LastStatus() != FX_OK) { std::fprintf(stderr, "frame %u: %s\n", f, fx_error_string(fluid.LastStatus())); return 1; }

@@ -34,7 +34,7 @@ class Desc(C.Structure):
 class FrameInfo(C.Structure):
     _fields_ = [("cube_lod", C.c_uint32), ("cube_size", C.c_uint32), ("ray_samples", C.c_uint32),
                 ("visibility_mask", C.c_uint32), ("frame_parity", C.c_uint32), ("edge_pixels", C.c_float),
-                ("time_step", C.c_float), ("world_view_proj_i", C.c_float * 16)]
+                ("time_step", C.c_float), ("world_view_proj_i", C.c_float * 16), ("screen_to_world", C.c_float * 16)]
 
 
 class Timing(C.Structure):
@@ -66,6 +66,8 @@ SYMBOLS = {
     "fx_jacobi": (C.c_int, [_vp, _vp, C.c_uint32]),
     "fx_project": (C.c_int, [_vp, _vp]),
     "fx_sh_transform": (C.c_int, [_vp, _fp, C.c_uint32, _fp]),
+    "fx_set_environment": (C.c_int, [_vp, _fp, C.c_uint32]),
+    "fx_render_environment": (C.c_int, [_vp, _vp, C.c_uint8]),
     "fx_clear_render_target": (C.c_int, [_vp, _vp, _fp]),
     "fx_render_cube": (C.c_int, [_vp, _vp, C.c_uint8]),
     "fx_dds_cube_info": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

@@ -76,6 +76,7 @@ public:
 		m_status = fx_clear_render_target(m_ctx, pCommandList, clearColor);
 		m_hasTarget = m_status == FX_OK;
 	}
+	void UseRenderTarget() { m_hasTarget = true; }       // something (the sky pass) has drawn on the target: Render resolves onto it
 	// read the RGBA8 target back (the reference's screen-shot path reads the back buffer, FluidX12.cpp:640-660)
 	bool ReadRenderTarget(std::vector<uint8_t>& rgba)
 	{
@@ -122,6 +123,14 @@ public:
 		m_status = fx_dds_decode_cube(fluid.Handle(), dds.data(), dds.size(), mip, m_cube.data(), m_cube.size());
 		return m_status == FX_OK;
 	}
+	// LightProbe::RenderEnvironment (LightProbe.cpp:85-97): the radiance cube as the sky behind the volume.  The first call
+	// uploads the cube; draw it BEFORE Fluid::Render like the demo does (FluidX12.cpp:483)
+	void RenderEnvironment(Fluid& fluid, void* pCommandList, uint8_t frameIndex)
+	{
+		if (!m_envSet) { m_status = fx_set_environment(fluid.Handle(), m_cube.data(), m_n); m_envSet = m_status == FX_OK; }
+		if (m_envSet) m_status = fx_render_environment(fluid.Handle(), pCommandList, frameIndex);
+		fluid.UseRenderTarget();
+	}
 	void TransformSH(Fluid& fluid) { m_status = fx_sh_transform(fluid.Handle(), m_cube.data(), m_n, m_sh); }   // LightProbeEZ.cpp:117-123
 	const float* GetSH() const { return m_sh; }
 	int LastStatus() const { return m_status; }
@@ -130,6 +139,7 @@ private:
 	uint32_t m_n = 0;
 	float m_sh[27] = {};
 	int m_status = FX_OK;
+	bool m_envSet = false;
 };
 
 }  // namespace fluidx

@@ -104,7 +104,7 @@ void free_all(fx_ctx* c)
 		if (c->col[i]) (void)hipFree(c->col[i]);
 		if (c->p[i]) (void)hipFree(c->p[i]);
 	}
-	void* others[] = { c->occ, c->target, c->target_float, c->p_face[0], c->p_face[1], c->b, c->frozen, c->lightmap, c->cube, c->sh_dev, c->halo_overflow, c->stage,
+	void* others[] = { c->env, c->occ, c->target, c->target_float, c->p_face[0], c->p_face[1], c->b, c->frozen, c->lightmap, c->cube, c->sh_dev, c->halo_overflow, c->stage,
 		c->sh_scratch[0], c->sh_scratch[1], c->sh_scratch[2], c->sh_scratch[3] };
 	for (void* q : others) if (q) (void)hipFree(q);
 	for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -622,6 +622,9 @@ int fx_update_frame(fx_ctx* ctx, float time_step, uint8_t frame_index,
 			const Mat4 wvp = world * (Mat4::from(view) * Mat4::from(proj));
 			worldI.store3x4(c->fc.world_i);
 			world.store3x4(c->fc.world);
+			const Mat4 vpI = (Mat4::from(view) * Mat4::from(proj)).inverse();   // LightProbe::UpdateFrame (LightProbe.cpp:70-76)
+			for (int r = 0; r < 4; ++r)
+				for (int q = 0; q < 4; ++q) c->fc.s2w[r * 4 + q] = vpI.m[q][r];
 			const Mat4 wvpI = wvp.inverse();                                    // stored transposed (Fluid.cpp:318)
 			for (int r = 0; r < 4; ++r)
 				for (int q = 0; q < 4; ++q) c->fc.wvp_i[r * 4 + q] = wvpI.m[q][r];
@@ -802,6 +805,34 @@ int fx_render_cube(fx_ctx* ctx, void* stream, uint8_t frame_index)
 	return FX_OK;
 }
 
+int fx_set_environment(fx_ctx* ctx, const float* cube, uint32_t n)
+{
+	if (!ctx || (cube && (!n || n > 8192))) return FX_E_INVALID;
+	DeviceGuard dg(ctx->device);
+	FX_HIP(hipDeviceSynchronize());
+	if (ctx->env) { FX_HIP(hipFree(ctx->env)); ctx->env = nullptr; ctx->env_n = 0; }
+	if (!cube) return FX_OK;
+	const size_t bytes = (size_t)6 * n * n * 3 * sizeof(float);
+	FX_HIP(hipMalloc((void**)&ctx->env, bytes));
+	FX_HIP(hipMemcpy(ctx->env, cube, bytes, hipMemcpyHostToDevice));
+	ctx->env_n = n;
+	return FX_OK;
+}
+
+int fx_render_environment(fx_ctx* ctx, void* stream, uint8_t frame_index)
+{
+	if (!ctx || frame_index >= FX_FRAME_COUNT) return FX_E_INVALID;
+	if (!ctx->env || !ctx->view_valid) return FX_E_STATE;
+	DeviceGuard dg(ctx->device);
+	hipStream_t s = pick_stream(ctx, stream);
+	int rc = ensure_target(ctx, s);
+	if (rc) return rc;
+	ScopedMark mk(ctx, s, MK_RESOLVE);
+	FX_HIP(launch_environment(ctx->env, (int)ctx->env_n, ctx->fc, (int)ctx->desc.viewport_w, (int)ctx->desc.viewport_h,
+		ctx->target, ctx->target_float, s));
+	return FX_OK;
+}
+
 int fx_get_frame_info(fx_ctx* ctx, fx_frame_info* out)
 {
 	if (!ctx || !out) return FX_E_INVALID;
@@ -813,6 +844,7 @@ int fx_get_frame_info(fx_ctx* ctx, fx_frame_info* out)
 	out->edge_pixels = ctx->edge_pixels;
 	out->time_step = ctx->time_step;
 	std::memcpy(out->world_view_proj_i, ctx->fc.wvp_i, sizeof out->world_view_proj_i);
+	std::memcpy(out->screen_to_world, ctx->fc.s2w, sizeof out->screen_to_world);
 	return FX_OK;
 }
 

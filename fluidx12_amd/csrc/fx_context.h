@@ -27,6 +27,8 @@ struct fx_ctx {
 	uint32_t* lightmap;             // R11G11B10F packed (m_lightMap), owned planes only
 	uint8_t* cube;                  // RGBA8 cube map, 5 mips back to back (m_cubeMap)
 	size_t cube_mip_offset[5];
+	float* env;                     // radiance cube of the sky pass, float [6][env_n][env_n][3] (fx_set_environment)
+	uint32_t env_n;
 	float* occ;                     // occupancy grid of the ray marches: max alpha per 4^3 block (+1 voxel), rebuilt per fx_render
 	uint8_t* target;                // W x H RGBA8 render target of the cube resolve (lazily allocated)
 	float* target_float;            // the resolve's SV_TARGET before the output merger (parity tests; lazily allocated)

@@ -34,6 +34,7 @@ struct FrameConsts {
 	float light_color[4];
 	float ambient[4];
 	float wvp_i[16];       // CBPerObject.WorldViewProjI as its four constant-buffer rows (Fluid.cpp:318)
+	float s2w[16];         // LightProbe's ScreenToWorld = transpose(inverse(view * proj)) rows (LightProbe.cpp:70-76)
 };
 
 struct SimParams {
@@ -97,6 +98,8 @@ hipError_t launch_lightmap_decode(const uint32_t* lightmap, float* out, size_t n
 hipError_t launch_resolve_cube(const uint8_t* cube_mip, int N, const FrameConsts& fc, int W, int H, uint8_t* target,
 	float* out_float, hipStream_t s);
 hipError_t launch_clear_target(uint8_t* target, int W, int H, const float rgba[4], hipStream_t s);
+// sky pass (PSEnvironment): float radiance cube [6][n][n][3] on the device -> target (opaque write) and/or float4
+hipError_t launch_environment(const float* cube, int n, const FrameConsts& fc, int W, int H, uint8_t* target, float* out_float, hipStream_t s);
 
 // ---- BC6H_UF16 / DDS cube (fx_bc6h.hip; row f-4)
 hipError_t launch_bc6h_decode(const void* blocks_dev, int nbx, int nby, int n, float* out_dev, hipStream_t s);

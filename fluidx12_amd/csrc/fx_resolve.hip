@@ -219,6 +219,87 @@ __global__ __launch_bounds__(256) void k_resolve_cube(const uint32_t* __restrict
 	}
 }
 
+// sky pass: PSEnvironment.hlsl (LightProbe::RenderEnvironment, LightProbe.cpp:85-97).  pos = (x, y, 1, 1) * screenToWorld / w,
+// dir = normalize(eyePt - pos), the radiance cube (float3 texels, mip 0) sampled bilinearly at -dir with seamless edges;
+// the pass draws without blending: the target takes rgb and alpha 0.
+__global__ __launch_bounds__(256) void k_environment(const float* __restrict__ cube, int N, const FrameConsts fc, int W, int H,
+	uint32_t* __restrict__ target, float4* __restrict__ out_float)
+{
+	const int px = blockIdx.x * blockDim.x + threadIdx.x;
+	const int py = blockIdx.y * blockDim.y + threadIdx.y;
+	if (px >= W || py >= H) return;
+	const size_t pix = (size_t)py * W + px;
+	const float u = ((float)px + 0.5f) / (float)W, v = ((float)py + 0.5f) / (float)H;
+	const float qx = fmaf(u, 2.0f, -1.0f), qy = fmaf(v, -2.0f, 1.0f);
+	const float* M = fc.s2w;
+	float h[4];
+#pragma unroll
+	for (int r = 0; r < 4; ++r) h[r] = fmaf(1.0f, M[4 * r + 3], fmaf(1.0f, M[4 * r + 2], fmaf(qy, M[4 * r + 1], qx * M[4 * r + 0])));
+	float d[3];
+#pragma unroll
+	for (int a = 0; a < 3; ++a) d[a] = -(h[a] / h[3]) + fc.eye_pt[a];
+	const float inv = 1.0f / sqrtf(rdot3(d[0], d[1], d[2], d[0], d[1], d[2]));
+#pragma unroll
+	for (int a = 0; a < 3; ++a) d[a] = -(inv * d[a]);
+	int f;
+	{
+		const float ax = fabsf(d[0]), ay = fabsf(d[1]), az = fabsf(d[2]);
+		if (az >= ax && az >= ay) f = d[2] < 0.0f ? 5 : 4;
+		else if (ay >= ax) f = d[1] < 0.0f ? 3 : 2;
+		else f = d[0] < 0.0f ? 1 : 0;
+	}
+	float sc, tc;
+	face_coords(d, f, sc, tc);
+	const float ma = fabsf(d[f >> 1]);
+	const float tu = fmaf(0.5f * (sc / ma) + 0.5f, (float)N, -0.5f);
+	const float tv = fmaf(0.5f * (tc / ma) + 0.5f, (float)N, -0.5f);
+	const float flu = floorf(tu), flv = floorf(tv), fu = tu - flu, fv = tv - flv;
+	const int i0 = (int)flu, j0 = (int)flv;
+	float s[4][3];
+	int missing = -1;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const int ii = i0 + ((k == 1 || k == 2) ? 1 : 0), jj = j0 + (k < 2 ? 1 : 0);
+		const bool oi = ii < 0 || ii >= N, oj = jj < 0 || jj >= N;
+		if (oi && oj) { missing = k; s[k][0] = s[k][1] = s[k][2] = 0.0f; continue; }
+		int g = f, i2 = ii, j2 = jj;
+		if (oi || oj) {                                 // across one edge: the adjacent face's edge texel at the same place along it
+			const float se = ii < 0 ? -1.0f : ii >= N ? 1.0f : (2.0f * (float)ii + 1.0f) / (float)N - 1.0f;
+			const float te = jj < 0 ? -1.0f : jj >= N ? 1.0f : (2.0f * (float)jj + 1.0f) / (float)N - 1.0f;
+			float P[3];
+			face_point(P, f, se, te);
+#pragma unroll
+			for (int a = 0; a < 3; ++a)
+				if (a != (f >> 1) && fabsf(P[a]) == 1.0f) g = 2 * a + (P[a] < 0.0f ? 1 : 0);
+			float s2, t2;
+			face_coords(P, g, s2, t2);
+			i2 = min(max((int)floorf((0.5f * s2 + 0.5f) * (float)N), 0), N - 1);
+			j2 = min(max((int)floorf((0.5f * t2 + 0.5f) * (float)N), 0), N - 1);
+		}
+		const float* q = cube + (((size_t)g * N + j2) * N + i2) * 3;
+		s[k][0] = q[0]; s[k][1] = q[1]; s[k][2] = q[2];
+	}
+	if (missing >= 0) {
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			float acc = 0.0f;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) if (k != missing) acc += s[k][c];
+			const float m3 = acc / 3.0f;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) if (k == missing) s[k][c] = m3;
+		}
+	}
+	float o[3];
+#pragma unroll
+	for (int c = 0; c < 3; ++c) {
+		const float top = fmaf(fu, s[2][c] - s[3][c], s[3][c]), bot = fmaf(fu, s[1][c] - s[0][c], s[0][c]);
+		o[c] = fmaf(fv, bot - top, top);
+	}
+	if (out_float) out_float[pix] = make_float4(o[0], o[1], o[2], 0.0f);
+	if (target) target[pix] = unorm8(o[0]) | (unorm8(o[1]) << 8) | (unorm8(o[2]) << 16);
+}
+
 __global__ __launch_bounds__(256) void k_fill_u32(uint32_t* __restrict__ p, uint32_t v, size_t n)
 {
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
@@ -230,6 +311,13 @@ hipError_t launch_resolve_cube(const uint8_t* cube_mip, int N, const FrameConsts
 	const dim3 block(64, 4, 1), grid((W + 63) / 64, (H + 3) / 4, 1);
 	hipLaunchKernelGGL(k_resolve_cube, grid, block, 0, s, reinterpret_cast<const uint32_t*>(cube_mip), N, fc, W, H,
 		reinterpret_cast<uint32_t*>(target), reinterpret_cast<float4*>(out_float));
+	return hipGetLastError();
+}
+
+hipError_t launch_environment(const float* cube, int n, const FrameConsts& fc, int W, int H, uint8_t* target, float* out_float, hipStream_t s)
+{
+	const dim3 block(64, 4, 1), grid((W + 63) / 64, (H + 3) / 4, 1);
+	hipLaunchKernelGGL(k_environment, grid, block, 0, s, cube, n, fc, W, H, reinterpret_cast<uint32_t*>(target), reinterpret_cast<float4*>(out_float));
 	return hipGetLastError();
 }
 

@@ -156,6 +156,22 @@ class Fluid:
         c = (C.c_float * 4)(*[float(v) for v in rgba])
         capi.check(self._lib.fx_clear_render_target(self._ctx, stream, c), "ClearRenderTarget")
 
+    def SetEnvironment(self, radiance_cube):
+        """the radiance cube float[6][n][n][3] the sky pass draws (None releases it)"""
+        self._need()
+        if radiance_cube is None:
+            capi.check(self._lib.fx_set_environment(self._ctx, None, 0), "SetEnvironment")
+            return
+        a = np.ascontiguousarray(radiance_cube, np.float32)
+        if a.ndim != 4 or a.shape[0] != 6 or a.shape[1] != a.shape[2] or a.shape[3] != 3:
+            raise ValueError("radiance cube must be float[6][n][n][3]")
+        capi.check(self._lib.fx_set_environment(self._ctx, _fp(a), a.shape[1]), "SetEnvironment")
+
+    def RenderEnvironment(self, frameIndex=0, stream=None):
+        """LightProbe::RenderEnvironment (LightProbe.cpp:85-97): the sky onto the render target, before the volume"""
+        self._need()
+        capi.check(self._lib.fx_render_environment(self._ctx, stream, frameIndex), "RenderEnvironment")
+
     def RenderCube(self, frameIndex=0, stream=None):
         """Fluid::renderCube (Fluid.cpp:910-931), raster-free: PSRayCastCube per pixel + PREMULTIPLIED blend"""
         self._need()

@@ -103,6 +103,7 @@ typedef struct fx_frame_info {
 	float    edge_pixels;       /* EstimateCubeEdgePixelSize            */
 	float    time_step;
 	float    world_view_proj_i[16];  /* CBPerObject.WorldViewProjI as its 4 constant-buffer rows (Fluid.cpp:318; ABI 2) */
+	float    screen_to_world[16];    /* LightProbe CBPerFrame.ScreenToWorld rows (LightProbe.cpp:70-76; ABI 2)        */
 } fx_frame_info;
 
 /* HIP-event timings accumulated by fx_simulate / fx_render while enabled (milliseconds, launch counts) */
@@ -142,6 +143,13 @@ int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags);
  * the PREMULTIPLIED blend (Fluid.cpp:653).  Read the result with fx_download(FX_FIELD_TARGET). */
 int fx_clear_render_target(fx_ctx* ctx, void* stream, const float rgba[4]);
 int fx_render_cube(fx_ctx* ctx, void* stream, uint8_t frame_index);
+
+/* The light probe's sky pass (LightProbe::RenderEnvironment, LightProbe.cpp:85-97; PSEnvironment.hlsl), which the demo draws
+ * before the volume (FluidX12.cpp:483): fx_set_environment keeps a copy of the radiance cube float[6][n][n][3] on the device
+ * (NULL releases it), fx_render_environment writes it onto the render target as seen by the camera of the last
+ * fx_update_frame (no blending: rgb, alpha 0). */
+int fx_set_environment(fx_ctx* ctx, const float* cube, uint32_t n);
+int fx_render_environment(fx_ctx* ctx, void* stream, uint8_t frame_index);
 
 int fx_get_frame_info(fx_ctx* ctx, fx_frame_info* out);
 

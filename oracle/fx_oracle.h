@@ -70,6 +70,8 @@ void orc_unpack_r11g11b10(uint32_t v, float* rgb);
 void orc_world_view_proj_inverse(const float view[16], const float proj[16], float out16[16]);
 void orc_resolve_cube(const uint8_t* cube, int N, const orc_frame* fc, const float* wvp_i, int W, int H,
 	float* out_rgba, uint8_t* covered);
+// sky pass (PSEnvironment.hlsl): float radiance cube [6][N][N][3], world-space eye, screenToWorld rows -> float[H][W][4]
+void orc_environment(const float* cube, int N, const float eye[3], const float* s2w, int W, int H, float* out_rgba);
 // PREMULTIPLIED blend (Fluid.cpp:653) of a resolve result over an R8G8B8A8_UNORM target (FluidX12.cpp:31), in place
 void orc_blend_premultiplied(const float* src_rgba, const uint8_t* covered, uint8_t* target_rgba8, int W, int H);
 

@@ -63,6 +63,7 @@ def lib():
         _lib.orc_raymarch_view.argtypes = [fp, fp, i, i, i, C.POINTER(Frame), i, u, u, u, i, i, fp, u8p]
         _lib.orc_raycast_direct.argtypes = [fp, fp, i, i, i, C.POINTER(Frame), fp, i, i, u, u, i, i, fp, u8p]
         _lib.orc_visualize_color.argtypes = [fp, i, i, i, i, fp]
+        _lib.orc_environment.argtypes = [fp, i, fp, fp, i, i, fp]
         _lib.orc_bc6h_decode_block.argtypes = [u8p, C.POINTER(C.c_uint16)]
         _lib.orc_dds_bc6h_cube_face.argtypes = [u8p, C.c_size_t, i, i, fp, C.POINTER(C.c_int)]
         _lib.orc_world_view_proj_inverse.argtypes = [fp, fp, fp]
@@ -250,6 +251,14 @@ def dds_bc6h_cube(dds_bytes, mip=0):
             assert lib().orc_dds_bc6h_cube_face(buf.ctypes.data_as(u8), len(buf), f, mip, _fp(a), hist) == n
             faces.append(a)
     return np.stack(faces), np.array(list(hist))
+
+
+def environment(cube, eye, s2w, width, height):
+    """PSEnvironment per screen pixel: float cube [6][N][N][3] -> float[H][W][4] (rgb, alpha 0)"""
+    cube = _f32(cube)
+    out = np.empty((height, width, 4), np.float32)
+    lib().orc_environment(_fp(cube), cube.shape[1], _fp(_f32(eye)), _fp(_f32(s2w)), width, height, _fp(out))
+    return out
 
 
 def world_view_proj_inverse(view, proj):

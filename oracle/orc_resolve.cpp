@@ -229,4 +229,65 @@ void orc_blend_premultiplied(const float* src_rgba, const uint8_t* covered, uint
 	}
 }
 
+// ---------------------------------------------------------------------------------------------
+// PSEnvironment.hlsl (LightProbe::RenderEnvironment, LightProbe.cpp:70-97): the sky behind the volume.  Per pixel:
+// pos = (x, y, 1, 1) * screenToWorld, perspective divide, dir = normalize(eyePt - pos), sample the radiance cube at -dir
+// with level 0 (bilinear, seamless edges; float texels [6][N][N][3]).  s2w = the four constant-buffer rows of
+// transpose(inverse(view * proj)); out rgb + alpha 0.
+// ---------------------------------------------------------------------------------------------
+void orc_environment(const float* cube, int N, const float eye[3], const float* s2w, int W, int H, float* out_rgba)
+{
+#pragma omp parallel for schedule(static)
+	for (int py = 0; py < H; ++py)
+		for (int px = 0; px < W; ++px) {
+			const float u = ((float)px + 0.5f) / (float)W, v = ((float)py + 0.5f) / (float)H;
+			const float q[4] = { std::fmaf(u, 2.0f, -1.0f), std::fmaf(v, -2.0f, 1.0f), 1.0f, 1.0f };
+			float h[4];
+			for (int r = 0; r < 4; ++r) h[r] = dp4(q, s2w + 4 * r);
+			float d[3];
+			for (int a = 0; a < 3; ++a) d[a] = -(h[a] / h[3]) + eye[a];
+			const float inv = 1.0f / std::sqrt(dp3(d, d));
+			for (int a = 0; a < 3; ++a) d[a] = -(inv * d[a]);
+			// bilinear footprint of the float cube (same addressing rules as the RGBA8 cube map above)
+			const int f = major_face(d);
+			float sc, tc;
+			face_coords(d, f, sc, tc);
+			const float ma = std::fabs(d[f >> 1]);
+			const float tu = std::fmaf(0.5f * (sc / ma) + 0.5f, (float)N, -0.5f);
+			const float tv = std::fmaf(0.5f * (tc / ma) + 0.5f, (float)N, -0.5f);
+			const float flu = std::floor(tu), flv = std::floor(tv), fu = tu - flu, fv = tv - flv;
+			const int i0 = (int)flu, j0 = (int)flv;
+			const int ii[4] = { i0, i0 + 1, i0 + 1, i0 }, jj[4] = { j0 + 1, j0 + 1, j0, j0 };
+			float s[4][3];
+			int missing = -1;
+			for (int k = 0; k < 4; ++k) {
+				const bool oi = ii[k] < 0 || ii[k] >= N, oj = jj[k] < 0 || jj[k] >= N;
+				if (oi && oj) { missing = k; continue; }
+				int g = f, i2 = ii[k], j2 = jj[k];
+				if (oi || oj) {
+					const float se = ii[k] < 0 ? -1.0f : ii[k] >= N ? 1.0f : texel_centre(ii[k], N);
+					const float te = jj[k] < 0 ? -1.0f : jj[k] >= N ? 1.0f : texel_centre(jj[k], N);
+					float P[3];
+					face_point(P, f, se, te);
+					for (int a = 0; a < 3; ++a)
+						if (a != (f >> 1) && std::fabs(P[a]) == 1.0f) g = 2 * a + (P[a] < 0.0f ? 1 : 0);
+					float s2, t2;
+					face_coords(P, g, s2, t2);
+					i2 = std::min(std::max((int)std::floor((0.5f * s2 + 0.5f) * (float)N), 0), N - 1);
+					j2 = std::min(std::max((int)std::floor((0.5f * t2 + 0.5f) * (float)N), 0), N - 1);
+				}
+				for (int c = 0; c < 3; ++c) s[k][c] = cube[(((size_t)g * N + j2) * N + i2) * 3 + c];
+			}
+			if (missing >= 0)
+				for (int c = 0; c < 3; ++c) {
+					float acc = 0.0f;
+					for (int k = 0; k < 4; ++k) if (k != missing) acc += s[k][c];
+					s[missing][c] = acc / 3.0f;
+				}
+			float* o = out_rgba + ((size_t)py * W + px) * 4;
+			for (int c = 0; c < 3; ++c) o[c] = lerpf(lerpf(s[3][c], s[2][c], fu), lerpf(s[0][c], s[1][c], fu), fv);
+			o[3] = 0.0f;
+		}
+}
+
 }  // extern "C"

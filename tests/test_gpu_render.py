@@ -379,3 +379,33 @@ def test_empty_space_skipping_changes_no_bit(storage, use_sh, monkeypatch):
     assert a[1][..., 3].max() > 30 and a[4][..., 3].max() > 0.2
     for u, v in zip(a, b):
         assert np.array_equal(u.view(np.uint8), v.view(np.uint8))
+
+
+def test_environment_pass_equals_oracle():
+    """the light probe's sky pass (PSEnvironment) onto the render target: bit-identical to the oracle given the library's own
+    ScreenToWorld; then the volume composites over it exactly like over a cleared target"""
+    X, vp = 32, (200, 150)
+    rng = np.random.default_rng(9)
+    cube = (rng.random((6, 16, 16, 3)) ** 3 * 4.0).astype(f32)
+    f, fr, lod, rs, mask = setup(X, smoke_state(X, 8, seed=4), *vp)
+    view, proj, eye = fx.default_camera(*vp)
+    with pytest.raises(fx.FluidxError):
+        f.RenderEnvironment(0)                              # no cube yet
+    f.SetEnvironment(cube)
+    f.RenderEnvironment(0)
+    f.Synchronize()
+    fi = f.frame_info()
+    s2w = np.array(list(fi.screen_to_world), f32).reshape(4, 4)
+    want = orc.environment(cube, eye, s2w, *vp)
+    got = f.download(fx.FIELD_TARGET_FLOAT)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    sky8 = f.download(fx.FIELD_TARGET)
+    q = np.clip(want[..., :3], 0, 1)
+    assert np.array_equal(sky8[..., :3], np.floor(q * f32(255) + f32(0.5)).astype(np.uint8)) and not sky8[..., 3].any()
+    # the volume over the sky = the oracle's blend over the sky image
+    f.Render(0, fx.Fluid.OPTIMIZED, to_target=True)
+    f.Synchronize()
+    cube_map = f.download(fx.FIELD_CUBEMAP)
+    fr2, wvp_i = oracle_frame_of(f, view, proj, eye, X)
+    out, cov = orc.resolve_cube(cube_map, fr2, wvp_i, *vp)
+    assert np.array_equal(f.download(fx.FIELD_TARGET), orc.blend_premultiplied(out, cov, sky8))

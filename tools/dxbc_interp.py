@@ -240,9 +240,22 @@ class CubeSeamless:
     cube edge onto the adjacent face (geometric, no adjacency table); a texel off a corner is the mean of the other
     three."""
 
-    def __init__(self, cube_u8):
-        self.t = np.ascontiguousarray(cube_u8, np.uint8)
+    def __init__(self, cube):
+        """cube: uint8 [6][N][N][4] (RGBA8_UNORM) or float [6][N][N][3|4] (a float format such as the decoded BC6H radiance)"""
+        cube = np.asarray(cube)
+        if cube.dtype == np.uint8:
+            self.t = np.ascontiguousarray(cube, np.uint8)
+            self.scale = F32(255.0)
+        else:
+            c = np.ones(cube.shape[:3] + (4,), F32)
+            c[..., :cube.shape[3]] = cube.astype(F32)
+            self.t = c
+            self.scale = None
         self.N = self.t.shape[1]
+
+    def _fetch(self, f, j, i):
+        v = self.t[f, j, i].astype(F32)
+        return v / self.scale if self.scale is not None else v
 
     @property
     def dims(self):
@@ -279,7 +292,7 @@ class CubeSeamless:
         out = np.zeros((len(face), 4), F32)
         oi = (i < 0) | (i >= N); oj = (j < 0) | (j >= N)
         inside = ~oi & ~oj
-        out[inside] = self.t[face[inside], j[inside], i[inside]].astype(F32) / F32(255.0)
+        out[inside] = self._fetch(face[inside], j[inside], i[inside])
         edge = oi ^ oj
         if edge.any():
             f = face[edge]
@@ -297,7 +310,7 @@ class CubeSeamless:
             g, s2, t2, _ = self._select(P.astype(F32))
             i2 = np.clip(np.floor((s2 * F32(0.5) + F32(0.5)) * N).astype(np.int64), 0, N - 1)
             j2 = np.clip(np.floor((t2 * F32(0.5) + F32(0.5)) * N).astype(np.int64), 0, N - 1)
-            out[edge] = self.t[g, j2, i2].astype(F32) / F32(255.0)
+            out[edge] = self._fetch(g, j2, i2)
         corner = oi & oj
         out[corner] = np.nan
         return out, corner

@@ -271,6 +271,38 @@ def make_direct():
 
 
 # ---------------------------------------------------------------------------------------------------------
+# sky pass of the light probe: PSEnvironment.cso per screen pixel (LightProbe::RenderEnvironment, LightProbe.cpp:85-97)
+# ---------------------------------------------------------------------------------------------------------
+def make_environment():
+    """cbPerFrame = {eyePt, screenToWorld = transpose(inverse(view * proj))} (LightProbe.cpp:70-76) for the demo's default camera,
+    a random HDR float cube as g_txEnv; output = SV_TARGET (rgb, alpha 0)."""
+    eye = np.array([4.0, 16.0, -40.0])
+    z = -eye / np.linalg.norm(eye)
+    x = np.cross([0, 1.0, 0], z); x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    view = np.eye(4); view[:3, 0], view[:3, 1], view[:3, 2] = x, y, z
+    view[3, :3] = [-x @ eye, -y @ eye, -z @ eye]
+    vw, vh = 640, 480
+    h = 1.0 / np.tan(np.pi / 8); w = h / (vw / vh); q = 1000.0 / 999.0
+    proj = np.zeros((4, 4)); proj[0, 0], proj[1, 1], proj[2, 2], proj[2, 3], proj[3, 2] = w, h, q, 1.0, -q
+    cb = np.zeros((5, 4), F32)
+    cb[0, :3] = eye
+    cb[1:5] = np.linalg.inv(view @ proj).T.astype(F32)
+    rng = np.random.default_rng(21)
+    cube = (rng.random((6, 8, 8, 3)) ** 4 * 30.0).astype(F32)          # HDR-ish: mostly dim, a few bright texels
+    W, H = 128, 96
+    py, px = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    uv = np.zeros((H * W, 4), F32)
+    uv[:, 0] = ((px.ravel().astype(F32) + F32(0.5)) / F32(W)).astype(F32)
+    uv[:, 1] = ((py.ravel().astype(F32) + F32(0.5)) / F32(H)).astype(F32)
+    m = di.run_pixel_shader(os.path.join(BIN, "PSEnvironment.cso"), {1: uv}, {"t0": di.CubeSeamless(cube)}, {0: cb.view(U32)},
+                            {"s0": di.Sampler("WRAP")})
+    out = {"cube": cube, "cb": cb, "target": m.outputs[0].view(F32).reshape(H, W, 4).copy(), "params": np.array([W, H, vw, vh], np.int64)}
+    print("environment: target range %.3f .. %.3f, alpha max %.1f" % (out["target"][..., :3].min(), out["target"][..., :3].max(), out["target"][..., 3].max()))
+    np.savez_compressed(os.path.join(OUT, "dxbc_env.npz"), **out)
+
+
+# ---------------------------------------------------------------------------------------------------------
 # spherical harmonics
 # ---------------------------------------------------------------------------------------------------------
 def make_sh():
@@ -301,7 +333,7 @@ def make_sh():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sim", "render", "sh", "resolve", "direct"]
+    which = sys.argv[1:] or ["sim", "render", "sh", "resolve", "direct", "env"]
     if "sim" in which:
         make_sim()
     if "render" in which:
@@ -312,3 +344,5 @@ if __name__ == "__main__":
         make_resolve()
     if "direct" in which:
         make_direct()
+    if "env" in which:
+        make_environment()
