@@ -57,10 +57,11 @@ def workload_grid(G, N, scaling):
     """Grid of the N-rank run.  strong: the same G^3 for every N.  weak (default): 16.8 M voxels per GPU at G = 256 --
     the grid doubles along z, then along x and y, alternately: 1: G^3, 2: G x G x 2G, 4: 2G x 2G x G, 8: (2G)^3 (= BASELINE
     configs[3]'s 512^3 on 8 GPUs); other N stack along z.  Returns ((X, Y, Z), advect halo planes): the halo covers the
-    z back-trace reach measured with tools/reach_probe.py over 200 steps (9.9 / 2.3 / 4.4 cells for N = 2 / 4 / 8) + margin."""
+    z back-trace reach measured with tools/reach_probe.py over 600 steps (11.9 / 2.5 / 5.1 cells for N = 2 / 4 / 8; a reach r needs
+    floor(r) + 2 planes) + margin; a longer run that outgrows it stops with FX_E_HALO instead of computing something else."""
     if N == 1 or scaling == "strong":
         return (G, G, G), 0
-    table = {2: ((G, G, 2 * G), 14), 4: ((2 * G, 2 * G, G), 6), 8: ((2 * G, 2 * G, 2 * G), 8)}
+    table = {2: ((G, G, 2 * G), 16), 4: ((2 * G, 2 * G, G), 6), 8: ((2 * G, 2 * G, 2 * G), 8)}
     return table.get(N, ((G, G, G * N), 6 * N + 2))
 
 
