@@ -137,6 +137,10 @@ def main():
     ap.add_argument("--loopback", type=int, default=0,
                     help="run the N-rank code path (grid, slabs, halos, schedule selection) with N slab contexts in THIS process on "
                          "one GPU through the loop-back transport: a functional check of the multi-rank path, never a scaling number")
+    ap.add_argument("--shared-gpu", action="store_true",
+                    help="functional check only: all ranks of a torch.distributed.run launch use GPU 0 (torch.distributed over gloo; "
+                         "the product's RCCL calls must be redirected with FLUIDX_RCCL_LIB=tests/_build/libmockrccl.so, because "
+                         "RCCL refuses two ranks on one device); never a measurement, the JSON line says so")
     ap.add_argument("--dry-run", action="store_true",
                     help="distributed plumbing only (no GPU work); used by the gloo CPU tests, never a measurement")
     args = ap.parse_args()
@@ -158,8 +162,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.dry_run:
+        if args.dry_run or args.shared_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=N)
+            if args.shared_gpu:
+                local_rank = 0
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=N, device_id=torch.device("cuda", local_rank))
@@ -209,7 +215,7 @@ def main():
         if fluid is not None:
             fluid.Synchronize()
         if dist is not None:
-            if not args.dry_run:
+            if not (args.dry_run or args.shared_gpu):
                 import torch
                 torch.cuda.synchronize()
             dist.barrier()
@@ -219,7 +225,7 @@ def main():
             return seconds
         import torch
         t_ = torch.tensor([seconds], dtype=torch.float64)
-        if not args.dry_run:
+        if not (args.dry_run or args.shared_gpu):
             t_ = t_.cuda()
         dist.all_reduce(t_, op=dist.ReduceOp.MAX)      # identical on every rank afterwards
         return float(t_.item())
@@ -355,6 +361,9 @@ def main():
         }
         if args.dry_run:
             out["dry_run"] = True
+        if args.shared_gpu and N > 1:
+            out["shared_gpu"] = True
+            out["data"] = "synthetic; SHARED GPU: %d rank processes on ONE device (functional check of the one-process-per-GPU path, not a scaling measurement)" % N
         if timing is not None:
             out["stage_ms_per_step"] = {k: getattr(timing, k + "_ms") / max(timing.steps, 1)
                                         for k in ("advect", "divergence", "jacobi", "project", "exchange")}

@@ -194,6 +194,10 @@ int advect_range(fx_ctx* ctx, hipStream_t s, Range r, bool own_only)
 	const SimParams sp{ ctx->time_step, (int)ctx->desc.advect_address, ctx->g.Zg > 1 ? 1 : 0 };
 	const int par = ctx->frame_parity;
 	Geom g = ctx->g;
+	// only halo_advect planes per side were refreshed by EX_ADVECT_IN; the allocation may be wider (max with halo_jacobi), and
+	// a tap into those stale planes must count as "left the exchanged halo", not as present data
+	const int Ha = (int)ctx->desc.halo_advect;
+	g.zlo = std::max(g.zlo, g.z0 - Ha); g.zhi = std::min(g.zhi, g.z0 + g.nz - 1 + Ha);
 	if (own_only) { g.zlo = std::max(g.zlo, g.z0); g.zhi = std::min(g.zhi, g.z0 + g.nz - 1); }
 	FX_HIP(launch_advect(g, sp, ctx->half, ctx->vel[0], ctx->col[1 - par], ctx->vel[1], ctx->col[par],
 		r.lo, r.hi, ctx->halo_overflow, s));

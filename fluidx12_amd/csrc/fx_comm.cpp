@@ -120,8 +120,12 @@ static RcclApi* rccl(std::string* err)
 	if (tried) { if (err) *err = "librccl not available"; return nullptr; }
 	tried = true;
 	// a process that already imported torch has its bundled librccl loaded: the soname lookup reuses it
+	// FLUIDX_RCCL_LIB names one library explicitly (a site build of RCCL, or tests/mock_rccl's single-GPU stand-in) and
+	// is then the only candidate: a wrong path fails loudly instead of silently binding some other librccl.
+	const char* forced = std::getenv("FLUIDX_RCCL_LIB");
 	const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-	for (const char* n : names) {
+	if (forced && forced[0]) api.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+	else for (const char* n : names) {
 		api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
 		if (api.handle) break;
 	}

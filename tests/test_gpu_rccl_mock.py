@@ -1,0 +1,88 @@
+"""The one-process-per-GPU slab path (RcclTransport, fx_comm_init_rank, fx_comm_gather_color, bench.py under
+torch.distributed.run) on a ONE-GPU box: the rank processes share GPU 0 and the product's RCCL calls are bound, through
+FLUIDX_RCCL_LIB, to tests/mock_rccl (file rendezvous with RCCL's FIFO matching, byte-count checks and time-outs).
+What this pins: every rank issues the same exchange sequence under every schedule (a disagreement is an error here,
+a hang on real RCCL), and the result is bit-identical to the single-domain run.  It measures nothing."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+from test_dist_gloo import free_port
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mock_lib():
+    out = os.path.join(ROOT, "tests", "_build", "libmockrccl.so")
+    src = os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.run(["g++", "-O1", "-shared", "-fPIC", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-o", out,
+                        "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return out
+
+
+def launch(nranks, script_args, mock_lib, tmp_path, timeout=600):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", FLUIDX_RCCL_LIB=mock_lib,
+               FXMOCK_DIR=str(tmp_path), FXMOCK_TIMEOUT_S="120", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port())] + script_args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    leftovers = [n for n in os.listdir(tmp_path)]
+    shutil.rmtree(tmp_path, ignore_errors=True)
+    return r, leftovers
+
+
+@pytest.mark.parametrize("nranks,dims,halo_j,storage", [(2, "64x64x64", 8, "fp32"), (3, "64x64x96", 4, "fp32"),
+                                                       (4, "64x64x128", 8, "fp16")])
+def test_rank_processes_match_single_domain(nranks, dims, halo_j, storage, mock_lib, tmp_path):
+    r, leftovers = launch(nranks, [os.path.join(ROOT, "tests", "mp_slab_worker.py"), dims, "6", "16", str(halo_j), storage],
+                          mock_lib, tmp_path)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "OK %d ranks" % nranks in r.stdout
+    assert leftovers == [], leftovers                    # every message consumed, every communicator directory removed
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_bench_under_torchrun_shared_gpu(nranks, mock_lib, tmp_path):
+    r, _ = launch(nranks, [os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--grid", "64", "--steps", "3", "--warmup", "1",
+                           "--shared-gpu"], mock_lib, tmp_path)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == nranks and d["shared_gpu"] is True and d["value"] > 0
+    assert d["config"]["schedule"]["picked"].startswith("fastest") and len(d["config"]["schedule"]["candidates"]) == 4
+    assert "RCCL send/recv" in d["config"]["parallelism"] and d["roofline"]["achieved"] > 0
+
+
+def test_mock_flags_a_byte_count_mismatch(mock_lib, tmp_path):
+    """the checker checks: two ranks that disagree about a message size get an error, not a hang"""
+    code = r'''
+import ctypes as C, os, sys, torch, torch.distributed as dist
+rank = int(os.environ["RANK"]); dist.init_process_group("gloo", rank=rank, world_size=2)
+m = C.CDLL(os.environ["FLUIDX_RCCL_LIB"]); hip = C.CDLL("libamdhip64.so")
+uid = (C.c_char * 128)()
+if rank == 0: m.ncclGetUniqueId(uid)
+box = [bytes(uid)]; dist.broadcast_object_list(box, src=0); uid = (C.c_char * 128).from_buffer_copy(box[0])
+class Id(C.Structure): _fields_ = [("b", C.c_char * 128)]
+comm = C.c_void_p(); assert m.ncclCommInitRank(C.byref(comm), 2, Id(bytes(uid)), rank) == 0
+t = torch.zeros(64, dtype=torch.uint8, device="cuda")
+n = 64 if rank == 0 else 32
+m.ncclGroupStart()
+m.ncclSend(C.c_void_p(t.data_ptr()), C.c_size_t(n), 0, 1 - rank, comm, None)
+m.ncclRecv(C.c_void_p(t.data_ptr()), C.c_size_t(n), 0, 1 - rank, comm, None)
+rc = m.ncclGroupEnd()
+dist.barrier(); m.ncclCommDestroy(comm); dist.destroy_process_group()
+sys.exit(0 if rc != 0 else 3)
+'''
+    script = tmp_path.parent / "mock_mismatch.py"
+    script.write_text(code)
+    r, _ = launch(2, [str(script)], mock_lib, tmp_path, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])

@@ -118,6 +118,27 @@ def test_halo_overflow_is_reported():
     assert e.value.status == capi.FX_E_HALO
 
 
+def test_halo_overflow_counts_exchanged_planes_not_allocated_ones():
+    """the allocation is max(halo_advect, halo_jacobi) planes wide but only halo_advect planes are refreshed before the
+    advection: a 3-plane reach with halo_advect = 2, halo_jacobi = 8 reads stale planes and must be reported"""
+    dims = (32, 32, 32)
+    fl = []
+    for r in range(2):
+        f = fx.Fluid()
+        assert f.Init(800, 800, dims, slab=(r * 16, 16), halo_advect=2, halo_jacobi=8, jacobi_iters=8)
+        fl.append(f)
+    fx.comm_init_local(fl)
+    vel = np.zeros((3, 16, 32, 32), f32)
+    vel[2] = 1.5                                     # 1.5 * dt * Z = 3 cells of z reach: inside the allocation, outside the exchange
+    for f in fl:
+        f.upload(fx.FIELD_VELOCITY, vel)
+    fl[0].UpdateFrame(f32(2.0 / 32), 0)
+    fl[0].Simulate(0)
+    with pytest.raises(fx.FluidxError) as e:
+        fl[0].Synchronize()
+    assert e.value.status == capi.FX_E_HALO
+
+
 def test_rccl_transport_single_rank():
     """the RCCL transport on the one GPU we have: librccl is dlopen()ed, a unique id is created, ncclCommInitRank
     succeeds for a 1-rank world and a step runs through the same phase code (no neighbour => no send/recv)"""
