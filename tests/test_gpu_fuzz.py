@@ -1,0 +1,195 @@
+"""Seeded random-configuration parity tests: the hand-picked shapes of test_gpu_sim.py / test_gpu_slabs.py cover the
+cases the reference's defaults hit; these draw grid extents, storage, addressing, sweep counts / modes, fusion, slab cuts,
+halo widths and schedules at random (fixed seeds, so a failure reproduces) and hold the same bars:
+  * one full step from a random state: HIP vs oracle (bit-exact where no transcendental is on the path);
+  * random z-slab decompositions vs the single-domain HIP run: bit-identical."""
+import numpy as np
+import pytest
+
+import fluidx12_amd as fx
+from fluidx12_amd import capi
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    n = np.sqrt((b ** 2).sum())
+    d = np.sqrt(((a - b) ** 2).sum())
+    return d / n if n > 0 else d
+
+
+def draw_single(seed):
+    rng = np.random.default_rng(1000 + seed)
+    S = int(rng.choice([8, 12, 20, 24, 32, 36, 44, 52, 64, 72, 100, 128]))
+    Z = 1 if rng.random() < 0.2 else int(rng.integers(2, 41))
+    return dict(dims=(S, S, Z), storage=str(rng.choice(["fp32", "fp16"])), address=str(rng.choice(["clamp", "mirror"])),
+                mode=str(rng.choice(["fixed", "faithful"])), iters=int(rng.integers(1, 25)), fuse=int(rng.choice([0, 1, 2, 3, 4])),
+                scale=float(rng.choice([0.2, 1.0, 3.0])), rng=rng)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_step_matches_oracle(seed):
+    c = draw_single(seed)
+    X, Y, Z = c["dims"]
+    rng = c["rng"]
+    half = c["storage"] == "fp16"
+    vel = (rng.standard_normal((3, Z, Y, X)) * c["scale"]).astype(f32)
+    col = rng.random((Z, Y, X, 4)).astype(f32)
+    p0 = rng.standard_normal((Z, Y, X)).astype(f32)
+    if Z == 1:
+        vel[2] = 0
+    if half:                                               # the state must be storable
+        vel, col = vel.astype(np.float16).astype(f32), col.astype(np.float16).astype(f32)
+    f = fx.Fluid()
+    assert f.Init(800, 800, c["dims"], storage=c["storage"], advect_address=c["address"], jacobi_mode=c["mode"],
+                  jacobi_iters=c["iters"], jacobi_fuse=c["fuse"]), (c, f.last_status)
+    f.upload(fx.FIELD_VELOCITY, vel)
+    f.upload(fx.FIELD_COLOR, col)
+    f.upload(fx.FIELD_PRESSURE, p0)
+    s = orc.Sim(X, Y, Z, iters=c["iters"], mode=int(c["mode"] == "faithful"), address=int(c["address"] == "mirror"), half=half)
+    s.vel[0][:] = vel
+    s.col[s.parity][:] = col
+    s.p[:] = p0
+    dt = f32(f.default_time_step())
+    for k in range(2):
+        f.UpdateFrame(dt, k)
+        f.Simulate(k)
+        s.step()
+    f.Synchronize()
+    gv, gc, gp = f.download(fx.FIELD_VELOCITY), f.download(fx.FIELD_COLOR), f.download(fx.FIELD_PRESSURE)
+    tol = 2e-3 if half else 1e-5                           # half: an exp2 ulp can flip a stored rounding (2^-11 relative)
+    assert np.isfinite(gv).all() and np.isfinite(gc).all() and np.isfinite(gp).all(), c
+    assert rel_l2(gv, s.velocity) < tol, c
+    assert rel_l2(gc, s.color) < tol, c
+    assert rel_l2(gp, s.p) < tol, c
+    assert f.frame_info().frame_parity == s.parity
+    if half:
+        assert np.array_equal(gv.astype(np.float16).astype(f32), gv)
+
+
+def draw_slabs(seed):
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.integers(2, 5))
+    hj = int(rng.integers(1, 9))
+    ha = int(rng.integers(6, 13))
+    H = max(hj, ha)
+    # uneven cuts, every slab at least H planes (a halo may only span the direct neighbour)
+    sizes = [H + int(rng.integers(0, 20)) for _ in range(n)]
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    # X = Y >= Z keeps the z reach (|v_z| * dt * Z = 2 |v_z| Z / Y cells) inside the 6..12-plane advect halo for these few steps
+    S = max(32, (int(cuts[-1]) + 3) // 4 * 4)
+    if rng.random() < 0.5:
+        S = 1 << int(np.ceil(np.log2(S)))                 # power-of-two extents take the fast advect / strip Jacobi kernels
+    return dict(dims=(S, S, int(cuts[-1])), slabs=[(int(cuts[i]), int(sizes[i])) for i in range(n)], hj=hj, ha=ha,
+                storage=str(rng.choice(["fp32", "fp16"])), mode=str(rng.choice(["fixed", "fixed", "faithful"])),
+                iters=int(rng.integers(2, 21)), fuse=int(rng.choice([0, 1, 2, 3, 4])), overlap=int(rng.integers(0, 3)),
+                rnd=int(rng.integers(1, hj + 1)), steps=int(rng.integers(2, 5)))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_slab_decomposition_is_bit_identical(seed):
+    c = draw_slabs(seed)
+    kw = dict(storage=c["storage"], jacobi_mode=c["mode"], jacobi_iters=c["iters"])
+    ref = fx.Fluid()
+    assert ref.Init(800, 800, c["dims"], jacobi_fuse=1, **kw), (c, ref.last_status)
+    fl = []
+    for z0, nz in c["slabs"]:
+        f = fx.Fluid()
+        assert f.Init(800, 800, c["dims"], slab=(z0, nz), halo_advect=c["ha"], halo_jacobi=c["hj"], jacobi_fuse=c["fuse"], **kw), (c, f.last_status)
+        fl.append(f)
+    fx.comm_init_local(fl)
+    for f in fl:
+        f.set_option(capi.OPT_OVERLAP, c["overlap"])
+        f.set_option(capi.OPT_JACOBI_ROUND, c["rnd"])
+    dt = f32(ref.default_time_step())
+    for k in range(c["steps"]):
+        ref.UpdateFrame(dt, k % 3)
+        ref.Simulate(k % 3)
+        fl[0].UpdateFrame(dt, k % 3)
+        fl[0].Simulate(k % 3)
+    ref.Synchronize()
+    fl[0].Synchronize()                                   # raises FX_E_HALO if a back-trace left the exchanged planes
+    for field, axis in ((fx.FIELD_VELOCITY, 1), (fx.FIELD_COLOR, 0), (fx.FIELD_PRESSURE, 0)):
+        got = np.concatenate([f.download(field) for f in fl], axis=axis)
+        want = ref.download(field)
+        assert want.any(), c
+        assert np.array_equal(got, want), (c, field)
+
+
+# ---- random cameras / viewports / sample counts through every Render() mode ------------------------------------------------
+_STATE = {}
+
+
+def density(X):
+    if X not in _STATE:
+        s = orc.Sim(X, X, X, iters=20)
+        for _ in range(8):
+            s.step()
+        rng = np.random.default_rng(X)
+        z, y, x = np.meshgrid(*(np.arange(X),) * 3, indexing="ij")
+        blob = np.exp(-(((x - X * .55) ** 2 + (y - X * .5) ** 2 + (z - X * .45) ** 2) / (X * .22) ** 2)).astype(f32)
+        col = s.color + (blob[..., None] * rng.random((X, X, X, 4)) * np.array([.3, .5, .8, .6])).astype(f32)
+        _STATE[X] = np.clip(col, 0, 1).astype(f32)
+    return _STATE[X]
+
+
+def draw_camera(seed):
+    rng = np.random.default_rng(9000 + seed)
+    X = int(rng.choice([16, 24, 32]))
+    d = rng.standard_normal(3)
+    if rng.random() < 0.25:                                # straight down an axis: the degenerate cases of the face culling
+        d = np.eye(3)[int(rng.integers(0, 3))] * rng.choice([-1.0, 1.0]) + rng.standard_normal(3) * 1e-3
+    d /= np.linalg.norm(d)
+    eye = (d * rng.choice([6.0, 14.0, 25.0, 43.0, 90.0])).astype(f32)          # the volume is the cube |x| <= 10 (Fluid.cpp:171); 6 = an eye inside it
+    up = np.array([0, 1, 0], f32) if abs(d[1]) < 0.9 else np.array([0, 0, 1], f32)
+    focus = (rng.standard_normal(3) * 2.0).astype(f32)
+    vp = [(160, 120), (200, 150), (320, 200), (128, 256)][int(rng.integers(0, 4))]
+    flags = int(rng.choice([fx.Fluid.OPTIMIZED, fx.Fluid.RAY_MARCH_CUBEMAP, fx.Fluid.SEPARATE_LIGHT_PASS, fx.Fluid.RAY_MARCH_DIRECT]))
+    return dict(X=X, eye=eye, up=up, focus=focus, vp=vp, flags=flags, use_sh=bool(rng.random() < 0.4),
+                samples=(int(rng.choice([32, 48, 96, 192])), int(rng.choice([8, 16, 64]))),
+                fov=float(rng.choice([np.pi / 4, np.pi / 3, np.pi / 6])), rng=rng)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_camera_render_matches_oracle(seed):
+    c = draw_camera(seed)
+    X, (vw, vh), col = c["X"], c["vp"], density(c["X"])
+    view = fx.look_at_lh(c["eye"], c["focus"], c["up"])
+    proj = fx.perspective_fov_lh(f32(c["fov"]), vw / float(vh), 1.0, 1000.0)
+    sh = (c["rng"].random((9, 3)) * np.array([[2.0]] + [[0.5]] * 8)).astype(f32) if c["use_sh"] else None
+    f = fx.Fluid()
+    assert f.Init(vw, vh, (X, X, X))
+    f.SetMaxSamples(*c["samples"])
+    if sh is not None:
+        f.SetSH(sh)
+    f.upload(fx.FIELD_COLOR, col)
+    f.UpdateFrame(0.0, 0, view, proj, c["eye"])
+    fr, lod, rs, mask, _ = orc.update_frame(view, proj, c["eye"], vw, vh, X, c["samples"][0])
+    fi = f.frame_info()
+    assert (fi.cube_lod, fi.ray_samples, fi.visibility_mask) == (lod, rs, mask), c
+    if sh is not None:
+        for i, v in enumerate(sh.reshape(27)):
+            fr.sh[i] = v
+    nl = c["samples"][1]
+    separate = bool(c["flags"] & fx.Fluid.SEPARATE_LIGHT_PASS)
+    lm = orc.raymarch_light(col, fr, nl, c["use_sh"], 2) if separate else None
+    f.ClearRenderTarget()
+    f.Render(0, c["flags"])
+    f.Synchronize()
+    if c["flags"] & fx.Fluid.RAY_MARCH_CUBEMAP:
+        _, cu = orc.raymarch_view(col, lm, fr, X >> lod, mask, rs, nl, c["use_sh"], separate)
+        cube = f.download(fx.FIELD_CUBEMAP)
+        d = np.abs(cube.astype(np.int32) - cu.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() <= 0.02, (c, int(d.max()), float((d > 0).mean()))
+        assert cu[..., 3].max() > 20, c
+    else:
+        wvp_i = np.array(list(fi.world_view_proj_i), f32).reshape(4, 4)
+        out, cov = orc.raycast_direct(col, lm, fr, wvp_i, vw, vh, rs if separate else c["samples"][0], nl, c["use_sh"], separate)
+        got = f.download(fx.FIELD_TARGET_FLOAT)
+        if separate:
+            assert np.mean(got != out) < 5e-3 and np.abs(got - out).max() < 0.05, (c, float(np.mean(got != out)), float(np.abs(got - out).max()))
+        else:
+            assert np.mean(got != out) < 1e-4 and np.abs(got - out).max() < 1e-5, (c, float(np.mean(got != out)), float(np.abs(got - out).max()))
