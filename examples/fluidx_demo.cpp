@@ -2,7 +2,7 @@
 // OnUpdate's time-step rule (:266) and default camera (:243-253), PopulateCommandList's Simulate + Render
 // (:465,489-490), minus the window.  Build (after `python -m fluidx12_amd.build`):
 //   hipcc -std=c++17 examples/fluidx_demo.cpp -o fluidx_demo -Lfluidx12_amd -lfluidx_hip -Wl,-rpath,$PWD/fluidx12_amd
-// Usage: fluidx_demo [-gridSize X Y Z] [-maxRaySamples N] [-maxLightSamples N] [-radiance cube.dds] [-frames N] [-screenshot out.ppm]
+// Usage: fluidx_demo [-gridSize X Y Z] [-maxRaySamples N] [-maxLightSamples N] [-radiance cube.dds] [-frames N] [-screenshot out.ppm] [-resume in.fxck] [-checkpoint out.fxck]
 // (FluidX12.cpp:398-433; the screen shot replaces the stb_image_write path of FluidX12.cpp:640-660 with a binary PPM)
 #include "../fluidx12_amd/csrc/Fluid.hpp"
 #include <chrono>
@@ -42,6 +42,8 @@ int main(int argc, char** argv)
 	const uint32_t width = 800, height = 800;           // Main.cpp:17
 	const char* screenshot = nullptr;
 	const char* radiance = nullptr;                     // FluidGI.bat: -radiance Assets/rnl_cross.dds
+	const char* resume = nullptr;                       // not in the reference: continue from / leave behind a state file
+	const char* checkpoint = nullptr;
 	for (int i = 1; i < argc; ++i) {
 		if (!std::strcmp(argv[i], "-gridSize") && i + 3 < argc) { grid.x = atoi(argv[++i]); grid.y = atoi(argv[++i]); grid.z = atoi(argv[++i]); }
 		else if (!std::strcmp(argv[i], "-maxRaySamples") && i + 1 < argc) maxRay = atoi(argv[++i]);
@@ -49,6 +51,8 @@ int main(int argc, char** argv)
 		else if (!std::strcmp(argv[i], "-frames") && i + 1 < argc) frames = atoi(argv[++i]);
 		else if (!std::strcmp(argv[i], "-screenshot") && i + 1 < argc) screenshot = argv[++i];
 		else if (!std::strcmp(argv[i], "-radiance") && i + 1 < argc) radiance = argv[++i];
+		else if (!std::strcmp(argv[i], "-resume") && i + 1 < argc) resume = argv[++i];
+		else if (!std::strcmp(argv[i], "-checkpoint") && i + 1 < argc) checkpoint = argv[++i];
 	}
 	Fluid fluid;
 	if (!fluid.Init(nullptr, width, height, grid)) {   // ThrowIfFailed(E_FAIL) in the reference (FluidX12.cpp:198-200)
@@ -56,6 +60,7 @@ int main(int argc, char** argv)
 		return 1;
 	}
 	fluid.SetMaxSamples(maxRay, maxLight);
+	if (resume && !fluid.LoadCheckpoint(resume)) { std::fprintf(stderr, "cannot resume from %s: %s\n", resume, fx_error_string(fluid.LastStatus())); return 1; }
 	LightProbe probe;                                   // FluidX12.cpp:189-195, 205-210: load, TransformSH, SetSH
 	if (radiance) {
 		if (!probe.Init(fluid, radiance)) { std::fprintf(stderr, "cannot load %s as a BC6H_UF16 DDS cube map\n", radiance); return 1; }
@@ -83,6 +88,7 @@ int main(int argc, char** argv)
 		if (fluid.LastStatus() != FX_OK) { std::fprintf(stderr, "frame %u: %s\n", f, fx_error_string(fluid.LastStatus())); return 1; }
 	}
 	if (fx_synchronize(fluid.Handle()) != FX_OK) return 1;
+	if (checkpoint && !fluid.SaveCheckpoint(checkpoint)) { std::fprintf(stderr, "cannot write %s: %s\n", checkpoint, fx_error_string(fluid.LastStatus())); return 1; }
 	if (screenshot && grid.z > 1) {
 		std::vector<uint8_t> rgba;
 		if (!fluid.ReadRenderTarget(rgba)) { std::fprintf(stderr, "read-back failed\n"); return 1; }

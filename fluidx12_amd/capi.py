@@ -61,6 +61,8 @@ SYMBOLS = {
     "fx_upload": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
     "fx_download": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
     "fx_field_bytes": (C.c_size_t, [_vp, C.c_int]),
+    "fx_checkpoint_save": (C.c_int, [_vp, C.c_char_p]),
+    "fx_checkpoint_load": (C.c_int, [_vp, C.c_char_p]),
     "fx_advect": (C.c_int, [_vp, _vp]),
     "fx_divergence": (C.c_int, [_vp, _vp]),
     "fx_jacobi": (C.c_int, [_vp, _vp, C.c_uint32]),

@@ -86,6 +86,10 @@ public:
 		return m_status == FX_OK;
 	}
 
+	// not in the reference (its state dies with the window): whole-grid state files, see fx_checkpoint_save
+	bool SaveCheckpoint(const char* path) { m_status = fx_checkpoint_save(m_ctx, path); return m_status == FX_OK; }
+	bool LoadCheckpoint(const char* path) { m_status = fx_checkpoint_load(m_ctx, path); return m_status == FX_OK; }
+
 	// not in the reference: the void methods above cannot report failure there either (debug layer only)
 	int LastStatus() const { return m_status; }
 	fx_ctx* Handle() const { return m_ctx; }

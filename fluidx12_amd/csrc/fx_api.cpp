@@ -442,7 +442,7 @@ int simulate_impl(fx_ctx* ctx, hipStream_t s)
 			if (launch_copy_velocity(m->g, m->half, m->vel[1], m->vel[0], s) != hipSuccess) return FX_E_DEVICE;
 		}
 	}
-	for (fx_ctx* m : M) if (m->timing_on) m->acc.steps += 1;
+	for (fx_ctx* m : M) { if (m->timing_on) m->acc.steps += 1; if (ctx->time_step > 0.0f) m->steps_simulated += 1; }
 	return FX_OK;
 }
 

@@ -1,0 +1,117 @@
+// fx_checkpoint.cpp -- whole-grid state files ("field dump format for checkpoints").
+//
+// The reference has no checkpoint (its state dies with the window); what a later Fluid::Simulate depends on is exactly
+// m_velocities[0], m_colors[parity] and m_incompress (Fluid.cpp:360-384: advect reads velocity[0] and colour[!parity'] after
+// the parity flip, the Poisson solve warm-starts from the pressure).  One file holds those three fields of the WHOLE grid as
+// dense fp32 in the fx_download layouts, so any decomposition can write it (every slab context stores its own planes at
+// their offsets: ranks call fx_checkpoint_save on the same path concurrently) and any decomposition can resume from it.
+// fp16-storage contexts lose nothing: their stored halves convert to fp32 and back exactly.
+//
+//   offset 0   char[8]  "FXCKPT01"
+//          8   u32 X, Y, Z, storage (fx_storage of the writer, informational)
+//         24   u64 steps (simulated steps so far, from fx_get_step_count of the writer; informational)
+//         32   u32[8] reserved = 0
+//         64   float velocity[3][Z][Y][X] | float colour[Z][Y][X][4] | float pressure[Z][Y][X]
+#include "fx_context.h"
+
+#include <cerrno>
+#include <cstring>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace {
+
+struct Header { char magic[8]; uint32_t X, Y, Z, storage; uint64_t steps; uint32_t reserved[8]; };
+static_assert(sizeof(Header) == 64, "checkpoint header is 64 bytes");
+const char kMagic[8] = { 'F', 'X', 'C', 'K', 'P', 'T', '0', '1' };
+
+bool io_all(int fd, void* buf, size_t n, off_t off, bool write)
+{
+	char* p = static_cast<char*>(buf);
+	while (n) {
+		const ssize_t r = write ? pwrite(fd, p, n, off) : pread(fd, p, n, off);
+		if (r < 0 && errno == EINTR) continue;
+		if (r <= 0) return false;
+		p += r; n -= (size_t)r; off += r;
+	}
+	return true;
+}
+
+struct Layout { size_t plane, cells; off_t vel, col, prs, end; };
+Layout layout(uint32_t X, uint32_t Y, uint32_t Z)
+{
+	Layout l;
+	l.plane = (size_t)X * Y; l.cells = l.plane * Z;
+	l.vel = sizeof(Header); l.col = l.vel + (off_t)(3 * l.cells * 4); l.prs = l.col + (off_t)(4 * l.cells * 4); l.end = l.prs + (off_t)(l.cells * 4);
+	return l;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fx_checkpoint_save(fx_ctx* ctx, const char* path)
+{
+	if (!ctx || !path || !path[0]) return FX_E_INVALID;
+	if (ctx->desc.flags & FX_FLAG_RENDER_ONLY) return FX_E_STATE;
+	const uint32_t X = ctx->desc.grid_x, Y = ctx->desc.grid_y, Z = ctx->desc.grid_z;
+	const Layout l = layout(X, Y, Z);
+	const size_t z0 = (size_t)ctx->g.z0, nz = (size_t)ctx->g.nz, n = l.plane * nz;
+	std::vector<float> host(4 * n);
+	const int fd = open(path, O_RDWR | O_CREAT, 0644);                      // no O_TRUNC: the other slabs write the same file
+	if (fd < 0) { ctx->last_error = std::string("checkpoint: cannot open ") + path + ": " + std::strerror(errno); return FX_E_INVALID; }
+	int rc = FX_OK;
+	Header h{};
+	std::memcpy(h.magic, kMagic, 8);
+	h.X = X; h.Y = Y; h.Z = Z; h.storage = ctx->desc.storage; h.steps = ctx->steps_simulated;
+	bool ok = ftruncate(fd, l.end) == 0 && io_all(fd, &h, sizeof h, 0, true);   // every writer stores the identical header
+	if (ok && (rc = fx_download(ctx, FX_FIELD_VELOCITY, host.data(), 3 * n * 4)) == FX_OK)
+		for (int a = 0; a < 3 && ok; ++a)
+			ok = io_all(fd, host.data() + a * n, n * 4, l.vel + (off_t)(((size_t)a * l.cells + z0 * l.plane) * 4), true);
+	if (ok && rc == FX_OK && (rc = fx_download(ctx, FX_FIELD_COLOR, host.data(), 4 * n * 4)) == FX_OK)
+		ok = io_all(fd, host.data(), 4 * n * 4, l.col + (off_t)(z0 * l.plane * 16), true);
+	if (ok && rc == FX_OK && (rc = fx_download(ctx, FX_FIELD_PRESSURE, host.data(), n * 4)) == FX_OK)
+		ok = io_all(fd, host.data(), n * 4, l.prs + (off_t)(z0 * l.plane * 4), true);
+	if (ok && fsync(fd) != 0) ok = false;
+	close(fd);
+	if (rc != FX_OK) return rc;
+	if (!ok) { ctx->last_error = std::string("checkpoint: write failed: ") + std::strerror(errno); return FX_E_INVALID; }
+	return FX_OK;
+}
+
+int fx_checkpoint_load(fx_ctx* ctx, const char* path)
+{
+	if (!ctx || !path || !path[0]) return FX_E_INVALID;
+	if (ctx->desc.flags & FX_FLAG_RENDER_ONLY) return FX_E_STATE;
+	const int fd = open(path, O_RDONLY);
+	if (fd < 0) { ctx->last_error = std::string("checkpoint: cannot open ") + path + ": " + std::strerror(errno); return FX_E_INVALID; }
+	Header h{};
+	struct stat st{};
+	bool ok = io_all(fd, &h, sizeof h, 0, false) && fstat(fd, &st) == 0;
+	const Layout l = layout(h.X, h.Y, h.Z);
+	if (!ok || std::memcmp(h.magic, kMagic, 8) != 0 || h.X != ctx->desc.grid_x || h.Y != ctx->desc.grid_y || h.Z != ctx->desc.grid_z || st.st_size != l.end) {
+		close(fd);
+		ctx->last_error = "checkpoint: not a FXCKPT01 file of this grid (or truncated)";
+		return FX_E_INVALID;
+	}
+	const size_t z0 = (size_t)ctx->g.z0, nz = (size_t)ctx->g.nz, n = l.plane * nz;
+	std::vector<float> host(4 * n);
+	int rc = FX_OK;
+	for (int a = 0; a < 3 && ok; ++a)
+		ok = io_all(fd, host.data() + a * n, n * 4, l.vel + (off_t)(((size_t)a * l.cells + z0 * l.plane) * 4), false);
+	if (ok) rc = fx_upload(ctx, FX_FIELD_VELOCITY, host.data(), 3 * n * 4);
+	if (ok && rc == FX_OK && (ok = io_all(fd, host.data(), 4 * n * 4, l.col + (off_t)(z0 * l.plane * 16), false)))
+		rc = fx_upload(ctx, FX_FIELD_COLOR, host.data(), 4 * n * 4);
+	if (ok && rc == FX_OK && (ok = io_all(fd, host.data(), n * 4, l.prs + (off_t)(z0 * l.plane * 4), false)))
+		rc = fx_upload(ctx, FX_FIELD_PRESSURE, host.data(), n * 4);
+	close(fd);
+	if (rc != FX_OK) return rc;
+	if (!ok) { ctx->last_error = std::string("checkpoint: read failed: ") + std::strerror(errno); return FX_E_INVALID; }
+	ctx->steps_simulated = h.steps;
+	return FX_OK;
+}
+
+}  // extern "C"

@@ -63,6 +63,7 @@ struct fx_ctx {
 	int opt_overlap;                // FX_OPT_OVERLAP
 	int opt_round;                  // FX_OPT_JACOBI_ROUND
 	std::string last_error;
+	uint64_t steps_simulated = 0;   // fx_simulate calls with dt > 0 (recorded in checkpoints)
 };
 
 namespace fx {

@@ -9,6 +9,7 @@ are dropped; `CommandList*` becomes an optional HIP stream handle (int / None).
 This module only marshals: all arithmetic happens in libfluidx_hip.so.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -237,6 +238,16 @@ class Fluid:
         if a.shape != shape:
             raise ValueError("field %d expects shape %s, got %s" % (field, shape, a.shape))
         capi.check(self._lib.fx_upload(self._ctx, field, a.ctypes.data_as(C.c_void_p), a.nbytes), "upload")
+
+    def SaveCheckpoint(self, path):
+        """velocity[0], colour[parity] and pressure of this context's planes into the whole-grid file `path` (every slab
+        context of a chain saves to the same path); resuming from it continues bit-identically"""
+        self._need()
+        capi.check(self._lib.fx_checkpoint_save(self._ctx, os.fsencode(path)), "SaveCheckpoint")
+
+    def LoadCheckpoint(self, path):
+        self._need()
+        capi.check(self._lib.fx_checkpoint_load(self._ctx, os.fsencode(path)), "LoadCheckpoint")
 
     def timing_enable(self, on=True):
         capi.check(self._lib.fx_timing_enable(self._ctx, int(on)), "timing_enable")

@@ -162,6 +162,14 @@ int fx_upload(fx_ctx* ctx, int field, const void* host, size_t bytes);
 int fx_download(fx_ctx* ctx, int field, void* host, size_t bytes);
 size_t fx_field_bytes(fx_ctx* ctx, int field);
 
+/* Checkpoint / resume (the reference keeps no state across runs).  One file holds what a later
+ * fx_simulate depends on -- velocity[0], colour[parity], pressure (Fluid.cpp:360-384) -- for the WHOLE grid, dense fp32 in the
+ * layouts above behind a 64-byte header ("FXCKPT01", X, Y, Z, storage, step count).  Every slab context stores / loads its own
+ * planes at their offsets, so the ranks of a chain call these on the same path and a run may resume under another
+ * decomposition.  fp16-storage contexts round-trip exactly.  Resuming continues bit-identically to the uninterrupted run. */
+int fx_checkpoint_save(fx_ctx* ctx, const char* path);
+int fx_checkpoint_load(fx_ctx* ctx, const char* path);
+
 /* individual stages of Simulate, exposed for per-kernel parity tests and micro-benchmarks */
 int fx_advect(fx_ctx* ctx, void* stream);
 int fx_divergence(fx_ctx* ctx, void* stream);

@@ -290,3 +290,49 @@ def test_slabs_mirror_addressing(overlap):
     assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
     assert np.array_equal(gather(fl, fx.FIELD_COLOR, 0), ref.download(fx.FIELD_COLOR))
     assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
+
+
+def test_checkpoint_resume_is_bit_identical_across_decompositions(tmp_path):
+    """fx_checkpoint_save / _load: a run resumed from the state file equals the uninterrupted run bit for bit -- also when
+    the file was written by a 2-slab chain (both members into the same file) and is read by a 3-slab chain, and with
+    fp16 field storage (whose stored halves pass through the file's fp32 exactly)"""
+    dims = (64, 64, 72)
+    for storage in ("fp32", "fp16"):
+        kw = dict(storage=storage, jacobi_iters=12)
+        ref = run_single(dims, 9, **kw)                                  # uninterrupted
+        path = str(tmp_path / ("state_%s.fxck" % storage))
+        fl = run_slabs(dims, 5, 2, halo_jacobi=4, halo_advect=8, **kw)
+        for f in fl:
+            f.SaveCheckpoint(path)
+        hdr = np.fromfile(path, np.uint32, 8)
+        assert bytes(hdr[:2].tobytes()) == b"FXCKPT01" and tuple(hdr[2:5]) == dims and hdr[6] == 5
+        cells = dims[0] * dims[1] * dims[2]
+        assert (tmp_path / ("state_%s.fxck" % storage)).stat().st_size == 64 + 8 * cells * 4
+        # (a) single domain resumes
+        one = fx.Fluid()
+        assert one.Init(800, 800, dims, **kw)
+        one.LoadCheckpoint(path)
+        # (b) another decomposition resumes
+        three = []
+        for r in range(3):
+            f = fx.Fluid()
+            assert f.Init(800, 800, dims, slab=(r * 24, 24), halo_jacobi=3, halo_advect=8, **kw)
+            f.LoadCheckpoint(path)
+            three.append(f)
+        fx.comm_init_local(three)
+        for k in range(5, 9):                                            # frame indices continue; any index gives the same arithmetic
+            for drv in (one, three[0]):
+                drv.UpdateFrame(f32(drv.default_time_step()), k % 3)
+                drv.Simulate(k % 3)
+        one.Synchronize()
+        three[0].Synchronize()
+        for field, axis in ((fx.FIELD_VELOCITY, 1), (fx.FIELD_COLOR, 0), (fx.FIELD_PRESSURE, 0)):
+            want = ref.download(field)
+            assert want.any()
+            assert np.array_equal(one.download(field), want), (storage, field)
+            assert np.array_equal(gather(three, field, axis), want), (storage, field)
+    # a file of another grid is refused
+    other = fx.Fluid()
+    assert other.Init(800, 800, (32, 32, 32))
+    with pytest.raises(fx.FluidxError):
+        other.LoadCheckpoint(path)
