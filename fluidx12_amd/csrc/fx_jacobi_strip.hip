@@ -21,10 +21,27 @@ namespace {
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
+// x neighbours across lanes as DPP operand modifiers (wave_shr:1 / wave_shl:1 exist on the GFX9 family, which gfx950 is;
+// semantics checked on the device by tools/micro/dpp_test.cpp) instead of __shfl_up/__shfl_down, which compile to
+// ds_bpermute_b32: a trip through the LDS crossbar whose latency a one-wave-per-SIMD kernel cannot hide.  Lane 0 / lane 63
+// receive 0 and are overridden by the callers' edge rules.
+__device__ __forceinline__ float lane_up1(float v)   // lane i <- lane i - 1
+{
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_dn1(float v)   // lane i <- lane i + 1
+{
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+template <int N> __device__ __forceinline__ float row_dn(float v)   // lane i <- lane i + N inside its row of 16 lanes
+{
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
+}
+
 // one Jacobi update of a float4 column: ((((((L - b) + R) + U) + D) + F) + B) * (1/6)
 __device__ __forceinline__ float4 relax4(float4 c, float4 U, float4 D, float4 F, float4 Bk, float4 bb, bool x_first, bool x_last)
 {
-	float L = __shfl_up(c.w, 1), Rr = __shfl_down(c.x, 1);
+	float L = lane_up1(c.w), Rr = lane_dn1(c.x);
 	if (x_first) L = c.x;
 	if (x_last) Rr = c.w;
 	const float4 Lv = make_float4(L, c.x, c.y, c.z), Rv = make_float4(c.y, c.z, c.w, Rr);
@@ -259,8 +276,8 @@ __device__ __forceinline__ float4 relax4_lr(float4 c, float L, float Rr, float4 
 // relax both halves of one row: inputs are [2]-arrays (A, B)
 #define FX_RELAX_W(out, c, U, D, F, Bk, bb) do { \
 	const float4 cA = (c)[0], cB = (c)[1]; \
-	float LA = __shfl_up(cA.w, 1), RA = __shfl_down(cA.x, 1), LB = __shfl_up(cB.w, 1), RB = __shfl_down(cB.x, 1); \
-	const float midA = __shfl(cA.w, 63), midB = __shfl(cB.x, 0); \
+	float LA = lane_up1(cA.w), RA = lane_dn1(cA.x), LB = lane_up1(cB.w), RB = lane_dn1(cB.x); \
+	const float midA = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cA.w), 63)), midB = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cB.x), 0)); \
 	if (lane == 0) { LA = cA.x; LB = midA; } \
 	if (lane == 63) { RA = midB; RB = cB.w; } \
 	(out)[0] = relax4_lr(cA, LA, RA, (U)[0], (D)[0], (F)[0], (Bk)[0], (bb)[0]); \
@@ -360,6 +377,148 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip2w(const Geom g, const f
 #undef FX_STRIPW_STEP
 #undef FX_RELAX_W
 
+// ---------------------------------------------------------------------------------------------------------------
+// X = 512, second design: the row is cut in the middle and every wave runs the X = 256 recipe (R = 4 rows, one float4
+// per lane) on ONE half.  What the 256-wide kernel gets from the wall clamp at its outer lane, the half-row wave gets
+// from a "seam": the two columns just across the cut (s, the neighbour of the wave's edge cell, and t, the one
+// behind it).  The seam lives transposed in three scalar-sized window registers -- lane i < 8 holds row i of column s,
+// lane 8 + i row i of column t (one masked load instruction per plane for p, one for b) -- and the first sweep's value
+// of column s (needed by the second sweep's edge cell) is computed for the four strip rows in lanes 0..3 with the same
+// association order as relax4.  Edge-lane neighbours come out of those registers by v_readlane.  Cost over the 256-wide
+// kernel: two loads, a dozen lane reads and one scalar-width relax per z step; unlike k_jacobi_strip2w it keeps R = 4
+// (2.5 instead of 3 row updates per output row, 14 instead of 20 float4 loads per 4 x 256 outputs).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 relax4_edge(float4 c, float4 U, float4 D, float4 F, float4 Bk, float4 bb,
+	bool x_first, bool x_last, float edge_l, float edge_r)
+{
+	float L = lane_up1(c.w), Rr = lane_dn1(c.x);
+	if (x_first) L = edge_l;
+	if (x_last) Rr = edge_r;
+	const float4 Lv = make_float4(L, c.x, c.y, c.z), Rv = make_float4(c.y, c.z, c.w, Rr);
+	float4 x = add4(add4(add4(add4(add4(sub4(Lv, bb), Rv), U), D), F), Bk);
+	const float inv = __uint_as_float(0x3e2aaaabu);
+	x.x *= inv; x.y *= inv; x.z *= inv; x.w *= inv;
+	return x;
+}
+
+// lane value -> wave-uniform scalar
+#define FX_RL(v, l) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (v)), (l)))
+
+#define FX_STRIPH_STEP(PH) do { \
+	constexpr int NEW = (PH) % 3, CTR = ((PH) + 2) % 3, OLD = ((PH) + 1) % 3; \
+	_Pragma("unroll") for (int i = 0; i < R + 4; ++i) P0[NEW][i] = NP[i]; \
+	_Pragma("unroll") for (int i = 0; i < R + 2; ++i) Bq[NEW][i] = NB[i]; \
+	SP[NEW] = SNP; SB[NEW] = SNB; \
+	if (q == 0) { \
+		_Pragma("unroll") for (int i = 0; i < R + 4; ++i) P0[CTR][i] = NP[i]; \
+		SP[CTR] = SNP; \
+	} \
+	if (q + 1 <= q_load_last) { \
+		const size_t zo = (size_t)g.lz(q + 1) * plane; \
+		_Pragma("unroll") for (int i = 0; i < R + 4; ++i) NP[i] = *reinterpret_cast<const float4*>(p_in + zo + roff[i]); \
+		_Pragma("unroll") for (int i = 0; i < R + 2; ++i) NB[i] = *reinterpret_cast<const float4*>(b + zo + roff[i + 1]); \
+		if (lane < 16) SNP = p_in[zo + seam_off]; \
+		if (lane < 8) SNB = b[zo + seam_off]; \
+	} \
+	/* sweep 1, plane q-1 */ \
+	if (q - 1 == g.Zg) { \
+		_Pragma("unroll") for (int i = 0; i < R + 2; ++i) P1[NEW][i] = P1[CTR][i]; \
+		S1[NEW] = S1[CTR]; \
+	} else { \
+		/* column s of the first sweep, strip rows j = 0..R-1 in lanes 0..R-1 (row j = seam row j + 2) */ \
+		{ \
+			const float c = row_dn<2>(SP[CTR]), U = row_dn<1>(SP[CTR]), D = row_dn<3>(SP[CTR]); \
+			const float F = row_dn<2>(SP[OLD]), Bk = row_dn<2>(SP[NEW]), far = row_dn<10>(SP[CTR]); \
+			const float bb = row_dn<2>(SB[CTR]); \
+			float own = 0.0f;                       /* the wave's edge cell of the same row: x = 255 (.w of lane 63) or x = 256 (.x of lane 0) */ \
+			_Pragma("unroll") for (int j = 0; j < R; ++j) { \
+				const float e = right_half ? FX_RL(P0[CTR][j + 2].x, 0) : FX_RL(P0[CTR][j + 2].w, 63); \
+				if (lane == j) own = e; \
+			} \
+			const float Lc = right_half ? far : own, Rc = right_half ? own : far; \
+			S1[NEW] = ((((((Lc - bb) + Rc) + U) + D) + F) + Bk) * __uint_as_float(0x3e2aaaabu); \
+		} \
+		_Pragma("unroll") for (int i = 0; i < R + 2; ++i) { \
+			const float e = FX_RL(SP[CTR], i + 1); \
+			P1[NEW][i] = relax4_edge(P0[CTR][i + 1], P0[CTR][i], P0[CTR][i + 2], P0[OLD][i + 1], P0[NEW][i + 1], Bq[CTR][i], \
+				x_first, x_last, right_half ? e : P0[CTR][i + 1].x, right_half ? P0[CTR][i + 1].w : e); \
+		} \
+		if (q - 1 == 0) { \
+			_Pragma("unroll") for (int i = 0; i < R + 2; ++i) P1[CTR][i] = P1[NEW][i]; \
+			S1[CTR] = S1[NEW]; \
+		} \
+	} \
+	/* sweep 2, plane q-2 */ \
+	if (q - 2 >= zb && q - 2 < ze) { \
+		const size_t zo2 = (size_t)g.lz(q - 2) * plane; \
+		_Pragma("unroll") for (int j = 0; j < R; ++j) { \
+			const float4 c = P1[CTR][j + 1]; \
+			float4 U = P1[CTR][j], D = P1[CTR][j + 2]; \
+			if (j == 0 && y0 == 0) U = c; \
+			if (j == R - 1 && y0 + R >= g.Y) D = c; \
+			const float e = FX_RL(S1[CTR], j); \
+			const float4 x = relax4_edge(c, U, D, P1[OLD][j + 1], P1[NEW][j + 1], Bq[OLD][j + 1], x_first, x_last, \
+				right_half ? e : c.x, right_half ? c.w : e); \
+			if (strip_live) *reinterpret_cast<float4*>(p_out + zo2 + (size_t)(y0 + j) * g.X + xb + 4 * lane) = x; \
+		} \
+	} \
+} while (0)
+
+template <int R>
+__global__ __launch_bounds__(256, 1) void k_jacobi_strip2h(const Geom g, const float* __restrict__ p_in,
+	const float* __restrict__ b, float* __restrict__ p_out, int z_begin, int z_end, int zchunk, int ngroups, int nchunks, int remap)
+{
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: scalar branches on the half
+	const int tile = xcd_index(ngroups * nchunks, remap);
+	const int grp = tile % ngroups, chunk = tile / ngroups;
+	const int hs = grp * 4 + wave;                   // half-strip index: the two halves of a row strip are neighbours in a workgroup
+	const bool right_half = hs & 1;
+	const int y0 = (hs >> 1) * R;
+	const int xb = right_half ? 256 : 0;
+	const bool strip_live = y0 < g.Y;
+	const int zb = z_begin + chunk * zchunk, ze = min(zb + zchunk, z_end);
+	const int qs = max(zb - 2, g.zlo), q_last = ze - 1 + 2, q_load_last = min(q_last, g.zhi);
+	const bool x_first = lane == 0, x_last = lane == 63;
+	const size_t plane = g.plane();
+
+	size_t roff[R + 4];
+#pragma unroll
+	for (int i = 0; i < R + 4; ++i) roff[i] = (size_t)min(max(y0 - 2 + i, 0), g.Y - 1) * g.X + xb + 4 * lane;
+	// seam: lanes 0..7 = column s (first across the cut), lanes 8..15 = column t (second), row (lane & 7) of the R + 4 rows
+	const size_t seam_off = (size_t)min(max(y0 - 2 + (lane & 7), 0), g.Y - 1) * g.X + (right_half ? (lane < 8 ? 255 : 254) : (lane < 8 ? 256 : 257));
+
+	float4 P0[3][R + 4], P1[3][R + 2], Bq[3][R + 2], NP[R + 4], NB[R + 2];
+	float SP[3] = { 0.0f, 0.0f, 0.0f }, SB[3] = { 0.0f, 0.0f, 0.0f }, S1[3] = { 0.0f, 0.0f, 0.0f }, SNP = 0.0f, SNB = 0.0f;
+	const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+#pragma unroll
+		for (int i = 0; i < R + 4; ++i) P0[k][i] = zero;
+#pragma unroll
+		for (int i = 0; i < R + 2; ++i) { P1[k][i] = zero; Bq[k][i] = zero; }
+	}
+	{
+		const size_t zo = (size_t)g.lz(min(qs, q_load_last)) * plane;
+#pragma unroll
+		for (int i = 0; i < R + 4; ++i) NP[i] = *reinterpret_cast<const float4*>(p_in + zo + roff[i]);
+#pragma unroll
+		for (int i = 0; i < R + 2; ++i) NB[i] = *reinterpret_cast<const float4*>(b + zo + roff[i + 1]);
+		if (lane < 16) SNP = p_in[zo + seam_off];
+		if (lane < 8) SNB = b[zo + seam_off];
+	}
+	int q = qs;
+	for (;;) {
+		FX_STRIPH_STEP(0);
+		if (++q > q_last) break;
+		FX_STRIPH_STEP(1);
+		if (++q > q_last) break;
+		FX_STRIPH_STEP(2);
+		if (++q > q_last) break;
+	}
+}
+#undef FX_STRIPH_STEP
+#undef FX_RL
+
 int env_i(const char* n, int d) { const char* v = getenv(n); return v && *v ? atoi(v) : d; }
 
 }  // namespace
@@ -382,10 +541,14 @@ hipError_t launch_jacobi_strip(const Geom& g, const float* p_in, const float* b,
 	static const int Rsel = env_i("FLUIDX_STRIP_R", 0);
 	const bool wide = jacobi_strip_wide(g);
 	if (wide && sweeps != 2) return hipErrorNotSupported;
-	const int rows = wide ? 2 : (Rsel == 2 || Rsel == 4 ? Rsel : (sweeps == 3 ? 2 : 4));
+	// X = 512: half-row waves with a seam (k_jacobi_strip2h, R = 4) unless Y % 4 != 0 or FLUIDX_STRIP_WIDE=1 asks for the
+	// two-float4-per-lane kernel (k_jacobi_strip2w, R = 2): the A/B switch of DESIGN.md section 6
+	static const int force_w = env_i("FLUIDX_STRIP_WIDE", 0);
+	const bool halves = wide && (g.Y & 3) == 0 && !force_w;
+	const int rows = halves ? 4 : wide ? 2 : (Rsel == 2 || Rsel == 4 ? Rsel : (sweeps == 3 ? 2 : 4));
 	const int R = rows;
 	const int LX = g.X >> 2, SPW = wide ? 1 : 64 / LX;
-	const int nstrips = (g.Y + R - 1) / R;
+	const int nstrips = ((g.Y + R - 1) / R) * (halves ? 2 : 1);
 	const int ngroups = (nstrips + 4 * SPW - 1) / (4 * SPW);            // 4 waves per workgroup
 	const int nzp = z_end - z_begin;
 	static const int wg_target = env_i("FLUIDX_STRIP_WGS", 256);
@@ -397,7 +560,9 @@ hipError_t launch_jacobi_strip(const Geom& g, const float* p_in, const float* b,
 	const dim3 grid(ngroups * nchunks), block(256);
 #define FX_STRIP(T_, R_) hipLaunchKernelGGL((k_jacobi_strip<T_, R_>), grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap)
 	static const int generic = env_i("FLUIDX_STRIP_GENERIC", 0);
-	if (wide)
+	if (halves)
+		hipLaunchKernelGGL(k_jacobi_strip2h<4>, grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
+	else if (wide)
 		hipLaunchKernelGGL(k_jacobi_strip2w<2>, grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
 	else if (sweeps == 2 && R == 4 && (g.Y & 3) == 0 && !generic)
 		hipLaunchKernelGGL((k_jacobi_strip2u<4, 1>), grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);

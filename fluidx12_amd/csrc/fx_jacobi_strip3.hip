@@ -40,10 +40,12 @@ namespace {
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
-// ((((((L - b) + R) + U) + D) + F) + B) * (1/6) on a float4 column; x neighbours by wave shuffle
+// ((((((L - b) + R) + U) + D) + F) + B) * (1/6) on a float4 column; x neighbours by DPP wave shifts
 __device__ __forceinline__ float4 relax4(float4 c, float4 U, float4 D, float4 F, float4 Bk, float4 bb, bool x_first, bool x_last)
 {
-	float L = __shfl_up(c.w, 1), Rr = __shfl_down(c.x, 1);
+	// DPP wave_shr:1 / wave_shl:1 instead of __shfl_up/_down (= ds_bpermute): see fx_jacobi_strip.hip
+	float L = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c.w), 0x138, 0xf, 0xf, false));
+	float Rr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c.x), 0x130, 0xf, 0xf, false));
 	if (x_first) L = c.x;
 	if (x_last) Rr = c.w;
 	const float4 Lv = make_float4(L, c.x, c.y, c.z), Rv = make_float4(c.y, c.z, c.w, Rr);

@@ -790,16 +790,14 @@ static bool tb_supported(const Geom& g)
 	return g.Zg > 1 && (g.X & 3) == 0 && (LX == 16 || LX == 32 || LX == 64) && g.Y >= 16;
 }
 
-// the strip kernel needs ~256 workgroups of >= 16 planes each to beat the one-sweep kernel: measured on MI355X,
-// 256^3 wins (20 vs 30 us/sweep) while 128^3 and the 256x256x{32,64} slabs lose (profiles/r01c_jacobi_strip.txt)
+// where two sweeps per launch (register strips) beat one: measured on MI355X with the DPP lane shifts in place
+// (us per sweep, one / two sweeps per launch): 256^3 30 / 17.8, 512x512x64 41 / 18.9, 512x512x32 21.8 / 12.0, 512x512x16
+// 12.5 / 9.9, 256x256x64 10.0 / 9.0 -- but 256x256x32 6.2 / 8.2, 128^3 5.7 / 7.6, 128x128x32 3.3 / 7.8, 64^3 2.8 / 7.3: below
+// ~4 M cells a launch is too short for 8-plane z chunks to fill the chip
 static bool strip_profitable(const Geom& g, int nzp)
 {
 	if (!jacobi_strip_supported(g)) return false;
-	const bool wide = jacobi_strip_wide(g);
-	const int SPW = wide ? 1 : 64 / (g.X >> 2), R = wide ? 2 : 4;
-	const int ngroups = ((g.Y + R - 1) / R + 4 * SPW - 1) / (4 * SPW);
-	const int nchunks = (256 + ngroups - 1) / ngroups;
-	return nzp / nchunks >= 16;
+	return (size_t)g.X * g.Y * (size_t)nzp >= ((size_t)7 << 19);           // 3.5 M cells
 }
 
 int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp)
