@@ -473,8 +473,13 @@ __global__ __launch_bounds__(256) void k_jacobi_v4(const Geom g, const float* __
 	const float4 F = *reinterpret_cast<const float4*>(p_in + (size_t)g.lz(zf) * plane + (size_t)y * g.X + 4 * x4);
 	const float4 B = *reinterpret_cast<const float4*>(p_in + (size_t)g.lz(zb) * plane + (size_t)y * g.X + 4 * x4);
 	const float4 bb = *reinterpret_cast<const float4*>(b + c_off);
-	const float L = x4 > 0 ? p_in[c_off - 1] : c.x;
-	const float R = x4 < X4 - 1 ? p_in[c_off + 4] : c.w;
+	// x neighbours: the adjacent float4 column sits in the adjacent lane (DPP wave_shr:1 / wave_shl:1, see fx_jacobi_strip.hip);
+	// only a wave's first / last lane inside a row (X > 256, or the tail of a partial wave) still loads them
+	const int wl = (int)((threadIdx.y * blockDim.x + threadIdx.x) & 63);
+	float L = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c.w), 0x138, 0xf, 0xf, false));
+	float R = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c.x), 0x130, 0xf, 0xf, false));
+	if (x4 == 0) L = c.x; else if (wl == 0 || lane == 0) L = p_in[c_off - 1];
+	if (x4 == X4 - 1) R = c.w; else if (wl == 63 || lane == (int)blockDim.x - 1) R = p_in[c_off + 4];
 	const float inv = __uint_as_float(0x3e2aaaabu);
 	float4 o;
 	o.x = ((((((L - bb.x) + c.y) + U.x) + D.x) + F.x) + B.x) * inv;
