@@ -30,6 +30,15 @@
 // serialise with the prefetch (33 us per sweep).  A third input slot in the LDS would fix it and does not fit: 48 rows
 // against the 40 a wave can have.  So this kernel serves jacobi_fuse = 3 (23 us -> 19.2 us against the all-register
 // version) and the default stays at two sweeps.
+//
+// Later in round 1 the x-neighbour shuffles (ds_bpermute) became DPP wave shifts: 19.2 -> 17.3 us per sweep, level with
+// the two-sweep kernel's 17.8.  The double-buffered variant was tried again on top of that (two register buffers for
+// the plane in flight alternating by step parity, z loop unrolled by six, loads issued at the top of the step): it
+// compiles without scratch (436 VGPR + AGPR) and is bit-exact, but runs 21.2 us per sweep -- the allocator parks the
+// buffer that is live across the whole step in AGPRs, loads into VGPRs and copies over, so an `s_waitcnt vmcnt` lands
+// directly behind the loads (1542 v_accvgpr moves per six steps against 240 per three here) and the prefetch distance
+// is gone.  Getting the distance back needs loads that target AGPRs directly or land in the LDS
+// (global_load_lds_dwordx4) with a fourth input slot, which the 160 KiB do not have at R = 4.
 #include "fx_internal.h"
 #include <cstdlib>
 
