@@ -37,7 +37,7 @@ struct DeviceGuard {
 };
 
 // ---- timing ---------------------------------------------------------------------------------
-enum MarkKind { MK_ADVECT, MK_DIV, MK_JACOBI, MK_PROJECT, MK_LIGHT, MK_VIEW, MK_EXCH, MK_RESOLVE };
+enum MarkKind { MK_ADVECT, MK_DIV, MK_JACOBI, MK_PROJECT, MK_LIGHT, MK_VIEW, MK_EXCH, MK_RESOLVE, MK_JACOBI_TAIL };
 
 size_t ev_record(fx_ctx* c, hipStream_t s)
 {
@@ -55,6 +55,15 @@ struct ScopedMark {
 	ScopedMark(fx_ctx* c_, hipStream_t s_, int kind_) : c(c_), s(s_), kind(kind_), e0((size_t)-1), launches(0), sweeps(0)
 	{
 		if (c->timing_on) e0 = ev_record(c, s);
+	}
+	// close the mark here and continue as `new_kind` from the same event (one event more, no gap)
+	void split(int new_kind)
+	{
+		if (c->timing_on && e0 != (size_t)-1) {
+			const size_t e1 = ev_record(c, s);
+			if (e1 != (size_t)-1) { c->marks.push_back(fx_ctx::Mark{ kind, e0, e1, launches, sweeps }); e0 = e1; }
+		}
+		kind = new_kind; launches = 0; sweeps = 0;
 	}
 	~ScopedMark()
 	{
@@ -74,7 +83,9 @@ int drain_timing(fx_ctx* c)
 		switch (m.kind) {
 		case MK_ADVECT: c->acc.advect_ms += ms; break;
 		case MK_DIV: c->acc.divergence_ms += ms; break;
-		case MK_JACOBI: c->acc.jacobi_ms += ms; c->acc.jacobi_launches += m.launches; c->acc.jacobi_sweeps += m.sweeps; break;
+		case MK_JACOBI: c->acc.jacobi_ms += ms; c->acc.jacobi_launches += m.launches; c->acc.jacobi_sweeps += m.sweeps;
+			c->acc.jacobi_main_ms += ms; c->acc.jacobi_main_launches += m.launches; c->acc.jacobi_main_sweeps += m.sweeps; break;
+		case MK_JACOBI_TAIL: c->acc.jacobi_ms += ms; c->acc.jacobi_launches += m.launches; c->acc.jacobi_sweeps += m.sweeps; break;
 		case MK_PROJECT: c->acc.project_ms += ms; break;
 		case MK_LIGHT: c->acc.light_ms += ms; break;
 		case MK_VIEW: c->acc.view_ms += ms; break;
@@ -270,7 +281,10 @@ int jacobi_round(fx_ctx* ctx, hipStream_t s, int count, ScopedMark* mk)
 	int done = 0;
 	while (done < count) {
 		const int left = count - done;
-		const int t = std::min(left, fused_sweeps(ctx));
+		int t = std::min(left, fused_sweeps(ctx));
+		if (!multi_rank(ctx) && !ctx->frozen && jacobi_prefers_three(ctx->g, (int)(ctx->desc.flags & FX_FLAG_JACOBI_FUSE_MASK), ctx->g.nz))
+			t = left == 4 ? 2 : std::min(left, 3);           // threes, and a remainder of 4 as 2 + 2 rather than 3 + 1
+		if (mk && mk->kind == MK_JACOBI && mk->launches && t * mk->launches < mk->sweeps) mk->split(MK_JACOBI_TAIL);   // shorter launches from here on
 		const int rc = jacobi_launch(ctx, s, ctx->p_cur, t, grown(ctx, multi_rank(ctx) ? left - t : 0), mk);
 		if (rc) return rc;
 		ctx->p_cur ^= 1;

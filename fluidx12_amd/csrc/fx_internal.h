@@ -68,6 +68,7 @@ bool jacobi_strip3_supported(const Geom& g);
 hipError_t launch_jacobi_strip3(const Geom& g, const float* p_in, const float* b, float* p_out, int z_begin, int z_end, hipStream_t s);
 // sweeps fused per launch for this geometry (1 = no fused path); requested > 0 overrides the default
 int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp);
+bool jacobi_prefers_three(const Geom& g, int requested, int nzp);
 hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const float* p,
 	void* vel_out, int z_begin, int z_end, hipStream_t s);
 hipError_t launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t s);   // device-to-device, as a kernel

@@ -820,6 +820,20 @@ int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp)
 	return t < 1 ? 1 : (t > 4 ? 4 : t);
 }
 
+// Single-domain default schedule: THREE sweeps per launch (k_jacobi_strip3) where that kernel exists and the grid is large
+// enough, the remainder as two-sweep launches (40 = 12 x 3 + 2 x 2).  Measured 256^3: Jacobi stage of the bench 0.664 ms
+// against 0.714 ms in twos (15.0 against 14.3 G voxel-updates/s).  FLUIDX_JACOBI_PREFER3=0 keeps two sweeps per launch throughout; an explicit jacobi_fuse / FLUIDX_JACOBI_T
+// request is always honoured as given.
+bool jacobi_prefers_three(const Geom& g, int requested, int nzp)
+{
+	static const int forced = env_int("FLUIDX_JACOBI_T", 0);
+	static const int prefer = env_int("FLUIDX_JACOBI_PREFER3", 1);
+	static const int no_lds3 = env_int("FLUIDX_STRIP3_OFF", 0);
+	static const int use_tb = env_int("FLUIDX_FUSE2_TB", 0);
+	return prefer && !requested && !forced && !no_lds3 && !use_tb && jacobi_strip3_supported(g) &&
+		(size_t)g.X * g.Y * (size_t)nzp >= ((size_t)3 << 22);           // 12.6 M cells: 256x256x128 still loses (11.3 against 11.0 us per sweep)
+}
+
 // tile geometry of the fused kernel: TY rows per workgroup (threads = X/4 * TY), D input planes in flight
 struct TbConfig { int T, TY, D, zchunk; };
 

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 2
+#define FX_ABI_VERSION 3
 
 enum fx_status {
 	FX_OK = 0,
@@ -111,6 +111,10 @@ typedef struct fx_timing {
 	double   advect_ms, divergence_ms, jacobi_ms, project_ms, light_ms, view_ms, exchange_ms;
 	uint64_t steps, jacobi_launches, jacobi_sweeps, renders;
 	double   resolve_ms;        /* fx_render_cube (ABI 2) */
+	/* ABI 3: when a step mixes launch shapes (40 sweeps = 12 launches of three + 2 of two), the launches with the most
+	 * sweeps each -- the dominant kernel -- are also booked on their own; otherwise these equal the jacobi_* totals */
+	double   jacobi_main_ms;
+	uint64_t jacobi_main_launches, jacobi_main_sweeps;
 } fx_timing;
 
 int fx_abi_version(void);
