@@ -39,6 +39,15 @@
 // directly behind the loads (1542 v_accvgpr moves per six steps against 240 per three here) and the prefetch distance
 // is gone.  Getting the distance back needs loads that target AGPRs directly or land in the LDS
 // (global_load_lds_dwordx4) with a fourth input slot, which the 160 KiB do not have at R = 4.
+// The first of those was tried too: inline-assembly loads straight into accumulator registers ("+a" operands, one
+// s_waitcnt that takes every in-flight register as an in/out operand, AGPR -> VGPR moves at the top of the next step).
+// The ISA came out as intended -- loads issued at the top of the step, one wait per step -- and it was SLOWER (56.4
+// against 49.8 us per launch; it also broke one bit-exactness test, the allocator renames the in-flight registers between
+// the unrolled phases).  So the step is not waiting for memory: at one wave per SIMD it is issue bound.  Per z step the
+// wave issues ~1080 instructions (250 packed FP32 adds/multiplies, 150 v_mov that line the x-shifted operands up for
+// v_pk_add_f32, 80 v_accvgpr moves, 66 LDS and 24 vector-memory instructions, 50 selects, 36 DPP shifts), i.e. ~4300
+// cycles = the 2.25 us it takes.  The next step for this kernel is fewer instructions (an even/odd cell layout would make
+// the x neighbours register-pair aligned and drop most of the v_mov), not more memory-level parallelism.
 #include "fx_internal.h"
 #include <cstdlib>
 
