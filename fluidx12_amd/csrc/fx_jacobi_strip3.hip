@@ -46,8 +46,12 @@
 // the unrolled phases).  So the step is not waiting for memory: at one wave per SIMD it is issue bound.  Per z step the
 // wave issues ~1080 instructions (250 packed FP32 adds/multiplies, 150 v_mov that line the x-shifted operands up for
 // v_pk_add_f32, 80 v_accvgpr moves, 66 LDS and 24 vector-memory instructions, 50 selects, 36 DPP shifts), i.e. ~4300
-// cycles = the 2.25 us it takes.  The next step for this kernel is fewer instructions (an even/odd cell layout would make
-// the x neighbours register-pair aligned and drop most of the v_mov), not more memory-level parallelism.
+// cycles = the 2.25 us it takes.  What this kernel needs next is fewer instructions, not more memory-level parallelism.
+// One attempt at that: an even/odd register layout (c0, c2, c1, c3), in which the left neighbours of (c1, c3) and the right
+// neighbours of (c0, c2) are aligned register pairs as they stand.  Written at the source level (permute at the global
+// loads/stores, relax4 on the permuted vectors) the compiler answers with MORE moves (1184 v_mov + 627 v_accvgpr per three
+// steps against 553 + 240): the permutation of a loaded 128-bit tuple costs four moves and the pairs are not kept
+// aligned.  It would take hand-scheduled assembly.
 #include "fx_internal.h"
 #include <cstdlib>
 
