@@ -282,7 +282,7 @@ int jacobi_round(fx_ctx* ctx, hipStream_t s, int count, ScopedMark* mk)
 	while (done < count) {
 		const int left = count - done;
 		int t = std::min(left, fused_sweeps(ctx));
-		if (!multi_rank(ctx) && !ctx->frozen && jacobi_prefers_three(ctx->g, (int)(ctx->desc.flags & FX_FLAG_JACOBI_FUSE_MASK), ctx->g.nz))
+		if (!ctx->frozen && jacobi_prefers_three(ctx->g, (int)(ctx->desc.flags & FX_FLAG_JACOBI_FUSE_MASK), ctx->g.nz))
 			t = left == 4 ? 2 : std::min(left, 3);           // threes, and a remainder of 4 as 2 + 2 rather than 3 + 1
 		if (mk && mk->kind == MK_JACOBI && mk->launches && t * mk->launches < mk->sweeps) mk->split(MK_JACOBI_TAIL);   // shorter launches from here on
 		const int rc = jacobi_launch(ctx, s, ctx->p_cur, t, grown(ctx, multi_rank(ctx) ? left - t : 0), mk);

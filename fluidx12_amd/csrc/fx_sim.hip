@@ -820,7 +820,7 @@ int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp)
 	return t < 1 ? 1 : (t > 4 ? 4 : t);
 }
 
-// Single-domain default schedule: THREE sweeps per launch (k_jacobi_strip3) where that kernel exists and the grid is large
+// Default schedule of the serial rounds (single domain, and slab ranks thick enough): THREE sweeps per launch (k_jacobi_strip3) where that kernel exists and the grid is large
 // enough, the remainder as two-sweep launches (40 = 12 x 3 + 2 x 2).  Measured 256^3: Jacobi stage of the bench 0.664 ms
 // against 0.714 ms in twos (15.0 against 14.3 G voxel-updates/s).  FLUIDX_JACOBI_PREFER3=0 keeps two sweeps per launch throughout; an explicit jacobi_fuse / FLUIDX_JACOBI_T
 // request is always honoured as given.

@@ -98,6 +98,25 @@ def test_uneven_slabs_and_fp16():
     assert np.array_equal(gather(fl, fx.FIELD_COLOR, 0), ref.download(fx.FIELD_COLOR))
 
 
+def test_thick_slabs_take_the_three_sweep_kernel():
+    """slabs of >= 12.6 M cells at X = 256 run their serial rounds as 3 + 3 + 2 sweeps (k_jacobi_strip3 on the shrinking
+    trapezoid ranges, halo planes included): bit-identical to one sweep per launch on the single domain"""
+    dims = (256, 256, 400)
+    ref = run_single(dims, 2, jacobi_iters=19, jacobi_fuse=1)
+    fl = run_slabs(dims, 2, 2, jacobi_iters=19, halo_jacobi=8, halo_advect=8, overlap=1)
+    fl[0].timing_enable(True)
+    fl[0].UpdateFrame(f32(fl[0].default_time_step()), 2)
+    fl[0].Simulate(2)
+    fl[0].Synchronize()
+    t = fl[0].timing_read()
+    assert t.jacobi_sweeps == 19 and t.jacobi_launches == 7 and t.jacobi_main_sweeps == 15      # 3+3+2, 3+3+2, 3
+    ref.UpdateFrame(f32(ref.default_time_step()), 2)
+    ref.Simulate(2)
+    ref.Synchronize()
+    assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
+    assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
+
+
 def test_halo_overflow_is_reported():
     """a back-trace that leaves the exchanged halo must be reported, not silently clamped"""
     dims = (32, 32, 32)
