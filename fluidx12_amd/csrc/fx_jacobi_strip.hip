@@ -51,6 +51,19 @@ __device__ __forceinline__ float4 relax4(float4 c, float4 U, float4 D, float4 F,
 	return x;
 }
 
+// X = 256: the row is the wave, so the lanes without a DPP source (0 for wave_shr:1, 63 for wave_shl:1) are exactly the clamped
+// wall cells; they keep the DPP's `old` operand, which is set to the cell itself -- no select per update
+__device__ __forceinline__ float4 relax4_row(float4 c, float4 U, float4 D, float4 F, float4 Bk, float4 bb)
+{
+	const float L = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, c.x), __builtin_bit_cast(int, c.w), 0x138, 0xf, 0xf, false));
+	const float Rr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, c.w), __builtin_bit_cast(int, c.x), 0x130, 0xf, 0xf, false));
+	const float4 Lv = make_float4(L, c.x, c.y, c.z), Rv = make_float4(c.y, c.z, c.w, Rr);
+	float4 x = add4(add4(add4(add4(add4(sub4(Lv, bb), Rv), U), D), F), Bk);
+	const float inv = __uint_as_float(0x3e2aaaabu);
+	x.x *= inv; x.y *= inv; x.z *= inv; x.w *= inv;
+	return x;
+}
+
 // same XCD-aware tile order as fx_sim.hip (see xcd_tile there)
 __device__ __forceinline__ int xcd_index(int n, int remap)
 {
@@ -190,7 +203,8 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip(const Geom g, const flo
 		_Pragma("unroll") for (int i = 0; i < R + 2; ++i) P1[NEW][i] = P1[CTR][i]; \
 	} else { \
 		_Pragma("unroll") for (int i = 0; i < R + 2; ++i) \
-			P1[NEW][i] = relax4(P0[CTR][i + 1], P0[CTR][i], P0[CTR][i + 2], P0[OLD][i + 1], P0[NEW][i + 1], Bq[CTR][i], x_first, x_last); \
+			P1[NEW][i] = FULLROW ? relax4_row(P0[CTR][i + 1], P0[CTR][i], P0[CTR][i + 2], P0[OLD][i + 1], P0[NEW][i + 1], Bq[CTR][i]) \
+				: relax4(P0[CTR][i + 1], P0[CTR][i], P0[CTR][i + 2], P0[OLD][i + 1], P0[NEW][i + 1], Bq[CTR][i], x_first, x_last); \
 		if (q - 1 == 0) { \
 			_Pragma("unroll") for (int i = 0; i < R + 2; ++i) P1[CTR][i] = P1[NEW][i]; \
 		} \
@@ -203,13 +217,14 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip(const Geom g, const flo
 			float4 U = P1[CTR][j], D = P1[CTR][j + 2]; \
 			if (j == 0 && y0 == 0) U = c;                                /* rows outside the domain hold no data */ \
 			if (j == R - 1 && y0 + R >= g.Y) D = c; \
-			const float4 x = relax4(c, U, D, P1[OLD][j + 1], P1[NEW][j + 1], Bq[OLD][j + 1], x_first, x_last); \
+			const float4 x = FULLROW ? relax4_row(c, U, D, P1[OLD][j + 1], P1[NEW][j + 1], Bq[OLD][j + 1]) \
+				: relax4(c, U, D, P1[OLD][j + 1], P1[NEW][j + 1], Bq[OLD][j + 1], x_first, x_last); \
 			if (strip_live) *reinterpret_cast<float4*>(p_out + zo2 + (size_t)(y0 + j) * g.X + 4 * lx) = x; \
 		} \
 	} \
 } while (0)
 
-template <int R, int MINW>
+template <int R, int MINW, bool FULLROW>
 __global__ __launch_bounds__(256, MINW) void k_jacobi_strip2u(const Geom g, const float* __restrict__ p_in,
 	const float* __restrict__ b, float* __restrict__ p_out, int z_begin, int z_end, int zchunk, int ngroups, int nchunks, int remap)
 {
@@ -564,10 +579,12 @@ hipError_t launch_jacobi_strip(const Geom& g, const float* p_in, const float* b,
 		hipLaunchKernelGGL(k_jacobi_strip2h<4>, grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
 	else if (wide)
 		hipLaunchKernelGGL(k_jacobi_strip2w<2>, grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
+	else if (sweeps == 2 && R == 4 && (g.Y & 3) == 0 && !generic && g.X == 256)
+		hipLaunchKernelGGL((k_jacobi_strip2u<4, 1, true>), grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
 	else if (sweeps == 2 && R == 4 && (g.Y & 3) == 0 && !generic)
-		hipLaunchKernelGGL((k_jacobi_strip2u<4, 1>), grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
+		hipLaunchKernelGGL((k_jacobi_strip2u<4, 1, false>), grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
 	else if (sweeps == 2 && R == 2 && (g.Y & 1) == 0 && !generic)   // two waves per SIMD (<= 256 registers): FLUIDX_STRIP_R=2
-		hipLaunchKernelGGL((k_jacobi_strip2u<2, 2>), grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
+		hipLaunchKernelGGL((k_jacobi_strip2u<2, 2, false>), grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
 	else if (sweeps == 2) { if (R == 2) FX_STRIP(2, 2); else FX_STRIP(2, 4); }
 	else if (sweeps == 3) { if (R == 4) FX_STRIP(3, 4); else FX_STRIP(3, 2); }
 	else return hipErrorNotSupported;

@@ -66,10 +66,11 @@ __device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(
 __device__ __forceinline__ float4 relax4(float4 c, float4 U, float4 D, float4 F, float4 Bk, float4 bb, bool x_first, bool x_last)
 {
 	// DPP wave_shr:1 / wave_shl:1 instead of __shfl_up/_down (= ds_bpermute): see fx_jacobi_strip.hip
-	float L = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c.w), 0x138, 0xf, 0xf, false));
-	float Rr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c.x), 0x130, 0xf, 0xf, false));
-	if (x_first) L = c.x;
-	if (x_last) Rr = c.w;
+	// X = 256: the row is the wave, so the lanes without a source (0 for wave_shr, 63 for wave_shl) are exactly the clamped
+	// wall cells -- they keep the DPP's `old` operand, which is set to the cell itself: no select needed
+	(void)x_first; (void)x_last;
+	const float L = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, c.x), __builtin_bit_cast(int, c.w), 0x138, 0xf, 0xf, false));
+	const float Rr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, c.w), __builtin_bit_cast(int, c.x), 0x130, 0xf, 0xf, false));
 	const float4 Lv = make_float4(L, c.x, c.y, c.z), Rv = make_float4(c.y, c.z, c.w, Rr);
 	float4 x = add4(add4(add4(add4(add4(sub4(Lv, bb), Rv), U), D), F), Bk);
 	const float inv = __uint_as_float(0x3e2aaaabu);
