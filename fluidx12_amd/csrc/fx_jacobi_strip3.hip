@@ -94,6 +94,11 @@ constexpr int LDS_P0_ROWS = R3 + 6;         // one input plane: rows y0-3 .. y0+
 constexpr int LDS_B_ROWS = R3 + 2;          // one stored b plane: rows y0-1 .. y0+R
 constexpr int LDS_ROWS_PER_WAVE = 2 * LDS_P0_ROWS + 3 * LDS_B_ROWS;   // 38 rows of 1 KiB
 
+// a 32-bit row offset the optimiser may not widen ahead of time: hoisted out of the z loop, zext(offset) becomes a 64-bit
+// register pair and every access a v_lshl_add_u64 + `global_load ... off`; kept 32 bits wide at the use it folds into the
+// `global_load v, v_offset, s[base]` form
+__device__ __forceinline__ uint32_t opaque32(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
+
 // row `r` of an LDS slot whose first row starts `slot` float4s into the wave's slice
 #define FX_LDS(slot, r) lds[(slot) + (r) * 64]
 
@@ -123,12 +128,12 @@ constexpr int LDS_ROWS_PER_WAVE = 2 * LDS_P0_ROWS + 3 * LDS_B_ROWS;   // 38 rows
 	{ const int t_ = s_old; s_old = s_ctr; s_ctr = t_; }            /* plane q is next step's centre */ \
 	{ const int t_ = s_bfree; s_bfree = s_b3; s_b3 = s_b2; s_b2 = t_; } /* after this: s_b2 = b[q-1], s_b3 = b[q-2], s_bfree = b[q-3] */ \
 	if (q + 1 <= q_load_last) {                     /* prefetch input plane q+1; past the last plane NP keeps plane zhi */ \
-		const size_t zo = (size_t)g.lz(q + 1) * plane; \
-		_Pragma("unroll") for (int i = 0; i < R3 + 6; ++i) NP[i] = *reinterpret_cast<const float4*>(p_in + zo + roff[i]); \
+		const char* pb_ = reinterpret_cast<const char*>(p_in + (size_t)g.lz(q + 1) * plane); \
+		_Pragma("unroll") for (int i = 0; i < R3 + 6; ++i) NP[i] = *reinterpret_cast<const float4*>(pb_ + opaque32(roff[i])); \
 	} \
 	if (q <= b_load_last) {                         /* b[q] for the next step's sweep 1 */ \
-		const size_t zo = (size_t)g.lz(q) * plane; \
-		_Pragma("unroll") for (int i = 0; i < R3 + 4; ++i) NB[i] = *reinterpret_cast<const float4*>(b + zo + roff[i + 1]); \
+		const char* bb_ = reinterpret_cast<const char*>(b + (size_t)g.lz(q) * plane); \
+		_Pragma("unroll") for (int i = 0; i < R3 + 4; ++i) NB[i] = *reinterpret_cast<const float4*>(bb_ + opaque32(roff[i + 1])); \
 	} \
 	/* ---- sweep 2: level-2 plane q-2, rows k <-> y0-1+k; b[q-2] is s_b3 (rows y0-1 ..) ------------------------------- */ \
 	if (q - 2 == g.Zg) { \
@@ -147,14 +152,14 @@ constexpr int LDS_ROWS_PER_WAVE = 2 * LDS_P0_ROWS + 3 * LDS_B_ROWS;   // 38 rows
 	} \
 	/* ---- sweep 3: output plane q-3, rows m <-> y0+m; b[q-3] is s_bfree (its rows 1..4) ------------------------------- */ \
 	if (q - 3 >= zb && q - 3 < ze) { \
-		const size_t zo3 = (size_t)g.lz(q - 3) * plane; \
+		char* ob_ = reinterpret_cast<char*>(p_out + (size_t)g.lz(q - 3) * plane); \
 		_Pragma("unroll") for (int m = 0; m < R3; ++m) { \
 			const float4 c_ = P2[CTR][m + 1]; \
 			float4 u_ = P2[CTR][m], d_ = P2[CTR][m + 2]; \
 			if (m == 0 && y0 == 0) u_ = c_; \
 			if (m == R3 - 1 && y0 + R3 >= g.Y) d_ = c_; \
 			const float4 x_ = relax4(c_, u_, d_, P2[OLD][m + 1], P2[NEW][m + 1], FX_LDS(s_bfree, m + 1), x_first, x_last); \
-			if (strip_live) *reinterpret_cast<float4*>(p_out + zo3 + (size_t)(y0 + m) * g.X + 4 * lx) = x_; \
+			if (strip_live) *reinterpret_cast<float4*>(ob_ + opaque32(roff[m + 3])) = x_;   /* rows y0 .. y0+3 of a live strip are never clamped */ \
 		} \
 	} \
 } while (0)
@@ -176,9 +181,11 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip3(const Geom g, const fl
 	const bool x_first = lx == 0, x_last = lx == 63;
 	const size_t plane = g.plane();
 
-	size_t roff[R3 + 6];
+	// byte offsets of the strip's rows inside a plane, 32 bits each: the plane base is wave-uniform (SGPR pair), so every access
+	// is `global_load/store v, v_offset, s[base]` with no 64-bit address arithmetic per row
+	uint32_t roff[R3 + 6];
 #pragma unroll
-	for (int i = 0; i < R3 + 6; ++i) roff[i] = (size_t)min(max(y0 - 3 + i, 0), g.Y - 1) * g.X + 4 * lx;
+	for (int i = 0; i < R3 + 6; ++i) roff[i] = ((uint32_t)min(max(y0 - 3 + i, 0), g.Y - 1) * (uint32_t)g.X + 4u * (uint32_t)lx) * 4u;
 
 	// LDS slots (float4 offsets into the wave's slice): two input planes, three b planes
 	int s_ctr = 0, s_old = LDS_P0_ROWS * 64;
@@ -196,13 +203,13 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip3(const Geom g, const fl
 #pragma unroll
 	for (int i = 0; i < LDS_ROWS_PER_WAVE; ++i) lds[i * 64] = zero;
 	{
-		const size_t zo = (size_t)g.lz(min(qs, q_load_last)) * plane;
+		const char* pb = reinterpret_cast<const char*>(p_in + (size_t)g.lz(min(qs, q_load_last)) * plane);
 #pragma unroll
-		for (int i = 0; i < R3 + 6; ++i) NP[i] = *reinterpret_cast<const float4*>(p_in + zo + roff[i]);
+		for (int i = 0; i < R3 + 6; ++i) NP[i] = *reinterpret_cast<const float4*>(pb + roff[i]);
 		// b[qs - 1] for the first step's sweep 1 (clamped into the present planes: its level-1 plane is never used when qs - 1 < zlo)
-		const size_t zob = (size_t)g.lz(min(max(qs - 1, g.zlo), g.zhi)) * plane;
+		const char* bbase = reinterpret_cast<const char*>(b + (size_t)g.lz(min(max(qs - 1, g.zlo), g.zhi)) * plane);
 #pragma unroll
-		for (int i = 0; i < R3 + 4; ++i) NB[i] = *reinterpret_cast<const float4*>(b + zob + roff[i + 1]);
+		for (int i = 0; i < R3 + 4; ++i) NB[i] = *reinterpret_cast<const float4*>(bbase + roff[i + 1]);
 	}
 	int q = qs;
 	for (;;) {
