@@ -111,17 +111,21 @@ __device__ __forceinline__ uint32_t opaque32(uint32_t v) { asm volatile("" : "+v
 	if (q - 1 == g.Zg) {                            /* level-1 plane Zg := plane Zg-1 */ \
 		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) P1[NEW][j] = P1[CTR][j]; \
 	} else { \
-		float4 u_ = FX_LDS(s_ctr, 0), c_ = FX_LDS(s_ctr, 1); \
-		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) { \
-			const float4 d_ = FX_LDS(s_ctr, j + 2); \
-			const float4 f_ = FX_LDS(s_old, j + 1); \
-			P1[NEW][j] = relax4(c_, u_, d_, f_, NP[j + 1], NB[j], x_first, x_last); \
-			u_ = c_; c_ = d_; \
-		} \
+		/* all 18 LDS rows first: with one wave per SIMD a ds_read that is issued next to its use costs its whole latency */ \
+		float4 C_[R3 + 6], F_[R3 + 4]; \
+		_Pragma("unroll") for (int i = 0; i < R3 + 6; ++i) C_[i] = FX_LDS(s_ctr, i); \
+		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) F_[j] = FX_LDS(s_old, j + 1); \
+		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) \
+			P1[NEW][j] = relax4(C_[j + 1], C_[j], C_[j + 2], F_[j], NP[j + 1], NB[j], x_first, x_last); \
 		if (q - 1 == 0) { \
 			_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) P1[CTR][j] = P1[NEW][j]; \
 		} \
 	} \
+	/* ---- the b rows sweeps 2 and 3 will need (slots untouched by the writes below), read now so that they arrive behind the \
+	   writes and the prefetch instead of in front of each update ---- */ \
+	float4 B2_[R3 + 2], B3_[R3]; \
+	_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) B2_[k] = FX_LDS(s_b2, k);        /* b[q-2]: becomes s_b3 in the rotation */ \
+	_Pragma("unroll") for (int m = 0; m < R3; ++m) B3_[m] = FX_LDS(s_b3, m + 1);        /* b[q-3]: becomes s_bfree */ \
 	/* ---- the plane in flight moves to the LDS (over the input plane q-2, dead now); b[q-1] rows 1..6 to the free b slot ---- */ \
 	_Pragma("unroll") for (int i = 0; i < R3 + 6; ++i) FX_LDS(s_old, i) = NP[i]; \
 	_Pragma("unroll") for (int i = 0; i < R3 + 2; ++i) FX_LDS(s_bfree, i) = NB[i + 1]; \
@@ -144,7 +148,7 @@ __device__ __forceinline__ uint32_t opaque32(uint32_t v) { asm volatile("" : "+v
 			float4 u_ = P1[CTR][k], d_ = P1[CTR][k + 2]; \
 			if (k == 1 && y0 == 0) u_ = c_;                             /* rows outside the domain hold no data */ \
 			if (k == R3 && y0 + R3 >= g.Y) d_ = c_; \
-			P2[NEW][k] = relax4(c_, u_, d_, P1[OLD][k + 1], P1[NEW][k + 1], FX_LDS(s_b3, k), x_first, x_last); \
+			P2[NEW][k] = relax4(c_, u_, d_, P1[OLD][k + 1], P1[NEW][k + 1], B2_[k], x_first, x_last); \
 		} \
 		if (q - 2 == 0) { \
 			_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) P2[CTR][k] = P2[NEW][k]; \
@@ -158,7 +162,7 @@ __device__ __forceinline__ uint32_t opaque32(uint32_t v) { asm volatile("" : "+v
 			float4 u_ = P2[CTR][m], d_ = P2[CTR][m + 2]; \
 			if (m == 0 && y0 == 0) u_ = c_; \
 			if (m == R3 - 1 && y0 + R3 >= g.Y) d_ = c_; \
-			const float4 x_ = relax4(c_, u_, d_, P2[OLD][m + 1], P2[NEW][m + 1], FX_LDS(s_bfree, m + 1), x_first, x_last); \
+			const float4 x_ = relax4(c_, u_, d_, P2[OLD][m + 1], P2[NEW][m + 1], B3_[m], x_first, x_last); \
 			if (strip_live) *reinterpret_cast<float4*>(ob_ + opaque32(roff[m + 3])) = x_;   /* rows y0 .. y0+3 of a live strip are never clamped */ \
 		} \
 	} \
