@@ -52,6 +52,13 @@
 // loads/stores, relax4 on the permuted vectors) the compiler answers with MORE moves (1184 v_mov + 627 v_accvgpr per three
 // steps against 553 + 240): the permutation of a loaded 128-bit tuple costs four moves and the pairs are not kept
 // aligned.  It would take hand-scheduled assembly.
+// And the LDS-direct route (global_load_lds_dwordx4, checked on the device by tools/micro/ldslds.cpp): three rotating input
+// slots + a b landing slot in the same 38 KiB, the rows of plane q-2 and the three b planes in registers, every LDS read in
+// inline assembly so that the only `s_waitcnt vmcnt(0)` of a step is the one at its top -- 11 waits per three steps in the
+// ISA, no ds_write left, and the SAME 44.2 us per launch (390 registers, three times the v_accvgpr traffic).  Together
+// with the AGPR prefetch this settles it: hiding the memory latency buys nothing here, the kernel's time is its ~580
+// issued instructions per z step (rocprofv3: 9.9 k VALU + 1.3 k scalar + 1.0 k LDS + 0.45 k vector-memory per wave and
+// launch, a wave issuing 61 % of its cycles).
 #include "fx_internal.h"
 #include <cstdlib>
 
