@@ -233,13 +233,187 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip3(const Geom g, const fl
 	}
 }
 #undef FX_STRIP3_STEP
+
+// X = 512: the 256-wide recipe on half a row per wave.  The wall side of the wave clamps as before; on the cut side the
+// neighbour cell belongs to the partner wave (the other half of the same rows, the next wave of the same workgroup) and
+// comes in as `edge`: the input level from memory (a wave-uniform scalar load per row), the first- and second-sweep
+// levels from a 512-byte LDS mailbox the partner filled one z step earlier (one s_barrier per step orders it).
+__device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 F, float4 Bk, float4 bb, float edge, bool right_half)
+{
+	const float oldL = right_half ? edge : c.x, oldR = right_half ? c.w : edge;
+	const float L = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldL), __builtin_bit_cast(int, c.w), 0x138, 0xf, 0xf, false));
+	const float Rr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldR), __builtin_bit_cast(int, c.x), 0x130, 0xf, 0xf, false));
+	const float4 Lv = make_float4(L, c.x, c.y, c.z), Rv = make_float4(c.y, c.z, c.w, Rr);
+	float4 x = add4(add4(add4(add4(add4(sub4(Lv, bb), Rv), U), D), F), Bk);
+	const float inv = __uint_as_float(0x3e2aaaabu);
+	x.x *= inv; x.y *= inv; x.z *= inv; x.w *= inv;
+	return x;
+}
+
+#define FX_STRIP3H_STEP(PH) do { \
+	constexpr int NEW = (PH) % 3, CTR = ((PH) + 2) % 3, OLD = ((PH) + 1) % 3; \
+	/* the partner half-row wave published, one step ago, the first- and second-sweep values of its cell next to the cut */ \
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+	float e1_[R3 + 4], e2_[R3 + 2]; \
+	{ \
+		const float* xr_ = xbuf + (((q - 1) & 1) * 4 + (wave ^ 1)) * 16; \
+		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) e1_[j] = xr_[j]; \
+		_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) e2_[k] = xr_[8 + k]; \
+	} \
+	/* ---- sweep 1: level-1 plane q-1, rows j <-> y0-2+j; input rows i <-> y0-3+i ------------------------------- */ \
+	if (q == 0) {                                   /* input plane -1 := plane 0, once (clamped front neighbour) */ \
+		_Pragma("unroll") for (int i = 0; i < R3 + 6; ++i) FX_LDS(s_ctr, i) = NP[i]; \
+		_Pragma("unroll") for (int i = 0; i < R3 + 6; ++i) E0c[i] = E0n[i]; \
+	} \
+	if (q - 1 == g.Zg) {                            /* level-1 plane Zg := plane Zg-1 */ \
+		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) P1[NEW][j] = P1[CTR][j]; \
+	} else { \
+		/* all 18 LDS rows first: with one wave per SIMD a ds_read that is issued next to its use costs its whole latency */ \
+		float4 C_[R3 + 6], F_[R3 + 4]; \
+		_Pragma("unroll") for (int i = 0; i < R3 + 6; ++i) C_[i] = FX_LDS(s_ctr, i); \
+		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) F_[j] = FX_LDS(s_old, j + 1); \
+		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) \
+			P1[NEW][j] = relax4_h(C_[j + 1], C_[j], C_[j + 2], F_[j], NP[j + 1], NB[j], E0c[j + 1], right_half); \
+		if (q - 1 == 0) { \
+			_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) P1[CTR][j] = P1[NEW][j]; \
+		} \
+	} \
+	/* publish this wave's first-sweep cell next to the cut (plane q-1) for the partner's sweep 2 of the next step */ \
+	if (lane == edge_lane) { \
+		float* xw_ = xbuf + ((q & 1) * 4 + wave) * 16; \
+		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) xw_[j] = right_half ? P1[NEW][j].x : P1[NEW][j].w; \
+	} \
+	/* ---- the b rows sweeps 2 and 3 will need (slots untouched by the writes below), read now so that they arrive behind the \
+	   writes and the prefetch instead of in front of each update ---- */ \
+	float4 B2_[R3 + 2], B3_[R3]; \
+	_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) B2_[k] = FX_LDS(s_b2, k);        /* b[q-2]: becomes s_b3 in the rotation */ \
+	_Pragma("unroll") for (int m = 0; m < R3; ++m) B3_[m] = FX_LDS(s_b3, m + 1);        /* b[q-3]: becomes s_bfree */ \
+	/* ---- the plane in flight moves to the LDS (over the input plane q-2, dead now); b[q-1] rows 1..6 to the free b slot ---- */ \
+	_Pragma("unroll") for (int i = 0; i < R3 + 6; ++i) FX_LDS(s_old, i) = NP[i]; \
+	_Pragma("unroll") for (int i = 0; i < R3 + 2; ++i) FX_LDS(s_bfree, i) = NB[i + 1]; \
+	{ const int t_ = s_old; s_old = s_ctr; s_ctr = t_; }            /* plane q is next step's centre */ \
+	{ const int t_ = s_bfree; s_bfree = s_b3; s_b3 = s_b2; s_b2 = t_; } /* after this: s_b2 = b[q-1], s_b3 = b[q-2], s_bfree = b[q-3] */ \
+	_Pragma("unroll") for (int i = 0; i < R3 + 6; ++i) E0c[i] = E0n[i];              /* plane q is next step's centre */ \
+	if (q + 1 <= q_load_last) {                     /* prefetch input plane q+1; past the last plane NP keeps plane zhi */ \
+		const char* pb_ = reinterpret_cast<const char*>(p_in + (size_t)g.lz(q + 1) * plane); \
+		_Pragma("unroll") for (int i = 0; i < R3 + 6; ++i) E0n[i] = *reinterpret_cast<const float*>(pb_ + soff[i]);   /* uniform address: scalar load */ \
+		_Pragma("unroll") for (int i = 0; i < R3 + 6; ++i) NP[i] = *reinterpret_cast<const float4*>(pb_ + opaque32(roff[i])); \
+	} \
+	if (q <= b_load_last) {                         /* b[q] for the next step's sweep 1 */ \
+		const char* bb_ = reinterpret_cast<const char*>(b + (size_t)g.lz(q) * plane); \
+		_Pragma("unroll") for (int i = 0; i < R3 + 4; ++i) NB[i] = *reinterpret_cast<const float4*>(bb_ + opaque32(roff[i + 1])); \
+	} \
+	/* ---- sweep 2: level-2 plane q-2, rows k <-> y0-1+k; b[q-2] is s_b3 (rows y0-1 ..) ------------------------------- */ \
+	if (q - 2 == g.Zg) { \
+		_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) P2[NEW][k] = P2[CTR][k]; \
+	} else { \
+		_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) { \
+			const float4 c_ = P1[CTR][k + 1]; \
+			float4 u_ = P1[CTR][k], d_ = P1[CTR][k + 2]; \
+			if (k == 1 && y0 == 0) u_ = c_;                             /* rows outside the domain hold no data */ \
+			if (k == R3 && y0 + R3 >= g.Y) d_ = c_; \
+			P2[NEW][k] = relax4_h(c_, u_, d_, P1[OLD][k + 1], P1[NEW][k + 1], B2_[k], e1_[k + 1], right_half); \
+		} \
+		if (q - 2 == 0) { \
+			_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) P2[CTR][k] = P2[NEW][k]; \
+		} \
+	} \
+	if (lane == edge_lane) { \
+		float* xw_ = xbuf + ((q & 1) * 4 + wave) * 16 + 8; \
+		_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) xw_[k] = right_half ? P2[NEW][k].x : P2[NEW][k].w; \
+	} \
+	/* ---- sweep 3: output plane q-3, rows m <-> y0+m; b[q-3] is s_bfree (its rows 1..4) ------------------------------- */ \
+	if (q - 3 >= zb && q - 3 < ze) { \
+		char* ob_ = reinterpret_cast<char*>(p_out + (size_t)g.lz(q - 3) * plane); \
+		_Pragma("unroll") for (int m = 0; m < R3; ++m) { \
+			const float4 c_ = P2[CTR][m + 1]; \
+			float4 u_ = P2[CTR][m], d_ = P2[CTR][m + 2]; \
+			if (m == 0 && y0 == 0) u_ = c_; \
+			if (m == R3 - 1 && y0 + R3 >= g.Y) d_ = c_; \
+			const float4 x_ = relax4_h(c_, u_, d_, P2[OLD][m + 1], P2[NEW][m + 1], B3_[m], e2_[m + 1], right_half); \
+			if (strip_live) *reinterpret_cast<float4*>(ob_ + opaque32(roff[m + 3])) = x_;   /* rows y0 .. y0+3 of a live strip are never clamped */ \
+		} \
+	} \
+} while (0)
+
+__global__ __launch_bounds__(256, 1) void k_jacobi_strip3h(const Geom g, const float* __restrict__ p_in,
+	const float* __restrict__ b, float* __restrict__ p_out, int z_begin, int z_end, int zchunk, int ngroups, int nchunks, int remap)
+{
+	__shared__ float4 lds_all[4 * LDS_ROWS_PER_WAVE * 64];
+	__shared__ float xbuf[2 * 4 * 16];                                // [step parity][wave][8 first-sweep + 6 second-sweep edge cells]
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int lx = lane;
+	float4* lds = lds_all + wave * (LDS_ROWS_PER_WAVE * 64) + lane;
+	const int tile = xcd_index3(ngroups * nchunks, remap);
+	const int grp = tile % ngroups, chunk = tile / ngroups;
+	const int hs = grp * 4 + wave;                                    // half-strip: the two halves of a row strip are waves 2k, 2k + 1
+	const bool right_half = hs & 1;
+	const int y0 = (hs >> 1) * R3;
+	const int xb = right_half ? 256 : 0, edge_lane = right_half ? 0 : 63;
+	const bool strip_live = y0 < g.Y;
+	const int zb = z_begin + chunk * zchunk, ze = min(zb + zchunk, z_end);
+	const int qs = max(zb - 3, g.zlo), q_last = ze - 1 + 3, q_load_last = min(q_last, g.zhi);
+	const int b_load_last = min(q_last - 1, g.zhi);
+	const size_t plane = g.plane();
+
+	// byte offsets of the strip's rows inside a plane, 32 bits each: the plane base is wave-uniform (SGPR pair), so every access
+	// is `global_load/store v, v_offset, s[base]` with no 64-bit address arithmetic per row
+	uint32_t roff[R3 + 6];
+#pragma unroll
+	for (int i = 0; i < R3 + 6; ++i) roff[i] = ((uint32_t)min(max(y0 - 3 + i, 0), g.Y - 1) * (uint32_t)g.X + (uint32_t)xb + 4u * (uint32_t)lx) * 4u;
+	// the cell across the cut, per row: a wave-uniform byte offset (scalar loads)
+	uint32_t soff[R3 + 6];
+#pragma unroll
+	for (int i = 0; i < R3 + 6; ++i) soff[i] = ((uint32_t)min(max(y0 - 3 + i, 0), g.Y - 1) * (uint32_t)g.X + (right_half ? 255u : 256u)) * 4u;
+
+	// LDS slots (float4 offsets into the wave's slice): two input planes, three b planes
+	int s_ctr = 0, s_old = LDS_P0_ROWS * 64;
+	int s_b2 = 2 * LDS_P0_ROWS * 64, s_b3 = s_b2 + LDS_B_ROWS * 64, s_bfree = s_b3 + LDS_B_ROWS * 64;
+
+	float4 P1[3][R3 + 4], P2[3][R3 + 2], NP[R3 + 6], NB[R3 + 4];
+	float E0c[R3 + 6], E0n[R3 + 6];                                     // input cells across the cut: centre plane, plane in flight
+	const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+#pragma unroll
+		for (int i = 0; i < R3 + 4; ++i) P1[k][i] = zero;
+#pragma unroll
+		for (int i = 0; i < R3 + 2; ++i) P2[k][i] = zero;
+	}
+#pragma unroll
+	for (int i = 0; i < LDS_ROWS_PER_WAVE; ++i) lds[i * 64] = zero;
+	if (threadIdx.x < 2 * 4 * 16) xbuf[threadIdx.x] = 0.0f;
+	__syncthreads();
+	{
+		const char* pb = reinterpret_cast<const char*>(p_in + (size_t)g.lz(min(qs, q_load_last)) * plane);
+#pragma unroll
+		for (int i = 0; i < R3 + 6; ++i) NP[i] = *reinterpret_cast<const float4*>(pb + roff[i]);
+#pragma unroll
+		for (int i = 0; i < R3 + 6; ++i) { E0n[i] = *reinterpret_cast<const float*>(pb + soff[i]); E0c[i] = 0.0f; }
+		// b[qs - 1] for the first step's sweep 1 (clamped into the present planes: its level-1 plane is never used when qs - 1 < zlo)
+		const char* bbase = reinterpret_cast<const char*>(b + (size_t)g.lz(min(max(qs - 1, g.zlo), g.zhi)) * plane);
+#pragma unroll
+		for (int i = 0; i < R3 + 4; ++i) NB[i] = *reinterpret_cast<const float4*>(bbase + roff[i + 1]);
+	}
+	int q = qs;
+	for (;;) {
+		FX_STRIP3H_STEP(0);
+		if (++q > q_last) break;
+		FX_STRIP3H_STEP(1);
+		if (++q > q_last) break;
+		FX_STRIP3H_STEP(2);
+		if (++q > q_last) break;
+	}
+}
+#undef FX_STRIP3H_STEP
 #undef FX_LDS
 
 }  // namespace
 
 bool jacobi_strip3_supported(const Geom& g)
 {
-	return g.Zg > 1 && g.X == 256 && (g.Y & 3) == 0 && g.Y >= 8;
+	static const bool no_h = [] { const char* e = getenv("FLUIDX_STRIP3_NO512"); return e && e[0] == '1'; }();
+	return g.Zg > 1 && (g.X == 256 || (g.X == 512 && !no_h)) && (g.Y & 3) == 0 && g.Y >= 8;
 }
 
 hipError_t launch_jacobi_strip3(const Geom& g, const float* p_in, const float* b, float* p_out, int z_begin, int z_end, hipStream_t s)
@@ -250,7 +424,8 @@ hipError_t launch_jacobi_strip3(const Geom& g, const float* p_in, const float* b
 	const char* re = getenv("FLUIDX_STRIP_REMAP");
 	const int forced_chunk = ce && *ce ? atoi(ce) : 0;
 	const int remap = re && *re ? atoi(re) : 1;
-	const int nstrips = g.Y / R3;
+	const bool halves = g.X == 512;                                     // two half-row waves per strip (k_jacobi_strip3h)
+	const int nstrips = (g.Y / R3) * (halves ? 2 : 1);
 	const int ngroups = (nstrips + 3) / 4;                              // 4 waves (strips) per workgroup
 	const int nzp = z_end - z_begin;
 	int nchunks = (256 + ngroups - 1) / ngroups;                        // one workgroup per CU
@@ -258,7 +433,8 @@ hipError_t launch_jacobi_strip3(const Geom& g, const float* p_in, const float* b
 	if (zchunk < 8) zchunk = 8;
 	if (zchunk > nzp) zchunk = nzp;
 	nchunks = (nzp + zchunk - 1) / zchunk;
-	hipLaunchKernelGGL(k_jacobi_strip3, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
+	if (halves) hipLaunchKernelGGL(k_jacobi_strip3h, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
+	else hipLaunchKernelGGL(k_jacobi_strip3, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
 	return hipGetLastError();
 }
 

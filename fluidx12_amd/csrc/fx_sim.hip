@@ -810,7 +810,7 @@ int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp)
 	static const int forced = env_int("FLUIDX_JACOBI_T", 0);
 	if (jacobi_strip_supported(g) && jacobi_strip_wide(g)) {            // X = 512: one fused shape (two sweeps, wide strips)
 		const int want = requested > 0 ? requested : (forced > 0 ? forced : (strip_profitable(g, nzp) ? 2 : 1));
-		return want >= 2 ? 2 : 1;
+		return want >= 3 && jacobi_strip3_supported(g) ? 3 : (want >= 2 ? 2 : 1);
 	}
 	if (!tb_supported(g)) return 1;
 	// default: two sweeps per launch in the register-strip kernel (fx_jacobi_strip.hip) where the geometry allows it,
@@ -831,7 +831,10 @@ bool jacobi_prefers_three(const Geom& g, int requested, int nzp)
 	static const int no_lds3 = env_int("FLUIDX_STRIP3_OFF", 0);
 	static const int use_tb = env_int("FLUIDX_FUSE2_TB", 0);
 	return prefer && !requested && !forced && !no_lds3 && !use_tb && jacobi_strip3_supported(g) &&
-		(size_t)g.X * g.Y * (size_t)nzp >= ((size_t)3 << 22);           // 12.6 M cells: 256x256x128 still loses (11.3 against 11.0 us per sweep)
+		(size_t)g.X * g.Y * (size_t)nzp >= ((size_t)3 << (g.X == 512 ? 23 : 22));
+	// X = 256: from 12.6 M cells (256x256x128 still loses, 11.3 against 11.0 us per sweep).  X = 512 (k_jacobi_strip3h, one
+	// workgroup barrier per z step): from 25 M cells -- 512x512x128 39.6 against 43.3 us, 512^3 133.7 against 159.7, but
+	// 512x512x64 20.3 against 19.0
 }
 
 // tile geometry of the fused kernel: TY rows per workgroup (threads = X/4 * TY), D input planes in flight
@@ -903,8 +906,10 @@ hipError_t launch_jacobi_fused(const Geom& g, const float* p_in, const float* b,
 	int z_begin, int z_end, hipStream_t s)
 {
 	if (z_end <= z_begin) return hipSuccess;
-	if (jacobi_strip_supported(g) && jacobi_strip_wide(g))
+	if (jacobi_strip_supported(g) && jacobi_strip_wide(g)) {
+		if (sweeps == 3 && jacobi_strip3_supported(g)) return launch_jacobi_strip3(g, p_in, b, p_out, z_begin, z_end, s);
 		return sweeps == 2 ? launch_jacobi_strip(g, p_in, b, p_out, 2, z_begin, z_end, s) : hipErrorNotSupported;
+	}
 	if (!tb_supported(g)) return hipErrorNotSupported;
 	switch (sweeps) {
 	case 2: {
