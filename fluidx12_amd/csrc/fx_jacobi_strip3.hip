@@ -60,6 +60,7 @@
 // issued instructions per z step (rocprofv3: 9.9 k VALU + 1.3 k scalar + 1.0 k LDS + 0.45 k vector-memory per wave and
 // launch, a wave issuing 61 % of its cycles).
 #include "fx_internal.h"
+#include <climits>
 #include <cstdlib>
 
 namespace fx {
@@ -237,7 +238,8 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip3(const Geom g, const fl
 // X = 512: the 256-wide recipe on half a row per wave.  The wall side of the wave clamps as before; on the cut side the
 // neighbour cell belongs to the partner wave (the other half of the same rows, the next wave of the same workgroup) and
 // comes in as `edge`: the input level from memory (a wave-uniform scalar load per row), the first- and second-sweep
-// levels from a 512-byte LDS mailbox the partner filled one z step earlier (one s_barrier per step orders it).
+// levels from a 512-byte LDS mailbox the partner filled one z step earlier; a per-wave LDS counter of the last published
+// step orders it (a wave waits only while its partner is more than a step behind; a workgroup barrier per step cost 3 %).
 __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 F, float4 Bk, float4 bb, float edge, bool right_half)
 {
 	const float oldL = right_half ? edge : c.x, oldR = right_half ? c.w : edge;
@@ -253,10 +255,11 @@ __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 
 #define FX_STRIP3H_STEP(PH) do { \
 	constexpr int NEW = (PH) % 3, CTR = ((PH) + 2) % 3, OLD = ((PH) + 1) % 3; \
 	/* the partner half-row wave published, one step ago, the first- and second-sweep values of its cell next to the cut */ \
-	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+	while (*reinterpret_cast<volatile int*>(xflag + (wave ^ 1)) < q - 1) __builtin_amdgcn_s_sleep(1);   /* partner has published step q-1 (and therefore read ours of q-2) */ \
+	asm volatile("" ::: "memory"); \
 	float e1_[R3 + 4], e2_[R3 + 2]; \
 	{ \
-		const float* xr_ = xbuf + (((q - 1) & 1) * 4 + (wave ^ 1)) * 16; \
+		const float* xr_ = xbuf + (((q - 1) & 1) * WPG + (wave ^ 1)) * 16; \
 		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) e1_[j] = xr_[j]; \
 		_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) e2_[k] = xr_[8 + k]; \
 	} \
@@ -280,7 +283,7 @@ __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 
 	} \
 	/* publish this wave's first-sweep cell next to the cut (plane q-1) for the partner's sweep 2 of the next step */ \
 	if (lane == edge_lane) { \
-		float* xw_ = xbuf + ((q & 1) * 4 + wave) * 16; \
+		float* xw_ = xbuf + ((q & 1) * WPG + wave) * 16; \
 		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) xw_[j] = right_half ? P1[NEW][j].x : P1[NEW][j].w; \
 	} \
 	/* ---- the b rows sweeps 2 and 3 will need (slots untouched by the writes below), read now so that they arrive behind the \
@@ -319,8 +322,10 @@ __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 
 		} \
 	} \
 	if (lane == edge_lane) { \
-		float* xw_ = xbuf + ((q & 1) * 4 + wave) * 16 + 8; \
+		float* xw_ = xbuf + ((q & 1) * WPG + wave) * 16 + 8; \
 		_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) xw_[k] = right_half ? P2[NEW][k].x : P2[NEW][k].w; \
+		asm volatile("" ::: "memory"); \
+		*reinterpret_cast<volatile int*>(xflag + wave) = q;          /* LDS operations of a wave execute in order: the data is there before the counter */ \
 	} \
 	/* ---- sweep 3: output plane q-3, rows m <-> y0+m; b[q-3] is s_bfree (its rows 1..4) ------------------------------- */ \
 	if (q - 3 >= zb && q - 3 < ze) { \
@@ -336,17 +341,19 @@ __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 
 	} \
 } while (0)
 
-__global__ __launch_bounds__(256, 1) void k_jacobi_strip3h(const Geom g, const float* __restrict__ p_in,
+template <int WPG>
+__global__ __launch_bounds__(64 * WPG, 4 / WPG) void k_jacobi_strip3h(const Geom g, const float* __restrict__ p_in,
 	const float* __restrict__ b, float* __restrict__ p_out, int z_begin, int z_end, int zchunk, int ngroups, int nchunks, int remap)
 {
-	__shared__ float4 lds_all[4 * LDS_ROWS_PER_WAVE * 64];
-	__shared__ float xbuf[2 * 4 * 16];                                // [step parity][wave][8 first-sweep + 6 second-sweep edge cells]
+	__shared__ float4 lds_all[WPG * LDS_ROWS_PER_WAVE * 64];
+	__shared__ float xbuf[2 * WPG * 16];
+	__shared__ int xflag[WPG];                                        // last z step each wave has published                                // [step parity][wave][8 first-sweep + 6 second-sweep edge cells]
 	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int lx = lane;
 	float4* lds = lds_all + wave * (LDS_ROWS_PER_WAVE * 64) + lane;
 	const int tile = xcd_index3(ngroups * nchunks, remap);
 	const int grp = tile % ngroups, chunk = tile / ngroups;
-	const int hs = grp * 4 + wave;                                    // half-strip: the two halves of a row strip are waves 2k, 2k + 1
+	const int hs = grp * WPG + wave;                                    // half-strip: the two halves of a row strip are waves 2k, 2k + 1
 	const bool right_half = hs & 1;
 	const int y0 = (hs >> 1) * R3;
 	const int xb = right_half ? 256 : 0, edge_lane = right_half ? 0 : 63;
@@ -382,7 +389,8 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip3h(const Geom g, const f
 	}
 #pragma unroll
 	for (int i = 0; i < LDS_ROWS_PER_WAVE; ++i) lds[i * 64] = zero;
-	if (threadIdx.x < 2 * 4 * 16) xbuf[threadIdx.x] = 0.0f;
+	if (threadIdx.x < 2 * WPG * 16) xbuf[threadIdx.x] = 0.0f;
+	if (threadIdx.x < WPG) xflag[threadIdx.x] = INT_MIN;
 	__syncthreads();
 	{
 		const char* pb = reinterpret_cast<const char*>(p_in + (size_t)g.lz(min(qs, q_load_last)) * plane);
@@ -395,6 +403,8 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip3h(const Geom g, const f
 #pragma unroll
 		for (int i = 0; i < R3 + 4; ++i) NB[i] = *reinterpret_cast<const float4*>(bbase + roff[i + 1]);
 	}
+	if (lane == 0) xflag[wave] = qs - 1;                              // both waves of a pair share the chunk, hence qs
+	__syncthreads();
 	int q = qs;
 	for (;;) {
 		FX_STRIP3H_STEP(0);
@@ -426,14 +436,17 @@ hipError_t launch_jacobi_strip3(const Geom& g, const float* p_in, const float* b
 	const int remap = re && *re ? atoi(re) : 1;
 	const bool halves = g.X == 512;                                     // two half-row waves per strip (k_jacobi_strip3h)
 	const int nstrips = (g.Y / R3) * (halves ? 2 : 1);
-	const int ngroups = (nstrips + 3) / 4;                              // 4 waves (strips) per workgroup
+	static const int pair_wg = [] { const char* e = getenv("FLUIDX_STRIP3H_PAIRS"); return e ? atoi(e) : 0; }();
+	const int wpg = halves && pair_wg ? 2 : 4;                          // X = 512: a workgroup = one pair of half-row waves (its barrier syncs only them)
+	const int ngroups = (nstrips + wpg - 1) / wpg;                      // waves (strips) per workgroup
 	const int nzp = z_end - z_begin;
-	int nchunks = (256 + ngroups - 1) / ngroups;                        // one workgroup per CU
+	int nchunks = (1024 / wpg + ngroups - 1) / ngroups;                 // 1024 waves: one per SIMD
 	int zchunk = forced_chunk > 0 ? forced_chunk : (nzp + nchunks - 1) / nchunks;
 	if (zchunk < 8) zchunk = 8;
 	if (zchunk > nzp) zchunk = nzp;
 	nchunks = (nzp + zchunk - 1) / zchunk;
-	if (halves) hipLaunchKernelGGL(k_jacobi_strip3h, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
+	if (halves && wpg == 2) hipLaunchKernelGGL(k_jacobi_strip3h<2>, dim3(ngroups * nchunks), dim3(128), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
+	else if (halves) hipLaunchKernelGGL(k_jacobi_strip3h<4>, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
 	else hipLaunchKernelGGL(k_jacobi_strip3, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
 	return hipGetLastError();
 }
