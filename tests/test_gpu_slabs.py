@@ -98,10 +98,11 @@ def test_uneven_slabs_and_fp16():
     assert np.array_equal(gather(fl, fx.FIELD_COLOR, 0), ref.download(fx.FIELD_COLOR))
 
 
-def test_thick_slabs_take_the_three_sweep_kernel():
-    """slabs of >= 12.6 M cells at X = 256 run their serial rounds as 3 + 3 + 2 sweeps (k_jacobi_strip3 on the shrinking
-    trapezoid ranges, halo planes included): bit-identical to one sweep per launch on the single domain"""
-    dims = (256, 256, 400)
+@pytest.mark.parametrize("dims", [(256, 256, 400), (512, 512, 260)])
+def test_thick_slabs_take_the_three_sweep_kernel(dims):
+    """slabs of >= 12.6 M cells at X = 256 (>= 25 M at X = 512) run their serial rounds as 3 + 3 + 2 sweeps (k_jacobi_strip3 /
+    k_jacobi_strip3h on the shrinking trapezoid ranges, halo planes included): bit-identical to one sweep per launch on the
+    single domain"""
     ref = run_single(dims, 2, jacobi_iters=19, jacobi_fuse=1)
     fl = run_slabs(dims, 2, 2, jacobi_iters=19, halo_jacobi=8, halo_advect=8, overlap=1)
     fl[0].timing_enable(True)
