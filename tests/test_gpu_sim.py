@@ -91,6 +91,32 @@ def test_jacobi_sweep_counts(iters):
     assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
 
 
+@pytest.mark.parametrize("dims", [(256, 256, 200), (512, 512, 100)])
+def test_default_schedule_of_large_grids_is_bit_identical(dims):
+    """grids large enough for the three-sweep kernels run N sweeps as threes + twos (+ a single): 4 = 2 + 2, 5 = 3 + 2,
+    7 = 3 + 2 + 2, ...; every count equals N launches of one sweep bit for bit"""
+    X, Y, Z = dims
+    rng = np.random.default_rng(31)
+    p = rng.standard_normal((Z, Y, X)).astype(f32)
+    b = rng.uniform(-1, 1, (Z, Y, X)).astype(f32)
+    ref = make(dims, jacobi_fuse=1)
+    dut = make(dims)                                     # default schedule
+    expect = {1: (1, 1), 2: (1, 2), 3: (1, 3), 4: (2, 4), 5: (2, 5), 7: (3, 7), 8: (3, 8), 10: (4, 10)}
+    for iters, (launches, sweeps) in expect.items():
+        for f in (ref, dut):
+            f.upload(fx.FIELD_PRESSURE, p)
+            f.upload(fx.FIELD_DIVERGENCE, b)
+        dut.timing_enable(True)
+        dut.timing_read(True)
+        ref.Jacobi(iters)
+        dut.Jacobi(iters)
+        ref.Synchronize()
+        dut.Synchronize()
+        t = dut.timing_read(True)
+        assert (t.jacobi_launches, t.jacobi_sweeps) == (launches, sweeps), (iters, t.jacobi_launches, t.jacobi_sweeps)
+        assert np.array_equal(dut.download(fx.FIELD_PRESSURE), ref.download(fx.FIELD_PRESSURE)), iters
+
+
 def test_jacobi_wide_strips_x512_bit_exact():
     """X = 512: the two-sweep strip kernel with two float4 per lane (k_jacobi_strip2w) == oracle, bit for bit"""
     X, Y, Z = 512, 512, 20
