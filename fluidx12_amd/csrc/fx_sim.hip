@@ -48,7 +48,12 @@ template <> struct Store<true> {
 		a = (float)v.a; b = (float)v.b;
 	}
 	static __device__ __forceinline__ float ld(const S* p, size_t i) { return (float)p[i]; }
-	static __device__ __forceinline__ void st(S* p, size_t i, float v) { p[i] = (h16)v; }   // RNE
+	// The fp32 result is rounded to binary16 in a SEPARATE step (RNE), as a typed store of an fp32 register does.  Left to
+	// itself the compiler folds the producing multiply/FMA and the conversion into v_fma_mixlo_f16, which rounds the exact
+	// product ONCE: different whenever the fp32 rounding lands on a binary16 tie (u * 0.95 does, for dt = 1/4).  The empty
+	// asm makes the fp32 value opaque, so the conversion stays a plain v_cvt_f16_f32.
+	static __device__ __forceinline__ float rounded_f32(float v) { asm("" : "+v"(v)); return v; }
+	static __device__ __forceinline__ void st(S* p, size_t i, float v) { p[i] = (h16)rounded_f32(v); }   // RNE
 	static __device__ __forceinline__ float4 ld4(const S4* p, size_t i)
 	{
 		const h16x4 h = p[i];
@@ -57,7 +62,7 @@ template <> struct Store<true> {
 	static __device__ __forceinline__ void st4(S4* p, size_t i, float4 v)
 	{
 		h16x4 h;
-		h.x = (h16)v.x; h.y = (h16)v.y; h.z = (h16)v.z; h.w = (h16)v.w;
+		h.x = (h16)rounded_f32(v.x); h.y = (h16)rounded_f32(v.y); h.z = (h16)rounded_f32(v.z); h.w = (h16)rounded_f32(v.w);
 		p[i] = h;
 	}
 };

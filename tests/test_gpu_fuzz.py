@@ -3,6 +3,8 @@ cases the reference's defaults hit; these draw grid extents, storage, addressing
 halo widths and schedules at random (fixed seeds, so a failure reproduces) and hold the same bars:
   * one full step from a random state: HIP vs oracle (bit-exact where no transcendental is on the path);
   * random z-slab decompositions vs the single-domain HIP run: bit-identical."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,6 +14,8 @@ from oracle import orc
 
 pytestmark = pytest.mark.gpu
 f32 = np.float32
+# FLUIDX_FUZZ_SEEDS=N widens every seed range to N (a soak run; the default ranges run in seconds)
+SOAK = int(os.environ.get("FLUIDX_FUZZ_SEEDS", "0"))
 
 
 def rel_l2(a, b):
@@ -30,7 +34,7 @@ def draw_single(seed):
                 scale=float(rng.choice([0.2, 1.0, 3.0])), rng=rng)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(SOAK or 24))
 def test_random_step_matches_oracle(seed):
     c = draw_single(seed)
     X, Y, Z = c["dims"]
@@ -58,9 +62,17 @@ def test_random_step_matches_oracle(seed):
         f.UpdateFrame(dt, k)
         f.Simulate(k)
         s.step()
+        if k == 0 and half:
+            # one step: the only freedom is the exp2 ulp inside the impulse ball flipping the binary16 rounding of a stored
+            # value (measured over 1000 seeds: 999 within 1e-5, one at 1.5e-5); the conversion itself is a separate RNE
+            # step on both sides -- a fused multiply-convert (v_fma_mixlo_f16) was what this test caught
+            f.Synchronize()
+            assert rel_l2(f.download(fx.FIELD_VELOCITY), s.velocity) < 1e-4, c
+            assert rel_l2(f.download(fx.FIELD_COLOR), s.color) < 1e-4, c
     f.Synchronize()
     gv, gc, gp = f.download(fx.FIELD_VELOCITY), f.download(fx.FIELD_COLOR), f.download(fx.FIELD_PRESSURE)
-    tol = 2e-3 if half else 1e-5                           # half: an exp2 ulp can flip a stored rounding (2^-11 relative)
+    # two steps: a flipped half moves the second step's back-trace and, in faithful mode, freeze decisions
+    tol = 1e-3 if half else 1e-5
     assert np.isfinite(gv).all() and np.isfinite(gc).all() and np.isfinite(gp).all(), c
     assert rel_l2(gv, s.velocity) < tol, c
     assert rel_l2(gc, s.color) < tol, c
@@ -89,7 +101,7 @@ def draw_slabs(seed):
                 rnd=int(rng.integers(1, hj + 1)), steps=int(rng.integers(2, 5)))
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(SOAK or 24))
 def test_random_slab_decomposition_is_bit_identical(seed):
     c = draw_slabs(seed)
     kw = dict(storage=c["storage"], jacobi_mode=c["mode"], jacobi_iters=c["iters"])
@@ -153,7 +165,7 @@ def draw_camera(seed):
                 fov=float(rng.choice([np.pi / 4, np.pi / 3, np.pi / 6])), rng=rng)
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(SOAK or 40))
 def test_random_camera_render_matches_oracle(seed):
     c = draw_camera(seed)
     X, (vw, vh), col = c["X"], c["vp"], density(c["X"])
