@@ -160,7 +160,7 @@ def draw_camera(seed):
     focus = (rng.standard_normal(3) * 2.0).astype(f32)
     vp = [(160, 120), (200, 150), (320, 200), (128, 256)][int(rng.integers(0, 4))]
     flags = int(rng.choice([fx.Fluid.OPTIMIZED, fx.Fluid.RAY_MARCH_CUBEMAP, fx.Fluid.SEPARATE_LIGHT_PASS, fx.Fluid.RAY_MARCH_DIRECT]))
-    return dict(X=X, eye=eye, up=up, focus=focus, vp=vp, flags=flags, use_sh=bool(rng.random() < 0.4),
+    return dict(X=X, eye=eye, up=up, focus=focus, vp=vp, flags=flags, use_sh=bool(rng.random() < 0.4), storage=str(rng.choice(["fp32", "fp16"])),
                 samples=(int(rng.choice([32, 48, 96, 192])), int(rng.choice([8, 16, 64]))),
                 fov=float(rng.choice([np.pi / 4, np.pi / 3, np.pi / 6])), rng=rng)
 
@@ -169,11 +169,13 @@ def draw_camera(seed):
 def test_random_camera_render_matches_oracle(seed):
     c = draw_camera(seed)
     X, (vw, vh), col = c["X"], c["vp"], density(c["X"])
+    if c["storage"] == "fp16":
+        col = col.astype(np.float16).astype(f32)               # what a fp16-storage context holds after the upload
     view = fx.look_at_lh(c["eye"], c["focus"], c["up"])
     proj = fx.perspective_fov_lh(f32(c["fov"]), vw / float(vh), 1.0, 1000.0)
     sh = (c["rng"].random((9, 3)) * np.array([[2.0]] + [[0.5]] * 8)).astype(f32) if c["use_sh"] else None
     f = fx.Fluid()
-    assert f.Init(vw, vh, (X, X, X))
+    assert f.Init(vw, vh, (X, X, X), storage=c["storage"])
     f.SetMaxSamples(*c["samples"])
     if sh is not None:
         f.SetSH(sh)
@@ -205,3 +207,57 @@ def test_random_camera_render_matches_oracle(seed):
             assert np.mean(got != out) < 5e-3 and np.abs(got - out).max() < 0.05, (c, float(np.mean(got != out)), float(np.abs(got - out).max()))
         else:
             assert np.mean(got != out) < 1e-4 and np.abs(got - out).max() < 1e-5, (c, float(np.mean(got != out)), float(np.abs(got - out).max()))
+
+
+@pytest.mark.parametrize("seed", range(SOAK or 24))
+def test_random_camera_resolve_and_sky_match_oracle(seed):
+    """cube map -> screen resolve (PSRayCastCube) of a fully random cube map and the sky pass (PSEnvironment) of a random
+    radiance cube under the random cameras: SV_TARGET bit for bit, the blended RGBA8 target exactly"""
+    c = draw_camera(seed)
+    rng = c["rng"]
+    (vw, vh) = c["vp"]
+    N = int(rng.choice([8, 16, 32]))
+    view = fx.look_at_lh(c["eye"], c["focus"], c["up"])
+    proj = fx.perspective_fov_lh(f32(c["fov"]), vw / float(vh), 1.0, 1000.0)
+    f = fx.Fluid()
+    assert f.Init(vw, vh, (N, N, N))
+    f.UpdateFrame(0.0, 0, view, proj, c["eye"])
+    fi = f.frame_info()
+    fr = orc.update_frame(view, proj, c["eye"], vw, vh, N, 192)[0]
+    S = fi.cube_size
+    cube = rng.integers(0, 256, (6, S, S, 4), dtype=np.uint8)
+    f.upload(fx.FIELD_CUBEMAP, cube)
+    wvp_i = np.array(list(fi.world_view_proj_i), f32).reshape(4, 4)
+    out, cov = orc.resolve_cube(cube, fr, wvp_i, vw, vh)
+    rgba = (float(rng.random()), float(rng.random()), float(rng.random()), 0.0)
+    f.ClearRenderTarget(rgba)
+    f.RenderCube(0)
+    f.Synchronize()
+    assert np.array_equal(f.download(fx.FIELD_TARGET_FLOAT).view(np.uint32), out.view(np.uint32)), c
+    target = np.empty((vh, vw, 4), np.uint8)
+    target[...] = [int(np.floor(f32(min(max(v, 0.0), 1.0)) * f32(255) + f32(0.5))) for v in rgba]
+    assert np.array_equal(f.download(fx.FIELD_TARGET), orc.blend_premultiplied(out, cov, target)), c
+    # sky
+    M = int(rng.choice([4, 16, 33]))
+    sky = (rng.random((6, M, M, 3)) ** 3 * 4.0).astype(f32)
+    f.SetEnvironment(sky)
+    f.RenderEnvironment(0)
+    f.Synchronize()
+    s2w = np.array(list(fi.screen_to_world), f32).reshape(4, 4)
+    want = orc.environment(sky, c["eye"], s2w, vw, vh)
+    assert np.array_equal(f.download(fx.FIELD_TARGET_FLOAT).view(np.uint32), want.view(np.uint32)), c
+
+
+@pytest.mark.parametrize("seed", range(SOAK or 12))
+def test_random_sh_projection_matches_oracle(seed):
+    rng = np.random.default_rng(12000 + seed)
+    n = int(rng.choice([4, 8, 16, 24, 32, 64, 100, 128]))
+    cube = (rng.random((6, n, n, 3)) ** 2 * 3.0).astype(f32)
+    f = fx.Fluid()
+    assert f.Init(64, 64, (16, 16, 16))
+    probe = fx.LightProbe(f)
+    probe.Init(cube)
+    probe.TransformSH()
+    got = np.asarray(probe.GetSH(), f32).reshape(9, 3)
+    want = np.asarray(orc.sh_transform(cube), f32).reshape(9, 3)
+    assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max()), (n, float(np.abs(got - want).max()))
