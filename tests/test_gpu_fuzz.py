@@ -261,3 +261,61 @@ def test_random_sh_projection_matches_oracle(seed):
     got = np.asarray(probe.GetSH(), f32).reshape(9, 3)
     want = np.asarray(orc.sh_transform(cube), f32).reshape(9, 3)
     assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max()), (n, float(np.abs(got - want).max()))
+
+
+@pytest.mark.parametrize("seed", range(SOAK or 12))
+def test_random_call_sequences_leave_the_simulation_alone(seed, tmp_path):
+    """API state machine: one context runs its simulation steps interleaved with a random mix of everything else the ABI offers
+    (renders in every mode, sky, resolve, downloads, timing on/off, sample counts, SH on/off, a checkpoint save + reload of its
+    own state, paused frames); a second context runs the steps alone.  The fields must come out bit-identical."""
+    rng = np.random.default_rng(20000 + seed)
+    X = int(rng.choice([16, 24, 32]))
+    storage = str(rng.choice(["fp32", "fp16"]))
+    vp = [(96, 64), (160, 120), (64, 96)][int(rng.integers(0, 3))]
+    kw = dict(storage=storage, jacobi_iters=int(rng.integers(2, 12)), jacobi_mode=str(rng.choice(["fixed", "faithful"])))
+    a, b = fx.Fluid(), fx.Fluid()
+    assert a.Init(vp[0], vp[1], (X, X, X), **kw) and b.Init(vp[0], vp[1], (X, X, X), **kw)
+    view, proj, eye = fx.default_camera(*vp)
+    dt = f32(a.default_time_step())
+    sky = (rng.random((6, 8, 8, 3)) * 2).astype(f32)
+    ck = str(tmp_path / "state.fxck")
+    for f in (a, b):
+        f.UpdateFrame(0.0, 0, view, proj, eye)                 # Render / RenderEnvironment before the first frame are call-order errors
+    steps = 0
+    for op in rng.integers(0, 12, size=40):
+        k = steps % 3
+        if op <= 3:                                            # a simulation step on both
+            for f in (a, b):
+                f.UpdateFrame(dt, k, view, proj, eye)
+                f.Simulate(k)
+            steps += 1
+        elif op == 4:
+            a.UpdateFrame(0.0, k, view, proj, eye)             # paused frame: velocity copied, nothing else moves
+            a.Simulate(k)
+            b.UpdateFrame(0.0, k, view, proj, eye)
+            b.Simulate(k)
+        elif op == 5:
+            a.SetMaxSamples(int(rng.integers(8, 64)), int(rng.integers(4, 32)))
+            a.ClearRenderTarget()
+            a.Render(k, int(rng.integers(0, 4)), to_target=bool(rng.integers(0, 2)))
+        elif op == 6:
+            a.SetSH((rng.random((9, 3)) * 0.5).astype(f32) if rng.random() < 0.7 else None)
+        elif op == 7:
+            a.SetEnvironment(sky)
+            a.ClearRenderTarget()
+            a.RenderEnvironment(k)
+            a.RenderCube(k)
+        elif op == 8:
+            a.timing_enable(bool(rng.integers(0, 2)))
+            a.timing_read(bool(rng.integers(0, 2)))
+        elif op == 9:
+            a.download(int(rng.choice([fx.FIELD_VELOCITY, fx.FIELD_COLOR, fx.FIELD_PRESSURE, fx.FIELD_VELOCITY1, fx.FIELD_DIVERGENCE])))
+        elif op == 10:
+            a.SaveCheckpoint(ck)
+            a.LoadCheckpoint(ck)                               # its own state back in: a no-op for the fields
+        else:
+            a.Synchronize()
+    a.Synchronize()
+    b.Synchronize()
+    for field in (fx.FIELD_VELOCITY, fx.FIELD_COLOR, fx.FIELD_PRESSURE):
+        assert np.array_equal(a.download(field), b.download(field)), (seed, field)
