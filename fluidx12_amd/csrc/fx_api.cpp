@@ -633,7 +633,7 @@ int fx_update_frame(fx_ctx* ctx, float time_step, uint8_t frame_index,
 	for_members(ctx, M);
 	if (!is_driver(ctx) || group_broken(ctx)) return FX_E_STATE;
 	for (fx_ctx* c : M) {
-		if (c->g.Zg > 1 && view && proj && eye) {
+		if (c->g.Zg > 1 && view && proj && eye && c->desc.viewport_w && c->desc.viewport_h) {   // a context without a viewport only simulates
 			// Fluid.cpp:296-334
 			const Mat4 world = Mat4::scaling(10.0f, 10.0f, 10.0f);              // m_volumeWorld, Fluid.cpp:182
 			const Mat4 worldI = world.inverse();
@@ -741,6 +741,7 @@ int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags)
 		if (ctx->timing_on) ctx->acc.renders += 1;
 		return FX_OK;
 	}
+	if (!ctx->desc.viewport_w || !ctx->desc.viewport_h) return FX_E_INVALID;   // created without a viewport: nothing to project the cube onto
 	if (!ctx->view_valid) return FX_E_STATE;
 	if (ctx->g.nz != ctx->g.Zg) return FX_E_INVALID;            // rays cross slabs: multi-GPU rendering is row f-3
 	if (!(flags & FX_RAY_MARCH_CUBEMAP)) {

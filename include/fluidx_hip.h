@@ -71,7 +71,7 @@ typedef struct fx_ctx fx_ctx;
 typedef struct fx_desc {
 	uint32_t struct_size;       /* = sizeof(fx_desc)                                        */
 	uint32_t grid_x, grid_y, grid_z;    /* global grid; grid_x == grid_y (Fluid.cpp:201); grid_z == 1 -> 2D */
-	uint32_t viewport_w, viewport_h;    /* Init(width, height)                              */
+	uint32_t viewport_w, viewport_h;    /* Init(width, height); 0 x 0 = a context that only simulates (fx_render: FX_E_INVALID) */
 	uint32_t storage;           /* fx_storage                                               */
 	uint32_t jacobi_iters;      /* N (BASELINE: 20/40/80; reference faithful: 64)           */
 	uint32_t jacobi_mode;       /* fx_jacobi_mode                                           */

@@ -319,3 +319,53 @@ def test_random_call_sequences_leave_the_simulation_alone(seed, tmp_path):
     b.Synchronize()
     for field in (fx.FIELD_VELOCITY, fx.FIELD_COLOR, fx.FIELD_PRESSURE):
         assert np.array_equal(a.download(field), b.download(field)), (seed, field)
+
+
+@pytest.mark.parametrize("seed", range(SOAK or 40))
+def test_random_descriptors_fail_cleanly_or_work(seed):
+    """fx_create with random descriptors -- half of them deliberately broken (zero / unequal extents, unknown enum values,
+    slabs outside the grid or thinner than their halo, wrong struct size, unknown flags): every call returns FX_OK or a negative
+    status and leaves no context behind on failure; what it accepts can step, render, report and be destroyed"""
+    import ctypes as C
+    rng = np.random.default_rng(30000 + seed)
+    lib = capi.load()
+    pick = lambda good, bad, p=0.85: int(rng.choice(good) if rng.random() < p else rng.choice(bad))
+    d = capi.Desc()
+    d.struct_size = pick([C.sizeof(capi.Desc)], [0, 4, C.sizeof(capi.Desc) - 4, C.sizeof(capi.Desc) + 8], 0.95)
+    S = pick([4, 8, 12, 20, 32, 36, 64, 100], [0, 1, 2, 3, 5, 7])
+    d.grid_x, d.grid_y = S, (S if rng.random() < 0.9 else S + 4)
+    d.grid_z = pick([1, 2, 3, 8, 17, 32, 40], [0])
+    d.viewport_w, d.viewport_h = pick([16, 64, 200], [0]), pick([16, 48, 150], [0])
+    d.storage, d.jacobi_mode, d.advect_address = pick([0, 1], [2, 7, 255]), pick([0, 1], [2, 9]), pick([0, 1], [2, 3])
+    d.jacobi_iters = pick([1, 2, 5, 20, 64], [0])
+    d.device = pick([-1, 0], [1, 7, -2, 99], 0.9)
+    if rng.random() < 0.35:
+        d.slab_z0, d.slab_nz = int(rng.integers(0, 45)), int(rng.integers(0, 45))
+        d.halo_advect, d.halo_jacobi = int(rng.integers(0, 12)), int(rng.integers(0, 12))
+    d.flags = int(rng.integers(0, 5)) | (0x10 if rng.random() < 0.2 else 0) | (0x20 if rng.random() < 0.15 else 0) | (int(rng.integers(1, 1 << 20)) << 8 if rng.random() < 0.1 else 0)
+    ctx = C.c_void_p()
+    rc = lib.fx_create(C.byref(ctx), C.byref(d))
+    assert rc in (capi.FX_OK, capi.FX_E_INVALID, capi.FX_E_DEVICE, capi.FX_E_NOMEM, capi.FX_E_STATE), rc
+    if rc != capi.FX_OK:
+        assert not ctx.value
+        return
+    try:
+        whole = d.slab_nz == 0 or (d.slab_z0 == 0 and d.slab_nz == d.grid_z)
+        view, proj, eye = fx.default_camera(max(d.viewport_w, 1), max(d.viewport_h, 1))
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        v, p_, e = (np.ascontiguousarray(m, f32) for m in (view, proj, eye))
+        assert lib.fx_update_frame(ctx, C.c_float(1.0 / max(d.grid_y, 1)), 0, fp(v), fp(p_), fp(e)) == capi.FX_OK
+        rc = lib.fx_simulate(ctx, None, 0)
+        assert rc == (capi.FX_E_STATE if d.flags & 0x20 else capi.FX_OK), rc        # render-only contexts do not simulate
+        if whole and d.grid_z > 1:
+            rflags = int(rng.integers(0, 4))
+            rc = lib.fx_render(ctx, None, 0, rflags)
+            no_viewport = d.viewport_w == 0 or d.viewport_h == 0       # a simulate-only context: rendering is an argument error
+            assert rc == (capi.FX_E_INVALID if no_viewport else capi.FX_OK), (rc, rflags, [getattr(d, n) for n, _ in capi.Desc._fields_])
+        rc = lib.fx_synchronize(ctx)
+        assert rc in (capi.FX_OK, capi.FX_E_HALO), rc       # a lone slab context has no neighbour data: its halo check may fire
+        fi = capi.FrameInfo()
+        assert lib.fx_get_frame_info(ctx, C.byref(fi)) == capi.FX_OK
+        assert lib.fx_field_bytes(ctx, 99) == 0 and lib.fx_download(ctx, 99, C.byref(fi), 4) < 0
+    finally:
+        assert lib.fx_destroy(ctx) == capi.FX_OK
