@@ -212,7 +212,9 @@ bool dds_bc6h_cube_layout(const void* dds, size_t bytes, uint32_t* size, uint32_
 	std::memcpy(dx, p + 128, sizeof dx);
 	if (h[0] != 124 || h[18] != 32 || std::memcmp(&h[20], "DX10", 4) != 0) return false;
 	const uint32_t height = h[2], width = h[3], nm = h[6] ? h[6] : 1;
-	if (dx[0] != 95 /* DXGI_FORMAT_BC6H_UF16 */ || !(dx[2] & 4u) /* TEXTURECUBE */ || width != height || !width || nm > 16) return false;
+	if (dx[0] != 95 /* DXGI_FORMAT_BC6H_UF16 */ || !(dx[2] & 4u) /* TEXTURECUBE */ || width != height || !width || nm > 15) return false;
+	// D3D11's largest texture extent; also keeps (width + 3) inside 32 bits (0xFFFFFFFF used to wrap to a zero-block face and pass)
+	if (width > 16384u || (nm > 1 && (width >> (nm - 1)) == 0)) return false;
 	size_t per_face = 0;
 	for (uint32_t m = 0; m < nm; ++m) {
 		const size_t nb = ((width >> m ? width >> m : 1) + 3) / 4;

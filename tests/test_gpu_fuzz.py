@@ -369,3 +369,49 @@ def test_random_descriptors_fail_cleanly_or_work(seed):
         assert lib.fx_field_bytes(ctx, 99) == 0 and lib.fx_download(ctx, 99, C.byref(fi), 4) < 0
     finally:
         assert lib.fx_destroy(ctx) == capi.FX_OK
+
+
+@pytest.mark.parametrize("seed", range(SOAK or 40))
+def test_mutated_dds_files_never_crash_the_decoder(seed):
+    """the DDS / BC6H container parser on damaged input: random byte flips in the header, truncation, absurd sizes and mip
+    counts -- fx_dds_cube_info / fx_dds_decode_cube either succeed with consistent sizes or return a negative status"""
+    import ctypes as C
+    import os
+    rng = np.random.default_rng(40000 + seed)
+    data = bytearray(open(os.path.join(os.path.dirname(__file__), "..", "examples", "data", "probe_32.dds"), "rb").read())
+    kind = int(rng.integers(0, 5))
+    if kind == 0:                                              # flip bytes in the 148-byte header
+        for _ in range(int(rng.integers(1, 6))):
+            data[int(rng.integers(0, 148))] = int(rng.integers(0, 256))
+    elif kind == 1:                                            # truncate anywhere
+        data = data[:int(rng.integers(0, len(data)))]
+    elif kind == 2:                                            # huge / zero extents and mip counts
+        for off in (12, 16, 28):
+            if rng.random() < 0.6:
+                data[off:off + 4] = int(rng.choice([0, 1, 3, 1 << 16, 1 << 30, 0xFFFFFFFF])).to_bytes(4, "little")
+    elif kind == 3:                                            # payload garbage (every block decodes to something)
+        for _ in range(64):
+            data[int(rng.integers(148, len(data)))] = int(rng.integers(0, 256))
+    lib = capi.load()
+    f = fx.Fluid()
+    assert f.Init(64, 64, (16, 16, 16))
+    buf = (C.c_char * max(len(data), 1)).from_buffer_copy(bytes(data) if len(data) else b"\0")
+    size, mips = C.c_uint32(), C.c_uint32()
+    rc = lib.fx_dds_cube_info(buf, len(data), C.byref(size), C.byref(mips))
+    assert rc <= 0
+    if rc != capi.FX_OK:
+        out = np.zeros(6 * 4 * 4 * 3, f32)
+        assert lib.fx_dds_decode_cube(f._ctx, buf, len(data), 0, out.ctypes.data_as(C.POINTER(C.c_float)), out.size) < 0
+        return
+    assert 1 <= size.value <= 16384 and 1 <= mips.value <= 15
+    mip = int(rng.integers(0, mips.value + 2))
+    n = max(size.value >> mip, 1)
+    if 6 * n * n * 3 > (1 << 26):
+        return
+    out = np.zeros(6 * n * n * 3, f32)
+    rc = lib.fx_dds_decode_cube(f._ctx, buf, len(data), mip, out.ctypes.data_as(C.POINTER(C.c_float)), out.size)
+    assert rc == capi.FX_OK or rc < 0
+    if mip >= mips.value:
+        assert rc < 0
+    if rc == capi.FX_OK and kind == 4:
+        assert np.isfinite(out).all()
