@@ -163,6 +163,7 @@ int orc_dds_bc6h_cube_face(const uint8_t* dds, size_t bytes, int face, int mip, 
 	std::memcpy(dx, dds + 128, 20);
 	if (h[0] != 124 || h[18] != 32 || std::memcmp(&h[20], "DX10", 4) != 0) return 0;
 	if (dx[0] != 95 || !(dx[2] & 4u) || width != height || face < 0 || face > 5 || mip < 0 || (uint32_t)mip >= mips) return 0;
+	if (!width || width > 16384u || mips > 15) return 0;                 // same bounds as the product's parser: (width + 3) must not wrap
 	size_t face_bytes = 0, mip_off = 0;
 	for (uint32_t m = 0; m < mips; ++m) {
 		const size_t bw = std::max<uint32_t>(1, ((width >> m) + 3) / 4);
