@@ -415,3 +415,45 @@ def test_mutated_dds_files_never_crash_the_decoder(seed):
         assert rc < 0
     if rc == capi.FX_OK and kind == 4:
         assert np.isfinite(out).all()
+
+
+@pytest.mark.parametrize("seed", range(SOAK or 24))
+def test_damaged_checkpoint_files_are_refused(seed, tmp_path):
+    rng = np.random.default_rng(50000 + seed)
+    dims = (8, 8, 6)
+    f = fx.Fluid()
+    assert f.Init(32, 32, dims, jacobi_iters=4)
+    for k in range(2):
+        f.UpdateFrame(f32(f.default_time_step()), k)
+        f.Simulate(k)
+    good = tmp_path / "good.fxck"
+    f.SaveCheckpoint(str(good))
+    want = {fid: f.download(fid) for fid in (fx.FIELD_VELOCITY, fx.FIELD_COLOR, fx.FIELD_PRESSURE)}
+    data = bytearray(good.read_bytes())
+    kind = int(rng.integers(0, 4))
+    ok_expected = False
+    if kind == 0:
+        data = data[:int(rng.integers(0, len(data)))]                       # truncated
+    elif kind == 1:
+        off = int(rng.choice([0, 3, 8, 12, 16]))                            # magic or an extent
+        data[off] ^= int(rng.integers(1, 256))
+    elif kind == 2:
+        data += bytes(int(rng.integers(1, 64)))                             # trailing bytes
+    else:
+        data[int(rng.integers(64, len(data)))] ^= 0x01                      # payload: still a valid file of this grid
+        ok_expected = True
+    bad = tmp_path / "bad.fxck"
+    bad.write_bytes(bytes(data))
+    g2 = fx.Fluid()
+    assert g2.Init(32, 32, dims, jacobi_iters=4)
+    if ok_expected:
+        g2.LoadCheckpoint(str(bad))
+    else:
+        with pytest.raises(fx.FluidxError):
+            g2.LoadCheckpoint(str(bad))
+        # a refused file leaves the context usable, and the good one still loads
+        g2.LoadCheckpoint(str(good))
+        for fid, w in want.items():
+            assert np.array_equal(g2.download(fid), w)
+    with pytest.raises(fx.FluidxError):
+        g2.LoadCheckpoint(str(tmp_path / "missing.fxck"))
