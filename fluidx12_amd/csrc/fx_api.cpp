@@ -1280,8 +1280,14 @@ int fx_comm_init_local(fx_ctx** ctxs, int nranks)
 		int rc = check_slab_chain(ctxs[r], r, nranks);
 		if (rc) return rc;
 		if (ctxs[r]->g.z0 != zexp || ctxs[r]->device != ctxs[0]->device) return FX_E_INVALID;   // contiguous chain, one device
-		if (ctxs[r]->desc.halo_advect != ctxs[0]->desc.halo_advect || ctxs[r]->desc.halo_jacobi != ctxs[0]->desc.halo_jacobi)
+		// every member must describe the same run (the RCCL path checks a digest of the same fields across the ranks): members
+		// of different grids would exchange planes of different sizes
+		const fx_desc &a = ctxs[r]->desc, &b = ctxs[0]->desc;
+		if (a.grid_x != b.grid_x || a.grid_y != b.grid_y || a.grid_z != b.grid_z || a.halo_advect != b.halo_advect ||
+			a.halo_jacobi != b.halo_jacobi || a.jacobi_iters != b.jacobi_iters || a.jacobi_mode != b.jacobi_mode ||
+			a.storage != b.storage || a.advect_address != b.advect_address)
 			return FX_E_INVALID;
+		for (int q = 0; q < r; ++q) if (ctxs[q] == ctxs[r]) return FX_E_INVALID;
 		zexp += ctxs[r]->g.nz;
 	}
 	fx_comm_group* g = new fx_comm_group();

@@ -457,3 +457,59 @@ def test_damaged_checkpoint_files_are_refused(seed, tmp_path):
             assert np.array_equal(g2.download(fid), w)
     with pytest.raises(fx.FluidxError):
         g2.LoadCheckpoint(str(tmp_path / "missing.fxck"))
+
+
+@pytest.mark.parametrize("seed", range(SOAK or 40))
+def test_random_slab_groups_are_validated(seed):
+    """fx_comm_init_local with random member lists: a contiguous chain of like contexts is accepted and steps; anything else
+    (gaps, overlaps, wrong order, a whole-grid member, members of another grid / storage / sweep count / halo, the same context
+    twice, a member already in a group) is refused with a status -- never a crash, a hang or a corrupted neighbour"""
+    import ctypes as C
+    rng = np.random.default_rng(60000 + seed)
+    lib = capi.load()
+    S, Z = 32, 48
+    base = dict(storage="fp32", jacobi_iters=6, halo_advect=6, halo_jacobi=4)
+    cuts = [0, 16, 32, 48]
+    members, valid = [], True
+    for r in range(3):
+        kw, dims, slab = dict(base), (S, S, Z), (cuts[r], cuts[r + 1] - cuts[r])
+        fault = int(rng.integers(0, 14)) if rng.random() < 0.5 else -1
+        if fault == 0: dims = (S, S, Z + 16 * (r == 2)); valid &= r != 2
+        elif fault == 1: dims = (64, 64, Z); valid = False
+        elif fault == 2: kw["storage"] = "fp16"; valid = False
+        elif fault == 3: kw["jacobi_iters"] = 7; valid = False
+        elif fault == 4: kw["halo_jacobi"] = 5; valid = False
+        elif fault == 5: kw["halo_advect"] = 8; valid = False
+        elif fault == 6: slab = (slab[0] + 1, slab[1] - 1) if r else (slab[0], slab[1] - 1); valid = False      # gap
+        elif fault == 7: slab = None; valid = False                                                         # whole grid
+        elif fault == 8: kw["jacobi_mode"] = "faithful"; valid = False
+        elif fault == 9: kw["advect_address"] = "mirror"; valid = False
+        f = fx.Fluid()
+        assert f.Init(64, 64, dims, slab=slab, **kw), f.last_status
+        members.append(f)
+    order = list(range(3))
+    twist = rng.random()
+    if twist < 0.15:
+        order = [int(i) for i in rng.permutation(3)]
+        valid &= order == [0, 1, 2]
+    elif twist < 0.25:
+        order = [0, 1, 1]; valid = False
+    elif twist < 0.33:
+        order = [0, 1]; valid = False                        # the chain stops short of the grid
+    arr = (C.c_void_p * len(order))(*[members[i]._ctx for i in order])
+    rc = lib.fx_comm_init_local(arr, len(order))
+    assert rc == (capi.FX_OK if valid else capi.FX_E_INVALID), (rc, valid, order)
+    if rc == capi.FX_OK:
+        assert lib.fx_comm_init_local(arr, len(order)) == capi.FX_E_STATE          # already grouped
+        dt = f32(members[0].default_time_step())
+        for k in range(2):
+            members[0].UpdateFrame(dt, k)
+            members[0].Simulate(k)
+        members[0].Synchronize()
+        assert np.isfinite(members[1].download(fx.FIELD_PRESSURE)).all()
+    else:
+        # refused: every member is still a free context that can be destroyed (or grouped properly later)
+        for m in members:
+            assert m.frame_info() is not None
+    for m in members:
+        m.Release()
