@@ -1237,7 +1237,8 @@ int fx_comm_gather_color(fx_ctx* ctx, void* stream, fx_ctx* full, int root, cons
 	for (int r = 0; r < ctx->nranks; ++r) {
 		const fx_ctx* m = local ? ctx->group->members[r] : (r == ctx->rank ? ctx : nullptr);
 		const uint32_t z0 = local ? (uint32_t)m->g.z0 : slab_z0[r], nz = local ? (uint32_t)m->g.nz : slab_nz[r];
-		if (z0 + nz > (uint32_t)ctx->g.Zg) return FX_E_INVALID;
+		if (z0 > (uint32_t)ctx->g.Zg || nz > (uint32_t)ctx->g.Zg - z0) return FX_E_INVALID;   // (z0 + nz would wrap for absurd input)
+		if (!local && r == ctx->rank && (z0 != (uint32_t)ctx->g.z0 || nz != (uint32_t)ctx->g.nz)) return FX_E_INVALID;   // what this rank sends is its own slab
 		parts[r].rank = r;
 		parts[r].bytes = (size_t)nz * plane_bytes;
 		parts[r].src = m ? (const char*)m->col[m->frame_parity] + (size_t)m->g.H * plane_bytes : nullptr;
