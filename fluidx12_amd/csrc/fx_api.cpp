@@ -16,7 +16,10 @@
 
 using namespace fx;
 
-#define FX_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+// A failed HIP call also leaves its code in the runtime's sticky "last error": the launch helpers end in hipGetLastError(), and a
+// stale out-of-memory from one context's failed fx_create would otherwise surface as the status of the next, unrelated launch
+// (found by the descriptor fuzz).  Reading the last error here clears it.
+#define FX_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (void)hipGetLastError(); \
 	ctx->last_error = std::string(#call) + ": " + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? FX_E_NOMEM : FX_E_DEVICE; } } while (0)
 
 namespace {

@@ -162,7 +162,7 @@ struct RcclTransport : Transport {
 	int min_over_ranks(int v, hipStream_t s, int* out) override
 	{
 		int* d = nullptr;
-		if (hipMalloc((void**)&d, sizeof(int)) != hipSuccess) return FX_E_NOMEM;
+		if (hipMalloc((void**)&d, sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return FX_E_NOMEM; }   // (clears the sticky last error)
 		int rc = FX_OK;
 		if (hipMemcpyAsync(d, &v, sizeof v, hipMemcpyHostToDevice, s) != hipSuccess) rc = FX_E_DEVICE;
 		if (rc == FX_OK && api->AllReduce(d, d, 1, ncclInt32, ncclMin, comm, s) != ncclSuccess) rc = FX_E_COMM;
