@@ -520,3 +520,53 @@ def test_random_slab_groups_are_validated(seed):
             assert m.frame_info() is not None
     for m in members:
         m.Release()
+
+
+def test_every_entry_point_refuses_null_and_nonsense():
+    """each ABI call with a NULL context, NULL buffers, unknown enum values or sizes that do not fit: a negative status (or 0
+    bytes), never a crash"""
+    import ctypes as C
+    lib = capi.load()
+    null = C.c_void_p()
+    fbuf = (C.c_float * 64)()
+    fi, tm = capi.FrameInfo(), capi.Timing()
+    u = C.c_uint32()
+    calls = [
+        lambda c: lib.fx_destroy(c), lambda c: lib.fx_set_max_samples(c, 1, 1), lambda c: lib.fx_set_sh(c, fbuf),
+        lambda c: lib.fx_update_frame(c, C.c_float(0.1), 0, fbuf, fbuf, fbuf), lambda c: lib.fx_simulate(c, None, 0),
+        lambda c: lib.fx_render(c, None, 0, 3), lambda c: lib.fx_get_frame_info(c, C.byref(fi)), lambda c: lib.fx_synchronize(c),
+        lambda c: lib.fx_upload(c, 0, fbuf, 256), lambda c: lib.fx_download(c, 0, fbuf, 256),
+        lambda c: lib.fx_checkpoint_save(c, b"/tmp/x.fxck"), lambda c: lib.fx_checkpoint_load(c, b"/tmp/x.fxck"),
+        lambda c: lib.fx_advect(c, None), lambda c: lib.fx_divergence(c, None), lambda c: lib.fx_jacobi(c, None, 1),
+        lambda c: lib.fx_project(c, None), lambda c: lib.fx_sh_transform(c, fbuf, 1, fbuf), lambda c: lib.fx_set_environment(c, fbuf, 1),
+        lambda c: lib.fx_render_environment(c, None, 0), lambda c: lib.fx_clear_render_target(c, None, fbuf),
+        lambda c: lib.fx_render_cube(c, None, 0), lambda c: lib.fx_timing_enable(c, 1), lambda c: lib.fx_timing_read(c, C.byref(tm), 0),
+        lambda c: lib.fx_set_option(c, 1, 1), lambda c: lib.fx_comm_gather_color(c, None, None, 0, None, None),
+        lambda c: lib.fx_dds_decode_cube(c, fbuf, 256, 0, fbuf, 64),
+    ]
+    for i, call in enumerate(calls):
+        assert call(null) < 0, i
+    assert lib.fx_field_bytes(null, 0) == 0
+    assert lib.fx_dds_cube_info(None, 0, C.byref(u), C.byref(u)) < 0
+    assert lib.fx_comm_init_local(None, 2) < 0 and lib.fx_comm_get_unique_id(None, 0) < 0
+    assert lib.fx_create(None, None) < 0 and lib.fx_create(C.byref(null), None) < 0
+    # a live context with nonsense arguments
+    f = fx.Fluid()
+    assert f.Init(32, 32, (16, 16, 16))
+    c = f._ctx
+    assert lib.fx_update_frame(c, C.c_float(0.1), 3, fbuf, fbuf, fbuf) < 0 and lib.fx_simulate(c, None, 7) < 0 and lib.fx_render(c, None, 9, 3) < 0
+    assert lib.fx_upload(c, 0, None, 4) < 0 and lib.fx_upload(c, 0, fbuf, 4) < 0 and lib.fx_upload(c, 77, fbuf, 256) < 0
+    assert lib.fx_download(c, 2, fbuf, 1) < 0 and lib.fx_download(c, -1, fbuf, 256) < 0 and lib.fx_download(c, 8, fbuf, 256) < 0   # no target yet
+    assert lib.fx_set_option(c, 99, 1) < 0 and lib.fx_set_option(c, 1, 3) < 0 and lib.fx_set_option(c, 2, 0) < 0
+    assert lib.fx_sh_transform(c, None, 4, fbuf) < 0 and lib.fx_sh_transform(c, fbuf, 0, fbuf) < 0 and lib.fx_sh_transform(c, fbuf, 1 << 20, fbuf) < 0
+    assert lib.fx_set_environment(c, fbuf, 0) < 0 and lib.fx_set_environment(c, fbuf, 1 << 20) < 0
+    assert lib.fx_jacobi(c, None, 0) < 0 and lib.fx_get_frame_info(c, None) < 0 and lib.fx_timing_read(c, None, 0) < 0
+    assert lib.fx_checkpoint_save(c, None) < 0 and lib.fx_checkpoint_save(c, b"") < 0 and lib.fx_checkpoint_load(c, b"/nonexistent/dir/x") < 0
+    assert lib.fx_checkpoint_save(c, b"/nonexistent/dir/x") < 0
+    assert lib.fx_comm_gather_color(c, None, c, 0, None, None) < 0                       # not in a group
+    assert lib.fx_clear_render_target(c, None, None) <= 0
+    # and it still works
+    f.UpdateFrame(f32(f.default_time_step()), 0)
+    f.Simulate(0)
+    f.Synchronize()
+    assert f.download(fx.FIELD_COLOR).any()
