@@ -570,3 +570,41 @@ def test_every_entry_point_refuses_null_and_nonsense():
     f.Simulate(0)
     f.Synchronize()
     assert f.download(fx.FIELD_COLOR).any()
+
+
+def test_contexts_on_concurrent_host_threads_do_not_interfere():
+    """separate contexts driven from separate host threads (ctypes drops the GIL inside every call): each thread's fields equal
+    the same run done alone -- no shared mutable state behind the ABI besides the per-context one"""
+    import threading
+    configs = [((32, 32, 32), "fp32", 10, "fixed"), ((48, 48, 20), "fp16", 7, "faithful"), ((64, 64, 1), "fp32", 12, "fixed"),
+               ((40, 40, 24), "fp32", 5, "fixed"), ((32, 32, 32), "fp16", 9, "fixed"), ((256, 256, 64), "fp32", 6, "fixed")]
+
+    def run(cfg, out, idx, noisy):
+        dims, storage, iters, mode = cfg
+        f = fx.Fluid()
+        assert f.Init(96, 64, dims, storage=storage, jacobi_iters=iters, jacobi_mode=mode)
+        view, proj, eye = fx.default_camera(96, 64)
+        for k in range(6):
+            f.UpdateFrame(f32(f.default_time_step()), k % 3, view, proj, eye)
+            f.Simulate(k % 3)
+            if noisy and dims[2] > 1 and k % 2:
+                f.Render(k % 3, fx.Fluid.OPTIMIZED, to_target=True)
+                f.download(fx.FIELD_PRESSURE)
+        f.Synchronize()
+        out[idx] = (f.download(fx.FIELD_VELOCITY), f.download(fx.FIELD_COLOR), f.download(fx.FIELD_PRESSURE))
+        f.Release()
+
+    alone = [None] * len(configs)
+    for i, cfg in enumerate(configs):
+        run(cfg, alone, i, False)
+    for _ in range(3):
+        together = [None] * len(configs)
+        threads = [threading.Thread(target=run, args=(cfg, together, i, True)) for i, cfg in enumerate(configs)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for i in range(len(configs)):
+            assert together[i] is not None, i
+            for a, b in zip(alone[i], together[i]):
+                assert np.array_equal(a, b), configs[i]
