@@ -70,6 +70,13 @@ def workload_grid(G, N, scaling):
 SCHEDULE_CANDIDATES = [(1, 8), (2, 8), (2, 4), (0, 8)]
 
 
+def pressure_round(GX, nz_per_rank, iters):
+    """sweeps per pressure exchange.  Slab ranks thick enough for the three-sweep kernel (X = 256, >= 12.6 M cells) take rounds
+    of 9 = 3 + 3 + 3 (40 sweeps = 4 x 9 + 2 + 2: twelve launches of three and two of two, like the single domain) instead of
+    8 = 3 + 3 + 2; everything else keeps the library default of 8."""
+    return 9 if (GX == 256 and GX * GX * nz_per_rank >= 3 << 22 and iters >= 9) else 8
+
+
 def slab_for_rank(Z, rank, world):
     z0 = rank * Z // world
     z1 = (rank + 1) * Z // world
@@ -182,7 +189,8 @@ def main():
             f_ = fx.Fluid()
             ok = f_.Init(1920, 1080, (GX, GY, GZ), storage=args.storage, jacobi_iters=args.iters, jacobi_mode="fixed",
                          advect_address="clamp", device=local_rank if (N > 1 and not loop) else -1,
-                         slab=(z0r, nzr) if N > 1 else None, halo_advect=halo_adv)
+                         slab=(z0r, nzr) if N > 1 else None, halo_advect=halo_adv,
+                         halo_jacobi=pressure_round(GX, GZ // N, args.iters) if N > 1 else 0)
             if not ok:
                 raise SystemExit("Fluid.Init failed (status %d): the HIP library needs a MI355X" % f_.last_status)
             members.append(f_)
@@ -249,7 +257,8 @@ def main():
         else:
             tried = []
             kk = 0
-            for ov, rnd in SCHEDULE_CANDIDATES:
+            K = pressure_round(GX, GZ // N, args.iters)
+            for ov, rnd in [(o, K if r == 8 else r) for o, r in SCHEDULE_CANDIDATES]:
                 apply(ov, rnd)
                 one_step(kk); kk += 1
                 barrier_sync()
