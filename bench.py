@@ -66,8 +66,9 @@ def workload_grid(G, N, scaling):
 
 
 # (FX_OPT_OVERLAP, FX_OPT_JACOBI_ROUND): advection halo behind the interior advection + serial pressure rounds of 8 sweeps;
-# pressure exchanges behind the interior sweeps of rounds of 8 and of 4 sweeps (face planes first); nothing overlapped
-SCHEDULE_CANDIDATES = [(1, 8), (2, 8), (2, 4), (0, 8)]
+# pressure exchanges behind the interior sweeps of rounds of 8 (also with the next step's colour halo sent behind the pressure
+# phase) and of 4 sweeps (face planes first); nothing overlapped
+SCHEDULE_CANDIDATES = [(1, 8), (2, 8), (3, 8), (2, 4), (0, 8)]
 
 
 def pressure_round(GX, nz_per_rank, iters):

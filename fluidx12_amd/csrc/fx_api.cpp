@@ -157,7 +157,8 @@ int for_members(fx_ctx* ctx, std::vector<fx_ctx*>& out)
 
 bool multi_rank(const fx_ctx* c) { return c->group && c->nranks > 1; }
 
-// 0 = no side stream, 1 = advection halo overlapped, 2 = pressure rounds overlapped as well (fx_set_option)
+// 0 = no side stream, 1 = advection halo overlapped, 2 = pressure rounds overlapped as well, 3 = and the colour half of the
+// next step's advection halo travels behind this step's pressure phase (fx_set_option)
 int overlap_level(const fx_ctx* lead)
 {
 	if (!multi_rank(lead) || !lead->group->comm_stream) return 0;
@@ -222,7 +223,14 @@ int advect_all(fx_ctx* ctx, std::vector<fx_ctx*>& M, hipStream_t s)
 {
 	int rc;
 	const int Ha = (int)ctx->desc.halo_advect;
-	const ExchSpec spec{ EX_ADVECT_IN, Ha, 0 };
+	// FX_OPT_OVERLAP 3: the previous step already sent the colour planes this advection gathers from (simulate_impl); only
+	// the velocity, which the projection has just finished, travels now.  Every rank of a chain takes the same branch: the
+	// flag follows from the option level and the step history alone (a colour upload in between is refused, fx_upload).
+	bool col_ready = multi_rank(ctx);
+	for (fx_ctx* m : M) col_ready = col_ready && m->col_halo_buf == 1 - (int)m->frame_parity;
+	for (fx_ctx* m : M) m->col_halo_buf = -1;
+	if (col_ready) FX_HIP(hipStreamWaitEvent(s, ctx->group->ev_col_done, 0));
+	const ExchSpec spec{ col_ready ? EX_ADVECT_VEL : EX_ADVECT_IN, Ha, 0 };
 	bool ov = overlap_level(ctx) >= 1;
 	if (ov && ctx->group->min_nz <= 2 * Ha) ov = false;        // decided on the thinnest slab of the chain: the same on every rank
 	if (!ov) {
@@ -452,6 +460,17 @@ int simulate_impl(fx_ctx* ctx, hipStream_t s)
 	for_members(ctx, M);
 	int rc;
 	if ((rc = advect_all(ctx, M, s))) return rc;
+	if (overlap_level(ctx) >= 3) {
+		// colour[parity] is final for this step: its halo planes -- four of the seven plane-units the next advection needs --
+		// leave now on the side stream, behind divergence / pressure / projection
+		fx_comm_group* g = ctx->group;
+		FX_HIP(hipEventRecord(g->ev_col_ready, s));
+		FX_HIP(hipStreamWaitEvent(g->comm_stream, g->ev_col_ready, 0));
+		const ExchSpec cs{ EX_COLOR_CUR, (int)ctx->desc.halo_advect, 0 };
+		if ((rc = do_exchange(ctx, M, &cs, 1, g->comm_stream))) return rc;
+		FX_HIP(hipEventRecord(g->ev_col_done, g->comm_stream));
+		for (fx_ctx* m : M) m->col_halo_buf = (int)m->frame_parity;
+	}
 	if (ctx->time_step > 0.0f) {                       // CSProject3D.hlsl:88
 		const ExchSpec uz{ EX_UZ1, 1, 0 };
 		if ((rc = do_exchange(ctx, M, &uz, 1, s))) return rc;
@@ -603,6 +622,8 @@ int fx_destroy(fx_ctx* ctx)
 			if (g->face_stream) (void)hipStreamDestroy(g->face_stream);
 			if (g->ev_int) (void)hipEventDestroy(g->ev_int);
 			if (g->ev_face1) (void)hipEventDestroy(g->ev_face1);
+			if (g->ev_col_ready) (void)hipEventDestroy(g->ev_col_ready);
+			if (g->ev_col_done) (void)hipEventDestroy(g->ev_col_done);
 			if (g->ev_ready) (void)hipEventDestroy(g->ev_ready);
 			if (g->ev_done) (void)hipEventDestroy(g->ev_done);
 			delete g->transport;
@@ -947,6 +968,13 @@ int fx_upload(fx_ctx* ctx, int field, const void* host, size_t bytes)
 		break;
 	}
 	case FX_FIELD_COLOR: case FX_FIELD_COLOR_PREV: {
+		// FX_OPT_OVERLAP 3: the neighbours already hold this context's colour border planes for the next step.  In a loop-back
+		// group the flag can simply be dropped for everyone (the next step exchanges the colour again); across processes the
+		// neighbours cannot know, so the upload is refused (set FX_OPT_OVERLAP <= 2 before the step that precedes it).
+		if (ctx->col_halo_buf >= 0 && ctx->group) {
+			if (!ctx->group->transport->is_local()) return FX_E_STATE;
+			for (fx_ctx* m : ctx->group->members) if (m) m->col_halo_buf = -1;
+		}
 		char* dst = (char*)ctx->col[field == FX_FIELD_COLOR ? ctx->frame_parity : 1 - ctx->frame_parity];
 		if ((rc = ensure_stage(ctx, need))) return rc;
 		FX_HIP(hipMemcpy(ctx->stage, host, need, hipMemcpyHostToDevice));
@@ -1178,7 +1206,7 @@ static int make_comm_stream(fx_comm_group* g, int device)
 {
 	g->comm_stream = nullptr; g->ev_ready = nullptr; g->ev_done = nullptr;
 	g->shared_stream = nullptr; g->broken = false;
-	g->face_stream = nullptr; g->ev_int = nullptr; g->ev_face1 = nullptr;
+	g->face_stream = nullptr; g->ev_int = nullptr; g->ev_face1 = nullptr; g->ev_col_ready = nullptr; g->ev_col_done = nullptr;
 	DeviceGuard dg(device);
 	// DEFAULT priority.  A high-priority side stream made every dependency between it and the compute stream cost about a
 	// millisecond for the first group of a process (18 ms per step instead of 7.7, profiles/r01d_slab_schedule_loopback.txt);
@@ -1192,6 +1220,8 @@ static int make_comm_stream(fx_comm_group* g, int device)
 	if (hipStreamCreateWithFlags(&g->face_stream, hipStreamNonBlocking) != hipSuccess) return FX_E_DEVICE;
 	if (hipEventCreateWithFlags(&g->ev_int, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;
 	if (hipEventCreateWithFlags(&g->ev_face1, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;
+	if (hipEventCreateWithFlags(&g->ev_col_ready, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;
+	if (hipEventCreateWithFlags(&g->ev_col_done, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;
 	return FX_OK;
 }
 
@@ -1269,7 +1299,7 @@ int fx_set_option(fx_ctx* ctx, uint32_t option, uint32_t value)
 	if (!ctx) return FX_E_INVALID;
 	switch (option) {
 	case FX_OPT_OVERLAP:
-		if (value > 2) return FX_E_INVALID;
+		if (value > 3) return FX_E_INVALID;
 		ctx->opt_overlap = (int)value;
 		return FX_OK;
 	case FX_OPT_JACOBI_ROUND:

@@ -36,6 +36,12 @@ int exchange_items(fx_ctx* c, int which_set, int k, int pidx, ExchItem out[4])
 		if (!c->frozen) return 1;
 		out[1] = ExchItem{ (char*)c->frozen, plane, 1, k, nullptr };      // the neighbour's freeze state travels with its pressure
 		return 2;
+	case EX_ADVECT_VEL:
+		out[0] = ExchItem{ (char*)c->vel[0], plane * es, 3, k, nullptr };
+		return 1;
+	case EX_COLOR_CUR:
+		out[0] = ExchItem{ (char*)c->col[c->frame_parity], plane * es * 4, 1, k, nullptr };
+		return 1;
 	case EX_PRESSURE_FACE:
 		out[0] = ExchItem{ (char*)c->p_face[(pidx >> 1) & 1], plane * 4, 1, k, (char*)c->p[pidx & 1] };
 		return 1;

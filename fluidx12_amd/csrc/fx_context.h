@@ -63,6 +63,7 @@ struct fx_ctx {
 	int opt_overlap;                // FX_OPT_OVERLAP
 	int opt_round;                  // FX_OPT_JACOBI_ROUND
 	std::string last_error;
+	int col_halo_buf = -1;          // FX_OPT_OVERLAP 3: index of the colour buffer whose halo planes the previous step already exchanged (-1: none)
 	uint64_t steps_simulated = 0;   // fx_simulate calls with dt > 0 (recorded in checkpoints)
 };
 
@@ -106,6 +107,7 @@ struct fx_comm_group {
 	hipEvent_t ev_ready, ev_done;
 	// the face chains of the overlapped pressure rounds run on their own stream, beside the interior sweeps
 	hipStream_t face_stream;
+	hipEvent_t ev_col_ready, ev_col_done;   // FX_OPT_OVERLAP 3: "colour of this step is final" (compute -> comm), "its halo planes have arrived" (comm -> compute)
 	hipEvent_t ev_int, ev_face1;    // "interior + face copy of the round done" (compute -> face), "the chain has read its input" (face -> compute)
 	int min_nz;                     // thinnest slab of the chain: every rank takes the same schedule decisions from it
 	hipStream_t shared_stream;      // loop-back groups: the one compute stream of all members (owned by the group)
@@ -118,7 +120,9 @@ enum ExchSet {
 	EX_UZ1 = 1,         // z-component of the advected velocity: all the divergence reads across a slab face
 	EX_DIV = 2,         // divergence b
 	EX_PRESSURE = 3,    // pressure buffer `pidx` (+ the freeze mask in faithful mode)
-	EX_PRESSURE_FACE = 4 // face planes leave from scratch buffer p_face[pidx >> 1], halos land in pressure buffer pidx & 1
+	EX_PRESSURE_FACE = 4, // face planes leave from scratch buffer p_face[pidx >> 1], halos land in pressure buffer pidx & 1
+	EX_ADVECT_VEL = 5,   // velocity[0] only: the colour the advection gathers from was exchanged behind the previous step's pressure phase
+	EX_COLOR_CUR = 6     // colour[parity]: what the NEXT step's advection gathers from
 };
 // items of one member for an exchange set; returns their number (<= 4)
 int exchange_items(fx_ctx* c, int which_set, int k, int pidx, ExchItem out[4]);

@@ -88,7 +88,7 @@ class Fluid:
         if slab is not None:
             d.slab_z0, d.slab_nz = int(slab[0]), int(slab[1])
         d.halo_advect, d.halo_jacobi = int(halo_advect), int(halo_jacobi)
-        level = 2 if overlap is True else int(overlap)        # 0 none, 1 advection halo only, 2 (default) + pressure rounds
+        level = 2 if overlap is True else int(overlap)        # 0 none, 1 advection halo only, 2 (default) + pressure rounds, 3 + early colour halo
         d.flags = (int(jacobi_fuse) & 0xF) | (0 if level else capi.FLAG_NO_OVERLAP) | (capi.FLAG_RENDER_ONLY if render_only else 0)
         self.last_status = self._lib.fx_create(C.byref(self._ctx), C.byref(d))
         if self.last_status != capi.FX_OK:      # the reference's Init returns false (XUSG_N_RETURN)
@@ -97,8 +97,8 @@ class Fluid:
         self.grid = (X, Y, Z)
         self.viewport = (int(width), int(height))
         self.slab = (d.slab_z0, d.slab_nz if d.slab_nz else Z)
-        if level == 1:
-            self.set_option(capi.OPT_OVERLAP, 1)
+        if level in (1, 3):
+            self.set_option(capi.OPT_OVERLAP, level)
         return True
 
     def Release(self):
@@ -258,7 +258,7 @@ class Fluid:
         return t
 
     def set_option(self, option, value):
-        """slab schedule knobs (capi.OPT_OVERLAP 0/1/2, capi.OPT_JACOBI_ROUND 1..halo_jacobi); same on every rank"""
+        """slab schedule knobs (capi.OPT_OVERLAP 0..3, capi.OPT_JACOBI_ROUND 1..halo_jacobi); same on every rank"""
         self._need()
         capi.check(self._lib.fx_set_option(self._ctx, int(option), int(value)), "set_option")
 

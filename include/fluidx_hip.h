@@ -218,6 +218,11 @@ int fx_comm_gather_color(fx_ctx* ctx, void* stream, fx_ctx* full, int root, cons
  *                        1 = the advection halo travels on a side stream behind the interior advection;
  *                        2 = (default) additionally each pressure exchange travels behind the interior sweeps
  *                            of its round (the face planes are swept first)
+ *                        3 = additionally the colour half of the NEXT step's advection halo (4 of its 7 plane-units)
+ *                            leaves as soon as this step's advection has written it and travels behind the pressure
+ *                            phase; the next step only exchanges the velocity.  While such a halo is out, fx_upload of a
+ *                            colour field into an RCCL rank returns FX_E_STATE (its neighbours could not know; a
+ *                            loop-back group simply exchanges the colour again)
  *   FX_OPT_JACOBI_ROUND  sweeps per pressure exchange, 1 .. fx_desc.halo_jacobi (default = halo_jacobi) */
 enum fx_option { FX_OPT_OVERLAP = 1, FX_OPT_JACOBI_ROUND = 2 };
 int fx_set_option(fx_ctx* ctx, uint32_t option, uint32_t value);

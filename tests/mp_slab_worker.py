@@ -22,7 +22,7 @@ def main():
     slabs = [bench.slab_for_rank(Z, r, world) for r in range(world)]
     dt = np.float32(2.0 / Y)
     failures = []
-    for ov, rnd in ((0, halo_j), (1, halo_j), (2, halo_j), (2, max(1, halo_j // 2))):
+    for ov, rnd in ((0, halo_j), (1, halo_j), (2, halo_j), (3, halo_j), (2, max(1, halo_j // 2))):
         f = fx.Fluid()
         assert f.Init(640, 480, (X, Y, Z), storage=storage, jacobi_iters=iters, slab=slabs[rank], halo_advect=16,
                       halo_jacobi=halo_j, device=0), f.last_status
@@ -63,7 +63,7 @@ def main():
         print("MISMATCH", flag[0], flush=True)
         sys.exit(1)
     if rank == 0:
-        print("OK %d ranks, 4 schedules bit-identical" % world, flush=True)
+        print("OK %d ranks, 5 schedules bit-identical" % world, flush=True)
 
 
 if __name__ == "__main__":

@@ -97,7 +97,7 @@ def draw_slabs(seed):
         S = 1 << int(np.ceil(np.log2(S)))                 # power-of-two extents take the fast advect / strip Jacobi kernels
     return dict(dims=(S, S, int(cuts[-1])), slabs=[(int(cuts[i]), int(sizes[i])) for i in range(n)], hj=hj, ha=ha,
                 storage=str(rng.choice(["fp32", "fp16"])), mode=str(rng.choice(["fixed", "fixed", "faithful"])),
-                iters=int(rng.integers(2, 21)), fuse=int(rng.choice([0, 1, 2, 3, 4])), overlap=int(rng.integers(0, 3)),
+                iters=int(rng.integers(2, 21)), fuse=int(rng.choice([0, 1, 2, 3, 4])), overlap=int(rng.integers(0, 4)),
                 rnd=int(rng.integers(1, hj + 1)), steps=int(rng.integers(2, 5)))
 
 
@@ -560,7 +560,7 @@ def test_every_entry_point_refuses_null_and_nonsense():
     assert lib.fx_update_frame(c, C.c_float(0.1), 3, fbuf, fbuf, fbuf) < 0 and lib.fx_simulate(c, None, 7) < 0 and lib.fx_render(c, None, 9, 3) < 0
     assert lib.fx_upload(c, 0, None, 4) < 0 and lib.fx_upload(c, 0, fbuf, 4) < 0 and lib.fx_upload(c, 77, fbuf, 256) < 0
     assert lib.fx_download(c, 2, fbuf, 1) < 0 and lib.fx_download(c, -1, fbuf, 256) < 0 and lib.fx_download(c, 8, fbuf, 256) < 0   # no target yet
-    assert lib.fx_set_option(c, 99, 1) < 0 and lib.fx_set_option(c, 1, 3) < 0 and lib.fx_set_option(c, 2, 0) < 0
+    assert lib.fx_set_option(c, 99, 1) < 0 and lib.fx_set_option(c, 1, 4) < 0 and lib.fx_set_option(c, 2, 0) < 0
     assert lib.fx_sh_transform(c, None, 4, fbuf) < 0 and lib.fx_sh_transform(c, fbuf, 0, fbuf) < 0 and lib.fx_sh_transform(c, fbuf, 1 << 20, fbuf) < 0
     assert lib.fx_set_environment(c, fbuf, 0) < 0 and lib.fx_set_environment(c, fbuf, 1 << 20) < 0
     assert lib.fx_jacobi(c, None, 0) < 0 and lib.fx_get_frame_info(c, None) < 0 and lib.fx_timing_read(c, None, 0) < 0

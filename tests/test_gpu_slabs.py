@@ -42,7 +42,7 @@ def gather(fl, field, axis):
     return np.concatenate([f.download(field) for f in fl], axis=axis)
 
 
-@pytest.mark.parametrize("overlap", [2, 1, 0])
+@pytest.mark.parametrize("overlap", [3, 2, 1, 0])
 @pytest.mark.parametrize("nranks", [2, 4])
 @pytest.mark.parametrize("iters,hj", [(40, 4), (10, 3), (7, 8), (5, 1)])
 def test_slabs_equal_single_domain(nranks, iters, hj, overlap):
@@ -300,11 +300,11 @@ def test_bench_multi_rank_path_in_loopback():
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and "LOOP-BACK" in d["data"] and d["config"]["grid"] == [64, 64, 128]
     sched = d["config"]["schedule"]
-    assert len(sched["candidates"]) == 4 and (sched["overlap"], sched["jacobi_round"]) in [(1, 8), (2, 8), (2, 4), (0, 8)]
+    assert len(sched["candidates"]) == 5 and (sched["overlap"], sched["jacobi_round"]) in [(1, 8), (2, 8), (3, 8), (2, 4), (0, 8)]
     assert d["value"] > 0 and d["scaling"] == "weak"
 
 
-@pytest.mark.parametrize("overlap", [2, 0])
+@pytest.mark.parametrize("overlap", [3, 2, 0])
 def test_slabs_mirror_addressing(overlap):
     """the reference's `Fluid` sampler mode (MIRROR, Fluid.cpp:452) in slabs: mirrored taps only exist at the GLOBAL z faces"""
     dims = (64, 64, 64)
@@ -362,3 +362,47 @@ def test_checkpoint_resume_is_bit_identical_across_decompositions(tmp_path):
     assert other.Init(800, 800, (32, 32, 32))
     with pytest.raises(fx.FluidxError):
         other.LoadCheckpoint(path)
+
+
+def test_early_colour_halo_survives_uploads_pauses_and_level_changes():
+    """FX_OPT_OVERLAP 3 sends the colour half of the next advection halo a step early.  Whatever happens between the steps --
+    a colour upload (loop-back groups drop the early halo and exchange again), paused frames (the parity does not flip, so the
+    early halo is for the wrong buffer), switching the level back and forth, a checkpoint reload -- the run equals the single
+    domain bit for bit"""
+    dims = (64, 64, 96)
+    rng = np.random.default_rng(5)
+    ref = fx.Fluid()
+    assert ref.Init(800, 800, dims, jacobi_iters=9)
+    fl = []
+    for r in range(3):
+        f = fx.Fluid()
+        assert f.Init(800, 800, dims, slab=(r * 32, 32), jacobi_iters=9, halo_jacobi=4, halo_advect=8, overlap=3)
+        fl.append(f)
+    fx.comm_init_local(fl)
+    dt = f32(ref.default_time_step())
+
+    def step(dtv, k):
+        for drv in (ref, fl[0]):
+            drv.UpdateFrame(dtv, k % 3)
+            drv.Simulate(k % 3)
+
+    k = 0
+    for _ in range(3):
+        step(dt, k); k += 1
+    # a colour upload between two steps (same data into both runs)
+    col = ref.download(fx.FIELD_COLOR)
+    col[40:56] = rng.random(col[40:56].shape).astype(f32) * 0.5
+    ref.upload(fx.FIELD_COLOR, col)
+    for r, f in enumerate(fl):
+        f.upload(fx.FIELD_COLOR, col[r * 32:(r + 1) * 32])
+    step(dt, k); k += 1
+    step(f32(0.0), k); k += 1                              # paused frame, then running again
+    step(dt, k); k += 1
+    for lvl in (1, 3, 0, 3, 2, 3):
+        for f in fl:
+            f.set_option(capi.OPT_OVERLAP, lvl)
+        step(dt, k); k += 1
+    ref.Synchronize()
+    fl[0].Synchronize()
+    for field, axis in ((fx.FIELD_VELOCITY, 1), (fx.FIELD_COLOR, 0), (fx.FIELD_PRESSURE, 0)):
+        assert np.array_equal(gather(fl, field, axis), ref.download(field)), field
