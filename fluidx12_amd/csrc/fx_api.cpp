@@ -167,7 +167,7 @@ int overlap_level(const fx_ctx* lead)
 
 struct ExchSpec { int set, k, pidx; };
 
-int do_exchange(fx_ctx* ctx, const std::vector<fx_ctx*>& M, const ExchSpec* specs, int nspec, hipStream_t s)
+int do_exchange(fx_ctx* ctx, const std::vector<fx_ctx*>& M, const ExchSpec* specs, int nspec, hipStream_t s, int channel = 0)
 {
 	if (!multi_rank(ctx)) return FX_OK;
 	DeviceGuard dg(ctx->device);
@@ -184,7 +184,7 @@ int do_exchange(fx_ctx* ctx, const std::vector<fx_ctx*>& M, const ExchSpec* spec
 		total += segs[i].size();
 	}
 	if (!total) return FX_OK;
-	return ctx->group->transport->exchange(ctx->group, segs, s);
+	return ctx->group->transport->exchange(ctx->group, segs, s, channel);
 }
 
 // comm stream picks up after everything queued on the compute stream so far
@@ -467,7 +467,7 @@ int simulate_impl(fx_ctx* ctx, hipStream_t s)
 		FX_HIP(hipEventRecord(g->ev_col_ready, s));
 		FX_HIP(hipStreamWaitEvent(g->comm_stream, g->ev_col_ready, 0));
 		const ExchSpec cs{ EX_COLOR_CUR, (int)ctx->desc.halo_advect, 0 };
-		if ((rc = do_exchange(ctx, M, &cs, 1, g->comm_stream))) return rc;
+		if ((rc = do_exchange(ctx, M, &cs, 1, g->comm_stream, 1))) return rc;       // side channel: not queued with the step's own exchanges
 		FX_HIP(hipEventRecord(g->ev_col_done, g->comm_stream));
 		for (fx_ctx* m : M) m->col_halo_buf = (int)m->frame_parity;
 	}

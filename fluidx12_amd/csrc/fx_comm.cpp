@@ -71,8 +71,9 @@ void halo_segments(const fx_ctx* c, const ExchItem* items, int n, std::vector<Se
 struct LocalTransport : Transport {
 	bool is_local() const override { return true; }
 	int min_over_ranks(int v, hipStream_t, int* out) override { *out = v; return FX_OK; }   // the caller sees every member
-	int exchange(fx_comm_group* grp, const std::vector<std::vector<Seg>>& segs, hipStream_t s) override
+	int exchange(fx_comm_group* grp, const std::vector<std::vector<Seg>>& segs, hipStream_t s, int channel) override
 	{
+		(void)channel;                                   // one device: copies on the given stream either way
 		const int n = (int)grp->members.size();
 		if ((int)segs.size() != n) return FX_E_STATE;
 		// timing experiments only (results become wrong): keep the streams/events of the schedule, drop the copies
@@ -116,6 +117,7 @@ struct RcclApi {
 	decltype(&ncclGroupEnd) GroupEnd = nullptr;
 	decltype(&ncclAllReduce) AllReduce = nullptr;
 	decltype(&ncclGetErrorString) GetErrorString = nullptr;
+	decltype(&ncclCommSplit) CommSplit = nullptr;      // optional (NCCL >= 2.18): absent -> the side channel shares the communicator
 };
 
 static RcclApi* rccl(std::string* err)
@@ -141,6 +143,7 @@ static RcclApi* rccl(std::string* err)
 	FX_SYM(GetUniqueId) FX_SYM(CommInitRank) FX_SYM(CommDestroy) FX_SYM(Send) FX_SYM(Recv)
 	FX_SYM(GroupStart) FX_SYM(GroupEnd) FX_SYM(AllReduce) FX_SYM(GetErrorString)
 #undef FX_SYM
+	api.CommSplit = (decltype(api.CommSplit))dlsym(api.handle, "ncclCommSplit");
 	return &api;
 }
 
@@ -160,10 +163,10 @@ int rccl_get_unique_id(void* out, size_t bytes, std::string* err)
 
 struct RcclTransport : Transport {
 	RcclApi* api;
-	ncclComm_t comm;
+	ncclComm_t comm, comm2;                          // comm2: the side channel (== comm when it could not be split off)
 	int rank, nranks;
 	bool is_local() const override { return false; }
-	~RcclTransport() override { if (comm) api->CommDestroy(comm); }
+	~RcclTransport() override { if (comm2 && comm2 != comm) api->CommDestroy(comm2); if (comm) api->CommDestroy(comm); }
 	// smallest value of `v` over the ranks (one-time set-up traffic: the ranks must take the same schedule decisions)
 	int min_over_ranks(int v, hipStream_t s, int* out) override
 	{
@@ -176,10 +179,11 @@ struct RcclTransport : Transport {
 		(void)hipFree(d);
 		return rc;
 	}
-	int exchange(fx_comm_group* grp, const std::vector<std::vector<Seg>>& segs, hipStream_t s) override
+	int exchange(fx_comm_group* grp, const std::vector<std::vector<Seg>>& segs, hipStream_t s, int channel) override
 	{
 		fx_ctx* c = grp->members[0];
 		if (segs.size() != 1) return FX_E_STATE;
+		ncclComm_t comm = channel == 1 ? this->comm2 : this->comm;
 		ncclResult_t r = api->GroupStart();
 		for (const Seg& sg : segs[0]) {
 			if (r != ncclSuccess) break;
@@ -223,9 +227,16 @@ Transport* make_rccl_transport(const void* id, size_t bytes, int rank, int nrank
 	ncclUniqueId uid;
 	std::memcpy(&uid, id, sizeof uid);
 	RcclTransport* t = new RcclTransport();
-	t->api = a; t->comm = nullptr; t->rank = rank; t->nranks = nranks;
+	t->api = a; t->comm = nullptr; t->comm2 = nullptr; t->rank = rank; t->nranks = nranks;
 	const ncclResult_t r = a->CommInitRank(&t->comm, nranks, uid, rank);
 	if (r != ncclSuccess) { if (err) *err = std::string("ncclCommInitRank: ") + a->GetErrorString(r); t->comm = nullptr; delete t; return nullptr; }
+	// the side channel: every rank splits with the same colour and its rank as key (a collective call, like the init above)
+	t->comm2 = t->comm;
+	static const bool no_split = [] { const char* e = std::getenv("FLUIDX_RCCL_NO_SPLIT"); return e && e[0] == '1'; }();
+	if (a->CommSplit && !no_split) {
+		ncclComm_t c2 = nullptr;
+		if (a->CommSplit(t->comm, 0, rank, &c2, nullptr) == ncclSuccess && c2) t->comm2 = c2;
+	}
 	return t;
 }
 
