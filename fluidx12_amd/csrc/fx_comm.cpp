@@ -117,7 +117,6 @@ struct RcclApi {
 	decltype(&ncclGroupEnd) GroupEnd = nullptr;
 	decltype(&ncclAllReduce) AllReduce = nullptr;
 	decltype(&ncclGetErrorString) GetErrorString = nullptr;
-	decltype(&ncclCommSplit) CommSplit = nullptr;      // optional (NCCL >= 2.18): absent -> the side channel shares the communicator
 };
 
 static RcclApi* rccl(std::string* err)
@@ -143,21 +142,24 @@ static RcclApi* rccl(std::string* err)
 	FX_SYM(GetUniqueId) FX_SYM(CommInitRank) FX_SYM(CommDestroy) FX_SYM(Send) FX_SYM(Recv)
 	FX_SYM(GroupStart) FX_SYM(GroupEnd) FX_SYM(AllReduce) FX_SYM(GetErrorString)
 #undef FX_SYM
-	api.CommSplit = (decltype(api.CommSplit))dlsym(api.handle, "ncclCommSplit");
 	return &api;
 }
 
-size_t rccl_id_bytes() { return sizeof(ncclUniqueId); }
+// two ids: the communicator of the step's exchanges and the one of the side channel (Transport::exchange, channel 1)
+size_t rccl_id_bytes() { return 2 * sizeof(ncclUniqueId); }
 
 int rccl_get_unique_id(void* out, size_t bytes, std::string* err)
 {
 	if (bytes < sizeof(ncclUniqueId)) return FX_E_INVALID;
 	RcclApi* a = rccl(err);
 	if (!a) return FX_E_COMM;
-	ncclUniqueId id;
-	const ncclResult_t r = a->GetUniqueId(&id);
-	if (r != ncclSuccess) { if (err) *err = a->GetErrorString(r); return FX_E_COMM; }
-	std::memcpy(out, &id, sizeof id);
+	const size_t n = bytes >= 2 * sizeof(ncclUniqueId) ? 2 : 1;         // a caller with room for one id gets one communicator
+	for (size_t i = 0; i < n; ++i) {
+		ncclUniqueId id;
+		const ncclResult_t r = a->GetUniqueId(&id);
+		if (r != ncclSuccess) { if (err) *err = a->GetErrorString(r); return FX_E_COMM; }
+		std::memcpy(static_cast<char*>(out) + i * sizeof id, &id, sizeof id);
+	}
 	return FX_OK;
 }
 
@@ -230,12 +232,17 @@ Transport* make_rccl_transport(const void* id, size_t bytes, int rank, int nrank
 	t->api = a; t->comm = nullptr; t->comm2 = nullptr; t->rank = rank; t->nranks = nranks;
 	const ncclResult_t r = a->CommInitRank(&t->comm, nranks, uid, rank);
 	if (r != ncclSuccess) { if (err) *err = std::string("ncclCommInitRank: ") + a->GetErrorString(r); t->comm = nullptr; delete t; return nullptr; }
-	// the side channel: every rank splits with the same colour and its rank as key (a collective call, like the init above)
+	// the side channel: a second communicator from the second id, when the caller passed two (fx_comm_id_bytes); the plain
+	// ncclCommInitRank route, the one every framework exercises
 	t->comm2 = t->comm;
-	static const bool no_split = [] { const char* e = std::getenv("FLUIDX_RCCL_NO_SPLIT"); return e && e[0] == '1'; }();
-	if (a->CommSplit && !no_split) {
+	static const bool one_comm = [] { const char* e = std::getenv("FLUIDX_RCCL_ONE_COMM"); return e && e[0] == '1'; }();
+	if (bytes >= 2 * sizeof(ncclUniqueId) && !one_comm) {
+		ncclUniqueId uid2;
+		std::memcpy(&uid2, static_cast<const char*>(id) + sizeof uid, sizeof uid2);
 		ncclComm_t c2 = nullptr;
-		if (a->CommSplit(t->comm, 0, rank, &c2, nullptr) == ncclSuccess && c2) t->comm2 = c2;
+		const ncclResult_t r2 = a->CommInitRank(&c2, nranks, uid2, rank);
+		if (r2 != ncclSuccess) { if (err) *err = std::string("ncclCommInitRank (side channel): ") + a->GetErrorString(r2); delete t; return nullptr; }
+		t->comm2 = c2;
 	}
 	return t;
 }

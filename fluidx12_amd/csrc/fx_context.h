@@ -87,7 +87,7 @@ struct GatherPart { int rank; const char* src; char* dst; size_t bytes; };
 struct Transport {
 	virtual ~Transport() {}
 	// segs[i] = segments of grp->members[i] (RCCL: one member = this rank; loop-back: every rank)
-	// channel 1 = a second, independent communicator (RCCL: ncclCommSplit of the first) for traffic that must not queue behind, or
+	// channel 1 = a second, independent communicator (RCCL: from the second unique id) for traffic that must not queue behind, or
 	// in front of, the step's own exchanges: the early colour halo of FX_OPT_OVERLAP 3.  Operations of ONE communicator are
 	// serialised in issue order even across streams.
 	virtual int exchange(fx_comm_group* grp, const std::vector<std::vector<Seg>>& segs, hipStream_t s, int channel = 0) = 0;

@@ -198,7 +198,9 @@ int fx_timing_read(fx_ctx* ctx, fx_timing* out, int reset);
 /* ---- multi-GPU z-slabs (no reference counterpart) --------------------------------
  * One context per rank.  RCCL transport: fx_comm_id_bytes/fx_comm_get_unique_id on rank 0, broadcast
  * the bytes out of band, fx_comm_init_rank on every rank (rank r owns slab r).  Loop-back transport
- * (one process, one GPU, several slab contexts -- used by the tests): fx_comm_init_local. */
+ * (one process, one GPU, several slab contexts -- used by the tests): fx_comm_init_local.
+ * The id is TWO ncclUniqueIds (256 bytes): the communicator of the step's exchanges and a second one for traffic that must not
+ * queue with them (FX_OPT_OVERLAP 3).  Passing only the first 128 bytes gives one communicator serving both. */
 size_t fx_comm_id_bytes(void);
 int fx_comm_get_unique_id(void* id_out, size_t bytes);
 int fx_comm_init_rank(fx_ctx* ctx, const void* id, size_t bytes, int rank, int nranks);
