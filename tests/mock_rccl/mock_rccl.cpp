@@ -11,7 +11,6 @@
 //       real RCCL would hang or corrupt), copies it to the device and unlinks it.  Matching is FIFO per ordered
 //       pair, which is RCCL's rule.
 //   ncclAllReduce                                  int32 / float, min / max / sum, by the same file exchange.
-//   ncclCommSplit                                  same colour, key = rank: a second communicator with its own directory.
 //
 // It is deliberately STRICTER than RCCL: host-synchronous, every wait times out (FXMOCK_TIMEOUT_S, default 60 s) and
 // returns ncclSystemError, so a schedule that makes ranks disagree fails a test instead of hanging a node.  It says
@@ -39,7 +38,6 @@ struct Op { bool send; void* ptr; size_t bytes; int peer; hipStream_t stream; };
 
 struct Comm {
 	std::string dir;
-	int splits = 0;                 // ncclCommSplit calls so far: names the child's directory alike on every rank
 	int rank = 0, nranks = 0;
 	std::vector<unsigned long> send_seq, recv_seq;
 	unsigned long ar_seq = 0;
@@ -194,25 +192,6 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
 	}
 	rmdir(c->dir.c_str());                              // succeeds for the last rank out
 	delete c;
-	return ncclSuccess;
-}
-
-// the subset the product uses: every rank passes the same colour and its own rank as key -> a second communicator of the same
-// ranks with its own rendezvous directory (its messages never match the parent's)
-ncclResult_t ncclCommSplit(ncclComm_t comm, int color, int key, ncclComm_t* newcomm, ncclConfig_t*)
-{
-	Comm* c = reinterpret_cast<Comm*>(comm);
-	if (!c || !newcomm || color != 0 || key != c->rank) return ncclInvalidArgument;
-	Comm* n = new Comm();
-	char suffix[32];
-	std::snprintf(suffix, sizeof suffix, "_s%d", c->splits++);
-	n->dir = c->dir + suffix;
-	n->rank = c->rank; n->nranks = c->nranks;
-	n->send_seq.assign(n->nranks, 0); n->recv_seq.assign(n->nranks, 0);
-	mkdir(n->dir.c_str(), 0700);
-	struct stat st;
-	if (stat(n->dir.c_str(), &st) != 0) { delete n; return ncclSystemError; }
-	*newcomm = reinterpret_cast<ncclComm_t>(n);
 	return ncclSuccess;
 }
 
