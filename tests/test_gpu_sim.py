@@ -91,7 +91,7 @@ def test_jacobi_sweep_counts(iters):
     assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
 
 
-@pytest.mark.parametrize("dims", [(256, 256, 200), (512, 512, 100)])
+@pytest.mark.parametrize("dims", [(256, 256, 200), (512, 512, 100), (256, 256, 193), (256, 256, 257), (512, 512, 97), (512, 512, 131)])
 def test_default_schedule_of_large_grids_is_bit_identical(dims):
     """grids large enough for the three-sweep kernels run N sweeps as threes + twos (+ a single): 4 = 2 + 2, 5 = 3 + 2,
     7 = 3 + 2 + 2, ...; every count equals N launches of one sweep bit for bit"""
