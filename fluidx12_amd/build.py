@@ -25,6 +25,14 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__"]
 
 
+# per-source additions.  The strip kernels run one wave per SIMD with ~300 registers: the machine scheduler's default
+# (occupancy-driven) strategy has nothing to win there; "max-ilp" orders for instruction-level parallelism instead
+# (k_jacobi_strip3 44.4 -> 43.6 us per launch; "max-memory-clause" 43.8, "iterative-ilp" 48.5).  Scheduling only: results are
+# bit-identical (tests/test_gpu_sim.py).
+EXTRA_FLAGS = {"fx_jacobi_strip3.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+               "fx_jacobi_strip.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}     # 256x256x64: 8.9 -> 8.1 us per sweep; 512x512x64: 19.0 -> 18.8
+
+
 def hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -49,7 +57,7 @@ def build_lib(force=False, verbose=False):
         obj = os.path.join(OBJDIR, s + ".o")
         objs.append(obj)
         if force or _newer(obj, [src] + hdrs):
-            cmd = [cc] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+            cmd = [cc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-x", "hip", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
