@@ -86,3 +86,37 @@ sys.exit(0 if rc != 0 else 3)
     script.write_text(code)
     r, _ = launch(2, [str(script)], mock_lib, tmp_path, timeout=300)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+
+
+def test_ranks_with_different_descriptors_are_refused_at_init(mock_lib, tmp_path):
+    """fx_comm_init_rank compares a digest of the descriptor over the ranks (grid, halos, sweeps, mode, storage, addressing):
+    a chain whose ranks would run different schedules fails on EVERY rank at set-up, before any exchange can mismatch"""
+    code = r'''
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch.distributed as dist
+import fluidx12_amd as fx
+rank = int(os.environ["RANK"]); dist.init_process_group("gloo", rank=rank, world_size=2)
+f = fx.Fluid()
+assert f.Init(64, 64, (32, 32, 32), slab=(rank * 16, 16), jacobi_iters=10 + rank, halo_advect=6, halo_jacobi=4, device=0)
+box = [fx.comm_unique_id() if rank == 0 else None]; dist.broadcast_object_list(box, src=0)
+try:
+    f.comm_init_rank(box[0], rank, 2)
+    refused = False
+except fx.FluidxError as e:
+    refused = e.status == -1
+flags = [None, None]; dist.all_gather_object(flags, refused)
+# the context is still a free one: a matching chain can be formed afterwards
+g = fx.Fluid()
+assert g.Init(64, 64, (32, 32, 32), slab=(rank * 16, 16), jacobi_iters=10, halo_advect=6, halo_jacobi=4, device=0)
+box = [fx.comm_unique_id() if rank == 0 else None]; dist.broadcast_object_list(box, src=0)
+g.comm_init_rank(box[0], rank, 2)
+g.UpdateFrame(g.default_time_step(), 0); g.Simulate(0); g.Synchronize()
+dist.barrier(); g.Release(); f.Release(); dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if all(flags) else 5)
+'''
+    script = tmp_path.parent / "mock_digest.py"
+    script.write_text(code)
+    r, leftovers = launch(2, [str(script)], mock_lib, tmp_path, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2500:])
+    assert leftovers == [], leftovers
