@@ -10,7 +10,7 @@ with every field resident in HBM before the timed region.  metric = voxel-update
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the grid is cut into N z-slabs, one per rank, neighbour
 halo planes exchanged with RCCL send/recv pairs over xGMI inside libfluidx_hip.so.  Default = weak scaling: 16.8 M
-voxels per GPU (256^3, 256x256x512, 512x512x256, 512^3 for N = 1, 2, 4, 8 -- see workload_grid); --scaling strong
+voxels per GPU (256^3, 256x256x512, 256x256x1024, 512^3 for N = 1, 2, 4, 8 -- see workload_grid); --scaling strong
 keeps 256^3 for every N. torch.distributed only carries the rendezvous (RCCL unique id), the barriers and
 the max-over-ranks reduction of the step time.
 
@@ -54,14 +54,16 @@ def pmc_traffic(kernel, grid, iters, storage):
 
 
 def workload_grid(G, N, scaling):
-    """Grid of the N-rank run.  strong: the same G^3 for every N.  weak (default): 16.8 M voxels per GPU at G = 256 --
-    the grid doubles along z, then along x and y, alternately: 1: G^3, 2: G x G x 2G, 4: 2G x 2G x G, 8: (2G)^3 (= BASELINE
-    configs[3]'s 512^3 on 8 GPUs); other N stack along z.  Returns ((X, Y, Z), advect halo planes): the halo covers the
-    z back-trace reach measured with tools/reach_probe.py over 600 steps (11.9 / 2.5 / 5.1 cells for N = 2 / 4 / 8; a reach r needs
-    floor(r) + 2 planes) + margin; a longer run that outgrows it stops with FX_E_HALO instead of computing something else."""
+    """Grid of the N-rank run.  strong: the same G^3 for every N.  weak (default): 16.8 M voxels per GPU at G = 256.  N = 2 and 4
+    stack G^3 blocks along z (G x G x 2G, G x G x 4G): every rank owns exactly the single-GPU problem, the textbook weak-scaling
+    set-up, and a halo plane is G^2 cells.  N = 8 is (2G)^3 = BASELINE configs[3]'s 512^3 on 8 GPUs (64-plane slabs of 512^2); other N
+    stack along z.  Returns ((X, Y, Z), advect halo planes): the halo covers the z back-trace reach measured with
+    tools/reach_probe.py over 600 steps (11.9 / 18.8 / 5.1 cells for N = 2 / 4 / 8; a reach r needs floor(r) + 2 planes) + margin; a
+    longer run that outgrows it stops with FX_E_HALO instead of computing something else.  (Until late in round 1 N = 4 ran
+    2G x 2G x G: 42 + 40 MB per face and step instead of 39 + 10, and 1.48 instead of 1.14 ms of kernels per rank.)"""
     if N == 1 or scaling == "strong":
         return (G, G, G), 0
-    table = {2: ((G, G, 2 * G), 16), 4: ((2 * G, 2 * G, G), 6), 8: ((2 * G, 2 * G, 2 * G), 8)}
+    table = {2: ((G, G, 2 * G), 16), 4: ((G, G, 4 * G), 22), 8: ((2 * G, 2 * G, 2 * G), 8)}
     return table.get(N, ((G, G, G * N), 6 * N + 2))
 
 
