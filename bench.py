@@ -53,6 +53,34 @@ def pmc_traffic(kernel, grid, iters, storage):
     return best
 
 
+def baseline_config_label(GX, GY, GZ, iters, storage, N):
+    """which BASELINE.json config this line is (1-based as listed there), or how it differs from the nearest one"""
+    for c, (g, it, st) in BASELINE_CONFIGS.items():
+        if (GX, GY, GZ) == (g, g, g) and iters == it and storage == st:
+            ranks = {4: 8}.get(c, 1)
+            if N == ranks:
+                return "BASELINE configs[%d]%s" % (c - 1, " (simulation half; the ray march is reported under `render`)" if c == 3 else "")
+            return "BASELINE configs[%d]'s grid and sweep count on %d GPU%s instead of %d" % (c - 1, N, "s" if N > 1 else "", ranks)
+    if (GX, GY, GZ) == (512, 512, 512) and storage == "fp32":
+        return "BASELINE configs[3]'s 512^3 grid with %d instead of 80 sweeps (the weak-scaling series keeps the single-GPU sweep count; --config 4 runs configs[3] itself)" % iters
+    return "not a BASELINE config (weak-scaling stack of the 256^3 problem or a custom grid)"
+
+
+def limiter_note(kernel):
+    """what the committed SQ-counter summary (tools/sq_summary.py -> profiles/r*_sq_counters.json) says binds `kernel`"""
+    import glob
+    note = None
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters.json"))):
+        try:
+            d = json.load(open(fn))
+        except Exception:
+            continue
+        k = d.get("kernels", {}).get(kernel)
+        if k and k.get("limiter"):
+            note = "%s (%s)" % (k["limiter"], os.path.basename(fn))
+    return note
+
+
 def workload_grid(G, N, scaling):
     """Grid of the N-rank run.  strong: the same G^3 for every N.  weak (default): 16.8 M voxels per GPU at G = 256.  N = 2 and 4
     stack G^3 blocks along z (G x G x 2G, G x G x 4G): every rank owns exactly the single-GPU problem, the textbook weak-scaling
@@ -61,8 +89,10 @@ def workload_grid(G, N, scaling):
     tools/reach_probe.py over 600 steps (11.9 / 18.8 / 5.1 cells for N = 2 / 4 / 8; a reach r needs floor(r) + 2 planes) + margin; a
     longer run that outgrows it stops with FX_E_HALO instead of computing something else.  (Until late in round 1 N = 4 ran
     2G x 2G x G: 42 + 40 MB per face and step instead of 39 + 10, and 1.48 instead of 1.14 ms of kernels per rank.)"""
-    if N == 1 or scaling == "strong":
+    if N == 1:
         return (G, G, G), 0
+    if scaling == "strong":
+        return (G, G, G), (8 if G >= 512 else 0)      # 512^3: measured z reach 5.1 cells over 600 steps; 0 = the library default (6)
     table = {2: ((G, G, 2 * G), 16), 4: ((G, G, 4 * G), 22), 8: ((2 * G, 2 * G, 2 * G), 8)}
     return table.get(N, ((G, G, G * N), 6 * N + 2))
 
@@ -70,7 +100,14 @@ def workload_grid(G, N, scaling):
 # (FX_OPT_OVERLAP, FX_OPT_JACOBI_ROUND): advection halo behind the interior advection + serial pressure rounds of 8 sweeps;
 # pressure exchanges behind the interior sweeps of rounds of 8 (also with the next step's colour halo sent behind the pressure
 # phase) and of 4 sweeps (face planes first); nothing overlapped
-SCHEDULE_CANDIDATES = [(1, 8), (2, 8), (3, 8), (2, 4), (0, 8)]
+SCHEDULE_CANDIDATES = [(1, 8), (2, 8), (2, 4), (0, 8)]
+# FX_OPT_OVERLAP 3 drives a second RCCL communicator concurrently with the first; it has only ever run against the mock and the
+# loop-back transport, so it is a candidate only on request (FLUIDX_BENCH_OVERLAP3=1 or --schedule 3,8)
+if os.environ.get("FLUIDX_BENCH_OVERLAP3", "0") == "1":
+    SCHEDULE_CANDIDATES.insert(2, (3, 8))
+
+# BASELINE.json configs[i] -> (grid, sweeps, storage); configs[0] (64^2 2-D, CPU only) is a parity-test case, not a bench line
+BASELINE_CONFIGS = {2: (128, 40, "fp32"), 3: (256, 40, "fp32"), 4: (512, 80, "fp32"), 5: (256, 40, "fp16")}
 
 
 def pressure_round(GX, nz_per_rank, iters):
@@ -136,9 +173,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--grid", type=int, default=256)
-    ap.add_argument("--iters", type=int, default=40)
-    ap.add_argument("--storage", default="fp32", choices=["fp32", "fp16"])
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5],
+                    help="BASELINE.json config (1-based as listed there): 2 = 128^3/40, 3 = 256^3/40 (the default workload), "
+                         "4 = 512^3/80 sweeps (on 8 ranks: 64-plane z-slabs), 5 = 256^3 fp16 storage; sets --grid/--iters/--storage")
+    ap.add_argument("--grid", type=int, default=None)
+    ap.add_argument("--iters", type=int, default=None)
+    ap.add_argument("--storage", default=None, choices=["fp32", "fp16"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="how the grid grows with --gpus (N > 1)")
     ap.add_argument("--schedule", default="auto", help="N > 1: 'auto' times the slab schedules below for 3 steps each before the "
                     "warm-up and keeps the fastest, or 'OVERLAP,ROUND' (fx_set_option values) to pin one")
@@ -155,12 +195,31 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="distributed plumbing only (no GPU work); used by the gloo CPU tests, never a measurement")
     args = ap.parse_args()
+    cg, ci, cs = BASELINE_CONFIGS.get(args.config, (256, 40, "fp32"))
+    if args.grid is None:
+        args.grid = cg
+    if args.iters is None:
+        args.iters = ci
+    if args.storage is None:
+        args.storage = cs
+    if args.config == 4 and (args.gpus > 1 or args.loopback > 1):
+        args.scaling = "strong"                   # configs[3] is ONE 512^3 grid cut into --gpus slabs, whatever N
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.loopback:
+        # started directly (python bench.py --gpus N): become the launcher of N rank processes.  Nothing has touched the GPU
+        # yet in this process; the ranks are CHILD processes (never an exec of this one) and their exit code is ours.
+        import subprocess
+        port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world != 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                         % (args.gpus, world, args.gpus, args.gpus))
     N = world
     G = args.grid
     loop = args.loopback if (world == 1 and args.loopback > 1 and not args.dry_run) else 0
@@ -348,6 +407,9 @@ def main():
                 for cand in cands:
                     tr = tr or pmc_traffic(cand, G, args.iters, args.storage)
             tail_l = int(timing.jacobi_launches - main_l)
+            # what bounds a T-sweep launch: it must read p and b once and write p' once whatever T is (compulsory bytes);
+            # `achieved`/`frac` count SURVEY 8(d)'s 12 B per cell-SWEEP and therefore exceed the peak by up to T x
+            compulsory = JACOBI_BYTES_PER_CELL_SWEEP * cells
             roof = {"bound": "hbm",
                     "kernel": "k_jacobi_v4 (one lock-step Jacobi sweep per launch)" if sweeps_per_launch == 1 else
                               "%s (%g lock-step Jacobi sweeps per launch, register/LDS-resident temporal blocking: p and b are read once "
@@ -355,6 +417,10 @@ def main():
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
                     "traffic_source": tr[1] if tr else None,
+                    "compulsory_bytes_per_launch": compulsory,
+                    "frac_compulsory": compulsory / avg_launch_s / 1e9 / HBM_PEAK_GBS,
+                    "frac_traffic": (tr[0] / avg_launch_s / 1e9 / HBM_PEAK_GBS) if tr else None,
+                    "limiter": limiter_note(cands[0]),
                     "algorithmic_bytes_per_launch": JACOBI_BYTES_PER_CELL_SWEEP * cells * sweeps_per_launch,
                     "avg_launch_us": avg_launch_s * 1e6, "launches": int(main_l),
                     "sweeps_per_launch": sweeps_per_launch,
@@ -377,7 +443,8 @@ def main():
             "dtype": "f32" if args.storage == "fp32" else "f32 arithmetic / f16 field storage",
             "data": "synthetic" if not loop else "synthetic; LOOP-BACK: %d slab ranks share ONE GPU (functional check of the multi-rank path, not a scaling measurement)" % loop,
             "config": {"workload": "%dx%dx%d 3D smoke (%.1f M voxels per GPU), %d Jacobi sweeps, %s fields, "
-                                   "advect+divergence+Jacobi+project per step" % (GX, GY, GZ, GX * GY * GZ / N / 1e6, args.iters, args.storage),
+                                   "advect+divergence+Jacobi+project per step; %s"
+                                   % (GX, GY, GZ, GX * GY * GZ / N / 1e6, args.iters, args.storage, baseline_config_label(GX, GY, GZ, args.iters, args.storage, N)),
                        "grid": [GX, GY, GZ], "jacobi_iters": args.iters, "storage": args.storage,
                        "parallelism": "single GPU" if N == 1 else ("z-slab x%d (%d planes per rank), " % (N, GZ // N)) + ("loop-back copies on one GPU" if loop else "RCCL send/recv halo exchange"),
                        "schedule": schedule,

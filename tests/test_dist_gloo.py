@@ -45,3 +45,29 @@ def test_slab_partition_covers_the_grid():
             for (a, na), (b, _) in zip(slabs, slabs[1:]):
                 assert a + na == b
     assert bench.step_bytes_per_voxel(40, "fp32") == 580 and bench.step_bytes_per_voxel(40, "fp16") == 534
+
+
+def test_bench_started_directly_with_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without torch.distributed.run (WORLD_SIZE unset) must not fall back to one rank: the process
+    becomes the launcher of two CHILD rank processes (never an exec) and passes their result and exit code on"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_PORT=str(free_port()), OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+    # a world size that contradicts --gpus is an error, not a silent 1-GPU run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], cwd=ROOT,
+                       env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_baseline_config_flags():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.BASELINE_CONFIGS[4] == (512, 80, "fp32") and bench.BASELINE_CONFIGS[2] == (128, 40, "fp32")
+    assert bench.baseline_config_label(512, 512, 512, 80, "fp32", 8) == "BASELINE configs[3]"
+    assert "40 instead of 80" in bench.baseline_config_label(512, 512, 512, 40, "fp32", 8)
+    assert bench.baseline_config_label(256, 256, 256, 40, "fp32", 1).startswith("BASELINE configs[2]")
+    assert bench.workload_grid(512, 8, "strong") == ((512, 512, 512), 8)

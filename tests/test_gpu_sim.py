@@ -261,9 +261,53 @@ def test_errors_and_call_order():
 
 
 # ---- full BASELINE sizes: size-independent properties --------------------------------------------------
-@pytest.mark.parametrize("X", [128, 256])
+def test_x512_full_step_against_oracle():
+    """BASELINE configs[3]'s kernels (X = 512, 80 sweeps: k_jacobi_strip3h in threes + k_jacobi_strip2h for the remainder) through one
+    whole step on a 512 x 512 x 100 grid -- thick enough for the default schedule to take the three-sweep kernel -- stage by stage
+    against the oracle on the same inputs, then fx_simulate as a whole against the staged run"""
+    dims = (512, 512, 100)
+    X, Y, Z = dims
+    rng = np.random.default_rng(512)
+    vel = (rng.random((3, Z, Y, X), dtype=f32) - f32(0.5)) * f32(4.0)       # reach up to 4 cells in z, 4 in x / y
+    col = rng.random((Z, Y, X, 4), dtype=f32)
+    p = rng.standard_normal((Z, Y, X)).astype(f32)
+    f = make(dims, jacobi_iters=80)
+    dt = f32(f.default_time_step())
+    f.upload(fx.FIELD_VELOCITY, vel); f.upload(fx.FIELD_COLOR, col); f.upload(fx.FIELD_PRESSURE, p)
+    f.UpdateFrame(dt, 0)
+    f.Advect()
+    gv, gc = f.download(fx.FIELD_VELOCITY1), f.download(fx.FIELD_COLOR)
+    vo, co = orc.advect(vel, col, dt)
+    assert rel_l2(gv, vo) < 1e-6 and rel_l2(gc, co) < 1e-6
+    z, y, x = np.meshgrid(np.arange(Z), np.arange(Y), np.arange(X), indexing="ij", sparse=True)
+    far = ((x + .5) / X - .5) ** 2 + ((y + .5) / Y - .1) ** 2 + ((z + .5) / Z - .5) ** 2 > (1.5 / 16) ** 2
+    assert np.array_equal(gv[:, far], vo[:, far]) and np.array_equal(gc[far], co[far])       # no transcendental there: bit-exact
+    f.Divergence()
+    b = orc.divergence(gv)
+    assert np.array_equal(f.download(fx.FIELD_DIVERGENCE), b)
+    f.timing_enable(True); f.timing_read(True)
+    f.Jacobi(80)
+    f.Synchronize()
+    t = f.timing_read(True)
+    assert t.jacobi_sweeps == 80 and t.jacobi_launches == 27 and t.jacobi_main_sweeps == 78      # 26 x 3 + 1 x 2
+    q, _ = orc.jacobi(p, b, 80)
+    assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
+    f.Project()
+    want = orc.project(gv, q)
+    assert np.array_equal(f.download(fx.FIELD_VELOCITY), want)
+    # the same step through fx_simulate
+    g = make(dims, jacobi_iters=80)
+    g.upload(fx.FIELD_VELOCITY, vel); g.upload(fx.FIELD_COLOR, col); g.upload(fx.FIELD_PRESSURE, p)
+    g.UpdateFrame(dt, 0)
+    g.Simulate(0)
+    g.Synchronize()
+    assert np.array_equal(g.download(fx.FIELD_VELOCITY), want) and np.array_equal(g.download(fx.FIELD_COLOR), gc)
+    assert np.array_equal(g.download(fx.FIELD_PRESSURE), q)
+
+
+@pytest.mark.parametrize("X", [128, 256, 512])
 def test_full_size_properties(X):
-    f = make((X, X, X), jacobi_iters=40)
+    f = make((X, X, X), jacobi_iters=80 if X == 512 else 40)
     dt = f32(f.default_time_step())
     for k in range(2):
         f.UpdateFrame(dt, 0)
