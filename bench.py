@@ -43,7 +43,7 @@ def pmc_traffic(kernel, grid, iters, storage):
     produced by the same command under rocprofv3 --pmc and committed under profiles/."""
     import glob
     best = None
-    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json"))):
         try:
             d = json.load(open(fn))
         except Exception:
@@ -70,7 +70,7 @@ def limiter_note(kernel):
     """what the committed SQ-counter summary (tools/sq_summary.py -> profiles/r*_sq_counters.json) says binds `kernel`"""
     import glob
     note = None
-    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters.json"))):
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters*.json"))):
         try:
             d = json.load(open(fn))
         except Exception:

@@ -58,7 +58,7 @@ def test_bench_under_torchrun_shared_gpu(nranks, mock_lib, tmp_path):
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == nranks and d["shared_gpu"] is True and d["value"] > 0
-    assert d["config"]["schedule"]["picked"].startswith("fastest") and len(d["config"]["schedule"]["candidates"]) == 5
+    assert d["config"]["schedule"]["picked"].startswith("fastest") and len(d["config"]["schedule"]["candidates"]) == 4
     assert "RCCL send/recv" in d["config"]["parallelism"] and d["roofline"]["achieved"] > 0
 
 

@@ -9,8 +9,8 @@
         > profiles/rNN_sq_counters.json
 
 SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves (MI355X_MICROARCH.md); WAIT_ANY (parked in
-s_waitcnt / barrier) + WAIT_INST_ANY (issue stall) + ACTIVE_INST_ANY (issuing) ~= WAVE_CYCLES.  `limiter` is read off these:
-"issue" when a wave spends more of its life issuing (+ stalled at issue) than parked on memory, else "latency".  The per-wave
+s_waitcnt / barrier) + WAIT_INST_ANY (issue stall) + ACTIVE_INST_ANY (issuing) ~= WAVE_CYCLES.  `limiter` names the largest of the
+three.  The per-wave
 instruction counts are SQ_INSTS_* / SQ_WAVES.  Counter passes are separate runs (8 SQ slots per pass).
 """
 import argparse
@@ -58,11 +58,10 @@ def main():
             e["frac_lds"] = m1.get("SQ_ACTIVE_INST_LDS", 0.0) / wc
             e["frac_vmem"] = m1.get("SQ_ACTIVE_INST_VMEM", 0.0) / wc
             e["wave_quad_cycles"] = wc
-            busy = e["frac_issuing"] + e["frac_issue_stalled"]
-            e["limiter"] = ("issue: %.0f %% of wave cycles issuing + %.0f %% stalled at issue against %.0f %% parked in s_waitcnt"
-                            if busy >= e["frac_parked_waitcnt"] else
-                            "latency: %.0f %% of wave cycles issuing + %.0f %% stalled at issue against %.0f %% parked in s_waitcnt") % (
-                                100 * e["frac_issuing"], 100 * e["frac_issue_stalled"], 100 * e["frac_parked_waitcnt"])
+            top = max(("issue", e["frac_issuing"]), ("pipe-stall (a full VMEM / LDS queue holds the next instruction back)", e["frac_issue_stalled"]),
+                      ("latency (waves parked in s_waitcnt)", e["frac_parked_waitcnt"]), key=lambda t: t[1])[0]
+            e["limiter"] = "%s: %.0f %% of wave cycles issuing, %.0f %% stalled at issue, %.0f %% parked in s_waitcnt" % (
+                top, 100 * e["frac_issuing"], 100 * e["frac_issue_stalled"], 100 * e["frac_parked_waitcnt"])
         if waves:
             for c, key in (("SQ_INSTS_VALU", "valu_per_wave"), ("SQ_INSTS_SALU", "salu_per_wave"), ("SQ_INSTS_LDS", "lds_per_wave"),
                            ("SQ_INSTS_VMEM_RD", "vmem_rd_per_wave"), ("SQ_INSTS_VMEM_WR", "vmem_wr_per_wave")):
