@@ -1,0 +1,322 @@
+// fx_advect_lds.hip -- CSAdvect.hlsl:41-79 (/root/reference/FluidX12/Content/Shaders/) with the trilinear taps taken from an
+// LDS-staged tile instead of 35 per-lane gathers through the texture-address path.
+//
+// Why: k_advect_fast (fx_sim.hip) issues 3 + 24 + 8 vector loads per voxel whose addresses depend on the voxel's own
+// velocity.  rocprofv3 (profiles/r02a_sq_counters.json): its waves issue 10 % of their cycles, stand 36 % at a full vector-memory
+// queue and 54 % in s_waitcnt -- 19 cycles per wave-load against 6.7 for the L1's data path; every (row, plane) of the
+// fields is fetched by up to eight different gather instructions of neighbouring waves, out of a 32-KiB L1 that 24 resident
+// waves overflow.  But the back-trace is short almost everywhere: |u| dt N < 1 cell for 93-99 % of the 64-voxel rows of the
+// 256^3 bench state (steps 5-120, tools/reach_hist.py), because the plume is a small part of the volume.
+//
+// Design: a workgroup of 8 waves owns a 64 x 8 (x, y) tile and streams along z.  A ring of FOUR plane slots in the LDS holds
+// planes z-1, z, z+1 of the tile plus a one-cell border (66 x 10 cells: colour as float4, velocity as three float planes,
+// 18 KiB per slot) while plane z+2 is in flight: `global_load_lds` (the gfx950 LDS-DMA load: no staging VGPRs, no ds_write pass)
+// fills the fourth slot straight from HBM, lane-linear -- a slot is laid out in the order the lanes enumerate its cells,
+// addressing (CLAMP / MIRROR, slab range) is applied to the SOURCE address.  Per voxel: own velocity from the LDS, back-trace,
+// and if every lane of the wave lands inside the +-1 window (a wave-uniform ballot) the 24 + 8 taps are LDS reads
+// (ds_read2_b32 / ds_read_b128, lanes = consecutive cells, conflict-free); a wave with a longer trace takes the gathers of
+// k_advect_fast from global memory, arithmetic unchanged.  Fields are read from HBM 1.29 x (the tile border) instead of
+// being gathered 8 x through L1/L2.  73.9 KiB of LDS per workgroup: two workgroups (16 waves) per CU.
+//
+// Arithmetic, association order and rounding are those of k_advect / k_advect_fast: bit-identical outputs
+// (tests/test_gpu_sim.py::test_advect_lds_path_bit_identical).  Power-of-two extents, X >= 64, Y >= 8, fp32 storage.
+#include "fx_internal.h"
+#include <cstdlib>
+#include <cstdio>
+
+namespace fx {
+
+namespace {
+
+constexpr int TX = 64, TY = 8;                    // voxels per workgroup and plane
+constexpr int HX = TX + 2, HY = TY + 2;           // staged cells per plane
+constexpr int NCELL = HX * HY;                    // 660
+constexpr int COL_BYTES = NCELL * 16;             // 10560
+constexpr int VEL_BYTES = NCELL * 4;              // 2640 per component
+constexpr int SLOT_BYTES = COL_BYTES + 3 * VEL_BYTES;   // 18480 (a multiple of 16)
+constexpr int NSLOT = 4;
+
+__device__ __forceinline__ float lerpf(float a, float b, float f) { return fmaf(f, b - a, a); }
+__device__ __forceinline__ float saturatef(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+
+__device__ __forceinline__ int addr_tap(int i, int n, int mode)
+{
+	if (mode == FX_ADDRESS_MIRROR) {
+		const int period = 2 * n;
+		int m = i % period;
+		if (m < 0) m += period;
+		return m < n ? m : period - 1 - m;
+	}
+	return min(max(i, 0), n - 1);
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+// one LDS-DMA load per lane: 16 or 4 bytes from `src` (per lane) to lds_base + lane * size (wave-uniform base)
+// The four LDS-DMA loads that stage 64 cells (one per lane) of a plane: colour (16 B per lane) to lds_col + 16 lane, the three
+// velocity components (4 B per lane) to lds_vel + k * VEL_BYTES + 4 lane.  `global_load_lds_*` writes to M0 + lane * size; the
+// LDS offsets are wave-uniform (SGPRs).  Inline assembly on purpose: through the builtin the compiler knows the LDS is being
+// written and puts `s_waitcnt vmcnt(0)` in front of the next ds_read -- every tap read of plane z would then wait for plane
+// z + 2, which has the whole iteration to land.  The workgroup barrier (after an explicit vmcnt(0)) is what orders the ring.
+__device__ __forceinline__ void stage64(const void* col, const void* v0, const void* v1, const void* v2, uint32_t lds_col, uint32_t lds_vel)
+{
+	uint32_t keep;
+	lds_col = __builtin_amdgcn_readfirstlane(lds_col);     // wave-uniform by construction; pins the operands to SGPRs for the "s" constraints
+	lds_vel = __builtin_amdgcn_readfirstlane(lds_vel);
+	asm volatile(
+		"s_mov_b32 %0, m0\n\t"
+		"s_mov_b32 m0, %5\n\t"
+		"s_nop 0\n\t"
+		"global_load_lds_dwordx4 %1, off\n\t"
+		"s_mov_b32 m0, %6\n\t"
+		"s_nop 0\n\t"
+		"global_load_lds_dword %2, off\n\t"
+		"s_add_u32 m0, m0, %7\n\t"
+		"s_nop 0\n\t"
+		"global_load_lds_dword %3, off\n\t"
+		"s_add_u32 m0, m0, %7\n\t"
+		"s_nop 0\n\t"
+		"global_load_lds_dword %4, off\n\t"
+		"s_mov_b32 m0, %0"
+		: "=&s"(keep)
+		: "v"(col), "v"(v0), "v"(v1), "v"(v2), "s"(lds_col), "s"(lds_vel), "n"(VEL_BYTES));
+}
+
+template <typename T>
+__device__ __forceinline__ T ldg32(const void* base, uint32_t byte_off)
+{
+	return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_advect_lds(const Geom g, const SimParams sp,
+	const float* __restrict__ vel_in, const float4* __restrict__ col_in, float* __restrict__ vel_out, float4* __restrict__ col_out,
+	int z_begin, int nzp, int zchunk, int nchunks, unsigned* halo_overflow, float rX, float rY, float rZ, float inv_rr,
+	int lgX, int lgY, int lg_gx, int lg_gy, int dbg)
+{
+	extern __shared__ __attribute__((aligned(16))) char lds[];   // NSLOT slots: [colour float4 x NCELL][velocity float x 3 x NCELL]
+
+	const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	// tile order: XCD k (= workgroup index % 8) walks the k-th contiguous eighth of the (x, y, chunk)-ordered tile sequence, so
+	// that the tiles sharing a border row are neighbours in ONE L2
+	const int ntiles = (1 << (lg_gx + lg_gy)) * nchunks;
+	int tl = (int)blockIdx.x;
+	{
+		const int q = ntiles >> 3, r = ntiles & 7, xcd = tl & 7, j = tl >> 3;
+		tl = xcd * q + min(xcd, r) + j;
+	}
+	const int tx = tl & ((1 << lg_gx) - 1), ty = (tl >> lg_gx) & ((1 << lg_gy) - 1), chunk = tl >> (lg_gx + lg_gy);
+	const int x0t = tx << 6, y0t = ty << 3;
+	const int zb = z_begin + chunk * zchunk, ze = min(zb + zchunk, z_begin + nzp);
+	if (zb >= ze) return;                                        // uniform for the workgroup
+
+	const int lgP = lgX + lgY;
+	const uint32_t stride = (uint32_t)g.nzl() << lgP;           // cells between velocity component planes
+	const char* v0 = reinterpret_cast<const char*>(vel_in);
+	const char* v1 = v0 + (size_t)stride * 4;
+	const char* v2 = v1 + (size_t)stride * 4;
+
+	// ---- which cells of a staged plane this lane fetches: cell c = tid (every wave) and 512 + tid (waves 0..2) -------------
+	// source = the ADDRESSED cell (clamp / mirror of the unclamped coordinate), so a tap index needs no addressing afterwards
+	uint32_t src_a, src_b = 0;
+	{
+		const int c = tid, r = c / HX, cc = c - r * HX;
+		src_a = ((uint32_t)addr_tap(y0t - 1 + r, g.Y, sp.address) << lgX) + (uint32_t)addr_tap(x0t - 1 + cc, g.X, sp.address);
+	}
+	const bool has_b = 512 + tid < NCELL;
+	if (has_b) {
+		const int c = 512 + tid, r = c / HX, cc = c - r * HX;
+		src_b = ((uint32_t)addr_tap(y0t - 1 + r, g.Y, sp.address) << lgX) + (uint32_t)addr_tap(x0t - 1 + cc, g.X, sp.address);
+	}
+	const bool wave_has_b = 512 + wave * 64 < NCELL;             // waves 0, 1, 2
+
+	// stage global plane zq (unclamped; may be -1 or Zg, or beyond what this slab holds) into its ring slot
+	const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds;
+	auto fill = [&](int zq) {
+		const int za = min(max(addr_tap(zq, g.Zg, sp.address), g.zlo), g.zhi);   // voxels that would need a plane this slab lacks take the flagged path
+		const uint32_t pz = (uint32_t)g.lz(za) << lgP;
+		const uint32_t slot = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(((zq + 4) & 3) * SLOT_BYTES));
+		{
+			const size_t cell = pz + src_a;
+			stage64(reinterpret_cast<const char*>(col_in) + cell * 16, v0 + cell * 4, v1 + cell * 4, v2 + cell * 4,
+				slot + (uint32_t)wave * (64 * 16), slot + COL_BYTES + (uint32_t)wave * (64 * 4));
+		}
+		if (wave_has_b) {
+			if (has_b) {
+				const size_t cell = pz + src_b;
+				stage64(reinterpret_cast<const char*>(col_in) + cell * 16, v0 + cell * 4, v1 + cell * 4, v2 + cell * 4,
+					slot + (512 + (uint32_t)wave * 64) * 16, slot + COL_BYTES + (512 + (uint32_t)wave * 64) * 4);
+			}
+		}
+	};
+
+	fill(zb - 1);
+	fill(zb);
+	fill(zb + 1);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // LDS-DMA completion is counted by vmcnt
+	__syncthreads();
+
+	const int x = x0t + lane, y = y0t + wave;
+	const float dt = sp.dt;
+	const float px = ((float)x + 0.5f) * rX;                     // == / (float)g.X, exactly (power of two)
+	const float py = ((float)y + 0.5f) * rY;
+	const float dx = px + -0.5f, dy = py + -0.100000001f;
+	const float dxy2 = fmaf(dy, dy, dx * dx);
+	const uint32_t own = (uint32_t)((wave + 1) * HX + lane + 1);  // this voxel's cell inside a slot
+	const float atten = fmaxf(fmaf(-dt, 0.200000003f, 1.0f), 0.0f);
+
+	auto compute = [&](int z) {
+		const float pz = ((float)z + 0.5f) * rZ;
+		const float dz = pz + -0.5f;
+		const float d2 = fmaf(dz, dz, dxy2);
+		const float ex = ((d2 * -4.0f) * inv_rr) * 1.44269502f;
+
+		const char* sc = lds + ((z + 4) & 3) * SLOT_BYTES;      // slot of plane z
+		const float* vs = reinterpret_cast<const float*>(sc + COL_BYTES);
+		const float u0x = vs[own], u0y = vs[NCELL + own], u0z = vs[2 * NCELL + own];
+		const float ax = fmaf(-u0x, dt, px), ay = fmaf(-u0y, dt, py), az = fmaf(-u0z, dt, pz);
+		const float tx_ = ax * (float)g.X - 0.5f, ty_ = ay * (float)g.Y - 0.5f, tz_ = az * (float)g.Zg - 0.5f;
+		const float flx = floorf(tx_), fly = floorf(ty_), flz = floorf(tz_);
+		const float fx = tx_ - flx, fy = ty_ - fly, fz = tz_ - flz;
+		const int ix = (int)flx, iy = (int)fly, iz = (int)flz;
+		const int jx = ix - x, jy = iy - y, jz = iz - z;        // in {-1, 0} when the trace stays inside the window
+		int z0 = addr_tap(iz, g.Zg, sp.address), z1 = addr_tap(iz + 1, g.Zg, sp.address);
+		const bool z_present = z0 >= g.zlo && z0 <= g.zhi && z1 >= g.zlo && z1 <= g.zhi;
+		const bool inwin = (unsigned)(jx + 1) <= 1u && (unsigned)(jy + 1) <= 1u && (unsigned)(jz + 1) <= 1u && z_present;
+
+		float u[3], c[4];
+		if (dbg & 2) {                                           // timing experiments only: no taps at all
+			u[0] = u0x; u[1] = u0y; u[2] = u0z; c[0] = fx; c[1] = fy; c[2] = fz; c[3] = ex;
+		} else if ((dbg & 8) ? (__builtin_amdgcn_ballot_w64(!inwin) == 0) : inwin) {
+			// ---- the lanes that trace into the staged window: all 32 taps are LDS reads.  A mixed wave runs both branches under
+			// partial exec masks (its gathers then only carry the few far-tracing lanes); dbg & 8 = wave-uniform choice instead
+			const uint32_t c0 = (uint32_t)((int)own + jy * HX + jx);               // cell of tap (x0, y0) inside a slot
+			const char* s0 = lds + ((iz + 4) & 3) * SLOT_BYTES;
+			const char* s1 = lds + ((iz + 5) & 3) * SLOT_BYTES;
+#pragma unroll
+			for (int a = 0; a < 3; ++a) {
+				const float* p0 = reinterpret_cast<const float*>(s0 + COL_BYTES + a * VEL_BYTES) + c0;
+				const float* p1 = reinterpret_cast<const float*>(s1 + COL_BYTES + a * VEL_BYTES) + c0;
+				const float c00 = lerpf(p0[0], p0[1], fx);
+				const float c10 = lerpf(p0[HX], p0[HX + 1], fx);
+				const float c01 = lerpf(p1[0], p1[1], fx);
+				const float c11 = lerpf(p1[HX], p1[HX + 1], fx);
+				u[a] = lerpf(lerpf(c00, c10, fy), lerpf(c01, c11, fy), fz);
+			}
+			const float4* q0 = reinterpret_cast<const float4*>(s0) + c0;
+			const float4* q1 = reinterpret_cast<const float4*>(s1) + c0;
+			const float4 t000 = q0[0], t100 = q0[1], t010 = q0[HX], t110 = q0[HX + 1];
+			const float4 t001 = q1[0], t101 = q1[1], t011 = q1[HX], t111 = q1[HX + 1];
+#define FX_TRI(m) lerpf(lerpf(lerpf(t000.m, t100.m, fx), lerpf(t010.m, t110.m, fx), fy), \
+	lerpf(lerpf(t001.m, t101.m, fx), lerpf(t011.m, t111.m, fx), fy), fz)
+			c[0] = FX_TRI(x); c[1] = FX_TRI(y); c[2] = FX_TRI(z); c[3] = FX_TRI(w);
+#undef FX_TRI
+		} else {
+			// ---- a longer trace somewhere in the wave: the gathers of k_advect_fast, from global memory ----------------------
+			const int xa0 = addr_tap(ix, g.X, sp.address), xa1 = addr_tap(ix + 1, g.X, sp.address);
+			const int ya0 = addr_tap(iy, g.Y, sp.address), ya1 = addr_tap(iy + 1, g.Y, sp.address);
+			if (!z_present) {
+				atomicOr(halo_overflow, 1u);
+				z0 = min(max(z0, g.zlo), g.zhi);
+				z1 = min(max(z1, g.zlo), g.zhi);
+			}
+			const uint32_t p0 = (uint32_t)g.lz(z0) << lgP, p1 = (uint32_t)g.lz(z1) << lgP;
+			const uint32_t ry0 = (uint32_t)ya0 << lgX, ry1 = (uint32_t)ya1 << lgX;
+			const uint32_t c000 = p0 + ry0 + (uint32_t)xa0, c100 = p0 + ry0 + (uint32_t)xa1;
+			const uint32_t c010 = p0 + ry1 + (uint32_t)xa0, c110 = p0 + ry1 + (uint32_t)xa1;
+			const uint32_t c001 = p1 + ry0 + (uint32_t)xa0, c101 = p1 + ry0 + (uint32_t)xa1;
+			const uint32_t c011 = p1 + ry1 + (uint32_t)xa0, c111 = p1 + ry1 + (uint32_t)xa1;
+			const char* vb[3] = { v0, v1, v2 };
+#pragma unroll
+			for (int a = 0; a < 3; ++a) {
+				const float c00 = lerpf(ldg32<float>(vb[a], c000 * 4u), ldg32<float>(vb[a], c100 * 4u), fx);
+				const float c10 = lerpf(ldg32<float>(vb[a], c010 * 4u), ldg32<float>(vb[a], c110 * 4u), fx);
+				const float c01 = lerpf(ldg32<float>(vb[a], c001 * 4u), ldg32<float>(vb[a], c101 * 4u), fx);
+				const float c11 = lerpf(ldg32<float>(vb[a], c011 * 4u), ldg32<float>(vb[a], c111 * 4u), fx);
+				u[a] = lerpf(lerpf(c00, c10, fy), lerpf(c01, c11, fy), fz);
+			}
+			const float4 t000 = ldg32<float4>(col_in, c000 * 16u), t100 = ldg32<float4>(col_in, c100 * 16u);
+			const float4 t010 = ldg32<float4>(col_in, c010 * 16u), t110 = ldg32<float4>(col_in, c110 * 16u);
+			const float4 t001 = ldg32<float4>(col_in, c001 * 16u), t101 = ldg32<float4>(col_in, c101 * 16u);
+			const float4 t011 = ldg32<float4>(col_in, c011 * 16u), t111 = ldg32<float4>(col_in, c111 * 16u);
+#define FX_TRI(m) lerpf(lerpf(lerpf(t000.m, t100.m, fx), lerpf(t010.m, t110.m, fx), fy), \
+	lerpf(lerpf(t001.m, t101.m, fx), lerpf(t011.m, t111.m, fx), fy), fz)
+			c[0] = FX_TRI(x); c[1] = FX_TRI(y); c[2] = FX_TRI(z); c[3] = FX_TRI(w);
+#undef FX_TRI
+		}
+
+		// ---- impulse (CSAdvect.hlsl:59-68).  exp2(ex) >= e^-4 needs ex >= -5.77: a wave whose lanes are all far below that
+		// skips the transcendental; the decision itself still uses the computed basis, exactly as before
+		if (__builtin_amdgcn_ballot_w64(ex > -6.5f) != 0) {
+			const float basis = exp2f(ex);
+			if (basis >= 0.0183156393f) {
+				float Fx, Fy, Fz;
+				if (sp.is3d) {
+					Fx = fmaf(basis, 0.0f, dz * -200.0f);
+					Fy = fmaf(basis, 192.0f, 0.0f);
+					Fz = fmaf(basis, 0.0f, dx * 200.0f);
+				} else {
+					Fx = 0.0f; Fy = basis * 48.0f; Fz = 0.0f;
+				}
+				u[0] = fmaf(Fx, dt, u[0]); u[1] = fmaf(Fy, dt, u[1]); u[2] = fmaf(Fz, dt, u[2]);
+				const float bdt = basis * dt;
+				c[0] = saturatef(fmaf(bdt, 8.0f, c[0]));
+				c[1] = saturatef(fmaf(bdt, 16.0f, c[1]));
+				c[2] = saturatef(fmaf(bdt, 40.0f, c[2]));
+				c[3] = saturatef(fmaf(bdt, 40.0f, c[3]));
+			}
+		}
+		const uint32_t id = ((uint32_t)g.lz(z) << lgP) + ((uint32_t)y << lgX) + (uint32_t)x;
+		vel_out[id] = u[0] * atten;
+		vel_out[(size_t)stride + id] = u[1] * atten;
+		vel_out[2 * (size_t)stride + id] = u[2] * atten;
+		col_out[id] = make_float4(c[0] * atten, c[1] * atten, c[2] * atten, c[3] * atten);
+
+	};
+
+	for (int z = zb; z < ze; ++z) {
+		if (z + 2 <= ze) fill(z + 2);                           // plane ze is the z+1 of the chunk's last plane
+		compute(z);
+		// the four stores of this step were issued after the LDS-DMA loads and complete after them: vmcnt(4) = "plane z+2 has
+		// landed" without waiting for the store acknowledgements
+		asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+		__syncthreads();                                         // plane z+2 is in the ring; plane z-1's slot may be overwritten
+	}
+}
+
+static int env_i(const char* n, int d) { const char* v = getenv(n); return v && *v ? atoi(v) : d; }
+
+// hipErrorNotSupported: the geometry has no LDS path (the caller falls back to k_advect_fast / k_advect)
+hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const void* col_in,
+	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, hipStream_t s, bool force)
+{
+	auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+	const int nzp = z_end - z_begin;
+	if (half_store || g.Zg <= 1 || !pow2(g.X) || !pow2(g.Y) || !pow2(g.Zg) || g.X < TX || g.Y < TY || nzp < 12 ||
+		(!force && (size_t)g.X * g.Y * (size_t)nzp < ((size_t)1 << 22)) ||     // 128^3: 0.032-0.040 ms against 0.030 for k_advect_fast -- too few workgroups
+		g.cells_local() * 16 >= ((size_t)1 << 32))
+		return hipErrorNotSupported;
+	auto lg = [](int v) { int k = 0; while ((1 << k) < v) ++k; return k; };
+	const int lgX = lg(g.X), lgY = lg(g.Y), lg_gx = lg(g.X / TX), lg_gy = lg(g.Y / TY);
+	const int tiles_xy = (g.X / TX) * (g.Y / TY);
+	// planes per workgroup.  Every chunk re-reads two planes, yet short chunks win: the workgroups over the plume (gathers) take
+	// several times longer than the rest, and 2048 workgroups of 16 planes balance that where 512 of 64 cannot (256^3 at step
+	// 25: 0.216 ms with 16, 0.219 with 8, 0.241 with 32, 0.258 with 64; 512^3: 1.52 / 1.53 / 1.56 / 1.63 ms for 16 / 32 / 64 / 128)
+	int zchunk = env_i("FLUIDX_ADVECT_ZCHUNK", 16);
+	if (zchunk < 4) zchunk = 4;
+	if (zchunk > nzp) zchunk = nzp;
+	const int nchunks = (nzp + zchunk - 1) / zchunk;
+	static bool attr_set = false;
+	if (!attr_set) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_advect_lds), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * SLOT_BYTES);
+		attr_set = true;
+	}
+	const float rX = 1.0f / (float)g.X, rY = 1.0f / (float)g.Y, rZ = 1.0f / (float)g.Zg, inv_rr = sp.is3d ? 256.0f : 1024.0f;
+	hipLaunchKernelGGL(k_advect_lds, dim3(tiles_xy * nchunks), dim3(512), NSLOT * SLOT_BYTES, s, g, sp, (const float*)vel_in, (const float4*)col_in,
+		(float*)vel_out, (float4*)col_out, z_begin, nzp, zchunk, nchunks, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY, lg_gx, lg_gy, env_i("FLUIDX_ADVECT_DBG", 0));
+	return hipGetLastError();
+}
+
+}  // namespace fx

@@ -47,6 +47,9 @@ struct SimParams {
 // z_begin/z_end: global plane range to compute (within the locally present range)
 hipError_t launch_advect(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const void* col_in,
 	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, hipStream_t s);
+// LDS-staged variant (fx_advect_lds.hip); hipErrorNotSupported when the geometry has no such path (force: also below the size where it pays)
+hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const void* col_in,
+	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, hipStream_t s, bool force);
 hipError_t launch_divergence(const Geom& g, int half_store, const void* vel, float* b, int z_begin, int z_end, hipStream_t s);
 // one lock-step sweep p_in -> p_out on planes [z_begin, z_end); frozen may be null
 hipError_t launch_jacobi_sweep(const Geom& g, const float* p_in, const float* b, float* p_out, uint8_t* frozen,

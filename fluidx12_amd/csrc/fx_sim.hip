@@ -711,6 +711,15 @@ hipError_t launch_advect(const Geom& g, const SimParams& sp, int half_store, con
 		if (e && sscanf(e, "%d,%d,%d", &a, &b_, &c) == 3 && a > 0 && b_ > 0 && c > 0 && a * b_ * c <= 256) { bx = a; by = b_; bz = c; }
 	}
 	const int nzp = z_end - z_begin;
+	// taps from an LDS-staged tile (fx_advect_lds.hip) where the geometry allows it and the launch is large enough to pay;
+	// FLUIDX_ADVECT_LDS=0 switches it off, =2 takes it for small launches too (A/B and parity tests; read per launch)
+	{
+		const char* le = getenv("FLUIDX_ADVECT_LDS");
+		if (!(le && le[0] == '0') && bx == 64 && by == 4 && bz == 1 && !xcd_remap_on(REMAP_ADVECT)) {
+			const hipError_t e = launch_advect_lds(g, sp, half_store, vel_in, col_in, vel_out, col_out, z_begin, z_end, halo_overflow, s, le && le[0] == '2');
+			if (e != hipErrorNotSupported) return e;
+		}
+	}
 	// lean path (see k_advect_fast): power-of-two extents, fields below 4 GiB, default workgroup shape and tile order
 	const char* fe = getenv("FLUIDX_ADVECT_FAST");                  // "0" = always the general kernel (A/B tests; read per launch)
 	const bool fast_off = fe && fe[0] == '0';

@@ -478,3 +478,18 @@ def test_bench_config4_in_loopback():
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["config"]["grid"] == [512, 512, 512] and d["config"]["jacobi_iters"] == 80
     assert "64 planes per rank" in d["config"]["parallelism"] and d["value"] > 0
+
+
+@pytest.mark.parametrize("overlap", [2, 0])
+def test_slabs_with_lds_advection(overlap, monkeypatch):
+    """k_advect_lds inside the slab schedule (interior range with own-planes-only back-traces, full range after the exchange,
+    halo planes as the ring's z-1 / z+1): equal to the single domain advected by k_advect_fast, bit for bit"""
+    dims = (64, 64, 96)
+    monkeypatch.setenv("FLUIDX_ADVECT_LDS", "0")
+    ref = run_single(dims, 6, jacobi_iters=10)
+    want = (ref.download(fx.FIELD_VELOCITY), ref.download(fx.FIELD_COLOR), ref.download(fx.FIELD_PRESSURE))
+    monkeypatch.setenv("FLUIDX_ADVECT_LDS", "2")
+    fl = run_slabs(dims, 6, 2, jacobi_iters=10, halo_jacobi=4, halo_advect=6, overlap=overlap)
+    assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), want[0])
+    assert np.array_equal(gather(fl, fx.FIELD_COLOR, 0), want[1])
+    assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), want[2])
