@@ -652,6 +652,68 @@ __global__ __launch_bounds__(256) void k_project(const Geom g, const SimParams s
 	}
 }
 
+// fp32 3-D fast path of the projection: one thread = 4 consecutive x (16-B loads of the three velocity components and of the
+// pressure rows above / below / in front / behind, 16-B stores), the x neighbours of the pressure row through DPP lane shifts
+// like k_jacobi_v4, 32-bit offsets.  Per-cell arithmetic is k_project's; RCP: extents are powers of two and the three
+// coordinate divisions become multiplications by the exact reciprocal (bit-identical).
+template <bool RCP>
+__global__ __launch_bounds__(256) void k_project_v4(const Geom g, const float* __restrict__ vel_in, const float* __restrict__ p,
+	float* __restrict__ vel_out, int z_begin, int nzp, int remap, int rows_per_block, float rX, float rY, float rZ)
+{
+	const int X4 = g.X >> 2;
+	const int lane = threadIdx.x;
+	const Tile3 tile = xcd_tile((X4 + (int)blockDim.x - 1) / (int)blockDim.x, (g.Y + rows_per_block - 1) / rows_per_block, nzp, remap);
+	const int x4 = tile.x * blockDim.x + lane;
+	const int y = tile.y * rows_per_block + threadIdx.y;
+	const int z = z_begin + tile.z;
+	if (x4 >= X4 || y >= g.Y) return;
+	const uint32_t plane = (uint32_t)g.plane(), stride = (uint32_t)g.cells_local();
+	const int yu = max(y, 1) - 1, yd = min(y + 1, g.Y - 1);
+	const int zf = max(z, 1) - 1, zb = min(z + 1, g.Zg - 1);
+	const uint32_t zrow = (uint32_t)g.lz(z) * plane;
+	const uint32_t off = zrow + (uint32_t)y * g.X + 4u * x4;
+	const float4 c = *reinterpret_cast<const float4*>(p + off);
+	const float4 U = *reinterpret_cast<const float4*>(p + zrow + (uint32_t)yu * g.X + 4u * x4);
+	const float4 D = *reinterpret_cast<const float4*>(p + zrow + (uint32_t)yd * g.X + 4u * x4);
+	const float4 F = *reinterpret_cast<const float4*>(p + (uint32_t)g.lz(zf) * plane + (uint32_t)y * g.X + 4u * x4);
+	const float4 B = *reinterpret_cast<const float4*>(p + (uint32_t)g.lz(zb) * plane + (uint32_t)y * g.X + 4u * x4);
+	const float4 ux = *reinterpret_cast<const float4*>(vel_in + off);
+	const float4 uy = *reinterpret_cast<const float4*>(vel_in + stride + off);
+	const float4 uz = *reinterpret_cast<const float4*>(vel_in + 2u * stride + off);
+	const int wl = (int)((threadIdx.y * blockDim.x + threadIdx.x) & 63);
+	float L = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c.w), 0x138, 0xf, 0xf, false));
+	float R = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c.x), 0x130, 0xf, 0xf, false));
+	if (x4 == 0) L = c.x; else if (wl == 0 || lane == 0) L = p[off - 1];
+	if (x4 == X4 - 1) R = c.w; else if (wl == 63 || lane == (int)blockDim.x - 1) R = p[off + 4];
+	const float k = __uint_as_float(0x3f855556u);                          // 0.5f / 0.48f (g_density, CSProject3D.hlsl:26)
+	const float pl[4] = { L, c.x, c.y, c.z }, pr[4] = { c.y, c.z, c.w, R };
+	const float pu[4] = { U.x, U.y, U.z, U.w }, pd[4] = { D.x, D.y, D.z, D.w };
+	const float pf[4] = { F.x, F.y, F.z, F.w }, pb[4] = { B.x, B.y, B.z, B.w };
+	const float vx[4] = { ux.x, ux.y, ux.z, ux.w }, vy[4] = { uy.x, uy.y, uy.z, uy.w }, vz[4] = { uz.x, uz.y, uz.z, uz.w };
+	float py = RCP ? ((float)y + 0.5f) * rY : ((float)y + 0.5f) / (float)g.Y;
+	float pz = RCP ? ((float)z + 0.5f) * rZ : ((float)z + 0.5f) / (float)g.Zg;
+	py = fmaf(py, 2.0f, -1.0f); pz = fmaf(pz, 2.0f, -1.0f);
+	float fy = (-fabsf(py) + 0.970000029f) * 33.3333359f, fz = (-fabsf(pz) + 0.970000029f) * 33.3333359f;
+	fy = fminf(fmaxf(fy, -1.0f), 1.0f); fz = fminf(fmaxf(fz, -1.0f), 1.0f);
+	float ox[4], oy[4], oz[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const float gx = -pl[i] + pr[i], gy = -pu[i] + pd[i], gz = -pf[i] + pb[i];
+		const float wz_ = fmaf(-gz, k, vz[i]);                              // CSProject3D.hlsl:62 (the z component first, as k_project does)
+		const float wx_ = fmaf(-gx, k, vx[i]), wy_ = fmaf(-gy, k, vy[i]);
+		float px = RCP ? ((float)(4 * x4 + i) + 0.5f) * rX : ((float)(4 * x4 + i) + 0.5f) / (float)g.X;
+		px = fmaf(px, 2.0f, -1.0f);
+		float fxw = (-fabsf(px) + 0.970000029f) * 33.3333359f;
+		fxw = fminf(fmaxf(fxw, -1.0f), 1.0f);
+		ox[i] = wx_ * ((0.0f < wx_ * px) ? fxw : 1.0f);                    // :106-108
+		oy[i] = wy_ * ((0.0f < wy_ * py) ? fy : 1.0f);
+		oz[i] = wz_ * ((0.0f < wz_ * pz) ? fz : 1.0f);
+	}
+	*reinterpret_cast<float4*>(vel_out + off) = make_float4(ox[0], ox[1], ox[2], ox[3]);
+	*reinterpret_cast<float4*>(vel_out + stride + off) = make_float4(oy[0], oy[1], oy[2], oy[3]);
+	*reinterpret_cast<float4*>(vel_out + 2u * stride + off) = make_float4(oz[0], oz[1], oz[2], oz[3]);
+}
+
 template <bool HALF>
 __global__ __launch_bounds__(256) void k_copy_owned(const Geom g, const typename Store<HALF>::S* __restrict__ src,
 	typename Store<HALF>::S* __restrict__ dst)
@@ -965,6 +1027,20 @@ hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, co
 	void* vel_out, int z_begin, int z_end, hipStream_t s)
 {
 	if (z_end <= z_begin) return hipSuccess;
+	static const int v4_on = env_int("FLUIDX_PROJECT_V4", 1);
+	if (v4_on && !half_store && sp.is3d && (g.X & 3) == 0 && g.cells_local() * 3 < ((size_t)1 << 30)) {
+		auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+		const int nzp = z_end - z_begin, X4 = g.X >> 2;
+		const int bx = X4 < 64 ? X4 : 64;
+		int by = 256 / bx; if (by > g.Y) by = g.Y;
+		const dim3 block(bx, by, 1), grid(((X4 + bx - 1) / bx) * ((g.Y + by - 1) / by) * nzp, 1, 1);
+		const float rX = 1.0f / (float)g.X, rY = 1.0f / (float)g.Y, rZ = 1.0f / (float)g.Zg;
+		if (pow2(g.X) && pow2(g.Y) && pow2(g.Zg))
+			hipLaunchKernelGGL(k_project_v4<true>, grid, block, 0, s, g, (const float*)vel_in, p, (float*)vel_out, z_begin, nzp, xcd_remap_on(REMAP_PROJECT), by, rX, rY, rZ);
+		else
+			hipLaunchKernelGGL(k_project_v4<false>, grid, block, 0, s, g, (const float*)vel_in, p, (float*)vel_out, z_begin, nzp, xcd_remap_on(REMAP_PROJECT), by, rX, rY, rZ);
+		return hipGetLastError();
+	}
 	const dim3 grid = grid_xyz(g, z_end - z_begin), block(64, 4, 1);
 	if (half_store) hipLaunchKernelGGL(k_project<true>, grid, block, 0, s, g, sp, (const h16*)vel_in, p, (h16*)vel_out, z_begin, z_end - z_begin, xcd_remap_on(REMAP_PROJECT));
 	else hipLaunchKernelGGL(k_project<false>, grid, block, 0, s, g, sp, (const float*)vel_in, p, (float*)vel_out, z_begin, z_end - z_begin, xcd_remap_on(REMAP_PROJECT));
