@@ -69,6 +69,9 @@ hipError_t launch_jacobi_strip(const Geom& g, const float* p_in, const float* b,
 // three sweeps per launch, register strips + the LDS as a second register file (fx_jacobi_strip3.hip; X = 256)
 bool jacobi_strip3_supported(const Geom& g);
 hipError_t launch_jacobi_strip3(const Geom& g, const float* p_in, const float* b, float* p_out, int z_begin, int z_end, hipStream_t s);
+// two sweeps per launch, one 4 x 4-row block per wave (fx_jacobi_block.hip; X = 128)
+bool jacobi_block2_supported(const Geom& g);
+hipError_t launch_jacobi_block2(const Geom& g, const float* p_in, const float* b, float* p_out, int z_begin, int z_end, hipStream_t s);
 // sweeps fused per launch for this geometry (1 = no fused path); requested > 0 overrides the default
 int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp);
 bool jacobi_prefers_three(const Geom& g, int requested, int nzp);

@@ -1,0 +1,156 @@
+// fx_jacobi_block.hip -- two lock-step Jacobi sweeps per launch for X = 128 (BASELINE configs[1], the reference's default grid,
+// FluidX12/FluidX12.cpp:44): one wave64 = one 128-cell row, a lane = two cells, and a wave owns a 4 x 4 (y, z) block of rows
+// OUTRIGHT -- it loads the 8 x 8 rows of p and 6 x 6 rows of b the block's dependency cone covers in one burst (100 independent
+// 512-byte row loads in flight), relaxes 6 x 6 rows to the first level and 4 x 4 to the second in registers, stores 16 rows.
+// No streaming along z, no LDS, no barrier.
+//
+// Why not the strip kernels (fx_jacobi_strip.hip): they stream along z and need ~16 planes per wave to amortise the pipeline's
+// fill; 128^3 then has 256 waves for 1024 SIMDs and a launch lasts 14 dependent z steps (7.6 us per sweep against 5.6 for one
+// sweep per launch).  At 2.1 M cells the three fields (24 MiB) sit in L2 / Infinity Cache, a single-sweep launch is a 1.7-us
+// kernel boundary plus one round trip, and forty of them are the whole 0.226 ms of the step's Jacobi phase.  A block per wave
+// gives 1024 waves x one round trip x two sweeps: half the launches, 1.6 x the arithmetic (52 row updates for 32 useful).
+//
+// Measured (MI355X, 128^3, 40 sweeps): Jacobi phase 0.224 -> 0.131 ms (twenty 6.6-us launches instead of forty 5.6-us ones), step
+// 0.2975 -> 0.204 ms = 7.05 -> 10.3 G voxel-updates/s.  Other block shapes (FLUIDX_BLOCK_SHAPE = rows * 10 + planes): 4 x 2 7.1 us,
+// 2 x 4 7.3, 2 x 2 8.1, 4 x 3 8.3 per launch -- 4 x 4 (224 VGPRs, one wave per SIMD, 1024 waves at 128^3) it is.
+//
+// Restates CSPoisson.hlsli:8-26 (/root/reference/FluidX12/Content/Shaders/) like k_jacobi_v4; per-cell arithmetic and
+// association order are unchanged, so the result is bit-identical to two single sweeps (tests/test_gpu_sim.py).
+#include "fx_internal.h"
+#include <cstdlib>
+
+namespace fx {
+
+namespace {
+
+// ((((((L - b) + R) + U) + D) + F) + B) * (1/6) on a float2 column; the row IS the wave, so the lanes without a DPP source (0 for
+// wave_shr:1, 63 for wave_shl:1) are the clamped wall cells and keep the `old` operand = the cell itself
+__device__ __forceinline__ float2 relax2(float2 c, float2 U, float2 D, float2 F, float2 Bk, float2 bb)
+{
+	const float L = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, c.x), __builtin_bit_cast(int, c.y), 0x138, 0xf, 0xf, false));
+	const float R = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, c.y), __builtin_bit_cast(int, c.x), 0x130, 0xf, 0xf, false));
+	const float inv = __uint_as_float(0x3e2aaaabu);
+	float2 x;
+	x.x = ((((((L - bb.x) + c.y) + U.x) + D.x) + F.x) + Bk.x) * inv;
+	x.y = ((((((c.x - bb.y) + R) + U.y) + D.y) + F.y) + Bk.y) * inv;
+	return x;
+}
+
+
+// uniform base + 32-bit byte offset: the `global_load v, v_offset, s[base]` form, no 64-bit address arithmetic per row
+__device__ __forceinline__ float2 ld_row(const float* base, uint32_t byte_off)
+{
+	return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// BY x BZ = rows x planes a wave produces
+template <int BY, int BZ>
+__global__ __launch_bounds__(256, 1) void k_jacobi_block2(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
+	float* __restrict__ p_out, int z_begin, int z_end, int nby, int nbz, int remap)
+{
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int nblk = nby * nbz;
+	int t = (int)blockIdx.x;
+	if (remap) {                                            // XCD k walks the k-th contiguous eighth of the workgroup sequence
+		const int n = (nblk + 3) >> 2, q = n >> 3, r = n & 7, xcd = t & 7, j = t >> 3;
+		t = xcd * q + min(xcd, r) + j;
+	}
+	const int blk = t * 4 + wave;
+	if (blk >= nblk) return;                                // uniform per wave; no barrier in this kernel
+	const int by = blk % nby, bz = blk / nby;
+	const int y0 = by * BY, z0 = z_begin + bz * BZ;
+	const uint32_t plane = (uint32_t)g.plane();
+	const int zmin = max(g.zlo, 0), zmax = min(g.zhi, g.Zg - 1);
+
+	// ---- the block's dependency cone, clamped loads (the clamp IS the stencil's clamp-to-edge at the input level) -------------
+	float2 P0[BZ + 4][BY + 4], Bv[BZ + 2][BY + 2];
+	uint32_t roff[BY + 4];
+#pragma unroll
+	for (int i = 0; i < BY + 4; ++i) roff[i] = ((uint32_t)min(max(y0 - 2 + i, 0), g.Y - 1) * (uint32_t)g.X + 2u * lane) * 4u;   // bytes
+#pragma unroll
+	for (int k = 0; k < BZ + 4; ++k) {
+		const uint32_t zo = (uint32_t)g.lz(min(max(z0 - 2 + k, zmin), zmax)) * plane * 4u;
+#pragma unroll
+		for (int i = 0; i < BY + 4; ++i) P0[k][i] = ld_row(p_in, zo + roff[i]);
+	}
+#pragma unroll
+	for (int k = 0; k < BZ + 2; ++k) {
+		const uint32_t zo = (uint32_t)g.lz(min(max(z0 - 1 + k, zmin), zmax)) * plane * 4u;
+#pragma unroll
+		for (int j = 0; j < BY + 2; ++j) Bv[k][j] = ld_row(b, zo + roff[j + 1]);
+	}
+
+	// ---- first sweep: planes z0-1 .. z0+BZ (k1), rows y0-1 .. y0+BY (j) -----------------------------------------------------------
+	float2 P1[BZ + 2][BY + 2];
+#pragma unroll
+	for (int k1 = 0; k1 < BZ + 2; ++k1)
+#pragma unroll
+		for (int j = 0; j < BY + 2; ++j)
+			P1[k1][j] = relax2(P0[k1 + 1][j + 1], P0[k1 + 1][j], P0[k1 + 1][j + 2], P0[k1][j + 1], P0[k1 + 2][j + 1], Bv[k1][j]);
+
+	// ---- second sweep: planes z0 .. z0+BZ-1, rows y0 .. y0+BY-1.  Rows / planes outside the domain hold no first-level data:
+	// there the neighbour is the cell itself.  Blocks that touch no face of the domain (wave-uniform) run without the selects.
+	const bool edge = y0 == 0 || y0 + BY >= g.Y || z0 == 0 || z0 + BZ >= g.Zg;
+	if (!edge) {
+#pragma unroll
+		for (int k2 = 0; k2 < BZ; ++k2) {
+			const int z = z0 + k2;
+			if (z >= z_end) break;
+			const uint32_t zo = (uint32_t)g.lz(z) * plane;
+#pragma unroll
+			for (int r = 0; r < BY; ++r) {
+				const float2 x = relax2(P1[k2 + 1][r + 1], P1[k2 + 1][r], P1[k2 + 1][r + 2], P1[k2][r + 1], P1[k2 + 2][r + 1], Bv[k2 + 1][r + 1]);
+				*reinterpret_cast<float2*>(reinterpret_cast<char*>(p_out) + (zo + (uint32_t)(y0 + r) * (uint32_t)g.X + 2u * lane) * 4u) = x;
+			}
+		}
+		return;
+	}
+#pragma unroll
+	for (int k2 = 0; k2 < BZ; ++k2) {
+		const int z = z0 + k2;
+		if (z >= z_end) break;
+		const bool zfirst = z == 0, zlast = z == g.Zg - 1;
+		const uint32_t zo = (uint32_t)g.lz(z) * plane;
+#pragma unroll
+		for (int r = 0; r < BY; ++r) {
+			const int y = y0 + r;
+			const float2 c = P1[k2 + 1][r + 1];
+			const float2 U = y == 0 ? c : P1[k2 + 1][r], D = y == g.Y - 1 ? c : P1[k2 + 1][r + 2];
+			const float2 F = zfirst ? c : P1[k2][r + 1], Bk = zlast ? c : P1[k2 + 2][r + 1];
+			const float2 x = relax2(c, U, D, F, Bk, Bv[k2 + 1][r + 1]);
+			*reinterpret_cast<float2*>(reinterpret_cast<char*>(p_out) + (zo + (uint32_t)y * (uint32_t)g.X + 2u * lane) * 4u) = x;
+		}
+	}
+}
+
+int env_b(const char* n, int d) { const char* v = getenv(n); return v && *v ? atoi(v) : d; }
+
+}  // namespace
+
+bool jacobi_block2_supported(const Geom& g)
+{
+	static const int on = env_b("FLUIDX_JACOBI_BLOCK", 1);
+	return on && g.Zg > 1 && g.X == 128 && (g.Y & 3) == 0 && g.cells_local() < ((size_t)1 << 30);
+}
+
+hipError_t launch_jacobi_block2(const Geom& g, const float* p_in, const float* b, float* p_out, int z_begin, int z_end, hipStream_t s)
+{
+	if (z_end <= z_begin) return hipSuccess;
+	if (!jacobi_block2_supported(g)) return hipErrorNotSupported;
+	static const int remap = env_b("FLUIDX_BLOCK_REMAP", 1);
+	static const int shape = env_b("FLUIDX_BLOCK_SHAPE", 44);      // rows * 10 + planes per wave (measurement knob)
+#define FX_BLK(BY_, BZ_) do { \
+		const int nby = g.Y / (BY_), nbz = (z_end - z_begin + (BZ_) - 1) / (BZ_); \
+		hipLaunchKernelGGL((k_jacobi_block2<BY_, BZ_>), dim3((nby * nbz + 3) / 4), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, nby, nbz, remap); } while (0)
+	switch (shape) {
+	case 42: FX_BLK(4, 2); break;
+	case 24: FX_BLK(2, 4); break;
+	case 22: FX_BLK(2, 2); break;
+	case 43: FX_BLK(4, 3); break;
+	default: FX_BLK(4, 4); break;
+	}
+#undef FX_BLK
+	return hipGetLastError();
+}
+
+}  // namespace fx

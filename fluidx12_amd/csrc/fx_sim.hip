@@ -889,6 +889,8 @@ int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp)
 		return want >= 3 && jacobi_strip3_supported(g) ? 3 : (want >= 2 ? 2 : 1);
 	}
 	if (!tb_supported(g)) return 1;
+	// X = 128: a 4 x 4-row block per wave, two sweeps (fx_jacobi_block.hip) -- the strips have too few waves there
+	if (jacobi_block2_supported(g) && !requested && !forced) return nzp >= 2 ? 2 : 1;
 	// default: two sweeps per launch in the register-strip kernel (fx_jacobi_strip.hip) where the geometry allows it,
 	// else one sweep per launch; the LDS kernel k_jacobi_tb<T> lost to both in every shape measured
 	// (profiles/r01_jacobi_tile_sweep.txt)
@@ -990,6 +992,7 @@ hipError_t launch_jacobi_fused(const Geom& g, const float* p_in, const float* b,
 	switch (sweeps) {
 	case 2: {
 		static const int use_tb = env_int("FLUIDX_FUSE2_TB", 0);      // 1 = the LDS kernel instead of the register strips
+		if (!use_tb && jacobi_block2_supported(g)) return launch_jacobi_block2(g, p_in, b, p_out, z_begin, z_end, s);
 		if (!use_tb && jacobi_strip_supported(g)) return launch_jacobi_strip(g, p_in, b, p_out, 2, z_begin, z_end, s);
 		return launch_tb<2>(g, p_in, b, p_out, z_begin, z_end, s);
 	}

@@ -146,6 +146,26 @@ def test_jacobi_temporal_blocking_bit_exact(dims, fuse):
     assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
 
 
+@pytest.mark.parametrize("dims,iters", [((128, 128, 128), 9), ((128, 128, 30), 7), ((128, 128, 5), 4), ((128, 128, 128), 40)])
+def test_x128_default_schedule_block_kernel_bit_exact(dims, iters):
+    """X = 128 (BASELINE configs[1], the reference's default grid): the default schedule runs two sweeps per launch in
+    k_jacobi_block2 (one 4 x 4-row block per wave), odd counts end in a single sweep; == oracle, bit for bit, including the
+    partial blocks of depths that are no multiple of four"""
+    X, Y, Z = dims
+    _, _, p = rand_state(X, Y, Z, 23)
+    b = np.random.default_rng(24).uniform(-1, 1, (Z, Y, X)).astype(f32)
+    f = make(dims, jacobi_iters=iters)
+    f.upload(fx.FIELD_PRESSURE, p)
+    f.upload(fx.FIELD_DIVERGENCE, b)
+    f.timing_enable(True); f.timing_read(True)
+    f.Jacobi(iters)
+    f.Synchronize()
+    t = f.timing_read(True)
+    assert t.jacobi_sweeps == iters and t.jacobi_launches == (iters + 1) // 2
+    q, _ = orc.jacobi(p, b, iters)
+    assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
+
+
 def test_jacobi_faithful_mode_matches_oracle():
     X = 32
     s = orc.Sim(X, X, X, iters=64, mode=1)

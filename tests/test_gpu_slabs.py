@@ -80,6 +80,16 @@ def test_slabs_with_register_strips(dims, nranks, hj, overlap):
 
 
 @pytest.mark.parametrize("overlap", [True, False])
+def test_slabs_x128_block_kernel(overlap):
+    """X = 128 slabs: the rounds run in k_jacobi_block2 on the shrinking plane ranges (ragged depths, blocks cut by the range end)"""
+    dims = (128, 128, 72)
+    ref = run_single(dims, 3, jacobi_iters=13, jacobi_fuse=1)
+    fl = run_slabs(dims, 3, 3, jacobi_iters=13, halo_jacobi=5, halo_advect=6, overlap=overlap)
+    assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
+    assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
+
+
+@pytest.mark.parametrize("overlap", [True, False])
 def test_slabs_faithful_mode(overlap):
     """reference-faithful Jacobi (64-sweep cap, per-cell freeze at |delta| < 1e-3): the freeze mask of the face planes
     travels with the pressure halo, so the decomposed run freezes exactly the cells the single domain freezes"""
