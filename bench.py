@@ -313,6 +313,10 @@ def main():
                 m_.set_option(capi.OPT_OVERLAP, ov)
                 m_.set_option(capi.OPT_JACOBI_ROUND, rnd)
 
+        if os.environ.get("FLUIDX_BENCH_ADAPTIVE", "1") == "0":        # A/B knob: always exchange halo_advect planes
+            for m_ in members:
+                m_.set_option(capi.OPT_ADAPTIVE_HALO, 0)
+
         if args.schedule != "auto":
             ov, rnd = (int(v) for v in args.schedule.split(","))
             apply(ov, rnd)
@@ -356,6 +360,15 @@ def main():
     render = None
     if fluid is not None:
         timing = (members[len(members) // 2] if loop else fluid).timing_read(reset=True)   # loop-back: an inner rank's stages
+        if N > 1 and schedule is not None and timing.steps:
+            # what this rank (loop-back: an inner rank) sent across its faces, per face and step, and how many planes its advection
+            # exchange carried (FX_OPT_ADAPTIVE_HALO: the measured need; halo_advect planes per face otherwise)
+            my_rank = len(members) // 2 if loop else rank
+            faces = (1 if my_rank > 0 else 0) + (1 if my_rank < N - 1 else 0)
+            schedule["halo_advect_allocated_planes"] = halo_adv if halo_adv else 6
+            schedule["advect_planes_per_face_and_step"] = timing.advect_halo_planes / max(timing.steps, 1) / max(faces, 1)
+            schedule["sent_MB_per_face_and_step"] = timing.exchange_bytes / max(timing.steps, 1) / max(faces, 1) / 1e6
+            schedule["adaptive_halo"] = os.environ.get("FLUIDX_BENCH_ADAPTIVE", "1") != "0"
         if N == 1 and G > 1 and not args.no_render:
             # config 3's second half, reported beside (never inside) `value`: the cube-map-space ray march of the state the
             # timed steps left behind -- default camera at 1920x1080 (FluidX12.cpp:243-253), OPTIMIZED = light volume + view pass

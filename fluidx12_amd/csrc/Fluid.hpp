@@ -91,6 +91,9 @@ public:
 	bool LoadCheckpoint(const char* path) { m_status = fx_checkpoint_load(m_ctx, path); return m_status == FX_OK; }
 
 	// not in the reference: the void methods above cannot report failure there either (debug layer only)
+	// waits for everything this object enqueued; false (LastStatus() == FX_E_HALO) if a multi-GPU step's advection left its halo:
+	// the reference's void methods cannot report that, so a caller that renders or stores fields checks here (or LastStatus())
+	bool Synchronize() { m_status = fx_synchronize(m_ctx); return m_status == FX_OK; }
 	int LastStatus() const { return m_status; }
 	fx_ctx* Handle() const { return m_ctx; }
 

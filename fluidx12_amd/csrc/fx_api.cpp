@@ -122,6 +122,10 @@ void free_all(fx_ctx* c)
 		c->sh_scratch[0], c->sh_scratch[1], c->sh_scratch[2], c->sh_scratch[3] };
 	for (void* q : others) if (q) (void)hipFree(q);
 	for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+	if (c->step_rec) (void)hipFree(c->step_rec);
+	if (c->gath_dev) (void)hipFree(c->gath_dev);
+	if (c->rec_host) (void)hipHostFree(c->rec_host);
+	if (c->rec_ev) (void)hipEventDestroy(c->rec_ev);
 	if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
 }
 
@@ -182,6 +186,7 @@ int do_exchange(fx_ctx* ctx, const std::vector<fx_ctx*>& M, const ExchSpec* spec
 			halo_segments(M[i], it, n, segs[i]);
 		}
 		total += segs[i].size();
+		if (M[i]->timing_on) for (const Seg& sg : segs[i]) M[i]->acc.exchange_bytes += sg.bytes;     // what this rank sends
 	}
 	if (!total) return FX_OK;
 	return ctx->group->transport->exchange(ctx->group, segs, s, channel);
@@ -211,11 +216,82 @@ int advect_range(fx_ctx* ctx, hipStream_t s, Range r, bool own_only)
 	Geom g = ctx->g;
 	// only halo_advect planes per side were refreshed by EX_ADVECT_IN; the allocation may be wider (max with halo_jacobi), and
 	// a tap into those stale planes must count as "left the exchanged halo", not as present data
-	const int Ha = (int)ctx->desc.halo_advect;
-	g.zlo = std::max(g.zlo, g.z0 - Ha); g.zhi = std::min(g.zhi, g.z0 + g.nz - 1 + Ha);
+	// (with FX_OPT_ADAPTIVE_HALO: only the planes this step's exchange carried, adv_w_lo / adv_w_hi <= halo_advect)
+	g.zlo = std::max(g.zlo, g.z0 - ctx->adv_w_lo); g.zhi = std::min(g.zhi, g.z0 + g.nz - 1 + ctx->adv_w_hi);
 	if (own_only) { g.zlo = std::max(g.zlo, g.z0); g.zhi = std::min(g.zhi, g.z0 + g.nz - 1); }
 	FX_HIP(launch_advect(g, sp, ctx->half, ctx->vel[0], ctx->col[1 - par], ctx->vel[1], ctx->col[par],
 		r.lo, r.hi, ctx->halo_overflow, s));
+	return FX_OK;
+}
+
+// ---- the per-step record (fx_context.h): written behind the projection, read by the next step ------------------------------
+int options_digest(const fx_ctx* c)
+{
+	uint32_t h = 2166136261u;
+	for (uint32_t v : { (uint32_t)c->opt_overlap, (uint32_t)c->opt_round, (uint32_t)c->opt_adaptive }) h = (h ^ v) * 16777619u;
+	return (int)(h & 0x3FFFFFFFu);
+}
+
+int record_step(fx_ctx* ctx, std::vector<fx_ctx*>& M, hipStream_t s)
+{
+	if (!multi_rank(ctx) || !ctx->step_rec) return FX_OK;
+	for (fx_ctx* m : M) {
+		DeviceGuard dg(m->device);
+		FX_HIP(launch_face_need(m->g, m->half, m->vel[0], m->time_step, (int)m->desc.advect_address, options_digest(m), m->halo_overflow, m->step_rec, s));
+	}
+	DeviceGuard dg(ctx->device);
+	if (ctx->group->transport->is_local()) {
+		for (fx_ctx* m : M) FX_HIP(hipMemcpyAsync(m->rec_host, m->step_rec, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+		FX_HIP(hipEventRecord(ctx->rec_ev, s));
+	} else {
+		// off the compute stream when there is a side stream: the next step's interior advection need not wait for the gather
+		hipStream_t cs = s;
+		if (overlap_level(ctx) >= 1) { int rc = comm_fork(ctx, s); if (rc) return rc; cs = ctx->group->comm_stream; }
+		if (ctx->group->transport->allgather(ctx->step_rec, 4, ctx->gath_dev, cs) != FX_OK) { ctx->last_error = "rccl: all-gather of the step record failed"; return FX_E_COMM; }
+		FX_HIP(hipMemcpyAsync(ctx->rec_host, ctx->gath_dev, 4 * sizeof(int) * (size_t)ctx->nranks, hipMemcpyDeviceToHost, cs));
+		FX_HIP(hipEventRecord(ctx->rec_ev, cs));
+	}
+	for (fx_ctx* m : M) { m->rec_pending = true; m->need_valid = true; m->rec_dt = m->time_step; }
+	return FX_OK;
+}
+
+// Waits for the previous step's record and takes the step's decisions from it -- every rank holds the same records and therefore
+// decides alike: FX_E_HALO if ANY rank's advection left its exchanged planes (or the next one would need more than halo_advect),
+// FX_E_STATE if the ranks disagree about the schedule options; else the planes this step's advection exchange carries per face
+// (FX_OPT_ADAPTIVE_HALO: the measured need of the two slabs that share the face; otherwise, or when the measurement does not
+// cover this step -- first step, velocity uploaded since, larger dt -- the whole halo_advect).
+int consume_record(fx_ctx* ctx, std::vector<fx_ctx*>& M)
+{
+	const int Ha = (int)ctx->desc.halo_advect;
+	for (fx_ctx* m : M) { m->adv_w_lo = has_lower(m) ? Ha : 0; m->adv_w_hi = has_upper(m) ? Ha : 0; }
+	if (!multi_rank(ctx) || !ctx->rec_pending) return FX_OK;
+	{
+		DeviceGuard dg(ctx->device);
+		FX_HIP(hipEventSynchronize(ctx->rec_ev));
+	}
+	const bool local = ctx->group->transport->is_local();
+	const int n = ctx->nranks;
+	auto rec = [&](int r) -> const int* { return local ? M[(size_t)r]->rec_host : ctx->rec_host + 4 * r; };
+	bool fault = false, mismatch = false, usable = ctx->opt_adaptive != 0;
+	for (int r = 0; r < n; ++r) { fault = fault || rec(r)[3] != 0; mismatch = mismatch || rec(r)[2] != rec(0)[2]; }
+	for (fx_ctx* m : M) { usable = usable && m->need_valid && m->time_step <= m->rec_dt; m->rec_pending = false; }
+	if (fault) {
+		for (fx_ctx* m : M) m->halo_fault = true;
+		ctx->last_error = "the previous step's advection left the exchanged halo on at least one rank";
+		return FX_E_HALO;
+	}
+	if (mismatch) { ctx->last_error = "the ranks of the chain run with different schedule options (fx_set_option)"; return FX_E_STATE; }
+	if (!usable) return FX_OK;
+	for (int r = 0; r + 1 < n; ++r)
+		if (std::max(rec(r)[1], rec(r + 1)[0]) > Ha) {
+			ctx->last_error = "the next advection needs more planes across a slab face than halo_advect provides";
+			return FX_E_HALO;                            // nothing of this step has touched a field yet
+		}
+	for (fx_ctx* m : M) {
+		const int r = m->rank;
+		m->adv_w_lo = r > 0 ? std::max(rec(r - 1)[1], rec(r)[0]) : 0;
+		m->adv_w_hi = r + 1 < n ? std::max(rec(r)[1], rec(r + 1)[0]) : 0;
+	}
 	return FX_OK;
 }
 
@@ -229,26 +305,37 @@ int advect_all(fx_ctx* ctx, std::vector<fx_ctx*>& M, hipStream_t s)
 	bool col_ready = multi_rank(ctx);
 	for (fx_ctx* m : M) col_ready = col_ready && m->col_halo_buf == 1 - (int)m->frame_parity;
 	for (fx_ctx* m : M) m->col_halo_buf = -1;
-	if (col_ready) FX_HIP(hipStreamWaitEvent(s, ctx->group->ev_col_done, 0));
-	const ExchSpec spec{ col_ready ? EX_ADVECT_VEL : EX_ADVECT_IN, Ha, 0 };
 	bool ov = overlap_level(ctx) >= 1;
 	if (ov && ctx->group->min_nz <= 2 * Ha) ov = false;        // decided on the thinnest slab of the chain: the same on every rank
 	if (!ov) {
+		if ((rc = consume_record(ctx, M))) return rc;
+		if (col_ready) FX_HIP(hipStreamWaitEvent(s, ctx->group->ev_col_done, 0));
+		const ExchSpec spec{ col_ready ? EX_ADVECT_VEL : EX_ADVECT_IN, Ha, 0 };
 		if ((rc = do_exchange(ctx, M, &spec, 1, s))) return rc;
-		for (fx_ctx* m : M) { ScopedMark mk(m, s, MK_ADVECT); if ((rc = advect_range(m, s, owned(m), false))) return rc; }
+		for (fx_ctx* m : M) {
+			ScopedMark mk(m, s, MK_ADVECT);
+			if (m->timing_on) m->acc.advect_halo_planes += (uint64_t)(m->adv_w_lo + m->adv_w_hi);
+			if ((rc = advect_range(m, s, owned(m), false))) return rc;
+		}
 		return FX_OK;
 	}
-	if ((rc = comm_fork(ctx, s))) return rc;
-	if ((rc = do_exchange(ctx, M, &spec, 1, ctx->group->comm_stream))) return rc;
-	if ((rc = comm_mark_done(ctx))) return rc;
+	// the interior first (it reads owned planes only, whatever the exchange will carry): the device is busy while the host waits
+	// for the previous step's record, which sizes the exchange
+	if ((rc = comm_fork(ctx, s))) return rc;                   // the comm stream picks up behind the previous step
 	for (fx_ctx* m : M) {
 		ScopedMark mk(m, s, MK_ADVECT);
 		const Range o = owned(m);
 		if ((rc = advect_range(m, s, Range{ o.lo + (has_lower(m) ? Ha : 0), o.hi - (has_upper(m) ? Ha : 0) }, true))) return rc;
 	}
+	if ((rc = consume_record(ctx, M))) return rc;
+	if (col_ready) FX_HIP(hipStreamWaitEvent(ctx->group->comm_stream, ctx->group->ev_col_done, 0));
+	const ExchSpec spec{ col_ready ? EX_ADVECT_VEL : EX_ADVECT_IN, Ha, 0 };
+	if ((rc = do_exchange(ctx, M, &spec, 1, ctx->group->comm_stream))) return rc;
+	if ((rc = comm_mark_done(ctx))) return rc;
 	if ((rc = comm_join(ctx, s))) return rc;
 	for (fx_ctx* m : M) {
 		ScopedMark mk(m, s, MK_ADVECT);
+		if (m->timing_on) m->acc.advect_halo_planes += (uint64_t)(m->adv_w_lo + m->adv_w_hi);
 		const Range o = owned(m);
 		if (has_lower(m) && (rc = advect_range(m, s, Range{ o.lo, o.lo + Ha }, false))) return rc;
 		if (has_upper(m) && (rc = advect_range(m, s, Range{ o.hi - Ha, o.hi }, false))) return rc;
@@ -483,6 +570,7 @@ int simulate_impl(fx_ctx* ctx, hipStream_t s)
 			if (launch_copy_velocity(m->g, m->half, m->vel[1], m->vel[0], s) != hipSuccess) return FX_E_DEVICE;
 		}
 	}
+	if ((rc = record_step(ctx, M, s))) return rc;
 	for (fx_ctx* m : M) { if (m->timing_on) m->acc.steps += 1; if (ctx->time_step > 0.0f) m->steps_simulated += 1; }
 	return FX_OK;
 }
@@ -896,6 +984,17 @@ int fx_get_frame_info(fx_ctx* ctx, fx_frame_info* out)
 	return FX_OK;
 }
 
+// after a device synchronisation: has an advection of this context left its exchanged planes (and nobody acknowledged it yet)?
+// The fields are then not the single-domain run's any more: whatever reads them back or stores them says so.
+static int halo_fault_status(fx_ctx* c)
+{
+	if (!c->halo_overflow) return FX_OK;
+	unsigned flag = 0;
+	if (hipMemcpy(&flag, c->halo_overflow, sizeof flag, hipMemcpyDeviceToHost) != hipSuccess) return FX_E_DEVICE;
+	if (flag) c->halo_fault = true;
+	return c->halo_fault ? FX_E_HALO : FX_OK;
+}
+
 int fx_synchronize(fx_ctx* ctx)
 {
 	if (!ctx) return FX_E_INVALID;
@@ -905,11 +1004,12 @@ int fx_synchronize(fx_ctx* ctx)
 	for (fx_ctx* c : M) {
 		DeviceGuard dg(c->device);
 		if (hipDeviceSynchronize() != hipSuccess) return FX_E_DEVICE;
-		unsigned flag = 0;
-		if (hipMemcpy(&flag, c->halo_overflow, sizeof flag, hipMemcpyDeviceToHost) != hipSuccess) return FX_E_DEVICE;
-		if (flag) {
-			(void)hipMemset(c->halo_overflow, 0, sizeof flag);
+		const int st = halo_fault_status(c);
+		if (st == FX_E_DEVICE) return st;
+		if (st == FX_E_HALO) {                 // reported here, and acknowledged: the next step starts clean
+			(void)hipMemset(c->halo_overflow, 0, sizeof(unsigned));
 			(void)hipDeviceSynchronize();      // the context's streams do not order against the NULL stream
+			c->halo_fault = false;
 			rc = FX_E_HALO;
 		}
 	}
@@ -960,6 +1060,13 @@ int fx_upload(fx_ctx* ctx, int field, const void* host, size_t bytes)
 	const size_t es = elem_size(ctx);
 	switch (field) {
 	case FX_FIELD_VELOCITY: case FX_FIELD_VELOCITY1: {
+		if (field == FX_FIELD_VELOCITY && ctx->group) {
+			// the next advection exchange is sized from a measurement of THIS buffer (FX_OPT_ADAPTIVE_HALO).  A loop-back group
+			// simply exchanges the whole halo once; the neighbours of an RCCL rank could not know, so the upload is refused
+			// while a measurement is out (switch the option off on every rank first, or upload before the first step)
+			if (!ctx->group->transport->is_local() && ctx->opt_adaptive && ctx->rec_pending) return FX_E_STATE;
+			ctx->need_valid = false;
+		}
 		char* dst = (char*)ctx->vel[field == FX_FIELD_VELOCITY1];
 		if ((rc = ensure_stage(ctx, need))) return rc;
 		FX_HIP(hipMemcpy(ctx->stage, host, need, hipMemcpyHostToDevice));
@@ -1006,6 +1113,7 @@ int fx_download(fx_ctx* ctx, int field, void* host, size_t bytes)
 	if (bytes != need) return FX_E_INVALID;
 	DeviceGuard dg(ctx->device);
 	FX_HIP(hipDeviceSynchronize());
+	if (field <= FX_FIELD_DIVERGENCE && (rc = halo_fault_status(ctx))) return rc;     // simulation fields of a faulted slab run are not handed out as if nothing had happened
 	const size_t n = ctx->g.cells_owned(), off = (size_t)ctx->g.H * ctx->g.plane(), cl = ctx->g.cells_local();
 	const size_t es = elem_size(ctx);
 	switch (field) {
@@ -1225,6 +1333,19 @@ static int make_comm_stream(fx_comm_group* g, int device)
 	return FX_OK;
 }
 
+// buffers of the per-step record (fx_context.h); nrec = records the host copy holds (RCCL: every rank's; loop-back member: its own)
+static int make_step_record(fx_ctx* ctx, int nrec, bool gathered)
+{
+	DeviceGuard dg(ctx->device);
+	FX_HIP(hipMalloc((void**)&ctx->step_rec, 4 * sizeof(int)));
+	FX_HIP(hipMemset(ctx->step_rec, 0, 4 * sizeof(int)));
+	if (gathered) FX_HIP(hipMalloc((void**)&ctx->gath_dev, 4 * sizeof(int) * (size_t)nrec));
+	FX_HIP(hipHostMalloc((void**)&ctx->rec_host, 4 * sizeof(int) * (size_t)nrec, hipHostMallocDefault));
+	std::memset(ctx->rec_host, 0, 4 * sizeof(int) * (size_t)nrec);
+	FX_HIP(hipEventCreateWithFlags(&ctx->rec_ev, hipEventDisableTiming));
+	return FX_OK;
+}
+
 int fx_comm_init_rank(fx_ctx* ctx, const void* id, size_t bytes, int rank, int nranks)
 {
 	if (!ctx || !id) return FX_E_INVALID;
@@ -1241,7 +1362,10 @@ int fx_comm_init_rank(fx_ctx* ctx, const void* id, size_t bytes, int rank, int n
 	{	// every rank must run the same schedule: same grid, halos, sweep count, Jacobi mode and storage (min == max of a digest)
 		const fx_desc& d = ctx->desc;
 		uint32_t h = 2166136261u;
-		for (uint32_t v : { d.grid_x, d.grid_y, d.grid_z, d.halo_advect, d.halo_jacobi, d.jacobi_iters, d.jacobi_mode, d.storage, d.advect_address, (uint32_t)nranks })
+		// ... and the same schedule: what selects the exchange sequence (FX_FLAG_NO_OVERLAP / FX_OPT_OVERLAP, FX_OPT_JACOBI_ROUND,
+		// FX_OPT_ADAPTIVE_HALO) is part of the digest; later changes go through fx_set_option, which checks them across the chain
+		for (uint32_t v : { d.grid_x, d.grid_y, d.grid_z, d.halo_advect, d.halo_jacobi, d.jacobi_iters, d.jacobi_mode, d.storage, d.advect_address, (uint32_t)nranks,
+				d.flags & (FX_FLAG_NO_OVERLAP | FX_FLAG_JACOBI_FUSE_MASK), (uint32_t)ctx->opt_overlap, (uint32_t)ctx->opt_round, (uint32_t)ctx->opt_adaptive })
 			h = (h ^ v) * 16777619u;
 		const int digest = (int)(h & 0x3FFFFFFFu);
 		int lo = 0, hi = 0;
@@ -1251,6 +1375,25 @@ int fx_comm_init_rank(fx_ctx* ctx, const void* id, size_t bytes, int rank, int n
 			std::fprintf(stderr, "fluidx: %s\n", ctx->last_error.c_str());
 			delete t; delete g;
 			return FX_E_INVALID;
+		}
+	}
+	if ((rc = make_step_record(ctx, nranks, true))) { delete t; delete g; return rc; }
+	{	// the slabs must tile the grid in rank order: rank 0 starts at plane 0, the last ends at Zg (check_slab_chain), and every
+		// slab starts where its lower neighbour ends -- gaps or overlaps between middle slabs would exchange the wrong planes
+		DeviceGuard dg(ctx->device);
+		const int mine[4] = { ctx->g.z0, ctx->g.nz, 0, 0 };
+		bool ok = hipMemcpy(ctx->step_rec, mine, sizeof mine, hipMemcpyHostToDevice) == hipSuccess &&
+			t->allgather(ctx->step_rec, 4, ctx->gath_dev, ctx->stream) == FX_OK &&
+			hipMemcpyAsync(ctx->rec_host, ctx->gath_dev, 4 * sizeof(int) * (size_t)nranks, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+			hipStreamSynchronize(ctx->stream) == hipSuccess;
+		bool tiles = ok;
+		for (int r = 0; ok && r + 1 < nranks; ++r) tiles = tiles && ctx->rec_host[4 * r] + ctx->rec_host[4 * r + 1] == ctx->rec_host[4 * (r + 1)];
+		if (ok) ok = hipMemset(ctx->step_rec, 0, 4 * sizeof(int)) == hipSuccess;
+		if (!ok || !tiles) {
+			ctx->last_error = ok ? "fx_comm_init_rank: the slabs of the ranks do not tile the grid in rank order" : "fx_comm_init_rank: exchanging the slab ranges failed";
+			std::fprintf(stderr, "fluidx: %s\n", ctx->last_error.c_str());
+			delete t; delete g;
+			return ok ? FX_E_INVALID : FX_E_COMM;
 		}
 	}
 	ctx->group = g; ctx->rank = rank; ctx->nranks = nranks;
@@ -1284,6 +1427,7 @@ int fx_comm_gather_color(fx_ctx* ctx, void* stream, fx_ctx* full, int root, cons
 	}
 	DeviceGuard dg(ctx->device);
 	hipStream_t s = pick_stream(ctx, stream);
+	if (ctx->halo_fault) return FX_E_HALO;             // a colour field that is known to be off is not gathered into a picture
 	ScopedMark mk(ctx, s, MK_EXCH);
 	int rc = ctx->group->transport->gather(ctx->group, parts, root, s);
 	if (rc) return rc;
@@ -1297,17 +1441,28 @@ int fx_comm_gather_color(fx_ctx* ctx, void* stream, fx_ctx* full, int root, cons
 int fx_set_option(fx_ctx* ctx, uint32_t option, uint32_t value)
 {
 	if (!ctx) return FX_E_INVALID;
+	int* slot = nullptr;
 	switch (option) {
-	case FX_OPT_OVERLAP:
-		if (value > 3) return FX_E_INVALID;
-		ctx->opt_overlap = (int)value;
-		return FX_OK;
-	case FX_OPT_JACOBI_ROUND:
-		if (value < 1 || value > ctx->desc.halo_jacobi) return FX_E_INVALID;
-		ctx->opt_round = (int)value;
-		return FX_OK;
+	case FX_OPT_OVERLAP: if (value > 3) return FX_E_INVALID; slot = &ctx->opt_overlap; break;
+	case FX_OPT_JACOBI_ROUND: if (value < 1 || value > ctx->desc.halo_jacobi) return FX_E_INVALID; slot = &ctx->opt_round; break;
+	case FX_OPT_ADAPTIVE_HALO: if (value > 1) return FX_E_INVALID; slot = &ctx->opt_adaptive; break;
+	default: return FX_E_INVALID;
 	}
-	return FX_E_INVALID;
+	// These options select the exchange sequence and the exchanged byte counts: ranks that disagree would hang RCCL or corrupt
+	// halos.  On an RCCL chain the call is therefore collective -- every rank makes it, with the same arguments, between two
+	// steps -- and the values are compared across the chain (min == max) before any of them takes effect.
+	if (ctx->group && !ctx->group->transport->is_local() && ctx->nranks > 1) {
+		DeviceGuard dg(ctx->device);
+		const int key = (int)(((option & 0xFu) << 8) | (value & 0xFFu));
+		int lo = 0, hi = 0, rc;
+		if ((rc = ctx->group->transport->min_over_ranks(key, ctx->stream, &lo)) || (rc = ctx->group->transport->min_over_ranks(-key, ctx->stream, &hi))) return rc;
+		if (lo != key || -hi != key) {
+			ctx->last_error = "fx_set_option: the ranks of the chain asked for different options";
+			return FX_E_INVALID;
+		}
+	}
+	*slot = (int)value;
+	return FX_OK;
 }
 
 int fx_comm_init_local(fx_ctx** ctxs, int nranks)
@@ -1329,6 +1484,8 @@ int fx_comm_init_local(fx_ctx** ctxs, int nranks)
 		for (int q = 0; q < r; ++q) if (ctxs[q] == ctxs[r]) return FX_E_INVALID;
 		zexp += ctxs[r]->g.nz;
 	}
+	for (int r = 0; r < nranks; ++r)
+		if (!ctxs[r]->step_rec) { if (int rc = make_step_record(ctxs[r], 1, false)) return rc; }
 	fx_comm_group* g = new fx_comm_group();
 	g->transport = make_local_transport();
 	g->refs = nranks;

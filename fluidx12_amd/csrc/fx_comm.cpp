@@ -22,8 +22,8 @@ int exchange_items(fx_ctx* c, int which_set, int k, int pidx, ExchItem out[4])
 	const size_t es = c->half ? 2 : 4;
 	switch (which_set) {
 	case EX_ADVECT_IN:
-		out[0] = ExchItem{ (char*)c->vel[0], plane * es, 3, k, nullptr };
-		out[1] = ExchItem{ (char*)c->col[1 - c->frame_parity], plane * es * 4, 1, k, nullptr };
+		out[0] = ExchItem{ (char*)c->vel[0], plane * es, 3, k, nullptr, c->adv_w_lo, c->adv_w_hi };
+		out[1] = ExchItem{ (char*)c->col[1 - c->frame_parity], plane * es * 4, 1, k, nullptr, c->adv_w_lo, c->adv_w_hi };
 		return 2;
 	case EX_UZ1:
 		out[0] = ExchItem{ (char*)c->vel[1] + 2 * (size_t)c->g.nzl() * plane * es, plane * es, 1, k, nullptr };
@@ -37,7 +37,7 @@ int exchange_items(fx_ctx* c, int which_set, int k, int pidx, ExchItem out[4])
 		out[1] = ExchItem{ (char*)c->frozen, plane, 1, k, nullptr };      // the neighbour's freeze state travels with its pressure
 		return 2;
 	case EX_ADVECT_VEL:
-		out[0] = ExchItem{ (char*)c->vel[0], plane * es, 3, k, nullptr };
+		out[0] = ExchItem{ (char*)c->vel[0], plane * es, 3, k, nullptr, c->adv_w_lo, c->adv_w_hi };
 		return 1;
 	case EX_COLOR_CUR:
 		out[0] = ExchItem{ (char*)c->col[c->frame_parity], plane * es * 4, 1, k, nullptr };
@@ -55,14 +55,15 @@ void halo_segments(const fx_ctx* c, const ExchItem* items, int n, std::vector<Se
 	for (int i = 0; i < n; ++i) {
 		const ExchItem& it = items[i];
 		if (it.k <= 0) continue;
-		const size_t pb = it.plane_bytes, bytes = (size_t)it.k * pb;
+		const size_t pb = it.plane_bytes;
+		const int klo = it.k_lo >= 0 ? it.k_lo : it.k, khi = it.k_hi >= 0 ? it.k_hi : it.k;   // the same number on both sides of a face
 		for (int cpt = 0; cpt < it.ncomp; ++cpt) {
 			char* base = it.base + (size_t)cpt * g.nzl() * pb;
 			char* rbase = (it.recv_base ? it.recv_base : it.base) + (size_t)cpt * g.nzl() * pb;
-			if (c->rank > 0)                     // bottom k owned planes go down, the lower halo fills from below
-				out.push_back(Seg{ base + (size_t)g.H * pb, rbase + (size_t)(g.H - it.k) * pb, bytes, -1 });
-			if (c->rank + 1 < c->nranks)         // top k owned planes go up, the upper halo fills from above
-				out.push_back(Seg{ base + (size_t)(g.H + g.nz - it.k) * pb, rbase + (size_t)(g.H + g.nz) * pb, bytes, +1 });
+			if (c->rank > 0 && klo > 0)          // bottom k owned planes go down, the lower halo fills from below
+				out.push_back(Seg{ base + (size_t)g.H * pb, rbase + (size_t)(g.H - klo) * pb, (size_t)klo * pb, -1 });
+			if (c->rank + 1 < c->nranks && khi > 0)   // top k owned planes go up, the upper halo fills from above
+				out.push_back(Seg{ base + (size_t)(g.H + g.nz - khi) * pb, rbase + (size_t)(g.H + g.nz) * pb, (size_t)khi * pb, +1 });
 		}
 	}
 }
@@ -71,6 +72,7 @@ void halo_segments(const fx_ctx* c, const ExchItem* items, int n, std::vector<Se
 struct LocalTransport : Transport {
 	bool is_local() const override { return true; }
 	int min_over_ranks(int v, hipStream_t, int* out) override { *out = v; return FX_OK; }   // the caller sees every member
+	int allgather(const int*, int, int*, hipStream_t) override { return FX_OK; }
 	int exchange(fx_comm_group* grp, const std::vector<std::vector<Seg>>& segs, hipStream_t s, int channel) override
 	{
 		(void)channel;                                   // one device: copies on the given stream either way
@@ -116,6 +118,7 @@ struct RcclApi {
 	decltype(&ncclGroupStart) GroupStart = nullptr;
 	decltype(&ncclGroupEnd) GroupEnd = nullptr;
 	decltype(&ncclAllReduce) AllReduce = nullptr;
+	decltype(&ncclAllGather) AllGather = nullptr;
 	decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 
@@ -140,7 +143,7 @@ static RcclApi* rccl(std::string* err)
 #define FX_SYM(f) api.f = (decltype(api.f))dlsym(api.handle, "nccl" #f); \
 	if (!api.f) { if (err) *err = "librccl lacks nccl" #f; api.handle = nullptr; return nullptr; }
 	FX_SYM(GetUniqueId) FX_SYM(CommInitRank) FX_SYM(CommDestroy) FX_SYM(Send) FX_SYM(Recv)
-	FX_SYM(GroupStart) FX_SYM(GroupEnd) FX_SYM(AllReduce) FX_SYM(GetErrorString)
+	FX_SYM(GroupStart) FX_SYM(GroupEnd) FX_SYM(AllReduce) FX_SYM(AllGather) FX_SYM(GetErrorString)
 #undef FX_SYM
 	return &api;
 }
@@ -180,6 +183,10 @@ struct RcclTransport : Transport {
 		if (rc == FX_OK && (hipMemcpyAsync(out, d, sizeof v, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) rc = FX_E_DEVICE;
 		(void)hipFree(d);
 		return rc;
+	}
+	int allgather(const int* send_dev, int count, int* recv_dev, hipStream_t s) override
+	{
+		return api->AllGather(send_dev, recv_dev, (size_t)count, ncclInt32, comm, s) == ncclSuccess ? FX_OK : FX_E_COMM;
 	}
 	int exchange(fx_comm_group* grp, const std::vector<std::vector<Seg>>& segs, hipStream_t s, int channel) override
 	{

@@ -65,6 +65,20 @@ struct fx_ctx {
 	std::string last_error;
 	int col_halo_buf = -1;          // FX_OPT_OVERLAP 3: index of the colour buffer whose halo planes the previous step already exchanged (-1: none)
 	uint64_t steps_simulated = 0;   // fx_simulate calls with dt > 0 (recorded in checkpoints)
+	// ---- per-step record of a slab rank (ABI 4): { planes the next advection needs below / above the slab, digest of the schedule
+	// options, halo-overflow flag }.  Written on the device behind the projection, all-gathered over the chain (RCCL) and copied to
+	// pinned host memory; the NEXT fx_simulate waits for it: it sizes the advection exchange per face (FX_OPT_ADAPTIVE_HALO), and
+	// an overflow or an option mismatch on ANY rank stops EVERY rank there with the same status.
+	int* step_rec = nullptr;        // device, 4 ints
+	int* gath_dev = nullptr;        // device, 4 * nranks ints (RCCL groups)
+	int* rec_host = nullptr;        // pinned host: 4 * nranks ints (RCCL) or 4 (loop-back member)
+	hipEvent_t rec_ev = nullptr;
+	bool rec_pending = false;       // the previous step's record is on its way
+	bool need_valid = false;        // velocity[0] is what the record was measured on
+	float rec_dt = 0.0f;            // time step the needs were measured with (they hold for any smaller one)
+	int opt_adaptive = 1;           // FX_OPT_ADAPTIVE_HALO
+	int adv_w_lo = 0, adv_w_hi = 0; // planes the current step's advection exchange carries across the lower / upper face
+	bool halo_fault = false;        // an overflow was seen and not yet acknowledged by fx_synchronize
 };
 
 namespace fx {
@@ -72,7 +86,8 @@ namespace fx {
 // one array taking part in a halo exchange: `ncomp` back-to-back sub-arrays (velocity = 3 component
 // planes) of nzl planes each, plane_bytes per plane, k boundary planes travelling to each z-neighbour
 // recv_base (optional): the halo planes land in another array of the same geometry than the one the face planes leave from
-struct ExchItem { char* base; size_t plane_bytes; int ncomp; int k; char* recv_base; };
+// k_lo / k_hi: planes exchanged with the lower / upper neighbour when they differ from k (the advection halo follows the measured need per face)
+struct ExchItem { char* base; size_t plane_bytes; int ncomp; int k; char* recv_base; int k_lo = -1, k_hi = -1; };
 
 // a run of whole planes travelling between z-neighbours: `send` goes to rank + dir, `recv` comes from it.
 // Both sides of a pair build their lists from the same items in the same order, so the j-th segment a rank
@@ -96,6 +111,9 @@ struct Transport {
 	virtual bool is_local() const = 0;
 	// min of `v` over the ranks of the chain (RCCL: an all-reduce; loop-back: the caller combines its members itself)
 	virtual int min_over_ranks(int v, hipStream_t s, int* out) = 0;
+	// every rank contributes `count` device ints, every rank receives all of them in rank order (RCCL: ncclAllGather; the
+	// loop-back transport has no use for it: its driver sees every member)
+	virtual int allgather(const int* send_dev, int count, int* recv_dev, hipStream_t s) = 0;
 };
 
 }  // namespace fx

@@ -77,6 +77,9 @@ int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp);
 bool jacobi_prefers_three(const Geom& g, int requested, int nzp);
 hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const float* p,
 	void* vel_out, int z_begin, int z_end, hipStream_t s);
+// multi-GPU: what the next advection will need from the z-neighbours (rec[0] planes below, rec[1] above; exact for time steps
+// <= dt), closed with the options digest (rec[2]) and this step's halo-overflow flag (rec[3]); rec = 4 device ints
+hipError_t launch_face_need(const Geom& g, int half_store, const void* vel, float dt, int address, int digest, const unsigned* halo_overflow, int* rec, hipStream_t s);
 hipError_t launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t s);   // device-to-device, as a kernel
 hipError_t launch_copy_velocity(const Geom& g, int half_store, const void* vel_in, void* vel_out, hipStream_t s);
 

@@ -714,6 +714,43 @@ __global__ __launch_bounds__(256) void k_project_v4(const Geom g, const float* _
 	*reinterpret_cast<float4*>(vel_out + 2u * stride + off) = make_float4(oz[0], oz[1], oz[2], oz[3]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// What the NEXT advection will need from the z-neighbours, measured on the velocity the projection has just written
+// (multi-GPU slabs; no reference counterpart).  For every owned voxel the z taps of its back-trace are computed with the
+// arithmetic of k_advect (pz, az = fma(-uz, dt, pz), tz = az * Zg - 0.5, floor; CLAMP / MIRROR); need[0] = planes wanted below
+// the slab's first plane, need[1] = above its last.  Exact, not a bound: the exchange then carries exactly the planes the
+// kernel will touch (for any dt' <= dt the need can only shrink).  One read of uz, one atomicMax per wave that needs anything.
+// ---------------------------------------------------------------------------------------------
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_face_need(const Geom g, const typename Store<HALF>::S* __restrict__ uz, float dt, int address, int* __restrict__ need)
+{
+	typedef Store<HALF> St;
+	const size_t plane = g.plane();
+	const int zl = (int)blockIdx.y;                                  // owned plane index
+	const int z = g.z0 + zl;
+	const float pz = ((float)z + 0.5f) / (float)g.Zg;
+	const typename St::S* row = uz + (size_t)g.lz(z) * plane;
+	int lo = 0, hi = 0;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x) {
+		const float az = fmaf(-St::ld(row, i), dt, pz);
+		const int iz = (int)floorf(az * (float)g.Zg - 0.5f);
+		const int a = addr_tap(iz, g.Zg, address), b_ = addr_tap(iz + 1, g.Zg, address);
+		lo = max(lo, g.z0 - min(a, b_));
+		hi = max(hi, max(a, b_) - (g.z0 + g.nz - 1));
+	}
+	if (__builtin_amdgcn_ballot_w64(lo > 0 || hi > 0) == 0) return;   // the usual case: nothing leaves the slab
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) { lo = max(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+	if ((threadIdx.x & 63) == 0) { if (lo > 0) atomicMax(need, lo); if (hi > 0) atomicMax(need + 1, hi); }
+}
+
+// closes a step's record: rec = { need_lo, need_hi, digest of the schedule options, halo-overflow flag of this step }
+__global__ void k_step_record(int* __restrict__ rec, int digest, const unsigned* __restrict__ halo_overflow)
+{
+	rec[2] = digest;
+	rec[3] = (int)*halo_overflow;
+}
+
 template <bool HALF>
 __global__ __launch_bounds__(256) void k_copy_owned(const Geom g, const typename Store<HALF>::S* __restrict__ src,
 	typename Store<HALF>::S* __restrict__ dst)
@@ -1047,6 +1084,20 @@ hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, co
 	const dim3 grid = grid_xyz(g, z_end - z_begin), block(64, 4, 1);
 	if (half_store) hipLaunchKernelGGL(k_project<true>, grid, block, 0, s, g, sp, (const h16*)vel_in, p, (h16*)vel_out, z_begin, z_end - z_begin, xcd_remap_on(REMAP_PROJECT));
 	else hipLaunchKernelGGL(k_project<false>, grid, block, 0, s, g, sp, (const float*)vel_in, p, (float*)vel_out, z_begin, z_end - z_begin, xcd_remap_on(REMAP_PROJECT));
+	return hipGetLastError();
+}
+
+hipError_t launch_face_need(const Geom& g, int half_store, const void* vel, float dt, int address, int digest, const unsigned* halo_overflow, int* rec, hipStream_t s)
+{
+	hipError_t e = hipMemsetAsync(rec, 0, 2 * sizeof(int), s);
+	if (e != hipSuccess) return e;
+	const size_t es = half_store ? 2 : 4;
+	const char* uz = static_cast<const char*>(vel) + 2 * g.cells_local() * es;
+	const unsigned gx = (unsigned)((g.plane() / 4 + 255) / 256 < 64 ? (g.plane() / 4 + 255) / 256 : 64);
+	const dim3 grid(gx ? gx : 1, (unsigned)g.nz, 1);
+	if (half_store) hipLaunchKernelGGL(k_face_need<true>, grid, dim3(256), 0, s, g, (const h16*)uz, dt, address, rec);
+	else hipLaunchKernelGGL(k_face_need<false>, grid, dim3(256), 0, s, g, (const float*)uz, dt, address, rec);
+	hipLaunchKernelGGL(k_step_record, dim3(1), dim3(1), 0, s, rec, digest, halo_overflow);
 	return hipGetLastError();
 }
 

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 3
+#define FX_ABI_VERSION 4
 
 enum fx_status {
 	FX_OK = 0,
@@ -115,6 +115,9 @@ typedef struct fx_timing {
 	 * sweeps each -- the dominant kernel -- are also booked on their own; otherwise these equal the jacobi_* totals */
 	double   jacobi_main_ms;
 	uint64_t jacobi_main_launches, jacobi_main_sweeps;
+	/* ABI 4 (slab ranks): bytes this rank SENT in halo exchanges, and planes its advection exchange carried across its lower +
+	 * upper face (summed over the timed steps; halo_advect per face without FX_OPT_ADAPTIVE_HALO) */
+	uint64_t exchange_bytes, advect_halo_planes;
 } fx_timing;
 
 int fx_abi_version(void);
@@ -157,8 +160,10 @@ int fx_render_environment(fx_ctx* ctx, void* stream, uint8_t frame_index);
 
 int fx_get_frame_info(fx_ctx* ctx, fx_frame_info* out);
 
-/* blocks until everything enqueued by this context has finished; reports FX_E_HALO if the advection
- * back-trace of a multi-GPU step left the exchanged halo */
+/* blocks until everything enqueued by this context has finished; reports FX_E_HALO if the advection back-trace of a multi-GPU
+ * step left the exchanged halo, and thereby acknowledges it.  Until then fx_download of a simulation field, fx_checkpoint_save
+ * and fx_comm_gather_color return FX_E_HALO as well, and the next fx_simulate returns it on EVERY rank of the chain (the flag
+ * travels with the per-step record), so that no rank runs on, or stores, fields that differ from the single-domain run. */
 int fx_synchronize(fx_ctx* ctx);
 
 /* checkpoint / parity access (no reference counterpart; the reference cannot read fields back) */
@@ -225,8 +230,20 @@ int fx_comm_gather_color(fx_ctx* ctx, void* stream, fx_ctx* full, int root, cons
  *                            phase; the next step only exchanges the velocity.  While such a halo is out, fx_upload of a
  *                            colour field into an RCCL rank returns FX_E_STATE (its neighbours could not know; a
  *                            loop-back group simply exchanges the colour again)
- *   FX_OPT_JACOBI_ROUND  sweeps per pressure exchange, 1 .. fx_desc.halo_jacobi (default = halo_jacobi) */
-enum fx_option { FX_OPT_OVERLAP = 1, FX_OPT_JACOBI_ROUND = 2 };
+ *   FX_OPT_JACOBI_ROUND  sweeps per pressure exchange, 1 .. fx_desc.halo_jacobi (default = halo_jacobi)
+ *   FX_OPT_ADAPTIVE_HALO 1 = (default) the advection exchange carries, per slab face, exactly the planes the coming advection
+ *                        will touch: behind every projection a kernel measures them on the velocity just written (the z taps
+ *                        of every voxel's back-trace, computed with the advection's own arithmetic), the ranks all-gather the
+ *                        two numbers, and the next step exchanges max(need of the two slabs sharing the face) planes instead of
+ *                        fx_desc.halo_advect -- which remains the allocation and the limit: a need beyond it stops the step with
+ *                        FX_E_HALO on EVERY rank before a field is touched.  The measurement holds for time steps up to the one
+ *                        it was taken with; a larger one, the first step, or a velocity upload fall back to halo_advect planes.
+ *                        0 = always halo_advect planes.
+ * On an RCCL chain fx_set_option is COLLECTIVE: every rank calls it with the same arguments between two steps; the values are
+ * compared across the chain and a disagreement returns FX_E_INVALID everywhere with nothing changed.  While FX_OPT_ADAPTIVE_HALO
+ * is on and a step has run, fx_upload(FX_FIELD_VELOCITY) into an RCCL rank returns FX_E_STATE (its neighbours have sized the next
+ * exchange from the old field); switch the option off first. */
+enum fx_option { FX_OPT_OVERLAP = 1, FX_OPT_JACOBI_ROUND = 2, FX_OPT_ADAPTIVE_HALO = 3 };
 int fx_set_option(fx_ctx* ctx, uint32_t option, uint32_t value);
 
 #ifdef __cplusplus

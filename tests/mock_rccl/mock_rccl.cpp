@@ -11,6 +11,7 @@
 //       real RCCL would hang or corrupt), copies it to the device and unlinks it.  Matching is FIFO per ordered
 //       pair, which is RCCL's rule.
 //   ncclAllReduce                                  int32 / float, min / max / sum, by the same file exchange.
+//   ncclAllGather                                  any of the element types above, by the same file exchange.
 //
 // It is deliberately STRICTER than RCCL: host-synchronous, every wait times out (FXMOCK_TIMEOUT_S, default 60 s) and
 // returns ncclSystemError, so a schedule that makes ranks disagree fails a test instead of hanging a node.  It says
@@ -40,7 +41,7 @@ struct Comm {
 	std::string dir;
 	int rank = 0, nranks = 0;
 	std::vector<unsigned long> send_seq, recv_seq;
-	unsigned long ar_seq = 0;
+	unsigned long ar_seq = 0, ag_seq = 0;
 };
 
 thread_local int g_depth = 0;
@@ -185,7 +186,7 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
 		while (dirent* e = readdir(d)) {
 			const std::string n = e->d_name;
 			const bool own = n.compare(0, std::strlen(mine), mine) == 0 ||
-			                 (n.compare(0, 3, "ar_") == 0 && n.size() > std::strlen(ar) && n.compare(n.size() - std::strlen(ar), std::strlen(ar), ar) == 0);
+			                 ((n.compare(0, 3, "ar_") == 0 || n.compare(0, 3, "ag_") == 0) && n.size() > std::strlen(ar) && n.compare(n.size() - std::strlen(ar), std::strlen(ar), ar) == 0);
 			if (own) unlink((c->dir + "/" + n).c_str());
 		}
 		closedir(d);
@@ -243,6 +244,32 @@ ncclResult_t ncclAllReduce(const void* sendbuf, void* recvbuf, size_t count, ncc
 		else reduce(reinterpret_cast<float*>(acc.data()), reinterpret_cast<const float*>(other.data()), count, op);
 	}
 	if (hipMemcpy(recvbuf, acc.data(), acc.size(), hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+	return ncclSuccess;
+}
+
+// every rank publishes its `count` elements as <dir>/ag_<seq>_r<rank> and reads the others' in rank order.  A rank that reads
+// sequence number s knows every rank has written s, i.e. has finished reading s - 1: it may then remove its own s - 1 file.
+ncclResult_t ncclAllGather(const void* sendbuf, void* recvbuf, size_t count, ncclDataType_t type, ncclComm_t comm, hipStream_t stream)
+{
+	Comm* c = reinterpret_cast<Comm*>(comm);
+	const size_t tb = type_bytes(type);
+	if (!c || !tb) return ncclInvalidArgument;
+	if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
+	std::vector<char> mine(count * tb), other, all((size_t)c->nranks * count * tb);
+	if (hipMemcpy(mine.data(), sendbuf, mine.size(), hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+	const unsigned long seq = c->ag_seq++;
+	char b[64];
+	std::snprintf(b, sizeof b, "/ag_%lu_r%d", seq, c->rank);
+	if (!write_file(c->dir + b, mine.data(), mine.size())) return ncclSystemError;
+	for (int r = 0; r < c->nranks; ++r) {
+		if (r == c->rank) { std::memcpy(all.data() + (size_t)r * mine.size(), mine.data(), mine.size()); continue; }
+		std::snprintf(b, sizeof b, "/ag_%lu_r%d", seq, r);
+		if (!read_file(c->dir + b, other)) return ncclSystemError;
+		if (other.size() != mine.size()) return ncclInvalidUsage;
+		std::memcpy(all.data() + (size_t)r * mine.size(), other.data(), other.size());
+	}
+	if (seq > 0) { std::snprintf(b, sizeof b, "/ag_%lu_r%d", seq - 1, c->rank); unlink((c->dir + b).c_str()); }
+	if (hipMemcpy(recvbuf, all.data(), all.size(), hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
 	return ncclSuccess;
 }
 

@@ -15,16 +15,17 @@ def test_round_trip_and_layout(tmp_path):
     path = tmp_path / "s.fxck"
     fx.write_checkpoint(path, vel, col, p, storage=1, steps=77)
     raw = path.read_bytes()
-    assert len(raw) == 64 + 8 * X * Y * Z * 4
-    assert raw[:8] == b"FXCKPT01"
+    assert len(raw) == 64 + 8 * X * Y * Z * 4 + Z and raw[-Z:] == bytes([1]) * Z      # every plane marked complete
+    assert raw[:8] == b"FXCKPT02"
     assert tuple(np.frombuffer(raw, "<u4", 4, 8)) == (X, Y, Z, 1) and int(np.frombuffer(raw, "<u8", 1, 24)[0]) == 77
     assert raw[32:64] == bytes(32)
-    body = np.frombuffer(raw, np.float32, offset=64)
+    body = np.frombuffer(raw[:-Z], np.float32, offset=64)
     assert np.array_equal(body[:vel.size], vel.ravel()) and np.array_equal(body[-p.size:], p.ravel())
     for mm in (False, True):
         d = fx.read_checkpoint(path, mmap=mm)
         assert d["grid"] == (X, Y, Z) and d["storage"] == 1 and d["steps"] == 77
         assert np.array_equal(d["velocity"], vel) and np.array_equal(d["color"], col) and np.array_equal(d["pressure"], p)
+        assert d["complete"].all() and d["complete"].shape == (Z,)
 
 
 def test_foreign_and_truncated_files_are_refused(tmp_path):

@@ -437,7 +437,7 @@ def test_damaged_checkpoint_files_are_refused(seed, tmp_path):
     f.SaveCheckpoint(str(good))
     want = {fid: f.download(fid) for fid in (fx.FIELD_VELOCITY, fx.FIELD_COLOR, fx.FIELD_PRESSURE)}
     data = bytearray(good.read_bytes())
-    kind = int(rng.integers(0, 4))
+    kind = int(rng.integers(0, 5))
     ok_expected = False
     if kind == 0:
         data = data[:int(rng.integers(0, len(data)))]                       # truncated
@@ -446,9 +446,11 @@ def test_damaged_checkpoint_files_are_refused(seed, tmp_path):
         data[off] ^= int(rng.integers(1, 256))
     elif kind == 2:
         data += bytes(int(rng.integers(1, 64)))                             # trailing bytes
-    else:
-        data[int(rng.integers(64, len(data)))] ^= 0x01                      # payload: still a valid file of this grid
+    elif kind == 3:
+        data[int(rng.integers(64, len(data) - dims[2]))] ^= 0x01            # payload: still a valid file of this grid
         ok_expected = True
+    else:
+        data[len(data) - 1 - int(rng.integers(0, dims[2]))] = 0             # a plane not marked complete (interrupted save)
     bad = tmp_path / "bad.fxck"
     bad.write_bytes(bytes(data))
     g2 = fx.Fluid()

@@ -338,12 +338,12 @@ def test_checkpoint_resume_is_bit_identical_across_decompositions(tmp_path):
         for f in fl:
             f.SaveCheckpoint(path)
         hdr = np.fromfile(path, np.uint32, 8)
-        assert bytes(hdr[:2].tobytes()) == b"FXCKPT01" and tuple(hdr[2:5]) == dims and hdr[6] == 5
+        assert bytes(hdr[:2].tobytes()) == b"FXCKPT02" and tuple(hdr[2:5]) == dims and hdr[6] == 5
         ck = fx.read_checkpoint(path)                                    # the numpy reader sees what the slabs wrote
         assert ck["grid"] == dims and ck["steps"] == 5
         assert np.array_equal(ck["pressure"], gather(fl, fx.FIELD_PRESSURE, 0)) and np.array_equal(ck["velocity"], gather(fl, fx.FIELD_VELOCITY, 1))
         cells = dims[0] * dims[1] * dims[2]
-        assert (tmp_path / ("state_%s.fxck" % storage)).stat().st_size == 64 + 8 * cells * 4
+        assert (tmp_path / ("state_%s.fxck" % storage)).stat().st_size == 64 + 8 * cells * 4 + dims[2] and ck["complete"].all()
         # (a) single domain resumes
         one = fx.Fluid()
         assert one.Init(800, 800, dims, **kw)
@@ -367,6 +367,14 @@ def test_checkpoint_resume_is_bit_identical_across_decompositions(tmp_path):
             assert want.any()
             assert np.array_equal(one.download(field), want), (storage, field)
             assert np.array_equal(gather(three, field, axis), want), (storage, field)
+    # a save that only one rank of a chain made: the other rank's planes are not marked complete, nobody resumes from them
+    part = str(tmp_path / "partial.fxck")
+    fl[0].SaveCheckpoint(part)
+    assert not fx.read_checkpoint(part)["complete"][dims[2] // 2:].any() and fx.read_checkpoint(part)["complete"][:dims[2] // 2].all()
+    one = fx.Fluid()
+    assert one.Init(800, 800, dims, **kw)
+    with pytest.raises(fx.FluidxError):
+        one.LoadCheckpoint(part)
     # a file of another grid is refused
     other = fx.Fluid()
     assert other.Init(800, 800, (32, 32, 32))
@@ -503,3 +511,136 @@ def test_slabs_with_lds_advection(overlap, monkeypatch):
     assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), want[0])
     assert np.array_equal(gather(fl, fx.FIELD_COLOR, 0), want[1])
     assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), want[2])
+
+
+# ---- FX_OPT_ADAPTIVE_HALO: the advection exchange follows the measured need per face -----------------------------------------
+def _timed_steps(fl, k0, steps, dt=None):
+    for f in fl:
+        f.timing_enable(True); f.timing_read(True)
+    for k in range(k0, k0 + steps):
+        fl[0].UpdateFrame(f32(dt if dt is not None else fl[0].default_time_step()), k % 3)
+        fl[0].Simulate(k % 3)
+    fl[0].Synchronize()
+    return [f.timing_read(True) for f in fl]
+
+
+@pytest.mark.parametrize("overlap", [2, 0])
+def test_adaptive_halo_carries_only_what_the_advection_touches(overlap):
+    """with the option on (default) a face carries max(need of its two slabs) planes -- measured behind the projection with the
+    advection's own arithmetic -- instead of halo_advect; off, always halo_advect.  Same bits either way (and as the single
+    domain); far fewer bytes: the plume of this run never comes near the faces with more than a plane or two of reach"""
+    dims, Ha, steps = (64, 64, 96), 10, 6
+    ref = run_single(dims, 2 + steps, jacobi_iters=10)
+    want = (ref.download(fx.FIELD_VELOCITY), ref.download(fx.FIELD_COLOR), ref.download(fx.FIELD_PRESSURE))
+    sent = {}
+    for adaptive in (1, 0):
+        fl = run_slabs(dims, 2, 3, jacobi_iters=10, halo_jacobi=4, halo_advect=Ha, overlap=overlap)
+        for f in fl:
+            f.set_option(capi.OPT_ADAPTIVE_HALO, adaptive)
+        if not adaptive:                                   # (the record of step 2 is already out: one more step runs on it)
+            _timed_steps(fl, 2, 1); steps_left = steps - 1; k0 = 3
+        else:
+            steps_left, k0 = steps, 2
+        t = _timed_steps(fl, k0, steps_left)
+        assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), want[0])
+        assert np.array_equal(gather(fl, fx.FIELD_COLOR, 0), want[1])
+        assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), want[2])
+        planes = [x.advect_halo_planes / steps_left for x in t]
+        sent[adaptive] = sum(x.exchange_bytes for x in t) / steps_left
+        if adaptive:
+            assert planes[0] <= 3 and planes[1] <= 6 and planes[2] <= 3, planes      # one face / two faces / one face
+        else:
+            assert planes == [Ha, 2 * Ha, Ha], planes
+    assert sent[1] < 0.6 * sent[0], sent
+
+
+def test_adaptive_halo_falls_back_when_the_measurement_does_not_cover_the_step():
+    """the need was measured with the previous step's dt and on the velocity the projection left: a larger dt, or a velocity
+    upload in between, make the next exchange carry halo_advect planes again; every such run equals the single domain"""
+    dims, Ha = (64, 64, 128), 8                             # rank 0's only face is plane 32, far from the impulse at plane 64
+    rng = np.random.default_rng(9)
+    ref = fx.Fluid()
+    assert ref.Init(800, 800, dims, jacobi_iters=8)
+    fl = run_slabs(dims, 0, 4, jacobi_iters=8, halo_jacobi=4, halo_advect=Ha)
+    dt = 0.25 * ref.default_time_step()                     # a calm flow: the doubled step below must not outrun the 8-plane halo
+
+    def both(dtv, k):
+        ref.UpdateFrame(f32(dtv), k % 3); ref.Simulate(k % 3)
+        return _timed_steps(fl, k, 1, dtv)
+
+    for k in range(3):
+        t = both(dt, k)
+    assert t[0].advect_halo_planes <= 2                     # measured: a plane or two
+    t = both(2 * dt, 3)                                     # a larger step than the measurement covers
+    assert t[0].advect_halo_planes == Ha and t[1].advect_halo_planes == 2 * Ha
+    t = both(0.5 * dt, 4)                                   # a smaller one is covered
+    assert t[0].advect_halo_planes <= 2
+    vel = (rng.standard_normal((3,) + dims[::-1]) * 0.3).astype(f32)
+    ref.Synchronize()
+    ref.upload(fx.FIELD_VELOCITY, vel)
+    for r, f in enumerate(fl):
+        f.upload(fx.FIELD_VELOCITY, vel[:, r * 32:(r + 1) * 32])
+    t = both(0.5 * dt, 5)                                   # the measurement was of another field
+    assert t[0].advect_halo_planes == Ha
+    t = both(0.5 * dt, 6)
+    assert t[0].advect_halo_planes < Ha
+    ref.Synchronize()
+    for field, axis in ((fx.FIELD_VELOCITY, 1), (fx.FIELD_COLOR, 0), (fx.FIELD_PRESSURE, 0)):
+        assert np.array_equal(gather(fl, field, axis), ref.download(field)), field
+
+
+def test_a_need_beyond_the_allocated_halo_stops_the_step_before_it_touches_a_field():
+    """halo_advect = 1 and a flow that speeds up: at some step the measured need of a face exceeds the allocation.  The NEXT
+    fx_simulate then returns FX_E_HALO before anything is enqueued that could read a plane nobody sent -- no overflow has
+    happened, the fields are still those of the single-domain run"""
+    dims = (32, 32, 32)
+    fl = run_slabs(dims, 0, 2, jacobi_iters=8, halo_jacobi=2, halo_advect=1)
+    ref = fx.Fluid()
+    assert ref.Init(800, 800, dims, jacobi_iters=8)
+    dt = f32(ref.default_time_step())
+    done = None
+    for k in range(60):
+        fl[0].UpdateFrame(dt, k % 3)
+        try:
+            fl[0].Simulate(k % 3)
+        except fx.FluidxError as e:
+            assert e.status == capi.FX_E_HALO
+            done = k
+            break
+        ref.UpdateFrame(dt, k % 3); ref.Simulate(k % 3)
+    assert done is not None and done >= 1                  # (the first step has no measurement: it runs on halo_advect planes)
+    fl[0].Synchronize()                                      # no overflow flag: nothing went wrong on the device
+    ref.Synchronize()
+    assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
+    assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
+
+
+def test_an_overflow_on_one_rank_stops_every_rank_and_blocks_read_back():
+    """FX_OPT_ADAPTIVE_HALO off, halo_advect too small for the uploaded velocity: the advection of the step flags the overflow on
+    the device; fx_download / fx_checkpoint_save of that context refuse (FX_E_HALO), the next fx_simulate refuses for the whole
+    chain, fx_synchronize reports and acknowledges it"""
+    dims = (32, 32, 32)
+    fl = run_slabs(dims, 0, 2, jacobi_iters=4, halo_jacobi=1, halo_advect=1)
+    vel = np.zeros((3, 16, 32, 32), f32)
+    vel[2] = 3.0
+    for f in fl:
+        f.upload(fx.FIELD_VELOCITY, vel)
+    fl[0].UpdateFrame(f32(2.0 / 32), 0)
+    fl[0].Simulate(0)
+    with pytest.raises(fx.FluidxError) as e:
+        fl[1].download(fx.FIELD_VELOCITY)
+    assert e.value.status == capi.FX_E_HALO
+    with pytest.raises(fx.FluidxError) as e:
+        fl[1].SaveCheckpoint("/tmp/fluidx_never_written.fxck")
+    assert e.value.status == capi.FX_E_HALO
+    import os
+    assert not os.path.exists("/tmp/fluidx_never_written.fxck")
+    fl[0].UpdateFrame(f32(2.0 / 32), 1)
+    with pytest.raises(fx.FluidxError) as e:
+        fl[0].Simulate(1)
+    assert e.value.status == capi.FX_E_HALO
+    with pytest.raises(fx.FluidxError) as e:
+        fl[0].Synchronize()
+    assert e.value.status == capi.FX_E_HALO
+    fl[0].Synchronize()                                      # acknowledged
+    assert fl[1].download(fx.FIELD_VELOCITY).shape == (3, 16, 32, 32)
