@@ -589,12 +589,15 @@ def test_adaptive_halo_falls_back_when_the_measurement_does_not_cover_the_step()
         assert np.array_equal(gather(fl, field, axis), ref.download(field)), field
 
 
-def test_a_need_beyond_the_allocated_halo_stops_the_step_before_it_touches_a_field():
+@pytest.mark.parametrize("overlap", [0, 2])
+def test_a_need_beyond_the_allocated_halo_stops_the_step_before_it_touches_a_field(overlap):
     """halo_advect = 1 and a flow that speeds up: at some step the measured need of a face exceeds the allocation.  The NEXT
-    fx_simulate then returns FX_E_HALO before anything is enqueued that could read a plane nobody sent -- no overflow has
-    happened, the fields are still those of the single-domain run"""
+    fx_simulate then returns FX_E_HALO before anything is enqueued that could read a plane nobody sent: velocity[0] and the
+    pressure are still those of the single-domain run.  (Serial schedule: nothing at all was enqueued and no overflow is flagged;
+    overlapped: the interior advection, which reads owned planes only, was already on its way and may have flagged its own
+    far-tracing voxels -- fx_synchronize then reports the same status once more.)"""
     dims = (32, 32, 32)
-    fl = run_slabs(dims, 0, 2, jacobi_iters=8, halo_jacobi=2, halo_advect=1)
+    fl = run_slabs(dims, 0, 2, jacobi_iters=8, halo_jacobi=2, halo_advect=1, overlap=overlap)
     ref = fx.Fluid()
     assert ref.Init(800, 800, dims, jacobi_iters=8)
     dt = f32(ref.default_time_step())
@@ -609,7 +612,13 @@ def test_a_need_beyond_the_allocated_halo_stops_the_step_before_it_touches_a_fie
             break
         ref.UpdateFrame(dt, k % 3); ref.Simulate(k % 3)
     assert done is not None and done >= 1                  # (the first step has no measurement: it runs on halo_advect planes)
-    fl[0].Synchronize()                                      # no overflow flag: nothing went wrong on the device
+    if overlap == 0:
+        fl[0].Synchronize()                                  # no overflow flag: nothing went wrong on the device
+    else:
+        try:
+            fl[0].Synchronize()
+        except fx.FluidxError as e:
+            assert e.status == capi.FX_E_HALO
     ref.Synchronize()
     assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
     assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
