@@ -43,7 +43,7 @@ class Timing(C.Structure):
                 ("exchange_ms", C.c_double), ("steps", C.c_uint64), ("jacobi_launches", C.c_uint64),
                 ("jacobi_sweeps", C.c_uint64), ("renders", C.c_uint64), ("resolve_ms", C.c_double),
                 ("jacobi_main_ms", C.c_double), ("jacobi_main_launches", C.c_uint64), ("jacobi_main_sweeps", C.c_uint64),
-                ("exchange_bytes", C.c_uint64), ("advect_halo_planes", C.c_uint64)]
+                ("exchange_bytes", C.c_uint64), ("advect_halo_planes", C.c_uint64), ("chain_ms", C.c_double)]
 
 
 # every symbol include/fluidx_hip.h declares: name -> (restype, argtypes)

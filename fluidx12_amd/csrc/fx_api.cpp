@@ -40,7 +40,7 @@ struct DeviceGuard {
 };
 
 // ---- timing ---------------------------------------------------------------------------------
-enum MarkKind { MK_ADVECT, MK_DIV, MK_JACOBI, MK_PROJECT, MK_LIGHT, MK_VIEW, MK_EXCH, MK_RESOLVE, MK_JACOBI_TAIL };
+enum MarkKind { MK_ADVECT, MK_DIV, MK_JACOBI, MK_PROJECT, MK_LIGHT, MK_VIEW, MK_EXCH, MK_RESOLVE, MK_JACOBI_TAIL, MK_CHAIN };
 
 size_t ev_record(fx_ctx* c, hipStream_t s)
 {
@@ -94,6 +94,7 @@ int drain_timing(fx_ctx* c)
 		case MK_VIEW: c->acc.view_ms += ms; break;
 		case MK_EXCH: c->acc.exchange_ms += ms; break;
 		case MK_RESOLVE: c->acc.resolve_ms += ms; break;
+		case MK_CHAIN: c->acc.chain_ms += ms; break;
 		}
 	}
 	c->marks.clear();
@@ -445,6 +446,21 @@ int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint
 	hipStream_t fs = grp->face_stream, cs = grp->comm_stream;
 	int rc;
 	fx_ctx* ctx = lead;                                    // FX_HIP reports through `ctx`
+	// Sweeps per launch of the face chain.  Default 1: one single-sweep launch (k_jacobi_v4: 60 registers, both faces) per level.
+	// FLUIDX_CHAIN_FUSE=2|3 runs the chain in groups of fused sweeps with the interior's register-strip kernels instead (3 + 3 + 3
+	// for a round of nine; identical results) -- measured SLOWER (loop-back N = 4, 256^3 per rank, rounds of 9: 6.30 against
+	// 5.67 ms per step; rounds of 6: 6.81 / 5.79; of 3: 6.93 / 6.32; profiles/r02c_chain_fuse_loopback4.txt): on a 9..27-plane zone
+	// the strips have 64..192 waves whose 310 registers shut the interior's waves out of their SIMDs for a whole 14-step
+	// pipeline, where a single-sweep launch is a few microseconds of small waves beside them.
+	int tc = 3;
+	{
+		static const int forced = [] { const char* e = std::getenv("FLUIDX_CHAIN_FUSE"); return e && *e ? std::atoi(e) : 1; }();
+		for (fx_ctx* mctx : M) {
+			const int cap = jacobi_strip3_supported(mctx->g) ? 3 : (jacobi_fused_max_sweeps(mctx->g, 2, 2 * k) >= 2 ? 2 : 1);
+			tc = std::min(tc, cap);
+		}
+		if (forced >= 1 && forced <= 3) tc = std::min(tc, forced);
+	}
 	const ExchSpec first[2] = { { EX_DIV, k - 1, 0 }, { EX_PRESSURE, k, lead->p_cur } };
 	if ((rc = do_exchange(lead, M, first, 2, s))) return rc;
 	FX_HIP(hipEventRecord(grp->ev_int, s));
@@ -453,23 +469,39 @@ int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint
 	while (done < iters) {
 		const int cnt = (int)std::min<uint32_t>(k, iters - done);
 		const int m = (cnt + t - 1) / t, t_first = cnt - (m - 1) * t;
-		const int src = lead->p_cur, fin = src ^ (m & 1), fbuf = cnt & 1;   // the chain's level s lives in p_face[s & 1]
+		const int src = lead->p_cur, fin = src ^ (m & 1);
+		int fbuf = 0;                                      // which scratch buffer holds the chain's last level (set below)
 		// ---- face stream: the chain (needs the previous round's interior + face copy, and its exchange)
 		FX_HIP(hipStreamWaitEvent(fs, grp->ev_int, 0));
 		if (in_flight) FX_HIP(hipStreamWaitEvent(fs, grp->ev_done, 0));
-		ScopedMark chain_mark(lead, fs, MK_JACOBI);        // one mark per chain (loop-back: all members' chains, booked on the first)
-		for (int lvl = 1; lvl <= cnt; ++lvl) {
-			const int rem = cnt - lvl;
-			for (fx_ctx* mctx : M) {
-				if (!has_lower(mctx) && !has_upper(mctx)) continue;
-				DeviceGuard dg(mctx->device);
-				const Range o = owned(mctx);
-				const float* in = lvl == 1 ? mctx->p[src] : mctx->p_face[(lvl - 1) & 1];
-				const Range lo{ o.lo - rem, has_lower(mctx) ? o.lo + k + rem : o.lo - rem };
-				const Range hi{ has_upper(mctx) ? o.hi - k - rem : o.hi + rem, o.hi + rem };
-				FX_HIP(launch_jacobi_sweep2(mctx->g, in, mctx->b, mctx->p_face[lvl & 1], nullptr, lo.lo, lo.hi, hi.lo, hi.hi, fs));
+		ScopedMark chain_mark(lead, fs, MK_CHAIN);         // one mark per chain (loop-back: all members' chains, booked on the first)
+		{
+			// the chain in groups of tc sweeps over the two thin face zones (tc = 1 by default, see above)
+			int c = 0, grp_i = 0;
+			while (c < cnt) {
+				const int left = cnt - c;
+				int tg = std::min(left, tc);
+				if (tc == 3 && left == 4) tg = 2;              // 2 + 2 rather than 3 + 1
+				c += tg;
+				const int rem = cnt - c, ob = (grp_i + 1) & 1;
+				for (fx_ctx* mctx : M) {
+					if (!has_lower(mctx) && !has_upper(mctx)) continue;
+					DeviceGuard dg(mctx->device);
+					const Range o = owned(mctx);
+					const float* in = grp_i == 0 ? mctx->p[src] : mctx->p_face[grp_i & 1];
+					const Range lo{ o.lo - rem, has_lower(mctx) ? o.lo + k + rem : o.lo - rem };
+					const Range hi{ has_upper(mctx) ? o.hi - k - rem : o.hi + rem, o.hi + rem };
+					if (tg == 1) {
+						FX_HIP(launch_jacobi_sweep2(mctx->g, in, mctx->b, mctx->p_face[ob], nullptr, lo.lo, lo.hi, hi.lo, hi.hi, fs));
+					} else {
+						if (lo.hi > lo.lo) FX_HIP(launch_jacobi_fused(mctx->g, in, mctx->b, mctx->p_face[ob], tg, lo.lo, lo.hi, fs));
+						if (hi.hi > hi.lo) FX_HIP(launch_jacobi_fused(mctx->g, in, mctx->b, mctx->p_face[ob], tg, hi.lo, hi.hi, fs));
+					}
+				}
+				if (grp_i == 0) FX_HIP(hipEventRecord(grp->ev_face1, fs));
+				++grp_i;
 			}
-			if (lvl == 1) FX_HIP(hipEventRecord(grp->ev_face1, fs));
+			fbuf = grp_i & 1;                                  // the buffer the last group wrote
 		}
 		FX_HIP(hipEventRecord(grp->ev_ready, fs));
 		// ---- comm stream: the k final planes of the chain travel, the neighbour's land in the halo of p[fin]

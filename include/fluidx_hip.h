@@ -118,6 +118,7 @@ typedef struct fx_timing {
 	/* ABI 4 (slab ranks): bytes this rank SENT in halo exchanges, and planes its advection exchange carried across its lower +
 	 * upper face (summed over the timed steps; halo_advect per face without FX_OPT_ADAPTIVE_HALO) */
 	uint64_t exchange_bytes, advect_halo_planes;
+	double   chain_ms;          /* face chains of the overlapped pressure rounds (their own stream, beside the interior sweeps) */
 } fx_timing;
 
 int fx_abi_version(void);
