@@ -722,33 +722,38 @@ __global__ __launch_bounds__(256) void k_project_v4(const Geom g, const float* _
 // kernel will touch (for any dt' <= dt the need can only shrink).  One read of uz, one atomicMax per wave that needs anything.
 // ---------------------------------------------------------------------------------------------
 template <bool HALF>
-__global__ __launch_bounds__(256) void k_face_need(const Geom g, const typename Store<HALF>::S* __restrict__ uz, float dt, int address, int* __restrict__ need)
+__global__ __launch_bounds__(256) void k_face_need(const Geom g, const typename Store<HALF>::S* __restrict__ uz, float dt, int address, int* __restrict__ rec,
+	int digest, const unsigned* __restrict__ halo_overflow)
 {
 	typedef Store<HALF> St;
 	const size_t plane = g.plane();
-	const int zl = (int)blockIdx.y;                                  // owned plane index
-	const int z = g.z0 + zl;
+	const int z = g.z0 + (int)blockIdx.y;                            // one owned plane per blockIdx.y
 	const float pz = ((float)z + 0.5f) / (float)g.Zg;
 	const typename St::S* row = uz + (size_t)g.lz(z) * plane;
 	int lo = 0, hi = 0;
-	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x) {
-		const float az = fmaf(-St::ld(row, i), dt, pz);
+	auto one = [&](float u) {
+		const float az = fmaf(-u, dt, pz);
 		const int iz = (int)floorf(az * (float)g.Zg - 0.5f);
 		const int a = addr_tap(iz, g.Zg, address), b_ = addr_tap(iz + 1, g.Zg, address);
 		lo = max(lo, g.z0 - min(a, b_));
 		hi = max(hi, max(a, b_) - (g.z0 + g.nz - 1));
+	};
+	if (!HALF && (plane & 3) == 0) {                                 // 16-byte loads
+		const float4* row4 = reinterpret_cast<const float4*>(row);
+		for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane / 4; i += (size_t)gridDim.x * blockDim.x) {
+			const float4 v = row4[i];
+			one(v.x); one(v.y); one(v.z); one(v.w);
+		}
+	} else {
+		for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x) one(St::ld(row, i));
 	}
+	// the record is closed by the first thread of the launch: digest of the schedule options, this step's halo-overflow flag
+	// (final: the advection finished long before the projection whose output this kernel reads)
+	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { rec[2] = digest; rec[3] = (int)*halo_overflow; }
 	if (__builtin_amdgcn_ballot_w64(lo > 0 || hi > 0) == 0) return;   // the usual case: nothing leaves the slab
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) { lo = max(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
-	if ((threadIdx.x & 63) == 0) { if (lo > 0) atomicMax(need, lo); if (hi > 0) atomicMax(need + 1, hi); }
-}
-
-// closes a step's record: rec = { need_lo, need_hi, digest of the schedule options, halo-overflow flag of this step }
-__global__ void k_step_record(int* __restrict__ rec, int digest, const unsigned* __restrict__ halo_overflow)
-{
-	rec[2] = digest;
-	rec[3] = (int)*halo_overflow;
+	if ((threadIdx.x & 63) == 0) { if (lo > 0) atomicMax(rec, lo); if (hi > 0) atomicMax(rec + 1, hi); }
 }
 
 template <bool HALF>
@@ -1093,11 +1098,13 @@ hipError_t launch_face_need(const Geom& g, int half_store, const void* vel, floa
 	if (e != hipSuccess) return e;
 	const size_t es = half_store ? 2 : 4;
 	const char* uz = static_cast<const char*>(vel) + 2 * g.cells_local() * es;
-	const unsigned gx = (unsigned)((g.plane() / 4 + 255) / 256 < 64 ? (g.plane() / 4 + 255) / 256 : 64);
-	const dim3 grid(gx ? gx : 1, (unsigned)g.nz, 1);
-	if (half_store) hipLaunchKernelGGL(k_face_need<true>, grid, dim3(256), 0, s, g, (const h16*)uz, dt, address, rec);
-	else hipLaunchKernelGGL(k_face_need<false>, grid, dim3(256), 0, s, g, (const float*)uz, dt, address, rec);
-	hipLaunchKernelGGL(k_step_record, dim3(1), dim3(1), 0, s, rec, digest, halo_overflow);
+	const size_t per_thread = (!half_store && (g.plane() & 3) == 0) ? 16 : 4;      // cells a thread takes per plane (4 trips of 16 B, or 4 scalars)
+	size_t gx = (g.plane() / per_thread + 255) / 256;
+	if (gx < 1) gx = 1;
+	if (gx > 64) gx = 64;
+	const dim3 grid((unsigned)gx, (unsigned)g.nz, 1);
+	if (half_store) hipLaunchKernelGGL(k_face_need<true>, grid, dim3(256), 0, s, g, (const h16*)uz, dt, address, rec, digest, halo_overflow);
+	else hipLaunchKernelGGL(k_face_need<false>, grid, dim3(256), 0, s, g, (const float*)uz, dt, address, rec, digest, halo_overflow);
 	return hipGetLastError();
 }
 
