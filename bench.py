@@ -412,7 +412,7 @@ def main():
             avg_launch_s = main_ms * 1e-3 / main_l
             sweeps_per_launch = main_sw / main_l
             achieved = JACOBI_BYTES_PER_CELL_SWEEP * cells * sweeps_per_launch / avg_launch_s / 1e9
-            names = {1: ["k_jacobi_v4"], 2: (["k_jacobi_strip2h"] if GX == 512 else []) + ["k_jacobi_strip2u", "k_jacobi_strip"],
+            names = {1: ["k_jacobi_v4"], 2: (["k_jacobi_strip2h"] if GX == 512 else ["k_jacobi_block2"] if GX == 128 else []) + ["k_jacobi_strip2u", "k_jacobi_strip"],
                      3: (["k_jacobi_strip3h"] if GX == 512 else []) + ["k_jacobi_strip3", "k_jacobi_strip"]}
             cands = names.get(int(round(sweeps_per_launch)), ["k_jacobi_strip"]) if abs(sweeps_per_launch - round(sweeps_per_launch)) < 1e-9 else ["k_jacobi_strip"]
             tr = None
@@ -426,7 +426,8 @@ def main():
             roof = {"bound": "hbm",
                     "kernel": "k_jacobi_v4 (one lock-step Jacobi sweep per launch)" if sweeps_per_launch == 1 else
                               "%s (%g lock-step Jacobi sweeps per launch, register/LDS-resident temporal blocking: p and b are read once "
-                              "and p' written once per launch, so achieved > HBM peak is possible)" % (cands[0], sweeps_per_launch),
+                              "and p' written once per launch, so achieved > HBM peak is possible; frac_compulsory and frac_traffic are the "
+                              "fractions that bound)" % (cands[0], sweeps_per_launch),
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
                     "traffic_source": tr[1] if tr else None,
