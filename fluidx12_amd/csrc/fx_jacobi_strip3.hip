@@ -416,6 +416,181 @@ __global__ __launch_bounds__(64 * WPG, 4 / WPG) void k_jacobi_strip3h(const Geom
 	}
 }
 #undef FX_STRIP3H_STEP
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// X = 256, cooperative pairs.  k_jacobi_strip3 recomputes a strip's y-halo on BOTH sides (18 row updates per z step for 12 useful
+// ones: level 1 on 8 rows, level 2 on 6, output 4) so that no wave ever talks to another.  Here the two strips that share a
+// workgroup's rows 8k .. 8k+7 are a PAIR: each recomputes only its OUTER side and takes the one row per level it needs across the
+// inner boundary from its partner -- the partner's own edge row, handed over through a 1-KiB-per-row LDS mailbox one z step after
+// it was computed (the level-1 row of plane q-2 and the level-2 row of plane q-3 are exactly what step q-1 produced), ordered by a
+// per-wave step counter in the LDS like k_jacobi_strip3h's: a wave only waits while its partner is more than a step behind.  Per z
+// step: 6 + 5 + 4 = 15 row updates instead of 18, 8 + 6 row loads instead of 10 + 8, and 24 fewer float4 of window registers
+// (fewer AGPR round trips).  UP = the upper strip of the pair (outer side above, partner below); the lower strip is the mirror image
+// -- two expansions of the step, because the stencil's U and D enter the sum in a fixed order and cannot trade places.
+// Measured (256^3, rocprofv3 SQ counters): 7.96 k instead of 9.86 k VALU instructions per wave and launch (-19 %), bit-identical --
+// and 43.6-44.0 us per launch against 44.2-44.4, because the wave now issues only 52 % of its cycles (62 % before): with less
+// arithmetic per z step the step is as long as the prefetch's round trip (it is issued behind sweep 1 and needed at the next
+// step's start, two thirds of a step later), which one wave per SIMD cannot hide.  A first version that waited for the partner
+// at the top of the step was 4 % SLOWER (46.1 us); the order below (wait, read, then publish) lets a wave run a full step ahead.
+// Row indices (top to bottom): input i <-> y = yb + i (8 rows, yb = y0 - 3 | y0 - 1), level 1 j <-> yb + 1 + j (6 rows),
+// level 2 k <-> y0 - 1 + k | y0 + k (5 rows), output m <-> y0 + m.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int C_P0_ROWS = R3 + 4;           // input rows per plane
+constexpr int C_B_ROWS = R3 + 2;            // b rows per plane (= level-1 rows)
+constexpr int C_ROWS_PER_WAVE = 2 * C_P0_ROWS + 3 * C_B_ROWS;     // 34 rows of 1 KiB
+
+#define FX_STRIP3C_STEP(PH, UP) do { \
+	constexpr int NEW = (PH) % 3, CTR = ((PH) + 2) % 3, OLD = ((PH) + 1) % 3; \
+	/* ---- sweep 1: level-1 plane q-1 ------------------------------------------------------------------------------- */ \
+	if (q == 0) {                                   /* input plane -1 := plane 0, once (clamped front neighbour) */ \
+		_Pragma("unroll") for (int i = 0; i < C_P0_ROWS; ++i) FX_LDS(s_ctr, i) = NP[i]; \
+	} \
+	if (q - 1 == g.Zg) {                            /* level-1 plane Zg := plane Zg-1 */ \
+		_Pragma("unroll") for (int j = 0; j < C_B_ROWS; ++j) P1[NEW][j] = P1[CTR][j]; \
+	} else { \
+		float4 C_[C_P0_ROWS], F_[C_B_ROWS]; \
+		_Pragma("unroll") for (int i = 0; i < C_P0_ROWS; ++i) C_[i] = FX_LDS(s_ctr, i); \
+		_Pragma("unroll") for (int j = 0; j < C_B_ROWS; ++j) F_[j] = FX_LDS(s_old, j + 1); \
+		_Pragma("unroll") for (int j = 0; j < C_B_ROWS; ++j) \
+			P1[NEW][j] = relax4(C_[j + 1], C_[j], C_[j + 2], F_[j], NP[j + 1], NB[j], false, false); \
+		if (q - 1 == 0) { \
+			_Pragma("unroll") for (int j = 0; j < C_B_ROWS; ++j) P1[CTR][j] = P1[NEW][j]; \
+		} \
+	} \
+	/* hand-over 1 (level-1 edge rows).  Order: wait until the partner has published its step q-1, READ its row, only then publish \
+	   mine and my counter -- a wave that sees my counter at q knows I have already read what it wrote two steps ago into the slot \
+	   it is about to reuse, so two slots (step parity) suffice; and a wave may run a whole step ahead of its partner */ \
+	while (*reinterpret_cast<volatile int*>(xflag + (wave ^ 1)) < q - 1) __builtin_amdgcn_s_sleep(1); \
+	asm volatile("" ::: "memory"); \
+	const float4 H1_ = xbuf[((((q - 1) & 1) * 4 + (wave ^ 1)) * 2 + 0) * 64 + lane];           /* partner's level 1, plane q-2 */ \
+	xbuf[(((q & 1) * 4 + wave) * 2 + 0) * 64 + lane] = (UP) ? P1[NEW][C_B_ROWS - 1] : P1[NEW][0];   /* mine, plane q-1 */ \
+	asm volatile("" ::: "memory"); \
+	if (lane == 0) *reinterpret_cast<volatile int*>(xflag + wave) = q;   /* LDS operations of a wave execute in order */ \
+	float4 B2_[R3 + 1], B3_[R3]; \
+	_Pragma("unroll") for (int k = 0; k < R3 + 1; ++k) B2_[k] = FX_LDS(s_b2, (UP) ? k + 1 : k);        /* b[q-2], rows of level 2 */ \
+	_Pragma("unroll") for (int m = 0; m < R3; ++m) B3_[m] = FX_LDS(s_b3, (UP) ? m + 2 : m);            /* b[q-3], output rows */ \
+	_Pragma("unroll") for (int i = 0; i < C_P0_ROWS; ++i) FX_LDS(s_old, i) = NP[i]; \
+	_Pragma("unroll") for (int i = 0; i < C_B_ROWS; ++i) FX_LDS(s_bfree, i) = NB[i]; \
+	{ const int t_ = s_old; s_old = s_ctr; s_ctr = t_; } \
+	{ const int t_ = s_bfree; s_bfree = s_b3; s_b3 = s_b2; s_b2 = t_; } \
+	if (q + 1 <= q_load_last) { \
+		const char* pb_ = reinterpret_cast<const char*>(p_in + (size_t)g.lz(q + 1) * plane); \
+		_Pragma("unroll") for (int i = 0; i < C_P0_ROWS; ++i) NP[i] = *reinterpret_cast<const float4*>(pb_ + opaque32(roff[i])); \
+	} \
+	if (q <= b_load_last) { \
+		const char* bb_ = reinterpret_cast<const char*>(b + (size_t)g.lz(q) * plane); \
+		_Pragma("unroll") for (int i = 0; i < C_B_ROWS; ++i) NB[i] = *reinterpret_cast<const float4*>(bb_ + opaque32(roff[i + 1])); \
+	} \
+	/* ---- sweep 2: level-2 plane q-2 ------------------------------------------------------------------------------- */ \
+	if (q - 2 == g.Zg) { \
+		_Pragma("unroll") for (int k = 0; k < R3 + 1; ++k) P2[NEW][k] = P2[CTR][k]; \
+	} else { \
+		_Pragma("unroll") for (int k = 0; k < R3 + 1; ++k) { \
+			const int jc_ = (UP) ? k + 1 : k;                            /* level-1 index of this row */ \
+			const float4 c_ = P1[CTR][jc_]; \
+			float4 u_ = jc_ >= 1 ? P1[CTR][jc_ >= 1 ? jc_ - 1 : 0] : H1_; \
+			float4 d_ = jc_ + 1 < C_B_ROWS ? P1[CTR][jc_ + 1 < C_B_ROWS ? jc_ + 1 : 0] : H1_; \
+			if ((UP) && k == 1 && y0 == 0) u_ = c_;                       /* rows outside the domain hold no data */ \
+			if (!(UP) && k == R3 - 1 && y0 + R3 >= g.Y) d_ = c_; \
+			P2[NEW][k] = relax4(c_, u_, d_, P1[OLD][jc_], P1[NEW][jc_], B2_[k], false, false); \
+		} \
+		if (q - 2 == 0) { \
+			_Pragma("unroll") for (int k = 0; k < R3 + 1; ++k) P2[CTR][k] = P2[NEW][k]; \
+		} \
+	} \
+	/* hand-over 2 (level-2 edge rows), same order */ \
+	while (*reinterpret_cast<volatile int*>(xflag + 4 + (wave ^ 1)) < q - 1) __builtin_amdgcn_s_sleep(1); \
+	asm volatile("" ::: "memory"); \
+	const float4 H2_ = xbuf[((((q - 1) & 1) * 4 + (wave ^ 1)) * 2 + 1) * 64 + lane];           /* partner's level 2, plane q-3 */ \
+	xbuf[(((q & 1) * 4 + wave) * 2 + 1) * 64 + lane] = (UP) ? P2[NEW][R3] : P2[NEW][0];              /* mine, plane q-2 */ \
+	asm volatile("" ::: "memory"); \
+	if (lane == 0) *reinterpret_cast<volatile int*>(xflag + 4 + wave) = q; \
+	/* ---- sweep 3: output plane q-3 ------------------------------------------------------------------------------- */ \
+	if (q - 3 >= zb && q - 3 < ze) { \
+		char* ob_ = reinterpret_cast<char*>(p_out + (size_t)g.lz(q - 3) * plane); \
+		_Pragma("unroll") for (int m = 0; m < R3; ++m) { \
+			const int kc_ = (UP) ? m + 1 : m;                            /* level-2 index of this row */ \
+			const float4 c_ = P2[CTR][kc_]; \
+			float4 u_ = kc_ >= 1 ? P2[CTR][kc_ >= 1 ? kc_ - 1 : 0] : H2_; \
+			float4 d_ = kc_ + 1 < R3 + 1 ? P2[CTR][kc_ + 1 < R3 + 1 ? kc_ + 1 : 0] : H2_; \
+			if ((UP) && m == 0 && y0 == 0) u_ = c_; \
+			if (!(UP) && m == R3 - 1 && y0 + R3 >= g.Y) d_ = c_; \
+			const float4 x_ = relax4(c_, u_, d_, P2[OLD][kc_], P2[NEW][kc_], B3_[m], false, false); \
+			if (strip_live) *reinterpret_cast<float4*>(ob_ + opaque32(roff[(UP) ? m + 3 : m + 1])) = x_; \
+		} \
+	} \
+} while (0)
+
+__global__ __launch_bounds__(256, 1) void k_jacobi_strip3c(const Geom g, const float* __restrict__ p_in,
+	const float* __restrict__ b, float* __restrict__ p_out, int z_begin, int z_end, int zchunk, int ngroups, int nchunks, int remap)
+{
+	__shared__ float4 lds_all[4 * C_ROWS_PER_WAVE * 64];
+	__shared__ float4 xbuf[2 * 4 * 2 * 64];                           // [step parity][wave][level-1 row, level-2 row][lane]
+	__shared__ int xflag[8];                                          // last z step whose level-1 [0..3] / level-2 [4..7] edge row each wave has published
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	float4* lds = lds_all + wave * (C_ROWS_PER_WAVE * 64) + lane;
+	const int tile = xcd_index3(ngroups * nchunks, remap);
+	const int grp = tile % ngroups, chunk = tile / ngroups;
+	const int y0 = (grp * 4 + wave) * R3;                             // (Y % 8 == 0: both strips of every pair exist)
+	const bool up = (wave & 1) == 0;
+	const bool strip_live = y0 < g.Y;                                 // Y % 16 == 8: the last workgroup's second pair lies outside (computes, never stores)
+	const int yb = up ? y0 - 3 : y0 - 1;
+	const int zb = z_begin + chunk * zchunk, ze = min(zb + zchunk, z_end);
+	const int qs = max(zb - 3, g.zlo), q_last = ze - 1 + 3, q_load_last = min(q_last, g.zhi);
+	const int b_load_last = min(q_last - 1, g.zhi);
+	const size_t plane = g.plane();
+
+	uint32_t roff[C_P0_ROWS];
+#pragma unroll
+	for (int i = 0; i < C_P0_ROWS; ++i) roff[i] = ((uint32_t)min(max(yb + i, 0), g.Y - 1) * (uint32_t)g.X + 4u * (uint32_t)lane) * 4u;
+
+	int s_ctr = 0, s_old = C_P0_ROWS * 64;
+	int s_b2 = 2 * C_P0_ROWS * 64, s_b3 = s_b2 + C_B_ROWS * 64, s_bfree = s_b3 + C_B_ROWS * 64;
+
+	float4 P1[3][C_B_ROWS], P2[3][R3 + 1], NP[C_P0_ROWS], NB[C_B_ROWS];
+	const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+#pragma unroll
+		for (int i = 0; i < C_B_ROWS; ++i) P1[k][i] = zero;
+#pragma unroll
+		for (int i = 0; i < R3 + 1; ++i) P2[k][i] = zero;
+	}
+#pragma unroll
+	for (int i = 0; i < C_ROWS_PER_WAVE; ++i) lds[i * 64] = zero;
+	for (int i = (int)threadIdx.x; i < 2 * 4 * 2 * 64; i += 256) xbuf[i] = zero;
+	{
+		const char* pb = reinterpret_cast<const char*>(p_in + (size_t)g.lz(min(qs, q_load_last)) * plane);
+#pragma unroll
+		for (int i = 0; i < C_P0_ROWS; ++i) NP[i] = *reinterpret_cast<const float4*>(pb + roff[i]);
+		const char* bbase = reinterpret_cast<const char*>(b + (size_t)g.lz(min(max(qs - 1, g.zlo), g.zhi)) * plane);
+#pragma unroll
+		for (int i = 0; i < C_B_ROWS; ++i) NB[i] = *reinterpret_cast<const float4*>(bbase + roff[i + 1]);
+	}
+	if (threadIdx.x < 8) xflag[threadIdx.x] = qs - 1;                 // the waves of a workgroup share the chunk, hence qs
+	__syncthreads();
+	int q = qs;
+	if (up) {
+		for (;;) {
+			FX_STRIP3C_STEP(0, true);
+			if (++q > q_last) break;
+			FX_STRIP3C_STEP(1, true);
+			if (++q > q_last) break;
+			FX_STRIP3C_STEP(2, true);
+			if (++q > q_last) break;
+		}
+	} else {
+		for (;;) {
+			FX_STRIP3C_STEP(0, false);
+			if (++q > q_last) break;
+			FX_STRIP3C_STEP(1, false);
+			if (++q > q_last) break;
+			FX_STRIP3C_STEP(2, false);
+			if (++q > q_last) break;
+		}
+	}
+}
+#undef FX_STRIP3C_STEP
 #undef FX_LDS
 
 }  // namespace
@@ -447,7 +622,14 @@ hipError_t launch_jacobi_strip3(const Geom& g, const float* p_in, const float* b
 	nchunks = (nzp + zchunk - 1) / zchunk;
 	if (halves && wpg == 2) hipLaunchKernelGGL(k_jacobi_strip3h<2>, dim3(ngroups * nchunks), dim3(128), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
 	else if (halves) hipLaunchKernelGGL(k_jacobi_strip3h<4>, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
-	else hipLaunchKernelGGL(k_jacobi_strip3, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
+	else {
+		// cooperative pairs (k_jacobi_strip3c) where every workgroup holds whole pairs; FLUIDX_STRIP3_COOP=0: every strip on its own
+		static const int coop = [] { const char* e = getenv("FLUIDX_STRIP3_COOP"); return e && *e ? atoi(e) : 1; }();
+		if (coop && (g.Y & 7) == 0)
+			hipLaunchKernelGGL(k_jacobi_strip3c, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
+		else
+			hipLaunchKernelGGL(k_jacobi_strip3, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
+	}
 	return hipGetLastError();
 }
 
