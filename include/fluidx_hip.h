@@ -78,7 +78,7 @@ typedef struct fx_desc {
 	uint32_t advect_address;    /* fx_address                                               */
 	int32_t  device;            /* HIP device ordinal, -1 = current                         */
 	uint32_t slab_z0, slab_nz;  /* z-slab owned by this context; {0, 0} = whole grid        */
-	uint32_t halo_advect;       /* planes exchanged before advection (0 = default 8)        */
+	uint32_t halo_advect;       /* planes allocated (and at most exchanged) per face for the advection (0 = default 6) */
 	uint32_t halo_jacobi;       /* sweeps per pressure halo exchange (0 = default)          */
 	uint32_t flags;             /* FX_FLAG_*                                                */
 } fx_desc;
