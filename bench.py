@@ -111,10 +111,11 @@ BASELINE_CONFIGS = {2: (128, 40, "fp32"), 3: (256, 40, "fp32"), 4: (512, 80, "fp
 
 
 def pressure_round(GX, nz_per_rank, iters):
-    """sweeps per pressure exchange.  Slab ranks thick enough for the three-sweep kernel (X = 256, >= 12.6 M cells) take rounds
-    of 9 = 3 + 3 + 3 (40 sweeps = 4 x 9 + 2 + 2: twelve launches of three and two of two, like the single domain) instead of
-    8 = 3 + 3 + 2; everything else keeps the library default of 8."""
-    return 9 if (GX == 256 and GX * GX * nz_per_rank >= 3 << 22 and iters >= 9) else 8
+    """sweeps per pressure exchange.  Slab ranks thick enough for the three-sweep kernels (X = 256 from 12.6 M cells, X = 512 from
+    16.8 M -- a 64-plane rank of BASELINE configs[3]) take rounds of 9 = 3 + 3 + 3 instead of 8 = 3 + 3 + 2; everything else keeps
+    the library default of 8."""
+    three = (GX == 256 and GX * GX * nz_per_rank >= 3 << 22) or (GX == 512 and GX * GX * nz_per_rank >= 1 << 24)
+    return 9 if (three and iters >= 9) else 8
 
 
 def slab_for_rank(Z, rank, world):

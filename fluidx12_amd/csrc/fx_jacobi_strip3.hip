@@ -237,6 +237,8 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip3(const Geom g, const fl
 
 // X = 512: the 256-wide recipe on half a row per wave.  The wall side of the wave clamps as before; on the cut side the
 // neighbour cell belongs to the partner wave (the other half of the same rows, the next wave of the same workgroup) and
+// (round 2: 386 -> 353 us per launch at 512^3 by handing the edge cells over wait-read-publish AFTER the sweep that produced them,
+// with a counter per level, instead of waiting for the partner at the top of the step: a wave may now run a step ahead)
 // comes in as `edge`: the input level from memory (a wave-uniform scalar load per row), the first- and second-sweep
 // levels from a 512-byte LDS mailbox the partner filled one z step earlier; a per-wave LDS counter of the last published
 // step orders it (a wave waits only while its partner is more than a step behind; a workgroup barrier per step cost 3 %).
@@ -254,15 +256,6 @@ __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 
 
 #define FX_STRIP3H_STEP(PH) do { \
 	constexpr int NEW = (PH) % 3, CTR = ((PH) + 2) % 3, OLD = ((PH) + 1) % 3; \
-	/* the partner half-row wave published, one step ago, the first- and second-sweep values of its cell next to the cut */ \
-	while (*reinterpret_cast<volatile int*>(xflag + (wave ^ 1)) < q - 1) __builtin_amdgcn_s_sleep(1);   /* partner has published step q-1 (and therefore read ours of q-2) */ \
-	asm volatile("" ::: "memory"); \
-	float e1_[R3 + 4], e2_[R3 + 2]; \
-	{ \
-		const float* xr_ = xbuf + (((q - 1) & 1) * WPG + (wave ^ 1)) * 16; \
-		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) e1_[j] = xr_[j]; \
-		_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) e2_[k] = xr_[8 + k]; \
-	} \
 	/* ---- sweep 1: level-1 plane q-1, rows j <-> y0-2+j; input rows i <-> y0-3+i ------------------------------- */ \
 	if (q == 0) {                                   /* input plane -1 := plane 0, once (clamped front neighbour) */ \
 		_Pragma("unroll") for (int i = 0; i < R3 + 6; ++i) FX_LDS(s_ctr, i) = NP[i]; \
@@ -281,10 +274,21 @@ __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 
 			_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) P1[CTR][j] = P1[NEW][j]; \
 		} \
 	} \
-	/* publish this wave's first-sweep cell next to the cut (plane q-1) for the partner's sweep 2 of the next step */ \
+	/* hand-over 1: the partner half-row wave's first-sweep cells next to the cut of ITS step q-1 (plane q-2, for my sweep 2), then \
+	   mine of this step (plane q-1).  Order as in k_jacobi_strip3c: wait, read, only then publish data and counter -- a wave that \
+	   sees my counter at q knows I have read what it wrote two steps ago into the slot it reuses; a wave may run a step ahead */ \
+	while (*reinterpret_cast<volatile int*>(xflag + (wave ^ 1)) < q - 1) __builtin_amdgcn_s_sleep(1); \
+	asm volatile("" ::: "memory"); \
+	float e1_[R3 + 4]; \
+	{ \
+		const float* xr_ = xbuf + (((q - 1) & 1) * WPG + (wave ^ 1)) * 16; \
+		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) e1_[j] = xr_[j]; \
+	} \
 	if (lane == edge_lane) { \
 		float* xw_ = xbuf + ((q & 1) * WPG + wave) * 16; \
 		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) xw_[j] = right_half ? P1[NEW][j].x : P1[NEW][j].w; \
+		asm volatile("" ::: "memory"); \
+		*reinterpret_cast<volatile int*>(xflag + wave) = q;          /* LDS operations of a wave execute in order: the data is there before the counter */ \
 	} \
 	/* ---- the b rows sweeps 2 and 3 will need (slots untouched by the writes below), read now so that they arrive behind the \
 	   writes and the prefetch instead of in front of each update ---- */ \
@@ -321,11 +325,19 @@ __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 
 			_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) P2[CTR][k] = P2[NEW][k]; \
 		} \
 	} \
+	/* hand-over 2: the second-sweep cells (partner's plane q-3 for my sweep 3; mine of plane q-2), same order, their own counter */ \
+	while (*reinterpret_cast<volatile int*>(xflag + WPG + (wave ^ 1)) < q - 1) __builtin_amdgcn_s_sleep(1); \
+	asm volatile("" ::: "memory"); \
+	float e2_[R3 + 2]; \
+	{ \
+		const float* xr_ = xbuf + (((q - 1) & 1) * WPG + (wave ^ 1)) * 16 + 8; \
+		_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) e2_[k] = xr_[k]; \
+	} \
 	if (lane == edge_lane) { \
 		float* xw_ = xbuf + ((q & 1) * WPG + wave) * 16 + 8; \
 		_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) xw_[k] = right_half ? P2[NEW][k].x : P2[NEW][k].w; \
 		asm volatile("" ::: "memory"); \
-		*reinterpret_cast<volatile int*>(xflag + wave) = q;          /* LDS operations of a wave execute in order: the data is there before the counter */ \
+		*reinterpret_cast<volatile int*>(xflag + WPG + wave) = q; \
 	} \
 	/* ---- sweep 3: output plane q-3, rows m <-> y0+m; b[q-3] is s_bfree (its rows 1..4) ------------------------------- */ \
 	if (q - 3 >= zb && q - 3 < ze) { \
@@ -347,7 +359,7 @@ __global__ __launch_bounds__(64 * WPG, 4 / WPG) void k_jacobi_strip3h(const Geom
 {
 	__shared__ float4 lds_all[WPG * LDS_ROWS_PER_WAVE * 64];
 	__shared__ float xbuf[2 * WPG * 16];
-	__shared__ int xflag[WPG];                                        // last z step each wave has published                                // [step parity][wave][8 first-sweep + 6 second-sweep edge cells]
+	__shared__ int xflag[2 * WPG];                                    // last z step whose first-sweep [0..WPG) / second-sweep [WPG..) edge cells each wave has published                                // [step parity][wave][8 first-sweep + 6 second-sweep edge cells]
 	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int lx = lane;
 	float4* lds = lds_all + wave * (LDS_ROWS_PER_WAVE * 64) + lane;
@@ -390,7 +402,7 @@ __global__ __launch_bounds__(64 * WPG, 4 / WPG) void k_jacobi_strip3h(const Geom
 #pragma unroll
 	for (int i = 0; i < LDS_ROWS_PER_WAVE; ++i) lds[i * 64] = zero;
 	if (threadIdx.x < 2 * WPG * 16) xbuf[threadIdx.x] = 0.0f;
-	if (threadIdx.x < WPG) xflag[threadIdx.x] = INT_MIN;
+	if (threadIdx.x < 2 * WPG) xflag[threadIdx.x] = INT_MIN;
 	__syncthreads();
 	{
 		const char* pb = reinterpret_cast<const char*>(p_in + (size_t)g.lz(min(qs, q_load_last)) * plane);
@@ -403,7 +415,7 @@ __global__ __launch_bounds__(64 * WPG, 4 / WPG) void k_jacobi_strip3h(const Geom
 #pragma unroll
 		for (int i = 0; i < R3 + 4; ++i) NB[i] = *reinterpret_cast<const float4*>(bbase + roff[i + 1]);
 	}
-	if (lane == 0) xflag[wave] = qs - 1;                              // both waves of a pair share the chunk, hence qs
+	if (lane == 0) { xflag[wave] = qs - 1; xflag[WPG + wave] = qs - 1; }   // both waves of a pair share the chunk, hence qs
 	__syncthreads();
 	int q = qs;
 	for (;;) {

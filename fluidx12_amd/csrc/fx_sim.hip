@@ -951,10 +951,10 @@ bool jacobi_prefers_three(const Geom& g, int requested, int nzp)
 	static const int no_lds3 = env_int("FLUIDX_STRIP3_OFF", 0);
 	static const int use_tb = env_int("FLUIDX_FUSE2_TB", 0);
 	return prefer && !requested && !forced && !no_lds3 && !use_tb && jacobi_strip3_supported(g) &&
-		(size_t)g.X * g.Y * (size_t)nzp >= ((size_t)3 << (g.X == 512 ? 23 : 22));
-	// X = 256: from 12.6 M cells (256x256x128 still loses, 11.3 against 11.0 us per sweep).  X = 512 (k_jacobi_strip3h, one
-	// workgroup barrier per z step): from 25 M cells -- 512x512x128 39.6 against 43.3 us, 512^3 133.7 against 159.7, but
-	// 512x512x64 20.3 against 19.0
+		(size_t)g.X * g.Y * (size_t)nzp >= (g.X == 512 ? (size_t)1 << 24 : (size_t)3 << 22);
+	// X = 256: from 12.6 M cells (256x256x128 still loses, 11.3 against 11.0 us per sweep).  X = 512 (k_jacobi_strip3h): from 16.8 M
+	// cells since the round-2 hand-over order -- 512x512x64 (a rank of BASELINE configs[3]) 18.7 against 19.5 us per sweep,
+	// 512x512x128 36.2 against 43.7, 512^3 117.6 against 152 (before: 20.3 / 39.6 / 129)
 }
 
 // tile geometry of the fused kernel: TY rows per workgroup (threads = X/4 * TY), D input planes in flight
