@@ -348,8 +348,15 @@ def main():
             m_.timing_enable(True)
             m_.timing_read(reset=True)
     barrier_sync()
+    # N > 1: the library's HIP-event marks (two event records per phase, round and member) cost a multi-rank step about a tenth
+    # (profiles/r02d_comm_priority.txt: 5.1 -> 5.6 ms in loop-back N = 4), so only every fourth step of the timed region carries
+    # them; stage times, launch averages and exchanged bytes are per marked step.  N = 1 marks every step (five marks).
+    mark_every = 4 if (N > 1 and args.steps >= 8) else 1
     t0 = time.perf_counter()
     for k in range(args.steps):
+        if mark_every > 1 and (k % mark_every == 0 or k % mark_every == 1):
+            for m_ in members:
+                m_.timing_enable(k % mark_every == 0)
         one_step(args.warmup + k)
     barrier_sync()
     elapsed = time.perf_counter() - t0

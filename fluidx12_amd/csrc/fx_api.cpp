@@ -237,6 +237,7 @@ int record_step(fx_ctx* ctx, std::vector<fx_ctx*>& M, hipStream_t s)
 {
 	if (!multi_rank(ctx) || !ctx->step_rec) return FX_OK;
 	for (fx_ctx* m : M) {
+		if (m->rec_in_project) { m->rec_in_project = false; continue; }       // k_project_v4 has already written it
 		DeviceGuard dg(m->device);
 		FX_HIP(launch_face_need(m->g, m->half, m->vel[0], m->time_step, (int)m->desc.advect_address, options_digest(m), m->halo_overflow, m->step_rec, s));
 	}
@@ -563,13 +564,18 @@ int jacobi_all(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t it
 	return jacobi_serial(lead, M, s, iters);
 }
 
+int options_digest(const fx_ctx* c);
+
 int project_phase(fx_ctx* ctx, hipStream_t s)
 {
 	DeviceGuard dg(ctx->device);
 	const SimParams sp{ ctx->time_step, (int)ctx->desc.advect_address, ctx->g.Zg > 1 ? 1 : 0 };
 	ScopedMark mk(ctx, s, MK_PROJECT);
 	const Range r = owned(ctx);
-	FX_HIP(launch_project(ctx->g, sp, ctx->half, ctx->vel[1], ctx->p[ctx->p_cur], ctx->vel[0], r.lo, r.hi, s));
+	int* rec = multi_rank(ctx) ? ctx->step_rec : nullptr;           // slab ranks: the projection also measures the next advection's need
+	ctx->rec_in_project = false;
+	FX_HIP(launch_project(ctx->g, sp, ctx->half, ctx->vel[1], ctx->p[ctx->p_cur], ctx->vel[0], r.lo, r.hi, s,
+		rec, rec ? options_digest(ctx) : 0, ctx->halo_overflow, &ctx->rec_in_project));
 	return FX_OK;
 }
 
@@ -599,6 +605,7 @@ int simulate_impl(fx_ctx* ctx, hipStream_t s)
 	} else {
 		for (fx_ctx* m : M) {
 			DeviceGuard dg(m->device);
+			m->rec_in_project = false;
 			if (launch_copy_velocity(m->g, m->half, m->vel[1], m->vel[0], s) != hipSuccess) return FX_E_DEVICE;
 		}
 	}

@@ -75,8 +75,11 @@ hipError_t launch_jacobi_block2(const Geom& g, const float* p_in, const float* b
 // sweeps fused per launch for this geometry (1 = no fused path); requested > 0 overrides the default
 int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp);
 bool jacobi_prefers_three(const Geom& g, int requested, int nzp);
+// rec (optional, slab ranks): the step record of launch_face_need is produced by this launch when it can be (fp32 3-D kernel
+// over exactly the owned planes); *rec_done tells whether it was
 hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const float* p,
-	void* vel_out, int z_begin, int z_end, hipStream_t s);
+	void* vel_out, int z_begin, int z_end, hipStream_t s, int* rec = nullptr, int digest = 0, const unsigned* halo_overflow = nullptr,
+	bool* rec_done = nullptr);
 // multi-GPU: what the next advection will need from the z-neighbours (rec[0] planes below, rec[1] above; exact for time steps
 // <= dt), closed with the options digest (rec[2]) and this step's halo-overflow flag (rec[3]); rec = 4 device ints
 hipError_t launch_face_need(const Geom& g, int half_store, const void* vel, float dt, int address, int digest, const unsigned* halo_overflow, int* rec, hipStream_t s);

@@ -658,10 +658,14 @@ __global__ __launch_bounds__(256) void k_project(const Geom g, const SimParams s
 // coordinate divisions become multiplications by the exact reciprocal (bit-identical).
 template <bool RCP>
 __global__ __launch_bounds__(256) void k_project_v4(const Geom g, const float* __restrict__ vel_in, const float* __restrict__ p,
-	float* __restrict__ vel_out, int z_begin, int nzp, int remap, int rows_per_block, float rX, float rY, float rZ)
+	float* __restrict__ vel_out, int z_begin, int nzp, int remap, int rows_per_block, float rX, float rY, float rZ,
+	int* __restrict__ rec, float dt, int address, int digest, const unsigned* __restrict__ halo_overflow)
 {
 	const int X4 = g.X >> 2;
 	const int lane = threadIdx.x;
+	// slab ranks: this launch also measures what the next advection will need from the z-neighbours (see k_face_need) and
+	// closes the step's record -- the projected u_z is in registers here anyway
+	if (rec && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) { rec[2] = digest; rec[3] = (int)*halo_overflow; }
 	const Tile3 tile = xcd_tile((X4 + (int)blockDim.x - 1) / (int)blockDim.x, (g.Y + rows_per_block - 1) / rows_per_block, nzp, remap);
 	const int x4 = tile.x * blockDim.x + lane;
 	const int y = tile.y * rows_per_block + threadIdx.y;
@@ -712,6 +716,23 @@ __global__ __launch_bounds__(256) void k_project_v4(const Geom g, const float* _
 	*reinterpret_cast<float4*>(vel_out + off) = make_float4(ox[0], ox[1], ox[2], ox[3]);
 	*reinterpret_cast<float4*>(vel_out + stride + off) = make_float4(oy[0], oy[1], oy[2], oy[3]);
 	*reinterpret_cast<float4*>(vel_out + 2u * stride + off) = make_float4(oz[0], oz[1], oz[2], oz[3]);
+	if (rec) {
+		const float pzn = ((float)z + 0.5f) / (float)g.Zg;              // k_advect's pz (== * rZ for the power-of-two grids of the fast paths)
+		int lo = 0, hi = 0;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const float az = fmaf(-oz[i], dt, pzn);
+			const int iz = (int)floorf(az * (float)g.Zg - 0.5f);
+			const int a = addr_tap(iz, g.Zg, address), b_ = addr_tap(iz + 1, g.Zg, address);
+			lo = max(lo, g.z0 - min(a, b_));
+			hi = max(hi, max(a, b_) - (g.z0 + g.nz - 1));
+		}
+		if (__builtin_amdgcn_ballot_w64(lo > 0 || hi > 0) != 0) {       // rare: only the planes next to a face, and not even those when the flow leaves them alone
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) { lo = max(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+			if (((threadIdx.y * blockDim.x + threadIdx.x) & 63) == 0) { if (lo > 0) atomicMax(rec, lo); if (hi > 0) atomicMax(rec + 1, hi); }
+		}
+	}
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1069,8 +1090,9 @@ hipError_t launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream
 }
 
 hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const float* p,
-	void* vel_out, int z_begin, int z_end, hipStream_t s)
+	void* vel_out, int z_begin, int z_end, hipStream_t s, int* rec, int digest, const unsigned* halo_overflow, bool* rec_done)
 {
+	if (rec_done) *rec_done = false;
 	if (z_end <= z_begin) return hipSuccess;
 	static const int v4_on = env_int("FLUIDX_PROJECT_V4", 1);
 	if (v4_on && !half_store && sp.is3d && (g.X & 3) == 0 && g.cells_local() * 3 < ((size_t)1 << 30)) {
@@ -1080,10 +1102,19 @@ hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, co
 		int by = 256 / bx; if (by > g.Y) by = g.Y;
 		const dim3 block(bx, by, 1), grid(((X4 + bx - 1) / bx) * ((g.Y + by - 1) / by) * nzp, 1, 1);
 		const float rX = 1.0f / (float)g.X, rY = 1.0f / (float)g.Y, rZ = 1.0f / (float)g.Zg;
+		// the step record rides along when this launch covers exactly the owned planes (what k_face_need would scan)
+		int* r = (rec && z_begin == g.z0 && z_end == g.z0 + g.nz) ? rec : nullptr;
+		if (r) {
+			const hipError_t e = hipMemsetAsync(r, 0, 2 * sizeof(int), s);
+			if (e != hipSuccess) return e;
+			if (rec_done) *rec_done = true;
+		}
 		if (pow2(g.X) && pow2(g.Y) && pow2(g.Zg))
-			hipLaunchKernelGGL(k_project_v4<true>, grid, block, 0, s, g, (const float*)vel_in, p, (float*)vel_out, z_begin, nzp, xcd_remap_on(REMAP_PROJECT), by, rX, rY, rZ);
+			hipLaunchKernelGGL(k_project_v4<true>, grid, block, 0, s, g, (const float*)vel_in, p, (float*)vel_out, z_begin, nzp, xcd_remap_on(REMAP_PROJECT), by, rX, rY, rZ,
+				r, sp.dt, sp.address, digest, halo_overflow);
 		else
-			hipLaunchKernelGGL(k_project_v4<false>, grid, block, 0, s, g, (const float*)vel_in, p, (float*)vel_out, z_begin, nzp, xcd_remap_on(REMAP_PROJECT), by, rX, rY, rZ);
+			hipLaunchKernelGGL(k_project_v4<false>, grid, block, 0, s, g, (const float*)vel_in, p, (float*)vel_out, z_begin, nzp, xcd_remap_on(REMAP_PROJECT), by, rX, rY, rZ,
+				r, sp.dt, sp.address, digest, halo_overflow);
 		return hipGetLastError();
 	}
 	const dim3 grid = grid_xyz(g, z_end - z_begin), block(64, 4, 1);
