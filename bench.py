@@ -382,6 +382,31 @@ def main():
             # timed steps left behind -- default camera at 1920x1080 (FluidX12.cpp:243-253), OPTIMIZED = light volume + view pass
             import fluidx12_amd as fx
             view, proj, eye = fx.default_camera(1920, 1080)
+            sh_info = None
+            if args.config == 5:
+                # BASELINE configs[4]'s second half: the SH light-probe GI path (CSSHCubeMap / Sum / Normalize) from the
+                # synthetic 256^2 x 6 radiance cube L(dir) = max(dir.y, 0) * (1, .9, .8) + 0.1, then OPTIMIZED rendering with hasSH = 1
+                import numpy as np
+                n = 256
+                idx = np.arange(n, dtype=np.float32)
+                px_, py_ = np.meshgrid(idx - n / 2 + 0.5, -(idx - n / 2 + 0.5))       # the D3D cube-face convention of CubeMap.hlsli:5-35
+                pz_ = np.full_like(px_, n / 2)
+                dirs = [(pz_, py_, -px_), (-pz_, py_, px_), (px_, pz_, -py_), (px_, -pz_, py_), (px_, py_, pz_), (-px_, py_, -pz_)]
+                cube = np.empty((6, n, n, 3), np.float32)
+                for f_, (x_, y_, z_) in enumerate(dirs):
+                    dy = y_ / np.sqrt(x_ * x_ + y_ * y_ + z_ * z_)
+                    cube[f_] = np.maximum(dy, 0)[..., None] * np.array([1.0, 0.9, 0.8], np.float32) + np.float32(0.1)
+                probe = fx.LightProbe(fluid)
+                assert probe.Init(cube)
+                probe.TransformSH(); fluid.Synchronize()
+                t_sh = time.perf_counter()
+                for _ in range(5):
+                    probe.TransformSH()
+                fluid.Synchronize()
+                sh_info = {"radiance_cube": "synthetic 256^2 x 6, L = max(dir.y, 0) * (1, .9, .8) + 0.1",
+                           "transform_ms_incl_upload": (time.perf_counter() - t_sh) / 5 * 1e3,
+                           "sh_band0_rgb": [float(v) for v in probe.GetSH()[0]]}
+                fluid.SetSH(probe.GetSH())
             fluid.UpdateFrame(0.0, 0, view, proj, eye)
             fluid.Render(0, fx.Fluid.OPTIMIZED)
             fluid.Synchronize()
@@ -409,6 +434,9 @@ def main():
                       "direct_march_ms": td_.view_ms / nr, "direct_rays": 1920 * 1080,
                       "rays_per_s": rays / (tr_.view_ms / nr * 1e-3) if tr_.view_ms > 0 else None,
                       "light_voxels_per_s": float(G) ** 3 / (tr_.light_ms / nr * 1e-3) if tr_.light_ms > 0 else None}
+            if sh_info is not None:
+                render["mode"] += ", hasSH = 1 (light probe)"
+                render["sh_light_probe"] = sh_info
         fluid.timing_enable(False)
         if timing.jacobi_launches:
             cells = float(GX) * GY * nz                                # cells this rank sweeps
