@@ -242,9 +242,10 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip3(const Geom g, const fl
 // comes in as `edge`: the input level from memory (a wave-uniform scalar load per row), the first- and second-sweep
 // levels from a 512-byte LDS mailbox the partner filled one z step earlier; a per-wave LDS counter of the last published
 // step orders it (a wave waits only while its partner is more than a step behind; a workgroup barrier per step cost 3 %).
-__device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 F, float4 Bk, float4 bb, float edge, bool right_half)
+template <bool right_half>
+__device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 F, float4 Bk, float4 bb, float edge)
 {
-	const float oldL = right_half ? edge : c.x, oldR = right_half ? c.w : edge;
+	const float oldL = right_half ? edge : c.x, oldR = right_half ? c.w : edge;    // compile-time: the step is expanded once per half
 	const float L = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldL), __builtin_bit_cast(int, c.w), 0x138, 0xf, 0xf, false));
 	const float Rr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldR), __builtin_bit_cast(int, c.x), 0x130, 0xf, 0xf, false));
 	const float4 Lv = make_float4(L, c.x, c.y, c.z), Rv = make_float4(c.y, c.z, c.w, Rr);
@@ -254,7 +255,7 @@ __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 
 	return x;
 }
 
-#define FX_STRIP3H_STEP(PH) do { \
+#define FX_STRIP3H_STEP(PH, RIGHT) do { \
 	constexpr int NEW = (PH) % 3, CTR = ((PH) + 2) % 3, OLD = ((PH) + 1) % 3; \
 	/* ---- sweep 1: level-1 plane q-1, rows j <-> y0-2+j; input rows i <-> y0-3+i ------------------------------- */ \
 	if (q == 0) {                                   /* input plane -1 := plane 0, once (clamped front neighbour) */ \
@@ -269,7 +270,7 @@ __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 
 		_Pragma("unroll") for (int i = 0; i < R3 + 6; ++i) C_[i] = FX_LDS(s_ctr, i); \
 		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) F_[j] = FX_LDS(s_old, j + 1); \
 		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) \
-			P1[NEW][j] = relax4_h(C_[j + 1], C_[j], C_[j + 2], F_[j], NP[j + 1], NB[j], E0c[j + 1], right_half); \
+			P1[NEW][j] = relax4_h<RIGHT>(C_[j + 1], C_[j], C_[j + 2], F_[j], NP[j + 1], NB[j], E0c[j + 1]); \
 		if (q - 1 == 0) { \
 			_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) P1[CTR][j] = P1[NEW][j]; \
 		} \
@@ -286,7 +287,7 @@ __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 
 	} \
 	if (lane == edge_lane) { \
 		float* xw_ = xbuf + ((q & 1) * WPG + wave) * 16; \
-		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) xw_[j] = right_half ? P1[NEW][j].x : P1[NEW][j].w; \
+		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) xw_[j] = (RIGHT) ? P1[NEW][j].x : P1[NEW][j].w; \
 		asm volatile("" ::: "memory"); \
 		*reinterpret_cast<volatile int*>(xflag + wave) = q;          /* LDS operations of a wave execute in order: the data is there before the counter */ \
 	} \
@@ -319,7 +320,7 @@ __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 
 			float4 u_ = P1[CTR][k], d_ = P1[CTR][k + 2]; \
 			if (k == 1 && y0 == 0) u_ = c_;                             /* rows outside the domain hold no data */ \
 			if (k == R3 && y0 + R3 >= g.Y) d_ = c_; \
-			P2[NEW][k] = relax4_h(c_, u_, d_, P1[OLD][k + 1], P1[NEW][k + 1], B2_[k], e1_[k + 1], right_half); \
+			P2[NEW][k] = relax4_h<RIGHT>(c_, u_, d_, P1[OLD][k + 1], P1[NEW][k + 1], B2_[k], e1_[k + 1]); \
 		} \
 		if (q - 2 == 0) { \
 			_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) P2[CTR][k] = P2[NEW][k]; \
@@ -335,7 +336,7 @@ __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 
 	} \
 	if (lane == edge_lane) { \
 		float* xw_ = xbuf + ((q & 1) * WPG + wave) * 16 + 8; \
-		_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) xw_[k] = right_half ? P2[NEW][k].x : P2[NEW][k].w; \
+		_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) xw_[k] = (RIGHT) ? P2[NEW][k].x : P2[NEW][k].w; \
 		asm volatile("" ::: "memory"); \
 		*reinterpret_cast<volatile int*>(xflag + WPG + wave) = q; \
 	} \
@@ -347,7 +348,7 @@ __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 
 			float4 u_ = P2[CTR][m], d_ = P2[CTR][m + 2]; \
 			if (m == 0 && y0 == 0) u_ = c_; \
 			if (m == R3 - 1 && y0 + R3 >= g.Y) d_ = c_; \
-			const float4 x_ = relax4_h(c_, u_, d_, P2[OLD][m + 1], P2[NEW][m + 1], B3_[m], e2_[m + 1], right_half); \
+			const float4 x_ = relax4_h<RIGHT>(c_, u_, d_, P2[OLD][m + 1], P2[NEW][m + 1], B3_[m], e2_[m + 1]); \
 			if (strip_live) *reinterpret_cast<float4*>(ob_ + opaque32(roff[m + 3])) = x_;   /* rows y0 .. y0+3 of a live strip are never clamped */ \
 		} \
 	} \
@@ -418,13 +419,24 @@ __global__ __launch_bounds__(64 * WPG, 4 / WPG) void k_jacobi_strip3h(const Geom
 	if (lane == 0) { xflag[wave] = qs - 1; xflag[WPG + wave] = qs - 1; }   // both waves of a pair share the chunk, hence qs
 	__syncthreads();
 	int q = qs;
-	for (;;) {
-		FX_STRIP3H_STEP(0);
-		if (++q > q_last) break;
-		FX_STRIP3H_STEP(1);
-		if (++q > q_last) break;
-		FX_STRIP3H_STEP(2);
-		if (++q > q_last) break;
+	if (right_half) {                                                 // wave-uniform: each half runs its own expansion, free of per-update selects
+		for (;;) {
+			FX_STRIP3H_STEP(0, true);
+			if (++q > q_last) break;
+			FX_STRIP3H_STEP(1, true);
+			if (++q > q_last) break;
+			FX_STRIP3H_STEP(2, true);
+			if (++q > q_last) break;
+		}
+	} else {
+		for (;;) {
+			FX_STRIP3H_STEP(0, false);
+			if (++q > q_last) break;
+			FX_STRIP3H_STEP(1, false);
+			if (++q > q_last) break;
+			FX_STRIP3H_STEP(2, false);
+			if (++q > q_last) break;
+		}
 	}
 }
 #undef FX_STRIP3H_STEP
