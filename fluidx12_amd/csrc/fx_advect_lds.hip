@@ -31,10 +31,19 @@ namespace {
 constexpr int TX = 64, TY = 8;                    // voxels per workgroup and plane
 constexpr int HX = TX + 2, HY = TY + 2;           // staged cells per plane
 constexpr int NCELL = HX * HY;                    // 660
-constexpr int COL_BYTES = NCELL * 16;             // 10560
-constexpr int VEL_BYTES = NCELL * 4;              // 2640 per component
-constexpr int SLOT_BYTES = COL_BYTES + 3 * VEL_BYTES;   // 18480 (a multiple of 16)
+constexpr int VEL_BYTES = NCELL * 4;              // 2640 per component (fp16 storage: the half sits zero-extended in a dword -- a 2-byte LDS-DMA load writes a dword per lane, tools/micro/ldslds2.cpp)
 constexpr int NSLOT = 4;
+// colour bytes per staged cell and per slot: fp32 = one float4 per cell; fp16 = two dword planes (r|g, b|a) -- there is no 8-byte LDS-DMA
+template <bool HALF> struct Lay {
+	static constexpr int COL_BYTES = HALF ? 2 * NCELL * 4 : NCELL * 16;          // 5280 | 10560
+	static constexpr int SLOT_BYTES = COL_BYTES + 3 * VEL_BYTES;                 // 13200 | 18480 (multiples of 16)
+};
+typedef _Float16 h16;
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+// the fp32 result is rounded to binary16 in a SEPARATE step, as a typed store of an fp32 register does (fx_sim.hip, Store<true>)
+__device__ __forceinline__ h16 to_h16(float v) { asm("" : "+v"(v)); return (h16)v; }
+__device__ __forceinline__ float lo_half(uint32_t d) { return (float)__builtin_bit_cast(h16, (uint16_t)(d & 0xffffu)); }
+__device__ __forceinline__ float hi_half(uint32_t d) { return (float)__builtin_bit_cast(h16, (uint16_t)(d >> 16)); }
 
 __device__ __forceinline__ float lerpf(float a, float b, float f) { return fmaf(f, b - a, a); }
 __device__ __forceinline__ float saturatef(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
@@ -83,6 +92,35 @@ __device__ __forceinline__ void stage64(const void* col, const void* v0, const v
 		: "v"(col), "v"(v0), "v"(v1), "v"(v2), "s"(lds_col), "s"(lds_vel), "n"(VEL_BYTES));
 }
 
+// fp16 storage: colour texel = 8 bytes -> its two dwords to two LDS planes NCELL * 4 bytes apart; a velocity half -> a dword per lane
+__device__ __forceinline__ void stage64h(const void* col, const void* v0, const void* v1, const void* v2, uint32_t lds_col, uint32_t lds_vel)
+{
+	uint32_t keep;
+	lds_col = __builtin_amdgcn_readfirstlane(lds_col);
+	lds_vel = __builtin_amdgcn_readfirstlane(lds_vel);
+	const void* col_hi = static_cast<const char*>(col) + 4;      // (an instruction offset would shift the LDS address too)
+	asm volatile(
+		"s_mov_b32 %0, m0\n\t"
+		"s_mov_b32 m0, %6\n\t"
+		"s_nop 0\n\t"
+		"global_load_lds_dword %1, off\n\t"
+		"s_add_u32 m0, m0, %8\n\t"
+		"s_nop 0\n\t"
+		"global_load_lds_dword %2, off\n\t"
+		"s_mov_b32 m0, %7\n\t"
+		"s_nop 0\n\t"
+		"global_load_lds_ushort %3, off\n\t"
+		"s_add_u32 m0, m0, %8\n\t"
+		"s_nop 0\n\t"
+		"global_load_lds_ushort %4, off\n\t"
+		"s_add_u32 m0, m0, %8\n\t"
+		"s_nop 0\n\t"
+		"global_load_lds_ushort %5, off\n\t"
+		"s_mov_b32 m0, %0"
+		: "=&s"(keep)
+		: "v"(col), "v"(col_hi), "v"(v0), "v"(v1), "v"(v2), "s"(lds_col), "s"(lds_vel), "n"(VEL_BYTES));
+}
+
 template <typename T>
 __device__ __forceinline__ T ldg32(const void* base, uint32_t byte_off)
 {
@@ -91,8 +129,11 @@ __device__ __forceinline__ T ldg32(const void* base, uint32_t byte_off)
 
 }  // namespace
 
+// HALF: fp16 storage of velocity / colour (BASELINE configs[4], the reference's RGBA16F): arithmetic unchanged (fp32), half the HBM
+// bytes, 13.2 instead of 18.5 KB per slot
+template <bool HALF>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_advect_lds(const Geom g, const SimParams sp,
-	const float* __restrict__ vel_in, const float4* __restrict__ col_in, float* __restrict__ vel_out, float4* __restrict__ col_out,
+	const void* __restrict__ vel_in, const void* __restrict__ col_in, void* __restrict__ vel_out, void* __restrict__ col_out,
 	int z_begin, int nzp, int zchunk, int nchunks, unsigned* halo_overflow, float rX, float rY, float rZ, float inv_rr,
 	int lgX, int lgY, int lg_gx, int lg_gy, int dbg)
 {
@@ -113,10 +154,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 	if (zb >= ze) return;                                        // uniform for the workgroup
 
 	const int lgP = lgX + lgY;
+	constexpr int COL_BYTES = Lay<HALF>::COL_BYTES, SLOT_BYTES = Lay<HALF>::SLOT_BYTES;
+	constexpr uint32_t ES = HALF ? 2 : 4, CS = HALF ? 8 : 16;    // bytes per velocity element / colour texel in HBM
 	const uint32_t stride = (uint32_t)g.nzl() << lgP;           // cells between velocity component planes
 	const char* v0 = reinterpret_cast<const char*>(vel_in);
-	const char* v1 = v0 + (size_t)stride * 4;
-	const char* v2 = v1 + (size_t)stride * 4;
+	const char* v1 = v0 + (size_t)stride * ES;
+	const char* v2 = v1 + (size_t)stride * ES;
 
 	// ---- which cells of a staged plane this lane fetches: cell c = tid (every wave) and 512 + tid (waves 0..2) -------------
 	// source = the ADDRESSED cell (clamp / mirror of the unclamped coordinate), so a tap index needs no addressing afterwards
@@ -140,13 +183,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 		const uint32_t slot = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(((zq + 4) & 3) * SLOT_BYTES));
 		{
 			const size_t cell = pz + src_a;
-			stage64(reinterpret_cast<const char*>(col_in) + cell * 16, v0 + cell * 4, v1 + cell * 4, v2 + cell * 4,
+			if (HALF) stage64h(reinterpret_cast<const char*>(col_in) + cell * CS, v0 + cell * ES, v1 + cell * ES, v2 + cell * ES,
+				slot + (uint32_t)wave * (64 * 4), slot + COL_BYTES + (uint32_t)wave * (64 * 4));
+			else stage64(reinterpret_cast<const char*>(col_in) + cell * CS, v0 + cell * ES, v1 + cell * ES, v2 + cell * ES,
 				slot + (uint32_t)wave * (64 * 16), slot + COL_BYTES + (uint32_t)wave * (64 * 4));
 		}
 		if (wave_has_b) {
 			if (has_b) {
 				const size_t cell = pz + src_b;
-				stage64(reinterpret_cast<const char*>(col_in) + cell * 16, v0 + cell * 4, v1 + cell * 4, v2 + cell * 4,
+				if (HALF) stage64h(reinterpret_cast<const char*>(col_in) + cell * CS, v0 + cell * ES, v1 + cell * ES, v2 + cell * ES,
+					slot + (512 + (uint32_t)wave * 64) * 4, slot + COL_BYTES + (512 + (uint32_t)wave * 64) * 4);
+				else stage64(reinterpret_cast<const char*>(col_in) + cell * CS, v0 + cell * ES, v1 + cell * ES, v2 + cell * ES,
 					slot + (512 + (uint32_t)wave * 64) * 16, slot + COL_BYTES + (512 + (uint32_t)wave * 64) * 4);
 			}
 		}
@@ -174,8 +221,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 		const float ex = ((d2 * -4.0f) * inv_rr) * 1.44269502f;
 
 		const char* sc = lds + ((z + 4) & 3) * SLOT_BYTES;      // slot of plane z
-		const float* vs = reinterpret_cast<const float*>(sc + COL_BYTES);
-		const float u0x = vs[own], u0y = vs[NCELL + own], u0z = vs[2 * NCELL + own];
+		const uint32_t* vs = reinterpret_cast<const uint32_t*>(sc + COL_BYTES);
+		auto vval = [](uint32_t d) -> float { return HALF ? lo_half(d) : __uint_as_float(d); };      // a staged velocity dword as fp32
+		const float u0x = vval(vs[own]), u0y = vval(vs[NCELL + own]), u0z = vval(vs[2 * NCELL + own]);
 		const float ax = fmaf(-u0x, dt, px), ay = fmaf(-u0y, dt, py), az = fmaf(-u0z, dt, pz);
 		const float tx_ = ax * (float)g.X - 0.5f, ty_ = ay * (float)g.Y - 0.5f, tz_ = az * (float)g.Zg - 0.5f;
 		const float flx = floorf(tx_), fly = floorf(ty_), flz = floorf(tz_);
@@ -197,18 +245,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 			const char* s1 = lds + ((iz + 5) & 3) * SLOT_BYTES;
 #pragma unroll
 			for (int a = 0; a < 3; ++a) {
-				const float* p0 = reinterpret_cast<const float*>(s0 + COL_BYTES + a * VEL_BYTES) + c0;
-				const float* p1 = reinterpret_cast<const float*>(s1 + COL_BYTES + a * VEL_BYTES) + c0;
-				const float c00 = lerpf(p0[0], p0[1], fx);
-				const float c10 = lerpf(p0[HX], p0[HX + 1], fx);
-				const float c01 = lerpf(p1[0], p1[1], fx);
-				const float c11 = lerpf(p1[HX], p1[HX + 1], fx);
+				const uint32_t* p0 = reinterpret_cast<const uint32_t*>(s0 + COL_BYTES + a * VEL_BYTES) + c0;
+				const uint32_t* p1 = reinterpret_cast<const uint32_t*>(s1 + COL_BYTES + a * VEL_BYTES) + c0;
+				const float c00 = lerpf(vval(p0[0]), vval(p0[1]), fx);
+				const float c10 = lerpf(vval(p0[HX]), vval(p0[HX + 1]), fx);
+				const float c01 = lerpf(vval(p1[0]), vval(p1[1]), fx);
+				const float c11 = lerpf(vval(p1[HX]), vval(p1[HX + 1]), fx);
 				u[a] = lerpf(lerpf(c00, c10, fy), lerpf(c01, c11, fy), fz);
 			}
-			const float4* q0 = reinterpret_cast<const float4*>(s0) + c0;
-			const float4* q1 = reinterpret_cast<const float4*>(s1) + c0;
-			const float4 t000 = q0[0], t100 = q0[1], t010 = q0[HX], t110 = q0[HX + 1];
-			const float4 t001 = q1[0], t101 = q1[1], t011 = q1[HX], t111 = q1[HX + 1];
+			float4 t000, t100, t010, t110, t001, t101, t011, t111;
+			if (HALF) {
+				// a texel = dword c0 of the r|g plane and dword c0 of the b|a plane
+				auto tex = [](const char* slot, uint32_t c) -> float4 {
+					const uint32_t rg = reinterpret_cast<const uint32_t*>(slot)[c], ba = reinterpret_cast<const uint32_t*>(slot)[NCELL + c];
+					return make_float4(lo_half(rg), hi_half(rg), lo_half(ba), hi_half(ba));
+				};
+				t000 = tex(s0, c0); t100 = tex(s0, c0 + 1); t010 = tex(s0, c0 + HX); t110 = tex(s0, c0 + HX + 1);
+				t001 = tex(s1, c0); t101 = tex(s1, c0 + 1); t011 = tex(s1, c0 + HX); t111 = tex(s1, c0 + HX + 1);
+			} else {
+				const float4* q0 = reinterpret_cast<const float4*>(s0) + c0;
+				const float4* q1 = reinterpret_cast<const float4*>(s1) + c0;
+				t000 = q0[0]; t100 = q0[1]; t010 = q0[HX]; t110 = q0[HX + 1];
+				t001 = q1[0]; t101 = q1[1]; t011 = q1[HX]; t111 = q1[HX + 1];
+			}
 #define FX_TRI(m) lerpf(lerpf(lerpf(t000.m, t100.m, fx), lerpf(t010.m, t110.m, fx), fy), \
 	lerpf(lerpf(t001.m, t101.m, fx), lerpf(t011.m, t111.m, fx), fy), fz)
 			c[0] = FX_TRI(x); c[1] = FX_TRI(y); c[2] = FX_TRI(z); c[3] = FX_TRI(w);
@@ -229,18 +288,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 			const uint32_t c001 = p1 + ry0 + (uint32_t)xa0, c101 = p1 + ry0 + (uint32_t)xa1;
 			const uint32_t c011 = p1 + ry1 + (uint32_t)xa0, c111 = p1 + ry1 + (uint32_t)xa1;
 			const char* vb[3] = { v0, v1, v2 };
+			auto gv = [](const char* b, uint32_t cell) -> float { return HALF ? (float)ldg32<h16>(b, cell * 2u) : ldg32<float>(b, cell * 4u); };
+			auto gc = [&](uint32_t cell) -> float4 {
+				if (HALF) { const h16x4 h = ldg32<h16x4>(col_in, cell * 8u); return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w); }
+				return ldg32<float4>(col_in, cell * 16u);
+			};
 #pragma unroll
 			for (int a = 0; a < 3; ++a) {
-				const float c00 = lerpf(ldg32<float>(vb[a], c000 * 4u), ldg32<float>(vb[a], c100 * 4u), fx);
-				const float c10 = lerpf(ldg32<float>(vb[a], c010 * 4u), ldg32<float>(vb[a], c110 * 4u), fx);
-				const float c01 = lerpf(ldg32<float>(vb[a], c001 * 4u), ldg32<float>(vb[a], c101 * 4u), fx);
-				const float c11 = lerpf(ldg32<float>(vb[a], c011 * 4u), ldg32<float>(vb[a], c111 * 4u), fx);
+				const float c00 = lerpf(gv(vb[a], c000), gv(vb[a], c100), fx);
+				const float c10 = lerpf(gv(vb[a], c010), gv(vb[a], c110), fx);
+				const float c01 = lerpf(gv(vb[a], c001), gv(vb[a], c101), fx);
+				const float c11 = lerpf(gv(vb[a], c011), gv(vb[a], c111), fx);
 				u[a] = lerpf(lerpf(c00, c10, fy), lerpf(c01, c11, fy), fz);
 			}
-			const float4 t000 = ldg32<float4>(col_in, c000 * 16u), t100 = ldg32<float4>(col_in, c100 * 16u);
-			const float4 t010 = ldg32<float4>(col_in, c010 * 16u), t110 = ldg32<float4>(col_in, c110 * 16u);
-			const float4 t001 = ldg32<float4>(col_in, c001 * 16u), t101 = ldg32<float4>(col_in, c101 * 16u);
-			const float4 t011 = ldg32<float4>(col_in, c011 * 16u), t111 = ldg32<float4>(col_in, c111 * 16u);
+			const float4 t000 = gc(c000), t100 = gc(c100), t010 = gc(c010), t110 = gc(c110);
+			const float4 t001 = gc(c001), t101 = gc(c101), t011 = gc(c011), t111 = gc(c111);
 #define FX_TRI(m) lerpf(lerpf(lerpf(t000.m, t100.m, fx), lerpf(t010.m, t110.m, fx), fy), \
 	lerpf(lerpf(t001.m, t101.m, fx), lerpf(t011.m, t111.m, fx), fy), fz)
 			c[0] = FX_TRI(x); c[1] = FX_TRI(y); c[2] = FX_TRI(z); c[3] = FX_TRI(w);
@@ -269,10 +331,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 			}
 		}
 		const uint32_t id = ((uint32_t)g.lz(z) << lgP) + ((uint32_t)y << lgX) + (uint32_t)x;
-		vel_out[id] = u[0] * atten;
-		vel_out[(size_t)stride + id] = u[1] * atten;
-		vel_out[2 * (size_t)stride + id] = u[2] * atten;
-		col_out[id] = make_float4(c[0] * atten, c[1] * atten, c[2] * atten, c[3] * atten);
+		if (HALF) {
+			h16* vo = static_cast<h16*>(vel_out);
+			vo[id] = to_h16(u[0] * atten);
+			vo[(size_t)stride + id] = to_h16(u[1] * atten);
+			vo[2 * (size_t)stride + id] = to_h16(u[2] * atten);
+			h16x4 hc;
+			hc.x = to_h16(c[0] * atten); hc.y = to_h16(c[1] * atten); hc.z = to_h16(c[2] * atten); hc.w = to_h16(c[3] * atten);
+			static_cast<h16x4*>(col_out)[id] = hc;
+		} else {
+			float* vo = static_cast<float*>(vel_out);
+			vo[id] = u[0] * atten;
+			vo[(size_t)stride + id] = u[1] * atten;
+			vo[2 * (size_t)stride + id] = u[2] * atten;
+			static_cast<float4*>(col_out)[id] = make_float4(c[0] * atten, c[1] * atten, c[2] * atten, c[3] * atten);
+		}
 
 	};
 
@@ -294,10 +367,12 @@ hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store,
 {
 	auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
 	const int nzp = z_end - z_begin;
-	if (half_store || g.Zg <= 1 || !pow2(g.X) || !pow2(g.Y) || !pow2(g.Zg) || g.X < TX || g.Y < TY || nzp < 12 ||
+	if (g.Zg <= 1 || !pow2(g.X) || !pow2(g.Y) || !pow2(g.Zg) || g.X < TX || g.Y < TY || nzp < 12 ||
 		(!force && (size_t)g.X * g.Y * (size_t)nzp < ((size_t)1 << 22)) ||     // 128^3: 0.032-0.040 ms against 0.030 for k_advect_fast -- too few workgroups
 		g.cells_local() * 16 >= ((size_t)1 << 32))
 		return hipErrorNotSupported;
+	static const int half_on = env_i("FLUIDX_ADVECT_LDS_HALF", 1);
+	if (half_store && !half_on) return hipErrorNotSupported;
 	auto lg = [](int v) { int k = 0; while ((1 << k) < v) ++k; return k; };
 	const int lgX = lg(g.X), lgY = lg(g.Y), lg_gx = lg(g.X / TX), lg_gy = lg(g.Y / TY);
 	const int tiles_xy = (g.X / TX) * (g.Y / TY);
@@ -310,12 +385,18 @@ hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store,
 	const int nchunks = (nzp + zchunk - 1) / zchunk;
 	static bool attr_set = false;
 	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_advect_lds), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * SLOT_BYTES);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_advect_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * Lay<false>::SLOT_BYTES);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_advect_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * Lay<true>::SLOT_BYTES);
 		attr_set = true;
 	}
 	const float rX = 1.0f / (float)g.X, rY = 1.0f / (float)g.Y, rZ = 1.0f / (float)g.Zg, inv_rr = sp.is3d ? 256.0f : 1024.0f;
-	hipLaunchKernelGGL(k_advect_lds, dim3(tiles_xy * nchunks), dim3(512), NSLOT * SLOT_BYTES, s, g, sp, (const float*)vel_in, (const float4*)col_in,
-		(float*)vel_out, (float4*)col_out, z_begin, nzp, zchunk, nchunks, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY, lg_gx, lg_gy, env_i("FLUIDX_ADVECT_DBG", 0));
+	const int dbg = env_i("FLUIDX_ADVECT_DBG", 0);
+	if (half_store)
+		hipLaunchKernelGGL(k_advect_lds<true>, dim3(tiles_xy * nchunks), dim3(512), NSLOT * Lay<true>::SLOT_BYTES, s, g, sp, vel_in, col_in, vel_out, col_out,
+			z_begin, nzp, zchunk, nchunks, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY, lg_gx, lg_gy, dbg);
+	else
+		hipLaunchKernelGGL(k_advect_lds<false>, dim3(tiles_xy * nchunks), dim3(512), NSLOT * Lay<false>::SLOT_BYTES, s, g, sp, vel_in, col_in, vel_out, col_out,
+			z_begin, nzp, zchunk, nchunks, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY, lg_gx, lg_gy, dbg);
 	return hipGetLastError();
 }
 

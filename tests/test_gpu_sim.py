@@ -383,9 +383,10 @@ def test_advect_fast_path_bit_identical(dims, storage, address, monkeypatch):
     assert np.array_equal(v0.view(np.uint32), v1.view(np.uint32)) and np.array_equal(c0.view(np.uint32), c1.view(np.uint32))
 
 
+@pytest.mark.parametrize("storage", ["fp32", "fp16"])
 @pytest.mark.parametrize("dims,address,scale", [((64, 64, 64), "clamp", 0.2), ((64, 64, 64), "mirror", 3.0), ((128, 128, 32), "clamp", 1.0),
                                                  ((256, 256, 16), "mirror", 0.4), ((64, 64, 16), "clamp", 12.0)])
-def test_advect_lds_path_bit_identical(dims, address, scale, monkeypatch):
+def test_advect_lds_path_bit_identical(dims, address, scale, storage, monkeypatch):
     """k_advect_lds (taps from an LDS-staged 66 x 10 x 3-plane window, global gathers for the waves that trace further) against
     k_advect_fast and the oracle: random velocities from well inside the window (scale 0.2: every wave on the LDS path) to far
     outside (12: every wave on the gather path), both addressing modes, grid borders in every direction"""
@@ -394,10 +395,13 @@ def test_advect_lds_path_bit_identical(dims, address, scale, monkeypatch):
     vel = (rng.standard_normal((3, Z, Y, X)) * scale).astype(f32)
     vel[:, :, : Y // 2] *= f32(0.05)                       # half of the rows trace less than a cell: mixed waves inside one workgroup
     col = rng.random((Z, Y, X, 4)).astype(f32)
+    half = storage == "fp16"
+    if half:
+        vel, col = vel.astype(np.float16).astype(f32), col.astype(np.float16).astype(f32)
     got = {}
     for lds in ("1", "0"):
         monkeypatch.setenv("FLUIDX_ADVECT_LDS", "2" if lds == "1" else "0")      # 2 = the LDS path also below the size where it pays
-        f = make(dims, advect_address=address)
+        f = make(dims, advect_address=address, storage=storage)
         dt = f32(f.default_time_step())
         f.upload(fx.FIELD_VELOCITY, vel); f.upload(fx.FIELD_COLOR, col)
         f.UpdateFrame(dt, 0)
@@ -406,8 +410,8 @@ def test_advect_lds_path_bit_identical(dims, address, scale, monkeypatch):
         got[lds] = (f.download(fx.FIELD_VELOCITY1), f.download(fx.FIELD_COLOR))
     assert np.array_equal(got["1"][0].view(np.uint32), got["0"][0].view(np.uint32))
     assert np.array_equal(got["1"][1].view(np.uint32), got["0"][1].view(np.uint32))
-    vo, co = orc.advect(vel, col, dt, address=int(address == "mirror"))
-    assert rel_l2(got["1"][0], vo) < 1e-6 and rel_l2(got["1"][1], co) < 1e-6
+    vo, co = orc.advect(vel, col, dt, address=int(address == "mirror"), half=half)
+    assert rel_l2(got["1"][0], vo) < (1e-4 if half else 1e-6) and rel_l2(got["1"][1], co) < (1e-4 if half else 1e-6)
     z, y, x = np.meshgrid(np.arange(Z), np.arange(Y), np.arange(X), indexing="ij", sparse=True)
     far = ((x + .5) / X - .5) ** 2 + ((y + .5) / Y - .1) ** 2 + ((z + .5) / Z - .5) ** 2 > (1.5 / 16) ** 2
     assert np.array_equal(got["1"][0][:, far], vo[:, far]) and np.array_equal(got["1"][1][far], co[far])
