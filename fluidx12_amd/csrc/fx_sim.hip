@@ -35,6 +35,7 @@ template <> struct Store<false> {
 		a = v.a; b = v.b;
 	}
 	static __device__ __forceinline__ float ld(const S* p, size_t i) { return p[i]; }
+	static __device__ __forceinline__ float stored(float v) { return v; }               // the value a later load of this store returns
 	static __device__ __forceinline__ void st(S* p, size_t i, float v) { p[i] = v; }
 	static __device__ __forceinline__ float4 ld4(const S4* p, size_t i) { return p[i]; }
 	static __device__ __forceinline__ void st4(S4* p, size_t i, float4 v) { p[i] = v; }
@@ -53,6 +54,7 @@ template <> struct Store<true> {
 	// product ONCE: different whenever the fp32 rounding lands on a binary16 tie (u * 0.95 does, for dt = 1/4).  The empty
 	// asm makes the fp32 value opaque, so the conversion stays a plain v_cvt_f16_f32.
 	static __device__ __forceinline__ float rounded_f32(float v) { asm("" : "+v"(v)); return v; }
+	static __device__ __forceinline__ float stored(float v) { return (float)(h16)rounded_f32(v); }
 	static __device__ __forceinline__ void st(S* p, size_t i, float v) { p[i] = (h16)rounded_f32(v); }   // RNE
 	static __device__ __forceinline__ float4 ld4(const S4* p, size_t i)
 	{
@@ -388,10 +390,13 @@ __global__ __launch_bounds__(256) void k_divergence(const Geom g, const typename
 	b[row + x] = 0.5f * S;
 }
 
-// fp32 3-D fast path: one thread = 4 consecutive x (16-B loads of the y and z neighbour rows, 16-B store of b)
-__global__ __launch_bounds__(256) void k_divergence_v4(const Geom g, const float* __restrict__ vel, float* __restrict__ b,
+// 3-D fast path: one thread = 4 consecutive x (16-B / 8-B loads of the y and z neighbour rows, 16-B store of b)
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_divergence_v4(const Geom g, const typename Store<HALF>::S* __restrict__ vel, float* __restrict__ b,
 	int z_begin, int nzp, int remap, int rows_per_block)
 {
+	typedef Store<HALF> St;
+	typedef typename St::S4 S4;
 	const int X4 = g.X >> 2;
 	const Tile3 tile = xcd_tile((X4 + (int)blockDim.x - 1) / (int)blockDim.x, (g.Y + rows_per_block - 1) / rows_per_block, nzp, remap);
 	const int x4 = tile.x * blockDim.x + threadIdx.x;
@@ -402,13 +407,13 @@ __global__ __launch_bounds__(256) void k_divergence_v4(const Geom g, const float
 	const int yu = max(y, 1) - 1, yd = min(y + 1, g.Y - 1);
 	const int zf = max(z, 1) - 1, zb = min(z + 1, g.Zg - 1);
 	const size_t zrow = (size_t)g.lz(z) * plane, off = zrow + (size_t)y * g.X + 4 * x4;
-	const float4 cx = *reinterpret_cast<const float4*>(vel + off);
-	const float L = x4 > 0 ? vel[off - 1] : cx.x;
-	const float R = x4 < X4 - 1 ? vel[off + 4] : cx.w;
-	const float4 U = *reinterpret_cast<const float4*>(vel + stride + zrow + (size_t)yu * g.X + 4 * x4);
-	const float4 D = *reinterpret_cast<const float4*>(vel + stride + zrow + (size_t)yd * g.X + 4 * x4);
-	const float4 F = *reinterpret_cast<const float4*>(vel + 2 * stride + (size_t)g.lz(zf) * plane + (size_t)y * g.X + 4 * x4);
-	const float4 B = *reinterpret_cast<const float4*>(vel + 2 * stride + (size_t)g.lz(zb) * plane + (size_t)y * g.X + 4 * x4);
+	const float4 cx = St::ld4(reinterpret_cast<const S4*>(vel + off), 0);
+	const float L = x4 > 0 ? St::ld(vel, off - 1) : cx.x;
+	const float R = x4 < X4 - 1 ? St::ld(vel, off + 4) : cx.w;
+	const float4 U = St::ld4(reinterpret_cast<const S4*>(vel + stride + zrow + (size_t)yu * g.X + 4 * x4), 0);
+	const float4 D = St::ld4(reinterpret_cast<const S4*>(vel + stride + zrow + (size_t)yd * g.X + 4 * x4), 0);
+	const float4 F = St::ld4(reinterpret_cast<const S4*>(vel + 2 * stride + (size_t)g.lz(zf) * plane + (size_t)y * g.X + 4 * x4), 0);
+	const float4 B = St::ld4(reinterpret_cast<const S4*>(vel + 2 * stride + (size_t)g.lz(zb) * plane + (size_t)y * g.X + 4 * x4), 0);
 	float4 o;
 	o.x = 0.5f * ((-F.x + B.x) + ((-U.x + D.x) + (-L + cx.y)));
 	o.y = 0.5f * ((-F.y + B.y) + ((-U.y + D.y) + (-cx.x + cx.z)));
@@ -656,9 +661,9 @@ __global__ __launch_bounds__(256) void k_project(const Geom g, const SimParams s
 // pressure rows above / below / in front / behind, 16-B stores), the x neighbours of the pressure row through DPP lane shifts
 // like k_jacobi_v4, 32-bit offsets.  Per-cell arithmetic is k_project's; RCP: extents are powers of two and the three
 // coordinate divisions become multiplications by the exact reciprocal (bit-identical).
-template <bool RCP>
-__global__ __launch_bounds__(256) void k_project_v4(const Geom g, const float* __restrict__ vel_in, const float* __restrict__ p,
-	float* __restrict__ vel_out, int z_begin, int nzp, int remap, int rows_per_block, float rX, float rY, float rZ,
+template <bool RCP, bool HALF>
+__global__ __launch_bounds__(256) void k_project_v4(const Geom g, const typename Store<HALF>::S* __restrict__ vel_in, const float* __restrict__ p,
+	typename Store<HALF>::S* __restrict__ vel_out, int z_begin, int nzp, int remap, int rows_per_block, float rX, float rY, float rZ,
 	int* __restrict__ rec, float dt, int address, int digest, const unsigned* __restrict__ halo_overflow)
 {
 	const int X4 = g.X >> 2;
@@ -681,9 +686,11 @@ __global__ __launch_bounds__(256) void k_project_v4(const Geom g, const float* _
 	const float4 D = *reinterpret_cast<const float4*>(p + zrow + (uint32_t)yd * g.X + 4u * x4);
 	const float4 F = *reinterpret_cast<const float4*>(p + (uint32_t)g.lz(zf) * plane + (uint32_t)y * g.X + 4u * x4);
 	const float4 B = *reinterpret_cast<const float4*>(p + (uint32_t)g.lz(zb) * plane + (uint32_t)y * g.X + 4u * x4);
-	const float4 ux = *reinterpret_cast<const float4*>(vel_in + off);
-	const float4 uy = *reinterpret_cast<const float4*>(vel_in + stride + off);
-	const float4 uz = *reinterpret_cast<const float4*>(vel_in + 2u * stride + off);
+	typedef Store<HALF> St;
+	typedef typename St::S4 S4;
+	const float4 ux = St::ld4(reinterpret_cast<const S4*>(vel_in + off), 0);
+	const float4 uy = St::ld4(reinterpret_cast<const S4*>(vel_in + stride + off), 0);
+	const float4 uz = St::ld4(reinterpret_cast<const S4*>(vel_in + 2u * stride + off), 0);
 	const int wl = (int)((threadIdx.y * blockDim.x + threadIdx.x) & 63);
 	float L = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c.w), 0x138, 0xf, 0xf, false));
 	float R = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c.x), 0x130, 0xf, 0xf, false));
@@ -713,10 +720,12 @@ __global__ __launch_bounds__(256) void k_project_v4(const Geom g, const float* _
 		oy[i] = wy_ * ((0.0f < wy_ * py) ? fy : 1.0f);
 		oz[i] = wz_ * ((0.0f < wz_ * pz) ? fz : 1.0f);
 	}
-	*reinterpret_cast<float4*>(vel_out + off) = make_float4(ox[0], ox[1], ox[2], ox[3]);
-	*reinterpret_cast<float4*>(vel_out + stride + off) = make_float4(oy[0], oy[1], oy[2], oy[3]);
-	*reinterpret_cast<float4*>(vel_out + 2u * stride + off) = make_float4(oz[0], oz[1], oz[2], oz[3]);
+	St::st4(reinterpret_cast<S4*>(vel_out + off), 0, make_float4(ox[0], ox[1], ox[2], ox[3]));
+	St::st4(reinterpret_cast<S4*>(vel_out + stride + off), 0, make_float4(oy[0], oy[1], oy[2], oy[3]));
+	St::st4(reinterpret_cast<S4*>(vel_out + 2u * stride + off), 0, make_float4(oz[0], oz[1], oz[2], oz[3]));
 	if (rec) {
+#pragma unroll
+		for (int i = 0; i < 4; ++i) oz[i] = St::stored(oz[i]);           // the next advection reads what was STORED (fp16 storage: the binary16 value)
 		const float pzn = ((float)z + 0.5f) / (float)g.Zg;              // k_advect's pz (== * rZ for the power-of-two grids of the fast paths)
 		int lo = 0, hi = 0;
 #pragma unroll
@@ -877,12 +886,13 @@ hipError_t launch_advect(const Geom& g, const SimParams& sp, int half_store, con
 hipError_t launch_divergence(const Geom& g, int half_store, const void* vel, float* b, int z_begin, int z_end, hipStream_t s)
 {
 	if (z_end <= z_begin) return hipSuccess;
-	if (!half_store && g.Zg > 1 && (g.X & 3) == 0) {
+	if (g.Zg > 1 && (g.X & 3) == 0 && (g.cells_local() & 3) == 0) {
 		const int nzp = z_end - z_begin, X4 = g.X >> 2;
 		const int bx = X4 < 64 ? X4 : 64;
 		int by = 256 / bx; if (by > g.Y) by = g.Y;
 		const dim3 block(bx, by, 1), grid(((X4 + bx - 1) / bx) * ((g.Y + by - 1) / by) * nzp, 1, 1);
-		hipLaunchKernelGGL(k_divergence_v4, grid, block, 0, s, g, (const float*)vel, b, z_begin, nzp, xcd_remap_on(REMAP_DIV), by);
+		if (half_store) hipLaunchKernelGGL(k_divergence_v4<true>, grid, block, 0, s, g, (const h16*)vel, b, z_begin, nzp, xcd_remap_on(REMAP_DIV), by);
+		else hipLaunchKernelGGL(k_divergence_v4<false>, grid, block, 0, s, g, (const float*)vel, b, z_begin, nzp, xcd_remap_on(REMAP_DIV), by);
 		return hipGetLastError();
 	}
 	const dim3 grid = grid_xyz(g, z_end - z_begin), block(64, 4, 1);
@@ -1095,7 +1105,7 @@ hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, co
 	if (rec_done) *rec_done = false;
 	if (z_end <= z_begin) return hipSuccess;
 	static const int v4_on = env_int("FLUIDX_PROJECT_V4", 1);
-	if (v4_on && !half_store && sp.is3d && (g.X & 3) == 0 && g.cells_local() * 3 < ((size_t)1 << 30)) {
+	if (v4_on && sp.is3d && (g.X & 3) == 0 && (g.cells_local() & 3) == 0 && g.cells_local() * 3 < ((size_t)1 << 30)) {
 		auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
 		const int nzp = z_end - z_begin, X4 = g.X >> 2;
 		const int bx = X4 < 64 ? X4 : 64;
@@ -1109,12 +1119,12 @@ hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, co
 			if (e != hipSuccess) return e;
 			if (rec_done) *rec_done = true;
 		}
-		if (pow2(g.X) && pow2(g.Y) && pow2(g.Zg))
-			hipLaunchKernelGGL(k_project_v4<true>, grid, block, 0, s, g, (const float*)vel_in, p, (float*)vel_out, z_begin, nzp, xcd_remap_on(REMAP_PROJECT), by, rX, rY, rZ,
-				r, sp.dt, sp.address, digest, halo_overflow);
-		else
-			hipLaunchKernelGGL(k_project_v4<false>, grid, block, 0, s, g, (const float*)vel_in, p, (float*)vel_out, z_begin, nzp, xcd_remap_on(REMAP_PROJECT), by, rX, rY, rZ,
-				r, sp.dt, sp.address, digest, halo_overflow);
+		const bool rcp = pow2(g.X) && pow2(g.Y) && pow2(g.Zg);
+#define FX_PV4(RCP_, H_, T_) hipLaunchKernelGGL((k_project_v4<RCP_, H_>), grid, block, 0, s, g, (const T_*)vel_in, p, (T_*)vel_out, z_begin, nzp, \
+			xcd_remap_on(REMAP_PROJECT), by, rX, rY, rZ, r, sp.dt, sp.address, digest, halo_overflow)
+		if (half_store) { if (rcp) FX_PV4(true, true, h16); else FX_PV4(false, true, h16); }
+		else { if (rcp) FX_PV4(true, false, float); else FX_PV4(false, false, float); }
+#undef FX_PV4
 		return hipGetLastError();
 	}
 	const dim3 grid = grid_xyz(g, z_end - z_begin), block(64, 4, 1);
