@@ -49,9 +49,10 @@ def test_rank_processes_match_single_domain(nranks, dims, halo_j, storage, mock_
     assert leftovers == [], leftovers                    # every message consumed, every communicator directory removed
 
 
-@pytest.mark.parametrize("nranks", [2, 4])
-def test_bench_under_torchrun_shared_gpu(nranks, mock_lib, tmp_path):
-    r, _ = launch(nranks, [os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--grid", "64", "--steps", "3", "--warmup", "1",
+@pytest.mark.parametrize("nranks,steps", [(2, 3), (4, 3), (8, 9)])
+def test_bench_under_torchrun_shared_gpu(nranks, steps, mock_lib, tmp_path):
+    """(8 ranks, 9 steps: the driver's N = 8 launch shape -- (2G)^3 grid, 8-plane advection halo, marks on every fourth step)"""
+    r, _ = launch(nranks, [os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--grid", "64", "--steps", str(steps), "--warmup", "1",
                            "--shared-gpu"], mock_lib, tmp_path)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
