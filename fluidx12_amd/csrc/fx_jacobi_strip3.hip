@@ -107,6 +107,27 @@ constexpr int LDS_ROWS_PER_WAVE = 2 * LDS_P0_ROWS + 3 * LDS_B_ROWS;   // 38 rows
 // `global_load v, v_offset, s[base]` form
 __device__ __forceinline__ uint32_t opaque32(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 
+// The step counters of k_jacobi_strip3c's hand-overs live in the LDS and are polled / published with inline-assembly DS
+// instructions: as `volatile` C++ accesses they make the compiler put `s_waitcnt vmcnt(0)` in front of every poll, i.e. the wave
+// waits for its own prefetch (the next input plane, in flight since sweep 1) in the middle of the step.  A wave's LDS operations
+// execute in order, so "data rows, then counter" needs no fence; the asm's "memory" clobber keeps the compiler from moving the
+// rows' reads / writes across it.  (Measured neutral for k_jacobi_strip3c, 43.5 us either way, and WORSE for k_jacobi_strip3h --
+// 337 -> 359 us: its scalar seam loads share lgkmcnt with the DS poll -- which therefore keeps the volatile form.)
+__device__ __forceinline__ int lds_peek(uint32_t lds_byte_addr)
+{
+	int v;
+	asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_byte_addr) : "memory");
+	return v;
+}
+__device__ __forceinline__ void lds_post(uint32_t lds_byte_addr, int v)
+{
+	asm volatile("ds_write_b32 %0, %1" :: "v"(lds_byte_addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_wait_ge(uint32_t lds_byte_addr, int v)
+{
+	while (lds_peek(lds_byte_addr) < v) __builtin_amdgcn_s_sleep(1);
+}
+
 // row `r` of an LDS slot whose first row starts `slot` float4s into the wave's slice
 #define FX_LDS(slot, r) lds[(slot) + (r) * 64]
 
@@ -481,15 +502,6 @@ constexpr int C_ROWS_PER_WAVE = 2 * C_P0_ROWS + 3 * C_B_ROWS;     // 34 rows of 
 			_Pragma("unroll") for (int j = 0; j < C_B_ROWS; ++j) P1[CTR][j] = P1[NEW][j]; \
 		} \
 	} \
-	/* hand-over 1 (level-1 edge rows).  Order: wait until the partner has published its step q-1, READ its row, only then publish \
-	   mine and my counter -- a wave that sees my counter at q knows I have already read what it wrote two steps ago into the slot \
-	   it is about to reuse, so two slots (step parity) suffice; and a wave may run a whole step ahead of its partner */ \
-	while (*reinterpret_cast<volatile int*>(xflag + (wave ^ 1)) < q - 1) __builtin_amdgcn_s_sleep(1); \
-	asm volatile("" ::: "memory"); \
-	const float4 H1_ = xbuf[((((q - 1) & 1) * 4 + (wave ^ 1)) * 2 + 0) * 64 + lane];           /* partner's level 1, plane q-2 */ \
-	xbuf[(((q & 1) * 4 + wave) * 2 + 0) * 64 + lane] = (UP) ? P1[NEW][C_B_ROWS - 1] : P1[NEW][0];   /* mine, plane q-1 */ \
-	asm volatile("" ::: "memory"); \
-	if (lane == 0) *reinterpret_cast<volatile int*>(xflag + wave) = q;   /* LDS operations of a wave execute in order */ \
 	float4 B2_[R3 + 1], B3_[R3]; \
 	_Pragma("unroll") for (int k = 0; k < R3 + 1; ++k) B2_[k] = FX_LDS(s_b2, (UP) ? k + 1 : k);        /* b[q-2], rows of level 2 */ \
 	_Pragma("unroll") for (int m = 0; m < R3; ++m) B3_[m] = FX_LDS(s_b3, (UP) ? m + 2 : m);            /* b[q-3], output rows */ \
@@ -505,6 +517,14 @@ constexpr int C_ROWS_PER_WAVE = 2 * C_P0_ROWS + 3 * C_B_ROWS;     // 34 rows of 
 		const char* bb_ = reinterpret_cast<const char*>(b + (size_t)g.lz(q) * plane); \
 		_Pragma("unroll") for (int i = 0; i < C_B_ROWS; ++i) NB[i] = *reinterpret_cast<const float4*>(bb_ + opaque32(roff[i + 1])); \
 	} \
+	/* hand-over 1 (level-1 edge rows), BEHIND the prefetch issue: a wait here must not delay the loads.  Order: wait until the \
+	   partner has published its step q-1, READ its row, only then publish \
+	   mine and my counter -- a wave that sees my counter at q knows I have already read what it wrote two steps ago into the slot \
+	   it is about to reuse, so two slots (step parity) suffice; and a wave may run a whole step ahead of its partner */ \
+	lds_wait_ge(xf_partner, q - 1); \
+	const float4 H1_ = xbuf[((((q - 1) & 1) * 4 + (wave ^ 1)) * 2 + 0) * 64 + lane];           /* partner's level 1, plane q-2 */ \
+	xbuf[(((q & 1) * 4 + wave) * 2 + 0) * 64 + lane] = (UP) ? P1[NEW][C_B_ROWS - 1] : P1[NEW][0];   /* mine, plane q-1 */ \
+	if (lane == 0) lds_post(xf_mine, q);                               /* LDS operations of a wave execute in order */ \
 	/* ---- sweep 2: level-2 plane q-2 ------------------------------------------------------------------------------- */ \
 	if (q - 2 == g.Zg) { \
 		_Pragma("unroll") for (int k = 0; k < R3 + 1; ++k) P2[NEW][k] = P2[CTR][k]; \
@@ -523,12 +543,10 @@ constexpr int C_ROWS_PER_WAVE = 2 * C_P0_ROWS + 3 * C_B_ROWS;     // 34 rows of 
 		} \
 	} \
 	/* hand-over 2 (level-2 edge rows), same order */ \
-	while (*reinterpret_cast<volatile int*>(xflag + 4 + (wave ^ 1)) < q - 1) __builtin_amdgcn_s_sleep(1); \
-	asm volatile("" ::: "memory"); \
+	lds_wait_ge(xf_partner + 16, q - 1); \
 	const float4 H2_ = xbuf[((((q - 1) & 1) * 4 + (wave ^ 1)) * 2 + 1) * 64 + lane];           /* partner's level 2, plane q-3 */ \
 	xbuf[(((q & 1) * 4 + wave) * 2 + 1) * 64 + lane] = (UP) ? P2[NEW][R3] : P2[NEW][0];              /* mine, plane q-2 */ \
-	asm volatile("" ::: "memory"); \
-	if (lane == 0) *reinterpret_cast<volatile int*>(xflag + 4 + wave) = q; \
+	if (lane == 0) lds_post(xf_mine + 16, q); \
 	/* ---- sweep 3: output plane q-3 ------------------------------------------------------------------------------- */ \
 	if (q - 3 >= zb && q - 3 < ze) { \
 		char* ob_ = reinterpret_cast<char*>(p_out + (size_t)g.lz(q - 3) * plane); \
@@ -593,6 +611,8 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip3c(const Geom g, const f
 	}
 	if (threadIdx.x < 8) xflag[threadIdx.x] = qs - 1;                 // the waves of a workgroup share the chunk, hence qs
 	__syncthreads();
+	const uint32_t xf0 = (uint32_t)(size_t)(__attribute__((address_space(3))) int*)xflag;      // LDS byte address of the counters
+	const uint32_t xf_mine = xf0 + 4u * (uint32_t)wave, xf_partner = xf0 + 4u * (uint32_t)(wave ^ 1);
 	int q = qs;
 	if (up) {
 		for (;;) {

@@ -2,8 +2,12 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/r02n; mkdir -p $O
-python -m pytest tests -m gpu -x -q -k "large_grids or temporal_blocking or full_size or thick" > $O/pytest.txt 2>&1; tail -2 $O/pytest.txt
-for c in 1 0 1 0; do FLUIDX_STRIP3_COOP=$c python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-render 2>> $O/bench.err | python -c "
+python -m pytest tests -m gpu -x -q -k "large_grids or temporal_blocking or full_size or thick or x512 or wide_strips or config4" > $O/pytest.txt 2>&1; tail -2 $O/pytest.txt
+for c in 1 0 1; do FLUIDX_STRIP3_COOP=$c python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-render 2>> $O/bench.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('coop $c', '%.4g'%d['value'], '%.4f ms'%d['ms_per_step'], {k:round(v,4) for k,v in d['stage_ms_per_step'].items()}, 'launch us %.2f'%d['roofline']['avg_launch_us'])"; done
+python bench.py --config 4 --steps 8 --warmup 2 --no-cpu-baseline --no-render 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('512^3/80', '%.4g'%d['value'], '%.4f ms'%d['ms_per_step'], {k:round(v,4) for k,v in d['stage_ms_per_step'].items()}, 'launch us %.2f'%d['roofline']['avg_launch_us'])"
