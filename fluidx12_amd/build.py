@@ -29,7 +29,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # (occupancy-driven) strategy has nothing to win there; "max-ilp" orders for instruction-level parallelism instead
 # (k_jacobi_strip3 44.4 -> 43.6 us per launch; "max-memory-clause" 43.8, "iterative-ilp" 48.5).  Scheduling only: results are
 # bit-identical (tests/test_gpu_sim.py).
-EXTRA_FLAGS = {"fx_jacobi_strip3.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+EXTRA_FLAGS = {"fx_jacobi_strip3.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] + (["-DFX_STRIP3C_ROWS=" + os.environ["FLUIDX_BUILD_STRIP3C_ROWS"]] if os.environ.get("FLUIDX_BUILD_STRIP3C_ROWS") else []),
                "fx_jacobi_strip.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}     # 256x256x64: 8.9 -> 8.1 us per sweep; 512x512x64: 19.0 -> 18.8
 
 

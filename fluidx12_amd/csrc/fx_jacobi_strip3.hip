@@ -480,8 +480,13 @@ __global__ __launch_bounds__(64 * WPG, 4 / WPG) void k_jacobi_strip3h(const Geom
 // Row indices (top to bottom): input i <-> y = yb + i (8 rows, yb = y0 - 3 | y0 - 1), level 1 j <-> yb + 1 + j (6 rows),
 // level 2 k <-> y0 - 1 + k | y0 + k (5 rows), output m <-> y0 + m.
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int C_P0_ROWS = R3 + 4;           // input rows per plane
-constexpr int C_B_ROWS = R3 + 2;            // b rows per plane (= level-1 rows)
+#ifndef FX_STRIP3C_ROWS
+#define FX_STRIP3C_ROWS 4
+#endif
+constexpr int RC = FX_STRIP3C_ROWS;          // output rows per strip of the cooperative kernel.  2 rows (FLUIDX_BUILD_STRIP3C_ROWS=2: 128 strips x 8
+                                             // chunks of 32 planes, 226 instead of 249 MB of traffic per launch) measured 47.6-48.0 us per launch against 43.5 for 4
+constexpr int C_P0_ROWS = RC + 4;           // input rows per plane
+constexpr int C_B_ROWS = RC + 2;            // b rows per plane (= level-1 rows)
 constexpr int C_ROWS_PER_WAVE = 2 * C_P0_ROWS + 3 * C_B_ROWS;     // 34 rows of 1 KiB
 
 #define FX_STRIP3C_STEP(PH, UP) do { \
@@ -502,9 +507,9 @@ constexpr int C_ROWS_PER_WAVE = 2 * C_P0_ROWS + 3 * C_B_ROWS;     // 34 rows of 
 			_Pragma("unroll") for (int j = 0; j < C_B_ROWS; ++j) P1[CTR][j] = P1[NEW][j]; \
 		} \
 	} \
-	float4 B2_[R3 + 1], B3_[R3]; \
-	_Pragma("unroll") for (int k = 0; k < R3 + 1; ++k) B2_[k] = FX_LDS(s_b2, (UP) ? k + 1 : k);        /* b[q-2], rows of level 2 */ \
-	_Pragma("unroll") for (int m = 0; m < R3; ++m) B3_[m] = FX_LDS(s_b3, (UP) ? m + 2 : m);            /* b[q-3], output rows */ \
+	float4 B2_[RC + 1], B3_[RC]; \
+	_Pragma("unroll") for (int k = 0; k < RC + 1; ++k) B2_[k] = FX_LDS(s_b2, (UP) ? k + 1 : k);        /* b[q-2], rows of level 2 */ \
+	_Pragma("unroll") for (int m = 0; m < RC; ++m) B3_[m] = FX_LDS(s_b3, (UP) ? m + 2 : m);            /* b[q-3], output rows */ \
 	_Pragma("unroll") for (int i = 0; i < C_P0_ROWS; ++i) FX_LDS(s_old, i) = NP[i]; \
 	_Pragma("unroll") for (int i = 0; i < C_B_ROWS; ++i) FX_LDS(s_bfree, i) = NB[i]; \
 	{ const int t_ = s_old; s_old = s_ctr; s_ctr = t_; } \
@@ -527,36 +532,36 @@ constexpr int C_ROWS_PER_WAVE = 2 * C_P0_ROWS + 3 * C_B_ROWS;     // 34 rows of 
 	if (lane == 0) lds_post(xf_mine, q);                               /* LDS operations of a wave execute in order */ \
 	/* ---- sweep 2: level-2 plane q-2 ------------------------------------------------------------------------------- */ \
 	if (q - 2 == g.Zg) { \
-		_Pragma("unroll") for (int k = 0; k < R3 + 1; ++k) P2[NEW][k] = P2[CTR][k]; \
+		_Pragma("unroll") for (int k = 0; k < RC + 1; ++k) P2[NEW][k] = P2[CTR][k]; \
 	} else { \
-		_Pragma("unroll") for (int k = 0; k < R3 + 1; ++k) { \
+		_Pragma("unroll") for (int k = 0; k < RC + 1; ++k) { \
 			const int jc_ = (UP) ? k + 1 : k;                            /* level-1 index of this row */ \
 			const float4 c_ = P1[CTR][jc_]; \
 			float4 u_ = jc_ >= 1 ? P1[CTR][jc_ >= 1 ? jc_ - 1 : 0] : H1_; \
 			float4 d_ = jc_ + 1 < C_B_ROWS ? P1[CTR][jc_ + 1 < C_B_ROWS ? jc_ + 1 : 0] : H1_; \
 			if ((UP) && k == 1 && y0 == 0) u_ = c_;                       /* rows outside the domain hold no data */ \
-			if (!(UP) && k == R3 - 1 && y0 + R3 >= g.Y) d_ = c_; \
+			if (!(UP) && k == RC - 1 && y0 + RC >= g.Y) d_ = c_; \
 			P2[NEW][k] = relax4(c_, u_, d_, P1[OLD][jc_], P1[NEW][jc_], B2_[k], false, false); \
 		} \
 		if (q - 2 == 0) { \
-			_Pragma("unroll") for (int k = 0; k < R3 + 1; ++k) P2[CTR][k] = P2[NEW][k]; \
+			_Pragma("unroll") for (int k = 0; k < RC + 1; ++k) P2[CTR][k] = P2[NEW][k]; \
 		} \
 	} \
 	/* hand-over 2 (level-2 edge rows), same order */ \
 	lds_wait_ge(xf_partner + 16, q - 1); \
 	const float4 H2_ = xbuf[((((q - 1) & 1) * 4 + (wave ^ 1)) * 2 + 1) * 64 + lane];           /* partner's level 2, plane q-3 */ \
-	xbuf[(((q & 1) * 4 + wave) * 2 + 1) * 64 + lane] = (UP) ? P2[NEW][R3] : P2[NEW][0];              /* mine, plane q-2 */ \
+	xbuf[(((q & 1) * 4 + wave) * 2 + 1) * 64 + lane] = (UP) ? P2[NEW][RC] : P2[NEW][0];              /* mine, plane q-2 */ \
 	if (lane == 0) lds_post(xf_mine + 16, q); \
 	/* ---- sweep 3: output plane q-3 ------------------------------------------------------------------------------- */ \
 	if (q - 3 >= zb && q - 3 < ze) { \
 		char* ob_ = reinterpret_cast<char*>(p_out + (size_t)g.lz(q - 3) * plane); \
-		_Pragma("unroll") for (int m = 0; m < R3; ++m) { \
+		_Pragma("unroll") for (int m = 0; m < RC; ++m) { \
 			const int kc_ = (UP) ? m + 1 : m;                            /* level-2 index of this row */ \
 			const float4 c_ = P2[CTR][kc_]; \
 			float4 u_ = kc_ >= 1 ? P2[CTR][kc_ >= 1 ? kc_ - 1 : 0] : H2_; \
-			float4 d_ = kc_ + 1 < R3 + 1 ? P2[CTR][kc_ + 1 < R3 + 1 ? kc_ + 1 : 0] : H2_; \
+			float4 d_ = kc_ + 1 < RC + 1 ? P2[CTR][kc_ + 1 < RC + 1 ? kc_ + 1 : 0] : H2_; \
 			if ((UP) && m == 0 && y0 == 0) u_ = c_; \
-			if (!(UP) && m == R3 - 1 && y0 + R3 >= g.Y) d_ = c_; \
+			if (!(UP) && m == RC - 1 && y0 + RC >= g.Y) d_ = c_; \
 			const float4 x_ = relax4(c_, u_, d_, P2[OLD][kc_], P2[NEW][kc_], B3_[m], false, false); \
 			if (strip_live) *reinterpret_cast<float4*>(ob_ + opaque32(roff[(UP) ? m + 3 : m + 1])) = x_; \
 		} \
@@ -573,7 +578,7 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip3c(const Geom g, const f
 	float4* lds = lds_all + wave * (C_ROWS_PER_WAVE * 64) + lane;
 	const int tile = xcd_index3(ngroups * nchunks, remap);
 	const int grp = tile % ngroups, chunk = tile / ngroups;
-	const int y0 = (grp * 4 + wave) * R3;                             // (Y % 8 == 0: both strips of every pair exist)
+	const int y0 = (grp * 4 + wave) * RC;                             // (Y % 8 == 0: both strips of every pair exist)
 	const bool up = (wave & 1) == 0;
 	const bool strip_live = y0 < g.Y;                                 // Y % 16 == 8: the last workgroup's second pair lies outside (computes, never stores)
 	const int yb = up ? y0 - 3 : y0 - 1;
@@ -589,14 +594,14 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip3c(const Geom g, const f
 	int s_ctr = 0, s_old = C_P0_ROWS * 64;
 	int s_b2 = 2 * C_P0_ROWS * 64, s_b3 = s_b2 + C_B_ROWS * 64, s_bfree = s_b3 + C_B_ROWS * 64;
 
-	float4 P1[3][C_B_ROWS], P2[3][R3 + 1], NP[C_P0_ROWS], NB[C_B_ROWS];
+	float4 P1[3][C_B_ROWS], P2[3][RC + 1], NP[C_P0_ROWS], NB[C_B_ROWS];
 	const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
 	for (int k = 0; k < 3; ++k) {
 #pragma unroll
 		for (int i = 0; i < C_B_ROWS; ++i) P1[k][i] = zero;
 #pragma unroll
-		for (int i = 0; i < R3 + 1; ++i) P2[k][i] = zero;
+		for (int i = 0; i < RC + 1; ++i) P2[k][i] = zero;
 	}
 #pragma unroll
 	for (int i = 0; i < C_ROWS_PER_WAVE; ++i) lds[i * 64] = zero;
@@ -654,7 +659,9 @@ hipError_t launch_jacobi_strip3(const Geom& g, const float* p_in, const float* b
 	const int forced_chunk = ce && *ce ? atoi(ce) : 0;
 	const int remap = re && *re ? atoi(re) : 1;
 	const bool halves = g.X == 512;                                     // two half-row waves per strip (k_jacobi_strip3h)
-	const int nstrips = (g.Y / R3) * (halves ? 2 : 1);
+	static const int coop = [] { const char* e = getenv("FLUIDX_STRIP3_COOP"); return e && *e ? atoi(e) : 1; }();
+	const bool use_coop = !halves && coop && (g.Y % (2 * RC)) == 0;
+	const int nstrips = use_coop ? g.Y / RC : (g.Y / R3) * (halves ? 2 : 1);
 	static const int pair_wg = [] { const char* e = getenv("FLUIDX_STRIP3H_PAIRS"); return e ? atoi(e) : 0; }();
 	const int wpg = halves && pair_wg ? 2 : 4;                          // X = 512: a workgroup = one pair of half-row waves (its barrier syncs only them)
 	const int ngroups = (nstrips + wpg - 1) / wpg;                      // waves (strips) per workgroup
@@ -668,8 +675,7 @@ hipError_t launch_jacobi_strip3(const Geom& g, const float* p_in, const float* b
 	else if (halves) hipLaunchKernelGGL(k_jacobi_strip3h<4>, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
 	else {
 		// cooperative pairs (k_jacobi_strip3c) where every workgroup holds whole pairs; FLUIDX_STRIP3_COOP=0: every strip on its own
-		static const int coop = [] { const char* e = getenv("FLUIDX_STRIP3_COOP"); return e && *e ? atoi(e) : 1; }();
-		if (coop && (g.Y & 7) == 0)
+		if (use_coop)
 			hipLaunchKernelGGL(k_jacobi_strip3c, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
 		else
 			hipLaunchKernelGGL(k_jacobi_strip3, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
