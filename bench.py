@@ -81,6 +81,21 @@ def limiter_note(kernel):
     return note
 
 
+def step_traffic(grid, iters, storage):
+    """fabric bytes ONE step moves, summed over its kernels from the newest committed PMC summary of this workload (the summary was
+    taken with `bench.py --steps 4 --warmup 1`: every kernel's dispatch count / 5 = launches per step).  None if no summary matches."""
+    import glob
+    best = None
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json"))):
+        try:
+            d = json.load(open(fn))
+        except Exception:
+            continue
+        if (d.get("grid"), d.get("iters"), d.get("storage")) == (grid, iters, storage) and d.get("kernels"):
+            best = (sum(k["traffic"] * k["dispatches"] / 5.0 for k in d["kernels"].values()), os.path.basename(fn))
+    return best
+
+
 def workload_grid(G, N, scaling):
     """Grid of the N-rank run.  strong: the same G^3 for every N.  weak (default): 16.8 M voxels per GPU at G = 256.  N = 2 and 4
     stack G^3 blocks along z (G x G x 2G, G x G x 4G): every rank owns exactly the single-GPU problem, the textbook weak-scaling
@@ -510,6 +525,11 @@ def main():
                                         for k in ("advect", "divergence", "jacobi", "project", "exchange")}
             sb = step_bytes_per_voxel(args.iters, args.storage) * float(GX) * GY * GZ
             out["step_algorithmic_GBps"] = sb / (elapsed / args.steps) / 1e9
+            st = step_traffic(G, args.iters, args.storage) if N == 1 else None
+            if st:
+                # the whole step against the fabric: measured bytes of all its launches (PMC, committed summary) / measured time
+                out["step_fabric_traffic"] = {"bytes_per_step": st[0], "GBps": st[0] / (elapsed / args.steps) / 1e9,
+                                              "frac_of_peak": st[0] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, "source": st[1]}
         if roof is not None:
             out["roofline"] = roof
         if render is not None:
