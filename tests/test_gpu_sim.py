@@ -415,3 +415,37 @@ def test_advect_lds_path_bit_identical(dims, address, scale, storage, monkeypatc
     z, y, x = np.meshgrid(np.arange(Z), np.arange(Y), np.arange(X), indexing="ij", sparse=True)
     far = ((x + .5) / X - .5) ** 2 + ((y + .5) / Y - .1) ** 2 + ((z + .5) / Z - .5) ** 2 > (1.5 / 16) ** 2
     assert np.array_equal(got["1"][0][:, far], vo[:, far]) and np.array_equal(got["1"][1][far], co[far])
+
+
+@pytest.mark.parametrize("grid,steps,storage", [(256, 40, "fp32"), (128, 60, "fp32"), (256, 24, "fp16")])
+def test_round2_kernels_reproduce_the_round1_kernels_over_a_whole_run(grid, steps, storage):
+    """the kernels added in round 2 (LDS-staged advection, cooperative three-sweep strips, the X = 128 block kernel, four-cell
+    projection / divergence) against the ones they replaced, over a whole run from the zero state at full BASELINE size: the plume
+    develops, waves fall off the LDS window, the schedule mixes threes and twos -- and every field ends bit-identical.  (The
+    switches are read once per process, hence the child processes.)"""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, hashlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import fluidx12_amd as fx\n"
+        "f = fx.Fluid(); assert f.Init(64, 64, (%d, %d, %d), jacobi_iters=40, storage=%r)\n"
+        "dt = np.float32(f.default_time_step())\n"
+        "for k in range(%d):\n"
+        "    f.UpdateFrame(dt, k %% 3); f.Simulate(k %% 3)\n"
+        "f.Synchronize()\n"
+        "h = hashlib.sha256()\n"
+        "for fid in (fx.FIELD_VELOCITY, fx.FIELD_COLOR, fx.FIELD_PRESSURE):\n"
+        "    a = f.download(fid); assert np.isfinite(a).all() and a.any(); h.update(a.tobytes())\n"
+        "print('DIGEST', h.hexdigest())\n" % (root, grid, grid, grid, storage, steps))
+    old = dict(FLUIDX_ADVECT_LDS="0", FLUIDX_STRIP3_COOP="0", FLUIDX_JACOBI_BLOCK="0", FLUIDX_PROJECT_V4="0")
+    digests = []
+    for extra in ({}, old):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1]
