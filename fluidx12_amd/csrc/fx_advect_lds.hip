@@ -28,13 +28,15 @@ namespace fx {
 
 namespace {
 
-constexpr int TX = 64, TY = 8;                    // voxels per workgroup and plane
-constexpr int HX = TX + 2, HY = TY + 2;           // staged cells per plane
-constexpr int NCELL = HX * HY;                    // 660
-constexpr int VEL_BYTES = NCELL * 4;              // 2640 per component (fp16 storage: the half sits zero-extended in a dword -- a 2-byte LDS-DMA load writes a dword per lane, tools/micro/ldslds2.cpp)
+constexpr int TX = 64;                            // voxels per workgroup and plane: TX x TY (TY = 8 rows, one per wave; 16 as an experiment)
+constexpr int HX = TX + 2;                        // staged cells per row
 constexpr int NSLOT = 4;
-// colour bytes per staged cell and per slot: fp32 = one float4 per cell; fp16 = two dword planes (r|g, b|a) -- there is no 8-byte LDS-DMA
-template <bool HALF> struct Lay {
+// staged cells per plane, bytes per velocity component (fp16 storage: the half sits zero-extended in a dword -- a 2-byte LDS-DMA load
+// writes a dword per lane, tools/micro/ldslds2.cpp), colour bytes per slot: fp32 = one float4 per cell; fp16 = two dword planes
+// (r|g, b|a) -- there is no 8-byte LDS-DMA
+template <bool HALF, int TY> struct Lay {
+	static constexpr int NCELL = HX * (TY + 2);                                  // 660 (TY = 8)
+	static constexpr int VEL_BYTES = NCELL * 4;                                  // 2640
 	static constexpr int COL_BYTES = HALF ? 2 * NCELL * 4 : NCELL * 16;          // 5280 | 10560
 	static constexpr int SLOT_BYTES = COL_BYTES + 3 * VEL_BYTES;                 // 13200 | 18480 (multiples of 16)
 };
@@ -68,6 +70,7 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // LDS offsets are wave-uniform (SGPRs).  Inline assembly on purpose: through the builtin the compiler knows the LDS is being
 // written and puts `s_waitcnt vmcnt(0)` in front of the next ds_read -- every tap read of plane z would then wait for plane
 // z + 2, which has the whole iteration to land.  The workgroup barrier (after an explicit vmcnt(0)) is what orders the ring.
+template <int VEL_BYTES>
 __device__ __forceinline__ void stage64(const void* col, const void* v0, const void* v1, const void* v2, uint32_t lds_col, uint32_t lds_vel)
 {
 	uint32_t keep;
@@ -93,6 +96,7 @@ __device__ __forceinline__ void stage64(const void* col, const void* v0, const v
 }
 
 // fp16 storage: colour texel = 8 bytes -> its two dwords to two LDS planes NCELL * 4 bytes apart; a velocity half -> a dword per lane
+template <int VEL_BYTES>
 __device__ __forceinline__ void stage64h(const void* col, const void* v0, const void* v1, const void* v2, uint32_t lds_col, uint32_t lds_vel)
 {
 	uint32_t keep;
@@ -131,8 +135,8 @@ __device__ __forceinline__ T ldg32(const void* base, uint32_t byte_off)
 
 // HALF: fp16 storage of velocity / colour (BASELINE configs[4], the reference's RGBA16F): arithmetic unchanged (fp32), half the HBM
 // bytes, 13.2 instead of 18.5 KB per slot
-template <bool HALF>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_advect_lds(const Geom g, const SimParams sp,
+template <bool HALF, int TY>
+__global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_advect_lds(const Geom g, const SimParams sp,
 	const void* __restrict__ vel_in, const void* __restrict__ col_in, void* __restrict__ vel_out, void* __restrict__ col_out,
 	int z_begin, int nzp, int zchunk, int nchunks, unsigned* halo_overflow, float rX, float rY, float rZ, float inv_rr,
 	int lgX, int lgY, int lg_gx, int lg_gy, int dbg)
@@ -149,12 +153,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 		tl = xcd * q + min(xcd, r) + j;
 	}
 	const int tx = tl & ((1 << lg_gx) - 1), ty = (tl >> lg_gx) & ((1 << lg_gy) - 1), chunk = tl >> (lg_gx + lg_gy);
-	const int x0t = tx << 6, y0t = ty << 3;
+	const int x0t = tx << 6, y0t = ty * TY;
 	const int zb = z_begin + chunk * zchunk, ze = min(zb + zchunk, z_begin + nzp);
 	if (zb >= ze) return;                                        // uniform for the workgroup
 
 	const int lgP = lgX + lgY;
-	constexpr int COL_BYTES = Lay<HALF>::COL_BYTES, SLOT_BYTES = Lay<HALF>::SLOT_BYTES;
+	constexpr int COL_BYTES = Lay<HALF, TY>::COL_BYTES, SLOT_BYTES = Lay<HALF, TY>::SLOT_BYTES;
+	constexpr int NCELL = Lay<HALF, TY>::NCELL, VEL_BYTES = Lay<HALF, TY>::VEL_BYTES, NT = 64 * TY;
 	constexpr uint32_t ES = HALF ? 2 : 4, CS = HALF ? 8 : 16;    // bytes per velocity element / colour texel in HBM
 	const uint32_t stride = (uint32_t)g.nzl() << lgP;           // cells between velocity component planes
 	const char* v0 = reinterpret_cast<const char*>(vel_in);
@@ -168,12 +173,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 		const int c = tid, r = c / HX, cc = c - r * HX;
 		src_a = ((uint32_t)addr_tap(y0t - 1 + r, g.Y, sp.address) << lgX) + (uint32_t)addr_tap(x0t - 1 + cc, g.X, sp.address);
 	}
-	const bool has_b = 512 + tid < NCELL;
+	const bool has_b = NT + tid < NCELL;
 	if (has_b) {
-		const int c = 512 + tid, r = c / HX, cc = c - r * HX;
+		const int c = NT + tid, r = c / HX, cc = c - r * HX;
 		src_b = ((uint32_t)addr_tap(y0t - 1 + r, g.Y, sp.address) << lgX) + (uint32_t)addr_tap(x0t - 1 + cc, g.X, sp.address);
 	}
-	const bool wave_has_b = 512 + wave * 64 < NCELL;             // waves 0, 1, 2
+	const bool wave_has_b = NT + wave * 64 < NCELL;              // waves 0, 1, 2
 
 	// stage global plane zq (unclamped; may be -1 or Zg, or beyond what this slab holds) into its ring slot
 	const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds;
@@ -183,18 +188,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 		const uint32_t slot = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(((zq + 4) & 3) * SLOT_BYTES));
 		{
 			const size_t cell = pz + src_a;
-			if (HALF) stage64h(reinterpret_cast<const char*>(col_in) + cell * CS, v0 + cell * ES, v1 + cell * ES, v2 + cell * ES,
+			if (HALF) stage64h<VEL_BYTES>(reinterpret_cast<const char*>(col_in) + cell * CS, v0 + cell * ES, v1 + cell * ES, v2 + cell * ES,
 				slot + (uint32_t)wave * (64 * 4), slot + COL_BYTES + (uint32_t)wave * (64 * 4));
-			else stage64(reinterpret_cast<const char*>(col_in) + cell * CS, v0 + cell * ES, v1 + cell * ES, v2 + cell * ES,
+			else stage64<VEL_BYTES>(reinterpret_cast<const char*>(col_in) + cell * CS, v0 + cell * ES, v1 + cell * ES, v2 + cell * ES,
 				slot + (uint32_t)wave * (64 * 16), slot + COL_BYTES + (uint32_t)wave * (64 * 4));
 		}
 		if (wave_has_b) {
 			if (has_b) {
 				const size_t cell = pz + src_b;
-				if (HALF) stage64h(reinterpret_cast<const char*>(col_in) + cell * CS, v0 + cell * ES, v1 + cell * ES, v2 + cell * ES,
-					slot + (512 + (uint32_t)wave * 64) * 4, slot + COL_BYTES + (512 + (uint32_t)wave * 64) * 4);
-				else stage64(reinterpret_cast<const char*>(col_in) + cell * CS, v0 + cell * ES, v1 + cell * ES, v2 + cell * ES,
-					slot + (512 + (uint32_t)wave * 64) * 16, slot + COL_BYTES + (512 + (uint32_t)wave * 64) * 4);
+				if (HALF) stage64h<VEL_BYTES>(reinterpret_cast<const char*>(col_in) + cell * CS, v0 + cell * ES, v1 + cell * ES, v2 + cell * ES,
+					slot + (NT + (uint32_t)wave * 64) * 4, slot + COL_BYTES + (NT + (uint32_t)wave * 64) * 4);
+				else stage64<VEL_BYTES>(reinterpret_cast<const char*>(col_in) + cell * CS, v0 + cell * ES, v1 + cell * ES, v2 + cell * ES,
+					slot + (NT + (uint32_t)wave * 64) * 16, slot + COL_BYTES + (NT + (uint32_t)wave * 64) * 4);
 			}
 		}
 	};
@@ -367,6 +372,9 @@ hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store,
 {
 	auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
 	const int nzp = z_end - z_begin;
+	// rows per workgroup tile.  16 (one 1024-thread workgroup per CU, 1.16 x instead of 1.29 x border) measured 0.228 / 0.269 ms against
+	// 0.223 / 0.263 for 8 (256^3, states of step 25 / 110): the bytes it saves it loses to the single workgroup's barrier stalls
+	static const int TY = env_i("FLUIDX_ADVECT_TILE_ROWS", 8) == 16 ? 16 : 8;
 	if (g.Zg <= 1 || !pow2(g.X) || !pow2(g.Y) || !pow2(g.Zg) || g.X < TX || g.Y < TY || nzp < 12 ||
 		(!force && (size_t)g.X * g.Y * (size_t)nzp < ((size_t)1 << 22)) ||     // 128^3: 0.032-0.040 ms against 0.030 for k_advect_fast -- too few workgroups
 		g.cells_local() * 16 >= ((size_t)1 << 32))
@@ -383,20 +391,16 @@ hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store,
 	if (zchunk < 4) zchunk = 4;
 	if (zchunk > nzp) zchunk = nzp;
 	const int nchunks = (nzp + zchunk - 1) / zchunk;
-	static bool attr_set = false;
-	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_advect_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * Lay<false>::SLOT_BYTES);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_advect_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * Lay<true>::SLOT_BYTES);
-		attr_set = true;
-	}
 	const float rX = 1.0f / (float)g.X, rY = 1.0f / (float)g.Y, rZ = 1.0f / (float)g.Zg, inv_rr = sp.is3d ? 256.0f : 1024.0f;
 	const int dbg = env_i("FLUIDX_ADVECT_DBG", 0);
-	if (half_store)
-		hipLaunchKernelGGL(k_advect_lds<true>, dim3(tiles_xy * nchunks), dim3(512), NSLOT * Lay<true>::SLOT_BYTES, s, g, sp, vel_in, col_in, vel_out, col_out,
-			z_begin, nzp, zchunk, nchunks, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY, lg_gx, lg_gy, dbg);
-	else
-		hipLaunchKernelGGL(k_advect_lds<false>, dim3(tiles_xy * nchunks), dim3(512), NSLOT * Lay<false>::SLOT_BYTES, s, g, sp, vel_in, col_in, vel_out, col_out,
-			z_begin, nzp, zchunk, nchunks, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY, lg_gx, lg_gy, dbg);
+#define FX_ADV(H_, TY_) do { \
+		static bool attr_set = false; \
+		if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_advect_lds<H_, TY_>), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * Lay<H_, TY_>::SLOT_BYTES); attr_set = true; } \
+		hipLaunchKernelGGL((k_advect_lds<H_, TY_>), dim3(tiles_xy * nchunks), dim3(64 * TY_), (NSLOT * Lay<H_, TY_>::SLOT_BYTES), s, g, sp, vel_in, col_in, vel_out, col_out, \
+			z_begin, nzp, zchunk, nchunks, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY, lg_gx, lg_gy, dbg); } while (0)
+	if (TY == 16) { if (half_store) FX_ADV(true, 16); else FX_ADV(false, 16); }
+	else { if (half_store) FX_ADV(true, 8); else FX_ADV(false, 8); }
+#undef FX_ADV
 	return hipGetLastError();
 }
 
