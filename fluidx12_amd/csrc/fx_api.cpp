@@ -1376,6 +1376,7 @@ static int make_comm_stream(fx_comm_group* g, int device)
 static int make_step_record(fx_ctx* ctx, int nrec, bool gathered)
 {
 	DeviceGuard dg(ctx->device);
+	if (ctx->step_rec) return FX_OK;
 	FX_HIP(hipMalloc((void**)&ctx->step_rec, 4 * sizeof(int)));
 	FX_HIP(hipMemset(ctx->step_rec, 0, 4 * sizeof(int)));
 	if (gathered) FX_HIP(hipMalloc((void**)&ctx->gath_dev, 4 * sizeof(int) * (size_t)nrec));
@@ -1416,7 +1417,7 @@ int fx_comm_init_rank(fx_ctx* ctx, const void* id, size_t bytes, int rank, int n
 			return FX_E_INVALID;
 		}
 	}
-	if ((rc = make_step_record(ctx, nranks, true))) { delete t; delete g; return rc; }
+	if (!ctx->step_rec && (rc = make_step_record(ctx, nranks, true))) { delete t; delete g; return rc; }   // (kept from a refused earlier attempt)
 	{	// the slabs must tile the grid in rank order: rank 0 starts at plane 0, the last ends at Zg (check_slab_chain), and every
 		// slab starts where its lower neighbour ends -- gaps or overlaps between middle slabs would exchange the wrong planes
 		DeviceGuard dg(ctx->device);
