@@ -146,6 +146,38 @@ def test_jacobi_temporal_blocking_bit_exact(dims, fuse):
     assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
 
 
+@pytest.mark.parametrize("depth", [4, 5, 17, 33, 50, 128, 256])
+def test_x256_meeting_streams_bit_exact(depth, monkeypatch):
+    """k_jacobi_strip3z (FLUIDX_STRIP3_ZMEET=1; X = 256, three sweeps per launch): a workgroup's two z streams run towards each other
+    and hand the planes across their meeting plane over instead of re-reading them -- odd and tiny depths put the meeting plane next
+    to the domain faces and give the two streams unequal lengths; == oracle, bit for bit"""
+    monkeypatch.setenv("FLUIDX_STRIP3_ZMEET", "1")
+    dims = (256, 256, depth)
+    _, _, p = rand_state(*dims, 31)
+    b = np.random.default_rng(32).uniform(-1, 1, (depth, 256, 256)).astype(f32)
+    f = make(dims, jacobi_iters=6, jacobi_fuse=3)
+    f.upload(fx.FIELD_PRESSURE, p)
+    f.upload(fx.FIELD_DIVERGENCE, b)
+    f.timing_enable(True); f.timing_read(True)
+    f.Jacobi(6)
+    f.Synchronize()
+    assert f.timing_read(True).jacobi_launches == 2
+    q, _ = orc.jacobi(p, b, 6)
+    assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
+
+
+@pytest.mark.parametrize("overlap", [0, 2])
+def test_x256_meeting_streams_in_slabs(overlap, monkeypatch):
+    """the same kernel on the shrinking ranges of z-slabs (halo planes included, ranges that start and end inside the slab)"""
+    monkeypatch.setenv("FLUIDX_STRIP3_ZMEET", "1")
+    from test_gpu_slabs import run_single, run_slabs, gather
+    dims = (256, 256, 400)
+    ref = run_single(dims, 2, jacobi_iters=19, jacobi_fuse=1)
+    fl = run_slabs(dims, 2, 2, jacobi_iters=19, halo_jacobi=8, halo_advect=8, overlap=overlap)
+    assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
+    assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
+
+
 @pytest.mark.parametrize("dims,iters", [((128, 128, 128), 9), ((128, 128, 30), 7), ((128, 128, 5), 4), ((128, 128, 128), 40)])
 def test_x128_default_schedule_block_kernel_bit_exact(dims, iters):
     """X = 128 (BASELINE configs[1], the reference's default grid): the default schedule runs two sweeps per launch in
