@@ -463,7 +463,7 @@ def main():
             avg_launch_s = main_ms * 1e-3 / main_l
             sweeps_per_launch = main_sw / main_l
             achieved = JACOBI_BYTES_PER_CELL_SWEEP * cells * sweeps_per_launch / avg_launch_s / 1e9
-            names = {1: ["k_jacobi_v4"], 2: (["k_jacobi_strip2h"] if GX == 512 else ["k_jacobi_block2"] if GX == 128 else []) + ["k_jacobi_strip2u", "k_jacobi_strip"],
+            names = {1: ["k_jacobi_v4"], 2: (["k_jacobi_strip2h"] if GX == 512 else ["k_jacobi_block2"] if GX == 128 else ["k_jacobi_blockg"] if GX not in (64, 256) else []) + ["k_jacobi_strip2u", "k_jacobi_strip"],
                      3: (["k_jacobi_strip3h"] if GX == 512 else ["k_jacobi_strip3c"] if (GX == 256 and GY % 8 == 0 and os.environ.get("FLUIDX_STRIP3_COOP", "1") != "0") else []) + ["k_jacobi_strip3", "k_jacobi_strip"]}
             cands = names.get(int(round(sweeps_per_launch)), ["k_jacobi_strip"]) if abs(sweeps_per_launch - round(sweeps_per_launch)) < 1e-9 else ["k_jacobi_strip"]
             tr = None

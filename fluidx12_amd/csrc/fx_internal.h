@@ -72,6 +72,9 @@ hipError_t launch_jacobi_strip3(const Geom& g, const float* p_in, const float* b
 // two sweeps per launch, one 4 x 4-row block per wave (fx_jacobi_block.hip; X = 128)
 bool jacobi_block2_supported(const Geom& g);
 hipError_t launch_jacobi_block2(const Geom& g, const float* p_in, const float* b, float* p_out, int z_begin, int z_end, hipStream_t s);
+// the same scheme for any X = CPL x (<= 64 lanes), CPL <= 4: rows that are no multiple of four cells (150^3, the reference's GI preset)
+bool jacobi_blockg_supported(const Geom& g);
+hipError_t launch_jacobi_blockg(const Geom& g, const float* p_in, const float* b, float* p_out, int z_begin, int z_end, hipStream_t s);
 // sweeps fused per launch for this geometry (1 = no fused path); requested > 0 overrides the default
 int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp);
 bool jacobi_prefers_three(const Geom& g, int requested, int nzp);

@@ -123,6 +123,131 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_block2(const Geom g, const fl
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same block-per-wave scheme for any row that fits one wave: X <= 256 with X = CPL x (active lanes), CPL = 1 .. 4 cells per
+// lane.  Written for the reference's own GI preset, 150^3 (Bin/FluidGI.bat:1: X = 150 = 3 x 50 lanes): it ran forty launches of the
+// scalar k_jacobi_generic, 19.3 us each = 0.76 of its 0.89-ms step.  Rows are not 16-byte aligned there (600 bytes), so the loads are
+// 4-byte-aligned vector loads (global_load_dwordx3: fine in the global address space); lanes beyond the row work on the last
+// lane's cells and store nothing; the row's last lane takes its right neighbour from itself (the DPP shift would hand it a copy
+// from a lane outside the row).  Partial blocks at the y / z ends: clamped loads, guarded stores.  Arithmetic and association
+// order per cell as above: bit-identical to two single sweeps.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int CPL> struct RowVec { typedef float __attribute__((ext_vector_type(CPL))) aligned_t; };
+template <> struct RowVec<1> { typedef float aligned_t; };
+
+template <int CPL> struct Cells { float v[CPL]; };
+
+template <int CPL>
+__device__ __forceinline__ Cells<CPL> ld_cells(const float* base, uint32_t byte_off)
+{
+	Cells<CPL> c;
+	if constexpr (CPL == 1) {
+		c.v[0] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+	} else {
+		typedef typename RowVec<CPL>::aligned_t __attribute__((aligned(4))) vec_t;
+		const vec_t t = *reinterpret_cast<const vec_t*>(reinterpret_cast<const char*>(base) + byte_off);
+#pragma unroll
+		for (int i = 0; i < CPL; ++i) c.v[i] = t[i];
+	}
+	return c;
+}
+
+template <int CPL>
+__device__ __forceinline__ void st_cells(float* base, uint32_t byte_off, const Cells<CPL>& c)
+{
+	if constexpr (CPL == 1) {
+		*reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = c.v[0];
+	} else {
+		typedef typename RowVec<CPL>::aligned_t __attribute__((aligned(4))) vec_t;
+		vec_t t;
+#pragma unroll
+		for (int i = 0; i < CPL; ++i) t[i] = c.v[i];
+		*reinterpret_cast<vec_t*>(reinterpret_cast<char*>(base) + byte_off) = t;
+	}
+}
+
+template <int CPL>
+__device__ __forceinline__ Cells<CPL> relax_cells(const Cells<CPL>& c, const Cells<CPL>& U, const Cells<CPL>& D, const Cells<CPL>& F,
+	const Cells<CPL>& Bk, const Cells<CPL>& bb, bool last_lane)
+{
+	const float first = c.v[0], last = c.v[CPL - 1];
+	const float L = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, last), 0x138, 0xf, 0xf, false));
+	float R = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, last), __builtin_bit_cast(int, first), 0x130, 0xf, 0xf, false));
+	if (last_lane) R = last;                                  // the wall cell: its right neighbour is itself
+	const float inv = __uint_as_float(0x3e2aaaabu);
+	Cells<CPL> x;
+#pragma unroll
+	for (int i = 0; i < CPL; ++i) {
+		const float l = i == 0 ? L : c.v[i > 0 ? i - 1 : 0], r = i == CPL - 1 ? R : c.v[i < CPL - 1 ? i + 1 : 0];
+		x.v[i] = ((((((l - bb.v[i]) + r) + U.v[i]) + D.v[i]) + F.v[i]) + Bk.v[i]) * inv;
+	}
+	return x;
+}
+
+template <int CPL, int BY, int BZ>
+__global__ __launch_bounds__(256, 1) void k_jacobi_blockg(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
+	float* __restrict__ p_out, int z_begin, int z_end, int nby, int nbz, int remap)
+{
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int nblk = nby * nbz;
+	int t = (int)blockIdx.x;
+	if (remap) {
+		const int n = (nblk + 3) >> 2, q = n >> 3, r = n & 7, xcd = t & 7, j = t >> 3;
+		t = xcd * q + min(xcd, r) + j;
+	}
+	const int blk = t * 4 + wave;
+	if (blk >= nblk) return;
+	const int by = blk % nby, bz = blk / nby;
+	const int y0 = by * BY, z0 = z_begin + bz * BZ;
+	const int nl = g.X / CPL;                               // active lanes
+	const bool live = lane < nl, last_lane = lane == nl - 1;
+	const uint32_t xoff = (uint32_t)min(lane, nl - 1) * (uint32_t)(CPL * 4);
+	const uint32_t plane = (uint32_t)g.plane();
+	const int zmin = max(g.zlo, 0), zmax = min(g.zhi, g.Zg - 1);
+
+	Cells<CPL> P0[BZ + 4][BY + 4], Bv[BZ + 2][BY + 2];
+	uint32_t roff[BY + 4];
+#pragma unroll
+	for (int i = 0; i < BY + 4; ++i) roff[i] = (uint32_t)min(max(y0 - 2 + i, 0), g.Y - 1) * (uint32_t)g.X * 4u + xoff;
+#pragma unroll
+	for (int k = 0; k < BZ + 4; ++k) {
+		const uint32_t zo = (uint32_t)g.lz(min(max(z0 - 2 + k, zmin), zmax)) * plane * 4u;
+#pragma unroll
+		for (int i = 0; i < BY + 4; ++i) P0[k][i] = ld_cells<CPL>(p_in, zo + roff[i]);
+	}
+#pragma unroll
+	for (int k = 0; k < BZ + 2; ++k) {
+		const uint32_t zo = (uint32_t)g.lz(min(max(z0 - 1 + k, zmin), zmax)) * plane * 4u;
+#pragma unroll
+		for (int j = 0; j < BY + 2; ++j) Bv[k][j] = ld_cells<CPL>(b, zo + roff[j + 1]);
+	}
+
+	Cells<CPL> P1[BZ + 2][BY + 2];
+#pragma unroll
+	for (int k1 = 0; k1 < BZ + 2; ++k1)
+#pragma unroll
+		for (int j = 0; j < BY + 2; ++j)
+			P1[k1][j] = relax_cells<CPL>(P0[k1 + 1][j + 1], P0[k1 + 1][j], P0[k1 + 1][j + 2], P0[k1][j + 1], P0[k1 + 2][j + 1], Bv[k1][j], last_lane);
+
+#pragma unroll
+	for (int k2 = 0; k2 < BZ; ++k2) {
+		const int z = z0 + k2;
+		if (z >= z_end) break;
+		const bool zfirst = z == 0, zlast = z == g.Zg - 1;
+		const uint32_t zo = (uint32_t)g.lz(z) * plane * 4u;
+#pragma unroll
+		for (int r = 0; r < BY; ++r) {
+			const int y = y0 + r;
+			if (y >= g.Y) break;
+			const Cells<CPL> c = P1[k2 + 1][r + 1];
+			const Cells<CPL> U = y == 0 ? c : P1[k2 + 1][r], D = y == g.Y - 1 ? c : P1[k2 + 1][r + 2];
+			const Cells<CPL> F = zfirst ? c : P1[k2][r + 1], Bk = zlast ? c : P1[k2 + 2][r + 1];
+			const Cells<CPL> x = relax_cells<CPL>(c, U, D, F, Bk, Bv[k2 + 1][r + 1], last_lane);
+			if (live) st_cells<CPL>(p_out, zo + (uint32_t)y * (uint32_t)g.X * 4u + xoff, x);
+		}
+	}
+}
+
 int env_b(const char* n, int d) { const char* v = getenv(n); return v && *v ? atoi(v) : d; }
 
 }  // namespace
@@ -131,6 +256,51 @@ bool jacobi_block2_supported(const Geom& g)
 {
 	static const int on = env_b("FLUIDX_JACOBI_BLOCK", 1);
 	return on && g.Zg > 1 && g.X == 128 && (g.Y & 3) == 0 && g.cells_local() < ((size_t)1 << 30);
+}
+
+// cells per lane of the general kernel: the smallest CPL <= 4 with X = CPL x (at most 64 lanes); 0 = none
+static int blockg_cpl(const Geom& g)
+{
+	for (int c = 1; c <= 4; ++c)
+		if (g.X % c == 0 && g.X / c <= 64) return c;
+	return 0;
+}
+
+bool jacobi_blockg_supported(const Geom& g)
+{
+	static const int on = env_b("FLUIDX_JACOBI_BLOCKG", 1);
+	return on && g.Zg > 1 && g.X >= 8 && blockg_cpl(g) != 0 && g.cells_local() < ((size_t)1 << 30);
+}
+
+hipError_t launch_jacobi_blockg(const Geom& g, const float* p_in, const float* b, float* p_out, int z_begin, int z_end, hipStream_t s)
+{
+	if (z_end <= z_begin) return hipSuccess;
+	if (!jacobi_blockg_supported(g)) return hipErrorNotSupported;
+	static const int remap = env_b("FLUIDX_BLOCK_REMAP", 1);
+	static const int shape = env_b("FLUIDX_BLOCKG_SHAPE", 0);      // rows * 10 + planes per wave (measurement knob); 0 = per CPL
+	const int cpl = blockg_cpl(g);
+#define FX_BLKG(C_, BY_, BZ_) do { \
+		const int nby = (g.Y + (BY_) - 1) / (BY_), nbz = (z_end - z_begin + (BZ_) - 1) / (BZ_); \
+		hipLaunchKernelGGL((k_jacobi_blockg<C_, BY_, BZ_>), dim3((nby * nbz + 3) / 4), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, nby, nbz, remap); } while (0)
+#define FX_BLKG_SHAPES(C_, DEF_) do { \
+		switch (shape ? shape : (DEF_)) { \
+		case 44: FX_BLKG(C_, 4, 4); break; \
+		case 42: FX_BLKG(C_, 4, 2); break; \
+		case 24: FX_BLKG(C_, 2, 4); break; \
+		default: FX_BLKG(C_, 2, 2); break; \
+		} } while (0)
+	// measured (Jacobi phase of a step, ms; single sweeps / 4 x 4 / 4 x 2 / 2 x 4 / 2 x 2): 150^3 0.767 / 0.319 / 0.277 / 0.285 / 0.250,
+	// 192^3 0.581 / 0.533 / 0.485 / 0.512 / 0.438, 160^3 0.386 / 0.339 / 0.365 / 0.376 / 0.303, 100^3 0.167 / 0.136 / 0.139 / 0.142 / 0.132:
+	// the small block everywhere -- unlike X = 128, whose float2 rows leave the 4 x 4 block at 224 registers
+	switch (cpl) {
+	case 1: FX_BLKG_SHAPES(1, 22); break;
+	case 2: FX_BLKG_SHAPES(2, 22); break;
+	case 3: FX_BLKG_SHAPES(3, 22); break;
+	default: FX_BLKG_SHAPES(4, 22); break;
+	}
+#undef FX_BLKG_SHAPES
+#undef FX_BLKG
+	return hipGetLastError();
 }
 
 hipError_t launch_jacobi_block2(const Geom& g, const float* p_in, const float* b, float* p_out, int z_begin, int z_end, hipStream_t s)

@@ -961,7 +961,9 @@ int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp)
 		const int want = requested > 0 ? requested : (forced > 0 ? forced : (strip_profitable(g, nzp) ? 2 : 1));
 		return want >= 3 && jacobi_strip3_supported(g) ? 3 : (want >= 2 ? 2 : 1);
 	}
-	if (!tb_supported(g)) return 1;
+	// rows that fit no strip / tile kernel (X no multiple of 4, or not 64 / 128 / 256 wide): the general block-per-wave kernel, two
+	// sweeps per launch (fx_jacobi_block.hip; 150^3, the reference's GI preset: 19.3 us per single-sweep launch before)
+	if (!tb_supported(g)) return jacobi_blockg_supported(g) && !requested && !forced && nzp >= 2 ? 2 : 1;
 	// X = 128: a 4 x 4-row block per wave, two sweeps (fx_jacobi_block.hip) -- the strips have too few waves there
 	if (jacobi_block2_supported(g) && !requested && !forced) return nzp >= 2 ? 2 : 1;
 	// default: two sweeps per launch in the register-strip kernel (fx_jacobi_strip.hip) where the geometry allows it,
@@ -1061,7 +1063,7 @@ hipError_t launch_jacobi_fused(const Geom& g, const float* p_in, const float* b,
 		if (sweeps == 3 && jacobi_strip3_supported(g)) return launch_jacobi_strip3(g, p_in, b, p_out, z_begin, z_end, s);
 		return sweeps == 2 ? launch_jacobi_strip(g, p_in, b, p_out, 2, z_begin, z_end, s) : hipErrorNotSupported;
 	}
-	if (!tb_supported(g)) return hipErrorNotSupported;
+	if (!tb_supported(g)) return sweeps == 2 && jacobi_blockg_supported(g) ? launch_jacobi_blockg(g, p_in, b, p_out, z_begin, z_end, s) : hipErrorNotSupported;
 	switch (sweeps) {
 	case 2: {
 		static const int use_tb = env_int("FLUIDX_FUSE2_TB", 0);      // 1 = the LDS kernel instead of the register strips

@@ -146,6 +146,27 @@ def test_jacobi_temporal_blocking_bit_exact(dims, fuse):
     assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
 
 
+@pytest.mark.parametrize("dims,iters", [((150, 150, 150), 40), ((150, 150, 37), 9), ((100, 100, 9), 5), ((192, 192, 20), 8), ((160, 160, 7), 6),
+                                        ((200, 200, 5), 4), ((30, 30, 30), 7), ((66, 66, 10), 6), ((8, 8, 8), 3), ((252, 252, 6), 4)])
+def test_general_block_kernel_bit_exact(dims, iters):
+    """rows that are no multiple of four cells or fit no strip kernel (150^3 = the reference's GI preset, Bin/FluidGI.bat) run two
+    sweeps per launch in k_jacobi_blockg (X = 1 .. 4 cells per lane x up to 64 lanes, unaligned row loads, partial blocks at the
+    y and z ends); odd counts end in a single sweep; == oracle, bit for bit"""
+    X, Y, Z = dims
+    _, _, p = rand_state(X, Y, Z, 41)
+    b = np.random.default_rng(42).uniform(-1, 1, (Z, Y, X)).astype(f32)
+    f = make(dims, jacobi_iters=iters)
+    f.upload(fx.FIELD_PRESSURE, p)
+    f.upload(fx.FIELD_DIVERGENCE, b)
+    f.timing_enable(True); f.timing_read(True)
+    f.Jacobi(iters)
+    f.Synchronize()
+    t = f.timing_read(True)
+    assert t.jacobi_sweeps == iters and t.jacobi_launches == (iters + 1) // 2
+    q, _ = orc.jacobi(p, b, iters)
+    assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
+
+
 @pytest.mark.parametrize("depth", [4, 5, 17, 33, 50, 128, 256])
 def test_x256_meeting_streams_bit_exact(depth, monkeypatch):
     """k_jacobi_strip3z (FLUIDX_STRIP3_ZMEET=1; X = 256, three sweeps per launch): a workgroup's two z streams run towards each other
