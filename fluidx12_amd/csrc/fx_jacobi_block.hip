@@ -287,16 +287,20 @@ hipError_t launch_jacobi_blockg(const Geom& g, const float* p_in, const float* b
 		case 44: FX_BLKG(C_, 4, 4); break; \
 		case 42: FX_BLKG(C_, 4, 2); break; \
 		case 24: FX_BLKG(C_, 2, 4); break; \
+		case 33: FX_BLKG(C_, 3, 3); break; \
+		case 32: FX_BLKG(C_, 3, 2); break; \
+		case 23: FX_BLKG(C_, 2, 3); break; \
 		default: FX_BLKG(C_, 2, 2); break; \
 		} } while (0)
-	// measured (Jacobi phase of a step, ms; single sweeps / 4 x 4 / 4 x 2 / 2 x 4 / 2 x 2): 150^3 0.767 / 0.319 / 0.277 / 0.285 / 0.250,
-	// 192^3 0.581 / 0.533 / 0.485 / 0.512 / 0.438, 160^3 0.386 / 0.339 / 0.365 / 0.376 / 0.303, 100^3 0.167 / 0.136 / 0.139 / 0.142 / 0.132:
-	// the small block everywhere -- unlike X = 128, whose float2 rows leave the 4 x 4 block at 224 registers
+	// measured (Jacobi phase of a step, ms; single sweeps / 4 x 4 / 4 x 2 / 2 x 4 / 2 x 2 / 3 x 3 / 3 x 2 / 2 x 3 rows x planes per wave):
+	// 150^3 0.767 / 0.319 / 0.277 / 0.285 / 0.250 / 0.299 / 0.237 / 0.236, 192^3 0.581 / 0.533 / 0.485 / 0.512 / 0.440 / 0.478 / 0.388 / 0.387,
+	// 160^3 0.386 / 0.339 / 0.365 / 0.376 / 0.304 / 0.327 / 0.303 / 0.303, 100^3 0.167 / 0.136 / 0.139 / 0.142 / 0.131 / 0.146 / 0.125 / 0.128:
+	// six rows per wave everywhere -- unlike X = 128, whose float2 rows leave the 4 x 4 block at 224 registers
 	switch (cpl) {
-	case 1: FX_BLKG_SHAPES(1, 22); break;
-	case 2: FX_BLKG_SHAPES(2, 22); break;
-	case 3: FX_BLKG_SHAPES(3, 22); break;
-	default: FX_BLKG_SHAPES(4, 22); break;
+	case 1: FX_BLKG_SHAPES(1, 32); break;
+	case 2: FX_BLKG_SHAPES(2, 32); break;
+	case 3: FX_BLKG_SHAPES(3, 32); break;
+	default: FX_BLKG_SHAPES(4, 32); break;
 	}
 #undef FX_BLKG_SHAPES
 #undef FX_BLKG
