@@ -112,7 +112,10 @@ __device__ __forceinline__ uint32_t opaque32(uint32_t v) { asm volatile("" : "+v
 // waits for its own prefetch (the next input plane, in flight since sweep 1) in the middle of the step.  A wave's LDS operations
 // execute in order, so "data rows, then counter" needs no fence; the asm's "memory" clobber keeps the compiler from moving the
 // rows' reads / writes across it.  (Measured neutral for k_jacobi_strip3c, 43.5 us either way, and WORSE for k_jacobi_strip3h --
-// 337 -> 359 us: its scalar seam loads share lgkmcnt with the DS poll -- which therefore keeps the volatile form.)
+// 337 -> 359 us: its scalar seam loads share lgkmcnt with the DS poll -- which therefore keeps the volatile form.  Tried again with
+// the seam cells fetched by VECTOR loads, so that no wait of the step except the next sweep 1's touches the prefetch: 347 -> 372-381 us
+// at 512^3.  The volatile form's `s_waitcnt vmcnt(0)` at hand-over 2 -- the wave stands until its own prefetch has landed, half a
+// step after issuing it -- is what keeps the two halves of a row in step; without it they drift and spin at the hand-overs.)
 __device__ __forceinline__ int lds_peek(uint32_t lds_byte_addr)
 {
 	int v;
