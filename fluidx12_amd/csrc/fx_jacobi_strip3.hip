@@ -131,6 +131,22 @@ __device__ __forceinline__ void lds_wait_ge(uint32_t lds_byte_addr, int v)
 	while (lds_peek(lds_byte_addr) < v) __builtin_amdgcn_s_sleep(1);
 }
 
+// counter and row in ONE LDS round trip: both reads are issued back to back (LDS operations of a wave execute in order, and the
+// partner wrote the row before the counter: a counter that is high enough vouches for the row read behind it); only a partner that is
+// late costs a second trip.  Saves one ~100-cycle LDS latency per hand-over, which one wave per SIMD cannot hide.
+typedef float fx_q4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 lds_wait_read(uint32_t flag_byte_addr, int need, uint32_t row_byte_addr)
+{
+	int f;
+	fx_q4 d;
+	for (;;) {
+		asm volatile("ds_read_b32 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f), "=&v"(d) : "v"(flag_byte_addr), "v"(row_byte_addr) : "memory");
+		if (f >= need) break;
+		__builtin_amdgcn_s_sleep(1);
+	}
+	return make_float4(d.x, d.y, d.z, d.w);
+}
+
 // row `r` of an LDS slot whose first row starts `slot` float4s into the wave's slice
 #define FX_LDS(slot, r) lds[(slot) + (r) * 64]
 
@@ -529,8 +545,7 @@ constexpr int C_ROWS_PER_WAVE = 2 * C_P0_ROWS + 3 * C_B_ROWS;     // 34 rows of 
 	   partner has published its step q-1, READ its row, only then publish \
 	   mine and my counter -- a wave that sees my counter at q knows I have already read what it wrote two steps ago into the slot \
 	   it is about to reuse, so two slots (step parity) suffice; and a wave may run a whole step ahead of its partner */ \
-	lds_wait_ge(xf_partner, q - 1); \
-	const float4 H1_ = xbuf[((((q - 1) & 1) * 4 + (wave ^ 1)) * 2 + 0) * 64 + lane];           /* partner's level 1, plane q-2 */ \
+	const float4 H1_ = lds_wait_read(xf_partner, q - 1, xb0 + 16u * (uint32_t)(((((q - 1) & 1) * 4 + (wave ^ 1)) * 2 + 0) * 64 + lane));   /* partner's level 1, plane q-2 */ \
 	xbuf[(((q & 1) * 4 + wave) * 2 + 0) * 64 + lane] = (UP) ? P1[NEW][C_B_ROWS - 1] : P1[NEW][0];   /* mine, plane q-1 */ \
 	if (lane == 0) lds_post(xf_mine, q);                               /* LDS operations of a wave execute in order */ \
 	/* ---- sweep 2: level-2 plane q-2 ------------------------------------------------------------------------------- */ \
@@ -551,8 +566,7 @@ constexpr int C_ROWS_PER_WAVE = 2 * C_P0_ROWS + 3 * C_B_ROWS;     // 34 rows of 
 		} \
 	} \
 	/* hand-over 2 (level-2 edge rows), same order */ \
-	lds_wait_ge(xf_partner + 16, q - 1); \
-	const float4 H2_ = xbuf[((((q - 1) & 1) * 4 + (wave ^ 1)) * 2 + 1) * 64 + lane];           /* partner's level 2, plane q-3 */ \
+	const float4 H2_ = lds_wait_read(xf_partner + 16, q - 1, xb0 + 16u * (uint32_t)(((((q - 1) & 1) * 4 + (wave ^ 1)) * 2 + 1) * 64 + lane));   /* partner's level 2, plane q-3 */ \
 	xbuf[(((q & 1) * 4 + wave) * 2 + 1) * 64 + lane] = (UP) ? P2[NEW][RC] : P2[NEW][0];              /* mine, plane q-2 */ \
 	if (lane == 0) lds_post(xf_mine + 16, q); \
 	/* ---- sweep 3: output plane q-3 ------------------------------------------------------------------------------- */ \
@@ -621,6 +635,7 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip3c(const Geom g, const f
 	__syncthreads();
 	const uint32_t xf0 = (uint32_t)(size_t)(__attribute__((address_space(3))) int*)xflag;      // LDS byte address of the counters
 	const uint32_t xf_mine = xf0 + 4u * (uint32_t)wave, xf_partner = xf0 + 4u * (uint32_t)(wave ^ 1);
+	const uint32_t xb0 = (uint32_t)(size_t)(__attribute__((address_space(3))) float4*)xbuf;   // LDS byte address of the mailbox
 	int q = qs;
 	if (up) {
 		for (;;) {
