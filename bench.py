@@ -363,15 +363,19 @@ def main():
             m_.timing_enable(True)
             m_.timing_read(reset=True)
     barrier_sync()
-    # N > 1: the library's HIP-event marks (two event records per phase, round and member) cost a multi-rank step about a tenth
-    # (profiles/r02d_comm_priority.txt: 5.1 -> 5.6 ms in loop-back N = 4), so only every fourth step of the timed region carries
-    # them; stage times, launch averages and exchanged bytes are per marked step.  N = 1 marks every step (five marks).
-    mark_every = 4 if (N > 1 and args.steps >= 8) else 1
+    # The library's HIP-event marks (two event records per phase, round and member: the stream drains at each) are instrumentation
+    # the product runs without; they cost a multi-rank step about a tenth (profiles/r02d_comm_priority.txt: 5.1 -> 5.6 ms in
+    # loop-back N = 4) and a single-GPU step 0.980 -> 0.947 ms at 256^3, 0.2047 -> 0.1814 ms at 128^3 (ten event records, ~2.5 us
+    # each).  So only every fourth step of the timed region carries them; stage times, launch averages (roofline) and exchanged
+    # bytes are per marked step, `value` is over all steps.  FLUIDX_BENCH_MARK_EVERY=1: every step.
+    mark_every = 4 if args.steps >= 8 else 1
+    if os.environ.get("FLUIDX_BENCH_MARK_EVERY"):
+        mark_every = max(1, int(os.environ["FLUIDX_BENCH_MARK_EVERY"]))
     t0 = time.perf_counter()
     for k in range(args.steps):
-        if mark_every > 1 and (k % mark_every == 0 or k % mark_every == 1):
+        if mark_every > 1 and k % mark_every in (0, 2, 3):             # marked: steps 2, 6, 10 ... (not the first one behind the barrier)
             for m_ in members:
-                m_.timing_enable(k % mark_every == 0)
+                m_.timing_enable(k % mark_every == 2)
         one_step(args.warmup + k)
     barrier_sync()
     elapsed = time.perf_counter() - t0
@@ -521,6 +525,7 @@ def main():
             out["shared_gpu"] = True
             out["data"] = "synthetic; SHARED GPU: %d rank processes on ONE device (functional check of the one-process-per-GPU path, not a scaling measurement)" % N
         if timing is not None:
+            out["timing_marks"] = {"every": mark_every, "marked_steps": int(timing.steps)}      # stage / launch figures are per marked step
             out["stage_ms_per_step"] = {k: getattr(timing, k + "_ms") / max(timing.steps, 1)
                                         for k in ("advect", "divergence", "jacobi", "project", "exchange")}
             sb = step_bytes_per_voxel(args.iters, args.storage) * float(GX) * GY * GZ
