@@ -745,6 +745,120 @@ __global__ __launch_bounds__(256) void k_project_v4(const Geom g, const typename
 }
 
 // ---------------------------------------------------------------------------------------------
+// Rows that are no multiple of four cells (150^3, the reference's GI preset: Bin/FluidGI.bat:1), fp32 fields: the v4 kernels'
+// scheme with W = 3 or 2 cells per thread and 4-byte-aligned vector accesses (rows of 600 bytes are not 16-byte aligned).
+// Per-cell arithmetic is k_divergence's / k_project's.
+// ---------------------------------------------------------------------------------------------
+template <int W> struct CellsW { float v[W]; };
+
+template <int W>
+__device__ __forceinline__ CellsW<W> ldw(const float* base, uint32_t cell)
+{
+	typedef float __attribute__((ext_vector_type(W))) vt;
+	typedef vt __attribute__((aligned(4))) vu;
+	const vu t = *reinterpret_cast<const vu*>(base + cell);
+	CellsW<W> c;
+#pragma unroll
+	for (int i = 0; i < W; ++i) c.v[i] = t[i];
+	return c;
+}
+
+template <int W>
+__device__ __forceinline__ void stw(float* base, uint32_t cell, const CellsW<W>& c)
+{
+	typedef float __attribute__((ext_vector_type(W))) vt;
+	typedef vt __attribute__((aligned(4))) vu;
+	vt t;
+#pragma unroll
+	for (int i = 0; i < W; ++i) t[i] = c.v[i];
+	*reinterpret_cast<vu*>(base + cell) = t;
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void k_divergence_vw(const Geom g, const float* __restrict__ vel, float* __restrict__ b,
+	int z_begin, int nzp, int remap, int rows_per_block)
+{
+	const int XW = g.X / W;
+	const Tile3 tile = xcd_tile((XW + (int)blockDim.x - 1) / (int)blockDim.x, (g.Y + rows_per_block - 1) / rows_per_block, nzp, remap);
+	const int xw = tile.x * blockDim.x + threadIdx.x;
+	const int y = tile.y * rows_per_block + threadIdx.y;
+	const int z = z_begin + tile.z;
+	if (xw >= XW || y >= g.Y) return;
+	const uint32_t plane = (uint32_t)g.plane(), stride = (uint32_t)g.cells_local();
+	const int yu = max(y, 1) - 1, yd = min(y + 1, g.Y - 1);
+	const int zf = max(z, 1) - 1, zb = min(z + 1, g.Zg - 1);
+	const uint32_t zrow = (uint32_t)g.lz(z) * plane, col = (uint32_t)(W * xw), off = zrow + (uint32_t)y * g.X + col;
+	const CellsW<W> cx = ldw<W>(vel, off);
+	const float L = xw > 0 ? vel[off - 1] : cx.v[0];
+	const float R = xw < XW - 1 ? vel[off + W] : cx.v[W - 1];
+	const CellsW<W> U = ldw<W>(vel, stride + zrow + (uint32_t)yu * g.X + col), D = ldw<W>(vel, stride + zrow + (uint32_t)yd * g.X + col);
+	const CellsW<W> F = ldw<W>(vel, 2u * stride + (uint32_t)g.lz(zf) * plane + (uint32_t)y * g.X + col);
+	const CellsW<W> B = ldw<W>(vel, 2u * stride + (uint32_t)g.lz(zb) * plane + (uint32_t)y * g.X + col);
+	CellsW<W> o;
+#pragma unroll
+	for (int i = 0; i < W; ++i) {
+		const float l = i == 0 ? L : cx.v[i > 0 ? i - 1 : 0], r = i == W - 1 ? R : cx.v[i < W - 1 ? i + 1 : 0];
+		o.v[i] = 0.5f * ((-F.v[i] + B.v[i]) + ((-U.v[i] + D.v[i]) + (-l + r)));
+	}
+	stw<W>(b, off, o);
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void k_project_vw(const Geom g, const float* __restrict__ vel_in, const float* __restrict__ p,
+	float* __restrict__ vel_out, int z_begin, int nzp, int remap, int rows_per_block)
+{
+	const int XW = g.X / W;
+	const Tile3 tile = xcd_tile((XW + (int)blockDim.x - 1) / (int)blockDim.x, (g.Y + rows_per_block - 1) / rows_per_block, nzp, remap);
+	const int xw = tile.x * blockDim.x + threadIdx.x;
+	const int y = tile.y * rows_per_block + threadIdx.y;
+	const int z = z_begin + tile.z;
+	if (xw >= XW || y >= g.Y) return;
+	const uint32_t plane = (uint32_t)g.plane(), stride = (uint32_t)g.cells_local();
+	const int yu = max(y, 1) - 1, yd = min(y + 1, g.Y - 1);
+	const int zf = max(z, 1) - 1, zb = min(z + 1, g.Zg - 1);
+	const uint32_t zrow = (uint32_t)g.lz(z) * plane, col = (uint32_t)(W * xw), off = zrow + (uint32_t)y * g.X + col;
+	const CellsW<W> c = ldw<W>(p, off);
+	const float L = xw > 0 ? p[off - 1] : c.v[0];
+	const float R = xw < XW - 1 ? p[off + W] : c.v[W - 1];
+	const CellsW<W> U = ldw<W>(p, zrow + (uint32_t)yu * g.X + col), D = ldw<W>(p, zrow + (uint32_t)yd * g.X + col);
+	const CellsW<W> F = ldw<W>(p, (uint32_t)g.lz(zf) * plane + (uint32_t)y * g.X + col);
+	const CellsW<W> B = ldw<W>(p, (uint32_t)g.lz(zb) * plane + (uint32_t)y * g.X + col);
+	const CellsW<W> ux = ldw<W>(vel_in, off), uy = ldw<W>(vel_in, stride + off), uz = ldw<W>(vel_in, 2u * stride + off);
+	const float k = __uint_as_float(0x3f855556u);                          // 0.5f / 0.48f (g_density, CSProject3D.hlsl:26)
+	float py = ((float)y + 0.5f) / (float)g.Y, pz = ((float)z + 0.5f) / (float)g.Zg;
+	py = fmaf(py, 2.0f, -1.0f); pz = fmaf(pz, 2.0f, -1.0f);
+	float fy = (-fabsf(py) + 0.970000029f) * 33.3333359f, fz = (-fabsf(pz) + 0.970000029f) * 33.3333359f;
+	fy = fminf(fmaxf(fy, -1.0f), 1.0f); fz = fminf(fmaxf(fz, -1.0f), 1.0f);
+	CellsW<W> ox, oy, oz;
+#pragma unroll
+	for (int i = 0; i < W; ++i) {
+		const float pl = i == 0 ? L : c.v[i > 0 ? i - 1 : 0], pr = i == W - 1 ? R : c.v[i < W - 1 ? i + 1 : 0];
+		const float gx = -pl + pr, gy = -U.v[i] + D.v[i], gz = -F.v[i] + B.v[i];
+		const float wz_ = fmaf(-gz, k, uz.v[i]);                            // CSProject3D.hlsl:62 (the z component first, as k_project does)
+		const float wx_ = fmaf(-gx, k, ux.v[i]), wy_ = fmaf(-gy, k, uy.v[i]);
+		float px = ((float)(W * xw + i) + 0.5f) / (float)g.X;
+		px = fmaf(px, 2.0f, -1.0f);
+		float fxw = (-fabsf(px) + 0.970000029f) * 33.3333359f;
+		fxw = fminf(fmaxf(fxw, -1.0f), 1.0f);
+		ox.v[i] = wx_ * ((0.0f < wx_ * px) ? fxw : 1.0f);                  // :106-108
+		oy.v[i] = wy_ * ((0.0f < wy_ * py) ? fy : 1.0f);
+		oz.v[i] = wz_ * ((0.0f < wz_ * pz) ? fz : 1.0f);
+	}
+	stw<W>(vel_out, off, ox);
+	stw<W>(vel_out, stride + off, oy);
+	stw<W>(vel_out, 2u * stride + off, oz);
+}
+
+static int env_int(const char* name, int dflt);
+// cells per thread of the vW kernels: 3 or 2 where that divides the row, 0 = none (the scalar kernels)
+static int vw_width(const Geom& g, int half_store)
+{
+	static const int on = env_int("FLUIDX_ROW_VW", 1);
+	if (!on || half_store || g.Zg <= 1 || g.cells_local() * 3 >= ((size_t)1 << 30)) return 0;
+	return g.X % 3 == 0 ? 3 : (g.X % 2 == 0 ? 2 : 0);
+}
+
+// ---------------------------------------------------------------------------------------------
 // What the NEXT advection will need from the z-neighbours, measured on the velocity the projection has just written
 // (multi-GPU slabs; no reference counterpart).  For every owned voxel the z taps of its back-trace are computed with the
 // arithmetic of k_advect (pz, az = fma(-uz, dt, pz), tz = az * Zg - 0.5, floor; CLAMP / MIRROR); need[0] = planes wanted below
@@ -893,6 +1007,15 @@ hipError_t launch_divergence(const Geom& g, int half_store, const void* vel, flo
 		const dim3 block(bx, by, 1), grid(((X4 + bx - 1) / bx) * ((g.Y + by - 1) / by) * nzp, 1, 1);
 		if (half_store) hipLaunchKernelGGL(k_divergence_v4<true>, grid, block, 0, s, g, (const h16*)vel, b, z_begin, nzp, xcd_remap_on(REMAP_DIV), by);
 		else hipLaunchKernelGGL(k_divergence_v4<false>, grid, block, 0, s, g, (const float*)vel, b, z_begin, nzp, xcd_remap_on(REMAP_DIV), by);
+		return hipGetLastError();
+	}
+	if (const int w = vw_width(g, half_store)) {
+		const int nzp = z_end - z_begin, XW = g.X / w;
+		const int bx = XW < 64 ? XW : 64;
+		int by = 256 / bx; if (by > g.Y) by = g.Y;
+		const dim3 block(bx, by, 1), grid(((XW + bx - 1) / bx) * ((g.Y + by - 1) / by) * nzp, 1, 1);
+		if (w == 3) hipLaunchKernelGGL(k_divergence_vw<3>, grid, block, 0, s, g, (const float*)vel, b, z_begin, nzp, xcd_remap_on(REMAP_DIV), by);
+		else hipLaunchKernelGGL(k_divergence_vw<2>, grid, block, 0, s, g, (const float*)vel, b, z_begin, nzp, xcd_remap_on(REMAP_DIV), by);
 		return hipGetLastError();
 	}
 	const dim3 grid = grid_xyz(g, z_end - z_begin), block(64, 4, 1);
@@ -1127,6 +1250,15 @@ hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, co
 		if (half_store) { if (rcp) FX_PV4(true, true, h16); else FX_PV4(false, true, h16); }
 		else { if (rcp) FX_PV4(true, false, float); else FX_PV4(false, false, float); }
 #undef FX_PV4
+		return hipGetLastError();
+	}
+	if (const int w = sp.is3d ? vw_width(g, half_store) : 0) {
+		const int nzp = z_end - z_begin, XW = g.X / w;
+		const int bx = XW < 64 ? XW : 64;
+		int by = 256 / bx; if (by > g.Y) by = g.Y;
+		const dim3 block(bx, by, 1), grid(((XW + bx - 1) / bx) * ((g.Y + by - 1) / by) * nzp, 1, 1);
+		if (w == 3) hipLaunchKernelGGL(k_project_vw<3>, grid, block, 0, s, g, (const float*)vel_in, p, (float*)vel_out, z_begin, nzp, xcd_remap_on(REMAP_PROJECT), by);
+		else hipLaunchKernelGGL(k_project_vw<2>, grid, block, 0, s, g, (const float*)vel_in, p, (float*)vel_out, z_begin, nzp, xcd_remap_on(REMAP_PROJECT), by);
 		return hipGetLastError();
 	}
 	const dim3 grid = grid_xyz(g, z_end - z_begin), block(64, 4, 1);

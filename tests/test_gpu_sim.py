@@ -34,7 +34,8 @@ def make(dims, **kw):
     return f
 
 
-DIMS = [(32, 32, 32), (64, 64, 16), (20, 20, 12), (150, 150, 6), (64, 64, 1), (36, 36, 1)]
+DIMS = [(32, 32, 32), (64, 64, 16), (20, 20, 12), (150, 150, 6), (64, 64, 1), (36, 36, 1),
+        (70, 70, 5), (130, 130, 4), (201, 201, 3)]        # rows of 2 x 35, 2 x 65 (two x tiles) and 3 x 67 cells per thread (k_*_vw)
 
 
 @pytest.mark.parametrize("dims", DIMS)
