@@ -90,6 +90,26 @@ def test_slabs_x128_block_kernel(overlap):
 
 
 @pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("dims,nranks", [((150, 150, 60), 3), ((100, 100, 33), 2)])
+def test_slabs_general_block_kernel(dims, nranks, overlap):
+    """rows that fit no strip kernel (150 wide: the reference's GI preset) in slabs: the rounds run two sweeps per launch in
+    k_jacobi_blockg on the shrinking plane ranges; divergence / projection in the three-cells-per-thread kernels"""
+    ref = run_single(dims, 3, jacobi_iters=13, jacobi_fuse=1)
+    fl = run_slabs(dims, 3, nranks, jacobi_iters=13, halo_jacobi=5, halo_advect=6, overlap=overlap)
+    fl[0].timing_enable(True)
+    fl[0].UpdateFrame(f32(fl[0].default_time_step()), 0)
+    fl[0].Simulate(0)
+    fl[0].Synchronize()
+    t = fl[0].timing_read()
+    assert t.jacobi_sweeps >= 13 and t.jacobi_launches < t.jacobi_sweeps      # fused launches took part
+    ref.UpdateFrame(f32(ref.default_time_step()), 0)
+    ref.Simulate(0)
+    ref.Synchronize()
+    assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
+    assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
+
+
+@pytest.mark.parametrize("overlap", [True, False])
 def test_slabs_faithful_mode(overlap):
     """reference-faithful Jacobi (64-sweep cap, per-cell freeze at |delta| < 1e-3): the freeze mask of the face planes
     travels with the pressure halo, so the decomposed run freezes exactly the cells the single domain freezes"""
