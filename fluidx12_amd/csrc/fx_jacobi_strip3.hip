@@ -508,13 +508,14 @@ constexpr int C_P0_ROWS = RC + 4;           // input rows per plane
 constexpr int C_B_ROWS = RC + 2;            // b rows per plane (= level-1 rows)
 constexpr int C_ROWS_PER_WAVE = 2 * C_P0_ROWS + 3 * C_B_ROWS;     // 34 rows of 1 KiB
 
-#define FX_STRIP3C_STEP(PH, UP) do { \
+#define FX_STRIP3C_STEP(PH, UP, S1, S2, S3) do { \
 	constexpr int NEW = (PH) % 3, CTR = ((PH) + 2) % 3, OLD = ((PH) + 1) % 3; \
 	/* ---- sweep 1: level-1 plane q-1 ------------------------------------------------------------------------------- */ \
 	if (q == 0) {                                   /* input plane -1 := plane 0, once (clamped front neighbour) */ \
 		_Pragma("unroll") for (int i = 0; i < C_P0_ROWS; ++i) FX_LDS(s_ctr, i) = NP[i]; \
 	} \
-	if (q - 1 == g.Zg) {                            /* level-1 plane Zg := plane Zg-1 */ \
+	if (!(S1)) {                                    /* (a fill step: see the kernel) */ \
+	} else if (q - 1 == g.Zg) {                     /* level-1 plane Zg := plane Zg-1 */ \
 		_Pragma("unroll") for (int j = 0; j < C_B_ROWS; ++j) P1[NEW][j] = P1[CTR][j]; \
 	} else { \
 		float4 C_[C_P0_ROWS], F_[C_B_ROWS]; \
@@ -545,11 +546,15 @@ constexpr int C_ROWS_PER_WAVE = 2 * C_P0_ROWS + 3 * C_B_ROWS;     // 34 rows of 
 	   partner has published its step q-1, READ its row, only then publish \
 	   mine and my counter -- a wave that sees my counter at q knows I have already read what it wrote two steps ago into the slot \
 	   it is about to reuse, so two slots (step parity) suffice; and a wave may run a whole step ahead of its partner */ \
-	const float4 H1_ = lds_wait_read(xf_partner, q - 1, xb0 + 16u * (uint32_t)(((((q - 1) & 1) * 4 + (wave ^ 1)) * 2 + 0) * 64 + lane));   /* partner's level 1, plane q-2 */ \
-	xbuf[(((q & 1) * 4 + wave) * 2 + 0) * 64 + lane] = (UP) ? P1[NEW][C_B_ROWS - 1] : P1[NEW][0];   /* mine, plane q-1 */ \
-	if (lane == 0) lds_post(xf_mine, q);                               /* LDS operations of a wave execute in order */ \
+	float4 H1_ = zero; \
+	if (S1) { \
+		H1_ = lds_wait_read(xf_partner, q - 1, xb0 + 16u * (uint32_t)(((((q - 1) & 1) * 4 + (wave ^ 1)) * 2 + 0) * 64 + lane));   /* partner's level 1, plane q-2 */ \
+		xbuf[(((q & 1) * 4 + wave) * 2 + 0) * 64 + lane] = (UP) ? P1[NEW][C_B_ROWS - 1] : P1[NEW][0];   /* mine, plane q-1 */ \
+		if (lane == 0) lds_post(xf_mine, q);                           /* LDS operations of a wave execute in order */ \
+	} \
 	/* ---- sweep 2: level-2 plane q-2 ------------------------------------------------------------------------------- */ \
-	if (q - 2 == g.Zg) { \
+	if (!(S2)) { \
+	} else if (q - 2 == g.Zg) { \
 		_Pragma("unroll") for (int k = 0; k < RC + 1; ++k) P2[NEW][k] = P2[CTR][k]; \
 	} else { \
 		_Pragma("unroll") for (int k = 0; k < RC + 1; ++k) { \
@@ -566,11 +571,14 @@ constexpr int C_ROWS_PER_WAVE = 2 * C_P0_ROWS + 3 * C_B_ROWS;     // 34 rows of 
 		} \
 	} \
 	/* hand-over 2 (level-2 edge rows), same order */ \
-	const float4 H2_ = lds_wait_read(xf_partner + 16, q - 1, xb0 + 16u * (uint32_t)(((((q - 1) & 1) * 4 + (wave ^ 1)) * 2 + 1) * 64 + lane));   /* partner's level 2, plane q-3 */ \
-	xbuf[(((q & 1) * 4 + wave) * 2 + 1) * 64 + lane] = (UP) ? P2[NEW][RC] : P2[NEW][0];              /* mine, plane q-2 */ \
-	if (lane == 0) lds_post(xf_mine + 16, q); \
+	float4 H2_ = zero; \
+	if (S2) { \
+		H2_ = lds_wait_read(xf_partner + 16, q - 1, xb0 + 16u * (uint32_t)(((((q - 1) & 1) * 4 + (wave ^ 1)) * 2 + 1) * 64 + lane));   /* partner's level 2, plane q-3 */ \
+		xbuf[(((q & 1) * 4 + wave) * 2 + 1) * 64 + lane] = (UP) ? P2[NEW][RC] : P2[NEW][0];          /* mine, plane q-2 */ \
+		if (lane == 0) lds_post(xf_mine + 16, q); \
+	} \
 	/* ---- sweep 3: output plane q-3 ------------------------------------------------------------------------------- */ \
-	if (q - 3 >= zb && q - 3 < ze) { \
+	if ((S3) && q - 3 >= zb && q - 3 < ze) { \
 		char* ob_ = reinterpret_cast<char*>(p_out + (size_t)g.lz(q - 3) * plane); \
 		_Pragma("unroll") for (int m = 0; m < RC; ++m) { \
 			const int kc_ = (UP) ? m + 1 : m;                            /* level-2 index of this row */ \
@@ -631,32 +639,41 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip3c(const Geom g, const f
 #pragma unroll
 		for (int i = 0; i < C_B_ROWS; ++i) NB[i] = *reinterpret_cast<const float4*>(bbase + roff[i + 1]);
 	}
-	if (threadIdx.x < 8) xflag[threadIdx.x] = qs - 1;                 // the waves of a workgroup share the chunk, hence qs
+	// The pipeline's fill (a chunk that starts three planes before its first output plane): level-1 planes below zb-2 and level-2
+	// planes below zb-1 feed nothing that is stored, so the first two steps only park and prefetch, the next two add sweep 1, the two
+	// after that sweep 2 -- six peeled steps (two whole triples of phases) in front of the loop, 32 of a chunk's 330 row updates
+	// less; and with the peeled copies the allocator keeps the loop itself free of AGPR moves (105-146 per three steps before).
+	// 43.0 -> 41.7 us per launch.  (As branches inside the step: +150 instructions per three steps in the hot loop, a net loss.  With
+	// the two load-only steps folded into a prologue that fetches all three planes at once: 41.95 us -- the launch is bound by its
+	// bytes and its issue slots, not by the round trips of one workgroup.)  The hand-over counters start where the first active
+	// hand-over of each level expects them.
+	const bool fill = qs == zb - 3;
+	if (threadIdx.x < 8) xflag[threadIdx.x] = !fill ? qs - 1 : threadIdx.x < 4 ? zb - 2 : zb;     // the waves of a workgroup share the chunk
 	__syncthreads();
 	const uint32_t xf0 = (uint32_t)(size_t)(__attribute__((address_space(3))) int*)xflag;      // LDS byte address of the counters
 	const uint32_t xf_mine = xf0 + 4u * (uint32_t)wave, xf_partner = xf0 + 4u * (uint32_t)(wave ^ 1);
 	const uint32_t xb0 = (uint32_t)(size_t)(__attribute__((address_space(3))) float4*)xbuf;   // LDS byte address of the mailbox
 	int q = qs;
-	if (up) {
-		for (;;) {
-			FX_STRIP3C_STEP(0, true);
-			if (++q > q_last) break;
-			FX_STRIP3C_STEP(1, true);
-			if (++q > q_last) break;
-			FX_STRIP3C_STEP(2, true);
-			if (++q > q_last) break;
-		}
-	} else {
-		for (;;) {
-			FX_STRIP3C_STEP(0, false);
-			if (++q > q_last) break;
-			FX_STRIP3C_STEP(1, false);
-			if (++q > q_last) break;
-			FX_STRIP3C_STEP(2, false);
-			if (++q > q_last) break;
-		}
-	}
+#define FX_STRIP3C_RUN(UP) do { \
+		if (fill) { \
+			FX_STRIP3C_STEP(0, UP, false, false, false); ++q; \
+			FX_STRIP3C_STEP(1, UP, false, false, false); ++q; \
+			FX_STRIP3C_STEP(2, UP, true, false, false); ++q; \
+			FX_STRIP3C_STEP(0, UP, true, false, false); ++q; \
+			FX_STRIP3C_STEP(1, UP, true, true, false); ++q; \
+			FX_STRIP3C_STEP(2, UP, true, true, false); ++q; \
+		} \
+		for (;;) { \
+			FX_STRIP3C_STEP(0, UP, true, true, true); \
+			if (++q > q_last) break; \
+			FX_STRIP3C_STEP(1, UP, true, true, true); \
+			if (++q > q_last) break; \
+			FX_STRIP3C_STEP(2, UP, true, true, true); \
+			if (++q > q_last) break; \
+		} } while (0)
+	if (up) FX_STRIP3C_RUN(true); else FX_STRIP3C_RUN(false);
 }
+#undef FX_STRIP3C_RUN
 #undef FX_STRIP3C_STEP
 
 // ---------------------------------------------------------------------------------------------------------------------------
