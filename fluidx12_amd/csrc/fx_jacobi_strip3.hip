@@ -534,14 +534,15 @@ constexpr int C_ROWS_PER_WAVE = 2 * C_P0_ROWS + 3 * C_B_ROWS;     // 34 rows of 
 	_Pragma("unroll") for (int i = 0; i < C_B_ROWS; ++i) FX_LDS(s_bfree, i) = NB[i]; \
 	{ const int t_ = s_old; s_old = s_ctr; s_ctr = t_; } \
 	{ const int t_ = s_bfree; s_bfree = s_b3; s_b3 = s_b2; s_b2 = t_; } \
+	/* the plane bases walk along with q (pp: input plane q+1, pbq: b plane q, po: output plane q-3): two scalar adds each instead of \
+	   the eleven of a 64-bit `lz(q) * plane` */ \
 	if (q + 1 <= q_load_last) { \
-		const char* pb_ = reinterpret_cast<const char*>(p_in + (size_t)g.lz(q + 1) * plane); \
-		_Pragma("unroll") for (int i = 0; i < C_P0_ROWS; ++i) NP[i] = *reinterpret_cast<const float4*>(pb_ + opaque32(roff[i])); \
+		_Pragma("unroll") for (int i = 0; i < C_P0_ROWS; ++i) NP[i] = *reinterpret_cast<const float4*>(pp + opaque32(roff[i])); \
 	} \
 	if (q <= b_load_last) { \
-		const char* bb_ = reinterpret_cast<const char*>(b + (size_t)g.lz(q) * plane); \
-		_Pragma("unroll") for (int i = 0; i < C_B_ROWS; ++i) NB[i] = *reinterpret_cast<const float4*>(bb_ + opaque32(roff[i + 1])); \
+		_Pragma("unroll") for (int i = 0; i < C_B_ROWS; ++i) NB[i] = *reinterpret_cast<const float4*>(pbq + opaque32(roff[i + 1])); \
 	} \
+	pp += plane_bytes; pbq += plane_bytes; \
 	/* hand-over 1 (level-1 edge rows), BEHIND the prefetch issue: a wait here must not delay the loads.  Order: wait until the \
 	   partner has published its step q-1, READ its row, only then publish \
 	   mine and my counter -- a wave that sees my counter at q knows I have already read what it wrote two steps ago into the slot \
@@ -579,7 +580,7 @@ constexpr int C_ROWS_PER_WAVE = 2 * C_P0_ROWS + 3 * C_B_ROWS;     // 34 rows of 
 	} \
 	/* ---- sweep 3: output plane q-3 ------------------------------------------------------------------------------- */ \
 	if ((S3) && q - 3 >= zb && q - 3 < ze) { \
-		char* ob_ = reinterpret_cast<char*>(p_out + (size_t)g.lz(q - 3) * plane); \
+		char* ob_ = po; \
 		_Pragma("unroll") for (int m = 0; m < RC; ++m) { \
 			const int kc_ = (UP) ? m + 1 : m;                            /* level-2 index of this row */ \
 			const float4 c_ = P2[CTR][kc_]; \
@@ -591,6 +592,7 @@ constexpr int C_ROWS_PER_WAVE = 2 * C_P0_ROWS + 3 * C_B_ROWS;     // 34 rows of 
 			if (strip_live) *reinterpret_cast<float4*>(ob_ + opaque32(roff[(UP) ? m + 3 : m + 1])) = x_; \
 		} \
 	} \
+	po += plane_bytes; \
 } while (0)
 
 __global__ __launch_bounds__(256, 1) void k_jacobi_strip3c(const Geom g, const float* __restrict__ p_in,
@@ -654,6 +656,10 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip3c(const Geom g, const f
 	const uint32_t xf_mine = xf0 + 4u * (uint32_t)wave, xf_partner = xf0 + 4u * (uint32_t)(wave ^ 1);
 	const uint32_t xb0 = (uint32_t)(size_t)(__attribute__((address_space(3))) float4*)xbuf;   // LDS byte address of the mailbox
 	int q = qs;
+	const size_t plane_bytes = plane * 4;
+	const char* pp = reinterpret_cast<const char*>(p_in) + ((ptrdiff_t)g.lz(qs) + 1) * (ptrdiff_t)plane_bytes;
+	const char* pbq = reinterpret_cast<const char*>(b) + (ptrdiff_t)g.lz(qs) * (ptrdiff_t)plane_bytes;
+	char* po = reinterpret_cast<char*>(p_out) + ((ptrdiff_t)g.lz(qs) - 3) * (ptrdiff_t)plane_bytes;     // (only dereferenced for planes inside the chunk)
 #define FX_STRIP3C_RUN(UP) do { \
 		if (fill) { \
 			FX_STRIP3C_STEP(0, UP, false, false, false); ++q; \
