@@ -12,6 +12,7 @@
 // Per-cell arithmetic and association order are those of k_jacobi_v4: results are bit-identical to two single
 // sweeps (tests/test_gpu_sim.py).
 #include "fx_internal.h"
+#include "fx_pk.h"
 #include <cstdlib>
 
 namespace fx {
@@ -55,13 +56,7 @@ __device__ __forceinline__ float4 relax4(float4 c, float4 U, float4 D, float4 F,
 // wall cells; they keep the DPP's `old` operand, which is set to the cell itself -- no select per update
 __device__ __forceinline__ float4 relax4_row(float4 c, float4 U, float4 D, float4 F, float4 Bk, float4 bb)
 {
-	const float L = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, c.x), __builtin_bit_cast(int, c.w), 0x138, 0xf, 0xf, false));
-	const float Rr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, c.w), __builtin_bit_cast(int, c.x), 0x130, 0xf, 0xf, false));
-	const float4 Lv = make_float4(L, c.x, c.y, c.z), Rv = make_float4(c.y, c.z, c.w, Rr);
-	float4 x = add4(add4(add4(add4(add4(sub4(Lv, bb), Rv), U), D), F), Bk);
-	const float inv = __uint_as_float(0x3e2aaaabu);
-	x.x *= inv; x.y *= inv; x.z *= inv; x.w *= inv;
-	return x;
+	return relax4_pairs(c, U, D, F, Bk, bb, 0.0f, true, true);         // (fx_pk.h)
 }
 
 // same XCD-aware tile order as fx_sim.hip (see xcd_tile there)

@@ -60,6 +60,7 @@
 // issued instructions per z step (rocprofv3: 9.9 k VALU + 1.3 k scalar + 1.0 k LDS + 0.45 k vector-memory per wave and
 // launch, a wave issuing 61 % of its cycles).
 #include "fx_internal.h"
+#include "fx_pk.h"
 #include <climits>
 #include <cstdlib>
 
@@ -70,40 +71,12 @@ namespace {
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
-// ((((((L - b) + R) + U) + D) + F) + B) * (1/6) on a float4 column; x neighbours by DPP wave shifts
-// The x-shifted operands (L, c.x | c.y, c.z) and (c.y, c.z | c.w, R) are built as register PAIRS for the packed adds by three
-// v_pk_mov_b32 -- (c.x, c.x), (c.y, c.z), (c.w, c.w), the DPP shift then lands in one half of the first / last -- instead of the
-// six v_mov_b32 the compiler spends on them (inline assembly: it only finds v_pk_mov_b32 now and then): 8 -> 5 instructions of
-// plumbing per 14 of arithmetic.
-typedef float fx_f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ fx_f2 pk_mov(fx_f2 a, fx_f2 b, int sel)
-{
-	fx_f2 d;
-	if (sel == 0) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(d) : "v"(a), "v"(b));          // (a.lo, b.lo)
-	else if (sel == 1) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(d) : "v"(a), "v"(b));     // (a.hi, b.lo)
-	else asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(d) : "v"(a), "v"(b));                   // (a.hi, b.hi)
-	return d;
-}
-
+// ((((((L - b) + R) + U) + D) + F) + B) * (1/6) on a float4 column; x neighbours by DPP wave shifts, the x-shifted operand pairs
+// built by v_pk_mov_b32 (fx_pk.h: 8 -> 5 instructions of plumbing per 14 of arithmetic; k_jacobi_strip3c 41.2 -> 40.7 us per launch)
 __device__ __forceinline__ float4 relax4(float4 c, float4 U, float4 D, float4 F, float4 Bk, float4 bb, bool x_first, bool x_last)
 {
-	// DPP wave_shr:1 / wave_shl:1 instead of __shfl_up/_down (= ds_bpermute): see fx_jacobi_strip.hip
-	// X = 256: the row is the wave, so the lanes without a source (0 for wave_shr, 63 for wave_shl) are exactly the clamped
-	// wall cells -- they keep the DPP's `old` operand, which is set to the cell itself: no select needed
 	(void)x_first; (void)x_last;
-	const fx_f2 c01 = { c.x, c.y }, c23 = { c.z, c.w };
-	fx_f2 lx = pk_mov(c01, c01, 0);                                  // (c.x, c.x)
-	const fx_f2 mid = pk_mov(c01, c23, 1);                           // (c.y, c.z)
-	fx_f2 rx = pk_mov(c23, c23, 2);                                  // (c.w, c.w)
-	lx.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, lx.x), __builtin_bit_cast(int, c.w), 0x138, 0xf, 0xf, false));
-	rx.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, rx.y), __builtin_bit_cast(int, c.x), 0x130, 0xf, 0xf, false));
-	const fx_f2 b01 = { bb.x, bb.y }, b23 = { bb.z, bb.w }, U01 = { U.x, U.y }, U23 = { U.z, U.w }, D01 = { D.x, D.y }, D23 = { D.z, D.w };
-	const fx_f2 F01 = { F.x, F.y }, F23 = { F.z, F.w }, B01 = { Bk.x, Bk.y }, B23 = { Bk.z, Bk.w };
-	fx_f2 s01 = (((((lx - b01) + mid) + U01) + D01) + F01) + B01;
-	fx_f2 s23 = (((((mid - b23) + rx) + U23) + D23) + F23) + B23;
-	const float inv = __uint_as_float(0x3e2aaaabu);
-	s01 *= inv; s23 *= inv;
-	return make_float4(s01.x, s01.y, s23.x, s23.y);
+	return relax4_pairs(c, U, D, F, Bk, bb, 0.0f, true, true);
 }
 
 __device__ __forceinline__ int xcd_index3(int n, int remap)
@@ -305,14 +278,8 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip3(const Geom g, const fl
 template <bool right_half>
 __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 F, float4 Bk, float4 bb, float edge)
 {
-	const float oldL = right_half ? edge : c.x, oldR = right_half ? c.w : edge;    // compile-time: the step is expanded once per half
-	const float L = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldL), __builtin_bit_cast(int, c.w), 0x138, 0xf, 0xf, false));
-	const float Rr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldR), __builtin_bit_cast(int, c.x), 0x130, 0xf, 0xf, false));
-	const float4 Lv = make_float4(L, c.x, c.y, c.z), Rv = make_float4(c.y, c.z, c.w, Rr);
-	float4 x = add4(add4(add4(add4(add4(sub4(Lv, bb), Rv), U), D), F), Bk);
-	const float inv = __uint_as_float(0x3e2aaaabu);
-	x.x *= inv; x.y *= inv; x.z *= inv; x.w *= inv;
-	return x;
+	// compile-time: the step is expanded once per half; the lane at the cut takes `edge`, the lane at the wall its own cell
+	return relax4_pairs(c, U, D, F, Bk, bb, edge, !right_half, right_half);
 }
 
 #define FX_STRIP3H_STEP(PH, RIGHT) do { \
