@@ -17,6 +17,7 @@
 // Restates CSPoisson.hlsli:8-26 (/root/reference/FluidX12/Content/Shaders/) like k_jacobi_v4; per-cell arithmetic and
 // association order are unchanged, so the result is bit-identical to two single sweeps (tests/test_gpu_sim.py).
 #include "fx_internal.h"
+#include "fx_pk.h"
 #include <cstdlib>
 
 namespace fx {
@@ -27,13 +28,15 @@ namespace {
 // wave_shr:1, 63 for wave_shl:1) are the clamped wall cells and keep the `old` operand = the cell itself
 __device__ __forceinline__ float2 relax2(float2 c, float2 U, float2 D, float2 F, float2 Bk, float2 bb)
 {
-	const float L = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, c.x), __builtin_bit_cast(int, c.y), 0x138, 0xf, 0xf, false));
-	const float R = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, c.y), __builtin_bit_cast(int, c.x), 0x130, 0xf, 0xf, false));
-	const float inv = __uint_as_float(0x3e2aaaabu);
-	float2 x;
-	x.x = ((((((L - bb.x) + c.y) + U.x) + D.x) + F.x) + Bk.x) * inv;
-	x.y = ((((((c.x - bb.y) + R) + U.y) + D.y) + F.y) + Bk.y) * inv;
-	return x;
+	// (L, c.x) and (c.y, R) as register pairs: (c.x, c.x) / (c.y, c.y) by one v_pk_mov_b32 each (fx_pk.h), the DPP shift lands in one half
+	const fx_f2 cc = { c.x, c.y };
+	fx_f2 lx = pk_mov(cc, cc, 0), rx = pk_mov(cc, cc, 2);
+	lx.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, lx.x), __builtin_bit_cast(int, c.y), 0x138, 0xf, 0xf, false));
+	rx.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, rx.y), __builtin_bit_cast(int, c.x), 0x130, 0xf, 0xf, false));
+	const fx_f2 b2 = { bb.x, bb.y }, U2 = { U.x, U.y }, D2 = { D.x, D.y }, F2 = { F.x, F.y }, B2 = { Bk.x, Bk.y };
+	fx_f2 x = (((((lx - b2) + rx) + U2) + D2) + F2) + B2;
+	x *= __uint_as_float(0x3e2aaaabu);
+	return make_float2(x.x, x.y);
 }
 
 
