@@ -2,7 +2,7 @@
 # round 2 (second half), final-state measurements: bench lines (configs 2-5, loop-back 2/4/8), kernel traces, PMC traffic, SQ counters, GPU test log
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r03m; mkdir -p $O
+O=gpurun_out/r03p; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_20.json 2>> $O/bench.err
 python bench.py --config 2 --steps 100 --warmup 16 --no-cpu-baseline > $O/bench_128.json 2>> $O/bench.err
