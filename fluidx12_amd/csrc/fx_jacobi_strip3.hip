@@ -282,14 +282,15 @@ __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 
 	return relax4_pairs(c, U, D, F, Bk, bb, edge, !right_half, right_half);
 }
 
-#define FX_STRIP3H_STEP(PH, RIGHT) do { \
+#define FX_STRIP3H_STEP(PH, RIGHT, S1, S2, S3) do { \
 	constexpr int NEW = (PH) % 3, CTR = ((PH) + 2) % 3, OLD = ((PH) + 1) % 3; \
 	/* ---- sweep 1: level-1 plane q-1, rows j <-> y0-2+j; input rows i <-> y0-3+i ------------------------------- */ \
 	if (q == 0) {                                   /* input plane -1 := plane 0, once (clamped front neighbour) */ \
 		_Pragma("unroll") for (int i = 0; i < R3 + 6; ++i) FX_LDS(s_ctr, i) = NP[i]; \
 		_Pragma("unroll") for (int i = 0; i < R3 + 6; ++i) E0c[i] = E0n[i]; \
 	} \
-	if (q - 1 == g.Zg) {                            /* level-1 plane Zg := plane Zg-1 */ \
+	if (!(S1)) {                                    /* (a fill step: see the kernel) */ \
+	} else if (q - 1 == g.Zg) {                     /* level-1 plane Zg := plane Zg-1 */ \
 		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) P1[NEW][j] = P1[CTR][j]; \
 	} else { \
 		/* all 18 LDS rows first: with one wave per SIMD a ds_read that is issued next to its use costs its whole latency */ \
@@ -305,18 +306,22 @@ __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 
 	/* hand-over 1: the partner half-row wave's first-sweep cells next to the cut of ITS step q-1 (plane q-2, for my sweep 2), then \
 	   mine of this step (plane q-1).  Order as in k_jacobi_strip3c: wait, read, only then publish data and counter -- a wave that \
 	   sees my counter at q knows I have read what it wrote two steps ago into the slot it reuses; a wave may run a step ahead */ \
-	while (*reinterpret_cast<volatile int*>(xflag + (wave ^ 1)) < q - 1) __builtin_amdgcn_s_sleep(1); \
-	asm volatile("" ::: "memory"); \
 	float e1_[R3 + 4]; \
-	{ \
-		const float* xr_ = xbuf + (((q - 1) & 1) * WPG + (wave ^ 1)) * 16; \
-		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) e1_[j] = xr_[j]; \
-	} \
-	if (lane == edge_lane) { \
-		float* xw_ = xbuf + ((q & 1) * WPG + wave) * 16; \
-		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) xw_[j] = (RIGHT) ? P1[NEW][j].x : P1[NEW][j].w; \
+	if (S1) { \
+		while (*reinterpret_cast<volatile int*>(xflag + (wave ^ 1)) < q - 1) __builtin_amdgcn_s_sleep(1); \
 		asm volatile("" ::: "memory"); \
-		*reinterpret_cast<volatile int*>(xflag + wave) = q;          /* LDS operations of a wave execute in order: the data is there before the counter */ \
+		{ \
+			const float* xr_ = xbuf + (((q - 1) & 1) * WPG + (wave ^ 1)) * 16; \
+			_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) e1_[j] = xr_[j]; \
+		} \
+		if (lane == edge_lane) { \
+			float* xw_ = xbuf + ((q & 1) * WPG + wave) * 16; \
+			_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) xw_[j] = (RIGHT) ? P1[NEW][j].x : P1[NEW][j].w; \
+			asm volatile("" ::: "memory"); \
+			*reinterpret_cast<volatile int*>(xflag + wave) = q;      /* LDS operations of a wave execute in order: the data is there before the counter */ \
+		} \
+	} else { \
+		_Pragma("unroll") for (int j = 0; j < R3 + 4; ++j) e1_[j] = 0.0f; \
 	} \
 	/* ---- the b rows sweeps 2 and 3 will need (slots untouched by the writes below), read now so that they arrive behind the \
 	   writes and the prefetch instead of in front of each update ---- */ \
@@ -339,7 +344,8 @@ __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 
 		_Pragma("unroll") for (int i = 0; i < R3 + 4; ++i) NB[i] = *reinterpret_cast<const float4*>(bb_ + opaque32(roff[i + 1])); \
 	} \
 	/* ---- sweep 2: level-2 plane q-2, rows k <-> y0-1+k; b[q-2] is s_b3 (rows y0-1 ..) ------------------------------- */ \
-	if (q - 2 == g.Zg) { \
+	if (!(S2)) { \
+	} else if (q - 2 == g.Zg) { \
 		_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) P2[NEW][k] = P2[CTR][k]; \
 	} else { \
 		_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) { \
@@ -354,21 +360,25 @@ __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 
 		} \
 	} \
 	/* hand-over 2: the second-sweep cells (partner's plane q-3 for my sweep 3; mine of plane q-2), same order, their own counter */ \
-	while (*reinterpret_cast<volatile int*>(xflag + WPG + (wave ^ 1)) < q - 1) __builtin_amdgcn_s_sleep(1); \
-	asm volatile("" ::: "memory"); \
 	float e2_[R3 + 2]; \
-	{ \
-		const float* xr_ = xbuf + (((q - 1) & 1) * WPG + (wave ^ 1)) * 16 + 8; \
-		_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) e2_[k] = xr_[k]; \
-	} \
-	if (lane == edge_lane) { \
-		float* xw_ = xbuf + ((q & 1) * WPG + wave) * 16 + 8; \
-		_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) xw_[k] = (RIGHT) ? P2[NEW][k].x : P2[NEW][k].w; \
+	if (S2) { \
+		while (*reinterpret_cast<volatile int*>(xflag + WPG + (wave ^ 1)) < q - 1) __builtin_amdgcn_s_sleep(1); \
 		asm volatile("" ::: "memory"); \
-		*reinterpret_cast<volatile int*>(xflag + WPG + wave) = q; \
+		{ \
+			const float* xr_ = xbuf + (((q - 1) & 1) * WPG + (wave ^ 1)) * 16 + 8; \
+			_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) e2_[k] = xr_[k]; \
+		} \
+		if (lane == edge_lane) { \
+			float* xw_ = xbuf + ((q & 1) * WPG + wave) * 16 + 8; \
+			_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) xw_[k] = (RIGHT) ? P2[NEW][k].x : P2[NEW][k].w; \
+			asm volatile("" ::: "memory"); \
+			*reinterpret_cast<volatile int*>(xflag + WPG + wave) = q; \
+		} \
+	} else { \
+		_Pragma("unroll") for (int k = 0; k < R3 + 2; ++k) e2_[k] = 0.0f; \
 	} \
 	/* ---- sweep 3: output plane q-3, rows m <-> y0+m; b[q-3] is s_bfree (its rows 1..4) ------------------------------- */ \
-	if (q - 3 >= zb && q - 3 < ze) { \
+	if ((S3) && q - 3 >= zb && q - 3 < ze) { \
 		char* ob_ = reinterpret_cast<char*>(p_out + (size_t)g.lz(q - 3) * plane); \
 		_Pragma("unroll") for (int m = 0; m < R3; ++m) { \
 			const float4 c_ = P2[CTR][m + 1]; \
@@ -443,29 +453,32 @@ __global__ __launch_bounds__(64 * WPG, 4 / WPG) void k_jacobi_strip3h(const Geom
 #pragma unroll
 		for (int i = 0; i < R3 + 4; ++i) NB[i] = *reinterpret_cast<const float4*>(bbase + roff[i + 1]);
 	}
-	if (lane == 0) { xflag[wave] = qs - 1; xflag[WPG + wave] = qs - 1; }   // both waves of a pair share the chunk, hence qs
+	// the pipeline's fill as six peeled steps without the sweeps that feed nothing stored (see k_jacobi_strip3c); the hand-over
+	// counters start where the first active hand-over of each level expects them
+	const bool fill = qs == zb - 3;
+	if (lane == 0) { xflag[wave] = fill ? zb - 2 : qs - 1; xflag[WPG + wave] = fill ? zb : qs - 1; }   // both waves of a pair share the chunk
 	__syncthreads();
 	int q = qs;
-	if (right_half) {                                                 // wave-uniform: each half runs its own expansion, free of per-update selects
-		for (;;) {
-			FX_STRIP3H_STEP(0, true);
-			if (++q > q_last) break;
-			FX_STRIP3H_STEP(1, true);
-			if (++q > q_last) break;
-			FX_STRIP3H_STEP(2, true);
-			if (++q > q_last) break;
-		}
-	} else {
-		for (;;) {
-			FX_STRIP3H_STEP(0, false);
-			if (++q > q_last) break;
-			FX_STRIP3H_STEP(1, false);
-			if (++q > q_last) break;
-			FX_STRIP3H_STEP(2, false);
-			if (++q > q_last) break;
-		}
-	}
+#define FX_STRIP3H_RUN(RIGHT) do { \
+		if (fill) { \
+			FX_STRIP3H_STEP(0, RIGHT, false, false, false); ++q; \
+			FX_STRIP3H_STEP(1, RIGHT, false, false, false); ++q; \
+			FX_STRIP3H_STEP(2, RIGHT, true, false, false); ++q; \
+			FX_STRIP3H_STEP(0, RIGHT, true, false, false); ++q; \
+			FX_STRIP3H_STEP(1, RIGHT, true, true, false); ++q; \
+			FX_STRIP3H_STEP(2, RIGHT, true, true, false); ++q; \
+		} \
+		for (;;) { \
+			FX_STRIP3H_STEP(0, RIGHT, true, true, true); \
+			if (++q > q_last) break; \
+			FX_STRIP3H_STEP(1, RIGHT, true, true, true); \
+			if (++q > q_last) break; \
+			FX_STRIP3H_STEP(2, RIGHT, true, true, true); \
+			if (++q > q_last) break; \
+		} } while (0)
+	if (right_half) FX_STRIP3H_RUN(true); else FX_STRIP3H_RUN(false);   // wave-uniform: each half runs its own expansion, free of per-update selects
 }
+#undef FX_STRIP3H_RUN
 #undef FX_STRIP3H_STEP
 
 // ---------------------------------------------------------------------------------------------------------------------------
