@@ -471,7 +471,7 @@ def test_advect_lds_path_bit_identical(dims, address, scale, storage, monkeypatc
     assert np.array_equal(got["1"][0][:, far], vo[:, far]) and np.array_equal(got["1"][1][far], co[far])
 
 
-@pytest.mark.parametrize("grid,steps,storage", [(256, 40, "fp32"), (128, 60, "fp32"), (256, 24, "fp16")])
+@pytest.mark.parametrize("grid,steps,storage", [(256, 40, "fp32"), (128, 60, "fp32"), (256, 24, "fp16"), (150, 30, "fp32")])
 def test_round2_kernels_reproduce_the_round1_kernels_over_a_whole_run(grid, steps, storage):
     """the kernels added in round 2 (LDS-staged advection, cooperative three-sweep strips, the X = 128 block kernel, four-cell
     projection / divergence) against the ones they replaced, over a whole run from the zero state at full BASELINE size: the plume
@@ -486,7 +486,8 @@ def test_round2_kernels_reproduce_the_round1_kernels_over_a_whole_run(grid, step
         "import sys, hashlib, numpy as np\n"
         "sys.path.insert(0, %r)\n"
         "import fluidx12_amd as fx\n"
-        "f = fx.Fluid(); assert f.Init(64, 64, (%d, %d, %d), jacobi_iters=40, storage=%r)\n"
+        "import os\n"
+        "f = fx.Fluid(); assert f.Init(64, 64, (%d, %d, %d), jacobi_iters=40, storage=%r, **({'jacobi_fuse': 1} if os.environ.get('FX_TEST_PLAIN') else {}))\n"
         "dt = np.float32(f.default_time_step())\n"
         "for k in range(%d):\n"
         "    f.UpdateFrame(dt, k %% 3); f.Simulate(k %% 3)\n"
@@ -496,10 +497,13 @@ def test_round2_kernels_reproduce_the_round1_kernels_over_a_whole_run(grid, step
         "    a = f.download(fid); assert np.isfinite(a).all() and a.any(); h.update(a.tobytes())\n"
         "print('DIGEST', h.hexdigest())\n" % (root, grid, grid, grid, storage, steps))
     old = dict(FLUIDX_ADVECT_LDS="0", FLUIDX_STRIP3_COOP="0", FLUIDX_JACOBI_BLOCK="0", FLUIDX_PROJECT_V4="0")
+    # ... and against the plainest kernels the library has: one Jacobi sweep per launch (k_jacobi_v4: none of the register-pair
+    # plumbing of fx_pk.h), gather advection, scalar projection (tools/long_run_parity.py runs the same comparison over hundreds of steps)
+    plain = dict(old, FX_TEST_PLAIN="1", FLUIDX_ADVECT_FAST="0", FLUIDX_ROW_VW="0", FLUIDX_JACOBI_BLOCKG="0")
     digests = []
-    for extra in ({}, old):
+    for extra in ({}, old, plain):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
-    assert digests[0] == digests[1]
+    assert digests[0] == digests[1] == digests[2]

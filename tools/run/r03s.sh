@@ -1,0 +1,3 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+python -m pytest tests -m gpu -x -q -k "round2_kernels" 2>&1 | grep -E "passed|failed" | tail -1
