@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-for zm in 0 1 0 1; do FLUIDX_STRIP3_ZMEET=$zm python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-render 2>/dev/null | python -c "
+for zc in 16 17 16 17; do FLUIDX_STRIP3_ZCHUNK=$zc python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-render 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('zmeet $zm', '%.4g'%d['value'], round(d['ms_per_step'],4), round(d['stage_ms_per_step']['jacobi'],4), round(d['roofline']['avg_launch_us'],2))"; done
+print('zchunk $zc', '%.4g'%d['value'], round(d['ms_per_step'],4), round(d['stage_ms_per_step']['jacobi'],4), round(d['roofline']['avg_launch_us'],2))"; done
