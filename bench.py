@@ -426,6 +426,7 @@ def main():
                            "transform_ms_incl_upload": (time.perf_counter() - t_sh) / 5 * 1e3,
                            "sh_band0_rgb": [float(v) for v in probe.GetSH()[0]]}
                 fluid.SetSH(probe.GetSH())
+            fluid.timing_enable(True)                               # (the timed loop leaves the marks off behind its last marked step)
             fluid.UpdateFrame(0.0, 0, view, proj, eye)
             fluid.Render(0, fx.Fluid.OPTIMIZED)
             fluid.Synchronize()

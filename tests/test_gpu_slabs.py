@@ -518,6 +518,31 @@ def test_bench_config4_in_loopback():
     assert "64 planes per rank" in d["config"]["parallelism"] and d["value"] > 0
 
 
+def test_bench_single_gpu_line_is_complete():
+    """the N = 1 bench line as the driver runs it (`--steps 20 --warmup 5`, smaller grid here): every figure it promises is there and
+    non-zero -- stage times and the roofline launch average from the marked steps (every fourth), the render passes measured behind
+    the timed loop (whose last marked step leaves the marks off), the CPU baseline"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--grid", "128", "--steps", "20", "--warmup", "5", "--cpu-budget", "2"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["value"] > 0 and d["ms_per_step"] > 0
+    assert d["timing_marks"] == {"every": 4, "marked_steps": 5}
+    assert all(d["stage_ms_per_step"][k] > 0 for k in ("advect", "divergence", "jacobi", "project"))
+    r = d["roofline"]
+    assert r["avg_launch_us"] > 0 and r["achieved"] > 0 and 0 < r["frac_compulsory"] < 1.5 and r["launches"] > 0
+    rn = d["render"]
+    assert rn["light_pass_ms"] > 0 and rn["view_pass_ms"] > 0 and rn["cube_resolve_ms"] > 0 and rn["direct_march_ms"] > 0 and rn["rays_per_s"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+
+
 @pytest.mark.parametrize("overlap", [2, 0])
 def test_slabs_with_lds_advection(overlap, monkeypatch):
     """k_advect_lds inside the slab schedule (interior range with own-planes-only back-traces, full range after the exchange,
