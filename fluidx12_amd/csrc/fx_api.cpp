@@ -26,6 +26,7 @@ namespace {
 
 const uint32_t kNumMips = 5;            // Fluid.cpp:229
 const uint32_t kDefaultAdvectHalo = 6;  // measured z back-trace reach at 256^3: <= 3.5 cells over 400 steps (tools/reach_probe.py)
+const uint32_t kFreezeStatRing = 1024;   // per-step statistics words of the sparse faithful solver kept on the device
 const uint32_t kDefaultJacobiHalo = 8;   // sweeps per pressure exchange: 5 messages per 40 sweeps, +11% halo sweeps at 64 planes/rank
 
 hipStream_t pick_stream(fx_ctx* ctx, void* s) { return s ? (hipStream_t)s : ctx->stream; }
@@ -120,7 +121,7 @@ void free_all(fx_ctx* c)
 		if (c->p[i]) (void)hipFree(c->p[i]);
 	}
 	void* others[] = { c->env, c->occ, c->target, c->target_float, c->p_face[0], c->p_face[1], c->b, c->frozen, c->lightmap, c->cube, c->sh_dev, c->halo_overflow, c->stage,
-		c->sh_scratch[0], c->sh_scratch[1], c->sh_scratch[2], c->sh_scratch[3] };
+		c->sh_scratch[0], c->sh_scratch[1], c->sh_scratch[2], c->sh_scratch[3], c->p_aux, c->fz_mask[0], c->fz_mask[1], c->fz_tile_next, c->fz_stat };
 	for (void* q : others) if (q) (void)hipFree(q);
 	for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
 	if (c->step_rec) (void)hipFree(c->step_rec);
@@ -400,12 +401,51 @@ int clear_freeze_masks(std::vector<fx_ctx*>& M, hipStream_t s)
 	return FX_OK;
 }
 
+// FX_JACOBI_FAITHFUL on a single domain: the sparse solver of fx_jacobi_freeze.hip.  Level 1 everywhere (into p[other] AND p_aux;
+// the input buffer becomes the spare), then ceil((iters - 1) / T) launches over the tiles that still relax, all enqueued; the
+// result is in the last launch's output buffer (settled tiles agree in both).  Bit-identical to `iters` generic sweeps with the
+// byte mask (tests/test_gpu_sim.py::test_freeze_fast_path_*).
+int jacobi_freeze(fx_ctx* ctx, hipStream_t s, uint32_t iters)
+{
+	DeviceGuard dg(ctx->device);
+	ScopedMark mk(ctx, s, MK_JACOBI);
+	if (++ctx->fz_gen >= (1u << 22)) {                                  // launch ids (gen * 128 + n) << 1 stay below 2^32: start over with clean marks
+		FX_HIP(hipMemsetAsync(ctx->fz_tile_next, 0, (size_t)jacobi_freeze_tiles(ctx->g) * sizeof(uint32_t), s));
+		FX_HIP(hipMemsetAsync(ctx->fz_stat, 0, kFreezeStatRing * sizeof(uint32_t), s));
+		ctx->fz_gen = 1; ctx->fz_gen_mark = 0;
+	}
+	const uint32_t gen = ctx->fz_gen, stat_hi = gen << 8;
+	uint32_t* stat = ctx->fz_stat + gen % kFreezeStatRing;
+	ctx->fz_iters[gen % kFreezeStatRing] = iters;
+	float* src = ctx->p[ctx->p_cur];
+	float* a = ctx->p[ctx->p_cur ^ 1];
+	float* d = ctx->p_aux;
+	uint8_t* ma = ctx->fz_mask[0];
+	uint8_t* md = ctx->fz_mask[1];
+	uint32_t launch = gen * 128u + 2u;
+	FX_HIP(launch_freeze_dense(ctx->g, src, ctx->b, a, d, ma, md, ctx->fz_tile_next, launch, stat, stat_hi, s));
+	mk.launches = 1; mk.sweeps = 1;
+	const int T = jacobi_freeze_levels_per_launch();
+	int level = 1;
+	for (uint32_t left = iters - 1; left > 0; ++launch) {
+		const int t = (int)std::min<uint32_t>((uint32_t)T, left);
+		FX_HIP(launch_freeze_tiles(ctx->g, a, ctx->b, d, ma, md, ctx->fz_tile_next, launch, t, level, stat, stat_hi, s));
+		std::swap(a, d); std::swap(ma, md);
+		left -= (uint32_t)t; level += t;
+		mk.launches += 1; mk.sweeps += (uint64_t)t;
+	}
+	ctx->p[0] = a; ctx->p[1] = d; ctx->p_aux = src; ctx->p_cur = 0;
+	return FX_OK;
+}
+
 // exchange, then k sweeps, exchange, ... on one stream
 int jacobi_serial(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t iters)
 {
 	const bool multi = multi_rank(lead);
 	const int k = multi ? lead->opt_round : (int)iters;
 	int rc;
+	if (!multi && lead->frozen && lead->fz_tile_next && jacobi_freeze_supported(lead->g) && iters <= 255 && (iters + (uint32_t)jacobi_freeze_levels_per_launch() - 2) / (uint32_t)jacobi_freeze_levels_per_launch() <= 120)   // levels fit the stat word, launch ids stay inside the step's 128
+		return jacobi_freeze(lead, s, iters);
 	if ((rc = clear_freeze_masks(M, s))) return rc;
 	const ExchSpec bspec{ EX_DIV, k - 1, 0 };
 	if ((rc = do_exchange(lead, M, &bspec, 1, s))) return rc;
@@ -707,6 +747,20 @@ int fx_create(fx_ctx** out, const fx_desc* d)
 		if (d->jacobi_mode == FX_JACOBI_FAITHFUL && !(d->flags & FX_FLAG_RENDER_ONLY)) {
 			FX_HIP(hipMalloc((void**)&ctx->frozen, cells));
 			FX_HIP(hipMemsetAsync(ctx->frozen, 0, cells, ctx->stream));
+			if (jacobi_freeze_supported(ctx->g)) {                           // the sparse solver of fx_jacobi_freeze.hip
+				const size_t mb = jacobi_freeze_mask_bytes(ctx->g), nt = (size_t)jacobi_freeze_tiles(ctx->g);
+				FX_HIP(hipMalloc((void**)&ctx->p_aux, cells * 4));
+				FX_HIP(hipMemsetAsync(ctx->p_aux, 0, cells * 4, ctx->stream));
+				for (int i = 0; i < 2; ++i) {
+					FX_HIP(hipMalloc((void**)&ctx->fz_mask[i], mb));
+					FX_HIP(hipMemsetAsync(ctx->fz_mask[i], 0, mb, ctx->stream));
+				}
+				FX_HIP(hipMalloc((void**)&ctx->fz_tile_next, nt * sizeof(uint32_t)));
+				FX_HIP(hipMemsetAsync(ctx->fz_tile_next, 0, nt * sizeof(uint32_t), ctx->stream));
+				FX_HIP(hipMalloc((void**)&ctx->fz_stat, kFreezeStatRing * sizeof(uint32_t)));
+				FX_HIP(hipMemsetAsync(ctx->fz_stat, 0, kFreezeStatRing * sizeof(uint32_t), ctx->stream));
+				ctx->fz_iters.assign(kFreezeStatRing, 0);
+			}
 		}
 		FX_HIP(hipMalloc((void**)&ctx->halo_overflow, sizeof(unsigned)));
 		FX_HIP(hipMemsetAsync(ctx->halo_overflow, 0, sizeof(unsigned), ctx->stream));
@@ -1322,7 +1376,20 @@ int fx_timing_read(fx_ctx* ctx, fx_timing* out, int reset)
 	int rc = drain_timing(ctx);
 	if (rc) return rc;
 	*out = ctx->acc;
-	if (reset) std::memset(&ctx->acc, 0, sizeof ctx->acc);
+	// faithful mode, sparse solver: sweeps the reference's loop would have executed, per solve since the last reset (the device
+	// keeps the last level that left a cell relaxing, one word per solve; older solves than the ring holds are not counted)
+	if (ctx->fz_stat && ctx->fz_gen > ctx->fz_gen_mark) {
+		std::vector<uint32_t> ring(kFreezeStatRing);
+		FX_HIP(hipDeviceSynchronize());
+		FX_HIP(hipMemcpy(ring.data(), ctx->fz_stat, kFreezeStatRing * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		const uint32_t first = std::max(ctx->fz_gen_mark + 1, ctx->fz_gen >= kFreezeStatRing ? ctx->fz_gen - kFreezeStatRing + 1 : 1u);
+		for (uint32_t gtag = first; gtag <= ctx->fz_gen; ++gtag) {
+			const uint32_t w = ring[gtag % kFreezeStatRing], lvl = (w >> 8) == gtag ? (w & 0xFFu) : 0u;
+			out->freeze_sweeps += std::min(ctx->fz_iters[gtag % kFreezeStatRing], 1u + lvl);
+			out->freeze_solves += 1;
+		}
+	}
+	if (reset) { std::memset(&ctx->acc, 0, sizeof ctx->acc); ctx->fz_gen_mark = ctx->fz_gen; }
 	return FX_OK;
 }
 

@@ -24,6 +24,15 @@ struct fx_ctx {
 	float* p_face[2];               // slab contexts: scratch levels of the Jacobi face chains (same geometry as p)
 	float* b;                       // divergence
 	uint8_t* frozen;                // faithful-mode freeze mask (null in fixed mode)
+	// faithful mode, single-domain fast path (fx_jacobi_freeze.hip): third pressure buffer, two quad-nibble freeze masks, tile marks,
+	// and a ring of per-step "last level that left a cell relaxing" words
+	float* p_aux = nullptr;
+	uint8_t* fz_mask[2] = { nullptr, nullptr };
+	uint32_t* fz_tile_next = nullptr;
+	uint32_t* fz_stat = nullptr;
+	uint32_t fz_gen = 0;            // solves so far (tags tile marks and stat words)
+	uint32_t fz_gen_mark = 0;       // fz_gen when the timing window opened
+	std::vector<uint32_t> fz_iters; // sweep cap of the solve with tag g, at [g % ring]
 	uint32_t* lightmap;             // R11G11B10F packed (m_lightMap), owned planes only
 	uint8_t* cube;                  // RGBA8 cube map, 5 mips back to back (m_cubeMap)
 	size_t cube_mip_offset[5];

@@ -1,0 +1,331 @@
+// fx_jacobi_freeze.hip -- the reference's OWN pressure solve as a sparse solver: CSPoisson.hlsli:8-26 under CSProject3D.hlsl:13
+// (/root/reference/FluidX12/Content/Shaders/): at most ITER = 64 sweeps, and a cell leaves the loop for good as soon as one
+// sweep changes it by less than 1e-3 (`if (abs(x - x0) < 0.001) break`, :24) -- FX_JACOBI_FAITHFUL, the configuration
+// Fluid.hpp's FluidOptions default to.  Lock-step schedule: sweep k reads level k - 1 everywhere; a cell
+// that broke out ("frozen") keeps the value it stored last, its neighbours keep reading that value.
+//
+// What the flow looks like (oracle, 128^3 / 64^3, steps 1..60): 72-99 % of the cells freeze in the FIRST sweep (the pressure is
+// warm-started and only moves near the plume), the rest in a shrinking region that needs 22-64 sweeps; summed over a step the
+// cells still relaxing amount to 1.0-2.0 sweeps of the grid, not 64.  So:
+//
+//   launch 1   k_freeze_dense   level 1 for every cell, streaming like k_jacobi_v4 (thread = 4 x-cells): p1 goes to TWO buffers
+//                               (A and B; the input lives in a third), the freeze mask (one byte per 4-cell quad, low nibble) to
+//                               two as well, and every 32 x 8 x 8-cell TILE that still has a relaxing cell is marked for launch 2
+//   launch L   k_freeze_tiles<T> T more levels, A -> B -> A ..., only on the marked tiles: a workgroup stages the tile's cone
+//                               (40 x (8 + 2T)^2 cells of p, b and mask) in the LDS, relaxes level by level there (halo cells are
+//                               RECOMPUTED, their freeze decisions included -- the same deterministic arithmetic the owner tile
+//                               does), stores its 32 x 8 x 8 core and marks itself for launch L + 1 while a core cell relaxes.
+//                               A tile whose core froze completely during launch L holds its final values in that launch's output
+//                               buffer only: launch L + 1 copies them across (core only, no LDS), after which both buffers
+//                               agree and the tile is never touched again -- its neighbours read either buffer alike.
+// Nothing is read back by the host: all 1 + ceil((N - 1) / T) launches are enqueued, and launches whose tile marks name nobody
+// find nothing to do.  Results are bit-identical to N lock-step sweeps with the freeze mask (oracle: orc_jacobi mode 1); once
+// every cell is frozen further sweeps change nothing, so the oracle's early exit at "active == 0" is not a different result.
+// The number of sweeps the reference's loop would have executed (1 + the last level that left a cell relaxing, capped at N) is
+// kept in a device word per step (`stat`), for fx_timing / bench.py's byte count.
+//
+// Scope: 3-D single-domain contexts with X % 4 == 0.  Slab contexts, 2-D grids and other widths keep k_jacobi_generic.
+#include "fx_internal.h"
+#include <cstdlib>
+
+namespace fx {
+
+namespace {
+
+constexpr int TCX = 32, TCY = 8, TCZ = 8;     // tile core (cells)
+constexpr int TQ = 10;                        // quads (4 x-cells) per staged row: the core's 8 + one halo quad per side
+constexpr float kFreezeBelow = 0.00100000005f;   // CSPoisson.hlsli:24 as compiled (0x3a83126f)
+
+__device__ __forceinline__ float inv6() { return __uint_as_float(0x3e2aaaabu); }
+
+// one cell: s = ((((((L - b) + R) + U) + D) + F) + B), x = s * 1/6, freezes when |fma(s, 1/6, -x0)| < 1e-3 (the DXBC's mad)
+__device__ __forceinline__ float relax1(float L, float R, float U, float D, float F, float Bk, float bb, float x0, bool& fr)
+{
+	float s = L - bb;
+	s = R + s; s = U + s; s = D + s; s = F + s; s = Bk + s;
+	fr = fabsf(fmaf(s, inv6(), -x0)) < kFreezeBelow;
+	return s * inv6();
+}
+
+// a quad; `m` = frozen nibble on entry (a frozen cell keeps x0), returns the new nibble
+__device__ __forceinline__ uint32_t relax_quad(float4 c, float L, float R, float4 U, float4 D, float4 F, float4 Bk, float4 bb, uint32_t m, float4& o)
+{
+	bool f0, f1, f2, f3;
+	const float x0 = relax1(L, c.y, U.x, D.x, F.x, Bk.x, bb.x, c.x, f0);
+	const float x1 = relax1(c.x, c.z, U.y, D.y, F.y, Bk.y, bb.y, c.y, f1);
+	const float x2 = relax1(c.y, c.w, U.z, D.z, F.z, Bk.z, bb.z, c.z, f2);
+	const float x3 = relax1(c.z, R, U.w, D.w, F.w, Bk.w, bb.w, c.w, f3);
+	o.x = (m & 1u) ? c.x : x0;
+	o.y = (m & 2u) ? c.y : x1;
+	o.z = (m & 4u) ? c.z : x2;
+	o.w = (m & 8u) ? c.w : x3;
+	return m | (f0 ? 1u : 0u) | (f1 ? 2u : 0u) | (f2 ? 4u : 0u) | (f3 ? 8u : 0u);
+}
+
+__device__ __forceinline__ void stat_raise(uint32_t* stat, uint32_t v)
+{
+	if (__hip_atomic_load(stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) atomicMax(stat, v);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// level 1, every cell.  Block = (bx quads, by rows), one plane per blockIdx slice, as k_jacobi_v4.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
+	float* __restrict__ pA, float* __restrict__ pB, uint8_t* __restrict__ mA, uint8_t* __restrict__ mB,
+	uint32_t* __restrict__ tile_next, uint32_t mark, int ntx, int nty, uint32_t* __restrict__ stat, uint32_t stat_val, int rows_per_block)
+{
+	const int X4 = g.X >> 2;
+	const int lane = threadIdx.x;
+	const int gx = (X4 + (int)blockDim.x - 1) / (int)blockDim.x, gy = (g.Y + rows_per_block - 1) / rows_per_block;
+	// XCD k walks the k-th contiguous eighth of the (x, y, z)-ordered block sequence (see xcd_tile in fx_sim.hip)
+	int t = (int)blockIdx.x;
+	{
+		const int n = gx * gy * g.Zg, q = n >> 3, r = n & 7, xcd = t & 7, j = t >> 3;
+		t = xcd * q + min(xcd, r) + j;
+	}
+	const int x4 = (t % gx) * blockDim.x + lane;
+	const int y = ((t / gx) % gy) * rows_per_block + threadIdx.y;
+	const int z = t / (gx * gy);
+	const bool in = x4 < X4 && y < g.Y;
+	uint32_t nib = 0xFu;
+	int tile = -1;
+	if (in) {
+		const size_t plane = g.plane();
+		const int yu = max(y, 1) - 1, yd = min(y + 1, g.Y - 1);
+		const int zf = max(z, 1) - 1, zb = min(z + 1, g.Zg - 1);
+		const size_t zrow = (size_t)z * plane;
+		const size_t c_off = zrow + (size_t)y * g.X + 4 * x4;
+		const float4 c = *reinterpret_cast<const float4*>(p_in + c_off);
+		const float4 U = *reinterpret_cast<const float4*>(p_in + zrow + (size_t)yu * g.X + 4 * x4);
+		const float4 D = *reinterpret_cast<const float4*>(p_in + zrow + (size_t)yd * g.X + 4 * x4);
+		const float4 F = *reinterpret_cast<const float4*>(p_in + (size_t)zf * plane + (size_t)y * g.X + 4 * x4);
+		const float4 Bk = *reinterpret_cast<const float4*>(p_in + (size_t)zb * plane + (size_t)y * g.X + 4 * x4);
+		const float4 bb = *reinterpret_cast<const float4*>(b + c_off);
+		const float L = x4 == 0 ? c.x : p_in[c_off - 1];
+		const float R = x4 == X4 - 1 ? c.w : p_in[c_off + 4];
+		float4 o;
+		nib = relax_quad(c, L, R, U, D, F, Bk, bb, 0u, o);
+		*reinterpret_cast<float4*>(pA + c_off) = o;
+		*reinterpret_cast<float4*>(pB + c_off) = o;
+		const size_t qi = c_off >> 2;
+		mA[qi] = (uint8_t)nib;
+		mB[qi] = (uint8_t)nib;
+		tile = ((z >> 3) * nty + (y >> 3)) * ntx + (x4 >> 3);
+	}
+	// mark the tile for launch 2: one store per run of lanes that share a tile
+	const bool active = nib != 0xFu;
+	const int mine = active ? tile : -1;
+	const int prev = __shfl_up(mine, 1);
+	const int wl = (int)((threadIdx.y * blockDim.x + threadIdx.x) & 63);
+	if (active && (wl == 0 || prev != mine)) tile_next[tile] = mark;
+	if (__ballot(active) != 0ull && wl == 0) stat_raise(stat, stat_val);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// T more levels on the marked tiles.  tile_next[t] = (launch id << 1) | copy_only.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int T, int NT>
+__global__ __launch_bounds__(NT, NT / 128) void k_freeze_tiles(const Geom g, const float* __restrict__ p_src, const float* __restrict__ b,
+	float* __restrict__ p_dst, const uint8_t* __restrict__ m_src, uint8_t* __restrict__ m_dst, uint32_t* __restrict__ tile_next,
+	uint32_t launch_id, int ntx, int nty, int ntiles, int level_base, uint32_t* __restrict__ stat, uint32_t stat_hi)
+{
+	constexpr int E = 8 + 2 * T;                 // staged rows per plane = staged planes
+	constexpr int NQ = E * E * TQ;               // staged quads
+	constexpr int EB = E - 2, NB = EB * EB * TQ; // b is needed one cell less deep
+	__shared__ __attribute__((aligned(16))) float4 Pq[NQ + 2];    // [1 + idx]: the x neighbours of a row's first / last quad stay inside the array
+	__shared__ __attribute__((aligned(16))) float4 Bq[NB];
+	__shared__ uint8_t Mq[NQ];
+	const int tid = threadIdx.x;
+	const int X4 = g.X >> 2;
+	const size_t plane4 = (size_t)X4 * g.Y;      // quads per plane
+
+	for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
+		const uint32_t mark = tile_next[t];
+		if ((mark >> 1) != launch_id) continue;                       // uniform per workgroup
+		const int tx = t % ntx, ty = (t / ntx) % nty, tz = t / (ntx * nty);
+		// ---- a tile that froze completely in the previous launch: carry its core across, then it is settled ---------------------
+		if (mark & 1u) {
+#pragma unroll
+			for (int j = 0; j < 512 / NT; ++j) {
+				const int i = tid + NT * j;                               // 512 core quads
+				const int q = i & 7, yy = (i >> 3) & 7, zz = i >> 6;
+				const int x4 = tx * 8 + q, y = ty * TCY + yy, z = tz * TCZ + zz;
+				if (x4 < X4 && y < g.Y && z < g.Zg) {
+					const size_t qi = (size_t)z * plane4 + (size_t)y * X4 + x4;
+					reinterpret_cast<float4*>(p_dst)[qi] = reinterpret_cast<const float4*>(p_src)[qi];
+					m_dst[qi] = m_src[qi];
+				}
+			}
+			continue;
+		}
+		const int x40 = tx * 8 - 1, y0 = ty * TCY - T, z0 = tz * TCZ - T;   // quad / row / plane of staged index 0
+		// the thread -> (quad, row, plane) decompositions below are the same for every tile: left visible, the compiler hoists all of
+		// them out of the tile loop and spills; opaque, they are a few multiply-shifts per level
+		int tl = tid;
+		asm volatile("" : "+v"(tl));
+		// ---- stage the cone ---------------------------------------------------------------------------------------------------
+		__syncthreads();                                                 // the previous tile of this workgroup is done with the LDS
+		{
+			// branch-free: every load goes to a valid (clamped) address and is issued before the first LDS store; what lies outside
+			// the grid is replaced afterwards ("frozen", never read by a cell inside: its taps are clamped)
+			constexpr int SJ = (NQ + NT - 1) / NT;
+			float4 sv[SJ], sb[SJ];
+			uint32_t sm[SJ];
+#pragma unroll
+			for (int j = 0; j < SJ; ++j) {
+				const int i = min(tl + NT * j, NQ - 1);
+				const int q = i % TQ, r = i / TQ, yy = r % E, zz = r / E;
+				const int x4 = x40 + q, y = y0 + yy, z = z0 + zz;
+				const size_t qi = (size_t)min(max(z, 0), g.Zg - 1) * plane4 + (size_t)min(max(y, 0), g.Y - 1) * X4 + min(max(x4, 0), X4 - 1);
+				sv[j] = reinterpret_cast<const float4*>(p_src)[qi];
+				sb[j] = reinterpret_cast<const float4*>(b)[qi];
+				sm[j] = m_src[qi];
+			}
+			// (the compiler otherwise sinks each load into the guarded store below and waits for them one by one)
+#pragma unroll
+			for (int j = 0; j < SJ; ++j)
+				asm volatile("" : "+v"(sv[j].x), "+v"(sv[j].y), "+v"(sv[j].z), "+v"(sv[j].w), "+v"(sb[j].x), "+v"(sb[j].y), "+v"(sb[j].z), "+v"(sb[j].w), "+v"(sm[j]));
+#pragma unroll
+			for (int j = 0; j < SJ; ++j) {
+				const int i = tl + NT * j;
+				if (i < NQ) {
+					const int q = i % TQ, r = i / TQ, yy = r % E, zz = r / E;
+					const int x4 = x40 + q, y = y0 + yy, z = z0 + zz;
+					const bool in = x4 >= 0 && x4 < X4 && y >= 0 && y < g.Y && z >= 0 && z < g.Zg;
+					Pq[1 + i] = sv[j];
+					Mq[i] = (uint8_t)(in ? sm[j] : 0xFu);
+					if (yy >= 1 && yy < E - 1 && zz >= 1 && zz < E - 1) Bq[((zz - 1) * EB + (yy - 1)) * TQ + q] = sb[j];
+				}
+			}
+		}
+		__syncthreads();
+		// ---- T levels in the LDS: level k on rows / planes [k, E - k) ------------------------------------------------------------
+		int last_active = 0;                                             // last level (1..T) that left a core cell relaxing
+		bool core_active = true;
+#pragma unroll
+		for (int k = 1; k <= T; ++k) {
+			const int n = E - 2 * k;                                      // rows = planes of this level
+			const int q0 = k == T ? 1 : 0, nq = k == T ? 8 : TQ;            // the last level: core quads only
+			const int total = n * n * nq;
+			constexpr int MAXJ = ((E - 2) * (E - 2) * TQ + NT - 1) / NT;
+			float4 nv[MAXJ];
+			uint32_t nm[MAXJ];
+			int thread_core_active = 0;
+#pragma unroll
+			for (int j = 0; j < MAXJ; ++j) {
+				const int i = tl + NT * j;
+				nm[j] = 0x100u;                                            // "nothing to write"
+				if (i < total) {
+					const int q = q0 + i % nq, r = i / nq, yy = k + r % n, zz = k + r / n;
+					const int idx = (zz * E + yy) * TQ + q;
+					const uint32_t m = Mq[idx];
+					const bool core = q >= 1 && q <= 8 && yy >= T && yy < T + TCY && zz >= T && zz < T + TCZ;
+					if (m != 0xFu) {
+						const int x4 = x40 + q, y = y0 + yy, z = z0 + zz;
+						const float4 c = Pq[1 + idx];
+						const float4 U = Pq[1 + (y == 0 ? idx : idx - TQ)];
+						const float4 D = Pq[1 + (y == g.Y - 1 ? idx : idx + TQ)];
+						const float4 F = Pq[1 + (z == 0 ? idx : idx - E * TQ)];
+						const float4 Bk = Pq[1 + (z == g.Zg - 1 ? idx : idx + E * TQ)];
+						const float L = x4 == 0 ? c.x : reinterpret_cast<const float*>(Pq)[4 * idx + 3];          // .w of quad idx - 1
+						const float R = x4 == X4 - 1 ? c.w : reinterpret_cast<const float*>(Pq)[4 * (idx + 2)];    // .x of quad idx + 1
+						const float4 bb = Bq[((zz - 1) * EB + (yy - 1)) * TQ + q];
+						nm[j] = relax_quad(c, L, R, U, D, F, Bk, bb, m, nv[j]) | (uint32_t)(idx << 9);
+						if (core && (nm[j] & 0xFu) != 0xFu) thread_core_active = 1;
+					}
+				}
+				if (T >= 4 && (j & 1)) __builtin_amdgcn_sched_barrier(0);      // two quads' reads in flight at a time: more would spill
+			}
+			__syncthreads();                                               // every read of level k - 1 is done
+#pragma unroll
+			for (int j = 0; j < MAXJ; ++j) {
+				if (nm[j] != 0x100u) {
+					const int idx = (int)(nm[j] >> 9);
+					Pq[1 + idx] = nv[j];
+					Mq[idx] = (uint8_t)(nm[j] & 0xFu);
+				}
+			}
+			const int any = __syncthreads_or(thread_core_active);
+			if (any) last_active = k;
+			core_active = any != 0;
+			if (!core_active) break;                                       // the core is frozen: deeper levels cannot change it
+		}
+		// ---- store the core ---------------------------------------------------------------------------------------------------
+#pragma unroll
+		for (int j = 0; j < 512 / NT; ++j) {
+			const int i = tl + NT * j;
+			const int q = 1 + (i & 7), yy = T + ((i >> 3) & 7), zz = T + (i >> 6);
+			const int x4 = x40 + q, y = y0 + yy, z = z0 + zz;
+			if (x4 < X4 && y < g.Y && z < g.Zg) {
+				const int idx = (zz * E + yy) * TQ + q;
+				const size_t qi = (size_t)z * plane4 + (size_t)y * X4 + x4;
+				reinterpret_cast<float4*>(p_dst)[qi] = Pq[1 + idx];
+				m_dst[qi] = Mq[idx];
+			}
+		}
+		if (tid == 0) {
+			tile_next[t] = ((launch_id + 1) << 1) | (core_active ? 0u : 1u);
+			if (last_active > 0) stat_raise(stat, stat_hi | (uint32_t)(level_base + last_active));
+		}
+	}
+}
+
+int env_int(const char* name, int dflt)
+{
+	const char* v = getenv(name);
+	return v && *v ? atoi(v) : dflt;
+}
+
+}  // namespace
+
+bool jacobi_freeze_supported(const Geom& g)
+{
+	return env_int("FLUIDX_FREEZE_FAST", 1) != 0 && g.Zg > 1 && g.H == 0 && g.z0 == 0 && g.nz == g.Zg && (g.X & 3) == 0 && g.X >= 4;
+}
+
+int jacobi_freeze_tiles(const Geom& g)
+{
+	return ((g.X + TCX - 1) / TCX) * ((g.Y + TCY - 1) / TCY) * ((g.Zg + TCZ - 1) / TCZ);
+}
+
+size_t jacobi_freeze_mask_bytes(const Geom& g) { return g.cells_local() / 4; }
+
+int jacobi_freeze_levels_per_launch()
+{
+	const int v = env_int("FLUIDX_FREEZE_T", 4);        // read per call: the tests switch it inside one process
+	return v < 1 ? 1 : (v > 4 ? 4 : v);
+}
+
+hipError_t launch_freeze_dense(const Geom& g, const float* p_in, const float* b, float* pA, float* pB, uint8_t* mA, uint8_t* mB,
+	uint32_t* tile_next, uint32_t launch_id, uint32_t* stat, uint32_t stat_hi, hipStream_t s)
+{
+	const int X4 = g.X >> 2;
+	const int bx = X4 < 64 ? X4 : 64;
+	int by = 256 / bx; if (by < 1) by = 1; if (by > g.Y) by = g.Y;
+	const int ntx = (g.X + TCX - 1) / TCX, nty = (g.Y + TCY - 1) / TCY;
+	const dim3 block(bx, by, 1), grid(((X4 + bx - 1) / bx) * ((g.Y + by - 1) / by) * g.Zg, 1, 1);
+	hipLaunchKernelGGL(k_freeze_dense, grid, block, 0, s, g, p_in, b, pA, pB, mA, mB, tile_next, launch_id << 1, ntx, nty, stat, stat_hi | 1u, by);
+	return hipGetLastError();
+}
+
+hipError_t launch_freeze_tiles(const Geom& g, const float* p_src, const float* b, float* p_dst, const uint8_t* m_src, uint8_t* m_dst,
+	uint32_t* tile_next, uint32_t launch_id, int levels, int level_base, uint32_t* stat, uint32_t stat_hi, hipStream_t s)
+{
+	const int max_wgs = env_int("FLUIDX_FREEZE_WGS", 1024);
+	const int ntx = (g.X + TCX - 1) / TCX, nty = (g.Y + TCY - 1) / TCY, ntiles = jacobi_freeze_tiles(g);
+	const int nt = env_int("FLUIDX_FREEZE_NT", 512);
+	const dim3 block(nt == 256 ? 256 : 512, 1, 1), grid(ntiles < max_wgs ? ntiles : max_wgs, 1, 1);
+#define FX_FREEZE_LAUNCH(T) if (nt == 256) hipLaunchKernelGGL((k_freeze_tiles<T, 256>), grid, block, 0, s, g, p_src, b, p_dst, m_src, m_dst, tile_next, launch_id, ntx, nty, ntiles, level_base, stat, stat_hi); \
+	else hipLaunchKernelGGL((k_freeze_tiles<T, 512>), grid, block, 0, s, g, p_src, b, p_dst, m_src, m_dst, tile_next, launch_id, ntx, nty, ntiles, level_base, stat, stat_hi)
+	switch (levels) {
+	case 1: FX_FREEZE_LAUNCH(1); break;
+	case 2: FX_FREEZE_LAUNCH(2); break;
+	case 3: FX_FREEZE_LAUNCH(3); break;
+	case 4: FX_FREEZE_LAUNCH(4); break;
+	default: return hipErrorInvalidValue;
+	}
+#undef FX_FREEZE_LAUNCH
+	return hipGetLastError();
+}
+
+}  // namespace fx

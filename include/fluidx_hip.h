@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 4
+#define FX_ABI_VERSION 5
 
 enum fx_status {
 	FX_OK = 0,
@@ -119,6 +119,10 @@ typedef struct fx_timing {
 	 * upper face (summed over the timed steps; halo_advect per face without FX_OPT_ADAPTIVE_HALO) */
 	uint64_t exchange_bytes, advect_halo_planes;
 	double   chain_ms;          /* face chains of the overlapped pressure rounds (their own stream, beside the interior sweeps) */
+	/* ABI 5 (FX_JACOBI_FAITHFUL, single-domain contexts): pressure solves since the last reset, and the sweeps the reference's
+	 * loop (CSPoisson.hlsli:11-25) executes in them -- per solve 1 + the last sweep that left a cell relaxing, at most N.
+	 * jacobi_sweeps above counts the levels ENQUEUED (always N: the sparse solver needs no read-back to stop early). */
+	uint64_t freeze_solves, freeze_sweeps;
 } fx_timing;
 
 int fx_abi_version(void);

@@ -1,0 +1,158 @@
+"""GPU parity tests of the reference's OWN pressure solve (FX_JACOBI_FAITHFUL: CSPoisson.hlsli:8-26 under CSProject3D.hlsl:13, at most 64
+sweeps, per-cell early-out at |dx| < 1e-3) on the sparse solver of fx_jacobi_freeze.hip: a dense first sweep + launches of <= 4
+levels over the 32 x 8 x 8 tiles that still relax.  Bar: BIT-EXACT against the oracle's lock-step replay (orc_jacobi mode 1), the same
+number of executed sweeps, and bit-identical to the one-sweep-per-launch kernel with the byte mask (k_jacobi_generic)."""
+import os
+
+import numpy as np
+import pytest
+
+import fluidx12_amd as fx
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def make(dims, **kw):
+    f = fx.Fluid()
+    assert f.Init(0, 0, dims, **kw), f.last_status
+    return f
+
+
+def plume_like(X, Y, Z, seed, amp=0.05):
+    """pressure and divergence whose sweeps move by more than 1e-3 only in a blob (plus a few specks), like the smoke solver's:
+    most cells freeze in the first sweep, the rest over tens of sweeps"""
+    rng = np.random.default_rng(seed)
+    z, y, x = np.meshgrid(np.arange(Z), np.arange(Y), np.arange(X), indexing="ij")
+    c = rng.uniform(0.3, 0.7, 3)
+    r2 = ((x + .5) / X - c[0]) ** 2 + ((y + .5) / Y - c[1]) ** 2 + ((z + .5) / Z - c[2]) ** 2
+    w = np.exp(-r2 / 0.02)
+    p = (rng.standard_normal((Z, Y, X)) * (amp * w + 2e-4)).astype(f32)
+    b = (rng.standard_normal((Z, Y, X)) * (amp * w + 1e-4)).astype(f32)
+    for _ in range(6):                                   # specks far from the blob: tiles that wake up alone
+        zz, yy, xx = rng.integers(0, Z), rng.integers(0, Y), rng.integers(0, X)
+        b[zz, yy, xx] += f32(0.3)
+    return p, b
+
+
+@pytest.fixture
+def knobs():
+    saved = {k: os.environ.get(k) for k in ("FLUIDX_FREEZE_T", "FLUIDX_FREEZE_NT", "FLUIDX_FREEZE_WGS", "FLUIDX_FREEZE_FAST")}
+    yield os.environ
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def solve(dims, p, b, iters):
+    f = make(dims, jacobi_iters=iters, jacobi_mode="faithful")
+    f.upload(fx.FIELD_PRESSURE, p)
+    f.upload(fx.FIELD_DIVERGENCE, b)
+    f.timing_read(True)
+    f.Jacobi(iters)
+    f.Synchronize()
+    t = f.timing_read(True)
+    out = f.download(fx.FIELD_PRESSURE)
+    f.Release()
+    return out, t
+
+
+DIMS = [(32, 32, 32), (64, 64, 40), (40, 40, 12), (8, 8, 8), (36, 36, 9), (96, 96, 17), (4, 4, 3), (160, 160, 24)]
+
+
+@pytest.mark.parametrize("dims", DIMS)
+@pytest.mark.parametrize("iters", [1, 2, 5, 6, 17, 64])
+def test_freeze_solver_equals_oracle(dims, iters, knobs):
+    X, Y, Z = dims
+    p, b = plume_like(X, Y, Z, 100 + X + iters)
+    want, k = orc.jacobi(p, b, iters, mode=1)
+    got, t = solve(dims, p, b, iters)
+    assert np.array_equal(got, want)
+    assert (t.freeze_solves, t.freeze_sweeps) == (1, k)
+
+
+@pytest.mark.parametrize("T,NT,WGS", [(1, 512, 1024), (2, 256, 7), (3, 512, 64), (4, 256, 1), (3, 256, 100000)])
+def test_freeze_solver_every_launch_shape(T, NT, WGS, knobs):
+    """levels per launch, threads per workgroup and workgroups per launch change nothing"""
+    knobs["FLUIDX_FREEZE_T"], knobs["FLUIDX_FREEZE_NT"], knobs["FLUIDX_FREEZE_WGS"] = str(T), str(NT), str(WGS)
+    for dims, iters in (((64, 64, 24), 64), ((40, 40, 20), 23), ((32, 32, 9), 7)):
+        p, b = plume_like(*dims, seed=7 * T + iters)
+        want, k = orc.jacobi(p, b, iters, mode=1)
+        got, t = solve(dims, p, b, iters)
+        assert np.array_equal(got, want), (dims, iters)
+        assert t.freeze_sweeps == k
+
+
+@pytest.mark.parametrize("dims", [(128, 128, 128), (256, 256, 64)])
+def test_freeze_solver_at_reference_sizes(dims):
+    """the reference's default grid (FluidX12.cpp:44) and a 256-wide slab of the headline grid, 64-sweep cap"""
+    X, Y, Z = dims
+    p, b = plume_like(X, Y, Z, 5, amp=0.08)
+    want, k = orc.jacobi(p, b, 64, mode=1)
+    got, t = solve(dims, p, b, 64)
+    assert np.array_equal(got, want)
+    assert t.freeze_sweeps == k and 1 < k <= 64
+
+
+def test_freeze_solver_all_frozen_and_never_frozen():
+    dims = (32, 32, 16)
+    z = np.zeros(dims[::-1], f32)
+    got, t = solve(dims, z, z, 64)                        # nothing moves: one sweep, like the oracle
+    assert np.array_equal(got, z) and t.freeze_sweeps == 1
+    rng = np.random.default_rng(3)
+    p = rng.standard_normal(dims[::-1]).astype(f32) * 50
+    b = rng.standard_normal(dims[::-1]).astype(f32) * 50
+    want, k = orc.jacobi(p, b, 9, mode=1)                  # far from converged: the cap decides
+    got, t = solve(dims, p, b, 9)
+    assert k == 9 and t.freeze_sweeps == 9 and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("storage,address", [("fp16", "clamp"), ("fp32", "mirror")])
+def test_freeze_fast_path_equals_generic_kernel_over_steps(storage, address, knobs):
+    """whole steps in the reference's configuration (64-cap, early-out, RGBA16F / fp32): the sparse solver against the one-sweep
+    kernel with the byte mask -- every field bit-identical after 12 steps, pressure buffer rotation included"""
+    dims = (64, 64, 64)
+    kw = dict(storage=storage, jacobi_iters=64, jacobi_mode="faithful", advect_address=address)
+    fast = make(dims, **kw)
+    knobs["FLUIDX_FREEZE_FAST"] = "0"
+    slow = make(dims, **kw)
+    knobs["FLUIDX_FREEZE_FAST"] = "1"
+    for k in range(12):
+        for f in (fast, slow):
+            f.UpdateFrame(f32(f.default_time_step()), k % 3)
+            f.Simulate(k % 3)
+        if k in (0, 5, 11):
+            for fld in (fx.FIELD_PRESSURE, fx.FIELD_VELOCITY, fx.FIELD_COLOR):
+                assert np.array_equal(fast.download(fld), slow.download(fld)), (k, fld)
+    t = fast.timing_read(True)
+    assert t.freeze_solves == 12 and 12 < t.freeze_sweeps <= 12 * 64
+
+
+def test_freeze_rollout_matches_oracle_128():
+    """one step = advect + divergence + faithful solve + project at 128^3, RGBA16F storage, against the oracle stage by stage"""
+    X = 128
+    s = orc.Sim(X, X, X, iters=64, mode=1, half=True)
+    f = make((X, X, X), storage="fp16", jacobi_iters=64, jacobi_mode="faithful")
+    for k in range(3):
+        s.step()
+        f.UpdateFrame(f32(f.default_time_step()), 0)
+        f.Simulate(0)
+    # step 4 stage by stage from the oracle's state
+    f.upload(fx.FIELD_VELOCITY, s.vel[0]); f.upload(fx.FIELD_COLOR, s.color); f.upload(fx.FIELD_PRESSURE, s.p)
+    dt = f32(f.default_time_step())
+    f.UpdateFrame(dt, 0)
+    f.Advect(); f.Divergence()
+    vo, _ = orc.advect(s.vel[0], s.color, dt, 0, True)
+    b = orc.divergence(f.download(fx.FIELD_VELOCITY1))
+    assert np.array_equal(f.download(fx.FIELD_DIVERGENCE), b)
+    f.timing_read(True)
+    f.Jacobi(64)
+    q, k = orc.jacobi(s.p, b, 64, mode=1)
+    assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
+    assert f.timing_read(True).freeze_sweeps == k
+    f.Project()
+    assert np.array_equal(f.download(fx.FIELD_VELOCITY), orc.project(f.download(fx.FIELD_VELOCITY1), q, True))
+    assert np.abs(f.download(fx.FIELD_VELOCITY1) - vo).max() < 1e-3
