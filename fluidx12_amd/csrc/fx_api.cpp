@@ -121,7 +121,7 @@ void free_all(fx_ctx* c)
 		if (c->p[i]) (void)hipFree(c->p[i]);
 	}
 	void* others[] = { c->env, c->occ, c->target, c->target_float, c->p_face[0], c->p_face[1], c->b, c->frozen, c->lightmap, c->cube, c->sh_dev, c->halo_overflow, c->stage,
-		c->sh_scratch[0], c->sh_scratch[1], c->sh_scratch[2], c->sh_scratch[3], c->p_aux, c->fz_mask[0], c->fz_mask[1], c->fz_tile_next, c->fz_stat };
+		c->sh_scratch[0], c->sh_scratch[1], c->sh_scratch[2], c->sh_scratch[3], c->p_aux, c->fz_mask[0], c->fz_mask[1], c->fz_tile_next, c->fz_stat, c->fz_list[0], c->fz_list[1], c->fz_counts };
 	for (void* q : others) if (q) (void)hipFree(q);
 	for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
 	if (c->step_rec) (void)hipFree(c->step_rec);
@@ -409,27 +409,31 @@ int jacobi_freeze(fx_ctx* ctx, hipStream_t s, uint32_t iters)
 {
 	DeviceGuard dg(ctx->device);
 	ScopedMark mk(ctx, s, MK_JACOBI);
-	if (++ctx->fz_gen >= (1u << 22)) {                                  // launch ids (gen * 128 + n) << 1 stay below 2^32: start over with clean marks
+	if (++ctx->fz_gen >= (1u << 23)) {                                  // the tag (gen << 8 | level) of the stat words stays below 2^32: start over
 		FX_HIP(hipMemsetAsync(ctx->fz_tile_next, 0, (size_t)jacobi_freeze_tiles(ctx->g) * sizeof(uint32_t), s));
 		FX_HIP(hipMemsetAsync(ctx->fz_stat, 0, kFreezeStatRing * sizeof(uint32_t), s));
-		ctx->fz_gen = 1; ctx->fz_gen_mark = 0;
+		FX_HIP(hipMemsetAsync(ctx->fz_counts, 0, 2 * jacobi_freeze_count_words() * sizeof(uint32_t), s));
+		ctx->fz_gen = 2; ctx->fz_gen_mark = 0;
 	}
 	const uint32_t gen = ctx->fz_gen, stat_hi = gen << 8;
 	uint32_t* stat = ctx->fz_stat + gen % kFreezeStatRing;
 	ctx->fz_iters[gen % kFreezeStatRing] = iters;
+	const size_t cw = jacobi_freeze_count_words();
+	const FreezeWork w{ ctx->fz_tile_next, gen, { ctx->fz_list[0], ctx->fz_list[1] }, jacobi_freeze_tiles(ctx->g),
+		ctx->fz_counts + (gen & 1u) * cw, ctx->fz_counts + ((gen & 1u) ^ 1u) * cw };
 	float* src = ctx->p[ctx->p_cur];
 	float* a = ctx->p[ctx->p_cur ^ 1];
 	float* d = ctx->p_aux;
 	uint8_t* ma = ctx->fz_mask[0];
 	uint8_t* md = ctx->fz_mask[1];
-	uint32_t launch = gen * 128u + 2u;
-	FX_HIP(launch_freeze_dense(ctx->g, src, ctx->b, a, d, ma, md, ctx->fz_tile_next, launch, stat, stat_hi, s));
+	int slot = 2;                                                       // the first tile launch
+	FX_HIP(launch_freeze_dense(ctx->g, src, ctx->b, a, d, ma, md, w, slot, stat, stat_hi, s));
 	mk.launches = 1; mk.sweeps = 1;
 	const int T = jacobi_freeze_levels_per_launch();
 	int level = 1;
-	for (uint32_t left = iters - 1; left > 0; ++launch) {
+	for (uint32_t left = iters - 1; left > 0; ++slot) {
 		const int t = (int)std::min<uint32_t>((uint32_t)T, left);
-		FX_HIP(launch_freeze_tiles(ctx->g, a, ctx->b, d, ma, md, ctx->fz_tile_next, launch, t, level, stat, stat_hi, s));
+		FX_HIP(launch_freeze_tiles(ctx->g, a, ctx->b, d, ma, md, w, slot, t, level, stat, stat_hi, s));
 		std::swap(a, d); std::swap(ma, md);
 		left -= (uint32_t)t; level += t;
 		mk.launches += 1; mk.sweeps += (uint64_t)t;
@@ -757,6 +761,9 @@ int fx_create(fx_ctx** out, const fx_desc* d)
 				}
 				FX_HIP(hipMalloc((void**)&ctx->fz_tile_next, nt * sizeof(uint32_t)));
 				FX_HIP(hipMemsetAsync(ctx->fz_tile_next, 0, nt * sizeof(uint32_t), ctx->stream));
+				for (int i = 0; i < 2; ++i) FX_HIP(hipMalloc(&ctx->fz_list[i], jacobi_freeze_list_bytes(ctx->g)));
+				FX_HIP(hipMalloc((void**)&ctx->fz_counts, 2 * jacobi_freeze_count_words() * sizeof(uint32_t)));
+				FX_HIP(hipMemsetAsync(ctx->fz_counts, 0, 2 * jacobi_freeze_count_words() * sizeof(uint32_t), ctx->stream));
 				FX_HIP(hipMalloc((void**)&ctx->fz_stat, kFreezeStatRing * sizeof(uint32_t)));
 				FX_HIP(hipMemsetAsync(ctx->fz_stat, 0, kFreezeStatRing * sizeof(uint32_t), ctx->stream));
 				ctx->fz_iters.assign(kFreezeStatRing, 0);
@@ -1615,3 +1622,4 @@ int fx_comm_init_local(fx_ctx** ctxs, int nranks)
 }
 
 }  // extern "C"
+

@@ -67,16 +67,46 @@ __device__ __forceinline__ void stat_raise(uint32_t* stat, uint32_t v)
 	if (__hip_atomic_load(stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) atomicMax(stat, v);
 }
 
+// OR over the wave (every lane active), returned in every lane: four row rotations, then the four rows through SGPRs
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+{
+	int x = (int)v;
+	x |= __builtin_amdgcn_update_dpp(0, x, 0x121, 0xf, 0xf, false);      // row_ror:1
+	x |= __builtin_amdgcn_update_dpp(0, x, 0x122, 0xf, 0xf, false);      // row_ror:2
+	x |= __builtin_amdgcn_update_dpp(0, x, 0x124, 0xf, 0xf, false);      // row_ror:4
+	x |= __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false);      // row_ror:8
+	return (uint32_t)(__builtin_amdgcn_readlane(x, 0) | __builtin_amdgcn_readlane(x, 16) | __builtin_amdgcn_readlane(x, 32) | __builtin_amdgcn_readlane(x, 48));
+}
+
+// Work lists.  An entry = { tile | copy_only << 31, box, dirty, 0 }.  box = the core quads / rows / planes that still relax, as
+// q0 | q1 << 3 | y0 << 6 | y1 << 9 | z0 << 12 | z1 << 15 (each 0..7): within T levels they depend on nothing further than one quad /
+// T rows / T planes outside it, so only that much is staged and relaxed.  dirty = the box the PREVIOUS launch was given: the only
+// core cells whose values can differ between the two pressure buffers, i.e. what this launch has to store (the relaxing set only
+// shrinks, so dirty contains box).  Eight lists per launch, one per XCD (workgroup b runs on XCD b % 8): a tile stays with the XCD
+// whose L2 holds what it stored last, and eight counters share the appends.
+// floor(i / d) = (i * kMagic[d]) >> 20, exact for i < 2^20 / 16 and d <= 16 (kMagic[d] = ceil(2^20 / d)): the thread -> (quad, row,
+// plane) decomposition over a box whose extents are only known at run time
+__constant__ uint32_t kMagic[17] = { 0u, 1048576u, 524288u, 349526u, 262144u, 209716u, 174763u, 149797u, 131072u, 116509u, 104858u, 95326u,
+	87382u, 80660u, 74899u, 69906u, 65536u };
+__device__ __forceinline__ int div_magic(int i, uint32_t m) { return (int)(((uint32_t)i * m) >> 20); }
+
+constexpr uint32_t kCopyOnly = 0x80000000u;
+constexpr uint32_t kFullBox = 0u | 7u << 3 | 0u << 6 | 7u << 9 | 0u << 12 | 7u << 15;
+constexpr int kShards = 8;
+
 // ---------------------------------------------------------------------------------------------------------------------------
-// level 1, every cell.  Block = (bx quads, by rows), one plane per blockIdx slice, as k_jacobi_v4.
+// level 1, every cell.  Block = (bx quads, by rows), one plane per blockIdx slice, as k_jacobi_v4 (x neighbours by DPP).
 // ---------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
 	float* __restrict__ pA, float* __restrict__ pB, uint8_t* __restrict__ mA, uint8_t* __restrict__ mB,
-	uint32_t* __restrict__ tile_next, uint32_t mark, int ntx, int nty, uint32_t* __restrict__ stat, uint32_t stat_val, int rows_per_block)
+	uint32_t* __restrict__ tile_mark, uint32_t gen, uint4* __restrict__ list_out, uint32_t* __restrict__ cnt_out, int cap,
+	uint32_t* __restrict__ cnt_clear, int n_clear, int ntx, int nty, uint32_t* __restrict__ stat, uint32_t stat_val, int rows_per_block)
 {
 	const int X4 = g.X >> 2;
 	const int lane = threadIdx.x;
 	const int gx = (X4 + (int)blockDim.x - 1) / (int)blockDim.x, gy = (g.Y + rows_per_block - 1) / rows_per_block;
+	if (blockIdx.x == 0)                                                 // the next solve's counters (this one's were cleared by the previous solve)
+		for (int i = (int)(threadIdx.y * blockDim.x + threadIdx.x); i < n_clear; i += (int)(blockDim.x * blockDim.y)) cnt_clear[i] = 0u;
 	// XCD k walks the k-th contiguous eighth of the (x, y, z)-ordered block sequence (see xcd_tile in fx_sim.hip)
 	int t = (int)blockIdx.x;
 	{
@@ -86,9 +116,11 @@ __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float*
 	const int x4 = (t % gx) * blockDim.x + lane;
 	const int y = ((t / gx) % gy) * rows_per_block + threadIdx.y;
 	const int z = t / (gx * gy);
+	const int wl = (int)((threadIdx.y * blockDim.x + threadIdx.x) & 63);
 	const bool in = x4 < X4 && y < g.Y;
 	uint32_t nib = 0xFu;
 	int tile = -1;
+	size_t qi = 0;
 	if (in) {
 		const size_t plane = g.plane();
 		const int yu = max(y, 1) - 1, yd = min(y + 1, g.Y - 1);
@@ -101,56 +133,82 @@ __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float*
 		const float4 F = *reinterpret_cast<const float4*>(p_in + (size_t)zf * plane + (size_t)y * g.X + 4 * x4);
 		const float4 Bk = *reinterpret_cast<const float4*>(p_in + (size_t)zb * plane + (size_t)y * g.X + 4 * x4);
 		const float4 bb = *reinterpret_cast<const float4*>(b + c_off);
-		const float L = x4 == 0 ? c.x : p_in[c_off - 1];
-		const float R = x4 == X4 - 1 ? c.w : p_in[c_off + 4];
+		// x neighbours: the adjacent quad sits in the adjacent lane (DPP wave_shr:1 / wave_shl:1); only a wave's first / last lane
+		// inside a row still loads them
+		float L = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c.w), 0x138, 0xf, 0xf, false));
+		float R = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c.x), 0x130, 0xf, 0xf, false));
+		if (x4 == 0) L = c.x; else if (wl == 0 || lane == 0) L = p_in[c_off - 1];
+		if (x4 == X4 - 1) R = c.w; else if (wl == 63 || lane == (int)blockDim.x - 1) R = p_in[c_off + 4];
 		float4 o;
 		nib = relax_quad(c, L, R, U, D, F, Bk, bb, 0u, o);
 		*reinterpret_cast<float4*>(pA + c_off) = o;
 		*reinterpret_cast<float4*>(pB + c_off) = o;
-		const size_t qi = c_off >> 2;
-		mA[qi] = (uint8_t)nib;
-		mB[qi] = (uint8_t)nib;
+		qi = c_off >> 2;
 		tile = ((z >> 3) * nty + (y >> 3)) * ntx + (x4 >> 3);
 	}
-	// mark the tile for launch 2: one store per run of lanes that share a tile
+	// the mask bytes of four adjacent quads leave as one dword where the row allows it (X4 % 4 == 0: every aligned lane quartet
+	// lies inside one row, inside the grid or outside it as a whole)
+	if ((X4 & 3) == 0) {
+		const int v = (int)nib;
+		const uint32_t packed = nib | (uint32_t)__builtin_amdgcn_update_dpp(0, v, 0x55, 0xf, 0xf, false) << 8 |
+			(uint32_t)__builtin_amdgcn_update_dpp(0, v, 0xAA, 0xf, 0xf, false) << 16 | (uint32_t)__builtin_amdgcn_update_dpp(0, v, 0xFF, 0xf, 0xf, false) << 24;
+		if (in && (wl & 3) == 0) {
+			*reinterpret_cast<uint32_t*>(mA + qi) = packed;
+			*reinterpret_cast<uint32_t*>(mB + qi) = packed;
+		}
+	} else if (in) { mA[qi] = (uint8_t)nib; mB[qi] = (uint8_t)nib; }
+	// a tile with a relaxing cell enters the list of launch 2, once: the first lane run that sees it takes the mark
 	const bool active = nib != 0xFu;
 	const int mine = active ? tile : -1;
 	const int prev = __shfl_up(mine, 1);
-	const int wl = (int)((threadIdx.y * blockDim.x + threadIdx.x) & 63);
-	if (active && (wl == 0 || prev != mine)) tile_next[tile] = mark;
+	if (active && (wl == 0 || prev != mine)) {
+		if (__hip_atomic_load(tile_mark + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen && atomicExch(tile_mark + tile, gen) != gen) {
+			const int shard = (int)(blockIdx.x & (kShards - 1));
+			const uint32_t pos = atomicAdd(cnt_out + shard, 1u);
+			list_out[(size_t)shard * cap + pos] = make_uint4((uint32_t)tile, kFullBox, kFullBox, 0u);
+		}
+	}
 	if (__ballot(active) != 0ull && wl == 0) stat_raise(stat, stat_val);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// T more levels on the marked tiles.  tile_next[t] = (launch id << 1) | copy_only.
+// T more levels on the listed tiles
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int T, int NT>
 __global__ __launch_bounds__(NT, NT / 128) void k_freeze_tiles(const Geom g, const float* __restrict__ p_src, const float* __restrict__ b,
-	float* __restrict__ p_dst, const uint8_t* __restrict__ m_src, uint8_t* __restrict__ m_dst, uint32_t* __restrict__ tile_next,
-	uint32_t launch_id, int ntx, int nty, int ntiles, int level_base, uint32_t* __restrict__ stat, uint32_t stat_hi)
+	float* __restrict__ p_dst, const uint8_t* __restrict__ m_src, uint8_t* __restrict__ m_dst,
+	const uint4* __restrict__ list_in, const uint32_t* __restrict__ cnt_in, uint4* __restrict__ list_out, uint32_t* __restrict__ cnt_out, int cap,
+	int ntx, int nty, int level_base, uint32_t* __restrict__ stat, uint32_t stat_hi)
 {
 	constexpr int E = 8 + 2 * T;                 // staged rows per plane = staged planes
 	constexpr int NQ = E * E * TQ;               // staged quads
 	constexpr int EB = E - 2, NB = EB * EB * TQ; // b is needed one cell less deep
+	constexpr int NW = NT / 64;
 	__shared__ __attribute__((aligned(16))) float4 Pq[NQ + 2];    // [1 + idx]: the x neighbours of a row's first / last quad stay inside the array
 	__shared__ __attribute__((aligned(16))) float4 Bq[NB];
 	__shared__ uint8_t Mq[NQ];
+	__shared__ uint32_t wave_bits[NW];
 	const int tid = threadIdx.x;
 	const int X4 = g.X >> 2;
 	const size_t plane4 = (size_t)X4 * g.Y;      // quads per plane
+	const int shard = (int)(blockIdx.x & (kShards - 1)), wg = (int)(blockIdx.x >> 3), nwg = (int)(gridDim.x >> 3);
+	const uint32_t n_in = cnt_in[shard];
 
-	for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
-		const uint32_t mark = tile_next[t];
-		if ((mark >> 1) != launch_id) continue;                       // uniform per workgroup
+	for (uint32_t e = (uint32_t)wg; e < n_in; e += (uint32_t)nwg) {
+		const uint4 entry = list_in[(size_t)shard * cap + e];
+		const int t = (int)(entry.x & ~kCopyOnly);
 		const int tx = t % ntx, ty = (t / ntx) % nty, tz = t / (ntx * nty);
+		// core quads / rows / planes the previous launch may have changed (core indices 0..7)
+		const int dq0 = (int)(entry.z & 7u), dq1 = (int)((entry.z >> 3) & 7u), dy0 = (int)((entry.z >> 6) & 7u), dy1 = (int)((entry.z >> 9) & 7u);
+		const int dz0 = (int)((entry.z >> 12) & 7u), dz1 = (int)((entry.z >> 15) & 7u);
 		// ---- a tile that froze completely in the previous launch: carry its core across, then it is settled ---------------------
-		if (mark & 1u) {
+		if (entry.x & kCopyOnly) {
 #pragma unroll
 			for (int j = 0; j < 512 / NT; ++j) {
 				const int i = tid + NT * j;                               // 512 core quads
 				const int q = i & 7, yy = (i >> 3) & 7, zz = i >> 6;
 				const int x4 = tx * 8 + q, y = ty * TCY + yy, z = tz * TCZ + zz;
-				if (x4 < X4 && y < g.Y && z < g.Zg) {
+				if (x4 < X4 && y < g.Y && z < g.Zg && q >= dq0 && q <= dq1 && yy >= dy0 && yy <= dy1 && zz >= dz0 && zz <= dz1) {
 					const size_t qi = (size_t)z * plane4 + (size_t)y * X4 + x4;
 					reinterpret_cast<float4*>(p_dst)[qi] = reinterpret_cast<const float4*>(p_src)[qi];
 					m_dst[qi] = m_src[qi];
@@ -159,27 +217,46 @@ __global__ __launch_bounds__(NT, NT / 128) void k_freeze_tiles(const Geom g, con
 			continue;
 		}
 		const int x40 = tx * 8 - 1, y0 = ty * TCY - T, z0 = tz * TCZ - T;   // quad / row / plane of staged index 0
-		// the thread -> (quad, row, plane) decompositions below are the same for every tile: left visible, the compiler hoists all of
-		// them out of the tile loop and spills; opaque, they are a few multiply-shifts per level
+		// the box of core cells that still relax (core indices) ...
+		const int aq0 = (int)(entry.y & 7u), aq1 = (int)((entry.y >> 3) & 7u), ay0 = (int)((entry.y >> 6) & 7u), ay1 = (int)((entry.y >> 9) & 7u);
+		const int az0 = (int)((entry.y >> 12) & 7u), az1 = (int)((entry.y >> 15) & 7u);
+		// ... and what has to be staged, in staged indices: that box grown by one quad / T rows / T planes (all its cells can depend on
+		// within T levels) and the dirty box (stored from the LDS)
+		const int rq0 = min(aq0, dq0 + 1), rq1 = max(aq1 + 2, dq1 + 1);
+		const int ry0 = min(ay0, dy0 + T), ry1 = max(ay1 + 2 * T, dy1 + T);
+		const int rz0 = min(az0, dz0 + T), rz1 = max(az1 + 2 * T, dz1 + T);
 		int tl = tid;
-		asm volatile("" : "+v"(tl));
+		asm volatile("" : "+v"(tl));                                     // (keeps the index arithmetic below inside the tile loop: hoisted, it spills)
 		// ---- stage the cone ---------------------------------------------------------------------------------------------------
 		__syncthreads();                                                 // the previous tile of this workgroup is done with the LDS
 		{
-			// branch-free: every load goes to a valid (clamped) address and is issued before the first LDS store; what lies outside
-			// the grid is replaced afterwards ("frozen", never read by a cell inside: its taps are clamped)
+			// every load is issued before the first LDS store; lanes beyond the box repeat its last quad.  Cells of the box outside
+			// the grid are marked frozen: no cell inside reads them (clamped taps).  What lies outside the box keeps whatever the LDS
+			// held: further than T cells from every relaxing core cell, it cannot reach one within T levels.
 			constexpr int SJ = (NQ + NT - 1) / NT;
+			const int nqs = rq1 - rq0 + 1, nys = ry1 - ry0 + 1, total_s = nqs * nys * (rz1 - rz0 + 1);
+			const uint32_t mq = kMagic[nqs], my = kMagic[nys];
 			float4 sv[SJ], sb[SJ];
 			uint32_t sm[SJ];
+			int si[SJ];
 #pragma unroll
 			for (int j = 0; j < SJ; ++j) {
-				const int i = min(tl + NT * j, NQ - 1);
-				const int q = i % TQ, r = i / TQ, yy = r % E, zz = r / E;
-				const int x4 = x40 + q, y = y0 + yy, z = z0 + zz;
-				const size_t qi = (size_t)min(max(z, 0), g.Zg - 1) * plane4 + (size_t)min(max(y, 0), g.Y - 1) * X4 + min(max(x4, 0), X4 - 1);
-				sv[j] = reinterpret_cast<const float4*>(p_src)[qi];
-				sb[j] = reinterpret_cast<const float4*>(b)[qi];
-				sm[j] = m_src[qi];
+				sv[j] = make_float4(0.f, 0.f, 0.f, 0.f); sb[j] = sv[j]; sm[j] = 0xFu; si[j] = -1;
+				if (NT * j < total_s) {                                    // uniform
+					const int i = min(tl + NT * j, total_s - 1);
+					const int r = div_magic(i, mq), q = rq0 + i - r * nqs, zr = div_magic(r, my), yy = ry0 + r - zr * nys, zz = rz0 + zr;
+					const int x4 = x40 + q, y = y0 + yy, z = z0 + zz;
+					const size_t qi = (size_t)min(max(z, 0), g.Zg - 1) * plane4 + (size_t)min(max(y, 0), g.Y - 1) * X4 + min(max(x4, 0), X4 - 1);
+					sv[j] = reinterpret_cast<const float4*>(p_src)[qi];
+					sb[j] = reinterpret_cast<const float4*>(b)[qi];
+					sm[j] = m_src[qi];
+					if (tl + NT * j < total_s) {
+						// LDS index | "outside the grid" | "no b row here"
+						const bool in = x4 >= 0 && x4 < X4 && y >= 0 && y < g.Y && z >= 0 && z < g.Zg;
+						const bool brow = yy >= 1 && yy < E - 1 && zz >= 1 && zz < E - 1;
+						si[j] = ((zz * E + yy) * TQ + q) | (in ? 0 : 0x20000000) | (brow ? 0 : 0x40000000);
+					}
+				}
 			}
 			// (the compiler otherwise sinks each load into the guarded store below and waits for them one by one)
 #pragma unroll
@@ -187,54 +264,56 @@ __global__ __launch_bounds__(NT, NT / 128) void k_freeze_tiles(const Geom g, con
 				asm volatile("" : "+v"(sv[j].x), "+v"(sv[j].y), "+v"(sv[j].z), "+v"(sv[j].w), "+v"(sb[j].x), "+v"(sb[j].y), "+v"(sb[j].z), "+v"(sb[j].w), "+v"(sm[j]));
 #pragma unroll
 			for (int j = 0; j < SJ; ++j) {
-				const int i = tl + NT * j;
-				if (i < NQ) {
-					const int q = i % TQ, r = i / TQ, yy = r % E, zz = r / E;
-					const int x4 = x40 + q, y = y0 + yy, z = z0 + zz;
-					const bool in = x4 >= 0 && x4 < X4 && y >= 0 && y < g.Y && z >= 0 && z < g.Zg;
-					Pq[1 + i] = sv[j];
-					Mq[i] = (uint8_t)(in ? sm[j] : 0xFu);
-					if (yy >= 1 && yy < E - 1 && zz >= 1 && zz < E - 1) Bq[((zz - 1) * EB + (yy - 1)) * TQ + q] = sb[j];
+				if (si[j] >= 0) {
+					const int idx = si[j] & 0xFFFFF;
+					Pq[1 + idx] = sv[j];
+					Mq[idx] = (uint8_t)((si[j] & 0x20000000) ? 0xFu : sm[j]);
+					if (!(si[j] & 0x40000000)) {
+						const int q = idx % TQ, r = idx / TQ, yy = r % E, zz = r / E;
+						Bq[((zz - 1) * EB + (yy - 1)) * TQ + q] = sb[j];
+					}
 				}
 			}
 		}
 		__syncthreads();
-		// ---- T levels in the LDS: level k on rows / planes [k, E - k) ------------------------------------------------------------
+		// ---- T levels in the LDS: level k on the box grown by T - k rows / planes (one quad, until the last level) -----------------
 		int last_active = 0;                                             // last level (1..T) that left a core cell relaxing
-		bool core_active = true;
+		uint32_t core_bits = 0;                                          // quads | rows << 8 | planes << 16 of the core that still relax
 #pragma unroll
 		for (int k = 1; k <= T; ++k) {
-			const int n = E - 2 * k;                                      // rows = planes of this level
-			const int q0 = k == T ? 1 : 0, nq = k == T ? 8 : TQ;            // the last level: core quads only
-			const int total = n * n * nq;
+			const int cq0 = k == T ? aq0 + 1 : aq0, nq = aq1 - aq0 + (k == T ? 1 : 3);
+			const int cy0 = ay0 + k, ny = ay1 - ay0 + 1 + 2 * (T - k), cz0 = az0 + k, nz = az1 - az0 + 1 + 2 * (T - k);
+			const int total = nq * ny * nz;
+			const uint32_t mq = kMagic[nq], my = kMagic[ny];
 			constexpr int MAXJ = ((E - 2) * (E - 2) * TQ + NT - 1) / NT;
 			float4 nv[MAXJ];
 			uint32_t nm[MAXJ];
-			int thread_core_active = 0;
+			uint32_t bits = 0;
 #pragma unroll
 			for (int j = 0; j < MAXJ; ++j) {
 				const int i = tl + NT * j;
 				nm[j] = 0x100u;                                            // "nothing to write"
-				if (i < total) {
-					const int q = q0 + i % nq, r = i / nq, yy = k + r % n, zz = k + r / n;
-					const int idx = (zz * E + yy) * TQ + q;
-					const uint32_t m = Mq[idx];
-					const bool core = q >= 1 && q <= 8 && yy >= T && yy < T + TCY && zz >= T && zz < T + TCZ;
-					if (m != 0xFu) {
-						const int x4 = x40 + q, y = y0 + yy, z = z0 + zz;
-						const float4 c = Pq[1 + idx];
-						const float4 U = Pq[1 + (y == 0 ? idx : idx - TQ)];
-						const float4 D = Pq[1 + (y == g.Y - 1 ? idx : idx + TQ)];
-						const float4 F = Pq[1 + (z == 0 ? idx : idx - E * TQ)];
-						const float4 Bk = Pq[1 + (z == g.Zg - 1 ? idx : idx + E * TQ)];
-						const float L = x4 == 0 ? c.x : reinterpret_cast<const float*>(Pq)[4 * idx + 3];          // .w of quad idx - 1
-						const float R = x4 == X4 - 1 ? c.w : reinterpret_cast<const float*>(Pq)[4 * (idx + 2)];    // .x of quad idx + 1
-						const float4 bb = Bq[((zz - 1) * EB + (yy - 1)) * TQ + q];
-						nm[j] = relax_quad(c, L, R, U, D, F, Bk, bb, m, nv[j]) | (uint32_t)(idx << 9);
-						if (core && (nm[j] & 0xFu) != 0xFu) thread_core_active = 1;
+				if (NT * j < total) {                                      // uniform
+					if (i < total) {
+						const int r = div_magic(i, mq), q = cq0 + i - r * nq, zr = div_magic(r, my), yy = cy0 + r - zr * ny, zz = cz0 + zr;
+						const int idx = (zz * E + yy) * TQ + q;
+						const uint32_t m = Mq[idx];
+						if (m != 0xFu) {
+							const int x4 = x40 + q, y = y0 + yy, z = z0 + zz;
+							const float4 c = Pq[1 + idx];
+							const float4 U = Pq[1 + (y == 0 ? idx : idx - TQ)];
+							const float4 D = Pq[1 + (y == g.Y - 1 ? idx : idx + TQ)];
+							const float4 F = Pq[1 + (z == 0 ? idx : idx - E * TQ)];
+							const float4 Bk = Pq[1 + (z == g.Zg - 1 ? idx : idx + E * TQ)];
+							const float L = x4 == 0 ? c.x : reinterpret_cast<const float*>(Pq)[4 * idx + 3];          // .w of quad idx - 1
+							const float R = x4 == X4 - 1 ? c.w : reinterpret_cast<const float*>(Pq)[4 * (idx + 2)];    // .x of quad idx + 1
+							const float4 bb = Bq[((zz - 1) * EB + (yy - 1)) * TQ + q];
+							nm[j] = relax_quad(c, L, R, U, D, F, Bk, bb, m, nv[j]) | (uint32_t)(idx << 9);
+							const bool core = q >= 1 && q <= 8 && yy >= T && yy < T + TCY && zz >= T && zz < T + TCZ;
+							if (core && (nm[j] & 0xFu) != 0xFu) bits |= 1u << (q - 1) | 0x100u << (yy - T) | 0x10000u << (zz - T);
+						}
 					}
 				}
-				if (T >= 4 && (j & 1)) __builtin_amdgcn_sched_barrier(0);      // two quads' reads in flight at a time: more would spill
 			}
 			__syncthreads();                                               // every read of level k - 1 is done
 #pragma unroll
@@ -245,10 +324,14 @@ __global__ __launch_bounds__(NT, NT / 128) void k_freeze_tiles(const Geom g, con
 					Mq[idx] = (uint8_t)(nm[j] & 0xFu);
 				}
 			}
-			const int any = __syncthreads_or(thread_core_active);
-			if (any) last_active = k;
-			core_active = any != 0;
-			if (!core_active) break;                                       // the core is frozen: deeper levels cannot change it
+			const uint32_t wb = wave_or(bits);
+			if ((tid & 63) == 0) wave_bits[tid >> 6] = wb;
+			__syncthreads();
+			core_bits = 0;
+#pragma unroll
+			for (int w = 0; w < NW; ++w) core_bits |= wave_bits[w];
+			if (core_bits) last_active = k;
+			if (!core_bits) break;                                         // the core is frozen: deeper levels cannot change it
 		}
 		// ---- store the core ---------------------------------------------------------------------------------------------------
 #pragma unroll
@@ -256,7 +339,7 @@ __global__ __launch_bounds__(NT, NT / 128) void k_freeze_tiles(const Geom g, con
 			const int i = tl + NT * j;
 			const int q = 1 + (i & 7), yy = T + ((i >> 3) & 7), zz = T + (i >> 6);
 			const int x4 = x40 + q, y = y0 + yy, z = z0 + zz;
-			if (x4 < X4 && y < g.Y && z < g.Zg) {
+			if (x4 < X4 && y < g.Y && z < g.Zg && q - 1 >= dq0 && q - 1 <= dq1 && yy - T >= dy0 && yy - T <= dy1 && zz - T >= dz0 && zz - T <= dz1) {
 				const int idx = (zz * E + yy) * TQ + q;
 				const size_t qi = (size_t)z * plane4 + (size_t)y * X4 + x4;
 				reinterpret_cast<float4*>(p_dst)[qi] = Pq[1 + idx];
@@ -264,7 +347,15 @@ __global__ __launch_bounds__(NT, NT / 128) void k_freeze_tiles(const Geom g, con
 			}
 		}
 		if (tid == 0) {
-			tile_next[t] = ((launch_id + 1) << 1) | (core_active ? 0u : 1u);
+			uint4 next = make_uint4((uint32_t)t | kCopyOnly, 0u, entry.y, 0u);     // what this launch was given is what the next one must store
+			if (core_bits) {
+				const uint32_t qm = core_bits & 0xFFu, ym = (core_bits >> 8) & 0xFFu, zm = (core_bits >> 16) & 0xFFu;
+				next.x = (uint32_t)t;
+				next.y = (uint32_t)(__ffs(qm) - 1) | (uint32_t)(31 - __clz(qm)) << 3 | (uint32_t)(__ffs(ym) - 1) << 6 |
+					(uint32_t)(31 - __clz(ym)) << 9 | (uint32_t)(__ffs(zm) - 1) << 12 | (uint32_t)(31 - __clz(zm)) << 15;
+			}
+			const uint32_t pos = atomicAdd(cnt_out + shard, 1u);
+			list_out[(size_t)shard * cap + pos] = next;
 			if (last_active > 0) stat_raise(stat, stat_hi | (uint32_t)(level_base + last_active));
 		}
 	}
@@ -289,6 +380,8 @@ int jacobi_freeze_tiles(const Geom& g)
 }
 
 size_t jacobi_freeze_mask_bytes(const Geom& g) { return g.cells_local() / 4; }
+size_t jacobi_freeze_list_bytes(const Geom& g) { return (size_t)kShards * (size_t)jacobi_freeze_tiles(g) * sizeof(uint4); }
+size_t jacobi_freeze_count_words() { return (size_t)kFreezeSlots * kShards; }
 
 int jacobi_freeze_levels_per_launch()
 {
@@ -297,26 +390,33 @@ int jacobi_freeze_levels_per_launch()
 }
 
 hipError_t launch_freeze_dense(const Geom& g, const float* p_in, const float* b, float* pA, float* pB, uint8_t* mA, uint8_t* mB,
-	uint32_t* tile_next, uint32_t launch_id, uint32_t* stat, uint32_t stat_hi, hipStream_t s)
+	const FreezeWork& w, int slot_out, uint32_t* stat, uint32_t stat_hi, hipStream_t s)
 {
 	const int X4 = g.X >> 2;
 	const int bx = X4 < 64 ? X4 : 64;
 	int by = 256 / bx; if (by < 1) by = 1; if (by > g.Y) by = g.Y;
 	const int ntx = (g.X + TCX - 1) / TCX, nty = (g.Y + TCY - 1) / TCY;
 	const dim3 block(bx, by, 1), grid(((X4 + bx - 1) / bx) * ((g.Y + by - 1) / by) * g.Zg, 1, 1);
-	hipLaunchKernelGGL(k_freeze_dense, grid, block, 0, s, g, p_in, b, pA, pB, mA, mB, tile_next, launch_id << 1, ntx, nty, stat, stat_hi | 1u, by);
+	hipLaunchKernelGGL(k_freeze_dense, grid, block, 0, s, g, p_in, b, pA, pB, mA, mB, w.tile_mark, w.gen, (uint4*)w.list[slot_out & 1],
+		w.counts + (size_t)slot_out * kShards, w.cap, w.counts_next, kFreezeSlots * kShards, ntx, nty, stat, stat_hi | 1u, by);
 	return hipGetLastError();
 }
 
 hipError_t launch_freeze_tiles(const Geom& g, const float* p_src, const float* b, float* p_dst, const uint8_t* m_src, uint8_t* m_dst,
-	uint32_t* tile_next, uint32_t launch_id, int levels, int level_base, uint32_t* stat, uint32_t stat_hi, hipStream_t s)
+	const FreezeWork& w, int slot_in, int levels, int level_base, uint32_t* stat, uint32_t stat_hi, hipStream_t s)
 {
-	const int max_wgs = env_int("FLUIDX_FREEZE_WGS", 1024);
+	int max_wgs = env_int("FLUIDX_FREEZE_WGS", 1024);
+	max_wgs = max_wgs < kShards ? kShards : (max_wgs & ~(kShards - 1));
 	const int ntx = (g.X + TCX - 1) / TCX, nty = (g.Y + TCY - 1) / TCY, ntiles = jacobi_freeze_tiles(g);
+	const int want = (ntiles + kShards - 1) / kShards * kShards;
 	const int nt = env_int("FLUIDX_FREEZE_NT", 512);
-	const dim3 block(nt == 256 ? 256 : 512, 1, 1), grid(ntiles < max_wgs ? ntiles : max_wgs, 1, 1);
-#define FX_FREEZE_LAUNCH(T) if (nt == 256) hipLaunchKernelGGL((k_freeze_tiles<T, 256>), grid, block, 0, s, g, p_src, b, p_dst, m_src, m_dst, tile_next, launch_id, ntx, nty, ntiles, level_base, stat, stat_hi); \
-	else hipLaunchKernelGGL((k_freeze_tiles<T, 512>), grid, block, 0, s, g, p_src, b, p_dst, m_src, m_dst, tile_next, launch_id, ntx, nty, ntiles, level_base, stat, stat_hi)
+	const dim3 block(nt == 256 ? 256 : 512, 1, 1), grid(want < max_wgs ? want : max_wgs, 1, 1);
+	const uint4* lin = (const uint4*)w.list[slot_in & 1];
+	uint4* lout = (uint4*)w.list[(slot_in + 1) & 1];
+	const uint32_t* cin = w.counts + (size_t)slot_in * kShards;
+	uint32_t* cout = w.counts + (size_t)(slot_in + 1) * kShards;
+#define FX_FREEZE_LAUNCH(T) if (nt == 256) hipLaunchKernelGGL((k_freeze_tiles<T, 256>), grid, block, 0, s, g, p_src, b, p_dst, m_src, m_dst, lin, cin, lout, cout, w.cap, ntx, nty, level_base, stat, stat_hi); \
+	else hipLaunchKernelGGL((k_freeze_tiles<T, 512>), grid, block, 0, s, g, p_src, b, p_dst, m_src, m_dst, lin, cin, lout, cout, w.cap, ntx, nty, level_base, stat, stat_hi)
 	switch (levels) {
 	case 1: FX_FREEZE_LAUNCH(1); break;
 	case 2: FX_FREEZE_LAUNCH(2); break;
