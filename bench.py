@@ -37,10 +37,17 @@ def step_bytes_per_voxel(iters, storage):
     return 5 * V + 2 * Cb + 2 * 4 + 12 * iters            # 5V + 2C + 2S + 12 N
 
 
-def pmc_traffic(kernel, grid, iters, storage):
-    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (tools/pmc_summary.py),
-    or None when no summary matches this workload.  bench.py cannot run the profiler on itself; the summary is
-    produced by the same command under rocprofv3 --pmc and committed under profiles/."""
+def _source_hash(kernel):
+    from fluidx12_amd.build import kernel_source_hash
+    return kernel_source_hash(kernel)
+
+
+def pmc_traffic(kernel, grid, iters, storage, mode="fixed"):
+    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (tools/pmc_summary.py) of this
+    workload: (bytes, file, stale).  bench.py cannot run the profiler on itself; the summary is produced by the same command under
+    rocprofv3 --pmc and committed under profiles/, stamped per kernel with a hash of the kernel's source file + build flags
+    (fluidx12_amd.build.kernel_source_hash).  A summary whose stamp differs from the tree's -- the kernel changed and was not
+    re-profiled -- is reported as stale and its figure is NOT used.  None when no summary matches the workload at all."""
     import glob
     best = None
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json"))):
@@ -48,8 +55,9 @@ def pmc_traffic(kernel, grid, iters, storage):
             d = json.load(open(fn))
         except Exception:
             continue
-        if (d.get("grid"), d.get("iters"), d.get("storage")) == (grid, iters, storage) and kernel in d.get("kernels", {}):
-            best = (d["kernels"][kernel]["traffic"], os.path.basename(fn))
+        if (d.get("grid"), d.get("iters"), d.get("storage"), d.get("mode", "fixed")) == (grid, iters, storage, mode) and kernel in d.get("kernels", {}):
+            e = d["kernels"][kernel]
+            best = (e["traffic"], os.path.basename(fn), e.get("source_hash") != _source_hash(kernel))
     return best
 
 
@@ -67,7 +75,8 @@ def baseline_config_label(GX, GY, GZ, iters, storage, N):
 
 
 def limiter_note(kernel):
-    """what the committed SQ-counter summary (tools/sq_summary.py -> profiles/r*_sq_counters.json) says binds `kernel`"""
+    """what the newest committed SQ-counter summary (tools/sq_summary.py -> profiles/r*_sq_counters.json) taken on THIS kernel source
+    says binds `kernel` (summaries of an older version of the kernel are skipped)"""
     import glob
     note = None
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters*.json"))):
@@ -76,14 +85,15 @@ def limiter_note(kernel):
         except Exception:
             continue
         k = d.get("kernels", {}).get(kernel)
-        if k and k.get("limiter"):
+        if k and k.get("limiter") and k.get("source_hash") == _source_hash(kernel):
             note = "%s (%s)" % (k["limiter"], os.path.basename(fn))
     return note
 
 
-def step_traffic(grid, iters, storage):
+def step_traffic(grid, iters, storage, mode="fixed"):
     """fabric bytes ONE step moves, summed over its kernels from the newest committed PMC summary of this workload (the summary was
-    taken with `bench.py --steps 4 --warmup 1`: every kernel's dispatch count / 5 = launches per step).  None if no summary matches."""
+    taken with `bench.py --steps 4 --warmup 1`: every kernel's dispatch count / 5 = launches per step): (bytes, file, stale kernels).
+    None if no summary matches."""
     import glob
     best = None
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json"))):
@@ -91,8 +101,9 @@ def step_traffic(grid, iters, storage):
             d = json.load(open(fn))
         except Exception:
             continue
-        if (d.get("grid"), d.get("iters"), d.get("storage")) == (grid, iters, storage) and d.get("kernels"):
-            best = (sum(k["traffic"] * k["dispatches"] / 5.0 for k in d["kernels"].values()), os.path.basename(fn))
+        if (d.get("grid"), d.get("iters"), d.get("storage"), d.get("mode", "fixed")) == (grid, iters, storage, mode) and d.get("kernels"):
+            stale = sorted(k for k, e in d["kernels"].items() if e.get("source_hash") != _source_hash(k))
+            best = (sum(k["traffic"] * k["dispatches"] / float(d.get("steps_profiled", 5)) for k in d["kernels"].values()), os.path.basename(fn), stale)
     return best
 
 
@@ -139,7 +150,7 @@ def slab_for_rank(Z, rank, world):
     return z0, z1 - z0
 
 
-def cpu_baseline(grid, iters, budget_s=20.0):
+def cpu_baseline(grid, iters, budget_s=20.0, mode=0, half=False, address=0):
     """Time the CPU oracle (port of the reference shaders) on a bounded sample of the same workload:
     full simulation steps on a grid x grid x nz sub-volume sized for ~budget_s of CPU work.  The thread count is the
     one that runs fastest on a thin calibration slab (the visible CPU count of a container can exceed what it may use)."""
@@ -159,7 +170,7 @@ def cpu_baseline(grid, iters, budget_s=20.0):
     def slab_rate(nz, steps, threads):
         if gomp is not None:
             gomp.omp_set_num_threads(int(threads))
-        sim = orc.Sim(grid, grid, nz, iters=iters)
+        sim = orc.Sim(grid, grid, nz, iters=iters, mode=mode, address=address, half=half)
         sim.step(2.0 / grid)                     # warm-up (page faults, OpenMP pool)
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -180,6 +191,7 @@ def cpu_baseline(grid, iters, budget_s=20.0):
     single = slab_rate(4, 1, 1) if gomp is not None else None       # the pure scalar replay, one thread, a 4-plane slab
     return {"value": rate, "unit": "voxel-updates/s", "cores": threads, "kind": "port", "single_thread_value": single,
             "sample": "%d steps of advect+divergence+%d Jacobi+project on a %dx%dx%d sub-volume of the %d^3 workload "
+                      + ("(reference configuration: sweep cap + per-cell early-out, RGBA16F storage) " if mode else "") +
                       "(oracle/liborc.so, -O3, OpenMP over planes; %d threads = the fastest of %s on a thin slab, %d CPUs visible)"
                       % (steps, iters, grid, grid, nz, grid, threads, sorted(tried), ncores)}
 
@@ -195,6 +207,12 @@ def main():
     ap.add_argument("--grid", type=int, default=None)
     ap.add_argument("--iters", type=int, default=None)
     ap.add_argument("--storage", default=None, choices=["fp32", "fp16"])
+    ap.add_argument("--mode", default="fixed", choices=["fixed", "faithful"],
+                    help="pressure solve: `fixed` = --iters lock-step sweeps (BASELINE's 20 / 40 / 80); `faithful` = the reference's own loop "
+                         "(CSPoisson.hlsli:8-26: at most --iters sweeps, default 64, a cell stops once a sweep moves it by < 1e-3)")
+    ap.add_argument("--address", default="clamp", choices=["clamp", "mirror"], help="advection sampler (FluidEZ = clamp, Fluid = mirror)")
+    ap.add_argument("--reference-config", action="store_true",
+                    help="the configuration the reference itself runs (Fluid.cpp:207-221, CSProject3D.hlsl:13): --mode faithful --iters 64 --storage fp16")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="how the grid grows with --gpus (N > 1)")
     ap.add_argument("--schedule", default="auto", help="N > 1: 'auto' times the slab schedules below for 3 steps each before the "
                     "warm-up and keeps the fastest, or 'OVERLAP,ROUND' (fx_set_option values) to pin one")
@@ -212,6 +230,11 @@ def main():
                     help="distributed plumbing only (no GPU work); used by the gloo CPU tests, never a measurement")
     args = ap.parse_args()
     cg, ci, cs = BASELINE_CONFIGS.get(args.config, (256, 40, "fp32"))
+    if args.reference_config:
+        args.mode = "faithful"
+        cs = "fp16"
+    if args.mode == "faithful":
+        ci = 64                                    # CSProject3D.hlsl:13
     if args.grid is None:
         args.grid = cg
     if args.iters is None:
@@ -266,8 +289,8 @@ def main():
         for r in ([rank] if not loop else range(N)):
             z0r, nzr = slab_for_rank(GZ, r, N)
             f_ = fx.Fluid()
-            ok = f_.Init(1920, 1080, (GX, GY, GZ), storage=args.storage, jacobi_iters=args.iters, jacobi_mode="fixed",
-                         advect_address="clamp", device=local_rank if (N > 1 and not loop) else -1,
+            ok = f_.Init(1920, 1080, (GX, GY, GZ), storage=args.storage, jacobi_iters=args.iters, jacobi_mode=args.mode,
+                         advect_address=args.address, device=local_rank if (N > 1 and not loop) else -1,
                          slab=(z0r, nzr) if N > 1 else None, halo_advect=halo_adv,
                          halo_jacobi=pressure_round(GX, GZ // N, args.iters) if N > 1 else 0)
             if not ok:
@@ -458,7 +481,41 @@ def main():
                 render["mode"] += ", hasSH = 1 (light probe)"
                 render["sh_light_probe"] = sh_info
         fluid.timing_enable(False)
-        if timing.jacobi_launches:
+        if timing.jacobi_launches and args.mode == "faithful" and timing.freeze_solves:
+            # The reference's own solve on the sparse solver (fx_jacobi_freeze.hip): one dense sweep (k_freeze_dense: the launch the
+            # library books as "main") + tile launches over the cells that still relax.  roofline = the dense sweep, the one streaming
+            # kernel of the phase with a fixed byte count: SURVEY 8(d)'s 12 B per cell-sweep (read p, read b, write p') x the cells of
+            # ONE sweep.  By design it moves more (16.25 B: level 1 goes to two buffers, + two quad-nibble masks): `design_bytes`.
+            cells = float(GX) * GY * nz
+            steps_m = max(timing.steps, 1)
+            dense_s = timing.jacobi_main_ms * 1e-3 / max(timing.jacobi_main_launches, 1)
+            tile_l = int(timing.jacobi_launches - timing.jacobi_main_launches)
+            tile_ms = timing.jacobi_ms - timing.jacobi_main_ms
+            sweeps = timing.freeze_sweeps / timing.freeze_solves           # what the reference's loop executes per solve (<= iters)
+            algo = JACOBI_BYTES_PER_CELL_SWEEP * cells
+            design = 16.25 * cells
+            tr = pmc_traffic("k_freeze_dense", G, args.iters, args.storage, "faithful") if N == 1 else None
+            use_tr = tr is not None and not tr[2]
+            roof = {"bound": "hbm",
+                    "kernel": "k_freeze_dense (sweep 1 of the reference's <= %d-sweep solve for every cell; sweeps 2.. run in %d tile launches of "
+                              "k_freeze_tiles over the 32x8x8 tiles that still hold a relaxing cell: `sparse_solver`)" % (args.iters, tile_l // steps_m),
+                    "achieved": algo / dense_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / dense_s / 1e9 / HBM_PEAK_GBS,
+                    "traffic": tr[0] if use_tr else None, "traffic_source": tr[1] if tr else None, "stale": bool(tr and tr[2]),
+                    "algorithmic_bytes_per_launch": algo, "design_bytes_per_launch": design,
+                    "frac_design_bytes": design / dense_s / 1e9 / HBM_PEAK_GBS,
+                    "frac_traffic": (tr[0] / dense_s / 1e9 / HBM_PEAK_GBS) if use_tr else None,
+                    "limiter": limiter_note("k_freeze_dense"),
+                    "avg_launch_us": dense_s * 1e6, "launches": int(timing.jacobi_main_launches), "sweeps_per_launch": 1.0,
+                    "sparse_solver": {
+                        "sweeps_executed_per_solve": sweeps, "sweep_cap": args.iters, "solves": int(timing.freeze_solves),
+                        "tile_launches_per_step": tile_l / steps_m, "tile_launches_ms_per_step": tile_ms / steps_m,
+                        "jacobi_phase_ms_per_step": timing.jacobi_ms / steps_m,
+                        # the rate a dense replay of the executed sweeps would need to finish in the same time
+                        "dense_equivalent_cell_updates_per_s": cells * sweeps / (timing.jacobi_ms / steps_m * 1e-3),
+                        "dense_equivalent_GBps": JACOBI_BYTES_PER_CELL_SWEEP * cells * sweeps / (timing.jacobi_ms / steps_m * 1e-3) / 1e9,
+                        "note": "bytes = 12 B x cells x the sweeps the reference's loop executes; above the HBM peak because most cells "
+                                "leave the loop after the first sweep and are never touched again"}}
+        elif timing.jacobi_launches:
             cells = float(GX) * GY * nz                                # cells this rank sweeps
             # the dominant kernel = the launches with the most sweeps each (a 40-sweep step is 12 launches of three + 2 of two);
             # the library books them separately, so the figure below is ONE kernel's average launch, as rocprofv3 reports it
@@ -467,31 +524,38 @@ def main():
             main_sw = timing.jacobi_main_sweeps if timing.jacobi_main_launches else timing.jacobi_sweeps
             avg_launch_s = main_ms * 1e-3 / main_l
             sweeps_per_launch = main_sw / main_l
-            achieved = JACOBI_BYTES_PER_CELL_SWEEP * cells * sweeps_per_launch / avg_launch_s / 1e9
-            names = {1: ["k_jacobi_v4"], 2: (["k_jacobi_strip2h"] if GX == 512 else ["k_jacobi_block2"] if GX == 128 else ["k_jacobi_blockg"] if GX not in (64, 256) else []) + ["k_jacobi_strip2u", "k_jacobi_strip"],
+            names = {1: ["k_jacobi_generic"] if (args.mode == "faithful" or GX % 4 or GZ == 1) else ["k_jacobi_v4"],
+                     2: (["k_jacobi_strip2h"] if GX == 512 else ["k_jacobi_block2"] if GX == 128 else ["k_jacobi_blockg"] if GX not in (64, 256) else []) + ["k_jacobi_strip2u", "k_jacobi_strip"],
                      3: (["k_jacobi_strip3h"] if GX == 512 else ["k_jacobi_strip3c"] if (GX == 256 and GY % 8 == 0 and os.environ.get("FLUIDX_STRIP3_COOP", "1") != "0") else []) + ["k_jacobi_strip3", "k_jacobi_strip"]}
             cands = names.get(int(round(sweeps_per_launch)), ["k_jacobi_strip"]) if abs(sweeps_per_launch - round(sweeps_per_launch)) < 1e-9 else ["k_jacobi_strip"]
             tr = None
             if N == 1:
                 for cand in cands:
                     tr = tr or pmc_traffic(cand, G, args.iters, args.storage)
+            use_tr = tr is not None and not tr[2]
             tail_l = int(timing.jacobi_launches - main_l)
-            # what bounds a T-sweep launch: it must read p and b once and write p' once whatever T is (compulsory bytes);
-            # `achieved`/`frac` count SURVEY 8(d)'s 12 B per cell-SWEEP and therefore exceed the peak by up to T x
+            # What bounds a T-sweep launch: it must read p and b once and write p' once whatever T is -- 12 B per cell (SURVEY 8(d)'s
+            # per-sweep figure x the cells of ONE sweep).  `achieved` / `frac` are that: a fraction of the HBM peak that cannot exceed 1.
+            # SURVEY 8(d)'s figure counted per fused sweep (12 B x cells x T: what T single-sweep launches would move) is kept beside it
+            # as `achieved_algorithmic` / `frac_algorithmic`; it exceeds the peak by up to T x -- the temporal blocking, not a bound.
             compulsory = JACOBI_BYTES_PER_CELL_SWEEP * cells
+            achieved = compulsory / avg_launch_s / 1e9
             roof = {"bound": "hbm",
-                    "kernel": "k_jacobi_v4 (one lock-step Jacobi sweep per launch)" if sweeps_per_launch == 1 else
+                    "kernel": "%s (one lock-step Jacobi sweep per launch)" % cands[0] if sweeps_per_launch == 1 else
                               "%s (%g lock-step Jacobi sweeps per launch, register/LDS-resident temporal blocking: p and b are read once "
-                              "and p' written once per launch, so achieved > HBM peak is possible; frac_compulsory and frac_traffic are the "
-                              "fractions that bound)" % (cands[0], sweeps_per_launch),
+                              "and p' written once per launch = the bytes `achieved` counts)" % (cands[0], sweeps_per_launch),
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
+                    "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": tr[0] if use_tr else None,
                     "traffic_source": tr[1] if tr else None,
+                    "stale": bool(tr and tr[2]),                     # the committed counter summary was taken on another version of this kernel
                     "compulsory_bytes_per_launch": compulsory,
-                    "frac_compulsory": compulsory / avg_launch_s / 1e9 / HBM_PEAK_GBS,
-                    "frac_traffic": (tr[0] / avg_launch_s / 1e9 / HBM_PEAK_GBS) if tr else None,
+                    "frac_compulsory": achieved / HBM_PEAK_GBS,
+                    "frac_traffic": (tr[0] / avg_launch_s / 1e9 / HBM_PEAK_GBS) if use_tr else None,
                     "limiter": limiter_note(cands[0]),
                     "algorithmic_bytes_per_launch": JACOBI_BYTES_PER_CELL_SWEEP * cells * sweeps_per_launch,
+                    "achieved_algorithmic": JACOBI_BYTES_PER_CELL_SWEEP * cells * sweeps_per_launch / avg_launch_s / 1e9,
+                    "frac_algorithmic": JACOBI_BYTES_PER_CELL_SWEEP * cells * sweeps_per_launch / avg_launch_s / 1e9 / HBM_PEAK_GBS,
                     "avg_launch_us": avg_launch_s * 1e6, "launches": int(main_l),
                     "sweeps_per_launch": sweeps_per_launch,
                     "other_jacobi_launches": None if not tail_l else {
@@ -502,7 +566,8 @@ def main():
     if rank == 0:
         voxels = float(GX) * GY * GZ * args.steps
         out = {
-            "metric": "voxel-updates/sec (advect+40 Jacobi) at 256^3; achieved HBM GB/s vs peak",
+            "metric": "voxel-updates/sec (advect+40 Jacobi) at 256^3; achieved HBM GB/s vs peak" if args.mode == "fixed" else
+                      "voxel-updates/sec (advect + the reference's <= %d-sweep early-out Jacobi) at %d^3; achieved HBM GB/s vs peak" % (args.iters, G),
             "value": voxels / elapsed if not args.dry_run else 0.0,
             "unit": "voxel-updates/s",
             "n_gpus": 1 if loop else N, "steps": args.steps, "warmup": args.warmup,
@@ -512,10 +577,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if args.storage == "fp32" else "f32 arithmetic / f16 field storage",
             "data": "synthetic" if not loop else "synthetic; LOOP-BACK: %d slab ranks share ONE GPU (functional check of the multi-rank path, not a scaling measurement)" % loop,
-            "config": {"workload": "%dx%dx%d 3D smoke (%.1f M voxels per GPU), %d Jacobi sweeps, %s fields, "
+            "config": {"workload": "%dx%dx%d 3D smoke (%.1f M voxels per GPU), %s, %s fields, %s sampler, "
                                    "advect+divergence+Jacobi+project per step; %s"
-                                   % (GX, GY, GZ, GX * GY * GZ / N / 1e6, args.iters, args.storage, baseline_config_label(GX, GY, GZ, args.iters, args.storage, N)),
-                       "grid": [GX, GY, GZ], "jacobi_iters": args.iters, "storage": args.storage,
+                                   % (GX, GY, GZ, GX * GY * GZ / N / 1e6,
+                                      "%d Jacobi sweeps" % args.iters if args.mode == "fixed" else "the reference's pressure loop (<= %d sweeps, per-cell early-out at |dx| < 1e-3)" % args.iters,
+                                      args.storage, args.address.upper(),
+                                      baseline_config_label(GX, GY, GZ, args.iters, args.storage, N) if args.mode == "fixed" else
+                                      "the REFERENCE's own configuration (CSProject3D.hlsl:13, CSPoisson.hlsli:8-26%s), not a BASELINE.json config (those fix the sweep count)"
+                                      % (", RGBA16F fields Fluid.cpp:207-213" if args.storage == "fp16" else "")),
+                       "grid": [GX, GY, GZ], "jacobi_iters": args.iters, "jacobi_mode": args.mode, "storage": args.storage, "address": args.address,
                        "parallelism": "single GPU" if N == 1 else ("z-slab x%d (%d planes per rank), " % (N, GZ // N)) + ("loop-back copies on one GPU" if loop else "RCCL send/recv halo exchange"),
                        "schedule": schedule,
                        "bytes_per_voxel_step": step_bytes_per_voxel(args.iters, args.storage)},
@@ -529,19 +599,30 @@ def main():
             out["timing_marks"] = {"every": mark_every, "marked_steps": int(timing.steps)}      # stage / launch figures are per marked step
             out["stage_ms_per_step"] = {k: getattr(timing, k + "_ms") / max(timing.steps, 1)
                                         for k in ("advect", "divergence", "jacobi", "project", "exchange")}
-            sb = step_bytes_per_voxel(args.iters, args.storage) * float(GX) * GY * GZ
-            out["step_algorithmic_GBps"] = sb / (elapsed / args.steps) / 1e9
-            st = step_traffic(G, args.iters, args.storage) if N == 1 else None
+            eff_iters = args.iters if args.mode == "fixed" else (timing.freeze_sweeps / timing.freeze_solves if timing.freeze_solves else args.iters)
+            sb = step_bytes_per_voxel(eff_iters, args.storage) * float(GX) * GY * GZ
+            out["step_algorithmic_GBps"] = sb / (elapsed / args.steps) / 1e9     # 5V + 2C + 2S + 12 N per voxel (N = sweeps executed); > peak under temporal blocking
+            if args.mode == "fixed" and roof is not None:
+                # the bytes a step cannot avoid with the launch shapes it used: every Jacobi LAUNCH reads p, b and writes p' once
+                V_, C_ = (12, 16) if args.storage == "fp32" else (6, 8)
+                launches_per_step = timing.jacobi_launches / max(timing.steps, 1)
+                sc = (5 * V_ + 2 * C_ + 2 * 4 + 12 * launches_per_step) * float(GX) * GY * GZ
+                out["step_compulsory"] = {"bytes_per_step": sc, "GBps": sc / (elapsed / args.steps) / 1e9,
+                                          "frac_of_peak": sc / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                          "jacobi_launches_per_step": launches_per_step}
+            st = step_traffic(G, args.iters, args.storage, args.mode) if N == 1 else None
             if st:
                 # the whole step against the fabric: measured bytes of all its launches (PMC, committed summary) / measured time
-                out["step_fabric_traffic"] = {"bytes_per_step": st[0], "GBps": st[0] / (elapsed / args.steps) / 1e9,
-                                              "frac_of_peak": st[0] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, "source": st[1]}
+                out["step_fabric_traffic"] = {"bytes_per_step": st[0] if not st[2] else None, "GBps": st[0] / (elapsed / args.steps) / 1e9 if not st[2] else None,
+                                              "frac_of_peak": st[0] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS if not st[2] else None, "source": st[1],
+                                              "stale_kernels": st[2]}
         if roof is not None:
             out["roofline"] = roof
         if render is not None:
             out["render"] = render
         if N == 1 and not args.no_cpu_baseline and not args.dry_run:
-            out["cpu_baseline"] = cpu_baseline(G, args.iters, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(G, args.iters, args.cpu_budget, mode=int(args.mode == "faithful"), half=args.storage == "fp16",
+                                               address=int(args.address == "mirror"))
         print(json.dumps(out), flush=True)
 
     for m_ in members:

@@ -33,6 +33,26 @@ EXTRA_FLAGS = {"fx_jacobi_strip3.hip": ["-mllvm", "-amdgpu-sched-strategy=max-il
                "fx_jacobi_strip.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}     # 256x256x64: 8.9 -> 8.1 us per sweep; 512x512x64: 19.0 -> 18.8
 
 
+def kernel_source_hash(kernel):
+    """16 hex digits identifying the device code of `kernel` (a __global__ name such as k_jacobi_strip3c): sha256 over the
+    .hip file that defines it, the device-side headers it can include and its compile flags.  profiles/*_pmc_traffic*.json and
+    *_sq_counters*.json carry this stamp per kernel; bench.py refuses a counter summary whose stamp differs from the tree's."""
+    import hashlib
+    import re
+    pat = re.compile(r"\bvoid\s+" + re.escape(kernel) + r"\s*\(")
+    for s in SOURCES:
+        if not s.endswith(".hip"):
+            continue
+        text = open(os.path.join(CSRC, s), "rb").read()
+        if pat.search(text.decode("utf-8", "replace")):
+            h = hashlib.sha256()
+            h.update(text)
+            h.update(open(os.path.join(CSRC, "fx_pk.h"), "rb").read())
+            h.update(" ".join(FLAGS + EXTRA_FLAGS.get(s, [])).encode())
+            return h.hexdigest()[:16]
+    return None
+
+
 def hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):

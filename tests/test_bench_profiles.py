@@ -1,0 +1,57 @@
+"""CPU tests of bench.py's handling of the committed counter summaries (profiles/*_pmc_traffic*.json, *_sq_counters*.json): a
+summary counts only while its per-kernel source stamp equals the tree's (silently stale figures)."""
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_kernel_source_hash_names_every_profiled_kernel():
+    from fluidx12_amd.build import kernel_source_hash
+    for k in ("k_jacobi_strip3c", "k_jacobi_strip3h", "k_jacobi_block2", "k_jacobi_blockg", "k_advect_lds", "k_divergence_v4",
+              "k_project_v4", "k_freeze_dense", "k_freeze_tiles", "k_jacobi_strip2u", "k_raymarch_light", "k_raymarch_view"):
+        h = kernel_source_hash(k)
+        assert h and len(h) == 16, k
+    assert kernel_source_hash("k_no_such_kernel") is None
+    # two kernels of one file share a stamp, kernels of different files do not
+    assert kernel_source_hash("k_freeze_dense") == kernel_source_hash("k_freeze_tiles") != kernel_source_hash("k_jacobi_strip3c")
+
+
+def test_stale_summary_is_flagged_and_not_used(tmp_path, monkeypatch):
+    from fluidx12_amd.build import kernel_source_hash
+    b = load_bench()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    k = "k_jacobi_strip3c"
+    fresh = {"grid": 256, "iters": 40, "storage": "fp32", "kernels": {k: {"traffic": 2.5e8, "dispatches": 60, "source_hash": kernel_source_hash(k)}}}
+    (prof / "r09a_pmc_traffic.json").write_text(json.dumps(fresh))
+    assert b.pmc_traffic(k, 256, 40, "fp32") == (2.5e8, "r09a_pmc_traffic.json", False)
+    assert b.step_traffic(256, 40, "fp32")[2] == []
+    stale = dict(fresh, kernels={k: dict(fresh["kernels"][k], source_hash="0" * 16)})
+    (prof / "r09b_pmc_traffic.json").write_text(json.dumps(stale))            # newer file, taken on another version of the kernel
+    assert b.pmc_traffic(k, 256, 40, "fp32") == (2.5e8, "r09b_pmc_traffic.json", True)
+    assert b.step_traffic(256, 40, "fp32")[2] == [k]
+    assert b.pmc_traffic(k, 256, 40, "fp32", "faithful") is None             # another workload: no summary at all
+    sq = {"kernels": {k: {"limiter": "issuing", "source_hash": "0" * 16}}}
+    (prof / "r09b_sq_counters.json").write_text(json.dumps(sq))
+    assert b.limiter_note(k) is None
+    sq["kernels"][k]["source_hash"] = kernel_source_hash(k)
+    (prof / "r09c_sq_counters.json").write_text(json.dumps(sq))
+    assert b.limiter_note(k) == "issuing (r09c_sq_counters.json)"
+
+
+def test_committed_summaries_of_the_headline_kernels_are_fresh():
+    """the summaries bench.py's default line cites must have been taken on the committed kernels"""
+    b = load_bench()
+    for kernel, grid, iters, storage in (("k_jacobi_strip3c", 256, 40, "fp32"), ("k_jacobi_block2", 128, 40, "fp32")):
+        t = b.pmc_traffic(kernel, grid, iters, storage)
+        assert t is not None and t[2] is False, (kernel, t)

@@ -537,10 +537,36 @@ def test_bench_single_gpu_line_is_complete():
     assert d["timing_marks"] == {"every": 4, "marked_steps": 5}
     assert all(d["stage_ms_per_step"][k] > 0 for k in ("advect", "divergence", "jacobi", "project"))
     r = d["roofline"]
-    assert r["avg_launch_us"] > 0 and r["achieved"] > 0 and 0 < r["frac_compulsory"] < 1.5 and r["launches"] > 0
+    assert r["avg_launch_us"] > 0 and r["achieved"] > 0 and r["launches"] > 0
+    # `frac` bounds: the launch's compulsory bytes (p, b read once, p' written once) / its average duration / the 8 TB/s peak, from the same line
+    assert 0 < r["frac"] <= 1 and abs(r["frac"] - r["compulsory_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 8e12) < 1e-9
+    assert r["frac_algorithmic"] == pytest.approx(r["frac"] * r["sweeps_per_launch"]) and isinstance(r["stale"], bool)
+    assert (r["traffic"] is None) == (r["stale"] or r["traffic_source"] is None)
+    assert 0 < d["step_compulsory"]["frac_of_peak"] <= 1
     rn = d["render"]
     assert rn["light_pass_ms"] > 0 and rn["view_pass_ms"] > 0 and rn["cube_resolve_ms"] > 0 and rn["direct_march_ms"] > 0 and rn["rays_per_s"] > 0
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+
+
+def test_bench_reference_configuration_line():
+    """`bench.py --reference-config`: the configuration the reference itself runs (64-sweep cap + early-out, RGBA16F) on the sparse
+    solver -- its own roofline object (the dense first sweep) and the executed-sweep statistics"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--reference-config", "--grid", "128", "--steps", "20", "--warmup", "12",
+                          "--cpu-budget", "2", "--no-render"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["jacobi_mode"] == "faithful" and d["config"]["jacobi_iters"] == 64 and d["config"]["storage"] == "fp16"
+    assert "REFERENCE's own configuration" in d["config"]["workload"] and d["value"] > 0
+    r = d["roofline"]
+    assert "k_freeze_dense" in r["kernel"] and 0 < r["frac"] <= 1 and r["sweeps_per_launch"] == 1.0
+    sp = r["sparse_solver"]
+    assert 1 < sp["sweeps_executed_per_solve"] <= 64 and sp["solves"] == 20 and sp["tile_launches_per_step"] == 16
+    assert d["cpu_baseline"]["value"] > 0 and "reference configuration" in d["cpu_baseline"]["sample"]
 
 
 @pytest.mark.parametrize("overlap", [2, 0])

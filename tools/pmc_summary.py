@@ -16,6 +16,11 @@ import argparse
 import collections
 import csv
 import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fluidx12_amd.build import kernel_source_hash   # noqa: E402  (stamps each kernel's summary with the code it was measured on)
 
 # Every kernel here streams whole 128-B lines (coalesced 4-B or 16-B per lane), i.e. 128-B fabric requests that the
 # counter tallies at 64 B: the doubling applies to all of them.  Evidence: k_divergence must read >= 201 MB (three
@@ -45,9 +50,11 @@ def main():
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--storage", default="fp32")
+    ap.add_argument("--mode", default="fixed", help="bench.py --mode of the profiled run (fixed / faithful)")
+    ap.add_argument("--steps-profiled", type=int, default=5, help="--steps + --warmup of the profiled bench.py run (dispatches / this = launches per step)")
     a = ap.parse_args()
     f, w = load(a.fetch_csv, "FETCH_SIZE"), load(a.write_csv, "WRITE_SIZE")
-    out = {"grid": a.grid, "iters": a.iters, "storage": a.storage, "unit": "bytes per launch",
+    out = {"grid": a.grid, "iters": a.iters, "storage": a.storage, "mode": a.mode, "steps_profiled": a.steps_profiled, "unit": "bytes per launch",
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB*1024; FETCH x2 for 16-B-load kernels "
                      "(gfx950 correction, MI355X_MICROARCH.md); includes Infinity-Cache hits", "kernels": {}}
     for k in sorted(set(f) | set(w)):
@@ -55,7 +62,7 @@ def main():
         wr = sum(w[k]) / max(len(w[k]), 1) * 1024.0
         fc = fr * (2.0 if WIDE.get(k, True) else 1.0)
         out["kernels"][k] = {"dispatches": len(f[k]), "fetch_raw": fr, "fetch_corrected": fc, "write": wr, "traffic": fc + wr,
-                             "wide_loads": bool(WIDE.get(k, True))}
+                             "wide_loads": bool(WIDE.get(k, True)), "source_hash": kernel_source_hash(k)}
     print(json.dumps(out, indent=1))
 
 

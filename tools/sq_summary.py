@@ -17,6 +17,11 @@ import argparse
 import collections
 import csv
 import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fluidx12_amd.build import kernel_source_hash   # noqa: E402  (stamps each kernel's summary with the code it was measured on)
 
 
 def short(name):
@@ -40,16 +45,17 @@ def main():
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--storage", default="fp32")
+    ap.add_argument("--mode", default="fixed", help="bench.py --mode of the profiled run (fixed / faithful)")
     a = ap.parse_args()
     p1, p2 = load(a.pass1_csv), load(a.pass2_csv)
-    out = {"grid": a.grid, "iters": a.iters, "storage": a.storage,
+    out = {"grid": a.grid, "iters": a.iters, "storage": a.storage, "mode": a.mode,
            "method": "rocprofv3 --pmc, two SQ passes (8 slots each), averages per dispatch; fractions are of SQ_WAVE_CYCLES", "kernels": {}}
     for k in sorted(set(p1) | set(p2)):
         m1 = {c: sum(v) / len(v) for c, v in p1.get(k, {}).items()}
         m2 = {c: sum(v) / len(v) for c, v in p2.get(k, {}).items()}
         wc = m1.get("SQ_WAVE_CYCLES", 0.0)
         waves = m2.get("SQ_WAVES", 0.0)
-        e = {"dispatches": len(next(iter(p1.get(k, p2.get(k)).values()))), "waves": waves}
+        e = {"dispatches": len(next(iter(p1.get(k, p2.get(k)).values()))), "waves": waves, "source_hash": kernel_source_hash(k)}
         if wc:
             e["frac_issuing"] = m1.get("SQ_ACTIVE_INST_ANY", 0.0) / wc
             e["frac_issue_stalled"] = m1.get("SQ_WAIT_INST_ANY", 0.0) / wc
