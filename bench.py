@@ -189,11 +189,11 @@ def cpu_baseline(grid, iters, budget_s=20.0, mode=0, half=False, address=0):
     nz = int(max(8, min(grid, 0.6 * budget_s * tried[threads] / (float(grid) * grid * (steps + 1)))))
     rate = slab_rate(nz, steps, threads)
     single = slab_rate(4, 1, 1) if gomp is not None else None       # the pure scalar replay, one thread, a 4-plane slab
+    fmt = ("%d steps of advect+divergence+%d Jacobi+project on a %dx%dx%d sub-volume of the %d^3 workload "
+           + ("(reference configuration: sweep cap + per-cell early-out, RGBA16F storage) " if mode else "")
+           + "(oracle/liborc.so, -O3, OpenMP over planes; %d threads = the fastest of %s on a thin slab, %d CPUs visible)")
     return {"value": rate, "unit": "voxel-updates/s", "cores": threads, "kind": "port", "single_thread_value": single,
-            "sample": "%d steps of advect+divergence+%d Jacobi+project on a %dx%dx%d sub-volume of the %d^3 workload "
-                      + ("(reference configuration: sweep cap + per-cell early-out, RGBA16F storage) " if mode else "") +
-                      "(oracle/liborc.so, -O3, OpenMP over planes; %d threads = the fastest of %s on a thin slab, %d CPUs visible)"
-                      % (steps, iters, grid, grid, nz, grid, threads, sorted(tried), ncores)}
+            "sample": fmt % (steps, iters, grid, grid, nz, grid, threads, sorted(tried), ncores)}
 
 
 def main():

@@ -426,15 +426,15 @@ int jacobi_freeze(fx_ctx* ctx, hipStream_t s, uint32_t iters)
 	float* d = ctx->p_aux;
 	uint8_t* ma = ctx->fz_mask[0];
 	uint8_t* md = ctx->fz_mask[1];
-	int slot = 2;                                                       // the first tile launch
-	FX_HIP(launch_freeze_dense(ctx->g, src, ctx->b, a, d, ma, md, w, slot, stat, stat_hi, s));
+	FX_HIP(launch_freeze_dense(ctx->g, src, ctx->b, a, d, ma, md, w, stat, stat_hi, s));
 	mk.launches = 1; mk.sweeps = 1;
 	if (iters > 1) mk.split(MK_JACOBI_TAIL);                            // fx_timing books the dense sweep as the "main" launch, the tile launches beside it
 	const int T = jacobi_freeze_levels_per_launch();
 	int level = 1;
-	for (uint32_t left = iters - 1; left > 0; ++slot) {
+	int n = 0;
+	for (uint32_t left = iters - 1; left > 0; ++n) {
 		const int t = (int)std::min<uint32_t>((uint32_t)T, left);
-		FX_HIP(launch_freeze_tiles(ctx->g, a, ctx->b, d, ma, md, w, slot, t, level, stat, stat_hi, s));
+		FX_HIP(launch_freeze_tiles(ctx->g, a, ctx->b, d, ma, md, w, n, t, level, stat, stat_hi, s));
 		std::swap(a, d); std::swap(ma, md);
 		left -= (uint32_t)t; level += t;
 		mk.launches += 1; mk.sweeps += (uint64_t)t;
@@ -449,7 +449,7 @@ int jacobi_serial(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t
 	const bool multi = multi_rank(lead);
 	const int k = multi ? lead->opt_round : (int)iters;
 	int rc;
-	if (!multi && lead->frozen && lead->fz_tile_next && jacobi_freeze_supported(lead->g) && iters <= 255 && (iters + (uint32_t)jacobi_freeze_levels_per_launch() - 2) / (uint32_t)jacobi_freeze_levels_per_launch() <= 120)   // levels fit the stat word, launch ids stay inside the step's 128
+	if (!multi && lead->frozen && lead->fz_tile_next && jacobi_freeze_supported(lead->g) && iters <= 255 && (int)iters / jacobi_freeze_levels_per_launch() + 3 < kFreezeSlots)   // a level fits the stat word's low byte, every launch has its counters
 		return jacobi_freeze(lead, s, iters);
 	if ((rc = clear_freeze_masks(M, s))) return rc;
 	const ExchSpec bspec{ EX_DIV, k - 1, 0 };

@@ -30,7 +30,7 @@ struct fx_ctx {
 	uint8_t* fz_mask[2] = { nullptr, nullptr };
 	uint32_t* fz_tile_next = nullptr;  // per tile: tag of the solve that listed it last
 	void* fz_list[2] = { nullptr, nullptr };   // work lists of alternate launches
-	uint32_t* fz_counts = nullptr;  // two solves' list counters [2][kFreezeSlots][8]
+	uint32_t* fz_counts = nullptr;  // list lengths of two solves [2][kFreezeSlots launches][8 sub-lists]
 	uint32_t* fz_stat = nullptr;
 	uint32_t fz_gen = 0;            // solves so far (tags tile marks and stat words)
 	uint32_t fz_gen_mark = 0;       // fz_gen when the timing window opened

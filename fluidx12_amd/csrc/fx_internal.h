@@ -82,17 +82,17 @@ bool jacobi_freeze_supported(const Geom& g);
 int jacobi_freeze_tiles(const Geom& g);
 size_t jacobi_freeze_mask_bytes(const Geom& g);
 size_t jacobi_freeze_list_bytes(const Geom& g);     // one work list (eight per-XCD sub-lists of { tile, box } entries)
-size_t jacobi_freeze_count_words();                 // counters of one solve: kFreezeSlots launches x 8 sub-lists
+const int kFreezeSlots = 128;                       // launches a solve may enqueue
+size_t jacobi_freeze_count_words();                 // list-length counters of one solve: kFreezeSlots launches x 8 sub-lists
 int jacobi_freeze_levels_per_launch();
-const int kFreezeSlots = 128;                       // launches a solve may enqueue (slot 1 = the dense sweep, tile launches from 2)
-// the device-side work state of one solve: tile_mark[tile] == gen <=> the tile is on the first list already; list[slot & 1] is
-// read by the launch in `slot` and written by the one before it; counts = this solve's counters [slot][8] (zero on entry),
-// counts_next = the next solve's, cleared by this solve's dense launch
+// the device-side work state of one solve: tile_mark[tile] == gen <=> the tile is on the first list already; the dense sweep fills
+// list[0] and counts[0][8] (zero on entry); tile launch n reads list[n & 1] / counts[n] and appends its surviving tiles to
+// list[(n + 1) & 1] / counts[n + 1]; counts_next = the next solve's counters, cleared by this solve's dense launch
 struct FreezeWork { uint32_t* tile_mark; uint32_t gen; void* list[2]; int cap; uint32_t* counts; uint32_t* counts_next; };
 hipError_t launch_freeze_dense(const Geom& g, const float* p_in, const float* b, float* pA, float* pB, uint8_t* mA, uint8_t* mB,
-	const FreezeWork& w, int slot_out, uint32_t* stat, uint32_t stat_hi, hipStream_t s);
+	const FreezeWork& w, uint32_t* stat, uint32_t stat_hi, hipStream_t s);
 hipError_t launch_freeze_tiles(const Geom& g, const float* p_src, const float* b, float* p_dst, const uint8_t* m_src, uint8_t* m_dst,
-	const FreezeWork& w, int slot_in, int levels, int level_base, uint32_t* stat, uint32_t stat_hi, hipStream_t s);
+	const FreezeWork& w, int n, int levels, int level_base, uint32_t* stat, uint32_t stat_hi, hipStream_t s);
 // sweeps fused per launch for this geometry (1 = no fused path); requested > 0 overrides the default
 int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp);
 bool jacobi_prefers_three(const Geom& g, int requested, int nzp);

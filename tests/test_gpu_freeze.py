@@ -74,7 +74,7 @@ def test_freeze_solver_equals_oracle(dims, iters, knobs):
     assert (t.freeze_solves, t.freeze_sweeps) == (1, k)
 
 
-@pytest.mark.parametrize("T,NT,WGS", [(1, 512, 1024), (2, 256, 7), (3, 512, 64), (4, 256, 1), (3, 256, 100000)])
+@pytest.mark.parametrize("T,NT,WGS", [(1, 512, 1024), (2, 256, 7), (3, 512, 64), (4, 256, 1), (3, 256, 100000), (4, 1024, 512), (2, 1024, 16)])
 def test_freeze_solver_every_launch_shape(T, NT, WGS, knobs):
     """levels per launch, threads per workgroup and workgroups per launch change nothing"""
     knobs["FLUIDX_FREEZE_T"], knobs["FLUIDX_FREEZE_NT"], knobs["FLUIDX_FREEZE_WGS"] = str(T), str(NT), str(WGS)

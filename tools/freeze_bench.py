@@ -61,6 +61,6 @@ if __name__ == "__main__":
     a = ap.parse_args()
     cases = [{"FLUIDX_FREEZE_FAST": 1}, {"FLUIDX_FREEZE_FAST": 0}]
     if a.variants:
-        cases += [{"FLUIDX_FREEZE_T": t, "FLUIDX_FREEZE_NT": nt, "FLUIDX_FREEZE_WGS": w} for t in (2, 3, 4) for nt in (256, 512) for w in (512, 1024, 4096)]
+        cases += [{"FLUIDX_FREEZE_T": t, "FLUIDX_FREEZE_NT": nt, "FLUIDX_FREEZE_WGS": w} for t in (2, 3, 4) for nt in (512, 1024) for w in (512, 1024, 2048)]
     for env in cases:
         print(json.dumps(dict(grid=a.grid, storage=a.storage, **run(a.grid, a.warm, a.steps, a.storage, env))), flush=True)
