@@ -92,7 +92,8 @@ __device__ __forceinline__ void stage64(const void* col, const void* v0, const v
 		"global_load_lds_dword %4, off\n\t"
 		"s_mov_b32 m0, %0"
 		: "=&s"(keep)
-		: "v"(col), "v"(v0), "v"(v1), "v"(v2), "s"(lds_col), "s"(lds_vel), "n"(VEL_BYTES));
+		: "v"(col), "v"(v0), "v"(v1), "v"(v2), "s"(lds_col), "s"(lds_vel), "n"(VEL_BYTES)
+		: "scc");                                              // s_add_u32 writes SCC: the compiler must not keep a compare live across the statement
 }
 
 // fp16 storage: colour texel = 8 bytes -> its two dwords to two LDS planes NCELL * 4 bytes apart; a velocity half -> a dword per lane
@@ -122,7 +123,8 @@ __device__ __forceinline__ void stage64h(const void* col, const void* v0, const 
 		"global_load_lds_ushort %5, off\n\t"
 		"s_mov_b32 m0, %0"
 		: "=&s"(keep)
-		: "v"(col), "v"(col_hi), "v"(v0), "v"(v1), "v"(v2), "s"(lds_col), "s"(lds_vel), "n"(VEL_BYTES));
+		: "v"(col), "v"(col_hi), "v"(v0), "v"(v1), "v"(v2), "s"(lds_col), "s"(lds_vel), "n"(VEL_BYTES)
+		: "scc");
 }
 
 template <typename T>
@@ -358,7 +360,8 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
 		if (z + 2 <= ze) fill(z + 2);                           // plane ze is the z+1 of the chunk's last plane
 		compute(z);
 		// the four stores of this step were issued after the LDS-DMA loads and complete after them: vmcnt(4) = "plane z+2 has
-		// landed" without waiting for the store acknowledgements
+		// landed" without waiting for the store acknowledgements.  That the compiler emits exactly four store instructions per
+		// step behind the fill is checked on the generated ISA by tests/test_isa_contract.py
 		asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 		__syncthreads();                                         // plane z+2 is in the ring; plane z-1's slot may be overwritten
 	}

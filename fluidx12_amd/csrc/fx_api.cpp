@@ -230,7 +230,9 @@ int advect_range(fx_ctx* ctx, hipStream_t s, Range r, bool own_only)
 int options_digest(const fx_ctx* c)
 {
 	uint32_t h = 2166136261u;
-	for (uint32_t v : { (uint32_t)c->opt_overlap, (uint32_t)c->opt_round, (uint32_t)c->opt_adaptive }) h = (h ^ v) * 16777619u;
+	uint32_t dt_bits;
+	std::memcpy(&dt_bits, &c->time_step, 4);               // the time step the record's needs were measured with: the ranks must agree on it too
+	for (uint32_t v : { (uint32_t)c->opt_overlap, (uint32_t)c->opt_round, (uint32_t)c->opt_adaptive, dt_bits }) h = (h ^ v) * 16777619u;
 	return (int)(h & 0x3FFFFFFFu);
 }
 
@@ -279,16 +281,20 @@ int consume_record(fx_ctx* ctx, std::vector<fx_ctx*>& M)
 	for (int r = 0; r < n; ++r) { fault = fault || rec(r)[3] != 0; mismatch = mismatch || rec(r)[2] != rec(0)[2]; }
 	for (fx_ctx* m : M) { usable = usable && m->need_valid && m->time_step <= m->rec_dt; m->rec_pending = false; }
 	if (fault) {
-		for (fx_ctx* m : M) m->halo_fault = true;
+		// This return IS the chain-wide notice of the fault: every rank gets it once, from the same gathered record, and the step
+		// after it starts clean.  It does not block read-back again: the rank whose own advection overflowed still has its device
+		// flag up until its fx_synchronize acknowledges it (before or after this call), the other ranks have nothing to acknowledge.
+		// (Before: this set halo_fault on every rank, so the order fx_synchronize -> fx_simulate reported the same fault three times.)
 		ctx->last_error = "the previous step's advection left the exchanged halo on at least one rank";
 		return FX_E_HALO;
 	}
-	if (mismatch) { ctx->last_error = "the ranks of the chain run with different schedule options (fx_set_option)"; return FX_E_STATE; }
+	if (mismatch) { ctx->last_error = "the ranks of the chain run with different schedule options (fx_set_option) or time steps"; return FX_E_STATE; }
 	if (!usable) return FX_OK;
 	for (int r = 0; r + 1 < n; ++r)
 		if (std::max(rec(r)[1], rec(r + 1)[0]) > Ha) {
 			ctx->last_error = "the next advection needs more planes across a slab face than halo_advect provides";
-			return FX_E_HALO;                            // nothing of this step has touched a field yet
+			return FX_E_HALO;                            // the step is abandoned; its INPUTS (velocity[0], colour[!parity], pressure) are untouched -- in the
+			                                             // overlapped schedule the interior advection has already written part of its outputs (velocity[1], colour[parity])
 		}
 	for (fx_ctx* m : M) {
 		const int r = m->rank;
@@ -426,12 +432,14 @@ int jacobi_freeze(fx_ctx* ctx, hipStream_t s, uint32_t iters)
 	float* d = ctx->p_aux;
 	uint8_t* ma = ctx->fz_mask[0];
 	uint8_t* md = ctx->fz_mask[1];
+	// (The dense sweep writes level 1 to BOTH buffers the tile launches alternate between.  Writing one and letting the first tile
+	// launch carry the unlisted tiles' border cells across was built and measured level: the dense sweep 75 -> 46 us at 256^3, the
+	// first tile launch slower by as much -- the shell of a 4-deep cone around ~3000 listed tiles is more bytes than the second copy.)
 	FX_HIP(launch_freeze_dense(ctx->g, src, ctx->b, a, d, ma, md, w, stat, stat_hi, s));
 	mk.launches = 1; mk.sweeps = 1;
 	if (iters > 1) mk.split(MK_JACOBI_TAIL);                            // fx_timing books the dense sweep as the "main" launch, the tile launches beside it
 	const int T = jacobi_freeze_levels_per_launch();
-	int level = 1;
-	int n = 0;
+	int level = 1, n = 0;
 	for (uint32_t left = iters - 1; left > 0; ++n) {
 		const int t = (int)std::min<uint32_t>((uint32_t)T, left);
 		FX_HIP(launch_freeze_tiles(ctx->g, a, ctx->b, d, ma, md, w, n, t, level, stat, stat_hi, s));
@@ -1165,7 +1173,8 @@ int fx_upload(fx_ctx* ctx, int field, const void* host, size_t bytes)
 			// the next advection exchange is sized from a measurement of THIS buffer (FX_OPT_ADAPTIVE_HALO).  A loop-back group
 			// simply exchanges the whole halo once; the neighbours of an RCCL rank could not know, so the upload is refused
 			// while a measurement is out (switch the option off on every rank first, or upload before the first step)
-			if (!ctx->group->transport->is_local() && ctx->opt_adaptive && ctx->rec_pending) return FX_E_STATE;
+			// (fx_checkpoint_load is made by every rank: each drops its measurement, and all fall back to halo_advect planes together)
+			if (!ctx->group->transport->is_local() && ctx->opt_adaptive && ctx->rec_pending && !ctx->collective_upload) return FX_E_STATE;
 			ctx->need_valid = false;
 		}
 		char* dst = (char*)ctx->vel[field == FX_FIELD_VELOCITY1];
@@ -1180,8 +1189,9 @@ int fx_upload(fx_ctx* ctx, int field, const void* host, size_t bytes)
 		// group the flag can simply be dropped for everyone (the next step exchanges the colour again); across processes the
 		// neighbours cannot know, so the upload is refused (set FX_OPT_OVERLAP <= 2 before the step that precedes it).
 		if (ctx->col_halo_buf >= 0 && ctx->group) {
-			if (!ctx->group->transport->is_local()) return FX_E_STATE;
-			for (fx_ctx* m : ctx->group->members) if (m) m->col_halo_buf = -1;
+			if (!ctx->group->transport->is_local() && !ctx->collective_upload) return FX_E_STATE;
+			if (ctx->group->transport->is_local()) { for (fx_ctx* m : ctx->group->members) if (m) m->col_halo_buf = -1; }
+			else ctx->col_halo_buf = -1;                   // collective load: every rank forgets the early halo, the next step exchanges the colour again
 		}
 		char* dst = (char*)ctx->col[field == FX_FIELD_COLOR ? ctx->frame_parity : 1 - ctx->frame_parity];
 		if ((rc = ensure_stage(ctx, need))) return rc;
@@ -1577,6 +1587,15 @@ int fx_set_option(fx_ctx* ctx, uint32_t option, uint32_t value)
 		}
 	}
 	*slot = (int)value;
+	if (option == FX_OPT_ADAPTIVE_HALO) {
+		// Whether the measured need may size the next exchange is decided per rank from `need_valid`; both sides of a face must
+		// decide alike.  The one way to make the ranks differ was: option off, velocity upload into ONE rank, option on.  Setting the
+		// option -- a call every rank makes -- therefore drops the measurement everywhere: the next step exchanges halo_advect planes
+		// on all ranks and measures afresh.
+		std::vector<fx_ctx*> M;
+		for_members(ctx, M);
+		for (fx_ctx* m : M) { m->need_valid = false; if (m != ctx) m->opt_adaptive = (int)value; }
+	}
 	return FX_OK;
 }
 

@@ -7,16 +7,20 @@
 // their offsets: ranks call fx_checkpoint_save on the same path concurrently) and any decomposition can resume from it.
 // fp16-storage contexts lose nothing: their stored halves convert to fp32 and back exactly.
 //
-//   offset 0   char[8]  "FXCKPT02"
+//   offset 0   char[8]  "FXCKPT03"
 //          8   u32 X, Y, Z, storage (fx_storage of the writer, informational)
 //         24   u64 steps (simulated steps so far, from fx_get_step_count of the writer; informational)
 //         32   u32[8] reserved = 0
 //         64   float velocity[3][Z][Y][X] | float colour[Z][Y][X][4] | float pressure[Z][Y][X]
-//        end   u8 done[Z]: 1 = the three fields of this z plane are complete
-// A writer first clears the marks of its planes (and syncs), then writes its planes (and syncs), then sets the marks: a save
-// that was interrupted on any rank, or that one rank of a chain never made, leaves planes unmarked and fx_checkpoint_load
-// refuses them instead of resuming from zeros or from an older run's planes.  A context whose advection has left its halo
-// (FX_E_HALO pending) writes nothing.  The loader reads all three fields into host memory before it touches the context.
+//        end   u64 mark[Z]: steps + 1 of the save that wrote this z plane completely, 0 = incomplete
+// A writer first clears the marks of its planes (and syncs), then writes its planes (and syncs), then sets the marks to the save's
+// identity: the step count every rank of a chain agrees on without talking (they step together), + 1.  The loader requires every
+// plane it reads to carry the identity of the HEADER: a save that was interrupted on any rank, or that one rank of a chain never
+// made, leaves planes unmarked -- or, when the path held an older complete save (the periodic-checkpoint case: no O_TRUNC, the
+// other slabs write the same file), marked with the OLDER save's identity -- and fx_checkpoint_load refuses them instead of
+// resuming from zeros or from a mix of two time steps.  (Two saves at the same step count hold the same fields.)  A context whose
+// advection has left its halo (FX_E_HALO pending) writes nothing.  The loader reads all three fields into host memory before it
+// touches the context; on a chain it is called by every rank (like the save) and may follow any step.
 #include "fx_context.h"
 
 #include <cerrno>
@@ -33,7 +37,7 @@ namespace {
 
 struct Header { char magic[8]; uint32_t X, Y, Z, storage; uint64_t steps; uint32_t reserved[8]; };
 static_assert(sizeof(Header) == 64, "checkpoint header is 64 bytes");
-const char kMagic[8] = { 'F', 'X', 'C', 'K', 'P', 'T', '0', '2' };
+const char kMagic[8] = { 'F', 'X', 'C', 'K', 'P', 'T', '0', '3' };
 
 bool io_all(int fd, void* buf, size_t n, off_t off, bool write)
 {
@@ -52,7 +56,7 @@ Layout layout(uint32_t X, uint32_t Y, uint32_t Z)
 {
 	Layout l;
 	l.plane = (size_t)X * Y; l.cells = l.plane * Z;
-	l.vel = sizeof(Header); l.col = l.vel + (off_t)(3 * l.cells * 4); l.prs = l.col + (off_t)(4 * l.cells * 4); l.done = l.prs + (off_t)(l.cells * 4); l.end = l.done + (off_t)Z;
+	l.vel = sizeof(Header); l.col = l.vel + (off_t)(3 * l.cells * 4); l.prs = l.col + (off_t)(4 * l.cells * 4); l.done = l.prs + (off_t)(l.cells * 4); l.end = l.done + (off_t)(Z * sizeof(uint64_t));
 	return l;
 }
 
@@ -79,16 +83,16 @@ int fx_checkpoint_save(fx_ctx* ctx, const char* path)
 	Header h{};
 	std::memcpy(h.magic, kMagic, 8);
 	h.X = X; h.Y = Y; h.Z = Z; h.storage = ctx->desc.storage; h.steps = ctx->steps_simulated;
-	std::vector<unsigned char> marks(nz, 0);
+	std::vector<uint64_t> marks(nz, 0);
 	bool ok = ftruncate(fd, l.end) == 0 && io_all(fd, &h, sizeof h, 0, true) &&    // every writer stores the identical header
-		io_all(fd, marks.data(), nz, l.done + (off_t)z0, true) && fsync(fd) == 0;  // my planes are incomplete from here on
+		io_all(fd, marks.data(), nz * 8, l.done + (off_t)(z0 * 8), true) && fsync(fd) == 0;  // my planes are incomplete from here on
 	for (int a = 0; a < 3 && ok; ++a)
 		ok = io_all(fd, vel.data() + a * n, n * 4, l.vel + (off_t)(((size_t)a * l.cells + z0 * l.plane) * 4), true);
 	ok = ok && io_all(fd, col.data(), 4 * n * 4, l.col + (off_t)(z0 * l.plane * 16), true);
 	ok = ok && io_all(fd, prs.data(), n * 4, l.prs + (off_t)(z0 * l.plane * 4), true);
 	ok = ok && fsync(fd) == 0;
-	std::fill(marks.begin(), marks.end(), (unsigned char)1);
-	ok = ok && io_all(fd, marks.data(), nz, l.done + (off_t)z0, true) && fsync(fd) == 0;
+	std::fill(marks.begin(), marks.end(), h.steps + 1);                     // the identity of this save
+	ok = ok && io_all(fd, marks.data(), nz * 8, l.done + (off_t)(z0 * 8), true) && fsync(fd) == 0;
 	close(fd);
 	if (!ok) { ctx->last_error = std::string("checkpoint: write failed: ") + std::strerror(errno); return FX_E_INVALID; }
 	return FX_OK;
@@ -106,18 +110,19 @@ int fx_checkpoint_load(fx_ctx* ctx, const char* path)
 	const Layout l = layout(h.X, h.Y, h.Z);
 	if (!ok || std::memcmp(h.magic, kMagic, 8) != 0 || h.X != ctx->desc.grid_x || h.Y != ctx->desc.grid_y || h.Z != ctx->desc.grid_z || st.st_size != l.end) {
 		close(fd);
-		ctx->last_error = "checkpoint: not a FXCKPT02 file of this grid (or truncated)";
+		ctx->last_error = "checkpoint: not a FXCKPT03 file of this grid (or truncated)";
 		return FX_E_INVALID;
 	}
 	const size_t z0 = (size_t)ctx->g.z0, nz = (size_t)ctx->g.nz, n = l.plane * nz;
 	std::vector<float> vel, col, prs;
-	std::vector<unsigned char> marks;
+	std::vector<uint64_t> marks;
 	try { vel.resize(3 * n); col.resize(4 * n); prs.resize(n); marks.resize(nz); } catch (const std::bad_alloc&) { close(fd); return FX_E_NOMEM; }
-	ok = io_all(fd, marks.data(), nz, l.done + (off_t)z0, false);
+	ok = io_all(fd, marks.data(), nz * 8, l.done + (off_t)(z0 * 8), false);
 	for (size_t i = 0; ok && i < nz; ++i)
-		if (marks[i] != 1) {
+		if (marks[i] != h.steps + 1) {
 			close(fd);
-			ctx->last_error = "checkpoint: the file holds incomplete planes (an interrupted save, or a rank of the chain never wrote)";
+			ctx->last_error = marks[i] == 0 ? "checkpoint: the file holds incomplete planes (an interrupted save, or a rank of the chain never wrote)"
+				: "checkpoint: the file mixes planes of two saves (a rank of the chain did not take part in the last one)";
 			return FX_E_INVALID;
 		}
 	for (int a = 0; a < 3 && ok; ++a)
@@ -126,11 +131,16 @@ int fx_checkpoint_load(fx_ctx* ctx, const char* path)
 	ok = ok && io_all(fd, prs.data(), n * 4, l.prs + (off_t)(z0 * l.plane * 4), false);
 	close(fd);
 	if (!ok) { ctx->last_error = std::string("checkpoint: read failed: ") + std::strerror(errno); return FX_E_INVALID; }
-	// everything is in host memory: only now the context changes
+	// everything is in host memory: only now the context changes.  A load is made by EVERY rank of a chain, so what a single rank's
+	// fx_upload must refuse (its neighbours could not know: the measured advection need, the early colour halo) is simply
+	// invalidated here -- on all ranks alike, which therefore keep walking the same schedule.
 	int rc;
-	if ((rc = fx_upload(ctx, FX_FIELD_VELOCITY, vel.data(), 3 * n * 4)) || (rc = fx_upload(ctx, FX_FIELD_COLOR, col.data(), 4 * n * 4)) ||
-		(rc = fx_upload(ctx, FX_FIELD_PRESSURE, prs.data(), n * 4)))
-		return rc;
+	ctx->collective_upload = true;
+	rc = fx_upload(ctx, FX_FIELD_VELOCITY, vel.data(), 3 * n * 4);
+	if (!rc) rc = fx_upload(ctx, FX_FIELD_COLOR, col.data(), 4 * n * 4);
+	if (!rc) rc = fx_upload(ctx, FX_FIELD_PRESSURE, prs.data(), n * 4);
+	ctx->collective_upload = false;
+	if (rc) return rc;
 	ctx->steps_simulated = h.steps;
 	return FX_OK;
 }

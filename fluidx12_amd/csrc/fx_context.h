@@ -90,6 +90,7 @@ struct fx_ctx {
 	int opt_adaptive = 1;           // FX_OPT_ADAPTIVE_HALO
 	int adv_w_lo = 0, adv_w_hi = 0; // planes the current step's advection exchange carries across the lower / upper face
 	bool halo_fault = false;        // an overflow was seen and not yet acknowledged by fx_synchronize
+	bool collective_upload = false; // fx_checkpoint_load is uploading: every rank of the chain does the same, nothing needs refusing
 	bool rec_in_project = false;    // this step's record was written by the projection launch itself (no k_face_need pass)
 };
 

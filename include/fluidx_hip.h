@@ -166,9 +166,11 @@ int fx_render_environment(fx_ctx* ctx, void* stream, uint8_t frame_index);
 int fx_get_frame_info(fx_ctx* ctx, fx_frame_info* out);
 
 /* blocks until everything enqueued by this context has finished; reports FX_E_HALO if the advection back-trace of a multi-GPU
- * step left the exchanged halo, and thereby acknowledges it.  Until then fx_download of a simulation field, fx_checkpoint_save
- * and fx_comm_gather_color return FX_E_HALO as well, and the next fx_simulate returns it on EVERY rank of the chain (the flag
- * travels with the per-step record), so that no rank runs on, or stores, fields that differ from the single-domain run. */
+ * step left the exchanged halo ON THIS RANK, and thereby acknowledges it.  Until then fx_download of a simulation field,
+ * fx_checkpoint_save and fx_comm_gather_color of this rank return FX_E_HALO as well.  Independently the fault travels with the
+ * per-step record: the next fx_simulate returns FX_E_HALO on EVERY rank of the chain, once, without stepping (its inputs are
+ * untouched) -- the chain-wide notice, whichever of the two calls comes first; the fx_simulate after that starts clean.  No rank
+ * runs on, or stores, fields that differ from the single-domain run without having been told. */
 int fx_synchronize(fx_ctx* ctx);
 
 /* checkpoint / parity access (no reference counterpart; the reference cannot read fields back) */

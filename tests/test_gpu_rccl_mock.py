@@ -121,3 +121,54 @@ sys.exit(0 if all(flags) else 5)
     r, leftovers = launch(2, [str(script)], mock_lib, tmp_path, timeout=300)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2500:])
     assert leftovers == [], leftovers
+
+
+def test_one_rank_uploads_between_option_switches_and_the_chain_stays_in_step(mock_lib, tmp_path):
+    """FX_OPT_ADAPTIVE_HALO off, a velocity upload into ONE rank, the option on again -- the workflow the header
+    prescribes -- used to leave that rank exchanging halo_advect planes and its neighbour the measured need (mismatched send / recv
+    counts: a hang on RCCL, an error on the mock).  Setting the option now drops the measurement on every rank.  Also: a checkpoint
+    load made by every rank in the middle of a run (it used to be refused through fx_upload) resumes bit-identically."""
+    code = r'''
+import os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch.distributed as dist
+import fluidx12_amd as fx
+from fluidx12_amd import capi
+rank = int(os.environ["RANK"]); dist.init_process_group("gloo", rank=rank, world_size=2)
+dims, ck = (32, 32, 64), sys.argv[1]
+def chain():
+    f = fx.Fluid()
+    assert f.Init(64, 64, dims, slab=(rank * 32, 32), jacobi_iters=8, halo_advect=8, halo_jacobi=4, device=0)
+    box = [fx.comm_unique_id() if rank == 0 else None]; dist.broadcast_object_list(box, src=0)
+    f.comm_init_rank(box[0], rank, 2)
+    return f
+def steps(f, k0, n):
+    for k in range(k0, k0 + n):
+        f.UpdateFrame(np.float32(2.0 / 32), k % 3); f.Simulate(k % 3)
+f = chain()
+steps(f, 0, 4)                                            # the measured need is in use by now
+f.Synchronize()
+f.set_option(capi.OPT_ADAPTIVE_HALO, 0)                   # collective
+if rank == 0:
+    f.upload(fx.FIELD_VELOCITY, f.download(fx.FIELD_VELOCITY))    # one rank only (same values: the run stays comparable)
+f.set_option(capi.OPT_ADAPTIVE_HALO, 1)                   # collective: every rank falls back to halo_advect planes for one step
+steps(f, 4, 3)
+f.Synchronize()
+f.SaveCheckpoint(ck); dist.barrier()
+steps(f, 7, 2); f.Synchronize()
+after9 = f.download(fx.FIELD_COLOR)
+f.LoadCheckpoint(ck); dist.barrier()                      # every rank, mid-run, adaptive halo on: refused before
+steps(f, 7, 2); f.Synchronize()
+same = bool((f.download(fx.FIELD_COLOR).view(np.uint8) == after9.view(np.uint8)).all())
+# reference: a chain that just steps
+g = chain(); steps(g, 0, 9); g.Synchronize()
+same = same and bool((g.download(fx.FIELD_COLOR).view(np.uint8) == after9.view(np.uint8)).all()) and bool(after9.any())
+flags = [None, None]; dist.all_gather_object(flags, same)
+dist.barrier(); f.Release(); g.Release(); dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if all(flags) else 7)
+'''
+    script = tmp_path.parent / "mock_one_rank_upload.py"
+    script.write_text(code)
+    ck = tmp_path.parent / "mock_chain.fxck"
+    r, _ = launch(2, [str(script), str(ck)], mock_lib, tmp_path, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])

@@ -379,6 +379,63 @@ def test_x512_full_step_against_oracle():
     assert np.array_equal(g.download(fx.FIELD_PRESSURE), q)
 
 
+@pytest.mark.parametrize("storage,address", [("fp32", "clamp"), ("fp32", "mirror"), ("fp16", "clamp"), ("fp16", "mirror")])
+def test_x256_full_step_against_oracle(storage, address):
+    """The headline grid itself (BASELINE configs[2], and configs[4] with fp16 storage): one whole step at 256^3 from a DEVELOPED state
+    -- 48 steps of the plume plus a patch of fast random flow, so that k_advect_lds serves lanes from its LDS tile and lanes through its
+    gather path -- stage by stage against the oracle on the same inputs: advection (k_advect_lds), divergence, 40 sweeps in the default
+    schedule (12 x k_jacobi_strip3c + 2 x k_jacobi_strip2u), projection; then fx_simulate as a whole against the staged run."""
+    dims = (256, 256, 256)
+    X, Y, Z = dims
+    half = storage == "fp16"
+    amode = int(address == "mirror")
+    f = make(dims, storage=storage, jacobi_iters=40, advect_address=address)
+    dt = f32(f.default_time_step())
+    for k in range(48):
+        f.UpdateFrame(dt, k % 3)
+        f.Simulate(k % 3)
+    vel, col, p = f.download(fx.FIELD_VELOCITY), f.download(fx.FIELD_COLOR), f.download(fx.FIELD_PRESSURE)
+    assert np.abs(vel).max() > 0.05                                     # the plume moves
+    rng = np.random.default_rng(256 + amode + 2 * half)
+    vel[:, 150:200, 100:180, 60:200] += (rng.random((3, 50, 80, 140), dtype=f32) - f32(0.5)) * f32(3.0)     # back-traces of up to 3 cells
+    if half:
+        vel = vel.astype(np.float16).astype(f32)
+    reach = np.abs(vel).max(axis=0) * dt * X
+    assert 0.005 < (reach >= 1.0).mean() < 0.5                          # both tap sources are exercised
+    f.upload(fx.FIELD_VELOCITY, vel); f.upload(fx.FIELD_COLOR, col); f.upload(fx.FIELD_PRESSURE, p)
+    f.UpdateFrame(dt, 0)
+    f.Advect()
+    gv, gc = f.download(fx.FIELD_VELOCITY1), f.download(fx.FIELD_COLOR)
+    vo, co = orc.advect(vel, col, dt, address=amode, half=half)
+    assert rel_l2(gv, vo) < (2e-4 if half else 1e-6) and rel_l2(gc, co) < (2e-4 if half else 1e-6)       # fp16: an exp2 ulp can flip a binary16 rounding
+    z, y, x = np.meshgrid(np.arange(Z), np.arange(Y), np.arange(X), indexing="ij", sparse=True)
+    far = ((x + .5) / X - .5) ** 2 + ((y + .5) / Y - .1) ** 2 + ((z + .5) / Z - .5) ** 2 > (1.5 / 16) ** 2
+    assert np.array_equal(gv[:, far], vo[:, far]) and np.array_equal(gc[far], co[far])       # no transcendental there: bit-exact
+    del vo, co, far
+    f.Divergence()
+    b = orc.divergence(gv)
+    assert np.array_equal(f.download(fx.FIELD_DIVERGENCE), b)
+    f.timing_enable(True); f.timing_read(True)
+    f.Jacobi(40)
+    f.Synchronize()
+    t = f.timing_read(True)
+    f.timing_enable(False)
+    assert t.jacobi_sweeps == 40 and t.jacobi_launches == 14 and t.jacobi_main_sweeps == 36      # 12 x 3 + 2 x 2
+    q, _ = orc.jacobi(p, b, 40)
+    assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
+    f.Project()
+    want = orc.project(gv, q, half)
+    assert np.array_equal(f.download(fx.FIELD_VELOCITY), want)
+    # the same step through fx_simulate
+    g = make(dims, storage=storage, jacobi_iters=40, advect_address=address)
+    g.upload(fx.FIELD_VELOCITY, vel); g.upload(fx.FIELD_COLOR, col); g.upload(fx.FIELD_PRESSURE, p)
+    g.UpdateFrame(dt, 0)
+    g.Simulate(0)
+    g.Synchronize()
+    assert np.array_equal(g.download(fx.FIELD_VELOCITY), want) and np.array_equal(g.download(fx.FIELD_COLOR), gc)
+    assert np.array_equal(g.download(fx.FIELD_PRESSURE), q)
+
+
 @pytest.mark.parametrize("X", [128, 256, 512])
 def test_full_size_properties(X):
     f = make((X, X, X), jacobi_iters=80 if X == 512 else 40)

@@ -724,3 +724,64 @@ def test_an_overflow_on_one_rank_stops_every_rank_and_blocks_read_back():
     assert e.value.status == capi.FX_E_HALO
     fl[0].Synchronize()                                      # acknowledged
     assert fl[1].download(fx.FIELD_VELOCITY).shape == (3, 16, 32, 32)
+
+
+def test_overwriting_a_checkpoint_from_one_rank_only_is_refused(tmp_path):
+    """the periodic-checkpoint case.  A complete file exists; at a later step only ONE slab saves again (its peer
+    crashed, or refused with FX_E_HALO).  The header then names the new save while the peer's planes still carry the old save's
+    marks: the load must refuse the mix of two time steps (format 02 accepted it: its marks were 0 / 1)."""
+    dims = (32, 32, 32)
+    path = str(tmp_path / "periodic.fxck")
+    fl = run_slabs(dims, 3, 2, jacobi_iters=6, halo_jacobi=2, halo_advect=6)
+    for f in fl:
+        f.SaveCheckpoint(path)
+    assert fx.read_checkpoint(path)["complete"].all()
+    fl2 = run_slabs(dims, 0, 2, jacobi_iters=6, halo_jacobi=2, halo_advect=6)
+    for f in fl2:
+        f.LoadCheckpoint(path)                               # a complete save loads
+    for k in range(2):
+        fl[0].UpdateFrame(f32(fl[0].default_time_step()), k)
+        fl[0].Simulate(k)
+    fl[0].Synchronize()
+    fl[0].SaveCheckpoint(path)                               # rank 1 never writes this one
+    ck = fx.read_checkpoint(path)
+    assert ck["steps"] == 5 and ck["complete"][:16].all() and not ck["complete"][16:].any() and (ck["marks"][16:] == 4).all()
+    whole = fx.Fluid()
+    assert whole.Init(0, 0, dims, jacobi_iters=6)
+    for f in (fl2[1], whole):                                # whoever reads a plane of the older save refuses
+        with pytest.raises(fx.FluidxError) as e:
+            f.LoadCheckpoint(path)
+        assert e.value.status == capi.FX_E_INVALID
+    fl[1].SaveCheckpoint(path)                               # the peer catches up: complete again
+    for f in fl2 + [whole]:
+        f.LoadCheckpoint(path)
+
+
+def test_fault_acknowledged_before_the_next_step_is_reported_once_more_and_no_further():
+    """the usual per-frame order Simulate -> Synchronize -> Simulate: the synchronize reports and acknowledges the fault of the
+    rank it happened on; the next fx_simulate still tells EVERY rank, once, and steps nothing; it does not block read-back again, and the
+    step after it runs"""
+    dims = (32, 32, 32)
+    fl = run_slabs(dims, 0, 2, jacobi_iters=4, halo_jacobi=1, halo_advect=1)
+    vel = np.zeros((3, 16, 32, 32), f32)
+    vel[2] = 3.0
+    for f in fl:
+        f.upload(fx.FIELD_VELOCITY, vel)
+    dt = f32(2.0 / 32)
+    fl[0].UpdateFrame(dt, 0)
+    fl[0].Simulate(0)                                        # overflows on the device
+    with pytest.raises(fx.FluidxError) as e:
+        fl[0].Synchronize()
+    assert e.value.status == capi.FX_E_HALO
+    for f in fl:                                             # acknowledged: read-back works, and a slow field stops the overflow
+        assert f.download(fx.FIELD_VELOCITY).shape == (3, 16, 32, 32)
+        f.upload(fx.FIELD_VELOCITY, np.zeros_like(vel))
+    fl[0].UpdateFrame(dt, 1)
+    with pytest.raises(fx.FluidxError) as e:
+        fl[0].Simulate(1)                                    # the chain-wide notice of the old fault
+    assert e.value.status == capi.FX_E_HALO
+    fl[0].Synchronize()                                      # nothing new to report
+    assert fl[1].download(fx.FIELD_COLOR).shape == (16, 32, 32, 4)
+    fl[0].UpdateFrame(dt, 2)
+    fl[0].Simulate(2)
+    fl[0].Synchronize()

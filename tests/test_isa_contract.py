@@ -1,0 +1,63 @@
+"""Contracts between hand-written `s_waitcnt` counts and the code the compiler generates around them, checked on the gfx950 ISA
+(hipcc cross-compiles without a GPU).  ADVICE r2: k_advect_lds hands a ring slot over with `s_waitcnt vmcnt(4)` = "everything but
+this step's four stores has landed", which silently breaks if the compiler ever emits another number of store instructions."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from fluidx12_amd import build as b
+
+
+def device_isa(source, tmp_path):
+    out = tmp_path / (source + ".s")
+    cmd = [b.hipcc()] + b.FLAGS + b.EXTRA_FLAGS.get(source, []) + ["-x", "hip", "--cuda-device-only", "-S", os.path.join(b.CSRC, source), "-o", str(out)]
+    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+    return out.read_text().splitlines()
+
+
+def kernels(lines, prefix):
+    """{mangled name: body lines} of the functions whose name contains `prefix`"""
+    out, cur = {}, None
+    for ln in lines:
+        m = re.match(r"^(_Z\w+):", ln)
+        if m:
+            cur = m.group(1) if prefix in m.group(1) else None
+            if cur:
+                out[cur] = []
+        elif cur:
+            if ln.strip().startswith(".end_amdhsa_kernel") or ln.strip().startswith(".Lfunc_end"):
+                cur = None
+            else:
+                out[cur].append(ln.strip())
+    return out
+
+
+def test_advect_lds_hands_over_behind_exactly_four_stores(tmp_path):
+    ks = kernels(device_isa("fx_advect_lds.hip", tmp_path), "k_advect_lds")
+    assert len(ks) >= 4                                         # <HALF> x <tile rows>
+    for name, body in ks.items():
+        waits = [i for i, ln in enumerate(body) if ln.startswith("s_waitcnt vmcnt(4)") and body[i - 1].startswith(";;#ASMSTART")]   # the hand-written ones
+        assert waits, name
+        for w in waits:
+            stores = 0
+            for ln in reversed(body[:w]):
+                if ln.startswith(("global_load", "buffer_load", "flat_load", "s_barrier", "scratch_")):
+                    break
+                if ln.startswith(("global_store", "buffer_store", "flat_store")):
+                    stores += 1
+            assert stores == 4, (name, w, stores)
+        # the LDS-DMA statements change SCC (s_add_u32 m0): they must say so
+        assert any("global_load_lds" in ln for ln in body)
+    src = open(os.path.join(b.CSRC, "fx_advect_lds.hip")).read()
+    assert src.count('"scc"') >= 2 and "s_add_u32 m0" in src
+
+
+def test_no_scratch_in_the_hot_kernels(tmp_path):
+    """register-resident kernels must not spill (a spill turns a bandwidth-bound kernel into a scratch-bound one silently)"""
+    for source, prefix in (("fx_jacobi_freeze.hip", "k_freeze_"), ("fx_advect_lds.hip", "k_advect_lds")):
+        text = "\n".join(device_isa(source, tmp_path))
+        for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
+            if prefix in m.group(1):
+                assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", m.group(2)), m.group(1)
