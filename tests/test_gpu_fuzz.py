@@ -386,7 +386,7 @@ def test_mutated_dds_files_never_crash_the_decoder(seed):
     import os
     rng = np.random.default_rng(40000 + seed)
     data = bytearray(open(os.path.join(os.path.dirname(__file__), "..", "examples", "data", "probe_32.dds"), "rb").read())
-    kind = int(rng.integers(0, 5))
+    kind = int(rng.integers(0, 6))
     if kind == 0:                                              # flip bytes in the 148-byte header
         for _ in range(int(rng.integers(1, 6))):
             data[int(rng.integers(0, 148))] = int(rng.integers(0, 256))
@@ -437,7 +437,7 @@ def test_damaged_checkpoint_files_are_refused(seed, tmp_path):
     f.SaveCheckpoint(str(good))
     want = {fid: f.download(fid) for fid in (fx.FIELD_VELOCITY, fx.FIELD_COLOR, fx.FIELD_PRESSURE)}
     data = bytearray(good.read_bytes())
-    kind = int(rng.integers(0, 5))
+    kind = int(rng.integers(0, 6))
     ok_expected = False
     if kind == 0:
         data = data[:int(rng.integers(0, len(data)))]                       # truncated
@@ -447,10 +447,12 @@ def test_damaged_checkpoint_files_are_refused(seed, tmp_path):
     elif kind == 2:
         data += bytes(int(rng.integers(1, 64)))                             # trailing bytes
     elif kind == 3:
-        data[int(rng.integers(64, len(data) - dims[2]))] ^= 0x01            # payload: still a valid file of this grid
+        data[int(rng.integers(64, len(data) - 8 * dims[2]))] ^= 0x01        # payload: still a valid file of this grid
         ok_expected = True
+    elif kind == 4:
+        data[len(data) - 8 * (1 + int(rng.integers(0, dims[2])))] = 0       # a plane not marked complete (interrupted save): u64 mark -> 0
     else:
-        data[len(data) - 1 - int(rng.integers(0, dims[2]))] = 0             # a plane not marked complete (interrupted save)
+        data[len(data) - 8 * (1 + int(rng.integers(0, dims[2])))] = 9       # a plane left over from another save (its mark names other steps)
     bad = tmp_path / "bad.fxck"
     bad.write_bytes(bytes(data))
     g2 = fx.Fluid()

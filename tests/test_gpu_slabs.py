@@ -358,12 +358,12 @@ def test_checkpoint_resume_is_bit_identical_across_decompositions(tmp_path):
         for f in fl:
             f.SaveCheckpoint(path)
         hdr = np.fromfile(path, np.uint32, 8)
-        assert bytes(hdr[:2].tobytes()) == b"FXCKPT02" and tuple(hdr[2:5]) == dims and hdr[6] == 5
+        assert bytes(hdr[:2].tobytes()) == b"FXCKPT03" and tuple(hdr[2:5]) == dims and hdr[6] == 5
         ck = fx.read_checkpoint(path)                                    # the numpy reader sees what the slabs wrote
         assert ck["grid"] == dims and ck["steps"] == 5
         assert np.array_equal(ck["pressure"], gather(fl, fx.FIELD_PRESSURE, 0)) and np.array_equal(ck["velocity"], gather(fl, fx.FIELD_VELOCITY, 1))
         cells = dims[0] * dims[1] * dims[2]
-        assert (tmp_path / ("state_%s.fxck" % storage)).stat().st_size == 64 + 8 * cells * 4 + dims[2] and ck["complete"].all()
+        assert (tmp_path / ("state_%s.fxck" % storage)).stat().st_size == 64 + 8 * cells * 4 + 8 * dims[2] and ck["complete"].all()
         # (a) single domain resumes
         one = fx.Fluid()
         assert one.Init(800, 800, dims, **kw)
