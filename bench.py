@@ -126,7 +126,10 @@ def workload_grid(G, N, scaling):
 # (FX_OPT_OVERLAP, FX_OPT_JACOBI_ROUND): advection halo behind the interior advection + serial pressure rounds of 8 sweeps;
 # pressure exchanges behind the interior sweeps of rounds of 8 (also with the next step's colour halo sent behind the pressure
 # phase) and of 4 sweeps (face planes first); nothing overlapped
-SCHEDULE_CANDIDATES = [(1, 8), (2, 8), (2, 4), (0, 8)]
+# Order: the plainest schedule first (everything on the compute stream), then one more overlapped piece at a time -- if the first
+# hardware run dies in one of them, the lines already printed say how far it got.  (0, 4) is there for the link model: two serial
+# schedules with different message counts separate per-call latency from bandwidth.
+SCHEDULE_CANDIDATES = [(0, 8), (0, 4), (1, 8), (2, 8), (2, 4)]
 # FX_OPT_OVERLAP 3 drives a second RCCL communicator concurrently with the first; it has only ever run against the mock and the
 # loop-back transport, so it is a candidate only on request (FLUIDX_BENCH_OVERLAP3=1 or --schedule 3,8)
 if os.environ.get("FLUIDX_BENCH_OVERLAP3", "0") == "1":
@@ -254,7 +257,23 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        raise SystemExit(subprocess.call(cmd, env=env))
+        # The first real N > 1 run is the driver's: it must not be able to hang.  The ranks run in their own process group under a
+        # wall-clock budget; past it the whole group is killed and this launcher (which never touched the GPU) exits non-zero.
+        # The ranks carry their own watchdog (below) with tighter, per-phase budgets, so this is the second line.
+        budget = float(os.environ.get("FLUIDX_BENCH_TIMEOUT_S", "1500"))
+        import signal
+        proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+        try:
+            rc_ = proc.wait(timeout=budget)
+        except subprocess.TimeoutExpired:
+            sys.stderr.write("bench.py: the %d rank processes did not finish within %.0f s (FLUIDX_BENCH_TIMEOUT_S): killing them\n" % (args.gpus, budget))
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            proc.wait()
+            rc_ = 124
+        raise SystemExit(rc_)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and not (world == 1 and args.gpus == 1):
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
@@ -265,12 +284,43 @@ def main():
     if loop:
         N = loop                                  # logical ranks; still one process, one GPU, no torch.distributed
 
+    # ---- watchdog (N > 1): a rank stuck in a collective or a stream wait cannot report anything; a thread can.  Every phase arms a
+    # deadline; past it the thread says which phase, on which rank, and ends the process (exit code 3) -- torch.distributed.run then
+    # tears the other ranks down and the launcher exits non-zero.  FLUIDX_BENCH_WATCHDOG_S scales the budgets (seconds per phase).
+    class Watchdog:
+        def __init__(self, on):
+            self.deadline, self.label, self.on = None, "", on
+            self.base = float(os.environ.get("FLUIDX_BENCH_WATCHDOG_S", "120"))
+            if on:
+                import threading
+                threading.Thread(target=self._run, daemon=True).start()
+
+        def arm(self, label, factor=1.0):
+            self.label, self.deadline = label, time.monotonic() + self.base * factor
+
+        def disarm(self):
+            self.deadline = None
+
+        def _run(self):
+            while True:
+                time.sleep(0.25)
+                d = self.deadline
+                if d is not None and time.monotonic() > d:
+                    sys.stderr.write("bench.py watchdog: rank %d stuck in phase '%s' for more than its budget -- exiting with code 3\n" % (rank, self.label))
+                    sys.stderr.flush()
+                    os._exit(3)
+
+    watch = Watchdog(N > 1 and not loop and not args.dry_run)
+
     dist = None
     if N > 1 and not loop:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")               # RCCL's own complaints, on stderr (stdout carries the one JSON line)
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+        watch.arm("process group init")
         if args.dry_run or args.shared_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=N)
             if args.shared_gpu:
@@ -312,7 +362,9 @@ def main():
         uid = box[0]
         assert isinstance(uid, (bytes, bytearray)) and len(uid) >= 128
         if not args.dry_run:
+            watch.arm("fx_comm_init_rank (ncclCommInitRank x 2)")
             fluid.comm_init_rank(uid, rank, N)
+        watch.disarm()
 
     dt = 2.0 / GY                                 # FluidX12.cpp:266
 
@@ -365,20 +417,49 @@ def main():
             kk = 0
             K = pressure_round(GX, GZ // N, args.iters)
             for ov, rnd in [(o, K if r == 8 else r) for o, r in SCHEDULE_CANDIDATES]:
+                watch.arm("schedule candidate overlap=%d round=%d" % (ov, rnd))
+                if os.environ.get("FLUIDX_BENCH_FAULT") == "stall:%d" % rank and ov == 1:
+                    watch.disarm()                                  # fault injection (tests): this rank never arrives; its PEERS must notice
+                    time.sleep(1e6)
                 apply(ov, rnd)
                 one_step(kk); kk += 1
                 barrier_sync()
+                for m_ in members:
+                    m_.timing_enable(True); m_.timing_read(reset=True)
                 t_ = time.perf_counter()
                 for _ in range(3):
                     one_step(kk); kk += 1
                 barrier_sync()
                 el = max_over_ranks(time.perf_counter() - t_)      # identical on every rank => identical pick
-                tried.append({"overlap": ov, "jacobi_round": rnd, "ms_per_step": el / 3 * 1e3})
+                tm = (members[len(members) // 2] if loop else fluid).timing_read(reset=True)
+                for m_ in members:
+                    m_.timing_enable(False)
+                c_ = {"overlap": ov, "jacobi_round": rnd, "ms_per_step": el / 3 * 1e3,
+                      # this rank's (loop-back: an inner rank's) exchanges over the three steps: group calls, bytes sent, time on their stream
+                      "exchange_calls_per_step": tm.exchange_calls / 3.0, "sent_MB_per_step": tm.exchange_bytes / 3.0 / 1e6,
+                      "exchange_ms_per_step": tm.exchange_ms / 3.0}
+                tried.append(c_)
+                if rank == 0:                                       # one line per candidate as it completes (stderr: stdout carries the result line)
+                    sys.stderr.write("bench.py candidate: " + json.dumps(c_) + "\n"); sys.stderr.flush()
+            watch.disarm()
             best = min(tried, key=lambda c: c["ms_per_step"])
             apply(best["overlap"], best["jacobi_round"])
             schedule = {"overlap": best["overlap"], "jacobi_round": best["jacobi_round"],
                         "picked": "fastest of the candidates timed before the warm-up", "candidates": tried}
+            # link model from the two SERIAL schedules (nothing hidden: exchange time = calls x latency + bytes / bandwidth; two
+            # equations, two unknowns) -- replaces the 50 GB/s and 20 us per call DESIGN.md section 7 had to assume
+            ser = [c for c in tried if c["overlap"] == 0 and c["exchange_calls_per_step"] > 0]
+            if len(ser) >= 2 and ser[0]["exchange_calls_per_step"] != ser[1]["exchange_calls_per_step"]:
+                a_, b_ = ser[0], ser[1]
+                det = a_["exchange_calls_per_step"] * b_["sent_MB_per_step"] - b_["exchange_calls_per_step"] * a_["sent_MB_per_step"]
+                if abs(det) > 1e-9:
+                    lat_ms = (a_["exchange_ms_per_step"] * b_["sent_MB_per_step"] - b_["exchange_ms_per_step"] * a_["sent_MB_per_step"]) / det
+                    per_mb = (a_["exchange_calls_per_step"] * b_["exchange_ms_per_step"] - b_["exchange_calls_per_step"] * a_["exchange_ms_per_step"]) / det
+                    schedule["link_model"] = {"group_call_latency_us": lat_ms * 1e3, "GBps_per_rank_both_faces": (1.0 / per_mb) if per_mb > 0 else None,
+                                              "from": "exchange_ms = calls x latency + MB / bandwidth over the serial candidates (0, %d) and (0, %d); "
+                                                      "loop-back and mock runs measure copies, not links" % (a_["jacobi_round"], b_["jacobi_round"])}
 
+    watch.arm("warm-up", 1.0 + args.warmup / 50.0)
     for k in range(args.warmup):
         one_step(k)
     if fluid is not None:
@@ -394,6 +475,7 @@ def main():
     mark_every = 4 if args.steps >= 8 else 1
     if os.environ.get("FLUIDX_BENCH_MARK_EVERY"):
         mark_every = max(1, int(os.environ["FLUIDX_BENCH_MARK_EVERY"]))
+    watch.arm("timed steps", 1.0 + args.steps / 50.0)
     t0 = time.perf_counter()
     for k in range(args.steps):
         if mark_every > 1 and k % mark_every in (0, 2, 3):             # marked: steps 2, 6, 10 ... (not the first one behind the barrier)
@@ -404,6 +486,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     elapsed = max_over_ranks(elapsed)
+    watch.disarm()
 
     roof = None
     timing = None
@@ -418,6 +501,10 @@ def main():
             schedule["halo_advect_allocated_planes"] = halo_adv if halo_adv else 6
             schedule["advect_planes_per_face_and_step"] = timing.advect_halo_planes / max(timing.steps, 1) / max(faces, 1)
             schedule["sent_MB_per_face_and_step"] = timing.exchange_bytes / max(timing.steps, 1) / max(faces, 1) / 1e6
+            schedule["exchange_calls_per_step"] = timing.exchange_calls / max(timing.steps, 1)
+            schedule["exchange_ms_per_step"] = timing.exchange_ms / max(timing.steps, 1)
+            if timing.exchange_ms > 0:                      # bytes this rank sent / the time its exchanges spent on their stream (latency included)
+                schedule["link_GBps_sent_over_exchange_time"] = timing.exchange_bytes / (timing.exchange_ms * 1e-3) / 1e9
             schedule["adaptive_halo"] = os.environ.get("FLUIDX_BENCH_ADAPTIVE", "1") != "0"
         if N == 1 and G > 1 and not args.no_render:
             # config 3's second half, reported beside (never inside) `value`: the cube-map-space ray march of the state the

@@ -191,6 +191,7 @@ int do_exchange(fx_ctx* ctx, const std::vector<fx_ctx*>& M, const ExchSpec* spec
 		if (M[i]->timing_on) for (const Seg& sg : segs[i]) M[i]->acc.exchange_bytes += sg.bytes;     // what this rank sends
 	}
 	if (!total) return FX_OK;
+	for (fx_ctx* m : M) if (m->timing_on) m->acc.exchange_calls += 1;  // one group call (ncclGroupStart .. End) per exchange
 	return ctx->group->transport->exchange(ctx->group, segs, s, channel);
 }
 

@@ -123,6 +123,7 @@ typedef struct fx_timing {
 	 * loop (CSPoisson.hlsli:11-25) executes in them -- per solve 1 + the last sweep that left a cell relaxing, at most N.
 	 * jacobi_sweeps above counts the levels ENQUEUED (always N: the sparse solver needs no read-back to stop early). */
 	uint64_t freeze_solves, freeze_sweeps;
+	uint64_t exchange_calls;    /* slab ranks: halo exchanges issued (one RCCL group call each) over the timed steps */
 } fx_timing;
 
 int fx_abi_version(void);

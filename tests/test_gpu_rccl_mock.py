@@ -59,8 +59,13 @@ def test_bench_under_torchrun_shared_gpu(nranks, steps, mock_lib, tmp_path):
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == nranks and d["shared_gpu"] is True and d["value"] > 0
-    assert d["config"]["schedule"]["picked"].startswith("fastest") and len(d["config"]["schedule"]["candidates"]) == 4
+    assert d["config"]["schedule"]["picked"].startswith("fastest") and len(d["config"]["schedule"]["candidates"]) == 5
     assert "RCCL send/recv" in d["config"]["parallelism"] and d["roofline"]["achieved"] > 0
+    sc = d["config"]["schedule"]
+    assert all(c["exchange_calls_per_step"] > 0 and c["sent_MB_per_step"] > 0 for c in sc["candidates"])
+    assert [c["overlap"] for c in sc["candidates"]] == [0, 0, 1, 2, 2]          # the plainest schedule first
+    assert "link_model" in sc and sc["exchange_calls_per_step"] > 0
+    assert r.stderr.count("bench.py candidate: {") == 5                      # one line per candidate as it completes
 
 
 def test_mock_flags_a_byte_count_mismatch(mock_lib, tmp_path):
@@ -172,3 +177,22 @@ sys.exit(0 if all(flags) else 7)
     ck = tmp_path.parent / "mock_chain.fxck"
     r, _ = launch(2, [str(script), str(ck)], mock_lib, tmp_path, timeout=300)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_a_stalled_peer_ends_the_bench_with_an_error_instead_of_a_hang(mock_lib, tmp_path):
+    """`python bench.py --gpus 2` as the driver starts it (the launcher path).  Rank 1 never enters the second
+    schedule candidate; rank 0 blocks in its exchange; its watchdog names the phase and exits, torch.distributed.run tears the
+    job down and the launcher returns non-zero -- well inside the launcher's own budget.  The candidate that completed before is on
+    stderr."""
+    import time
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), OMP_NUM_THREADS="1", FLUIDX_RCCL_LIB=mock_lib,
+               FXMOCK_DIR=str(tmp_path), FXMOCK_TIMEOUT_S="600", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               FLUIDX_BENCH_FAULT="stall:1", FLUIDX_BENCH_WATCHDOG_S="8", FLUIDX_BENCH_TIMEOUT_S="150")
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "64", "--steps", "3", "--warmup", "1", "--shared-gpu"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=400)
+    took = time.monotonic() - t0
+    shutil.rmtree(tmp_path, ignore_errors=True)
+    assert r.returncode != 0 and took < 140, (r.returncode, took, r.stderr[-2000:])
+    assert "watchdog: rank 0 stuck in phase 'schedule candidate overlap=1" in r.stderr, r.stderr[-3000:]
+    assert r.stderr.count("bench.py candidate: {") == 2 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
