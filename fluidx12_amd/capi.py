@@ -17,7 +17,7 @@ STORAGE_FP32, STORAGE_FP16 = 0, 1
 JACOBI_FIXED, JACOBI_FAITHFUL = 0, 1
 ADDRESS_CLAMP, ADDRESS_MIRROR = 0, 1
 FLAG_JACOBI_FUSE_MASK, FLAG_NO_OVERLAP, FLAG_RENDER_ONLY = 0xF, 0x10, 0x20
-OPT_OVERLAP, OPT_JACOBI_ROUND, OPT_ADAPTIVE_HALO = 1, 2, 3
+OPT_OVERLAP, OPT_JACOBI_ROUND, OPT_ADAPTIVE_HALO, OPT_COUNT_SAMPLES = 1, 2, 3, 4
 ABI_VERSION = 5                      # FX_ABI_VERSION of include/fluidx_hip.h
 (FIELD_VELOCITY, FIELD_VELOCITY1, FIELD_COLOR, FIELD_COLOR_PREV, FIELD_PRESSURE, FIELD_DIVERGENCE,
  FIELD_LIGHTMAP, FIELD_CUBEMAP, FIELD_TARGET, FIELD_TARGET_FLOAT) = range(10)
@@ -44,7 +44,8 @@ class Timing(C.Structure):
                 ("jacobi_sweeps", C.c_uint64), ("renders", C.c_uint64), ("resolve_ms", C.c_double),
                 ("jacobi_main_ms", C.c_double), ("jacobi_main_launches", C.c_uint64), ("jacobi_main_sweeps", C.c_uint64),
                 ("exchange_bytes", C.c_uint64), ("advect_halo_planes", C.c_uint64), ("chain_ms", C.c_double),
-                ("freeze_solves", C.c_uint64), ("freeze_sweeps", C.c_uint64), ("exchange_calls", C.c_uint64)]
+                ("freeze_solves", C.c_uint64), ("freeze_sweeps", C.c_uint64), ("exchange_calls", C.c_uint64),
+                ("view_samples", C.c_uint64), ("light_samples", C.c_uint64), ("lightmap_fetches", C.c_uint64)]
 
 
 # every symbol include/fluidx_hip.h declares: name -> (restype, argtypes)

@@ -121,7 +121,7 @@ void free_all(fx_ctx* c)
 		if (c->p[i]) (void)hipFree(c->p[i]);
 	}
 	void* others[] = { c->env, c->occ, c->target, c->target_float, c->p_face[0], c->p_face[1], c->b, c->frozen, c->lightmap, c->cube, c->sh_dev, c->halo_overflow, c->stage,
-		c->sh_scratch[0], c->sh_scratch[1], c->sh_scratch[2], c->sh_scratch[3], c->p_aux, c->fz_mask[0], c->fz_mask[1], c->fz_tile_next, c->fz_stat, c->fz_list[0], c->fz_list[1], c->fz_counts };
+		c->sh_scratch[0], c->sh_scratch[1], c->sh_scratch[2], c->sh_scratch[3], c->p_aux, c->fz_mask[0], c->fz_mask[1], c->fz_tile_next, c->fz_stat, c->fz_list[0], c->fz_list[1], c->fz_counts, c->sample_counters };
 	for (void* q : others) if (q) (void)hipFree(q);
 	for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
 	if (c->step_rec) (void)hipFree(c->step_rec);
@@ -971,6 +971,8 @@ int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags)
 	if (!ctx->desc.viewport_w || !ctx->desc.viewport_h) return FX_E_INVALID;   // created without a viewport: nothing to project the cube onto
 	if (!ctx->view_valid) return FX_E_STATE;
 	if (ctx->g.nz != ctx->g.Zg) return FX_E_INVALID;            // rays cross slabs: multi-GPU rendering is row f-3
+	unsigned long long* cnt = ctx->opt_count_samples ? ctx->sample_counters : nullptr;
+	if (cnt && (flags & FX_SEPARATE_LIGHT_PASS)) ctx->acc.light_samples += (uint64_t)ctx->g.cells_owned();   // the light pass's own fetch per voxel
 	if (!(flags & FX_RAY_MARCH_CUBEMAP)) {
 		// direct screen-space marching (Fluid.cpp:432-443): one ray per pixel, straight onto the render target
 		DeviceGuard dgd(ctx->device);
@@ -985,16 +987,16 @@ int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags)
 				ScopedMark mk(ctx, sd, MK_LIGHT);
 				occd = render_occupancy(ctx, colord, sd);
 				FX_HIP(launch_raymarch_light(ctx->g, ctx->half, colord, ctx->lightmap, ctx->fc,
-					ctx->has_sh ? ctx->sh_dev : nullptr, ctx->max_light_samples, occd, sd));
+					ctx->has_sh ? ctx->sh_dev : nullptr, ctx->max_light_samples, occd, sd, cnt));
 			}
 			ScopedMark mk(ctx, sd, MK_VIEW);
 			FX_HIP(launch_raycast_direct(ctx->g, ctx->half, colord, ctx->lightmap, ctx->fc, nullptr, W, H,
-				ctx->ray_samples, ctx->max_light_samples, 1, ctx->target, ctx->target_float, occd, sd));   // rayCastVDirect :953-972
+				ctx->ray_samples, ctx->max_light_samples, 1, ctx->target, ctx->target_float, occd, sd, cnt));   // rayCastVDirect :953-972
 		} else {
 			ScopedMark mk(ctx, sd, MK_VIEW);
 			occd = render_occupancy(ctx, colord, sd);
 			FX_HIP(launch_raycast_direct(ctx->g, ctx->half, colord, nullptr, ctx->fc, ctx->has_sh ? ctx->sh_dev : nullptr, W, H,
-				ctx->max_ray_samples, ctx->max_light_samples, 0, ctx->target, ctx->target_float, occd, sd));   // rayCastDirect :932-951
+				ctx->max_ray_samples, ctx->max_light_samples, 0, ctx->target, ctx->target_float, occd, sd, cnt));   // rayCastDirect :932-951
 		}
 		if (ctx->timing_on) ctx->acc.renders += 1;
 		return FX_OK;
@@ -1010,16 +1012,16 @@ int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags)
 			ScopedMark mk(ctx, s, MK_LIGHT);
 			occ = render_occupancy(ctx, color, s);
 			FX_HIP(launch_raymarch_light(ctx->g, ctx->half, color, ctx->lightmap, ctx->fc,
-				ctx->has_sh ? ctx->sh_dev : nullptr, ctx->max_light_samples, occ, s));     // Fluid.cpp:857-878
+				ctx->has_sh ? ctx->sh_dev : nullptr, ctx->max_light_samples, occ, s, cnt));     // Fluid.cpp:857-878
 		}
 		ScopedMark mk(ctx, s, MK_VIEW);
 		FX_HIP(launch_raymarch_view(ctx->g, ctx->half, color, ctx->lightmap, ctx->fc, nullptr, size,
-			ctx->visibility_mask, ctx->ray_samples, ctx->max_light_samples, 1, cube, occ, s));   // Fluid.cpp:880-908
+			ctx->visibility_mask, ctx->ray_samples, ctx->max_light_samples, 1, cube, occ, s, cnt));   // Fluid.cpp:880-908
 	} else {
 		ScopedMark mk(ctx, s, MK_VIEW);
 		occ = render_occupancy(ctx, color, s);
 		FX_HIP(launch_raymarch_view(ctx->g, ctx->half, color, nullptr, ctx->fc, ctx->has_sh ? ctx->sh_dev : nullptr,
-			size, ctx->visibility_mask, ctx->ray_samples, ctx->max_light_samples, 0, cube, occ, s));   // Fluid.cpp:825-855
+			size, ctx->visibility_mask, ctx->ray_samples, ctx->max_light_samples, 0, cube, occ, s, cnt));   // Fluid.cpp:825-855
 	}
 	if (ctx->timing_on) ctx->acc.renders += 1;
 	return FX_OK;
@@ -1394,6 +1396,13 @@ int fx_timing_read(fx_ctx* ctx, fx_timing* out, int reset)
 	DeviceGuard dg(ctx->device);
 	int rc = drain_timing(ctx);
 	if (rc) return rc;
+	if (ctx->sample_counters) {                         // FX_OPT_COUNT_SAMPLES: fold the device shards into the accumulators
+		unsigned long long h[kSampleShards * 3];
+		FX_HIP(hipDeviceSynchronize());
+		FX_HIP(hipMemcpy(h, ctx->sample_counters, sizeof h, hipMemcpyDeviceToHost));
+		FX_HIP(hipMemset(ctx->sample_counters, 0, sizeof h));
+		for (int i = 0; i < kSampleShards; ++i) { ctx->acc.view_samples += h[3 * i]; ctx->acc.light_samples += h[3 * i + 1]; ctx->acc.lightmap_fetches += h[3 * i + 2]; }
+	}
 	*out = ctx->acc;
 	// faithful mode, sparse solver: sweeps the reference's loop would have executed, per solve since the last reset (the device
 	// keeps the last level that left a cell relaxing, one word per solve; older solves than the ring holds are not counted)
@@ -1572,6 +1581,16 @@ int fx_set_option(fx_ctx* ctx, uint32_t option, uint32_t value)
 	case FX_OPT_OVERLAP: if (value > 3) return FX_E_INVALID; slot = &ctx->opt_overlap; break;
 	case FX_OPT_JACOBI_ROUND: if (value < 1 || value > ctx->desc.halo_jacobi) return FX_E_INVALID; slot = &ctx->opt_round; break;
 	case FX_OPT_ADAPTIVE_HALO: if (value > 1) return FX_E_INVALID; slot = &ctx->opt_adaptive; break;
+	case FX_OPT_COUNT_SAMPLES: {                       // local to the context: statistics of its own renders
+		if (value > 1) return FX_E_INVALID;
+		DeviceGuard dgc(ctx->device);
+		if (value && !ctx->sample_counters) {
+			FX_HIP(hipMalloc((void**)&ctx->sample_counters, kSampleShards * 3 * sizeof(unsigned long long)));
+			FX_HIP(hipMemset(ctx->sample_counters, 0, kSampleShards * 3 * sizeof(unsigned long long)));
+		}
+		ctx->opt_count_samples = (int)value;
+		return FX_OK;
+	}
 	default: return FX_E_INVALID;
 	}
 	// These options select the exchange sequence and the exchanged byte counts: ranks that disagree would hang RCCL or corrupt

@@ -73,6 +73,8 @@ struct fx_ctx {
 	int rank, nranks;
 	int opt_overlap;                // FX_OPT_OVERLAP
 	int opt_round;                  // FX_OPT_JACOBI_ROUND
+	int opt_count_samples = 0;      // FX_OPT_COUNT_SAMPLES
+	unsigned long long* sample_counters = nullptr;   // device, kSampleShards x 3 (allocated when the option is first switched on)
 	std::string last_error;
 	int col_halo_buf = -1;          // FX_OPT_OVERLAP 3: index of the colour buffer whose halo planes the previous step already exchanged (-1: none)
 	uint64_t steps_simulated = 0;   // fx_simulate calls with dt > 0 (recorded in checkpoints)

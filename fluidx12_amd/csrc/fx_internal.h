@@ -113,17 +113,20 @@ hipError_t launch_to_storage(const float* src, void* dst, size_t n, int half_sto
 hipError_t launch_from_storage(const void* src, float* dst, size_t n, int half_store, hipStream_t s);
 
 // ---- ray march launchers (fx_render.hip)
+// counters (FX_OPT_COUNT_SAMPLES, else null): 64 shards x { colour samples of view rays, density samples of light / AO rays, light-map
+// fetches }, added to by every thread that took one
+const int kSampleShards = 64;
 // `occ` (may be null) = the occupancy grid of launch_occupancy: lets the marches skip the gathers of empty space, bit-identically
 hipError_t launch_occupancy(const Geom& g, int half_store, const void* color, float* occ, hipStream_t s);
 hipError_t launch_raymarch_light(const Geom& g, int half_store, const void* color, uint32_t* lightmap,
-	const FrameConsts& fc, const float* sh, uint32_t num_samples, const float* occ, hipStream_t s);
+	const FrameConsts& fc, const float* sh, uint32_t num_samples, const float* occ, hipStream_t s, unsigned long long* counters = nullptr);
 hipError_t launch_raymarch_view(const Geom& g, int half_store, const void* color, const uint32_t* lightmap,
 	const FrameConsts& fc, const float* sh, int cube_size, uint32_t mask, uint32_t num_samples,
-	uint32_t num_light_samples, int separate, uint8_t* cube, const float* occ, hipStream_t s);
+	uint32_t num_light_samples, int separate, uint8_t* cube, const float* occ, hipStream_t s, unsigned long long* counters = nullptr);
 // direct screen-space march (row f-2): one ray per pixel, blended into the RGBA8 target (and/or kept as float4)
 hipError_t launch_raycast_direct(const Geom& g, int half_store, const void* color, const uint32_t* lightmap,
 	const FrameConsts& fc, const float* sh, int W, int H, uint32_t num_samples, uint32_t num_light_samples, int separate,
-	uint8_t* target, float* out_float, const float* occ, hipStream_t s);
+	uint8_t* target, float* out_float, const float* occ, hipStream_t s, unsigned long long* counters = nullptr);
 // 2-D visualiser (PSVisualizeColor): colour[parity] of a Z = 1 grid onto the render target
 hipError_t launch_visualize_color(const Geom& g, int half_store, const void* color, int W, int H, uint8_t* target, float* out_float, hipStream_t s);
 hipError_t launch_lightmap_decode(const uint32_t* lightmap, float* out, size_t n, hipStream_t s);

@@ -158,12 +158,13 @@ __device__ __forceinline__ float step_factor(float dDensity, float transm, float
 // CastLightRay (RayMarch.hlsli:215-247)
 template <bool HALF>
 __device__ void cast_light_ray(float& transm, const Geom& g, const typename ColTex<HALF>::T* col,
-	float ox, float oy, float oz, float dx, float dy, float dz, float stepScale, uint32_t numSamples, const float* __restrict__ occ = nullptr)
+	float ox, float oy, float oz, float dx, float dy, float dz, float stepScale, uint32_t numSamples, const float* __restrict__ occ, uint32_t& ns)
 {
 	float t = stepScale, prev = 0.0f;
 	for (uint32_t i = 0; i < numSamples; ++i) {
 		const float px = fmaf(dx, t, ox), py = fmaf(dy, t, oy), pz = fmaf(dz, t, oz);
 		if (outside(px, py, pz)) break;
+		++ns;                                                  // density samples taken (FX_OPT_COUNT_SAMPLES; a register increment otherwise)
 		const Taps tp = make_taps(g, fmaf(px, 0.5f, 0.5f), fmaf(py, 0.5f, 0.5f), fmaf(pz, 0.5f, 0.5f));
 		const float density = sample_density<HALF>(col, tp, occ);
 		const float nt = fmaf(-density, 0.800000012f, 1.0f) * transm;
@@ -204,8 +205,9 @@ __device__ void sh_irradiance(float out[3], const float* __restrict__ sh, float 
 template <bool HALF>
 __device__ void gi_term(float irr[3], float& ao, const Geom& g, const typename ColTex<HALF>::T* col, const FrameConsts& fc,
 	const float* __restrict__ sh, float px, float py, float pz, float u, float v, float w, float stepScale, uint32_t numSamples,
-	const float* __restrict__ occ = nullptr)
+	const float* __restrict__ occ, uint32_t& ns)
 {
+	ns += 6;
 	// GetDensityGradient (RayMarch.hlsli:73-95)
 	const float qxm = sample_density<HALF>(col, make_taps(g, u, v, w, -1, 0, 0), occ);
 	const float qxp = sample_density<HALF>(col, make_taps(g, u, v, w, 1, 0, 0), occ);
@@ -225,7 +227,7 @@ __device__ void gi_term(float irr[3], float& ao, const Geom& g, const typename C
 	const float rd = rsqf(dot3(dx, dy, dz, dx, dy, dz));
 	dx *= rd; dy *= rd; dz *= rd;
 	ao = 1.0f;
-	cast_light_ray<HALF>(ao, g, col, px, py, pz, dx, dy, dz, stepScale, numSamples, occ);
+	cast_light_ray<HALF>(ao, g, col, px, py, pz, dx, dy, dz, stepScale, numSamples, occ, ns);
 }
 
 __device__ __forceinline__ void light_dir_local(const FrameConsts& fc, float& lx, float& ly, float& lz)
@@ -237,10 +239,22 @@ __device__ __forceinline__ void light_dir_local(const FrameConsts& fc, float& lx
 	lx *= r; ly *= r; lz *= r;
 }
 
+// FX_OPT_COUNT_SAMPLES: counters = [64 shards][3] { colour samples of view rays, density samples of light / AO rays, light-map fetches };
+// null in every timed launch (the per-thread counts are then dead registers)
+__device__ __forceinline__ void flush_counts(unsigned long long* __restrict__ counters, uint32_t view, uint32_t light, uint32_t lm)
+{
+	if (!counters) return;
+	unsigned long long* c = counters + 3 * ((blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u) & 63u);
+	if (view) atomicAdd(c + 0, (unsigned long long)view);
+	if (light) atomicAdd(c + 1, (unsigned long long)light);
+	if (lm) atomicAdd(c + 2, (unsigned long long)lm);
+}
+
 // ---------------------------------------------------------------------------------------------------
 template <bool HALF>
 __global__ __launch_bounds__(256) void k_raymarch_light(const Geom g, const typename ColTex<HALF>::T* __restrict__ col,
-	uint32_t* __restrict__ lightmap, const FrameConsts fc, const float* __restrict__ sh, uint32_t numSamples, const float* __restrict__ occ)
+	uint32_t* __restrict__ lightmap, const FrameConsts fc, const float* __restrict__ sh, uint32_t numSamples, const float* __restrict__ occ,
+	unsigned long long* __restrict__ counters)
 {
 	const int x = blockIdx.x * 64 + threadIdx.x;
 	const int y = blockIdx.y * 4 + threadIdx.y;
@@ -252,12 +266,13 @@ __global__ __launch_bounds__(256) void k_raymarch_light(const Geom g, const type
 	const float u = fmaf(ox, 0.5f, 0.5f), v = fmaf(oy, 0.5f, 0.5f), w = fmaf(oz, 0.5f, 0.5f);   // :36
 	const float density = sample_density<HALF>(col, make_taps(g, u, v, w), occ);   // :37
 	float shadow = 1.0f, ao = 1.0f, irr[3] = { 0.0f, 0.0f, 0.0f };
+	uint32_t ns = 0;                                                               // (the voxel's own density sample is counted on the host: X Y Z of them)
 	if (density >= 0.00999999978f) {                                               // :44
 		const float stepScale = 3.46410155f / (float)numSamples;                   // RayMarch.hlsli:29-30
 		float lx, ly, lz;
 		light_dir_local(fc, lx, ly, lz);
-		cast_light_ray<HALF>(shadow, g, col, ox, oy, oz, lx, ly, lz, stepScale, numSamples, occ);   // :55
-		if (sh) gi_term<HALF>(irr, ao, g, col, fc, sh, ox, oy, oz, u, v, w, stepScale, numSamples, occ);   // :59-68
+		cast_light_ray<HALF>(shadow, g, col, ox, oy, oz, lx, ly, lz, stepScale, numSamples, occ, ns);   // :55
+		if (sh) gi_term<HALF>(irr, ao, g, col, fc, sh, ox, oy, oz, u, v, w, stepScale, numSamples, occ, ns);   // :59-68
 	}
 	float out[3];
 #pragma unroll
@@ -267,6 +282,7 @@ __global__ __launch_bounds__(256) void k_raymarch_light(const Geom g, const type
 		out[a] = fmaf(shadow, lc, amb);                                            // :79
 	}
 	lightmap[((size_t)z * g.Y + y) * g.X + x] = pack_r11g11b10(out[0], out[1], out[2]);
+	flush_counts(counters, 0u, ns, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -302,7 +318,8 @@ __device__ __forceinline__ uint32_t to_unorm8(float v)
 template <bool HALF, bool SEPARATE>
 __device__ __forceinline__ void march_ray(const Geom& g, const typename ColTex<HALF>::T* __restrict__ col,
 	const uint32_t* __restrict__ lightmap, const FrameConsts& fc, const float* __restrict__ sh, const float o[3], const float d[3],
-	float tMax, uint32_t numSamples, uint32_t numLightSamples, float& sr, float& sg, float& sb, float& sa, const float* __restrict__ occ)
+	float tMax, uint32_t numSamples, uint32_t numLightSamples, float& sr, float& sg, float& sb, float& sa, const float* __restrict__ occ,
+	uint32_t& nv, uint32_t& nl, uint32_t& nm)
 {
 	const float stepScale = 3.46410155f / (float)numSamples;
 	const float lightStep = 3.46410155f / (float)numLightSamples;
@@ -317,16 +334,18 @@ __device__ __forceinline__ void march_ray(const Geom& g, const typename ColTex<H
 		const float u = fmaf(qx, 0.5f, 0.5f), v = fmaf(qy, 0.5f, 0.5f), w = fmaf(qz, 0.5f, 0.5f);
 		const Taps tp = make_taps(g, u, v, w);
 		const float4 c = sample_color<HALF>(col, tp, occ);                         // :157
+		++nv;
 		float newStep = stepScale;
 		if (0.00999999978f < c.w) {                                                // :161
 			float light[3];
 			if (SEPARATE) {                                                        // RayMarch.hlsli:253-258
 				const float3 l = sample_light(lightmap, tp);
+				++nm;
 				light[0] = l.x; light[1] = l.y; light[2] = l.z;
 			} else {                                                               // RayMarch.hlsli:260-294
 				float shadow = 1.0f, ao = 1.0f, irr[3] = { 0.0f, 0.0f, 0.0f };
-				cast_light_ray<HALF>(shadow, g, col, qx, qy, qz, lx, ly, lz, lightStep, numLightSamples, occ);
-				if (sh) gi_term<HALF>(irr, ao, g, col, fc, sh, qx, qy, qz, u, v, w, lightStep, numLightSamples, occ);
+				cast_light_ray<HALF>(shadow, g, col, qx, qy, qz, lx, ly, lz, lightStep, numLightSamples, occ, nl);
+				if (sh) gi_term<HALF>(irr, ao, g, col, fc, sh, qx, qy, qz, u, v, w, lightStep, numLightSamples, occ, nl);
 #pragma unroll
 				for (int a = 0; a < 3; ++a) {
 					const float amb = sh ? ao * irr[a] : fc.ambient[3] * fc.ambient[a];
@@ -350,7 +369,7 @@ __device__ __forceinline__ void march_ray(const Geom& g, const typename ColTex<H
 template <bool HALF, bool SEPARATE>
 __global__ __launch_bounds__(64) void k_raymarch_view(const Geom g, const typename ColTex<HALF>::T* __restrict__ col,
 	const uint32_t* __restrict__ lightmap, const FrameConsts fc, const float* __restrict__ sh, int size, uint32_t mask,
-	uint32_t numSamples, uint32_t numLightSamples, uint32_t* __restrict__ cube, const float* __restrict__ occ)
+	uint32_t numSamples, uint32_t numLightSamples, uint32_t* __restrict__ cube, const float* __restrict__ occ, unsigned long long* __restrict__ counters)
 {
 	const int face = blockIdx.z;
 	if (!((mask >> face) & 1u)) return;                                            // CSRayMarch.hlsl:102
@@ -382,7 +401,9 @@ __global__ __launch_bounds__(64) void k_raymarch_view(const Geom g, const typena
 	const float tMax = fmaxf((tg[2] + -o[2]) / d[2], fmaxf((tg[1] + -o[1]) / d[1], (tg[0] + -o[0]) / d[0]));   // :118
 
 	float sr, sg, sb, sa;
-	march_ray<HALF, SEPARATE>(g, col, lightmap, fc, sh, o, d, tMax, numSamples, numLightSamples, sr, sg, sb, sa, occ);
+	uint32_t nv = 0, nl = 0, nm = 0;
+	march_ray<HALF, SEPARATE>(g, col, lightmap, fc, sh, o, d, tMax, numSamples, numLightSamples, sr, sg, sb, sa, occ, nv, nl, nm);
+	flush_counts(counters, nv, nl, nm);
 	sr *= 0.159154937f; sg *= 0.159154937f; sb *= 0.159154937f;                    // :192
 	cube[((size_t)face * size + y) * size + x] =
 		to_unorm8(sr) | (to_unorm8(sg) << 8) | (to_unorm8(sb) << 16) | (to_unorm8(sa) << 24);   // :195
@@ -397,7 +418,8 @@ __global__ __launch_bounds__(64) void k_raymarch_view(const Geom g, const typena
 template <bool HALF, bool SEPARATE>
 __global__ __launch_bounds__(64) void k_raycast_direct(const Geom g, const typename ColTex<HALF>::T* __restrict__ col,
 	const uint32_t* __restrict__ lightmap, const FrameConsts fc, const float* __restrict__ sh, int W, int H,
-	uint32_t numSamples, uint32_t numLightSamples, uint32_t* __restrict__ target, float4* __restrict__ out_float, const float* __restrict__ occ)
+	uint32_t numSamples, uint32_t numLightSamples, uint32_t* __restrict__ target, float4* __restrict__ out_float, const float* __restrict__ occ,
+	unsigned long long* __restrict__ counters)
 {
 	const int px = blockIdx.x * 8 + threadIdx.x, py = blockIdx.y * 8 + threadIdx.y;
 	if (px >= W || py >= H) return;
@@ -420,7 +442,9 @@ __global__ __launch_bounds__(64) void k_raycast_direct(const Geom g, const typen
 	d[0] *= rl; d[1] *= rl; d[2] *= rl;
 	if (!compute_ray_origin(o, d)) return;                                         // :50 discard
 	float sr, sg, sb, sa;
-	march_ray<HALF, SEPARATE>(g, col, lightmap, fc, sh, o, d, 3.40282347e+38f, numSamples, numLightSamples, sr, sg, sb, sa, occ);
+	uint32_t nv = 0, nl = 0, nm = 0;
+	march_ray<HALF, SEPARATE>(g, col, lightmap, fc, sh, o, d, 3.40282347e+38f, numSamples, numLightSamples, sr, sg, sb, sa, occ, nv, nl, nm);
+	flush_counts(counters, nv, nl, nm);
 	sr *= 0.159154937f; sg *= 0.159154937f; sb *= 0.159154937f;                    // :124
 	if (out_float) out_float[pix] = make_float4(sr, sg, sb, sa);
 	if (target) {
@@ -511,22 +535,22 @@ hipError_t launch_occupancy(const Geom& g, int half_store, const void* color, fl
 
 // ---------------------------------------------------------------------------------------------------
 hipError_t launch_raymarch_light(const Geom& g, int half_store, const void* color, uint32_t* lightmap,
-	const FrameConsts& fc, const float* sh, uint32_t num_samples, const float* occ, hipStream_t s)
+	const FrameConsts& fc, const float* sh, uint32_t num_samples, const float* occ, hipStream_t s, unsigned long long* counters)
 {
 	const dim3 grid((g.X + 63) / 64, (g.Y + 3) / 4, g.Zg), block(64, 4, 1);
-	if (half_store) hipLaunchKernelGGL(k_raymarch_light<true>, grid, block, 0, s, g, (const h16x4*)color, lightmap, fc, sh, num_samples, occ);
-	else hipLaunchKernelGGL(k_raymarch_light<false>, grid, block, 0, s, g, (const float4*)color, lightmap, fc, sh, num_samples, occ);
+	if (half_store) hipLaunchKernelGGL(k_raymarch_light<true>, grid, block, 0, s, g, (const h16x4*)color, lightmap, fc, sh, num_samples, occ, counters);
+	else hipLaunchKernelGGL(k_raymarch_light<false>, grid, block, 0, s, g, (const float4*)color, lightmap, fc, sh, num_samples, occ, counters);
 	return hipGetLastError();
 }
 
 hipError_t launch_raymarch_view(const Geom& g, int half_store, const void* color, const uint32_t* lightmap,
 	const FrameConsts& fc, const float* sh, int cube_size, uint32_t mask, uint32_t num_samples,
-	uint32_t num_light_samples, int separate, uint8_t* cube, const float* occ, hipStream_t s)
+	uint32_t num_light_samples, int separate, uint8_t* cube, const float* occ, hipStream_t s, unsigned long long* counters)
 {
 	const dim3 grid((cube_size + 7) / 8, (cube_size + 7) / 8, 6), block(8, 8, 1);
 	uint32_t* out = reinterpret_cast<uint32_t*>(cube);
 #define FX_LAUNCH(H, S) hipLaunchKernelGGL((k_raymarch_view<H, S>), grid, block, 0, s, g, \
-	(const typename ColTex<H>::T*)color, lightmap, fc, sh, cube_size, mask, num_samples, num_light_samples, out, occ)
+	(const typename ColTex<H>::T*)color, lightmap, fc, sh, cube_size, mask, num_samples, num_light_samples, out, occ, counters)
 	if (half_store) { if (separate) FX_LAUNCH(true, true); else FX_LAUNCH(true, false); }
 	else { if (separate) FX_LAUNCH(false, true); else FX_LAUNCH(false, false); }
 #undef FX_LAUNCH
@@ -535,12 +559,12 @@ hipError_t launch_raymarch_view(const Geom& g, int half_store, const void* color
 
 hipError_t launch_raycast_direct(const Geom& g, int half_store, const void* color, const uint32_t* lightmap,
 	const FrameConsts& fc, const float* sh, int W, int H, uint32_t num_samples, uint32_t num_light_samples, int separate,
-	uint8_t* target, float* out_float, const float* occ, hipStream_t s)
+	uint8_t* target, float* out_float, const float* occ, hipStream_t s, unsigned long long* counters)
 {
 	const dim3 grid((W + 7) / 8, (H + 7) / 8, 1), block(8, 8, 1);
 #define FX_LAUNCH(HF, S) hipLaunchKernelGGL((k_raycast_direct<HF, S>), grid, block, 0, s, g, \
 	(const typename ColTex<HF>::T*)color, lightmap, fc, sh, W, H, num_samples, num_light_samples, \
-	reinterpret_cast<uint32_t*>(target), reinterpret_cast<float4*>(out_float), occ)
+	reinterpret_cast<uint32_t*>(target), reinterpret_cast<float4*>(out_float), occ, counters)
 	if (half_store) { if (separate) FX_LAUNCH(true, true); else FX_LAUNCH(true, false); }
 	else { if (separate) FX_LAUNCH(false, true); else FX_LAUNCH(false, false); }
 #undef FX_LAUNCH

@@ -124,6 +124,9 @@ typedef struct fx_timing {
 	 * jacobi_sweeps above counts the levels ENQUEUED (always N: the sparse solver needs no read-back to stop early). */
 	uint64_t freeze_solves, freeze_sweeps;
 	uint64_t exchange_calls;    /* slab ranks: halo exchanges issued (one RCCL group call each) over the timed steps */
+	/* FX_OPT_COUNT_SAMPLES: trilinear colour fetches of the view rays, density fetches of the light / AO rays (the light pass's one
+	 * fetch per voxel included), light-map fetches -- summed over the renders since the last reset */
+	uint64_t view_samples, light_samples, lightmap_fetches;
 } fx_timing;
 
 int fx_abi_version(void);
@@ -247,11 +250,13 @@ int fx_comm_gather_color(fx_ctx* ctx, void* stream, fx_ctx* full, int root, cons
  *                        FX_E_HALO on EVERY rank before a field is touched.  The measurement holds for time steps up to the one
  *                        it was taken with; a larger one, the first step, or a velocity upload fall back to halo_advect planes.
  *                        0 = always halo_advect planes.
- * On an RCCL chain fx_set_option is COLLECTIVE: every rank calls it with the same arguments between two steps; the values are
+ *   FX_OPT_COUNT_SAMPLES 1 = fx_render counts the samples its marches take (fx_timing.view_samples / light_samples / lightmap_fetches): every
+ *                        thread adds its counts with atomics, so a counted render is for statistics, not for timing.  Local to the context.
+ * On an RCCL chain fx_set_option (of the three schedule options) is COLLECTIVE: every rank calls it with the same arguments between two steps; the values are
  * compared across the chain and a disagreement returns FX_E_INVALID everywhere with nothing changed.  While FX_OPT_ADAPTIVE_HALO
  * is on and a step has run, fx_upload(FX_FIELD_VELOCITY) into an RCCL rank returns FX_E_STATE (its neighbours have sized the next
  * exchange from the old field); switch the option off first. */
-enum fx_option { FX_OPT_OVERLAP = 1, FX_OPT_JACOBI_ROUND = 2, FX_OPT_ADAPTIVE_HALO = 3 };
+enum fx_option { FX_OPT_OVERLAP = 1, FX_OPT_JACOBI_ROUND = 2, FX_OPT_ADAPTIVE_HALO = 3, FX_OPT_COUNT_SAMPLES = 4 };
 int fx_set_option(fx_ctx* ctx, uint32_t option, uint32_t value);
 
 #ifdef __cplusplus
