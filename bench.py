@@ -610,7 +610,7 @@ def main():
                       "light_voxels_per_s": float(G) ** 3 / (tr_.light_ms / nr * 1e-3) if tr_.light_ms > 0 else None,
                       # from ONE counted render of the same state (FX_OPT_COUNT_SAMPLES): trilinear colour fetches of the view rays, density
                       # fetches of the light pass (one per voxel + the light rays of the voxels with density >= 0.01), light-map fetches
-                      "view_samples": int(tc_.view_samples), "light_samples": int(tc_.light_samples), "lightmap_fetches": int(tc_.lightmap_fetches),
+                      "view_samples_taken": int(tc_.view_samples), "light_samples_taken": int(tc_.light_samples), "lightmap_fetches_taken": int(tc_.lightmap_fetches),
                       "view_samples_per_s": tc_.view_samples / view_s if view_s > 0 else None,
                       "light_samples_per_s": tc_.light_samples / light_s if light_s > 0 else None,
                       "samples_per_s": (tc_.view_samples + tc_.light_samples + tc_.lightmap_fetches) / (view_s + light_s) if view_s + light_s > 0 else None,

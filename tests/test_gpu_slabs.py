@@ -545,6 +545,10 @@ def test_bench_single_gpu_line_is_complete():
     assert 0 < d["step_compulsory"]["frac_of_peak"] <= 1
     rn = d["render"]
     assert rn["light_pass_ms"] > 0 and rn["view_pass_ms"] > 0 and rn["cube_resolve_ms"] > 0 and rn["direct_march_ms"] > 0 and rn["rays_per_s"] > 0
+    # the render leg is pinned to frame 132 whatever --steps / --warmup were, and counts the samples it takes
+    assert rn["frame"] == 132 and rn["untimed_steps_to_frame"] == 107
+    assert rn["view_samples_taken"] > rn["rays"] and rn["light_samples_taken"] >= 128 ** 3 and rn["samples_per_s"] > 0
+    assert 0 < rn["bound"]["light_pass"]["frac_of_hbm_peak"] < 1 and 0 < rn["bound"]["view_pass"]["frac_of_hbm_peak"] < 1
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
 
 
