@@ -280,32 +280,20 @@ hipError_t launch_jacobi_blockg(const Geom& g, const float* p_in, const float* b
 	if (z_end <= z_begin) return hipSuccess;
 	if (!jacobi_blockg_supported(g)) return hipErrorNotSupported;
 	static const int remap = env_b("FLUIDX_BLOCK_REMAP", 1);
-	static const int shape = env_b("FLUIDX_BLOCKG_SHAPE", 0);      // rows * 10 + planes per wave (measurement knob); 0 = per CPL
 	const int cpl = blockg_cpl(g);
-#define FX_BLKG(C_, BY_, BZ_) do { \
-		const int nby = (g.Y + (BY_) - 1) / (BY_), nbz = (z_end - z_begin + (BZ_) - 1) / (BZ_); \
-		hipLaunchKernelGGL((k_jacobi_blockg<C_, BY_, BZ_>), dim3((nby * nbz + 3) / 4), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, nby, nbz, remap); } while (0)
-#define FX_BLKG_SHAPES(C_, DEF_) do { \
-		switch (shape ? shape : (DEF_)) { \
-		case 44: FX_BLKG(C_, 4, 4); break; \
-		case 42: FX_BLKG(C_, 4, 2); break; \
-		case 24: FX_BLKG(C_, 2, 4); break; \
-		case 33: FX_BLKG(C_, 3, 3); break; \
-		case 32: FX_BLKG(C_, 3, 2); break; \
-		case 23: FX_BLKG(C_, 2, 3); break; \
-		default: FX_BLKG(C_, 2, 2); break; \
-		} } while (0)
-	// measured (Jacobi phase of a step, ms; single sweeps / 4 x 4 / 4 x 2 / 2 x 4 / 2 x 2 / 3 x 3 / 3 x 2 / 2 x 3 rows x planes per wave):
-	// 150^3 0.767 / 0.319 / 0.277 / 0.285 / 0.250 / 0.299 / 0.237 / 0.236, 192^3 0.581 / 0.533 / 0.485 / 0.512 / 0.440 / 0.478 / 0.388 / 0.387,
-	// 160^3 0.386 / 0.339 / 0.365 / 0.376 / 0.304 / 0.327 / 0.303 / 0.303, 100^3 0.167 / 0.136 / 0.139 / 0.142 / 0.131 / 0.146 / 0.125 / 0.128:
-	// six rows per wave everywhere -- unlike X = 128, whose float2 rows leave the 4 x 4 block at 224 registers
+	// 3 rows x 2 planes per wave.  Measured in round 2 (Jacobi phase of a step, ms; single sweeps / 4 x 4 / 4 x 2 / 2 x 4 / 2 x 2 / 3 x 3 /
+	// 3 x 2 / 2 x 3 rows x planes per wave): 150^3 0.767 / 0.319 / 0.277 / 0.285 / 0.250 / 0.299 / 0.237 / 0.236, 192^3 0.581 / 0.533 / 0.485 /
+	// 0.512 / 0.440 / 0.478 / 0.388 / 0.387, 160^3 0.386 / 0.339 / 0.365 / 0.376 / 0.304 / 0.327 / 0.303 / 0.303, 100^3 0.167 / 0.136 / 0.139 /
+	// 0.142 / 0.131 / 0.146 / 0.125 / 0.128: six rows per wave everywhere -- unlike X = 128, whose float2 rows leave the 4 x 4 block at 224
+	// registers.  The other shapes are no longer compiled.
+	const int nby = (g.Y + 2) / 3, nbz = (z_end - z_begin + 1) / 2;
+#define FX_BLKG(C_) hipLaunchKernelGGL((k_jacobi_blockg<C_, 3, 2>), dim3((nby * nbz + 3) / 4), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, nby, nbz, remap)
 	switch (cpl) {
-	case 1: FX_BLKG_SHAPES(1, 32); break;
-	case 2: FX_BLKG_SHAPES(2, 32); break;
-	case 3: FX_BLKG_SHAPES(3, 32); break;
-	default: FX_BLKG_SHAPES(4, 32); break;
+	case 1: FX_BLKG(1); break;
+	case 2: FX_BLKG(2); break;
+	case 3: FX_BLKG(3); break;
+	default: FX_BLKG(4); break;
 	}
-#undef FX_BLKG_SHAPES
 #undef FX_BLKG
 	return hipGetLastError();
 }
@@ -315,18 +303,10 @@ hipError_t launch_jacobi_block2(const Geom& g, const float* p_in, const float* b
 	if (z_end <= z_begin) return hipSuccess;
 	if (!jacobi_block2_supported(g)) return hipErrorNotSupported;
 	static const int remap = env_b("FLUIDX_BLOCK_REMAP", 1);
-	static const int shape = env_b("FLUIDX_BLOCK_SHAPE", 44);      // rows * 10 + planes per wave (measurement knob)
-#define FX_BLK(BY_, BZ_) do { \
-		const int nby = g.Y / (BY_), nbz = (z_end - z_begin + (BZ_) - 1) / (BZ_); \
-		hipLaunchKernelGGL((k_jacobi_block2<BY_, BZ_>), dim3((nby * nbz + 3) / 4), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, nby, nbz, remap); } while (0)
-	switch (shape) {
-	case 42: FX_BLK(4, 2); break;
-	case 24: FX_BLK(2, 4); break;
-	case 22: FX_BLK(2, 2); break;
-	case 43: FX_BLK(4, 3); break;
-	default: FX_BLK(4, 4); break;
-	}
-#undef FX_BLK
+	// 4 rows x 4 planes per wave (224 VGPRs, one wave per SIMD, 1024 waves at 128^3); 4 x 2 7.1 us, 2 x 4 7.3, 2 x 2 8.1, 4 x 3 8.3 per launch
+	// against 6.6 -- the other shapes are no longer compiled
+	const int nby = g.Y / 4, nbz = (z_end - z_begin + 3) / 4;
+	hipLaunchKernelGGL((k_jacobi_block2<4, 4>), dim3((nby * nbz + 3) / 4), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, nby, nbz, remap);
 	return hipGetLastError();
 }
 

@@ -682,253 +682,8 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip3c(const Geom g, const f
 #undef FX_STRIP3C_RUN
 #undef FX_STRIP3C_STEP
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// X = 256, cooperative pairs in y AND two streams per workgroup that MEET in z.  k_jacobi_strip3c's chunk of 16 planes costs 22 z
-// steps and 22 planes of p and b: three planes of dependency cone at either end.  Here a workgroup owns 8 rows x 32 planes: waves
-// 0 / 1 (a y pair as above) stream planes zb .. zm-1 upwards, waves 2 / 3 stream planes ze-1 .. zm DOWNWARDS, and where they meet
-// nobody reads the other side's planes from memory or recomputes its levels -- the two streams hold them already:
-//   step Q   (Q = own coordinate of the first plane across the meeting plane) the input plane Q is the z partner's last input
-//            plane, still parked in its LDS slice; a full step without loads
-//   step Q+1 level-1 plane Q is what the partner's step Q produced (handed over through the LDS); sweeps 2 and 3 only
-//   step Q+2 level-2 plane Q is what the partner's step Q+1 produced; sweep 3 only
-// i.e. 19 loaded planes and 19 full steps + 28 of 45 row updates for 16 output planes instead of 22 / 22.  Each stream runs in its
-// OWN z coordinate (the downward one mirrored, z' = Zg - 1 - z), in which both are the same upward pipeline and the clamped
-// domain face is plane 0; the mirror shows in two places only: the plane addresses and the order in which the stencil's front and
-// back neighbours enter the sum (F before B, whichever way the stream runs -- two more expansions of the step).
-// MEASURED (MI355X, 256^3, profiles/r03c_strip3z.txt): bit-identical; 79.0 instead of 88.9 k KiB-units of FETCH_SIZE (-11 %), 7.59 M
-// instead of 8.07 M VALU instructions, I-cache misses negligible in both (the kernel is 140 KiB, its four hot loops 12 KiB each) --
-// and 45.9 us per launch against k_jacobi_strip3c's 43.0: the 19 main steps take 2.17 us each under full load (1.95 there; with only
-// the upward or only the downward streams running, 1.74 = the other kernel's figure at half load) and the three meeting steps with
-// their barriers 4.7 us (arrival skew of the two streams included).  It is not that a CU's waves now read two planes at once:
-// k_jacobi_strip3c with the two pairs of a workgroup mapped to DIFFERENT chunks runs at its usual 43 us.  Fewer bytes do not pay where the z step is a load round trip
-// plus a sweep.  Kept as FLUIDX_STRIP3_ZMEET=1, off by default.  Three things the compiler did on the way, each worth 5-10 % of a
-// launch: (i) a jump INTO the unrolled loop (to start at the phase that ends on phase 2) cost ~110 extra register moves per step
-// (irreducible control flow) -> peeled first steps; (ii) row loads written as HIP float4 (a struct) came out, in two of the four
-// expansions, as dwordx3 + an overlapping dwordx2 with `s_waitcnt vmcnt(0)` between them -> native 4-vector loads; (iii) the
-// `if (plane exists)` around the prefetch made it copy parts of the arriving rows at the end of that block, i.e. wait for them at
-// once -> unconditional prefetch with a clamped plane index.
-// The z partner of wave w is wave w ^ 2: same rows, same role in its y pair, so the handed-over planes need no re-indexing.
-// ---------------------------------------------------------------------------------------------------------------------------
-// A row load the optimiser does not take apart: written as loads of HIP's float4 (a struct: four scalar loads that the vectoriser
-// glues together again), two of the four expansions of the step below came out with a row fetched as dwordx3 + an OVERLAPPING
-// dwordx2 and an `s_waitcnt vmcnt(0)` between them in the middle of the prefetch -- the step then pays two memory round trips
-// (0.667 instead of 0.593 ms of Jacobi per 256^3 step).  One load of a native 4-vector stays one global_load_dwordx4.
-// (Raw buffer loads were tried: the allocator lands them in VGPRs and copies to AGPRs at once, i.e. waits for them at once.)
-typedef float fx_v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ld_row4(const char* base, uint32_t off)
-{
-	const fx_v4f v = *reinterpret_cast<const fx_v4f*>(base + off);
-	return make_float4(v.x, v.y, v.z, v.w);
-}
-
-#define FX_PLZ(ZDN, x) g.lz((ZDN) ? zmir - (x) : (x))
-#define FX_FB(ZDN, c, u, d, older, newer, bb) ((ZDN) ? relax4(c, u, d, newer, older, bb, false, false) : relax4(c, u, d, older, newer, bb, false, false))
-
-#define FX_STRIP3Z_STEP(PH, UP, ZDN, LD) do { \
-	constexpr int NEW = (PH) % 3, CTR = ((PH) + 2) % 3, OLD = ((PH) + 1) % 3; \
-	/* ---- sweep 1: level-1 plane q-1 (a stream never reaches the far face of the domain: no clamp on that side) ------ */ \
-	if (q == 0) {                                   /* input plane -1 := plane 0, once (clamped face of the domain) */ \
-		_Pragma("unroll") for (int i = 0; i < C_P0_ROWS; ++i) FX_LDS(s_ctr, i) = NP[i]; \
-	} \
-	{ \
-		float4 C_[C_P0_ROWS], F_[C_B_ROWS]; \
-		_Pragma("unroll") for (int i = 0; i < C_P0_ROWS; ++i) C_[i] = FX_LDS(s_ctr, i); \
-		_Pragma("unroll") for (int j = 0; j < C_B_ROWS; ++j) F_[j] = FX_LDS(s_old, j + 1); \
-		_Pragma("unroll") for (int j = 0; j < C_B_ROWS; ++j) \
-			P1[NEW][j] = FX_FB(ZDN, C_[j + 1], C_[j], C_[j + 2], F_[j], NP[j + 1], NB[j]); \
-		if (q - 1 == 0) { \
-			_Pragma("unroll") for (int j = 0; j < C_B_ROWS; ++j) P1[CTR][j] = P1[NEW][j]; \
-		} \
-	} \
-	float4 B2_[RC + 1], B3_[RC]; \
-	_Pragma("unroll") for (int k = 0; k < RC + 1; ++k) B2_[k] = FX_LDS(s_b2, (UP) ? k + 1 : k);        /* b[q-2], rows of level 2 */ \
-	_Pragma("unroll") for (int m = 0; m < RC; ++m) B3_[m] = FX_LDS(s_b3, (UP) ? m + 2 : m);            /* b[q-3], output rows */ \
-	_Pragma("unroll") for (int i = 0; i < C_P0_ROWS; ++i) FX_LDS(s_old, i) = NP[i]; \
-	_Pragma("unroll") for (int i = 0; i < C_B_ROWS; ++i) FX_LDS(s_bfree, i) = NB[i]; \
-	{ const int t_ = s_old; s_old = s_ctr; s_ctr = t_; } \
-	{ const int t_ = s_bfree; s_bfree = s_b3; s_b3 = s_b2; s_b2 = t_; } \
-	if (LD) {                                       /* unconditional in the main loop (the last step fetches its own plane again: a branch \
-	                                                   here makes the compiler copy parts of the arriving rows at once, i.e. wait for them at once) */ \
-		const char* pb_ = reinterpret_cast<const char*>(p_in + (size_t)FX_PLZ(ZDN, min(q + 1, q_load_last)) * plane); \
-		_Pragma("unroll") for (int i = 0; i < C_P0_ROWS; ++i) NP[i] = ld_row4(pb_, opaque32(roff[i])); \
-		const char* bb_ = reinterpret_cast<const char*>(b + (size_t)FX_PLZ(ZDN, min(q, b_load_last)) * plane); \
-		_Pragma("unroll") for (int i = 0; i < C_B_ROWS; ++i) NB[i] = ld_row4(bb_, opaque32(roff[i + 1])); \
-	} \
-	/* hand-over 1 between the strips of the y pair, as in k_jacobi_strip3c */ \
-	lds_wait_ge(xf_partner, q - 1); \
-	const float4 H1_ = xbuf[((((q - 1) & 1) * 4 + (wave ^ 1)) * 2 + 0) * 64 + lane]; \
-	xbuf[(((q & 1) * 4 + wave) * 2 + 0) * 64 + lane] = (UP) ? P1[NEW][C_B_ROWS - 1] : P1[NEW][0]; \
-	if (lane == 0) lds_post(xf_mine, q); \
-	/* ---- sweep 2: level-2 plane q-2 ------------------------------------------------------------------------------- */ \
-	FX_STRIP3Z_SWEEP2(NEW, CTR, OLD, UP, ZDN); \
-	/* hand-over 2 */ \
-	FX_STRIP3Z_HAND2(NEW, UP); \
-	/* ---- sweep 3: output plane q-3 ------------------------------------------------------------------------------- */ \
-	FX_STRIP3Z_SWEEP3(NEW, CTR, OLD, UP, ZDN); \
-} while (0)
-
-#define FX_STRIP3Z_SWEEP2(NEW, CTR, OLD, UP, ZDN) \
-	_Pragma("unroll") for (int k = 0; k < RC + 1; ++k) { \
-		const int jc_ = (UP) ? k + 1 : k; \
-		const float4 c_ = P1[CTR][jc_]; \
-		float4 u_ = jc_ >= 1 ? P1[CTR][jc_ >= 1 ? jc_ - 1 : 0] : H1_; \
-		float4 d_ = jc_ + 1 < C_B_ROWS ? P1[CTR][jc_ + 1 < C_B_ROWS ? jc_ + 1 : 0] : H1_; \
-		if ((UP) && k == 1 && y0 == 0) u_ = c_; \
-		if (!(UP) && k == RC - 1 && y0 + RC >= g.Y) d_ = c_; \
-		P2[NEW][k] = FX_FB(ZDN, c_, u_, d_, P1[OLD][jc_], P1[NEW][jc_], B2_[k]); \
-	} \
-	if (q - 2 == 0) { \
-		_Pragma("unroll") for (int k = 0; k < RC + 1; ++k) P2[CTR][k] = P2[NEW][k]; \
-	}
-
-#define FX_STRIP3Z_HAND2(NEW, UP) \
-	lds_wait_ge(xf_partner + 16, q - 1); \
-	const float4 H2_ = xbuf[((((q - 1) & 1) * 4 + (wave ^ 1)) * 2 + 1) * 64 + lane]; \
-	xbuf[(((q & 1) * 4 + wave) * 2 + 1) * 64 + lane] = (UP) ? P2[NEW][RC] : P2[NEW][0]; \
-	if (lane == 0) lds_post(xf_mine + 16, q);
-
-#define FX_STRIP3Z_SWEEP3(NEW, CTR, OLD, UP, ZDN) \
-	if (q - 3 >= zb_s && q - 3 < ze_s) { \
-		char* ob_ = reinterpret_cast<char*>(p_out + (size_t)FX_PLZ(ZDN, q - 3) * plane); \
-		_Pragma("unroll") for (int m = 0; m < RC; ++m) { \
-			const int kc_ = (UP) ? m + 1 : m; \
-			const float4 c_ = P2[CTR][kc_]; \
-			float4 u_ = kc_ >= 1 ? P2[CTR][kc_ >= 1 ? kc_ - 1 : 0] : H2_; \
-			float4 d_ = kc_ + 1 < RC + 1 ? P2[CTR][kc_ + 1 < RC + 1 ? kc_ + 1 : 0] : H2_; \
-			if ((UP) && m == 0 && y0 == 0) u_ = c_; \
-			if (!(UP) && m == RC - 1 && y0 + RC >= g.Y) d_ = c_; \
-			const float4 x_ = FX_FB(ZDN, c_, u_, d_, P2[OLD][kc_], P2[NEW][kc_], B3_[m]); \
-			*reinterpret_cast<float4*>(ob_ + opaque32(roff[(UP) ? m + 3 : m + 1])) = x_; \
-		} \
-	}
-
-// The three steps at the meeting plane, entered with the windows renamed to phase 0 (q == Qm).
-#define FX_STRIP3Z_MEET(UP, ZDN) do { \
-	/* step Q: the plane across the meeting plane is the z partner's centre slot */ \
-	if (lane == 0) xmeta[wave] = s_ctr; \
-	__syncthreads(); \
-	const int zp_ctr = __builtin_amdgcn_readfirstlane(xmeta[wave ^ 2]), my_ctr = s_ctr; \
-	_Pragma("unroll") for (int i = 0; i < C_P0_ROWS; ++i) NP[i] = zlds[zp_ctr + i * 64]; \
-	FX_STRIP3Z_STEP(0, UP, ZDN, false); \
-	/* my level-1 plane Q-1 for the partner's step Q+1, into the slot that held plane Q-2 (the step's own copy of plane Q went there: dead) */ \
-	_Pragma("unroll") for (int j = 0; j < C_B_ROWS; ++j) FX_LDS(C_P0_ROWS * 64 - my_ctr, j) = P1[0][j]; \
-	++q; \
-	/* step Q+1 (phase 1): level-1 plane Q from the partner; sweeps 2 and 3 */ \
-	__syncthreads(); \
-	_Pragma("unroll") for (int j = 0; j < C_B_ROWS; ++j) P1[1][j] = zlds[C_P0_ROWS * 64 - zp_ctr + j * 64]; \
-	{ \
-		float4 B2_[RC + 1], B3_[RC]; \
-		_Pragma("unroll") for (int k = 0; k < RC + 1; ++k) B2_[k] = FX_LDS(s_b2, (UP) ? k + 1 : k); \
-		_Pragma("unroll") for (int m = 0; m < RC; ++m) B3_[m] = FX_LDS(s_b3, (UP) ? m + 2 : m); \
-		{ const int t_ = s_bfree; s_bfree = s_b3; s_b3 = s_b2; s_b2 = t_; } \
-		lds_wait_ge(xf_partner, q - 1); \
-		const float4 H1_ = xbuf[((((q - 1) & 1) * 4 + (wave ^ 1)) * 2 + 0) * 64 + lane]; \
-		FX_STRIP3Z_SWEEP2(1, 0, 2, UP, ZDN); \
-		/* my level-2 plane Q-1 for the partner's step Q+2, into my old centre slot (the partner read it before the barrier above) */ \
-		_Pragma("unroll") for (int k = 0; k < RC + 1; ++k) FX_LDS(my_ctr, k) = P2[1][k]; \
-		FX_STRIP3Z_HAND2(1, UP); \
-		FX_STRIP3Z_SWEEP3(1, 0, 2, UP, ZDN); \
-	} \
-	++q; \
-	/* step Q+2 (phase 2): level-2 plane Q from the partner; sweep 3 */ \
-	__syncthreads(); \
-	_Pragma("unroll") for (int k = 0; k < RC + 1; ++k) P2[2][k] = zlds[zp_ctr + k * 64]; \
-	{ \
-		float4 B3_[RC]; \
-		_Pragma("unroll") for (int m = 0; m < RC; ++m) B3_[m] = FX_LDS(s_b3, (UP) ? m + 2 : m); \
-		FX_STRIP3Z_HAND2(2, UP); \
-		FX_STRIP3Z_SWEEP3(2, 1, 0, UP, ZDN); \
-	} \
-} while (0)
-
-// the main loop runs whole triples of steps and leaves behind phase 2, so that the meeting steps are phases 0, 1, 2 as written; a
-// step count that is no multiple of three STARTS at phase 1 or 2 (the windows start out all zero: any phase can be the first) --
-// peeled copies, because a jump into the loop body costs a hundred extra register moves per step (irreducible control flow)
-#define FX_STRIP3Z_RUN(UP, ZDN) do { \
-	if (ph0 == 1) { FX_STRIP3Z_STEP(1, UP, ZDN, true); ++q; FX_STRIP3Z_STEP(2, UP, ZDN, true); ++q; } \
-	else if (ph0 == 2) { FX_STRIP3Z_STEP(2, UP, ZDN, true); ++q; } \
-	while (q <= q_main_last) { \
-		FX_STRIP3Z_STEP(0, UP, ZDN, true); ++q; \
-		FX_STRIP3Z_STEP(1, UP, ZDN, true); ++q; \
-		FX_STRIP3Z_STEP(2, UP, ZDN, true); ++q; \
-	} \
-	FX_STRIP3Z_MEET(UP, ZDN); \
-} while (0)
-
-// zc2 = planes per workgroup (both streams); every workgroup's range must hold at least two planes (the launcher sees to it)
-__global__ __launch_bounds__(256, 1) void k_jacobi_strip3z(const Geom g, const float* __restrict__ p_in,
-	const float* __restrict__ b, float* __restrict__ p_out, int z_begin, int z_end, int zc2, int ngroups, int nchunks, int remap)
-{
-	__shared__ float4 lds_all[4 * C_ROWS_PER_WAVE * 64];
-	__shared__ float4 xbuf[2 * 4 * 2 * 64];
-	__shared__ int xflag[8];
-	__shared__ int xmeta[4];                                           // a wave's centre input slot when it arrives at the meeting plane
-	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	float4* lds = lds_all + wave * (C_ROWS_PER_WAVE * 64) + lane;
-	const float4* zlds = lds_all + (wave ^ 2) * (C_ROWS_PER_WAVE * 64) + lane;    // the z partner's slice
-	const int tile = xcd_index3(ngroups * nchunks, remap);
-	const int grp = tile % ngroups, chunk = tile / ngroups;
-	const int y0 = (grp * 2 + (wave & 1)) * RC;                       // (Y % 8 == 0)
-	const bool up = (wave & 1) == 0, zdn = (wave & 2) != 0;
-	const int yb = up ? y0 - 3 : y0 - 1;
-	const int zmir = g.Zg - 1;
-	const int zb = z_begin + chunk * zc2, ze = min(zb + zc2, z_end), zm = zb + (ze - zb + 1) / 2;
-	// the stream's own coordinate: z for the upward stream, Zg - 1 - z for the downward one
-	const int zb_s = zdn ? zmir - (ze - 1) : zb, ze_s = zdn ? zmir - zm + 1 : zm;
-	const int zlo_s = zdn ? zmir - g.zhi : g.zlo, zhi_s = zdn ? zmir - g.zlo : g.zhi;
-	const int Qm = ze_s;
-	const int qs = max(zb_s - 3, zlo_s), q_main_last = Qm - 1, q_load_last = min(Qm - 1, zhi_s), b_load_last = q_load_last;
-	const size_t plane = g.plane();
-
-	uint32_t roff[C_P0_ROWS];
-#pragma unroll
-	for (int i = 0; i < C_P0_ROWS; ++i) roff[i] = ((uint32_t)min(max(yb + i, 0), g.Y - 1) * (uint32_t)g.X + 4u * (uint32_t)lane) * 4u;
-
-	int s_ctr = 0, s_old = C_P0_ROWS * 64;
-	int s_b2 = 2 * C_P0_ROWS * 64, s_b3 = s_b2 + C_B_ROWS * 64, s_bfree = s_b3 + C_B_ROWS * 64;
-
-	float4 P1[3][C_B_ROWS], P2[3][RC + 1], NP[C_P0_ROWS], NB[C_B_ROWS];
-	const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-	for (int k = 0; k < 3; ++k) {
-#pragma unroll
-		for (int i = 0; i < C_B_ROWS; ++i) P1[k][i] = zero;
-#pragma unroll
-		for (int i = 0; i < RC + 1; ++i) P2[k][i] = zero;
-	}
-#pragma unroll
-	for (int i = 0; i < C_ROWS_PER_WAVE; ++i) lds[i * 64] = zero;
-	for (int i = (int)threadIdx.x; i < 2 * 4 * 2 * 64; i += 256) xbuf[i] = zero;
-	{
-		const int zp0 = min(qs, q_load_last), zb0 = min(max(qs - 1, zlo_s), zhi_s);
-		const char* pb = reinterpret_cast<const char*>(p_in + (size_t)g.lz(zdn ? zmir - zp0 : zp0) * plane);
-#pragma unroll
-		for (int i = 0; i < C_P0_ROWS; ++i) NP[i] = *reinterpret_cast<const float4*>(pb + roff[i]);
-		const char* bbase = reinterpret_cast<const char*>(b + (size_t)g.lz(zdn ? zmir - zb0 : zb0) * plane);
-#pragma unroll
-		for (int i = 0; i < C_B_ROWS; ++i) NB[i] = *reinterpret_cast<const float4*>(bbase + roff[i + 1]);
-	}
-	if (lane == 0) { xflag[wave] = qs - 1; xflag[4 + wave] = qs - 1; }   // the two streams start at different own coordinates; a y pair shares qs
-	__syncthreads();
-	const uint32_t xf0 = (uint32_t)(size_t)(__attribute__((address_space(3))) int*)xflag;
-	const uint32_t xf_mine = xf0 + 4u * (uint32_t)wave, xf_partner = xf0 + 4u * (uint32_t)(wave ^ 1);
-	int q = qs;
-	const int ph0 = (3 - (Qm - qs) % 3) % 3;                          // Qm - qs main steps
-	if (!zdn) {
-		if (up) FX_STRIP3Z_RUN(true, false); else FX_STRIP3Z_RUN(false, false);
-	} else {
-		if (up) FX_STRIP3Z_RUN(true, true); else FX_STRIP3Z_RUN(false, true);
-	}
-}
-#undef FX_STRIP3Z_RUN
-#undef FX_STRIP3Z_MEET
-#undef FX_STRIP3Z_SWEEP3
-#undef FX_STRIP3Z_HAND2
-#undef FX_STRIP3Z_SWEEP2
-#undef FX_STRIP3Z_STEP
-#undef FX_FB
-#undef FX_PLZ
-#undef FX_LDS
+// (k_jacobi_strip3z -- two z streams per workgroup that meet in the middle: 11 % fewer bytes, 6 % fewer instructions, and 45.9 us per
+// launch against k_jacobi_strip3c's 43.0 -- was measured in round 2 (profiles/r03c_strip3z.txt) and removed in round 3.)
 
 }  // namespace
 
@@ -962,23 +717,6 @@ hipError_t launch_jacobi_strip3(const Geom& g, const float* p_in, const float* b
 	if (halves && wpg == 2) hipLaunchKernelGGL(k_jacobi_strip3h<2>, dim3(ngroups * nchunks), dim3(128), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
 	else if (halves) hipLaunchKernelGGL(k_jacobi_strip3h<4>, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
 	else {
-		// FLUIDX_STRIP3_ZMEET=1: cooperative pairs whose two z streams meet (k_jacobi_strip3z), 8 rows x zc2 planes per workgroup, one
-		// workgroup per CU; a range that would leave a workgroup fewer than two planes takes k_jacobi_strip3c.  OFF by default: 11 % less
-		// traffic and 6 % fewer instructions, but 45.9 against 43.0 us per launch (see the kernel's comment).  (Read per launch: the test sets it.)
-		const char* ze_ = getenv("FLUIDX_STRIP3_ZMEET");
-		const int zmeet = ze_ && *ze_ ? atoi(ze_) : 0;
-		if (use_coop && zmeet && nzp >= 4 && g.cells_local() < ((size_t)1 << 30)) {
-			const int ng = g.Y / (2 * RC);
-			int nc = (256 + ng - 1) / ng;
-			int zc2 = forced_chunk > 0 ? 2 * forced_chunk : (nzp + nc - 1) / nc;
-			if (zc2 < 16) zc2 = 16;
-			if (zc2 > nzp) zc2 = nzp;
-			nc = (nzp + zc2 - 1) / zc2;
-			if (nzp - (nc - 1) * zc2 >= 2) {
-				hipLaunchKernelGGL(k_jacobi_strip3z, dim3(ng * nc), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zc2, ng, nc, remap);
-				return hipGetLastError();
-			}
-		}
 		// cooperative pairs (k_jacobi_strip3c) where every workgroup holds whole pairs; FLUIDX_STRIP3_COOP=0: every strip on its own
 		if (use_coop)
 			hipLaunchKernelGGL(k_jacobi_strip3c, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);

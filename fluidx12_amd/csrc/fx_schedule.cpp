@@ -1,0 +1,514 @@
+// fx_schedule.cpp -- Fluid::Simulate (/root/reference/FluidX12/Content/Fluid.cpp:348-410) as a schedule of kernel launches and halo
+// exchanges over a group of z-slab contexts: one code path serves the single-GPU case, the RCCL slabs and the in-process loop-back
+// slabs.  The C ABI entry points that drive it are in fx_api.cpp; contexts, fields and options in fx_context.cpp.
+#include "fx_host.h"
+
+using namespace fx;
+
+namespace fxh {
+
+// ---- the simulation step, phase by phase, over a group of slab contexts ----------------------------
+// (Fluid::Simulate, Fluid.cpp:348-410; the phase structure is what lets one code path serve the
+// single-GPU case, the RCCL slabs and the in-process loop-back slabs)
+//
+// Multi-rank schedule of one step (k = sweeps per pressure exchange, Ha = advect halo):
+//   1  [comm] exchange Ha planes of velocity + colour      || [compute] advect the planes >= Ha away from a slab face
+//      then advect the 2 x Ha face planes
+//   2  exchange 1 plane of the advected uz ; divergence on the owned planes
+//   3  exchange k-1 planes of b and k planes of p (one message group)
+//   4  per round of k sweeps: the k planes next to each face are brought to the round's last level first
+//      (thin single-sweep launches over both face zones, from the exchanged halo), [comm] they travel to the
+//      neighbour || [compute] the interior follows with the fused-sweep kernels (see jacobi_overlapped)
+//   5  projection (reads the 1st halo plane of the last exchange)
+// Every cell is computed with the arithmetic of the single-domain run, so results are bit-identical.
+int for_members(fx_ctx* ctx, std::vector<fx_ctx*>& out)
+{
+	out.clear();
+	if (ctx->group && ctx->group->transport->is_local() && !ctx->group->broken) out = ctx->group->members;
+	else out.push_back(ctx);                           // (a broken loop-back group: only this context, and only for teardown)
+	return FX_OK;
+}
+
+
+// 0 = no side stream, 1 = advection halo overlapped, 2 = pressure rounds overlapped as well, 3 = and the colour half of the
+// next step's advection halo travels behind this step's pressure phase (fx_set_option)
+int overlap_level(const fx_ctx* lead)
+{
+	if (!multi_rank(lead) || !lead->group->comm_stream) return 0;
+	return lead->opt_overlap;
+}
+
+struct ExchSpec { int set, k, pidx; };
+
+static int do_exchange(fx_ctx* ctx, const std::vector<fx_ctx*>& M, const ExchSpec* specs, int nspec, hipStream_t s, int channel = 0)
+{
+	if (!multi_rank(ctx)) return FX_OK;
+	DeviceGuard dg(ctx->device);
+	ScopedMark mk(ctx, s, MK_EXCH);
+	std::vector<std::vector<Seg>> segs(M.size());
+	size_t total = 0;
+	for (size_t i = 0; i < M.size(); ++i) {
+		for (int j = 0; j < nspec; ++j) {
+			if (specs[j].k <= 0) continue;
+			ExchItem it[4];
+			const int n = exchange_items(M[i], specs[j].set, specs[j].k, specs[j].pidx, it);
+			halo_segments(M[i], it, n, segs[i]);
+		}
+		total += segs[i].size();
+		if (M[i]->timing_on) for (const Seg& sg : segs[i]) M[i]->acc.exchange_bytes += sg.bytes;     // what this rank sends
+	}
+	if (!total) return FX_OK;
+	for (fx_ctx* m : M) if (m->timing_on) m->acc.exchange_calls += 1;  // one group call (ncclGroupStart .. End) per exchange
+	return ctx->group->transport->exchange(ctx->group, segs, s, channel);
+}
+
+// comm stream picks up after everything queued on the compute stream so far
+static int comm_fork(fx_ctx* ctx, hipStream_t s)
+{
+	fx_comm_group* g = ctx->group;
+	FX_HIP(hipEventRecord(g->ev_ready, s));
+	FX_HIP(hipStreamWaitEvent(g->comm_stream, g->ev_ready, 0));
+	return FX_OK;
+}
+static int comm_mark_done(fx_ctx* ctx) { FX_HIP(hipEventRecord(ctx->group->ev_done, ctx->group->comm_stream)); return FX_OK; }
+static int comm_join(fx_ctx* ctx, hipStream_t s) { FX_HIP(hipStreamWaitEvent(s, ctx->group->ev_done, 0)); return FX_OK; }
+
+
+// advect planes [r.lo, r.hi); own_only: back-traces must stay inside the owned planes (the halo is still in flight)
+int advect_range(fx_ctx* ctx, hipStream_t s, Range r, bool own_only)
+{
+	if (r.hi <= r.lo) return FX_OK;
+	DeviceGuard dg(ctx->device);
+	const SimParams sp{ ctx->time_step, (int)ctx->desc.advect_address, ctx->g.Zg > 1 ? 1 : 0 };
+	const int par = ctx->frame_parity;
+	Geom g = ctx->g;
+	// only halo_advect planes per side were refreshed by EX_ADVECT_IN; the allocation may be wider (max with halo_jacobi), and
+	// a tap into those stale planes must count as "left the exchanged halo", not as present data
+	// (with FX_OPT_ADAPTIVE_HALO: only the planes this step's exchange carried, adv_w_lo / adv_w_hi <= halo_advect)
+	g.zlo = std::max(g.zlo, g.z0 - ctx->adv_w_lo); g.zhi = std::min(g.zhi, g.z0 + g.nz - 1 + ctx->adv_w_hi);
+	if (own_only) { g.zlo = std::max(g.zlo, g.z0); g.zhi = std::min(g.zhi, g.z0 + g.nz - 1); }
+	FX_HIP(launch_advect(g, sp, ctx->half, ctx->vel[0], ctx->col[1 - par], ctx->vel[1], ctx->col[par],
+		r.lo, r.hi, ctx->halo_overflow, s));
+	return FX_OK;
+}
+
+// ---- the per-step record (fx_context.h): written behind the projection, read by the next step ------------------------------
+int options_digest(const fx_ctx* c)
+{
+	uint32_t h = 2166136261u;
+	uint32_t dt_bits;
+	std::memcpy(&dt_bits, &c->time_step, 4);               // the time step the record's needs were measured with: the ranks must agree on it too
+	for (uint32_t v : { (uint32_t)c->opt_overlap, (uint32_t)c->opt_round, (uint32_t)c->opt_adaptive, dt_bits }) h = (h ^ v) * 16777619u;
+	return (int)(h & 0x3FFFFFFFu);
+}
+
+static int record_step(fx_ctx* ctx, std::vector<fx_ctx*>& M, hipStream_t s)
+{
+	if (!multi_rank(ctx) || !ctx->step_rec) return FX_OK;
+	for (fx_ctx* m : M) {
+		if (m->rec_in_project) { m->rec_in_project = false; continue; }       // k_project_v4 has already written it
+		DeviceGuard dg(m->device);
+		FX_HIP(launch_face_need(m->g, m->half, m->vel[0], m->time_step, (int)m->desc.advect_address, options_digest(m), m->halo_overflow, m->step_rec, s));
+	}
+	DeviceGuard dg(ctx->device);
+	if (ctx->group->transport->is_local()) {
+		for (fx_ctx* m : M) FX_HIP(hipMemcpyAsync(m->rec_host, m->step_rec, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+		FX_HIP(hipEventRecord(ctx->rec_ev, s));
+	} else {
+		// off the compute stream when there is a side stream: the next step's interior advection need not wait for the gather
+		hipStream_t cs = s;
+		if (overlap_level(ctx) >= 1) { int rc = comm_fork(ctx, s); if (rc) return rc; cs = ctx->group->comm_stream; }
+		if (ctx->group->transport->allgather(ctx->step_rec, 4, ctx->gath_dev, cs) != FX_OK) { ctx->last_error = "rccl: all-gather of the step record failed"; return FX_E_COMM; }
+		FX_HIP(hipMemcpyAsync(ctx->rec_host, ctx->gath_dev, 4 * sizeof(int) * (size_t)ctx->nranks, hipMemcpyDeviceToHost, cs));
+		FX_HIP(hipEventRecord(ctx->rec_ev, cs));
+	}
+	for (fx_ctx* m : M) { m->rec_pending = true; m->need_valid = true; m->rec_dt = m->time_step; }
+	return FX_OK;
+}
+
+// Waits for the previous step's record and takes the step's decisions from it -- every rank holds the same records and therefore
+// decides alike: FX_E_HALO if ANY rank's advection left its exchanged planes (or the next one would need more than halo_advect),
+// FX_E_STATE if the ranks disagree about the schedule options; else the planes this step's advection exchange carries per face
+// (FX_OPT_ADAPTIVE_HALO: the measured need of the two slabs that share the face; otherwise, or when the measurement does not
+// cover this step -- first step, velocity uploaded since, larger dt -- the whole halo_advect).
+static int consume_record(fx_ctx* ctx, std::vector<fx_ctx*>& M)
+{
+	const int Ha = (int)ctx->desc.halo_advect;
+	for (fx_ctx* m : M) { m->adv_w_lo = has_lower(m) ? Ha : 0; m->adv_w_hi = has_upper(m) ? Ha : 0; }
+	if (!multi_rank(ctx) || !ctx->rec_pending) return FX_OK;
+	{
+		DeviceGuard dg(ctx->device);
+		FX_HIP(hipEventSynchronize(ctx->rec_ev));
+	}
+	const bool local = ctx->group->transport->is_local();
+	const int n = ctx->nranks;
+	auto rec = [&](int r) -> const int* { return local ? M[(size_t)r]->rec_host : ctx->rec_host + 4 * r; };
+	bool fault = false, mismatch = false, usable = ctx->opt_adaptive != 0;
+	for (int r = 0; r < n; ++r) { fault = fault || rec(r)[3] != 0; mismatch = mismatch || rec(r)[2] != rec(0)[2]; }
+	for (fx_ctx* m : M) { usable = usable && m->need_valid && m->time_step <= m->rec_dt; m->rec_pending = false; }
+	if (fault) {
+		// This return IS the chain-wide notice of the fault: every rank gets it once, from the same gathered record, and the step
+		// after it starts clean.  It does not block read-back again: the rank whose own advection overflowed still has its device
+		// flag up until its fx_synchronize acknowledges it (before or after this call), the other ranks have nothing to acknowledge.
+		// (Before: this set halo_fault on every rank, so the order fx_synchronize -> fx_simulate reported the same fault three times.)
+		ctx->last_error = "the previous step's advection left the exchanged halo on at least one rank";
+		return FX_E_HALO;
+	}
+	if (mismatch) { ctx->last_error = "the ranks of the chain run with different schedule options (fx_set_option) or time steps"; return FX_E_STATE; }
+	if (!usable) return FX_OK;
+	for (int r = 0; r + 1 < n; ++r)
+		if (std::max(rec(r)[1], rec(r + 1)[0]) > Ha) {
+			ctx->last_error = "the next advection needs more planes across a slab face than halo_advect provides";
+			return FX_E_HALO;                            // the step is abandoned; its INPUTS (velocity[0], colour[!parity], pressure) are untouched -- in the
+			                                             // overlapped schedule the interior advection has already written part of its outputs (velocity[1], colour[parity])
+		}
+	for (fx_ctx* m : M) {
+		const int r = m->rank;
+		m->adv_w_lo = r > 0 ? std::max(rec(r - 1)[1], rec(r)[0]) : 0;
+		m->adv_w_hi = r + 1 < n ? std::max(rec(r)[1], rec(r + 1)[0]) : 0;
+	}
+	return FX_OK;
+}
+
+int advect_all(fx_ctx* ctx, std::vector<fx_ctx*>& M, hipStream_t s)
+{
+	int rc;
+	const int Ha = (int)ctx->desc.halo_advect;
+	// FX_OPT_OVERLAP 3: the previous step already sent the colour planes this advection gathers from (simulate_impl); only
+	// the velocity, which the projection has just finished, travels now.  Every rank of a chain takes the same branch: the
+	// flag follows from the option level and the step history alone (a colour upload in between is refused, fx_upload).
+	bool col_ready = multi_rank(ctx);
+	for (fx_ctx* m : M) col_ready = col_ready && m->col_halo_buf == 1 - (int)m->frame_parity;
+	for (fx_ctx* m : M) m->col_halo_buf = -1;
+	bool ov = overlap_level(ctx) >= 1;
+	if (ov && ctx->group->min_nz <= 2 * Ha) ov = false;        // decided on the thinnest slab of the chain: the same on every rank
+	if (!ov) {
+		if ((rc = consume_record(ctx, M))) return rc;
+		if (col_ready) FX_HIP(hipStreamWaitEvent(s, ctx->group->ev_col_done, 0));
+		const ExchSpec spec{ col_ready ? EX_ADVECT_VEL : EX_ADVECT_IN, Ha, 0 };
+		if ((rc = do_exchange(ctx, M, &spec, 1, s))) return rc;
+		for (fx_ctx* m : M) {
+			ScopedMark mk(m, s, MK_ADVECT);
+			if (m->timing_on) m->acc.advect_halo_planes += (uint64_t)(m->adv_w_lo + m->adv_w_hi);
+			if ((rc = advect_range(m, s, owned(m), false))) return rc;
+		}
+		return FX_OK;
+	}
+	// the interior first (it reads owned planes only, whatever the exchange will carry): the device is busy while the host waits
+	// for the previous step's record, which sizes the exchange
+	if ((rc = comm_fork(ctx, s))) return rc;                   // the comm stream picks up behind the previous step
+	for (fx_ctx* m : M) {
+		ScopedMark mk(m, s, MK_ADVECT);
+		const Range o = owned(m);
+		if ((rc = advect_range(m, s, Range{ o.lo + (has_lower(m) ? Ha : 0), o.hi - (has_upper(m) ? Ha : 0) }, true))) return rc;
+	}
+	if ((rc = consume_record(ctx, M))) return rc;
+	if (col_ready) FX_HIP(hipStreamWaitEvent(ctx->group->comm_stream, ctx->group->ev_col_done, 0));
+	const ExchSpec spec{ col_ready ? EX_ADVECT_VEL : EX_ADVECT_IN, Ha, 0 };
+	if ((rc = do_exchange(ctx, M, &spec, 1, ctx->group->comm_stream))) return rc;
+	if ((rc = comm_mark_done(ctx))) return rc;
+	if ((rc = comm_join(ctx, s))) return rc;
+	for (fx_ctx* m : M) {
+		ScopedMark mk(m, s, MK_ADVECT);
+		if (m->timing_on) m->acc.advect_halo_planes += (uint64_t)(m->adv_w_lo + m->adv_w_hi);
+		const Range o = owned(m);
+		if (has_lower(m) && (rc = advect_range(m, s, Range{ o.lo, o.lo + Ha }, false))) return rc;
+		if (has_upper(m) && (rc = advect_range(m, s, Range{ o.hi - Ha, o.hi }, false))) return rc;
+	}
+	return FX_OK;
+}
+
+int divergence_phase(fx_ctx* ctx, hipStream_t s)
+{
+	DeviceGuard dg(ctx->device);
+	ScopedMark mk(ctx, s, MK_DIV);
+	const Range r = owned(ctx);
+	FX_HIP(launch_divergence(ctx->g, ctx->half, ctx->vel[1], ctx->b, r.lo, r.hi, s));
+	return FX_OK;
+}
+
+// t lock-step sweeps p[src] -> p[src ^ 1] on planes [r.lo, r.hi) in ONE launch
+static int jacobi_launch(fx_ctx* ctx, hipStream_t s, int src, int t, Range r, ScopedMark* mk)
+{
+	r.lo = std::max(r.lo, 0); r.hi = std::min(r.hi, ctx->g.Zg);
+	if (r.hi <= r.lo) return FX_OK;
+	DeviceGuard dg(ctx->device);
+	if (t > 1) {
+		FX_HIP(launch_jacobi_fused(ctx->g, ctx->p[src], ctx->b, ctx->p[src ^ 1], t, r.lo, r.hi, s));
+	} else {
+		FX_HIP(launch_jacobi_sweep(ctx->g, ctx->p[src], ctx->b, ctx->p[src ^ 1], ctx->frozen, r.lo, r.hi, s));
+	}
+	if (mk) { mk->launches += 1; mk->sweeps += t; }
+	return FX_OK;
+}
+
+static int fused_sweeps(const fx_ctx* c)
+{
+	return c->frozen ? 1 : jacobi_fused_max_sweeps(c->g, (int)(c->desc.flags & FX_FLAG_JACOBI_FUSE_MASK), c->g.nz);
+}
+
+// `count` lock-step sweeps whose first one may read `count` exchanged halo planes; the planes swept shrink by
+// one per sweep towards the owned range (redundant halo work instead of an exchange per sweep)
+static int jacobi_round(fx_ctx* ctx, hipStream_t s, int count, ScopedMark* mk)
+{
+	int done = 0;
+	while (done < count) {
+		const int left = count - done;
+		int t = std::min(left, fused_sweeps(ctx));
+		if (!ctx->frozen && jacobi_prefers_three(ctx->g, (int)(ctx->desc.flags & FX_FLAG_JACOBI_FUSE_MASK), ctx->g.nz))
+			t = left == 4 ? 2 : std::min(left, 3);           // threes, and a remainder of 4 as 2 + 2 rather than 3 + 1
+		if (mk && mk->kind == MK_JACOBI && mk->launches && t * mk->launches < mk->sweeps) mk->split(MK_JACOBI_TAIL);   // shorter launches from here on
+		const int rc = jacobi_launch(ctx, s, ctx->p_cur, t, grown(ctx, multi_rank(ctx) ? left - t : 0), mk);
+		if (rc) return rc;
+		ctx->p_cur ^= 1;
+		done += t;
+	}
+	return FX_OK;
+}
+
+static int clear_freeze_masks(std::vector<fx_ctx*>& M, hipStream_t s)
+{
+	for (fx_ctx* m : M)
+		if (m->frozen) { DeviceGuard dg(m->device); if (hipMemsetAsync(m->frozen, 0, m->g.cells_local(), s) != hipSuccess) return FX_E_DEVICE; }
+	return FX_OK;
+}
+
+// FX_JACOBI_FAITHFUL on a single domain: the sparse solver of fx_jacobi_freeze.hip.  Level 1 everywhere (into p[other] AND p_aux;
+// the input buffer becomes the spare), then ceil((iters - 1) / T) launches over the tiles that still relax, all enqueued; the
+// result is in the last launch's output buffer (settled tiles agree in both).  Bit-identical to `iters` generic sweeps with the
+// byte mask (tests/test_gpu_sim.py::test_freeze_fast_path_*).
+static int jacobi_freeze(fx_ctx* ctx, hipStream_t s, uint32_t iters)
+{
+	DeviceGuard dg(ctx->device);
+	ScopedMark mk(ctx, s, MK_JACOBI);
+	if (++ctx->fz_gen >= (1u << 23)) {                                  // the tag (gen << 8 | level) of the stat words stays below 2^32: start over
+		FX_HIP(hipMemsetAsync(ctx->fz_tile_next, 0, (size_t)jacobi_freeze_tiles(ctx->g) * sizeof(uint32_t), s));
+		FX_HIP(hipMemsetAsync(ctx->fz_stat, 0, kFreezeStatRing * sizeof(uint32_t), s));
+		FX_HIP(hipMemsetAsync(ctx->fz_counts, 0, 2 * jacobi_freeze_count_words() * sizeof(uint32_t), s));
+		ctx->fz_gen = 2; ctx->fz_gen_mark = 0;
+	}
+	const uint32_t gen = ctx->fz_gen, stat_hi = gen << 8;
+	uint32_t* stat = ctx->fz_stat + gen % kFreezeStatRing;
+	ctx->fz_iters[gen % kFreezeStatRing] = iters;
+	const size_t cw = jacobi_freeze_count_words();
+	const FreezeWork w{ ctx->fz_tile_next, gen, { ctx->fz_list[0], ctx->fz_list[1] }, jacobi_freeze_tiles(ctx->g),
+		ctx->fz_counts + (gen & 1u) * cw, ctx->fz_counts + ((gen & 1u) ^ 1u) * cw };
+	float* src = ctx->p[ctx->p_cur];
+	float* a = ctx->p[ctx->p_cur ^ 1];
+	float* d = ctx->p_aux;
+	uint8_t* ma = ctx->fz_mask[0];
+	uint8_t* md = ctx->fz_mask[1];
+	// (The dense sweep writes level 1 to BOTH buffers the tile launches alternate between.  Writing one and letting the first tile
+	// launch carry the unlisted tiles' border cells across was built and measured level: the dense sweep 75 -> 46 us at 256^3, the
+	// first tile launch slower by as much -- the shell of a 4-deep cone around ~3000 listed tiles is more bytes than the second copy.)
+	FX_HIP(launch_freeze_dense(ctx->g, src, ctx->b, a, d, ma, md, w, stat, stat_hi, s));
+	mk.launches = 1; mk.sweeps = 1;
+	if (iters > 1) mk.split(MK_JACOBI_TAIL);                            // fx_timing books the dense sweep as the "main" launch, the tile launches beside it
+	const int T = jacobi_freeze_levels_per_launch();
+	int level = 1, n = 0;
+	for (uint32_t left = iters - 1; left > 0; ++n) {
+		const int t = (int)std::min<uint32_t>((uint32_t)T, left);
+		FX_HIP(launch_freeze_tiles(ctx->g, a, ctx->b, d, ma, md, w, n, t, level, stat, stat_hi, s));
+		std::swap(a, d); std::swap(ma, md);
+		left -= (uint32_t)t; level += t;
+		mk.launches += 1; mk.sweeps += (uint64_t)t;
+	}
+	ctx->p[0] = a; ctx->p[1] = d; ctx->p_aux = src; ctx->p_cur = 0;
+	return FX_OK;
+}
+
+// exchange, then k sweeps, exchange, ... on one stream
+static int jacobi_serial(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t iters)
+{
+	const bool multi = multi_rank(lead);
+	const int k = multi ? lead->opt_round : (int)iters;
+	int rc;
+	if (!multi && lead->frozen && lead->fz_tile_next && jacobi_freeze_supported(lead->g) && iters <= 255 && (int)iters / jacobi_freeze_levels_per_launch() + 3 < kFreezeSlots)   // a level fits the stat word's low byte, every launch has its counters
+		return jacobi_freeze(lead, s, iters);
+	if ((rc = clear_freeze_masks(M, s))) return rc;
+	const ExchSpec bspec{ EX_DIV, k - 1, 0 };
+	if ((rc = do_exchange(lead, M, &bspec, 1, s))) return rc;
+	uint32_t done = 0;
+	while (done < iters) {
+		const int cnt = (int)std::min<uint32_t>(k, iters - done);
+		const ExchSpec pspec{ EX_PRESSURE, cnt, lead->p_cur };
+		if ((rc = do_exchange(lead, M, &pspec, 1, s))) return rc;
+		for (fx_ctx* m : M) {
+			ScopedMark mk(m, s, MK_JACOBI);
+			if ((rc = jacobi_round(m, s, cnt, &mk))) return rc;
+		}
+		done += cnt;
+	}
+	const ExchSpec last{ EX_PRESSURE, 1, lead->p_cur };          // the projection's z-gradient reads one plane across the face
+	return do_exchange(lead, M, &last, 1, s);
+}
+
+// Rounds of up to k sweeps with the pressure exchange of a round hidden behind its interior sweeps, on three streams.
+// With lo/hi = the owned planes, src = the buffer holding the round's level 0 (k halo planes valid), cnt <= k sweeps in the
+// round, done as m launches of t_1 <= t_2 = ... = t_m fused sweeps (c_j = t_1 + ... + t_j, rem_j = cnt - c_j):
+//   face stream   the FACE CHAIN: cnt single sweeps over both face zones per launch, level s on [lo - (cnt - s), lo + k + (cnt - s))
+//                 (mirrored at hi), entirely in two scratch buffers (only its first sweep reads src): thin, latency-bound
+//                 launches that run BESIDE the interior instead of in front of it.  Its last level holds the k planes the
+//                 neighbour needs.
+//   comm stream   after the chain: those k planes leave from the scratch buffer, the neighbour's land in the halo of the
+//                 round's last buffer (which no interior launch touches)
+//   compute       the INTERIOR, self-sufficient: launch j brings [lo + k - rem_j, hi - k + rem_j) from level c_(j-1) to c_j,
+//                 i.e. it recomputes the rem_j planes per side the chain also computes instead of waiting for them (it never
+//                 reads below lo + k - cnt >= lo, so it needs no halo).  Launch 2 overwrites src and therefore waits until
+//                 the chain's first sweep has read it; after the last launch the chain's k final planes are copied from the
+//                 scratch buffer into [lo, lo + k) of the round's last buffer, which completes the owned planes.
+// Per round the critical path is max(interior, chain + link) instead of chain + max(interior, link).  Every cell gets the
+// arithmetic of the single-domain sweep; (cell, level) pairs of the zone borders are computed twice, which is why the
+// faithful mode (its freeze mask is a side effect) takes the serial schedule instead.
+static int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t iters, int t, int k)
+{
+	fx_comm_group* grp = lead->group;
+	hipStream_t fs = grp->face_stream, cs = grp->comm_stream;
+	int rc;
+	fx_ctx* ctx = lead;                                    // FX_HIP reports through `ctx`
+	// The face chain runs one single-sweep launch (k_jacobi_v4: 60 registers, both faces) per level.  Groups of fused sweeps with the
+	// interior's register-strip kernels were built and measured slower (loop-back N = 4, 256^3 per rank, rounds of 9: 6.30 against 5.67 ms
+	// per step; profiles/r02c_chain_fuse_loopback4.txt): on a 9..27-plane zone the strips have 64..192 waves whose 310 registers shut
+	// the interior's waves out of their SIMDs for a whole 14-step pipeline -- removed in round 3.
+	const ExchSpec first[2] = { { EX_DIV, k - 1, 0 }, { EX_PRESSURE, k, lead->p_cur } };
+	if ((rc = do_exchange(lead, M, first, 2, s))) return rc;
+	FX_HIP(hipEventRecord(grp->ev_int, s));
+	bool in_flight = false;
+	uint32_t done = 0;
+	while (done < iters) {
+		const int cnt = (int)std::min<uint32_t>(k, iters - done);
+		const int m = (cnt + t - 1) / t, t_first = cnt - (m - 1) * t;
+		const int src = lead->p_cur, fin = src ^ (m & 1);
+		int fbuf = 0;                                      // which scratch buffer holds the chain's last level (set below)
+		// ---- face stream: the chain (needs the previous round's interior + face copy, and its exchange)
+		FX_HIP(hipStreamWaitEvent(fs, grp->ev_int, 0));
+		if (in_flight) FX_HIP(hipStreamWaitEvent(fs, grp->ev_done, 0));
+		ScopedMark chain_mark(lead, fs, MK_CHAIN);         // one mark per chain (loop-back: all members' chains, booked on the first)
+		{
+			// the chain: one sweep per launch over the two thin face zones
+			int grp_i = 0;
+			for (int c = 1; c <= cnt; ++c, ++grp_i) {
+				const int rem = cnt - c, ob = (grp_i + 1) & 1;
+				for (fx_ctx* mctx : M) {
+					if (!has_lower(mctx) && !has_upper(mctx)) continue;
+					DeviceGuard dg(mctx->device);
+					const Range o = owned(mctx);
+					const float* in = grp_i == 0 ? mctx->p[src] : mctx->p_face[grp_i & 1];
+					const Range lo{ o.lo - rem, has_lower(mctx) ? o.lo + k + rem : o.lo - rem };
+					const Range hi{ has_upper(mctx) ? o.hi - k - rem : o.hi + rem, o.hi + rem };
+					FX_HIP(launch_jacobi_sweep2(mctx->g, in, mctx->b, mctx->p_face[ob], nullptr, lo.lo, lo.hi, hi.lo, hi.hi, fs));
+				}
+				if (grp_i == 0) FX_HIP(hipEventRecord(grp->ev_face1, fs));
+			}
+			fbuf = grp_i & 1;                                  // the buffer the last group wrote
+		}
+		FX_HIP(hipEventRecord(grp->ev_ready, fs));
+		// ---- comm stream: the k final planes of the chain travel, the neighbour's land in the halo of p[fin]
+		FX_HIP(hipStreamWaitEvent(cs, grp->ev_ready, 0));
+		const ExchSpec pspec{ EX_PRESSURE_FACE, k, (fbuf << 1) | fin };
+		if ((rc = do_exchange(lead, M, &pspec, 1, cs))) return rc;
+		if ((rc = comm_mark_done(lead))) return rc;
+		in_flight = true;
+		// ---- compute stream: the interior
+		for (fx_ctx* mctx : M) {
+			ScopedMark mk(mctx, s, MK_JACOBI);
+			const Range o = owned(mctx);
+			int lvl = 0, cur = src;
+			for (int j = 0; j < m; ++j) {
+				const int tj = j == 0 ? t_first : t;
+				lvl += tj;
+				const int rem = cnt - lvl;
+				const Range in{ has_lower(mctx) ? o.lo + k - rem : o.lo, has_upper(mctx) ? o.hi - k + rem : o.hi };
+				if (j == 1 && mctx == M.front()) FX_HIP(hipStreamWaitEvent(s, grp->ev_face1, 0));   // launch 2 overwrites the chain's input
+				if ((rc = jacobi_launch(mctx, s, cur, tj, in, &mk))) return rc;
+				cur ^= 1;
+			}
+		}
+		// the chain's final planes complete the owned range of p[fin]
+		FX_HIP(hipStreamWaitEvent(s, grp->ev_ready, 0));
+		for (fx_ctx* mctx : M) {
+			DeviceGuard dg(mctx->device);
+			const size_t pl = mctx->g.plane(), kb = (size_t)k * pl * 4;
+			const Range o = owned(mctx);
+			if (has_lower(mctx))
+				FX_HIP(launch_copy_bytes(mctx->p[fin] + (size_t)mctx->g.lz(o.lo) * pl, mctx->p_face[fbuf] + (size_t)mctx->g.lz(o.lo) * pl, kb, s));
+			if (has_upper(mctx))
+				FX_HIP(launch_copy_bytes(mctx->p[fin] + (size_t)mctx->g.lz(o.hi - k) * pl, mctx->p_face[fbuf] + (size_t)mctx->g.lz(o.hi - k) * pl, kb, s));
+			mctx->p_cur = fin;
+		}
+		FX_HIP(hipEventRecord(grp->ev_int, s));
+		done += cnt;
+	}
+	if (in_flight) rc = comm_join(lead, s);
+	return rc;
+}
+
+int jacobi_all(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t iters)
+{
+	if (overlap_level(lead) >= 2) {
+		int t = fused_sweeps(lead);
+		bool three = true;
+		for (fx_ctx* m : M) {
+			t = std::min(t, fused_sweeps(m));
+			three = three && !m->frozen && jacobi_prefers_three(m->g, (int)(m->desc.flags & FX_FLAG_JACOBI_FUSE_MASK), m->g.nz);
+		}
+		if (three) t = 3;                              // the interior launches of a round as threes (k = 9: 3 + 3 + 3); local choice, the exchanges do not depend on it
+		const int k = lead->opt_round;
+		// two face zones (<= 2k - 1 planes each) and an interior; decided on the thinnest slab of the chain and on the (chain-wide)
+		// Jacobi mode, so that every rank takes the same branch -- the two schedules exchange different things
+		const bool ok = lead->group->face_stream != nullptr && lead->group->min_nz >= 4 * k && lead->p_face[0] && !lead->frozen;
+		if (ok) return jacobi_overlapped(lead, M, s, iters, t, k);
+	}
+	return jacobi_serial(lead, M, s, iters);
+}
+
+
+int project_phase(fx_ctx* ctx, hipStream_t s)
+{
+	DeviceGuard dg(ctx->device);
+	const SimParams sp{ ctx->time_step, (int)ctx->desc.advect_address, ctx->g.Zg > 1 ? 1 : 0 };
+	ScopedMark mk(ctx, s, MK_PROJECT);
+	const Range r = owned(ctx);
+	int* rec = multi_rank(ctx) ? ctx->step_rec : nullptr;           // slab ranks: the projection also measures the next advection's need
+	ctx->rec_in_project = false;
+	FX_HIP(launch_project(ctx->g, sp, ctx->half, ctx->vel[1], ctx->p[ctx->p_cur], ctx->vel[0], r.lo, r.hi, s,
+		rec, rec ? options_digest(ctx) : 0, ctx->halo_overflow, &ctx->rec_in_project));
+	return FX_OK;
+}
+
+int simulate_impl(fx_ctx* ctx, hipStream_t s)
+{
+	std::vector<fx_ctx*> M;
+	for_members(ctx, M);
+	int rc;
+	if ((rc = advect_all(ctx, M, s))) return rc;
+	if (overlap_level(ctx) >= 3) {
+		// colour[parity] is final for this step: its halo planes -- four of the seven plane-units the next advection needs --
+		// leave now on the side stream, behind divergence / pressure / projection
+		fx_comm_group* g = ctx->group;
+		FX_HIP(hipEventRecord(g->ev_col_ready, s));
+		FX_HIP(hipStreamWaitEvent(g->comm_stream, g->ev_col_ready, 0));
+		const ExchSpec cs{ EX_COLOR_CUR, (int)ctx->desc.halo_advect, 0 };
+		if ((rc = do_exchange(ctx, M, &cs, 1, g->comm_stream, 1))) return rc;       // side channel: not queued with the step's own exchanges
+		FX_HIP(hipEventRecord(g->ev_col_done, g->comm_stream));
+		for (fx_ctx* m : M) m->col_halo_buf = (int)m->frame_parity;
+	}
+	if (ctx->time_step > 0.0f) {                       // CSProject3D.hlsl:88
+		const ExchSpec uz{ EX_UZ1, 1, 0 };
+		if ((rc = do_exchange(ctx, M, &uz, 1, s))) return rc;
+		for (fx_ctx* m : M) if ((rc = divergence_phase(m, s))) return rc;
+		if ((rc = jacobi_all(ctx, M, s, ctx->desc.jacobi_iters))) return rc;
+		for (fx_ctx* m : M) if ((rc = project_phase(m, s))) return rc;
+	} else {
+		for (fx_ctx* m : M) {
+			DeviceGuard dg(m->device);
+			m->rec_in_project = false;
+			if (launch_copy_velocity(m->g, m->half, m->vel[1], m->vel[0], s) != hipSuccess) return FX_E_DEVICE;
+		}
+	}
+	if ((rc = record_step(ctx, M, s))) return rc;
+	for (fx_ctx* m : M) { if (m->timing_on) m->acc.steps += 1; if (ctx->time_step > 0.0f) m->steps_simulated += 1; }
+	return FX_OK;
+}
+
+}  // namespace fxh

@@ -500,118 +500,6 @@ __global__ __launch_bounds__(256) void k_jacobi_v4(const Geom g, const float* __
 }
 
 // ---------------------------------------------------------------------------------------------
-// Jacobi, temporally blocked: T lock-step sweeps per launch ("3.5-D blocking").
-//
-// A workgroup owns TY full-x rows (thread = one float4 column of one row, 1024 threads = 16 waves)
-// and streams along z.  Every level l = 0..T-1 keeps, per thread, a 3-plane register window of its own
-// column (the z neighbours) and, per workgroup, ONE plane in LDS (the y neighbours); x neighbours come
-// from wave64 shuffles of the centre value.  Level t lags level t-1 by one plane, so in step q level 0
-// takes plane q from HBM, level t produces plane q-t, level T is stored.  Per step: phase A gathers
-// (((L - b) + R) + U) + D of every level from the LDS planes written in the previous step, barrier,
-// phase B adds the front/back planes from the register windows in ascending level order and rewrites
-// the LDS planes, barrier.  p and b are read once and p' written once per T sweeps; the price is the
-// redundant halo: T rows on each side of the y tile and T planes on each side of the z chunk.
-// The per-cell arithmetic (association order included) is that of k_jacobi_v4, so results are
-// bit-identical to T single sweeps.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-
-template <int T, int D, int NT, int MINW>
-__global__ __launch_bounds__(NT, MINW) void k_jacobi_tb(const Geom g, const float* __restrict__ p_in,
-	const float* __restrict__ b, float* __restrict__ p_out, int z_begin, int z_end, int zchunk)
-{
-	extern __shared__ __attribute__((aligned(16))) float lds[];     // T planes of TY rows of X floats
-	const int LX = g.X >> 2, TY = blockDim.y;
-	const int lx = threadIdx.x, ry = threadIdx.y;
-	const int TYV = TY - 2 * T;
-	const int y = (int)blockIdx.x * TYV - T + ry;
-	const int yc = min(max(y, 0), g.Y - 1);
-	const bool row_store = ry >= T && ry < TY - T && y < g.Y;
-	const int zb = z_begin + (int)blockIdx.y * zchunk, ze = min(zb + zchunk, z_end);
-	if (zb >= ze) return;                                           // uniform for the workgroup
-	const int qs = max(zb - T, g.zlo), q_last = ze - 1 + T;
-	const int q_load_last = min(q_last, g.zhi);                     // last input plane that exists
-	const size_t plane = g.plane();
-	const size_t rowoff = (size_t)yc * g.X + 4 * lx;
-	const float inv = __uint_as_float(0x3e2aaaabu);
-	const int planeF4 = TY * LX;                                    // float4 per LDS plane
-	float4* lds4 = reinterpret_cast<float4*>(lds);
-	const int my = ry * LX + lx, up = max(ry - 1, 0) * LX + lx, dn = min(ry + 1, TY - 1) * LX + lx;
-	const bool x_first = lx == 0, x_last = lx == LX - 1, y_first = y <= 0, y_last = y >= g.Y - 1;
-
-	const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-	float4 w[T + 1][3], bq[T + 1], s[T];                            // w[T] is never live
-#pragma unroll
-	for (int l = 0; l < T; ++l) { w[l][0] = zero; w[l][1] = zero; w[l][2] = zero; s[l] = zero; }
-#pragma unroll
-	for (int l = 0; l <= T; ++l) bq[l] = zero;
-#pragma unroll
-	for (int l = 0; l < T; ++l) lds4[l * planeF4 + my] = zero;
-
-	// register FIFO of D input planes in flight: fp[i], fb[i] = planes q + i
-	float4 fp[D], fb[D];
-#pragma unroll
-	for (int i = 0; i < D; ++i) {
-		fp[i] = zero; fb[i] = zero;
-		if (qs + i <= q_load_last) {
-			const size_t o = (size_t)g.lz(qs + i) * plane + rowoff;
-			fp[i] = *reinterpret_cast<const float4*>(p_in + o);
-			fb[i] = *reinterpret_cast<const float4*>(b + o);
-		}
-	}
-	__syncthreads();
-
-	for (int q = qs; q <= q_last; ++q) {
-		const float4 curP = fp[0], curB = fb[0];
-#pragma unroll
-		for (int i = 0; i + 1 < D; ++i) { fp[i] = fp[i + 1]; fb[i] = fb[i + 1]; }
-		if (q + D <= q_load_last) {                                 // keep D planes in flight
-			const size_t o = (size_t)g.lz(q + D) * plane + rowoff;
-			fp[D - 1] = *reinterpret_cast<const float4*>(p_in + o);
-			fb[D - 1] = *reinterpret_cast<const float4*>(b + o);
-		}
-#pragma unroll
-		for (int l = T; l >= 1; --l) bq[l] = bq[l - 1];             // bq[i] = b of plane q - i
-		bq[0] = curB;
-
-		// ---- phase A: in-plane part of every level's stencil, centre = newest plane of level t-1 ----
-#pragma unroll
-		for (int t = 1; t <= T; ++t) {
-			const float4 c = w[t - 1][2];
-			float L = __shfl_up(c.w, 1), R = __shfl_down(c.x, 1);
-			if (x_first) L = c.x;
-			if (x_last) R = c.w;
-			const float4 U = y_first ? c : lds4[(t - 1) * planeF4 + up];
-			const float4 Dn = y_last ? c : lds4[(t - 1) * planeF4 + dn];
-			const float4 Lv = make_float4(L, c.x, c.y, c.z), Rv = make_float4(c.y, c.z, c.w, R);
-			s[t - 1] = f4add(f4add(f4add(f4sub(Lv, bq[t]), Rv), U), Dn);
-		}
-		__syncthreads();
-
-		// ---- phase B: add front/back from the register windows, ascending levels --------------------
-		w[0][0] = w[0][1]; w[0][1] = w[0][2]; w[0][2] = curP;
-		lds4[my] = curP;
-#pragma unroll
-		for (int t = 1; t <= T; ++t) {
-			const int m = q - t;
-			const float4 c = w[t - 1][1];
-			const float4 F = m == 0 ? c : w[t - 1][0];
-			const float4 Bk = m == g.Zg - 1 ? c : w[t - 1][2];
-			float4 x = f4add(f4add(s[t - 1], F), Bk);
-			x.x *= inv; x.y *= inv; x.z *= inv; x.w *= inv;
-			if (t < T) {
-				w[t][0] = w[t][1]; w[t][1] = w[t][2]; w[t][2] = x;
-				lds4[t * planeF4 + my] = x;
-			} else if (row_store && m >= zb && m < ze) {
-				*reinterpret_cast<float4*>(p_out + (size_t)g.lz(m) * plane + (size_t)y * g.X + 4 * lx) = x;
-			}
-		}
-		__syncthreads();
-	}
-}
-
-// ---------------------------------------------------------------------------------------------
 // projection + wall damping
 // ---------------------------------------------------------------------------------------------
 template <bool HALF>
@@ -1065,9 +953,11 @@ hipError_t launch_jacobi_sweep2(const Geom& g, const float* p_in, const float* b
 	return hipGetLastError();
 }
 
-// ---- temporal blocking: geometry support and tuning knobs -----------------------------------------
-// FLUIDX_JACOBI_T (1..4) overrides the sweeps fused per launch, FLUIDX_JACOBI_ZCHUNK the planes per
-// workgroup; both exist for the measurements recorded in DESIGN.md / profiles/.
+// ---- temporal blocking: which geometry fuses how many sweeps ----------------------------------------
+// FLUIDX_JACOBI_T (1..3) overrides the sweeps fused per launch (measurement knob, DESIGN.md / profiles/).
+// (The LDS tile kernel k_jacobi_tb<T> of round 1 -- z-streaming register windows + one LDS plane per level, two barriers per plane --
+// lost to the register strips in every shape measured, profiles/r01_jacobi_tile_sweep.txt, and was removed in round 3; with it went
+// four sweeps per launch: jacobi_fuse = 4 now runs threes.)
 static int env_int(const char* name, int dflt)
 {
 	const char* v = getenv(name);
@@ -1103,10 +993,9 @@ int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp)
 	// X = 128: a 4 x 4-row block per wave, two sweeps (fx_jacobi_block.hip) -- the strips have too few waves there
 	if (jacobi_block2_supported(g) && !requested && !forced) return nzp >= 2 ? 2 : 1;
 	// default: two sweeps per launch in the register-strip kernel (fx_jacobi_strip.hip) where the geometry allows it,
-	// else one sweep per launch; the LDS kernel k_jacobi_tb<T> lost to both in every shape measured
-	// (profiles/r01_jacobi_tile_sweep.txt)
+	// else one sweep per launch
 	const int t = requested > 0 ? requested : (forced > 0 ? forced : (strip_profitable(g, nzp) ? 2 : 1));
-	return t < 1 ? 1 : (t > 4 ? 4 : t);
+	return t < 1 ? 1 : (t > 3 ? 3 : t);
 }
 
 // Default schedule of the serial rounds (single domain, and slab ranks thick enough): THREE sweeps per launch (k_jacobi_strip3) where that kernel exists and the grid is large
@@ -1118,77 +1007,11 @@ bool jacobi_prefers_three(const Geom& g, int requested, int nzp)
 	static const int forced = env_int("FLUIDX_JACOBI_T", 0);
 	static const int prefer = env_int("FLUIDX_JACOBI_PREFER3", 1);
 	static const int no_lds3 = env_int("FLUIDX_STRIP3_OFF", 0);
-	static const int use_tb = env_int("FLUIDX_FUSE2_TB", 0);
-	return prefer && !requested && !forced && !no_lds3 && !use_tb && jacobi_strip3_supported(g) &&
+	return prefer && !requested && !forced && !no_lds3 && jacobi_strip3_supported(g) &&
 		(size_t)g.X * g.Y * (size_t)nzp >= (g.X == 512 ? (size_t)1 << 24 : (size_t)3 << 22);
 	// X = 256: from 12.6 M cells (256x256x128 still loses, 11.3 against 11.0 us per sweep).  X = 512 (k_jacobi_strip3h): from 16.8 M
 	// cells since the round-2 hand-over order -- 512x512x64 (a rank of BASELINE configs[3]) 18.7 against 19.5 us per sweep,
 	// 512x512x128 36.2 against 43.7, 512^3 117.6 against 152 (before: 20.3 / 39.6 / 129)
-}
-
-// tile geometry of the fused kernel: TY rows per workgroup (threads = X/4 * TY), D input planes in flight
-struct TbConfig { int T, TY, D, zchunk; };
-
-static TbConfig tb_config(const Geom& g, int T, int nzp)
-{
-	// FLUIDX_JACOBI_CFG="TY,D,zchunk" overrides (measurement knob)
-	static const char* env = getenv("FLUIDX_JACOBI_CFG");
-	const int LX = g.X >> 2;
-	TbConfig c{ T, 1024 / LX, 2, 0 };
-	if (T == 2) c.TY = 768 / LX;                                    // 12 waves/workgroup, 2 workgroups per CU
-	if (env && *env) {
-		int ty = 0, d = 0, zc = 0;
-		if (sscanf(env, "%d,%d,%d", &ty, &d, &zc) >= 1) {
-			if (ty > 2 * T && ty * LX <= 1024) c.TY = ty;
-			if (d >= 1 && d <= 4) c.D = d;
-			if (zc > 0) c.zchunk = zc;
-		}
-	}
-	if (c.TY > g.Y + 2 * T) c.TY = g.Y + 2 * T;
-	const int TYV = c.TY - 2 * T;
-	const int ytiles = (g.Y + TYV - 1) / TYV;
-	if (!c.zchunk) {
-		int nchunks = 512 / ytiles;                                 // ~2 workgroups per CU, no partial round
-		if (nchunks < 1) nchunks = 1;
-		c.zchunk = (nzp + nchunks - 1) / nchunks;
-		if (c.zchunk < 4 * T) c.zchunk = 4 * T;                     // keep the z-halo overhead <= 1.5x
-	}
-	if (c.zchunk > nzp) c.zchunk = nzp;
-	return c;
-}
-
-template <int T, int D, int NT, int MINW>
-static hipError_t launch_tb_k(const Geom& g, const TbConfig& c, const float* p_in, const float* b, float* p_out,
-	int z_begin, int z_end, hipStream_t s)
-{
-	const int LX = g.X >> 2, TYV = c.TY - 2 * T, nzp = z_end - z_begin;
-	const dim3 block(LX, c.TY, 1), grid((g.Y + TYV - 1) / TYV, (nzp + c.zchunk - 1) / c.zchunk, 1);
-	const size_t ldsBytes = (size_t)T * c.TY * g.X * sizeof(float);
-	static bool attr_set = false;
-	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_jacobi_tb<T, D, NT, MINW>),
-			hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		attr_set = true;
-	}
-	hipLaunchKernelGGL((k_jacobi_tb<T, D, NT, MINW>), grid, block, ldsBytes, s, g, p_in, b, p_out, z_begin, z_end, c.zchunk);
-	return hipGetLastError();
-}
-
-template <int T>
-static hipError_t launch_tb(const Geom& g, const float* p_in, const float* b, float* p_out, int z_begin, int z_end, hipStream_t s)
-{
-	const TbConfig c = tb_config(g, T, z_end - z_begin);
-	const int nt = (g.X >> 2) * c.TY;
-#define FX_TB(D_) do { \
-		if (nt <= 768) return launch_tb_k<T, D_, 768, 6>(g, c, p_in, b, p_out, z_begin, z_end, s); \
-		return launch_tb_k<T, D_, 1024, 4>(g, c, p_in, b, p_out, z_begin, z_end, s); } while (0)
-	switch (c.D) {
-	case 1: FX_TB(1);
-	case 3: FX_TB(3);
-	case 4: FX_TB(4);
-	default: FX_TB(2);
-	}
-#undef FX_TB
 }
 
 hipError_t launch_jacobi_fused(const Geom& g, const float* p_in, const float* b, float* p_out, int sweeps,
@@ -1201,21 +1024,15 @@ hipError_t launch_jacobi_fused(const Geom& g, const float* p_in, const float* b,
 	}
 	if (!tb_supported(g)) return sweeps == 2 && jacobi_blockg_supported(g) ? launch_jacobi_blockg(g, p_in, b, p_out, z_begin, z_end, s) : hipErrorNotSupported;
 	switch (sweeps) {
-	case 2: {
-		static const int use_tb = env_int("FLUIDX_FUSE2_TB", 0);      // 1 = the LDS kernel instead of the register strips
-		if (!use_tb && jacobi_block2_supported(g)) return launch_jacobi_block2(g, p_in, b, p_out, z_begin, z_end, s);
-		if (!use_tb && jacobi_strip_supported(g)) return launch_jacobi_strip(g, p_in, b, p_out, 2, z_begin, z_end, s);
-		return launch_tb<2>(g, p_in, b, p_out, z_begin, z_end, s);
-	}
+	case 2:
+		if (jacobi_block2_supported(g)) return launch_jacobi_block2(g, p_in, b, p_out, z_begin, z_end, s);
+		return launch_jacobi_strip(g, p_in, b, p_out, 2, z_begin, z_end, s);
 	case 3: {
-		static const int use_tb3 = env_int("FLUIDX_FUSE2_TB", 0);
-		static const int no_lds3 = env_int("FLUIDX_STRIP3_OFF", 0);    // 1 = the all-register three-sweep strips (spills)
-		if (!use_tb3 && !no_lds3 && jacobi_strip3_supported(g)) return launch_jacobi_strip3(g, p_in, b, p_out, z_begin, z_end, s);
-		if (!use_tb3 && jacobi_strip_supported(g)) return launch_jacobi_strip(g, p_in, b, p_out, 3, z_begin, z_end, s);
-		return launch_tb<3>(g, p_in, b, p_out, z_begin, z_end, s);
+		static const int no_lds3 = env_int("FLUIDX_STRIP3_OFF", 0);    // 1 = the all-register three-sweep strips
+		if (!no_lds3 && jacobi_strip3_supported(g)) return launch_jacobi_strip3(g, p_in, b, p_out, z_begin, z_end, s);
+		return launch_jacobi_strip(g, p_in, b, p_out, 3, z_begin, z_end, s);
 	}
-	case 4: return launch_tb<4>(g, p_in, b, p_out, z_begin, z_end, s);
-	default: return hipErrorNotSupported;
+	default: return hipErrorNotSupported;            // (jacobi_fused_max_sweeps never offers more than three)
 	}
 }
 

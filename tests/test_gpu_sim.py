@@ -169,11 +169,9 @@ def test_general_block_kernel_bit_exact(dims, iters):
 
 
 @pytest.mark.parametrize("depth", [4, 5, 17, 33, 50, 128, 256])
-def test_x256_meeting_streams_bit_exact(depth, monkeypatch):
-    """k_jacobi_strip3z (FLUIDX_STRIP3_ZMEET=1; X = 256, three sweeps per launch): a workgroup's two z streams run towards each other
-    and hand the planes across their meeting plane over instead of re-reading them -- odd and tiny depths put the meeting plane next
-    to the domain faces and give the two streams unequal lengths; == oracle, bit for bit"""
-    monkeypatch.setenv("FLUIDX_STRIP3_ZMEET", "1")
+def test_x256_three_sweeps_at_odd_depths_bit_exact(depth):
+    """X = 256, three sweeps per launch (k_jacobi_strip3c / k_jacobi_strip3) on odd and tiny depths: chunks of unequal length, the
+    pipeline's fill and drain next to both domain faces; == oracle, bit for bit"""
     dims = (256, 256, depth)
     _, _, p = rand_state(*dims, 31)
     b = np.random.default_rng(32).uniform(-1, 1, (depth, 256, 256)).astype(f32)
@@ -189,9 +187,8 @@ def test_x256_meeting_streams_bit_exact(depth, monkeypatch):
 
 
 @pytest.mark.parametrize("overlap", [0, 2])
-def test_x256_meeting_streams_in_slabs(overlap, monkeypatch):
-    """the same kernel on the shrinking ranges of z-slabs (halo planes included, ranges that start and end inside the slab)"""
-    monkeypatch.setenv("FLUIDX_STRIP3_ZMEET", "1")
+def test_x256_three_sweeps_in_slabs(overlap):
+    """the same kernels on the shrinking ranges of z-slabs (halo planes included, ranges that start and end inside the slab)"""
     from test_gpu_slabs import run_single, run_slabs, gather
     dims = (256, 256, 400)
     ref = run_single(dims, 2, jacobi_iters=19, jacobi_fuse=1)

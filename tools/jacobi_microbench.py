@@ -35,7 +35,7 @@ def run_once(args):
     t = f.timing_read(True)
     cells = float(G) * G * Z
     us_per_sweep = t.jacobi_ms * 1e3 / t.jacobi_sweeps
-    out = {"grid": [G, G, Z], "iters": args.iters, "fuse": args.fuse, "cfg": os.environ.get("FLUIDX_JACOBI_CFG", ""),
+    out = {"grid": [G, G, Z], "iters": args.iters, "fuse": args.fuse,
            "us_per_sweep": us_per_sweep, "launches": int(t.jacobi_launches), "sweeps": int(t.jacobi_sweeps),
            "Gcell_updates_per_s": cells / us_per_sweep / 1e3, "algorithmic_GBps": 12.0 * cells / us_per_sweep / 1e3}
     print(json.dumps(out))
@@ -53,21 +53,17 @@ def main():
     args = ap.parse_args()
     if not args.sweep:
         return run_once(args)
-    cfgs = [c for c in args.configs.split(";") if c] or [
-        "1:", "2:12,1,16", "2:12,2,16", "2:16,2,16", "2:16,3,16", "2:16,2,32", "3:16,2,32", "3:16,3,32", "3:14,2,32",
-        "4:16,1,32", "4:16,2,32", "4:16,2,64"]
-    for c in cfgs:
-        T, cfg = c.split(":")
-        env = dict(os.environ, FLUIDX_JACOBI_CFG=cfg)
+    # one run per fused-sweep count (1 = one launch per sweep, 2 / 3 = the register-strip or block kernels, 0 = the default schedule)
+    for T in [c for c in args.configs.split(";") if c] or ["1", "2", "3", "0"]:
         r = subprocess.run([sys.executable, __file__, "--grid", str(args.grid), "--iters", str(args.iters), "--reps",
                             str(args.reps), "--fuse", T] + (["--depth", str(args.depth)] if args.depth else []),
-                           env=env, capture_output=True, text=True)
+                           capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if line:
             d = json.loads(line[-1])
-            print("T=%s cfg=%-10s %7.2f us/sweep  %7.1f Gupd/s  %7.0f GB/s" % (T, cfg, d["us_per_sweep"], d["Gcell_updates_per_s"], d["algorithmic_GBps"]), flush=True)
+            print("fuse=%s %7.2f us/sweep  %7.1f Gupd/s  %7.0f GB/s" % (T, d["us_per_sweep"], d["Gcell_updates_per_s"], d["algorithmic_GBps"]), flush=True)
         else:
-            print("T=%s cfg=%s FAILED: %s" % (T, cfg, r.stderr[-300:]), flush=True)
+            print("fuse=%s FAILED: %s" % (T, r.stderr[-300:]), flush=True)
 
 
 if __name__ == "__main__":

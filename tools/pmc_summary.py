@@ -25,7 +25,7 @@ from fluidx12_amd.build import kernel_source_hash   # noqa: E402  (stamps each k
 # Every kernel here streams whole 128-B lines (coalesced 4-B or 16-B per lane), i.e. 128-B fabric requests that the
 # counter tallies at 64 B: the doubling applies to all of them.  Evidence: k_divergence must read >= 201 MB (three
 # velocity planes) and reports 142 MB raw.
-WIDE = {"k_jacobi_v4": True, "k_jacobi_tb": True, "k_advect": True, "k_divergence": True, "k_project": True,
+WIDE = {"k_jacobi_v4": True, "k_advect": True, "k_divergence": True, "k_project": True,
         "k_jacobi_generic": True}
 
 
