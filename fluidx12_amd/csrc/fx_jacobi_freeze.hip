@@ -24,7 +24,8 @@
 // The number of sweeps the reference's loop would have executed (1 + the last level that left a cell relaxing, capped at N) is
 // kept in a device word per step (`stat`), for fx_timing / bench.py's byte count.
 //
-// Scope: 3-D single-domain contexts with X % 4 == 0.  Slab contexts, 2-D grids and other widths keep k_jacobi_generic.
+// Scope: 3-D single-domain contexts (rows of any length >= 4: X % 4 != 0 -- 150^3, the reference's GI preset -- takes the cell-wise
+// path of ldq / stq for a row's last, short quad).  Slab contexts and 2-D grids keep k_jacobi_generic.
 #include "fx_internal.h"
 #include <cstdlib>
 
@@ -62,6 +63,44 @@ __device__ __forceinline__ uint32_t relax_quad(float4 c, float L, float R, float
 	return m | (f0 ? 1u : 0u) | (f1 ? 2u : 0u) | (f2 ? 4u : 0u) | (f3 ? 8u : 0u);
 }
 
+// A quad = cells 4 q .. 4 q + 3 of a row.  AL: X % 4 == 0, rows of whole 16-byte-aligned quads (128, 256, ...).  Otherwise (150^3, the
+// reference's GI preset) a row's quads sit at any 4-byte alignment and its last quad has nv = X - 4 (X4 - 1) < 4 cells: loaded /
+// stored cell by cell (the vector form would touch the next row, or run off the field's end), its missing cells carry the wall
+// cell's value -- which makes the clamped right neighbour of the wall cell fall out of the quad arithmetic -- and count as frozen.
+typedef float fz_v4 __attribute__((ext_vector_type(4)));
+typedef fz_v4 __attribute__((aligned(4))) fz_v4u;
+
+__device__ __forceinline__ float4 wall_patch(float4 c, int nv)
+{
+	if (nv < 2) c.y = c.x;
+	if (nv < 3) c.z = c.y;
+	if (nv < 4) c.w = c.z;
+	return c;
+}
+
+template <bool AL>
+__device__ __forceinline__ float4 ldq(const float* __restrict__ base, size_t off, int nv)
+{
+	if (AL) return *reinterpret_cast<const float4*>(base + off);
+	if (nv == 4) { const fz_v4u t = *reinterpret_cast<const fz_v4u*>(base + off); return make_float4(t.x, t.y, t.z, t.w); }
+	float4 c;
+	c.x = base[off];
+	c.y = nv > 1 ? base[off + 1] : c.x;
+	c.z = nv > 2 ? base[off + 2] : c.y;
+	c.w = c.z;
+	return c;
+}
+
+template <bool AL>
+__device__ __forceinline__ void stq(float* __restrict__ base, size_t off, int nv, float4 v)
+{
+	if (AL) { *reinterpret_cast<float4*>(base + off) = v; return; }
+	if (nv == 4) { fz_v4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *reinterpret_cast<fz_v4u*>(base + off) = t; return; }
+	base[off] = v.x;
+	if (nv > 1) base[off + 1] = v.y;
+	if (nv > 2) base[off + 2] = v.z;
+}
+
 __device__ __forceinline__ void stat_raise(uint32_t* stat, uint32_t v)
 {
 	if (__hip_atomic_load(stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) atomicMax(stat, v);
@@ -97,12 +136,13 @@ constexpr int kShards = 8;
 // ---------------------------------------------------------------------------------------------------------------------------
 // level 1, every cell.  Block = (bx quads, by rows), one plane per blockIdx slice, as k_jacobi_v4 (x neighbours by DPP).
 // ---------------------------------------------------------------------------------------------------------------------------
+template <bool AL>
 __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
 	float* __restrict__ pA, float* __restrict__ pB, uint8_t* __restrict__ mA, uint8_t* __restrict__ mB,
 	uint32_t* __restrict__ tile_mark, uint32_t gen, uint4* __restrict__ list_out, uint32_t* __restrict__ cnt_out, int cap,
 	uint32_t* __restrict__ cnt_clear, int n_clear, int ntx, int nty, uint32_t* __restrict__ stat, uint32_t stat_val, int rows_per_block)
 {
-	const int X4 = g.X >> 2;
+	const int X4 = (g.X + 3) >> 2;
 	const int lane = threadIdx.x;
 	const int gx = (X4 + (int)blockDim.x - 1) / (int)blockDim.x, gy = (g.Y + rows_per_block - 1) / rows_per_block;
 	if (blockIdx.x == 0)                                                 // the next solve's counters (this one's were cleared by the previous solve)
@@ -127,12 +167,13 @@ __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float*
 		const int zf = max(z, 1) - 1, zb = min(z + 1, g.Zg - 1);
 		const size_t zrow = (size_t)z * plane;
 		const size_t c_off = zrow + (size_t)y * g.X + 4 * x4;
-		const float4 c = *reinterpret_cast<const float4*>(p_in + c_off);
-		const float4 U = *reinterpret_cast<const float4*>(p_in + zrow + (size_t)yu * g.X + 4 * x4);
-		const float4 D = *reinterpret_cast<const float4*>(p_in + zrow + (size_t)yd * g.X + 4 * x4);
-		const float4 F = *reinterpret_cast<const float4*>(p_in + (size_t)zf * plane + (size_t)y * g.X + 4 * x4);
-		const float4 Bk = *reinterpret_cast<const float4*>(p_in + (size_t)zb * plane + (size_t)y * g.X + 4 * x4);
-		const float4 bb = *reinterpret_cast<const float4*>(b + c_off);
+		const int nv = x4 == X4 - 1 ? g.X - 4 * (X4 - 1) : 4;
+		const float4 c = ldq<AL>(p_in, c_off, nv);
+		const float4 U = ldq<AL>(p_in, zrow + (size_t)yu * g.X + 4 * x4, nv);
+		const float4 D = ldq<AL>(p_in, zrow + (size_t)yd * g.X + 4 * x4, nv);
+		const float4 F = ldq<AL>(p_in, (size_t)zf * plane + (size_t)y * g.X + 4 * x4, nv);
+		const float4 Bk = ldq<AL>(p_in, (size_t)zb * plane + (size_t)y * g.X + 4 * x4, nv);
+		const float4 bb = ldq<AL>(b, c_off, nv);
 		// x neighbours: the adjacent quad sits in the adjacent lane (DPP wave_shr:1 / wave_shl:1); only a wave's first / last lane
 		// inside a row still loads them
 		float L = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c.w), 0x138, 0xf, 0xf, false));
@@ -140,10 +181,10 @@ __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float*
 		if (x4 == 0) L = c.x; else if (wl == 0 || lane == 0) L = p_in[c_off - 1];
 		if (x4 == X4 - 1) R = c.w; else if (wl == 63 || lane == (int)blockDim.x - 1) R = p_in[c_off + 4];
 		float4 o;
-		nib = relax_quad(c, L, R, U, D, F, Bk, bb, 0u, o);
-		*reinterpret_cast<float4*>(pA + c_off) = o;
-		*reinterpret_cast<float4*>(pB + c_off) = o;
-		qi = c_off >> 2;
+		nib = relax_quad(c, L, R, U, D, F, Bk, bb, (0xFu << nv) & 0xFu, o);     // (cells a short last quad does not have: frozen)
+		stq<AL>(pA, c_off, nv, o);
+		stq<AL>(pB, c_off, nv, o);
+		qi = ((size_t)z * g.Y + y) * X4 + x4;
 		tile = ((z >> 3) * nty + (y >> 3)) * ntx + (x4 >> 3);
 	}
 	// the mask bytes of four adjacent quads leave as one dword where the row allows it (X4 % 4 == 0: every aligned lane quartet
@@ -174,7 +215,7 @@ __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float*
 // ---------------------------------------------------------------------------------------------------------------------------
 // T more levels on the listed tiles
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int T, int NT>
+template <int T, int NT, bool AL>
 __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(const Geom g, const float* __restrict__ p_src, const float* __restrict__ b,
 	float* __restrict__ p_dst, const uint8_t* __restrict__ m_src, uint8_t* __restrict__ m_dst,
 	const uint4* __restrict__ list_in, const uint32_t* __restrict__ cnt_in, uint4* __restrict__ list_out, uint32_t* __restrict__ cnt_out, int cap,
@@ -189,8 +230,10 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(
 	__shared__ uint8_t Mq[NQ];
 	__shared__ uint32_t wave_bits[NW];
 	const int tid = threadIdx.x;
-	const int X4 = g.X >> 2;
-	const size_t plane4 = (size_t)X4 * g.Y;      // quads per plane
+	const int X4 = (g.X + 3) >> 2, nv_last = g.X - 4 * (X4 - 1);   // quads per row; cells of a row's last quad
+	const size_t plane4 = (size_t)X4 * g.Y;      // quads per plane (mask bytes)
+	const size_t plane = g.plane();
+	auto foff = [&](int x4, int y, int z) -> size_t { return (size_t)z * plane + (size_t)y * g.X + 4 * (size_t)x4; };   // a quad's first cell
 	const int shard = (int)(blockIdx.x & (kShards - 1)), wg = (int)(blockIdx.x >> 3), nwg = (int)(gridDim.x >> 3);
 	// (the first entry is loaded together with the count it is checked against.  Leaving the tiles at fixed list positions -- no
 	// counters per launch, no returning atomic at a tile's end -- measured 4-10 % SLOWER than appending the survivors to a fresh
@@ -216,7 +259,8 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(
 				const int x4 = tx * 8 + q, y = ty * TCY + yy, z = tz * TCZ + zz;
 				if (x4 < X4 && y < g.Y && z < g.Zg && q >= dq0 && q <= dq1 && yy >= dy0 && yy <= dy1 && zz >= dz0 && zz <= dz1) {
 					const size_t qi = (size_t)z * plane4 + (size_t)y * X4 + x4;
-					reinterpret_cast<float4*>(p_dst)[qi] = reinterpret_cast<const float4*>(p_src)[qi];
+					const int nv = x4 == X4 - 1 ? nv_last : 4;
+					stq<AL>(p_dst, foff(x4, y, z), nv, ldq<AL>(p_src, foff(x4, y, z), nv));
 					m_dst[qi] = m_src[qi];
 				}
 			}
@@ -252,10 +296,11 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(
 					const int i = min(tl + NT * j, total_s - 1);
 					const int r = div_magic(i, mq), q = rq0 + i - r * nqs, zr = div_magic(r, my), yy = ry0 + r - zr * nys, zz = rz0 + zr;
 					const int x4 = x40 + q, y = y0 + yy, z = z0 + zz;
-					const size_t qi = (size_t)min(max(z, 0), g.Zg - 1) * plane4 + (size_t)min(max(y, 0), g.Y - 1) * X4 + min(max(x4, 0), X4 - 1);
-					sv[j] = reinterpret_cast<const float4*>(p_src)[qi];
-					sb[j] = reinterpret_cast<const float4*>(b)[qi];
-					sm[j] = m_src[qi];
+					const int xc = min(max(x4, 0), X4 - 1), yc = min(max(y, 0), g.Y - 1), zc = min(max(z, 0), g.Zg - 1);
+					const int nv = xc == X4 - 1 ? nv_last : 4;
+					sv[j] = ldq<AL>(p_src, foff(xc, yc, zc), nv);
+					sb[j] = ldq<AL>(b, foff(xc, yc, zc), nv);
+					sm[j] = m_src[(size_t)zc * plane4 + (size_t)yc * X4 + xc];
 					if (tl + NT * j < total_s) {
 						// LDS index | "outside the grid" | "no b row here"
 						const bool in = x4 >= 0 && x4 < X4 && y >= 0 && y < g.Y && z >= 0 && z < g.Zg;
@@ -306,7 +351,8 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(
 						const uint32_t m = Mq[idx];
 						if (m != 0xFu) {
 							const int x4 = x40 + q, y = y0 + yy, z = z0 + zz;
-							const float4 c = Pq[1 + idx];
+							float4 c = Pq[1 + idx];
+							if (!AL && x4 == X4 - 1) c = wall_patch(c, nv_last);   // the missing cells of a short last quad follow the wall cell
 							const float4 U = Pq[1 + (y == 0 ? idx : idx - TQ)];
 							const float4 D = Pq[1 + (y == g.Y - 1 ? idx : idx + TQ)];
 							const float4 F = Pq[1 + (z == 0 ? idx : idx - E * TQ)];
@@ -349,7 +395,7 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(
 			if (x4 < X4 && y < g.Y && z < g.Zg && q - 1 >= dq0 && q - 1 <= dq1 && yy - T >= dy0 && yy - T <= dy1 && zz - T >= dz0 && zz - T <= dz1) {
 				const int idx = (zz * E + yy) * TQ + q;
 				const size_t qi = (size_t)z * plane4 + (size_t)y * X4 + x4;
-				reinterpret_cast<float4*>(p_dst)[qi] = Pq[1 + idx];
+				stq<AL>(p_dst, foff(x4, y, z), x4 == X4 - 1 ? nv_last : 4, Pq[1 + idx]);
 				m_dst[qi] = Mq[idx];
 			}
 		}
@@ -377,7 +423,7 @@ int env_int(const char* name, int dflt)
 
 bool jacobi_freeze_supported(const Geom& g)
 {
-	return env_int("FLUIDX_FREEZE_FAST", 1) != 0 && g.Zg > 1 && g.H == 0 && g.z0 == 0 && g.nz == g.Zg && (g.X & 3) == 0 && g.X >= 4;
+	return env_int("FLUIDX_FREEZE_FAST", 1) != 0 && g.Zg > 1 && g.H == 0 && g.z0 == 0 && g.nz == g.Zg && g.X >= 4;
 }
 
 int jacobi_freeze_tiles(const Geom& g)
@@ -385,7 +431,7 @@ int jacobi_freeze_tiles(const Geom& g)
 	return ((g.X + TCX - 1) / TCX) * ((g.Y + TCY - 1) / TCY) * ((g.Zg + TCZ - 1) / TCZ);
 }
 
-size_t jacobi_freeze_mask_bytes(const Geom& g) { return g.cells_local() / 4; }
+size_t jacobi_freeze_mask_bytes(const Geom& g) { return (size_t)((g.X + 3) / 4) * g.Y * (size_t)g.nzl(); }
 size_t jacobi_freeze_list_bytes(const Geom& g) { return (size_t)kShards * (size_t)jacobi_freeze_tiles(g) * sizeof(uint4); }
 size_t jacobi_freeze_count_words() { return (size_t)kFreezeSlots * kShards; }
 
@@ -398,12 +444,14 @@ int jacobi_freeze_levels_per_launch()
 hipError_t launch_freeze_dense(const Geom& g, const float* p_in, const float* b, float* pA, float* pB, uint8_t* mA, uint8_t* mB,
 	const FreezeWork& w, uint32_t* stat, uint32_t stat_hi, hipStream_t s)
 {
-	const int X4 = g.X >> 2;
+	const int X4 = (g.X + 3) >> 2;
 	const int bx = X4 < 64 ? X4 : 64;
 	int by = 256 / bx; if (by < 1) by = 1; if (by > g.Y) by = g.Y;
 	const int ntx = (g.X + TCX - 1) / TCX, nty = (g.Y + TCY - 1) / TCY;
 	const dim3 block(bx, by, 1), grid(((X4 + bx - 1) / bx) * ((g.Y + by - 1) / by) * g.Zg, 1, 1);
-	hipLaunchKernelGGL(k_freeze_dense, grid, block, 0, s, g, p_in, b, pA, pB, mA, mB, w.tile_mark, w.gen, (uint4*)w.list[0],
+	if ((g.X & 3) == 0) hipLaunchKernelGGL(k_freeze_dense<true>, grid, block, 0, s, g, p_in, b, pA, pB, mA, mB, w.tile_mark, w.gen, (uint4*)w.list[0],
+		w.counts, w.cap, w.counts_next, kFreezeSlots * kShards, ntx, nty, stat, stat_hi | 1u, by);
+	else hipLaunchKernelGGL(k_freeze_dense<false>, grid, block, 0, s, g, p_in, b, pA, pB, mA, mB, w.tile_mark, w.gen, (uint4*)w.list[0],
 		w.counts, w.cap, w.counts_next, kFreezeSlots * kShards, ntx, nty, stat, stat_hi | 1u, by);
 	return hipGetLastError();
 }
@@ -417,15 +465,16 @@ hipError_t launch_freeze_tiles(const Geom& g, const float* p_src, const float* b
 	const int ntx = (g.X + TCX - 1) / TCX, nty = (g.Y + TCY - 1) / TCY, ntiles = jacobi_freeze_tiles(g);
 	const int want = (ntiles + kShards - 1) / kShards * kShards;
 	const int nt = env_int("FLUIDX_FREEZE_NT", 512);
-	const dim3 block(nt == 256 ? 256 : (nt == 1024 ? 1024 : 512), 1, 1), grid(want < max_wgs ? want : max_wgs, 1, 1);
+	const dim3 block((g.X & 3) != 0 ? 512 : (nt == 256 ? 256 : (nt == 1024 ? 1024 : 512)), 1, 1), grid(want < max_wgs ? want : max_wgs, 1, 1);
 	const uint4* lin = (const uint4*)w.list[n & 1];
 	uint4* lout = (uint4*)w.list[(n + 1) & 1];
 	const uint32_t* cin = w.counts + (size_t)n * kShards;
 	uint32_t* cout = w.counts + (size_t)(n + 1) * kShards;
 #define FX_FREEZE_ARGS grid, block, 0, s, g, p_src, b, p_dst, m_src, m_dst, lin, cin, lout, cout, w.cap, ntx, nty, level_base, stat, stat_hi
-#define FX_FREEZE_LAUNCH(T) if (nt == 256) hipLaunchKernelGGL((k_freeze_tiles<T, 256>), FX_FREEZE_ARGS); \
-	else if (nt == 1024) hipLaunchKernelGGL((k_freeze_tiles<T, 1024>), FX_FREEZE_ARGS); \
-	else hipLaunchKernelGGL((k_freeze_tiles<T, 512>), FX_FREEZE_ARGS)
+#define FX_FREEZE_LAUNCH(T) if ((g.X & 3) != 0) hipLaunchKernelGGL((k_freeze_tiles<T, 512, false>), FX_FREEZE_ARGS); \
+	else if (nt == 256) hipLaunchKernelGGL((k_freeze_tiles<T, 256, true>), FX_FREEZE_ARGS); \
+	else if (nt == 1024) hipLaunchKernelGGL((k_freeze_tiles<T, 1024, true>), FX_FREEZE_ARGS); \
+	else hipLaunchKernelGGL((k_freeze_tiles<T, 512, true>), FX_FREEZE_ARGS)
 	switch (levels) {
 	case 1: FX_FREEZE_LAUNCH(1); break;
 	case 2: FX_FREEZE_LAUNCH(2); break;

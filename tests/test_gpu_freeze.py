@@ -60,7 +60,8 @@ def solve(dims, p, b, iters):
     return out, t
 
 
-DIMS = [(32, 32, 32), (64, 64, 40), (40, 40, 12), (8, 8, 8), (36, 36, 9), (96, 96, 17), (4, 4, 3), (160, 160, 24)]
+DIMS = [(32, 32, 32), (64, 64, 40), (40, 40, 12), (8, 8, 8), (36, 36, 9), (96, 96, 17), (4, 4, 3), (160, 160, 24),
+        (150, 150, 20), (30, 30, 12), (37, 37, 9), (6, 6, 5), (67, 67, 11), (5, 5, 8)]        # rows that are no multiple of four cells: a short last quad
 
 
 @pytest.mark.parametrize("dims", DIMS)
@@ -86,9 +87,10 @@ def test_freeze_solver_every_launch_shape(T, NT, WGS, knobs):
         assert t.freeze_sweeps == k
 
 
-@pytest.mark.parametrize("dims", [(128, 128, 128), (256, 256, 64)])
+@pytest.mark.parametrize("dims", [(128, 128, 128), (256, 256, 64), (150, 150, 150)])
 def test_freeze_solver_at_reference_sizes(dims):
-    """the reference's default grid (FluidX12.cpp:44) and a 256-wide slab of the headline grid, 64-sweep cap"""
+    """the reference's default grid (FluidX12.cpp:44), a 256-wide slab of the headline grid and its GI preset (Bin/FluidGI.bat:1: rows of
+    150 cells), 64-sweep cap"""
     X, Y, Z = dims
     p, b = plume_like(X, Y, Z, 5, amp=0.08)
     want, k = orc.jacobi(p, b, 64, mode=1)
@@ -110,11 +112,10 @@ def test_freeze_solver_all_frozen_and_never_frozen():
     assert k == 9 and t.freeze_sweeps == 9 and np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("storage,address", [("fp16", "clamp"), ("fp32", "mirror")])
-def test_freeze_fast_path_equals_generic_kernel_over_steps(storage, address, knobs):
+@pytest.mark.parametrize("storage,address,dims", [("fp16", "clamp", (64, 64, 64)), ("fp32", "mirror", (64, 64, 64)), ("fp16", "clamp", (50, 50, 50))])
+def test_freeze_fast_path_equals_generic_kernel_over_steps(storage, address, dims, knobs):
     """whole steps in the reference's configuration (64-cap, early-out, RGBA16F / fp32): the sparse solver against the one-sweep
     kernel with the byte mask -- every field bit-identical after 12 steps, pressure buffer rotation included"""
-    dims = (64, 64, 64)
     kw = dict(storage=storage, jacobi_iters=64, jacobi_mode="faithful", advect_address=address)
     fast = make(dims, **kw)
     knobs["FLUIDX_FREEZE_FAST"] = "0"
