@@ -139,8 +139,7 @@ constexpr int kShards = 8;
 template <bool AL>
 __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
 	float* __restrict__ pA, float* __restrict__ pB, uint8_t* __restrict__ mA, uint8_t* __restrict__ mB,
-	uint32_t* __restrict__ tile_mark, uint32_t gen, uint4* __restrict__ list_out, uint32_t* __restrict__ cnt_out, int cap,
-	uint32_t* __restrict__ cnt_clear, int n_clear, int ntx, int nty, uint32_t* __restrict__ stat, uint32_t stat_val, int rows_per_block)
+	uint32_t* __restrict__ tile_mark, uint32_t gen, uint32_t* __restrict__ cnt_clear, int n_clear, int ntx, int nty, uint32_t* __restrict__ stat, uint32_t stat_val, int rows_per_block)
 {
 	const int X4 = (g.X + 3) >> 2;
 	const int lane = threadIdx.x;
@@ -198,17 +197,13 @@ __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float*
 			*reinterpret_cast<uint32_t*>(mB + qi) = packed;
 		}
 	} else if (in) { mA[qi] = (uint8_t)nib; mB[qi] = (uint8_t)nib; }
-	// a tile with a relaxing cell enters the list of launch 2, once: the first lane run that sees it takes the mark
+	// a tile with a relaxing cell is flagged for the first tile launch: one plain store per run of lanes that share a tile (every
+	// writer stores the same tag; no atomics, no list here -- with them the sweep took 72 us on a young plume and 95 us on a developed
+	// one, the difference being the marking)
 	const bool active = nib != 0xFu;
 	const int mine = active ? tile : -1;
 	const int prev = __shfl_up(mine, 1);
-	if (active && (wl == 0 || prev != mine)) {
-		if (__hip_atomic_load(tile_mark + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen && atomicExch(tile_mark + tile, gen) != gen) {
-			const int shard = (int)(blockIdx.x & (kShards - 1));
-			const uint32_t pos = atomicAdd(cnt_out + shard, 1u);
-			list_out[(size_t)shard * cap + pos] = make_uint4((uint32_t)tile, kFullBox, kFullBox, 0u);
-		}
-	}
+	if (active && (wl == 0 || prev != mine) && tile_mark[tile] != gen) tile_mark[tile] = gen;   // (the cached read keeps most of the ~64 stores per tile away from its one line)
 	if (__ballot(active) != 0ull && wl == 0) stat_raise(stat, stat_val);
 }
 
@@ -219,7 +214,7 @@ template <int T, int NT, bool AL>
 __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(const Geom g, const float* __restrict__ p_src, const float* __restrict__ b,
 	float* __restrict__ p_dst, const uint8_t* __restrict__ m_src, uint8_t* __restrict__ m_dst,
 	const uint4* __restrict__ list_in, const uint32_t* __restrict__ cnt_in, uint4* __restrict__ list_out, uint32_t* __restrict__ cnt_out, int cap,
-	int ntx, int nty, int level_base, uint32_t* __restrict__ stat, uint32_t stat_hi)
+	int ntx, int nty, int level_base, uint32_t* __restrict__ stat, uint32_t stat_hi, const uint32_t* __restrict__ tile_flag, uint32_t flag_gen, int ntiles)
 {
 	constexpr int E = 8 + 2 * T;                 // staged rows per plane = staged planes
 	constexpr int NQ = E * E * TQ;               // staged quads
@@ -235,15 +230,23 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(
 	const size_t plane = g.plane();
 	auto foff = [&](int x4, int y, int z) -> size_t { return (size_t)z * plane + (size_t)y * g.X + 4 * (size_t)x4; };   // a quad's first cell
 	const int shard = (int)(blockIdx.x & (kShards - 1)), wg = (int)(blockIdx.x >> 3), nwg = (int)(gridDim.x >> 3);
-	// (the first entry is loaded together with the count it is checked against.  Leaving the tiles at fixed list positions -- no
-	// counters per launch, no returning atomic at a tile's end -- measured 4-10 % SLOWER than appending the survivors to a fresh
-	// list: 256^3 0.847 against 0.815 ms per step, 128^3 0.311 against 0.283, same box.)
+	// The solve's FIRST tile launch (tile_flag != null) has no list yet: every workgroup looks at its share of the tile flags the dense
+	// sweep set (tiles w, w + grid, ...: neighbours in the grid go to different workgroups) and takes the flagged ones whole.  Later
+	// launches walk the list their predecessor appended to, one of eight per-XCD sub-lists per workgroup; the first entry is loaded
+	// together with the count it is checked against.  (Leaving the tiles at fixed list positions -- no counters per launch, no
+	// returning atomic at a tile's end -- measured 4-10 % SLOWER than appending the survivors to a fresh list: 256^3 0.847 against
+	// 0.815 ms per step, 128^3 0.311 against 0.283, same box.)
 	const uint4* my_list = list_in + (size_t)shard * cap;
-	uint4 entry = wg < cap ? my_list[wg] : make_uint4(0u, 0u, 0u, 0u);
-	const uint32_t n_in = cnt_in[shard];
+	uint4 entry = make_uint4(0u, 0u, 0u, 0u);
+	uint32_t first, limit, stride;
+	if (tile_flag) { first = blockIdx.x; limit = (uint32_t)ntiles; stride = gridDim.x; }
+	else { if (wg < cap) entry = my_list[wg]; first = (uint32_t)wg; limit = cnt_in[shard]; stride = (uint32_t)nwg; }
 
-	for (uint32_t e = (uint32_t)wg; e < n_in; e += (uint32_t)nwg) {
-		if (e != (uint32_t)wg) entry = my_list[e];
+	for (uint32_t e = first; e < limit; e += stride) {
+		if (tile_flag) {
+			if (tile_flag[e] != flag_gen) continue;
+			entry = make_uint4(e, kFullBox, kFullBox, 0u);
+		} else if (e != first) entry = my_list[e];
 		const int t = (int)(entry.x & ~kCopyOnly);
 		const int tx = t % ntx, ty = (t / ntx) % nty, tz = t / (ntx * nty);
 		// core quads / rows / planes the previous launch may have changed (core indices 0..7)
@@ -449,10 +452,10 @@ hipError_t launch_freeze_dense(const Geom& g, const float* p_in, const float* b,
 	int by = 256 / bx; if (by < 1) by = 1; if (by > g.Y) by = g.Y;
 	const int ntx = (g.X + TCX - 1) / TCX, nty = (g.Y + TCY - 1) / TCY;
 	const dim3 block(bx, by, 1), grid(((X4 + bx - 1) / bx) * ((g.Y + by - 1) / by) * g.Zg, 1, 1);
-	if ((g.X & 3) == 0) hipLaunchKernelGGL(k_freeze_dense<true>, grid, block, 0, s, g, p_in, b, pA, pB, mA, mB, w.tile_mark, w.gen, (uint4*)w.list[0],
-		w.counts, w.cap, w.counts_next, kFreezeSlots * kShards, ntx, nty, stat, stat_hi | 1u, by);
-	else hipLaunchKernelGGL(k_freeze_dense<false>, grid, block, 0, s, g, p_in, b, pA, pB, mA, mB, w.tile_mark, w.gen, (uint4*)w.list[0],
-		w.counts, w.cap, w.counts_next, kFreezeSlots * kShards, ntx, nty, stat, stat_hi | 1u, by);
+	if ((g.X & 3) == 0) hipLaunchKernelGGL(k_freeze_dense<true>, grid, block, 0, s, g, p_in, b, pA, pB, mA, mB, w.tile_mark, w.gen,
+		w.counts_next, kFreezeSlots * kShards, ntx, nty, stat, stat_hi | 1u, by);
+	else hipLaunchKernelGGL(k_freeze_dense<false>, grid, block, 0, s, g, p_in, b, pA, pB, mA, mB, w.tile_mark, w.gen,
+		w.counts_next, kFreezeSlots * kShards, ntx, nty, stat, stat_hi | 1u, by);
 	return hipGetLastError();
 }
 
@@ -470,7 +473,7 @@ hipError_t launch_freeze_tiles(const Geom& g, const float* p_src, const float* b
 	uint4* lout = (uint4*)w.list[(n + 1) & 1];
 	const uint32_t* cin = w.counts + (size_t)n * kShards;
 	uint32_t* cout = w.counts + (size_t)(n + 1) * kShards;
-#define FX_FREEZE_ARGS grid, block, 0, s, g, p_src, b, p_dst, m_src, m_dst, lin, cin, lout, cout, w.cap, ntx, nty, level_base, stat, stat_hi
+#define FX_FREEZE_ARGS grid, block, 0, s, g, p_src, b, p_dst, m_src, m_dst, lin, cin, lout, cout, w.cap, ntx, nty, level_base, stat, stat_hi, n == 0 ? w.tile_mark : nullptr, w.gen, ntiles
 #define FX_FREEZE_LAUNCH(T) if ((g.X & 3) != 0) hipLaunchKernelGGL((k_freeze_tiles<T, 512, false>), FX_FREEZE_ARGS); \
 	else if (nt == 256) hipLaunchKernelGGL((k_freeze_tiles<T, 256, true>), FX_FREEZE_ARGS); \
 	else if (nt == 1024) hipLaunchKernelGGL((k_freeze_tiles<T, 1024, true>), FX_FREEZE_ARGS); \
