@@ -6,6 +6,8 @@ def chk(rc, what):
     if rc != 0: raise SystemExit("%s failed: %d" % (what, rc))
 N = 1 << 20
 if len(sys.argv) == 1:
+    if os.environ.get("PROBE_PTRACER") == "1":
+        libc = C.CDLL("libc.so.6"); print("prctl rc", libc.prctl(0x59616d61, C.c_ulong(-1 & 0xFFFFFFFFFFFFFFFF), 0, 0, 0))   # PR_SET_PTRACER, PR_SET_PTRACER_ANY
     p = C.c_void_p(); chk(hip.hipMalloc(C.byref(p), N), "hipMalloc")
     host = (C.c_ubyte * N)(*([7] * N)); chk(hip.hipMemcpy(p, host, N, 1), "h2d")
     h = (C.c_ubyte * 64)(); chk(hip.hipIpcGetMemHandle(C.byref(h), p), "hipIpcGetMemHandle")
