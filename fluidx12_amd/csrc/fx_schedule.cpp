@@ -301,7 +301,7 @@ static int jacobi_freeze(fx_ctx* ctx, hipStream_t s, uint32_t iters)
 	// (The dense sweep writes level 1 to BOTH buffers the tile launches alternate between.  Writing one and letting the first tile
 	// launch carry the unlisted tiles' border cells across was built and measured level: the dense sweep 75 -> 46 us at 256^3, the
 	// first tile launch slower by as much -- the shell of a 4-deep cone around ~3000 listed tiles is more bytes than the second copy.)
-	FX_HIP(launch_freeze_dense(ctx->g, src, ctx->b, a, d, ma, md, w, stat, stat_hi, s));
+	FX_HIP(launch_freeze_dense(ctx->g, src, ctx->b, a, d, ma, md, w, s));
 	mk.launches = 1; mk.sweeps = 1;
 	if (iters > 1) mk.split(MK_JACOBI_TAIL);                            // fx_timing books the dense sweep as the "main" launch, the tile launches beside it
 	const int T = jacobi_freeze_levels_per_launch();

@@ -51,6 +51,32 @@ def run(grid, warm, steps, storage, env):
             else: os.environ[k] = v
 
 
+def all_active(grid, levels, env):
+    """every tile listed, no cell ever freezing: what one tile launch of `levels` levels costs per tile"""
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        f = fx.Fluid()
+        assert f.Init(0, 0, (grid, grid, grid), storage="fp32", jacobi_iters=1 + levels, jacobi_mode="faithful")
+        rng = np.random.default_rng(1)
+        p = (rng.standard_normal((grid, grid, grid)) * 50).astype(np.float32)
+        f.upload(fx.FIELD_DIVERGENCE, p)
+        out = []
+        for rep in range(6):
+            f.upload(fx.FIELD_PRESSURE, p)
+            f.timing_enable(True); f.timing_read(True)
+            f.Jacobi(1 + levels)
+            f.Synchronize()
+            t = f.timing_read(True)
+            out.append((round(t.jacobi_main_ms * 1e3, 2), round((t.jacobi_ms - t.jacobi_main_ms) * 1e3, 2), t.freeze_sweeps))
+        f.Release()
+        return dict(env=env, grid=grid, levels=levels, dense_us_tiles_us_sweeps=out[2:])
+    finally:
+        for k, v in saved.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--grid", type=int, default=256)
@@ -58,7 +84,13 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--storage", default="fp16")
     ap.add_argument("--variants", action="store_true")
+    ap.add_argument("--all-active", action="store_true", help="one tile launch over EVERY tile (nothing freezes): the per-tile cost")
     a = ap.parse_args()
+    if a.all_active:
+        for t in (4, 2, 1):
+            for nt in (512, 256, 1024):
+                print(json.dumps(all_active(a.grid, t, {"FLUIDX_FREEZE_T": t, "FLUIDX_FREEZE_NT": nt})), flush=True)
+        sys.exit(0)
     cases = [{"FLUIDX_FREEZE_FAST": 1}, {"FLUIDX_FREEZE_FAST": 0}]
     if a.variants:
         cases += [{"FLUIDX_FREEZE_T": t, "FLUIDX_FREEZE_NT": nt, "FLUIDX_FREEZE_WGS": w} for t in (2, 3, 4) for nt in (512, 1024) for w in (512, 1024, 2048)]
