@@ -215,7 +215,7 @@ template <int T, int NT, bool AL>
 __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(const Geom g, const float* __restrict__ p_src, const float* __restrict__ b,
 	float* __restrict__ p_dst, const uint8_t* __restrict__ m_src, uint8_t* __restrict__ m_dst,
 	const uint4* __restrict__ list_in, const uint32_t* __restrict__ cnt_in, uint4* __restrict__ list_out, uint32_t* __restrict__ cnt_out, int cap,
-	int ntx, int nty, int level_base, uint32_t* __restrict__ stat, uint32_t stat_hi, const uint32_t* __restrict__ tile_flag, uint32_t flag_gen, int ntiles)
+	int ntx, int nty, int level_base, uint32_t* __restrict__ stat, uint32_t stat_hi, const uint32_t* __restrict__ tile_flag, uint32_t flag_gen, int ntiles, int scan_limit)
 {
 	constexpr int E = 8 + 2 * T;                 // staged rows per plane = staged planes
 	constexpr int NQ = E * E * TQ;               // staged quads
@@ -240,13 +240,19 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(
 	const uint4* my_list = list_in + (size_t)shard * cap;
 	uint4 entry = make_uint4(0u, 0u, 0u, 0u);
 	uint32_t first, limit, stride, raised = 0u;
-	if (tile_flag) { first = blockIdx.x; limit = (uint32_t)ntiles; stride = gridDim.x; }
+	if (tile_flag) { first = blockIdx.x; limit = (uint32_t)(scan_limit ? scan_limit : ntiles); stride = gridDim.x; }
 	else { if (wg < cap) entry = my_list[wg]; first = (uint32_t)wg; limit = cnt_in[shard]; stride = (uint32_t)nwg; }
 
 	for (uint32_t e = first; e < limit; e += stride) {
 		if (tile_flag) {
-			if (tile_flag[e] != flag_gen) continue;
-			entry = make_uint4(e, kFullBox, kFullBox, 0u);
+			uint32_t t = e;
+			if (scan_limit) {                                              // XCD k (= e & 7) takes the tile planes k, k + 8, ...: x and y neighbours share its L2
+				const uint32_t per_plane = (uint32_t)(ntx * nty), j = e >> 3, pl = j / per_plane;
+				t = (pl * 8u + (e & 7u)) * per_plane + (j - pl * per_plane);
+				if (t >= (uint32_t)ntiles) continue;
+			}
+			if (tile_flag[t] != flag_gen) continue;
+			entry = make_uint4(t, kFullBox, kFullBox, 0u);
 		} else if (e != first) entry = my_list[e];
 		const int t = (int)(entry.x & ~kCopyOnly);
 		const int tx = t % ntx, ty = (t / ntx) % nty, tz = t / (ntx * nty);
@@ -474,11 +480,13 @@ hipError_t launch_freeze_tiles(const Geom& g, const float* p_src, const float* b
 	const int want = (ntiles + kShards - 1) / kShards * kShards;
 	const int nt = env_int("FLUIDX_FREEZE_NT", 512);
 	const dim3 block((g.X & 3) != 0 ? 512 : (nt == 256 ? 256 : (nt == 1024 ? 1024 : 512)), 1, 1), grid(want < max_wgs ? want : max_wgs, 1, 1);
+	const int ntz = (g.Zg + TCZ - 1) / TCZ;
+	const int scan_limit = env_int("FLUIDX_FREEZE_SCAN", 1) ? (ntz + 7) / 8 * 8 * ntx * nty : 0;
 	const uint4* lin = (const uint4*)w.list[n & 1];
 	uint4* lout = (uint4*)w.list[(n + 1) & 1];
 	const uint32_t* cin = w.counts + (size_t)n * kShards;
 	uint32_t* cout = w.counts + (size_t)(n + 1) * kShards;
-#define FX_FREEZE_ARGS grid, block, 0, s, g, p_src, b, p_dst, m_src, m_dst, lin, cin, lout, cout, w.cap, ntx, nty, level_base, stat, stat_hi, n == 0 ? w.tile_mark : nullptr, w.gen, ntiles
+#define FX_FREEZE_ARGS grid, block, 0, s, g, p_src, b, p_dst, m_src, m_dst, lin, cin, lout, cout, w.cap, ntx, nty, level_base, stat, stat_hi, n == 0 ? w.tile_mark : nullptr, w.gen, ntiles, scan_limit
 #define FX_FREEZE_LAUNCH(T) if ((g.X & 3) != 0) hipLaunchKernelGGL((k_freeze_tiles<T, 512, false>), FX_FREEZE_ARGS); \
 	else if (nt == 256) hipLaunchKernelGGL((k_freeze_tiles<T, 256, true>), FX_FREEZE_ARGS); \
 	else if (nt == 1024) hipLaunchKernelGGL((k_freeze_tiles<T, 1024, true>), FX_FREEZE_ARGS); \
