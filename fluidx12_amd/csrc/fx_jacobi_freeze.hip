@@ -33,6 +33,17 @@ namespace fx {
 
 namespace {
 
+// -DFX_FREEZE_PROF (tools/micro/freeze_prof.py): thread 0 of every workgroup adds the shader clocks it spent in each phase of a tile pass
+#ifdef FX_FREEZE_PROF
+__device__ unsigned long long fz_prof[16];
+#define PROF(i) do { if (tid == 0) { const unsigned long long now = __builtin_readcyclecounter(); atomicAdd(&fz_prof[i], now - tprev); tprev = now; } } while (0)
+#define PROF_INIT unsigned long long tprev = __builtin_readcyclecounter()
+#define PROF_COUNT do { if (tid == 0) atomicAdd(&fz_prof[15], 1ull); } while (0)
+#else
+#define PROF(i) do { } while (0)
+#define PROF_INIT do { } while (0)
+#define PROF_COUNT do { } while (0)
+#endif
 constexpr int TCX = 32, TCY = 8, TCZ = 8;     // tile core (cells)
 constexpr int TQ = 10;                        // quads (4 x-cells) per staged row: the core's 8 + one halo quad per side
 constexpr float kFreezeBelow = 0.00100000005f;   // CSPoisson.hlsli:24 as compiled (0x3a83126f)
@@ -78,10 +89,14 @@ __device__ __forceinline__ float4 wall_patch(float4 c, int nv)
 	return c;
 }
 
+// (cell offsets are 32-bit: uniform base + 32-bit byte offset is the `global_load v, v_offset, s[base]` form, and the 64-bit multiply-adds
+// of a size_t offset run at quarter rate -- jacobi_freeze_supported() keeps the fields below 4 GiB)
 template <bool AL>
-__device__ __forceinline__ float4 ldq(const float* __restrict__ base, size_t off, int nv)
+__device__ __forceinline__ float4 ldq(const float* __restrict__ base_, uint32_t off, int nv)
 {
-	if (AL) return *reinterpret_cast<const float4*>(base + off);
+	const float* __restrict__ base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(base_) + ((size_t)off << 2));
+	off = 0u;
+	if (AL) return *reinterpret_cast<const float4*>(base);
 	if (nv == 4) { const fz_v4u t = *reinterpret_cast<const fz_v4u*>(base + off); return make_float4(t.x, t.y, t.z, t.w); }
 	float4 c;
 	c.x = base[off];
@@ -92,18 +107,15 @@ __device__ __forceinline__ float4 ldq(const float* __restrict__ base, size_t off
 }
 
 template <bool AL>
-__device__ __forceinline__ void stq(float* __restrict__ base, size_t off, int nv, float4 v)
+__device__ __forceinline__ void stq(float* __restrict__ base_, uint32_t off, int nv, float4 v)
 {
-	if (AL) { *reinterpret_cast<float4*>(base + off) = v; return; }
+	float* __restrict__ base = reinterpret_cast<float*>(reinterpret_cast<char*>(base_) + ((size_t)off << 2));
+	off = 0u;
+	if (AL) { *reinterpret_cast<float4*>(base) = v; return; }
 	if (nv == 4) { fz_v4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *reinterpret_cast<fz_v4u*>(base + off) = t; return; }
 	base[off] = v.x;
 	if (nv > 1) base[off + 1] = v.y;
 	if (nv > 2) base[off + 2] = v.z;
-}
-
-__device__ __forceinline__ void stat_raise(uint32_t* stat, uint32_t v)
-{
-	if (__hip_atomic_load(stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) atomicMax(stat, v);
 }
 
 // OR over the wave (every lane active), returned in every lane: four row rotations, then the four rows through SGPRs
@@ -127,7 +139,7 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
 // plane) decomposition over a box whose extents are only known at run time
 __constant__ uint32_t kMagic[17] = { 0u, 1048576u, 524288u, 349526u, 262144u, 209716u, 174763u, 149797u, 131072u, 116509u, 104858u, 95326u,
 	87382u, 80660u, 74899u, 69906u, 65536u };
-__device__ __forceinline__ int div_magic(int i, uint32_t m) { return (int)(((uint32_t)i * m) >> 20); }
+__device__ __forceinline__ int div_magic(int i, uint32_t m) { return (int)(__umul24((uint32_t)i, m) >> 20); }   // (i < 2^12, m <= 2^20: the 24-bit multiply is exact and full rate)
 
 constexpr uint32_t kCopyOnly = 0x80000000u;
 constexpr uint32_t kFullBox = 0u | 7u << 3 | 0u << 6 | 7u << 9 | 0u << 12 | 7u << 15;
@@ -159,19 +171,19 @@ __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float*
 	const bool in = x4 < X4 && y < g.Y;
 	uint32_t nib = 0xFu;
 	int tile = -1;
-	size_t qi = 0;
+	uint32_t qi = 0;
 	if (in) {
-		const size_t plane = g.plane();
+		const uint32_t plane = (uint32_t)g.plane();
 		const int yu = max(y, 1) - 1, yd = min(y + 1, g.Y - 1);
 		const int zf = max(z, 1) - 1, zb = min(z + 1, g.Zg - 1);
-		const size_t zrow = (size_t)z * plane;
-		const size_t c_off = zrow + (size_t)y * g.X + 4 * x4;
+		const uint32_t zrow = (uint32_t)z * plane;
+		const uint32_t c_off = zrow + (uint32_t)y * g.X + 4 * x4;
 		const int nv = x4 == X4 - 1 ? g.X - 4 * (X4 - 1) : 4;
 		const float4 c = ldq<AL>(p_in, c_off, nv);
-		const float4 U = ldq<AL>(p_in, zrow + (size_t)yu * g.X + 4 * x4, nv);
-		const float4 D = ldq<AL>(p_in, zrow + (size_t)yd * g.X + 4 * x4, nv);
-		const float4 F = ldq<AL>(p_in, (size_t)zf * plane + (size_t)y * g.X + 4 * x4, nv);
-		const float4 Bk = ldq<AL>(p_in, (size_t)zb * plane + (size_t)y * g.X + 4 * x4, nv);
+		const float4 U = ldq<AL>(p_in, zrow + (uint32_t)yu * g.X + 4 * x4, nv);
+		const float4 D = ldq<AL>(p_in, zrow + (uint32_t)yd * g.X + 4 * x4, nv);
+		const float4 F = ldq<AL>(p_in, (uint32_t)zf * plane + (uint32_t)y * g.X + 4 * x4, nv);
+		const float4 Bk = ldq<AL>(p_in, (uint32_t)zb * plane + (uint32_t)y * g.X + 4 * x4, nv);
 		const float4 bb = ldq<AL>(b, c_off, nv);
 		// x neighbours: the adjacent quad sits in the adjacent lane (DPP wave_shr:1 / wave_shl:1); only a wave's first / last lane
 		// inside a row still loads them
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float*
 		nib = relax_quad(c, L, R, U, D, F, Bk, bb, (0xFu << nv) & 0xFu, o);     // (cells a short last quad does not have: frozen)
 		stq<AL>(pA, c_off, nv, o);
 		stq<AL>(pB, c_off, nv, o);
-		qi = ((size_t)z * g.Y + y) * X4 + x4;
+		qi = ((uint32_t)z * g.Y + y) * X4 + x4;
 		tile = ((z >> 3) * nty + (y >> 3)) * ntx + (x4 >> 3);
 	}
 	// the mask bytes of four adjacent quads leave as one dword where the row allows it (X4 % 4 == 0: every aligned lane quartet
@@ -226,10 +238,13 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(
 	__shared__ uint8_t Mq[NQ];
 	__shared__ uint32_t wave_bits[NW];
 	const int tid = threadIdx.x;
+	PROF_INIT;
 	const int X4 = (g.X + 3) >> 2, nv_last = g.X - 4 * (X4 - 1);   // quads per row; cells of a row's last quad
-	const size_t plane4 = (size_t)X4 * g.Y;      // quads per plane (mask bytes)
-	const size_t plane = g.plane();
-	auto foff = [&](int x4, int y, int z) -> size_t { return (size_t)z * plane + (size_t)y * g.X + 4 * (size_t)x4; };   // a quad's first cell
+	const uint32_t plane4 = (uint32_t)(X4 * g.Y);   // quads per plane (mask bytes)
+	const uint32_t plane = (uint32_t)g.plane();
+	// a quad's first cell / its mask byte (24-bit multiplies: full rate; X * Y < 2^24 is part of jacobi_freeze_supported())
+	auto foff = [&](int x4, int y, int z) -> uint32_t { return __umul24((uint32_t)z, plane) + __umul24((uint32_t)y, (uint32_t)g.X) + 4u * (uint32_t)x4; };
+	auto moff = [&](int x4, int y, int z) -> uint32_t { return __umul24((uint32_t)z, plane4) + __umul24((uint32_t)y, (uint32_t)X4) + (uint32_t)x4; };
 	const int shard = (int)(blockIdx.x & (kShards - 1)), wg = (int)(blockIdx.x >> 3), nwg = (int)(gridDim.x >> 3);
 	// The solve's FIRST tile launch (tile_flag != null) has no list yet: every workgroup looks at its share of the tile flags the dense
 	// sweep set (tiles w, w + grid, ...: neighbours in the grid go to different workgroups) and takes the flagged ones whole.  Later
@@ -240,13 +255,13 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(
 	const uint4* my_list = list_in + (size_t)shard * cap;
 	uint4 entry = make_uint4(0u, 0u, 0u, 0u);
 	uint32_t first, limit, stride, raised = 0u;
-	if (tile_flag) { first = blockIdx.x; limit = (uint32_t)(scan_limit ? scan_limit : ntiles); stride = gridDim.x; }
+	if (tile_flag) { first = blockIdx.x; limit = (uint32_t)scan_limit; stride = gridDim.x; }
 	else { if (wg < cap) entry = my_list[wg]; first = (uint32_t)wg; limit = cnt_in[shard]; stride = (uint32_t)nwg; }
 
 	for (uint32_t e = first; e < limit; e += stride) {
 		if (tile_flag) {
 			uint32_t t = e;
-			if (scan_limit) {                                              // XCD k (= e & 7) takes the tile planes k, k + 8, ...: x and y neighbours share its L2
+			{                                                              // XCD k (= e & 7) takes the tile planes k, k + 8, ...: x and y neighbours share its L2
 				const uint32_t per_plane = (uint32_t)(ntx * nty), j = e >> 3, pl = j / per_plane;
 				t = (pl * 8u + (e & 7u)) * per_plane + (j - pl * per_plane);
 				if (t >= (uint32_t)ntiles) continue;
@@ -268,7 +283,7 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(
 				const int q = i & 7, yy = (i >> 3) & 7, zz = i >> 6;
 				const int x4 = tx * 8 + q, y = ty * TCY + yy, z = tz * TCZ + zz;
 				if (x4 < X4 && y < g.Y && z < g.Zg && q >= dq0 && q <= dq1 && yy >= dy0 && yy <= dy1 && zz >= dz0 && zz <= dz1) {
-					const size_t qi = (size_t)z * plane4 + (size_t)y * X4 + x4;
+					const uint32_t qi = moff(x4, y, z);
 					const int nv = x4 == X4 - 1 ? nv_last : 4;
 					stq<AL>(p_dst, foff(x4, y, z), nv, ldq<AL>(p_src, foff(x4, y, z), nv));
 					m_dst[qi] = m_src[qi];
@@ -276,6 +291,11 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(
 			}
 			continue;
 		}
+		PROF(0); PROF_COUNT;
+		// every tile that gets here appends exactly one entry (itself, or itself as copy-only): its slot is reserved now, so that the
+		// returning atomic's round trip passes behind the staging loads instead of at the tile's end (3.5 of a tile pass's 20 us)
+		uint32_t slot;
+		asm volatile("" : "=v"(slot));                                  // (no value: a `= 0` here would become a register copy at the join, i.e. a wait for the atomic on the spot)
 		const int x40 = tx * 8 - 1, y0 = ty * TCY - T, z0 = tz * TCZ - T;   // quad / row / plane of staged index 0
 		// the box of core cells that still relax (core indices) ...
 		const int aq0 = (int)(entry.y & 7u), aq1 = (int)((entry.y >> 3) & 7u), ay0 = (int)((entry.y >> 6) & 7u), ay1 = (int)((entry.y >> 9) & 7u);
@@ -288,7 +308,8 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(
 		int tl = tid;
 		asm volatile("" : "+v"(tl));                                     // (keeps the index arithmetic below inside the tile loop: hoisted, it spills)
 		// ---- stage the cone ---------------------------------------------------------------------------------------------------
-		__syncthreads();                                                 // the previous tile of this workgroup is done with the LDS
+		__syncthreads(); PROF(1);
+		if (tid == 0) slot = atomicAdd(cnt_out + shard, 1u);                                                 // the previous tile of this workgroup is done with the LDS
 		{
 			// every load is issued before the first LDS store; lanes beyond the box repeat its last quad.  Cells of the box outside
 			// the grid are marked frozen: no cell inside reads them (clamped taps).  What lies outside the box keeps whatever the LDS
@@ -301,28 +322,28 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(
 			int si[SJ];
 #pragma unroll
 			for (int j = 0; j < SJ; ++j) {
-				sv[j] = make_float4(0.f, 0.f, 0.f, 0.f); sb[j] = sv[j]; sm[j] = 0xFu; si[j] = -1;
-				if (NT * j < total_s) {                                    // uniform
-					const int i = min(tl + NT * j, total_s - 1);
-					const int r = div_magic(i, mq), q = rq0 + i - r * nqs, zr = div_magic(r, my), yy = ry0 + r - zr * nys, zz = rz0 + zr;
-					const int x4 = x40 + q, y = y0 + yy, z = z0 + zz;
-					const int xc = min(max(x4, 0), X4 - 1), yc = min(max(y, 0), g.Y - 1), zc = min(max(z, 0), g.Zg - 1);
-					const int nv = xc == X4 - 1 ? nv_last : 4;
-					sv[j] = ldq<AL>(p_src, foff(xc, yc, zc), nv);
-					sb[j] = ldq<AL>(b, foff(xc, yc, zc), nv);
-					sm[j] = m_src[(size_t)zc * plane4 + (size_t)yc * X4 + xc];
-					if (tl + NT * j < total_s) {
-						// LDS index | "outside the grid" | "no b row here"
-						const bool in = x4 >= 0 && x4 < X4 && y >= 0 && y < g.Y && z >= 0 && z < g.Zg;
-						const bool brow = yy >= 1 && yy < E - 1 && zz >= 1 && zz < E - 1;
-						si[j] = ((zz * E + yy) * TQ + q) | (in ? 0 : 0x20000000) | (brow ? 0 : 0x40000000);
-					}
-				}
+				// no branch around the loads: a join after them makes the compiler move the loaded registers, i.e. wait for each of the
+				// SJ rounds in turn (measured: 7.5 of a tile pass's 20 us).  Rounds beyond the box re-read its last quad (one cached line).
+				const int i = min(tl + NT * j, total_s - 1);
+				const int r = div_magic(i, mq), q = rq0 + i - r * nqs, zr = div_magic(r, my), yy = ry0 + r - zr * nys, zz = rz0 + zr;
+				const int x4 = x40 + q, y = y0 + yy, z = z0 + zz;
+				const int xc = min(max(x4, 0), X4 - 1), yc = min(max(y, 0), g.Y - 1), zc = min(max(z, 0), g.Zg - 1);
+				const int nv = xc == X4 - 1 ? nv_last : 4;
+				sv[j] = ldq<AL>(p_src, foff(xc, yc, zc), nv);
+				sb[j] = ldq<AL>(b, foff(xc, yc, zc), nv);
+				sm[j] = m_src[moff(xc, yc, zc)];
+				// LDS index | "outside the grid" | "no b row here"; -1 = this lane has no quad in this round
+				const bool in = x4 >= 0 && x4 < X4 && y >= 0 && y < g.Y && z >= 0 && z < g.Zg;
+				const bool brow = yy >= 1 && yy < E - 1 && zz >= 1 && zz < E - 1;
+				const int code = ((zz * E + yy) * TQ + q) | (in ? 0 : 0x20000000) | (brow ? 0 : 0x40000000);
+				si[j] = tl + NT * j < total_s ? code : -1;
 			}
+			PROF(10);
 			// (the compiler otherwise sinks each load into the guarded store below and waits for them one by one)
 #pragma unroll
 			for (int j = 0; j < SJ; ++j)
 				asm volatile("" : "+v"(sv[j].x), "+v"(sv[j].y), "+v"(sv[j].z), "+v"(sv[j].w), "+v"(sb[j].x), "+v"(sb[j].y), "+v"(sb[j].z), "+v"(sb[j].w), "+v"(sm[j]));
+			PROF(2);
 #pragma unroll
 			for (int j = 0; j < SJ; ++j) {
 				if (si[j] >= 0) {
@@ -336,7 +357,7 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(
 				}
 			}
 		}
-		__syncthreads();
+		__syncthreads(); PROF(3);
 		// ---- T levels in the LDS: level k on the box grown by T - k rows / planes (one quad, until the last level) -----------------
 		int last_active = 0;                                             // last level (1..T) that left a core cell relaxing
 		uint32_t core_bits = 0;                                          // quads | rows << 8 | planes << 16 of the core that still relax
@@ -393,6 +414,7 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(
 #pragma unroll
 			for (int w = 0; w < NW; ++w) core_bits |= wave_bits[w];
 			if (core_bits) last_active = k;
+			PROF(3 + k);
 			if (!core_bits) break;                                         // the core is frozen: deeper levels cannot change it
 		}
 		// ---- store the core ---------------------------------------------------------------------------------------------------
@@ -404,11 +426,12 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(
 			const int x4 = x40 + q, y = y0 + yy, z = z0 + zz;
 			if (x4 < X4 && y < g.Y && z < g.Zg && q - 1 >= dq0 && q - 1 <= dq1 && yy - T >= dy0 && yy - T <= dy1 && zz - T >= dz0 && zz - T <= dz1) {
 				const int idx = (zz * E + yy) * TQ + q;
-				const size_t qi = (size_t)z * plane4 + (size_t)y * X4 + x4;
+				const uint32_t qi = moff(x4, y, z);
 				stq<AL>(p_dst, foff(x4, y, z), x4 == X4 - 1 ? nv_last : 4, Pq[1 + idx]);
 				m_dst[qi] = Mq[idx];
 			}
 		}
+		PROF(8);
 		if (tid == 0) {
 			uint4 next = make_uint4((uint32_t)t | kCopyOnly, 0u, entry.y, 0u);     // what this launch was given is what the next one must store
 			if (core_bits) {
@@ -417,16 +440,22 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(
 				next.y = (uint32_t)(__ffs(qm) - 1) | (uint32_t)(31 - __clz(qm)) << 3 | (uint32_t)(__ffs(ym) - 1) << 6 |
 					(uint32_t)(31 - __clz(ym)) << 9 | (uint32_t)(__ffs(zm) - 1) << 12 | (uint32_t)(31 - __clz(zm)) << 15;
 			}
-			list_out[(size_t)shard * cap + atomicAdd(cnt_out + shard, 1u)] = next;
+			list_out[(size_t)shard * cap + slot] = next;
 			// the last level that left a cell relaxing; a tile the dense sweep flagged had one after level `level_base` itself
 			if ((last_active > 0 || tile_flag) && stat_hi + (uint32_t)(level_base + last_active) > raised) {
 				raised = stat_hi + (uint32_t)(level_base + last_active);       // (one returning access per workgroup and level, not per tile)
-				stat_raise(stat, raised);
+				atomicMax(stat, raised);                                      // (no return value: nobody waits for it)
 			}
 		}
+		PROF(9);
 	}
 }
 
+}
+#ifdef FX_FREEZE_PROF
+extern "C" void fx_debug_freeze_prof(unsigned long long* out, int reset) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(fz_prof), sizeof fz_prof); if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(fz_prof), z, sizeof z); } }
+#endif
+namespace {
 int env_int(const char* name, int dflt)
 {
 	const char* v = getenv(name);
@@ -437,7 +466,8 @@ int env_int(const char* name, int dflt)
 
 bool jacobi_freeze_supported(const Geom& g)
 {
-	return env_int("FLUIDX_FREEZE_FAST", 1) != 0 && g.Zg > 1 && g.H == 0 && g.z0 == 0 && g.nz == g.Zg && g.X >= 4;
+	return env_int("FLUIDX_FREEZE_FAST", 1) != 0 && g.Zg > 1 && g.H == 0 && g.z0 == 0 && g.nz == g.Zg && g.X >= 4 &&
+		(uint64_t)g.X * g.Y < (1u << 24) && (uint64_t)g.X * g.Y * (uint64_t)g.Zg < (1u << 30);   // 24-bit row / plane multiplies, 32-bit byte offsets
 }
 
 int jacobi_freeze_tiles(const Geom& g)
@@ -481,7 +511,7 @@ hipError_t launch_freeze_tiles(const Geom& g, const float* p_src, const float* b
 	const int nt = env_int("FLUIDX_FREEZE_NT", 512);
 	const dim3 block((g.X & 3) != 0 ? 512 : (nt == 256 ? 256 : (nt == 1024 ? 1024 : 512)), 1, 1), grid(want < max_wgs ? want : max_wgs, 1, 1);
 	const int ntz = (g.Zg + TCZ - 1) / TCZ;
-	const int scan_limit = env_int("FLUIDX_FREEZE_SCAN", 1) ? (ntz + 7) / 8 * 8 * ntx * nty : 0;
+	const int scan_limit = (ntz + 7) / 8 * 8 * ntx * nty;   // the first launch's index space: (tile plane % 8 = XCD, plane / 8, tile in plane)
 	const uint4* lin = (const uint4*)w.list[n & 1];
 	uint4* lout = (uint4*)w.list[(n + 1) & 1];
 	const uint32_t* cin = w.counts + (size_t)n * kShards;
