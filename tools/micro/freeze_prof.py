@@ -11,12 +11,15 @@ f = fx.Fluid(); assert f.Init(0, 0, (grid,) * 3, storage="fp16", jacobi_iters=64
 dt = np.float32(f.default_time_step())
 for k in range(60): f.UpdateFrame(dt, k % 3); f.Simulate(k % 3)
 f.Synchronize(); lib.fx_debug_freeze_prof(buf, 1)
+passes = (ctypes.c_uint * 160)(); lib.fx_debug_freeze_passes(passes, 1)
 n = 20
 for k in range(n): f.UpdateFrame(dt, k % 3); f.Simulate(k % 3)
-f.Synchronize(); lib.fx_debug_freeze_prof(buf, 0)
+f.Synchronize(); lib.fx_debug_freeze_prof(buf, 0); lib.fx_debug_freeze_passes(passes, 0)
 v = list(buf); tiles = max(v[15], 1)
 names = ["to tile start", "barrier (LDS free)", "loads landed", "LDS stored+barrier", "level 1", "level 2", "level 3", "level 4", "core stored", "appended"]
 print("grid", grid, "tile passes per step", tiles / n)
 print("loads issued (address math)  %9.1f" % (v[10] / tiles))
 for i, nm in enumerate(names): print("%-22s %9.1f ticks per tile pass" % (nm, v[i] / tiles))
 print("sum", sum(v[:11]) / tiles)
+pp = list(passes)
+print("tile passes per launch (first level: passes / copy-only):", " ".join("%d:%.0f/%.0f" % (l, pp[l] / n, pp[80 + l] / n) for l in range(80) if pp[l] or pp[80 + l]))
