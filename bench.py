@@ -239,6 +239,7 @@ def main():
                     "warm-up and keeps the fastest, or 'OVERLAP,ROUND' (fx_set_option values) to pin one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-render", action="store_true", help="skip the (untimed-for-value) ray-march measurement")
+    ap.add_argument("--no-developed", action="store_true", help="skip the second timing of the step at frame 132 (`developed_plume`)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--loopback", type=int, default=0,
                     help="run the N-rank code path (grid, slabs, halos, schedule selection) with N slab contexts in THIS process on "
@@ -509,6 +510,8 @@ def main():
     roof = None
     timing = None
     render = None
+    developed = None
+    frame_now = args.warmup + args.steps
     if fluid is not None:
         timing = (members[len(members) // 2] if loop else fluid).timing_read(reset=True)   # loop-back: an inner rank's stages
         if N > 1 and schedule is not None and timing.steps:
@@ -624,7 +627,29 @@ def main():
             if sh_info is not None:
                 render["mode"] += ", hasSH = 1 (light probe)"
                 render["sh_light_probe"] = sh_info
+            frame_now = steps_done + extra
         fluid.timing_enable(False)
+        if N == 1 and G > 1 and not args.no_developed:
+            # `value` is measured on the plume the warm-up left (the driver's line: steps 6-25, a young plume).  Two stages cost more on a
+            # developed one: the advection (more waves trace beyond the staged window) and, in the reference's configuration, the pressure
+            # solve (more cells keep relaxing).  So the same steps are timed once more at SURVEY 8(d)'s frame 132, beside `value`.
+            DEV_FRAME, DEV_STEPS = 132, 20
+            for k in range(max(0, DEV_FRAME - frame_now)):
+                one_step(frame_now + k)
+            frame_now = max(frame_now, DEV_FRAME)
+            fluid.Synchronize()
+            fluid.timing_read(reset=True)
+            t_dev = time.perf_counter()
+            for k in range(DEV_STEPS):
+                one_step(frame_now + k)
+            fluid.Synchronize()
+            dev_s = (time.perf_counter() - t_dev) / DEV_STEPS
+            t_dev_ = fluid.timing_read(reset=True)
+            developed = {"frames": [frame_now + 1, frame_now + DEV_STEPS], "ms_per_step": dev_s * 1e3, "value": float(GX) * GY * nz / dev_s,
+                         "unit": "voxel-updates/s"}
+            if t_dev_.freeze_solves:
+                developed["sweeps_executed_per_solve"] = t_dev_.freeze_sweeps / t_dev_.freeze_solves
+            frame_now += DEV_STEPS
         if timing.jacobi_launches and args.mode == "faithful" and timing.freeze_solves:
             # The reference's own solve on the sparse solver (fx_jacobi_freeze.hip): one dense sweep (k_freeze_dense: the launch the
             # library books as "main") + tile launches over the cells that still relax.  roofline = the dense sweep, the one streaming
@@ -764,6 +789,8 @@ def main():
             out["roofline"] = roof
         if render is not None:
             out["render"] = render
+        if developed is not None:
+            out["developed_plume"] = developed
         if N == 1 and not args.no_cpu_baseline and not args.dry_run:
             out["cpu_baseline"] = cpu_baseline(G, args.iters, args.cpu_budget, mode=int(args.mode == "faithful"), half=args.storage == "fp16",
                                                address=int(args.address == "mirror"))

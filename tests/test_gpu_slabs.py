@@ -549,6 +549,9 @@ def test_bench_single_gpu_line_is_complete():
     assert rn["frame"] == 132 and rn["untimed_steps_to_frame"] == 107
     assert rn["view_samples_taken"] > rn["rays"] and rn["light_samples_taken"] >= 128 ** 3 and rn["samples_per_s"] > 0
     assert 0 < rn["bound"]["light_pass"]["frac_of_hbm_peak"] < 1 and 0 < rn["bound"]["view_pass"]["frac_of_hbm_peak"] < 1
+    # ... and the step is timed once more on the developed plume (frames 133-152), beside `value`
+    dv = d["developed_plume"]
+    assert dv["frames"] == [133, 152] and dv["ms_per_step"] > 0 and dv["value"] == pytest.approx(128 ** 3 / (dv["ms_per_step"] * 1e-3))
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
 
 
@@ -570,6 +573,8 @@ def test_bench_reference_configuration_line():
     assert "k_freeze_dense" in r["kernel"] and 0 < r["frac"] <= 1 and r["sweeps_per_launch"] == 1.0
     sp = r["sparse_solver"]
     assert 1 < sp["sweeps_executed_per_solve"] <= 64 and sp["solves"] == 20 and sp["tile_launches_per_step"] == 16
+    dv = d["developed_plume"]                                  # (--no-render: the untimed steps to frame 132 are run here)
+    assert dv["frames"] == [133, 152] and dv["ms_per_step"] > 0 and 1 < dv["sweeps_executed_per_solve"] <= 64
     assert d["cpu_baseline"]["value"] > 0 and "reference configuration" in d["cpu_baseline"]["sample"]
 
 

@@ -11,7 +11,7 @@ python bench.py --reference-config --grid 150 --no-cpu-baseline > $O/bench_refer
 python bench.py --reference-config --grid 512 --steps 6 --warmup 30 --no-cpu-baseline --no-render > $O/bench_reference_512.json 2>> $O/bench.err
 prof() {  # tag, summary args, bench args...
   tag=$1; sargs=$2; shift 2
-  B="python3 bench.py --no-cpu-baseline --no-render $*"
+  B="python3 bench.py --no-cpu-baseline --no-render --no-developed $*"
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$tag -o k -- $B > /dev/null 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmcf_$tag -o f -- $B > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmcw_$tag -o w -- $B > /dev/null 2>&1
