@@ -133,16 +133,106 @@ __device__ __forceinline__ T ldg32(const void* base, uint32_t byte_off)
 	return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off);
 }
 
+
+// the 24 + 8 taps of a voxel as gathers from global memory (k_advect_fast's): a trace that leaves the staged window
+template <bool HALF>
+__device__ __forceinline__ void advect_gather(const Geom& g, const SimParams& sp, int ix, int iy, int z0, int z1, bool z_present, float fx, float fy, float fz,
+	const char* v0, const char* v1, const char* v2, const void* __restrict__ col_in, int lgX, int lgP, unsigned* halo_overflow, float (&u)[3], float (&c)[4])
+{
+	// ---- a longer trace somewhere in the wave: the gathers of k_advect_fast, from global memory ----------------------
+	const int xa0 = addr_tap(ix, g.X, sp.address), xa1 = addr_tap(ix + 1, g.X, sp.address);
+	const int ya0 = addr_tap(iy, g.Y, sp.address), ya1 = addr_tap(iy + 1, g.Y, sp.address);
+	if (!z_present) {
+		atomicOr(halo_overflow, 1u);
+		z0 = min(max(z0, g.zlo), g.zhi);
+		z1 = min(max(z1, g.zlo), g.zhi);
+	}
+	const uint32_t p0 = (uint32_t)g.lz(z0) << lgP, p1 = (uint32_t)g.lz(z1) << lgP;
+	const uint32_t ry0 = (uint32_t)ya0 << lgX, ry1 = (uint32_t)ya1 << lgX;
+	const uint32_t c000 = p0 + ry0 + (uint32_t)xa0, c100 = p0 + ry0 + (uint32_t)xa1;
+	const uint32_t c010 = p0 + ry1 + (uint32_t)xa0, c110 = p0 + ry1 + (uint32_t)xa1;
+	const uint32_t c001 = p1 + ry0 + (uint32_t)xa0, c101 = p1 + ry0 + (uint32_t)xa1;
+	const uint32_t c011 = p1 + ry1 + (uint32_t)xa0, c111 = p1 + ry1 + (uint32_t)xa1;
+	const char* vb[3] = { v0, v1, v2 };
+	auto gv = [](const char* b, uint32_t cell) -> float { return HALF ? (float)ldg32<h16>(b, cell * 2u) : ldg32<float>(b, cell * 4u); };
+	auto gc = [&](uint32_t cell) -> float4 {
+		if (HALF) { const h16x4 h = ldg32<h16x4>(col_in, cell * 8u); return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w); }
+		return ldg32<float4>(col_in, cell * 16u);
+	};
+#pragma unroll
+	for (int a = 0; a < 3; ++a) {
+		const float c00 = lerpf(gv(vb[a], c000), gv(vb[a], c100), fx);
+		const float c10 = lerpf(gv(vb[a], c010), gv(vb[a], c110), fx);
+		const float c01 = lerpf(gv(vb[a], c001), gv(vb[a], c101), fx);
+		const float c11 = lerpf(gv(vb[a], c011), gv(vb[a], c111), fx);
+		u[a] = lerpf(lerpf(c00, c10, fy), lerpf(c01, c11, fy), fz);
+	}
+	const float4 t000 = gc(c000), t100 = gc(c100), t010 = gc(c010), t110 = gc(c110);
+	const float4 t001 = gc(c001), t101 = gc(c101), t011 = gc(c011), t111 = gc(c111);
+#define FX_TRI(m) lerpf(lerpf(lerpf(t000.m, t100.m, fx), lerpf(t010.m, t110.m, fx), fy), \
+	lerpf(lerpf(t001.m, t101.m, fx), lerpf(t011.m, t111.m, fx), fy), fz)
+	c[0] = FX_TRI(x); c[1] = FX_TRI(y); c[2] = FX_TRI(z); c[3] = FX_TRI(w);
+#undef FX_TRI
+}
+
+// impulse (CSAdvect.hlsl:59-68), attenuation and the stores of one voxel; u / c = the traced velocity / colour
+template <bool HALF>
+__device__ __forceinline__ void advect_finish(const SimParams& sp, float (&u)[3], float (&c)[4], float ex, float dx, float dz, float dt, float atten,
+	uint32_t id, uint32_t stride, void* __restrict__ vel_out, void* __restrict__ col_out)
+{
+	// ---- impulse (CSAdvect.hlsl:59-68).  exp2(ex) >= e^-4 needs ex >= -5.77: a wave whose lanes are all far below that
+	// skips the transcendental; the decision itself still uses the computed basis, exactly as before
+	if (__builtin_amdgcn_ballot_w64(ex > -6.5f) != 0) {
+		const float basis = exp2f(ex);
+		if (basis >= 0.0183156393f) {
+			float Fx, Fy, Fz;
+			if (sp.is3d) {
+				Fx = fmaf(basis, 0.0f, dz * -200.0f);
+				Fy = fmaf(basis, 192.0f, 0.0f);
+				Fz = fmaf(basis, 0.0f, dx * 200.0f);
+			} else {
+				Fx = 0.0f; Fy = basis * 48.0f; Fz = 0.0f;
+			}
+			u[0] = fmaf(Fx, dt, u[0]); u[1] = fmaf(Fy, dt, u[1]); u[2] = fmaf(Fz, dt, u[2]);
+			const float bdt = basis * dt;
+			c[0] = saturatef(fmaf(bdt, 8.0f, c[0]));
+			c[1] = saturatef(fmaf(bdt, 16.0f, c[1]));
+			c[2] = saturatef(fmaf(bdt, 40.0f, c[2]));
+			c[3] = saturatef(fmaf(bdt, 40.0f, c[3]));
+		}
+	}
+	if (HALF) {
+		h16* vo = static_cast<h16*>(vel_out);
+		vo[id] = to_h16(u[0] * atten);
+		vo[(size_t)stride + id] = to_h16(u[1] * atten);
+		vo[2 * (size_t)stride + id] = to_h16(u[2] * atten);
+		h16x4 hc;
+		hc.x = to_h16(c[0] * atten); hc.y = to_h16(c[1] * atten); hc.z = to_h16(c[2] * atten); hc.w = to_h16(c[3] * atten);
+		static_cast<h16x4*>(col_out)[id] = hc;
+	} else {
+		float* vo = static_cast<float*>(vel_out);
+		vo[id] = u[0] * atten;
+		vo[(size_t)stride + id] = u[1] * atten;
+		vo[2 * (size_t)stride + id] = u[2] * atten;
+		static_cast<float4*>(col_out)[id] = make_float4(c[0] * atten, c[1] * atten, c[2] * atten, c[3] * atten);
+	}
+
+}
+
 }  // namespace
 
 // HALF: fp16 storage of velocity / colour (BASELINE configs[4], the reference's RGBA16F): arithmetic unchanged (fp32), half the HBM
 // bytes, 13.2 instead of 18.5 KB per slot
-template <bool HALF, int TY>
+// DEFER: a voxel whose trace leaves the staged window is not gathered here -- its wave would issue 35 scattered loads for a few lanes and
+// hold the workgroup's barrier meanwhile -- but appended to the workgroup's segment of `far_list` (a placeholder is stored to its cell)
+// and advected by k_advect_far afterwards.  7 % of the waves of a developed plume (frame 132) have such a lane, 1.5 % of the voxels.
+template <bool HALF, int TY, bool DEFER>
 __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_advect_lds(const Geom g, const SimParams sp,
 	const void* __restrict__ vel_in, const void* __restrict__ col_in, void* __restrict__ vel_out, void* __restrict__ col_out,
 	int z_begin, int nzp, int zchunk, int nchunks, unsigned* halo_overflow, float rX, float rY, float rZ, float inv_rr,
-	int lgX, int lgY, int lg_gx, int lg_gy, int dbg)
+	int lgX, int lgY, int lg_gx, int lg_gy, uint32_t* __restrict__ far_list, uint32_t* __restrict__ far_flat, uint32_t* __restrict__ far_total, uint32_t far_cap)
 {
+	__shared__ uint32_t far_n, far_base;
 	extern __shared__ __attribute__((aligned(16))) char lds[];   // NSLOT slots: [colour float4 x NCELL][velocity float x 3 x NCELL]
 
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -206,6 +296,7 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
 		}
 	};
 
+	if (DEFER && tid == 0) far_n = 0u;
 	fill(zb - 1);
 	fill(zb);
 	fill(zb + 1);
@@ -242,14 +333,17 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
 		const bool inwin = (unsigned)(jx + 1) <= 1u && (unsigned)(jy + 1) <= 1u && (unsigned)(jz + 1) <= 1u && z_present;
 
 		float u[3], c[4];
-		if (dbg & 2) {                                           // timing experiments only: no taps at all
-			u[0] = u0x; u[1] = u0y; u[2] = u0z; c[0] = fx; c[1] = fy; c[2] = fz; c[3] = ex;
-		} else if ((dbg & 8) ? (__builtin_amdgcn_ballot_w64(!inwin) == 0) : inwin) {
-			// ---- the lanes that trace into the staged window: all 32 taps are LDS reads.  A mixed wave runs both branches under
-			// partial exec masks (its gathers then only carry the few far-tracing lanes); dbg & 8 = wave-uniform choice instead
-			const uint32_t c0 = (uint32_t)((int)own + jy * HX + jx);               // cell of tap (x0, y0) inside a slot
-			const char* s0 = lds + ((iz + 4) & 3) * SLOT_BYTES;
-			const char* s1 = lds + ((iz + 5) & 3) * SLOT_BYTES;
+		if (DEFER && !inwin) {                                   // noted for k_advect_far; below it reads the window like a voxel at rest
+			const uint32_t slot = atomicAdd(&far_n, 1u);
+			far_list[(size_t)blockIdx.x * far_cap + slot] = (uint32_t)x | (uint32_t)y << lgX | (uint32_t)z << lgP;
+		}
+		if (DEFER || inwin) {
+			// ---- the lanes that trace into the staged window: all 32 taps are LDS reads.  Without DEFER a mixed wave runs both
+			// branches under partial exec masks (its gathers then only carry the few far-tracing lanes)
+			const int kx = DEFER && !inwin ? 0 : jx, ky = DEFER && !inwin ? 0 : jy, kz = DEFER && !inwin ? z : iz;
+			const uint32_t c0 = (uint32_t)((int)own + ky * HX + kx);               // cell of tap (x0, y0) inside a slot
+			const char* s0 = lds + ((kz + 4) & 3) * SLOT_BYTES;
+			const char* s1 = lds + ((kz + 5) & 3) * SLOT_BYTES;
 #pragma unroll
 			for (int a = 0; a < 3; ++a) {
 				const uint32_t* p0 = reinterpret_cast<const uint32_t*>(s0 + COL_BYTES + a * VEL_BYTES) + c0;
@@ -280,80 +374,11 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
 			c[0] = FX_TRI(x); c[1] = FX_TRI(y); c[2] = FX_TRI(z); c[3] = FX_TRI(w);
 #undef FX_TRI
 		} else {
-			// ---- a longer trace somewhere in the wave: the gathers of k_advect_fast, from global memory ----------------------
-			const int xa0 = addr_tap(ix, g.X, sp.address), xa1 = addr_tap(ix + 1, g.X, sp.address);
-			const int ya0 = addr_tap(iy, g.Y, sp.address), ya1 = addr_tap(iy + 1, g.Y, sp.address);
-			if (!z_present) {
-				atomicOr(halo_overflow, 1u);
-				z0 = min(max(z0, g.zlo), g.zhi);
-				z1 = min(max(z1, g.zlo), g.zhi);
-			}
-			const uint32_t p0 = (uint32_t)g.lz(z0) << lgP, p1 = (uint32_t)g.lz(z1) << lgP;
-			const uint32_t ry0 = (uint32_t)ya0 << lgX, ry1 = (uint32_t)ya1 << lgX;
-			const uint32_t c000 = p0 + ry0 + (uint32_t)xa0, c100 = p0 + ry0 + (uint32_t)xa1;
-			const uint32_t c010 = p0 + ry1 + (uint32_t)xa0, c110 = p0 + ry1 + (uint32_t)xa1;
-			const uint32_t c001 = p1 + ry0 + (uint32_t)xa0, c101 = p1 + ry0 + (uint32_t)xa1;
-			const uint32_t c011 = p1 + ry1 + (uint32_t)xa0, c111 = p1 + ry1 + (uint32_t)xa1;
-			const char* vb[3] = { v0, v1, v2 };
-			auto gv = [](const char* b, uint32_t cell) -> float { return HALF ? (float)ldg32<h16>(b, cell * 2u) : ldg32<float>(b, cell * 4u); };
-			auto gc = [&](uint32_t cell) -> float4 {
-				if (HALF) { const h16x4 h = ldg32<h16x4>(col_in, cell * 8u); return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w); }
-				return ldg32<float4>(col_in, cell * 16u);
-			};
-#pragma unroll
-			for (int a = 0; a < 3; ++a) {
-				const float c00 = lerpf(gv(vb[a], c000), gv(vb[a], c100), fx);
-				const float c10 = lerpf(gv(vb[a], c010), gv(vb[a], c110), fx);
-				const float c01 = lerpf(gv(vb[a], c001), gv(vb[a], c101), fx);
-				const float c11 = lerpf(gv(vb[a], c011), gv(vb[a], c111), fx);
-				u[a] = lerpf(lerpf(c00, c10, fy), lerpf(c01, c11, fy), fz);
-			}
-			const float4 t000 = gc(c000), t100 = gc(c100), t010 = gc(c010), t110 = gc(c110);
-			const float4 t001 = gc(c001), t101 = gc(c101), t011 = gc(c011), t111 = gc(c111);
-#define FX_TRI(m) lerpf(lerpf(lerpf(t000.m, t100.m, fx), lerpf(t010.m, t110.m, fx), fy), \
-	lerpf(lerpf(t001.m, t101.m, fx), lerpf(t011.m, t111.m, fx), fy), fz)
-			c[0] = FX_TRI(x); c[1] = FX_TRI(y); c[2] = FX_TRI(z); c[3] = FX_TRI(w);
-#undef FX_TRI
+			advect_gather<HALF>(g, sp, ix, iy, z0, z1, z_present, fx, fy, fz, v0, v1, v2, col_in, lgX, lgP, halo_overflow, u, c);
 		}
 
-		// ---- impulse (CSAdvect.hlsl:59-68).  exp2(ex) >= e^-4 needs ex >= -5.77: a wave whose lanes are all far below that
-		// skips the transcendental; the decision itself still uses the computed basis, exactly as before
-		if (__builtin_amdgcn_ballot_w64(ex > -6.5f) != 0) {
-			const float basis = exp2f(ex);
-			if (basis >= 0.0183156393f) {
-				float Fx, Fy, Fz;
-				if (sp.is3d) {
-					Fx = fmaf(basis, 0.0f, dz * -200.0f);
-					Fy = fmaf(basis, 192.0f, 0.0f);
-					Fz = fmaf(basis, 0.0f, dx * 200.0f);
-				} else {
-					Fx = 0.0f; Fy = basis * 48.0f; Fz = 0.0f;
-				}
-				u[0] = fmaf(Fx, dt, u[0]); u[1] = fmaf(Fy, dt, u[1]); u[2] = fmaf(Fz, dt, u[2]);
-				const float bdt = basis * dt;
-				c[0] = saturatef(fmaf(bdt, 8.0f, c[0]));
-				c[1] = saturatef(fmaf(bdt, 16.0f, c[1]));
-				c[2] = saturatef(fmaf(bdt, 40.0f, c[2]));
-				c[3] = saturatef(fmaf(bdt, 40.0f, c[3]));
-			}
-		}
 		const uint32_t id = ((uint32_t)g.lz(z) << lgP) + ((uint32_t)y << lgX) + (uint32_t)x;
-		if (HALF) {
-			h16* vo = static_cast<h16*>(vel_out);
-			vo[id] = to_h16(u[0] * atten);
-			vo[(size_t)stride + id] = to_h16(u[1] * atten);
-			vo[2 * (size_t)stride + id] = to_h16(u[2] * atten);
-			h16x4 hc;
-			hc.x = to_h16(c[0] * atten); hc.y = to_h16(c[1] * atten); hc.z = to_h16(c[2] * atten); hc.w = to_h16(c[3] * atten);
-			static_cast<h16x4*>(col_out)[id] = hc;
-		} else {
-			float* vo = static_cast<float*>(vel_out);
-			vo[id] = u[0] * atten;
-			vo[(size_t)stride + id] = u[1] * atten;
-			vo[2 * (size_t)stride + id] = u[2] * atten;
-			static_cast<float4*>(col_out)[id] = make_float4(c[0] * atten, c[1] * atten, c[2] * atten, c[3] * atten);
-		}
-
+		advect_finish<HALF>(sp, u, c, ex, dx, dz, dt, atten, id, stride, vel_out, col_out);
 	};
 
 	for (int z = zb; z < ze; ++z) {
@@ -365,14 +390,70 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
 		asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 		__syncthreads();                                         // plane z+2 is in the ring; plane z-1's slot may be overwritten
 	}
+	// (behind the loop's last barrier: every append is in.)  The workgroup's notes move from its segment to ONE list every workgroup
+	// appends to -- a returning atomic per workgroup, not per note -- so that k_advect_far can share them out evenly: the plume's
+	// workgroups note thousands of voxels, most workgroups none.
+	if (DEFER) {
+		const uint32_t n = far_n;
+		if (n != 0u) {                                              // uniform
+			if (tid == 0) far_base = atomicAdd(far_total, n);
+			__syncthreads();
+			const uint32_t base = far_base;
+			const uint32_t* seg = far_list + (size_t)blockIdx.x * far_cap;
+			for (uint32_t i = (uint32_t)tid; i < n; i += (uint32_t)NT) far_flat[base + i] = seg[i];
+		}
+	}
+}
+
+// The voxels k_advect_lds<.., DEFER = true> put aside, one per thread off the common list: CSAdvect.hlsl:41-79 for one voxel with every tap a
+// gather (k_advect_fast's arithmetic, so the result is the one the staged path would have produced had the window been wide enough).
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_advect_far(const Geom g, const SimParams sp,
+	const void* __restrict__ vel_in, const void* __restrict__ col_in, void* __restrict__ vel_out, void* __restrict__ col_out,
+	const uint32_t* __restrict__ far_flat, const uint32_t* __restrict__ far_total, uint32_t* __restrict__ far_total_next, unsigned* halo_overflow,
+	float rX, float rY, float rZ, float inv_rr, int lgX, int lgY)
+{
+	const uint32_t n = *far_total;
+	if (blockIdx.x == 0 && threadIdx.x == 0) *far_total_next = 0u;   // the counter the NEXT step's advection appends through (the two alternate)
+	const int lgP = lgX + lgY;
+	constexpr uint32_t ES = HALF ? 2 : 4;
+	const uint32_t stride = (uint32_t)g.nzl() << lgP;
+	const char* v0 = reinterpret_cast<const char*>(vel_in);
+	const char* v1 = v0 + (size_t)stride * ES;
+	const char* v2 = v1 + (size_t)stride * ES;
+	const float dt = sp.dt;
+	const float atten = fmaxf(fmaf(-dt, 0.200000003f, 1.0f), 0.0f);
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+		const uint32_t code = far_flat[i];
+		const int x = (int)(code & (uint32_t)(g.X - 1)), y = (int)((code >> lgX) & (uint32_t)(g.Y - 1)), z = (int)(code >> lgP);
+		const float px = ((float)x + 0.5f) * rX, py = ((float)y + 0.5f) * rY, pz = ((float)z + 0.5f) * rZ;
+		const float dx = px + -0.5f, dy = py + -0.100000001f, dz = pz + -0.5f;
+		const float dxy2 = fmaf(dy, dy, dx * dx);
+		const float d2 = fmaf(dz, dz, dxy2);
+		const float ex = ((d2 * -4.0f) * inv_rr) * 1.44269502f;
+		const uint32_t id = ((uint32_t)g.lz(z) << lgP) + ((uint32_t)y << lgX) + (uint32_t)x;
+		auto gv = [](const char* b, uint32_t cell) -> float { return HALF ? (float)ldg32<h16>(b, cell * 2u) : ldg32<float>(b, cell * 4u); };
+		const float u0x = gv(v0, id), u0y = gv(v1, id), u0z = gv(v2, id);
+		const float ax = fmaf(-u0x, dt, px), ay = fmaf(-u0y, dt, py), az = fmaf(-u0z, dt, pz);
+		const float tx_ = ax * (float)g.X - 0.5f, ty_ = ay * (float)g.Y - 0.5f, tz_ = az * (float)g.Zg - 0.5f;
+		const float flx = floorf(tx_), fly = floorf(ty_), flz = floorf(tz_);
+		const float fx = tx_ - flx, fy = ty_ - fly, fz = tz_ - flz;
+		const int ix = (int)flx, iy = (int)fly, iz = (int)flz;
+		const int z0 = addr_tap(iz, g.Zg, sp.address), z1 = addr_tap(iz + 1, g.Zg, sp.address);
+		const bool z_present = z0 >= g.zlo && z0 <= g.zhi && z1 >= g.zlo && z1 <= g.zhi;
+		float u[3], c[4];
+		advect_gather<HALF>(g, sp, ix, iy, z0, z1, z_present, fx, fy, fz, v0, v1, v2, col_in, lgX, lgP, halo_overflow, u, c);
+		advect_finish<HALF>(sp, u, c, ex, dx, dz, dt, atten, id, stride, vel_out, col_out);
+	}
 }
 
 static int env_i(const char* n, int d) { const char* v = getenv(n); return v && *v ? atoi(v) : d; }
 
 // hipErrorNotSupported: the geometry has no LDS path (the caller falls back to k_advect_fast / k_advect)
 hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const void* col_in,
-	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, hipStream_t s, bool force)
+	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, uint32_t* far_scratch, size_t far_words, int far_parity, bool* far_used, hipStream_t s, bool force)
 {
+	if (far_used) *far_used = false;
 	auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
 	const int nzp = z_end - z_begin;
 	// rows per workgroup tile.  16 (one 1024-thread workgroup per CU, 1.16 x instead of 1.29 x border) measured 0.228 / 0.269 ms against
@@ -395,16 +476,41 @@ hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store,
 	if (zchunk > nzp) zchunk = nzp;
 	const int nchunks = (nzp + zchunk - 1) / zchunk;
 	const float rX = 1.0f / (float)g.X, rY = 1.0f / (float)g.Y, rZ = 1.0f / (float)g.Zg, inv_rr = sp.is3d ? 256.0f : 1024.0f;
-	const int dbg = env_i("FLUIDX_ADVECT_DBG", 0);
-#define FX_ADV(H_, TY_) do { \
+	// far-tracing voxels deferred to k_advect_far when the caller lent scratch: [two alternating totals][the common list: an id per voxel]
+	// [a segment of 64 * TY * zchunk ids per workgroup] (FLUIDX_ADVECT_DEFER=0: gathered inside the staged kernel, as before)
+	const uint32_t nwg = (uint32_t)(tiles_xy * nchunks), far_cap = (uint32_t)(TX * TY * zchunk);
+	const size_t flat_words = (size_t)g.X * g.Y * (size_t)nzp;
+	const bool defer = far_scratch && far_words >= 2 + flat_words + (size_t)nwg * far_cap && env_i("FLUIDX_ADVECT_DEFER", 1) != 0;
+	if (far_used) *far_used = defer;                              // (the caller alternates far_parity over the launches that did defer)
+	uint32_t* far_total = far_scratch ? far_scratch + (far_parity & 1) : nullptr;
+	uint32_t* far_total_next = far_scratch ? far_scratch + ((far_parity & 1) ^ 1) : nullptr;
+	uint32_t* far_flat = far_scratch ? far_scratch + 2 : nullptr;
+	uint32_t* far_list = far_scratch ? far_scratch + 2 + flat_words : nullptr;
+#define FX_ADV(H_, TY_, D_) do { \
 		static bool attr_set = false; \
-		if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_advect_lds<H_, TY_>), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * Lay<H_, TY_>::SLOT_BYTES); attr_set = true; } \
-		hipLaunchKernelGGL((k_advect_lds<H_, TY_>), dim3(tiles_xy * nchunks), dim3(64 * TY_), (NSLOT * Lay<H_, TY_>::SLOT_BYTES), s, g, sp, vel_in, col_in, vel_out, col_out, \
-			z_begin, nzp, zchunk, nchunks, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY, lg_gx, lg_gy, dbg); } while (0)
-	if (TY == 16) { if (half_store) FX_ADV(true, 16); else FX_ADV(false, 16); }
-	else { if (half_store) FX_ADV(true, 8); else FX_ADV(false, 8); }
+		if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_advect_lds<H_, TY_, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * Lay<H_, TY_>::SLOT_BYTES); attr_set = true; } \
+		hipLaunchKernelGGL((k_advect_lds<H_, TY_, D_>), dim3(tiles_xy * nchunks), dim3(64 * TY_), (NSLOT * Lay<H_, TY_>::SLOT_BYTES), s, g, sp, vel_in, col_in, vel_out, col_out, \
+			z_begin, nzp, zchunk, nchunks, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY, lg_gx, lg_gy, far_list, far_flat, far_total, far_cap); } while (0)
+	if (defer) {
+		if (TY == 16) { if (half_store) FX_ADV(true, 16, true); else FX_ADV(false, 16, true); }
+		else { if (half_store) FX_ADV(true, 8, true); else FX_ADV(false, 8, true); }
+		const int far_wgs = 1024;                                   // 262144 threads: a developed 256^3 plume notes 250-400 thousand voxels
+		if (half_store) hipLaunchKernelGGL(k_advect_far<true>, dim3(far_wgs), dim3(256), 0, s, g, sp, vel_in, col_in, vel_out, col_out, far_flat, far_total, far_total_next, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY);
+		else hipLaunchKernelGGL(k_advect_far<false>, dim3(far_wgs), dim3(256), 0, s, g, sp, vel_in, col_in, vel_out, col_out, far_flat, far_total, far_total_next, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY);
+	} else {
+		if (TY == 16) { if (half_store) FX_ADV(true, 16, false); else FX_ADV(false, 16, false); }
+		else { if (half_store) FX_ADV(true, 8, false); else FX_ADV(false, 8, false); }
+	}
 #undef FX_ADV
 	return hipGetLastError();
+}
+
+// scratch words launch_advect_lds needs to defer far-tracing voxels for planes [z_begin, z_end) of `g` (0: no staged path there)
+size_t advect_far_words(const Geom& g, int nzp)
+{
+	auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+	if (g.Zg <= 1 || !pow2(g.X) || !pow2(g.Y) || g.X < TX || g.Y < 16 || nzp < 12) return 0;
+	return 2 + (size_t)g.X * g.Y * (size_t)nzp + (size_t)g.X * g.Y * (size_t)(nzp + 32);   // two totals, the common list, the workgroups' segments (whole chunks)
 }
 
 }  // namespace fx

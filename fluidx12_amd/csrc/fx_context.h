@@ -32,6 +32,9 @@ struct fx_ctx {
 	void* fz_list[2] = { nullptr, nullptr };   // work lists of alternate launches
 	uint32_t* fz_counts = nullptr;  // list lengths of two solves [2][kFreezeSlots launches][8 sub-lists]
 	uint32_t* fz_stat = nullptr;
+	uint32_t* adv_far = nullptr;       // scratch of the staged advection: the far-tracing voxels it defers (single-domain contexts; allocated at first use)
+	size_t adv_far_words = 0;
+	uint32_t adv_far_turn = 0;        // which of the scratch's two totals the next advection appends through
 	uint32_t fz_gen = 0;            // solves so far (tags tile marks and stat words)
 	uint32_t fz_gen_mark = 0;       // fz_gen when the timing window opened
 	std::vector<uint32_t> fz_iters; // sweep cap of the solve with tag g, at [g % ring]

@@ -46,10 +46,13 @@ struct SimParams {
 // ---- simulation launchers (fx_sim.hip); `half_store` selects __half storage of velocity/colour
 // z_begin/z_end: global plane range to compute (within the locally present range)
 hipError_t launch_advect(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const void* col_in,
-	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, hipStream_t s);
+	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, hipStream_t s, uint32_t* far_scratch = nullptr, size_t far_words = 0, int far_parity = 0, bool* far_used = nullptr);
 // LDS-staged variant (fx_advect_lds.hip); hipErrorNotSupported when the geometry has no such path (force: also below the size where it pays)
 hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const void* col_in,
-	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, hipStream_t s, bool force);
+	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, uint32_t* far_scratch, size_t far_words, int far_parity, bool* far_used, hipStream_t s, bool force);
+// far_scratch: advect_far_words(g, planes) words lent by the caller (its first two words ZEROED once; far_parity alternates over the launches that report *far_used) let the staged kernel
+// defer far-tracing voxels to a second, small launch
+size_t advect_far_words(const Geom& g, int nzp);
 hipError_t launch_divergence(const Geom& g, int half_store, const void* vel, float* b, int z_begin, int z_end, hipStream_t s);
 // one lock-step sweep p_in -> p_out on planes [z_begin, z_end); frozen may be null
 hipError_t launch_jacobi_sweep(const Geom& g, const float* p_in, const float* b, float* p_out, uint8_t* frozen,

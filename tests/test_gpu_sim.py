@@ -507,8 +507,9 @@ def test_advect_lds_path_bit_identical(dims, address, scale, storage, monkeypatc
     if half:
         vel, col = vel.astype(np.float16).astype(f32), col.astype(np.float16).astype(f32)
     got = {}
-    for lds in ("1", "0"):
-        monkeypatch.setenv("FLUIDX_ADVECT_LDS", "2" if lds == "1" else "0")      # 2 = the LDS path also below the size where it pays
+    for lds in ("1", "inline", "0"):
+        monkeypatch.setenv("FLUIDX_ADVECT_LDS", "0" if lds == "0" else "2")      # 2 = the LDS path also below the size where it pays
+        monkeypatch.setenv("FLUIDX_ADVECT_DEFER", "0" if lds == "inline" else "1")   # far-tracing voxels: k_advect_far | gathers inside the kernel
         f = make(dims, advect_address=address, storage=storage)
         dt = f32(f.default_time_step())
         f.upload(fx.FIELD_VELOCITY, vel); f.upload(fx.FIELD_COLOR, col)
@@ -516,13 +517,41 @@ def test_advect_lds_path_bit_identical(dims, address, scale, storage, monkeypatc
         f.Advect()
         f.Synchronize()
         got[lds] = (f.download(fx.FIELD_VELOCITY1), f.download(fx.FIELD_COLOR))
-    assert np.array_equal(got["1"][0].view(np.uint32), got["0"][0].view(np.uint32))
-    assert np.array_equal(got["1"][1].view(np.uint32), got["0"][1].view(np.uint32))
+    for k in ("1", "inline"):
+        assert np.array_equal(got[k][0].view(np.uint32), got["0"][0].view(np.uint32)), k
+        assert np.array_equal(got[k][1].view(np.uint32), got["0"][1].view(np.uint32)), k
     vo, co = orc.advect(vel, col, dt, address=int(address == "mirror"), half=half)
     assert rel_l2(got["1"][0], vo) < (1e-4 if half else 1e-6) and rel_l2(got["1"][1], co) < (1e-4 if half else 1e-6)
     z, y, x = np.meshgrid(np.arange(Z), np.arange(Y), np.arange(X), indexing="ij", sparse=True)
     far = ((x + .5) / X - .5) ** 2 + ((y + .5) / Y - .1) ** 2 + ((z + .5) / Z - .5) ** 2 > (1.5 / 16) ** 2
     assert np.array_equal(got["1"][0][:, far], vo[:, far]) and np.array_equal(got["1"][1][far], co[far])
+
+
+def test_advect_deferred_voxels_over_changing_flows(monkeypatch):
+    """k_advect_lds puts the voxels that trace beyond its staged window on a list, k_advect_far advects them afterwards; the list's two
+    totals alternate launch by launch.  Five advections of one context whose flow swings between "every voxel far" and "none", with a
+    launch that does not defer in between: each equals the gather kernel's result bit for bit"""
+    dims = (128, 128, 48)
+    X, Y, Z = dims
+    rng = np.random.default_rng(5)
+    col = rng.random((Z, Y, X, 4)).astype(f32)
+    monkeypatch.setenv("FLUIDX_ADVECT_LDS", "2")
+    f = make(dims)
+    monkeypatch.setenv("FLUIDX_ADVECT_LDS", "0")
+    ref = make(dims)
+    dt = f32(f.default_time_step())
+    for k, (scale, defer) in enumerate([(12.0, "1"), (0.2, "1"), (3.0, "0"), (12.0, "1"), (1.0, "1"), (0.0, "1")]):
+        vel = (rng.standard_normal((3, Z, Y, X)) * scale).astype(f32)
+        out = []
+        for g, lds in ((f, "2"), (ref, "0")):
+            monkeypatch.setenv("FLUIDX_ADVECT_LDS", lds)
+            monkeypatch.setenv("FLUIDX_ADVECT_DEFER", defer)
+            g.upload(fx.FIELD_VELOCITY, vel); g.upload(fx.FIELD_COLOR, col)
+            g.UpdateFrame(dt, 0)
+            g.Advect()
+            out.append((g.download(fx.FIELD_VELOCITY1), g.download(fx.FIELD_COLOR)))
+        assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32)), k
+        assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32)), k
 
 
 @pytest.mark.parametrize("grid,steps,storage", [(256, 40, "fp32"), (128, 60, "fp32"), (256, 24, "fp16"), (150, 30, "fp32")])

@@ -36,7 +36,7 @@ def kernels(lines, prefix):
 
 def test_advect_lds_hands_over_behind_exactly_four_stores(tmp_path):
     ks = kernels(device_isa("fx_advect_lds.hip", tmp_path), "k_advect_lds")
-    assert len(ks) >= 4                                         # <HALF> x <tile rows>
+    assert len(ks) >= 8                                         # <HALF> x <tile rows> x <DEFER>
     for name, body in ks.items():
         waits = [i for i, ln in enumerate(body) if ln.startswith("s_waitcnt vmcnt(4)") and body[i - 1].startswith(";;#ASMSTART")]   # the hand-written ones
         assert waits, name
@@ -47,7 +47,11 @@ def test_advect_lds_hands_over_behind_exactly_four_stores(tmp_path):
                     break
                 if ln.startswith(("global_store", "buffer_store", "flat_store")):
                     stores += 1
-            assert stores == 4, (name, w, stores)
+            # DEFER kernels note a far-tracing voxel with one more (older, lane-masked) store somewhere in front of the four (the compiler
+            # rotates the loop, so it may sit behind the loop head): the wait then also covers that store -- never fewer operations
+            # than the LDS-DMA loads
+            deferring = re.search(r"k_advect_ldsILb[01]ELi\d+ELb1E", name) is not None
+            assert stores in ((4, 5) if deferring else (4,)), (name, w, stores)
         # the LDS-DMA statements change SCC (s_add_u32 m0): they must say so
         assert any("global_load_lds" in ln for ln in body)
     src = open(os.path.join(b.CSRC, "fx_advect_lds.hip")).read()
