@@ -468,10 +468,11 @@ hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store,
 	auto lg = [](int v) { int k = 0; while ((1 << k) < v) ++k; return k; };
 	const int lgX = lg(g.X), lgY = lg(g.Y), lg_gx = lg(g.X / TX), lg_gy = lg(g.Y / TY);
 	const int tiles_xy = (g.X / TX) * (g.Y / TY);
-	// planes per workgroup.  Every chunk re-reads two planes, yet short chunks win: the workgroups over the plume (gathers) take
-	// several times longer than the rest, and 2048 workgroups of 16 planes balance that where 512 of 64 cannot (256^3 at step
-	// 25: 0.216 ms with 16, 0.219 with 8, 0.241 with 32, 0.258 with 64; 512^3: 1.52 / 1.53 / 1.56 / 1.63 ms for 16 / 32 / 64 / 128)
-	int zchunk = env_i("FLUIDX_ADVECT_ZCHUNK", 16);
+	// planes per workgroup.  Every chunk re-reads two planes.  While the far-tracing voxels were gathered inside this kernel the
+	// workgroups over the plume took several times longer than the rest and short chunks (2048 workgroups of 16 planes at 256^3)
+	// balanced that: 0.216 ms with 16, 0.219 with 8, 0.241 with 32, 0.258 with 64.  With those voxels deferred every workgroup costs
+	// the same: 16 / 32 / 64 planes measure 0.211 / 0.203 / 0.212 ms (fp32), 0.147 / 0.143 / 0.144 (fp16), within the noise -- 32.
+	int zchunk = env_i("FLUIDX_ADVECT_ZCHUNK", 32);
 	if (zchunk < 4) zchunk = 4;
 	if (zchunk > nzp) zchunk = nzp;
 	const int nchunks = (nzp + zchunk - 1) / zchunk;
