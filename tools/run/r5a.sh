@@ -3,7 +3,7 @@
 # PMC traffic and SQ counters (stamped with kernel source hashes), render cache counters, GPU test log.  Summaries are copied to profiles/r05a_*.
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r5a; mkdir -p $O
+O=gpurun_out/r5a; rm -rf $O; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_steps20_warmup5.json 2>> $O/bench.err
 python bench.py --config 2 --steps 100 --warmup 16 --no-cpu-baseline > $O/bench_128.json 2>> $O/bench.err

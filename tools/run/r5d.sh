@@ -3,7 +3,7 @@
 # kernel stats, per-launch trace of one step, PMC traffic and SQ counters (stamped with kernel source hashes).  Summaries -> profiles/r05b_*.
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r5d; mkdir -p $O
+O=gpurun_out/r5d; rm -rf $O; mkdir -p $O
 python bench.py --reference-config > $O/bench_reference.json 2> $O/bench.err
 python bench.py --reference-config --address mirror --no-cpu-baseline > $O/bench_reference_mirror.json 2>> $O/bench.err
 python bench.py --reference-config --grid 128 --no-cpu-baseline > $O/bench_reference_128.json 2>> $O/bench.err
