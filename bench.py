@@ -663,11 +663,19 @@ def main():
             sweeps = timing.freeze_sweeps / timing.freeze_solves           # what the reference's loop executes per solve (<= iters)
             algo = JACOBI_BYTES_PER_CELL_SWEEP * cells
             design = 16.25 * cells
+            # whole steps leave the divergence to this launch (no divergence launch was timed): SURVEY 8(d)'s V + S for it on top of the
+            # sweep's 12 B -- the kernel reads the advected velocity instead of b and writes b for the tile launches
+            fused_div = timing.divergence_ms == 0 and GX % 4 == 0
+            if fused_div:
+                Vb = 12.0 if args.storage == "fp32" else 6.0
+                algo += (Vb + 4.0) * cells
+                design += (Vb + 4.0 - 4.0) * cells                     # + velocity, + b written, - b read
             tr = pmc_traffic("k_freeze_dense", G, args.iters, args.storage, "faithful") if N == 1 else None
             use_tr = tr is not None and not tr[2]
             roof = {"bound": "hbm",
-                    "kernel": "k_freeze_dense (sweep 1 of the reference's <= %d-sweep solve for every cell; sweeps 2.. run in %d tile launches of "
-                              "k_freeze_tiles over the 32x8x8 tiles that still hold a relaxing cell: `sparse_solver`)" % (args.iters, tile_l // steps_m),
+                    "kernel": "k_freeze_dense (%ssweep 1 of the reference's <= %d-sweep solve for every cell; sweeps 2.. run in %d tile launches of "
+                              "k_freeze_tiles over the 32x8x8 tiles that still hold a relaxing cell: `sparse_solver`)" % ("the divergence + " if fused_div else "", args.iters, tile_l // steps_m),
+                    "fused_divergence": fused_div,
                     "achieved": algo / dense_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / dense_s / 1e9 / HBM_PEAK_GBS,
                     "traffic": tr[0] if use_tr else None, "traffic_source": tr[1] if tr else None, "stale": bool(tr and tr[2]),
                     "algorithmic_bytes_per_launch": algo, "design_bytes_per_launch": design,

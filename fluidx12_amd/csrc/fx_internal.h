@@ -93,7 +93,8 @@ int jacobi_freeze_levels_per_launch();
 // list[(n + 1) & 1] / counts[n + 1]; counts_next = the next solve's counters, cleared by this solve's dense launch
 struct FreezeWork { uint32_t* tile_mark; uint32_t gen; void* list[2]; int cap; uint32_t* counts; uint32_t* counts_next; };
 hipError_t launch_freeze_dense(const Geom& g, const float* p_in, const float* b, float* pA, float* pB, uint8_t* mA, uint8_t* mB,
-	const FreezeWork& w, hipStream_t s);
+	const FreezeWork& w, hipStream_t s, const void* vel = nullptr, int vel_half = 0);   // vel: compute (and store) the divergence of this velocity instead of reading b
+bool jacobi_freeze_can_fuse_divergence(const Geom& g);
 hipError_t launch_freeze_tiles(const Geom& g, const float* p_src, const float* b, float* p_dst, const uint8_t* m_src, uint8_t* m_dst,
 	const FreezeWork& w, int n, int levels, int level_base, uint32_t* stat, uint32_t stat_hi, hipStream_t s);
 // sweeps fused per launch for this geometry (1 = no fused path); requested > 0 overrides the default

@@ -47,6 +47,22 @@ __device__ unsigned int fz_passes[2][80];      // tile passes / copy-only entrie
 #define PROF_COUNT do { } while (0)
 #define PROF_COPY do { } while (0)
 #endif
+typedef _Float16 fz_h16;
+typedef _Float16 fz_h16x4 __attribute__((ext_vector_type(4)));
+// a velocity quad from its storage (FUSE 1: fp32, 2: binary16 -- the reference's RGBA16F), cell offset `off` of component plane `comp`
+template <int FUSE>
+__device__ __forceinline__ float4 ldv4(const void* vel, uint32_t comp_cells, int comp, uint32_t off)
+{
+	const size_t cell = (size_t)comp * comp_cells + off;
+	if (FUSE == 2) { const fz_h16x4 h = *reinterpret_cast<const fz_h16x4*>(static_cast<const fz_h16*>(vel) + cell); return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w); }
+	return *reinterpret_cast<const float4*>(static_cast<const float*>(vel) + cell);
+}
+template <int FUSE>
+__device__ __forceinline__ float ldv1(const void* vel, uint32_t off)
+{
+	return FUSE == 2 ? (float)static_cast<const fz_h16*>(vel)[off] : static_cast<const float*>(vel)[off];
+}
+
 constexpr int TCX = 32, TCY = 8, TCZ = 8;     // tile core (cells)
 constexpr int TQ = 10;                        // quads (4 x-cells) per staged row: the core's 8 + one halo quad per side
 constexpr float kFreezeBelow = 0.00100000005f;   // CSPoisson.hlsli:24 as compiled (0x3a83126f)
@@ -151,10 +167,13 @@ constexpr int kShards = 8;
 // ---------------------------------------------------------------------------------------------------------------------------
 // level 1, every cell.  Block = (bx quads, by rows), one plane per blockIdx slice, as k_jacobi_v4 (x neighbours by DPP).
 // ---------------------------------------------------------------------------------------------------------------------------
-template <bool AL>
+// FUSE != 0 (whole steps, rows of whole quads): the divergence is computed here from the advected velocity -- k_divergence_v4's
+// arithmetic, CSProject3D.hlsl:68-86 -- and written to `b_out` for the tile launches, instead of being read back from a launch of its own.
+template <bool AL, int FUSE>
 __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
 	float* __restrict__ pA, float* __restrict__ pB, uint8_t* __restrict__ mA, uint8_t* __restrict__ mB,
-	uint32_t* __restrict__ tile_mark, uint32_t gen, uint32_t* __restrict__ cnt_clear, int n_clear, int ntx, int nty, int rows_per_block)
+	uint32_t* __restrict__ tile_mark, uint32_t gen, uint32_t* __restrict__ cnt_clear, int n_clear, int ntx, int nty, int rows_per_block,
+	const void* __restrict__ vel, float* __restrict__ b_out)
 {
 	const int X4 = (g.X + 3) >> 2;
 	const int lane = threadIdx.x;
@@ -187,7 +206,24 @@ __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float*
 		const float4 D = ldq<AL>(p_in, zrow + (uint32_t)yd * g.X + 4 * x4, nv);
 		const float4 F = ldq<AL>(p_in, (uint32_t)zf * plane + (uint32_t)y * g.X + 4 * x4, nv);
 		const float4 Bk = ldq<AL>(p_in, (uint32_t)zb * plane + (uint32_t)y * g.X + 4 * x4, nv);
-		const float4 bb = ldq<AL>(b, c_off, nv);
+		float4 bb;
+		if (FUSE) {
+			const uint32_t vcells = (uint32_t)g.cells_local();
+			const float4 cx = ldv4<FUSE>(vel, vcells, 0, c_off);
+			const float4 vU = ldv4<FUSE>(vel, vcells, 1, zrow + (uint32_t)yu * g.X + 4 * x4);
+			const float4 vD = ldv4<FUSE>(vel, vcells, 1, zrow + (uint32_t)yd * g.X + 4 * x4);
+			const float4 vF = ldv4<FUSE>(vel, vcells, 2, (uint32_t)zf * plane + (uint32_t)y * g.X + 4 * x4);
+			const float4 vB = ldv4<FUSE>(vel, vcells, 2, (uint32_t)zb * plane + (uint32_t)y * g.X + 4 * x4);
+			float vL = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cx.w), 0x138, 0xf, 0xf, false));
+			float vR = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cx.x), 0x130, 0xf, 0xf, false));
+			if (x4 == 0) vL = cx.x; else if (wl == 0 || lane == 0) vL = ldv1<FUSE>(vel, c_off - 1);
+			if (x4 == X4 - 1) vR = cx.w; else if (wl == 63 || lane == (int)blockDim.x - 1) vR = ldv1<FUSE>(vel, c_off + 4);
+			bb.x = 0.5f * ((-vF.x + vB.x) + ((-vU.x + vD.x) + (-vL + cx.y)));
+			bb.y = 0.5f * ((-vF.y + vB.y) + ((-vU.y + vD.y) + (-cx.x + cx.z)));
+			bb.z = 0.5f * ((-vF.z + vB.z) + ((-vU.z + vD.z) + (-cx.y + cx.w)));
+			bb.w = 0.5f * ((-vF.w + vB.w) + ((-vU.w + vD.w) + (-cx.z + vR)));
+			*reinterpret_cast<float4*>(b_out + c_off) = bb;
+		} else bb = ldq<AL>(b, c_off, nv);
 		// x neighbours: the adjacent quad sits in the adjacent lane (DPP wave_shr:1 / wave_shl:1); only a wave's first / last lane
 		// inside a row still loads them
 		float L = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c.w), 0x138, 0xf, 0xf, false));
@@ -492,19 +528,25 @@ int jacobi_freeze_levels_per_launch()
 }
 
 hipError_t launch_freeze_dense(const Geom& g, const float* p_in, const float* b, float* pA, float* pB, uint8_t* mA, uint8_t* mB,
-	const FreezeWork& w, hipStream_t s)
+	const FreezeWork& w, hipStream_t s, const void* vel, int vel_half)
 {
 	const int X4 = (g.X + 3) >> 2;
 	const int bx = X4 < 64 ? X4 : 64;
 	int by = 256 / bx; if (by < 1) by = 1; if (by > g.Y) by = g.Y;
 	const int ntx = (g.X + TCX - 1) / TCX, nty = (g.Y + TCY - 1) / TCY;
 	const dim3 block(bx, by, 1), grid(((X4 + bx - 1) / bx) * ((g.Y + by - 1) / by) * g.Zg, 1, 1);
-	if ((g.X & 3) == 0) hipLaunchKernelGGL(k_freeze_dense<true>, grid, block, 0, s, g, p_in, b, pA, pB, mA, mB, w.tile_mark, w.gen,
-		w.counts_next, kFreezeSlots * kShards, ntx, nty, by);
-	else hipLaunchKernelGGL(k_freeze_dense<false>, grid, block, 0, s, g, p_in, b, pA, pB, mA, mB, w.tile_mark, w.gen,
-		w.counts_next, kFreezeSlots * kShards, ntx, nty, by);
+	float* b_out = const_cast<float*>(b);
+#define FX_DENSE(AL_, F_) hipLaunchKernelGGL((k_freeze_dense<AL_, F_>), grid, block, 0, s, g, p_in, b, pA, pB, mA, mB, w.tile_mark, w.gen, \
+		w.counts_next, kFreezeSlots * kShards, ntx, nty, by, vel, b_out)
+	if ((g.X & 3) != 0) { if (vel) return hipErrorInvalidValue; FX_DENSE(false, 0); }
+	else if (!vel) FX_DENSE(true, 0);
+	else if (vel_half) FX_DENSE(true, 2);
+	else FX_DENSE(true, 1);
+#undef FX_DENSE
 	return hipGetLastError();
 }
+
+bool jacobi_freeze_can_fuse_divergence(const Geom& g) { return (g.X & 3) == 0 && env_int("FLUIDX_FREEZE_FUSE_DIV", 1) != 0; }
 
 // launch number `n` (0, 1, ...) of a solve reads list[n & 1] and writes list[(n + 1) & 1]
 hipError_t launch_freeze_tiles(const Geom& g, const float* p_src, const float* b, float* p_dst, const uint8_t* m_src, uint8_t* m_dst,

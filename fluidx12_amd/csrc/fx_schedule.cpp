@@ -290,6 +290,12 @@ static int clear_freeze_masks(std::vector<fx_ctx*>& M, hipStream_t s)
 // the input buffer becomes the spare), then ceil((iters - 1) / T) launches over the tiles that still relax, all enqueued; the
 // result is in the last launch's output buffer (settled tiles agree in both).  Bit-identical to `iters` generic sweeps with the
 // byte mask (tests/test_gpu_sim.py::test_freeze_fast_path_*).
+// (a level fits the stat word's low byte, every launch has its counters)
+static bool takes_sparse_solver(const fx_ctx* c, uint32_t iters)
+{
+	return !multi_rank(c) && c->frozen && c->fz_tile_next && jacobi_freeze_supported(c->g) && iters <= 255 && (int)iters / jacobi_freeze_levels_per_launch() + 3 < kFreezeSlots;
+}
+
 static int jacobi_freeze(fx_ctx* ctx, hipStream_t s, uint32_t iters)
 {
 	DeviceGuard dg(ctx->device);
@@ -314,7 +320,11 @@ static int jacobi_freeze(fx_ctx* ctx, hipStream_t s, uint32_t iters)
 	// (The dense sweep writes level 1 to BOTH buffers the tile launches alternate between.  Writing one and letting the first tile
 	// launch carry the unlisted tiles' border cells across was built and measured level: the dense sweep 75 -> 46 us at 256^3, the
 	// first tile launch slower by as much -- the shell of a 4-deep cone around ~3000 listed tiles is more bytes than the second copy.)
-	FX_HIP(launch_freeze_dense(ctx->g, src, ctx->b, a, d, ma, md, w, s));
+	// whole steps (simulate_impl) leave the divergence to this launch: it computes b from the advected velocity and stores it for the
+	// tile launches, instead of reading it back from a launch of its own
+	const bool fuse = ctx->fz_fuse_div;
+	ctx->fz_fuse_div = false;
+	FX_HIP(launch_freeze_dense(ctx->g, src, ctx->b, a, d, ma, md, w, s, fuse ? ctx->vel[1] : nullptr, ctx->half));
 	mk.launches = 1; mk.sweeps = 1;
 	if (iters > 1) mk.split(MK_JACOBI_TAIL);                            // fx_timing books the dense sweep as the "main" launch, the tile launches beside it
 	const int T = jacobi_freeze_levels_per_launch();
@@ -336,8 +346,7 @@ static int jacobi_serial(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 	const bool multi = multi_rank(lead);
 	const int k = multi ? lead->opt_round : (int)iters;
 	int rc;
-	if (!multi && lead->frozen && lead->fz_tile_next && jacobi_freeze_supported(lead->g) && iters <= 255 && (int)iters / jacobi_freeze_levels_per_launch() + 3 < kFreezeSlots)   // a level fits the stat word's low byte, every launch has its counters
-		return jacobi_freeze(lead, s, iters);
+	if (takes_sparse_solver(lead, iters)) return jacobi_freeze(lead, s, iters);
 	if ((rc = clear_freeze_masks(M, s))) return rc;
 	const ExchSpec bspec{ EX_DIV, k - 1, 0 };
 	if ((rc = do_exchange(lead, M, &bspec, 1, s))) return rc;
@@ -509,7 +518,8 @@ int simulate_impl(fx_ctx* ctx, hipStream_t s)
 	if (ctx->time_step > 0.0f) {                       // CSProject3D.hlsl:88
 		const ExchSpec uz{ EX_UZ1, 1, 0 };
 		if ((rc = do_exchange(ctx, M, &uz, 1, s))) return rc;
-		for (fx_ctx* m : M) if ((rc = divergence_phase(m, s))) return rc;
+		if (takes_sparse_solver(ctx, ctx->desc.jacobi_iters) && jacobi_freeze_can_fuse_divergence(ctx->g)) ctx->fz_fuse_div = true;   // k_freeze_dense computes it
+		else for (fx_ctx* m : M) if ((rc = divergence_phase(m, s))) return rc;
 		if ((rc = jacobi_all(ctx, M, s, ctx->desc.jacobi_iters))) return rc;
 		for (fx_ctx* m : M) if ((rc = project_phase(m, s))) return rc;
 	} else {
