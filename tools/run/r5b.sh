@@ -13,7 +13,7 @@ rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 # the last step's launches in order: name, duration, gap to previous end
 names=[r['Kernel_Name'] for r in rows]
-last=max(i for i,n in enumerate(names) if 'k_advect' in n)
+last=max(i for i,n in enumerate(names) if 'k_advect' in n and 'k_advect_far' not in n)
 prev=None
 out=open('gpurun_out/r5b/last_step_%s.txt'%sys.argv[2],'w')
 for r in rows[last:]:

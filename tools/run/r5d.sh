@@ -22,7 +22,7 @@ import sys,glob,csv
 f=glob.glob(sys.argv[1]+'/**/*kernel_trace.csv',recursive=True)[0]
 rows=sorted(csv.DictReader(open(f)),key=lambda r:int(r['Start_Timestamp']))
 names=[r['Kernel_Name'] for r in rows]
-last=max(i for i,n in enumerate(names) if 'k_advect' in n)
+last=max(i for i,n in enumerate(names) if 'k_advect' in n and 'k_advect_far' not in n)
 out=open('gpurun_out/r5d/last_step_%s.txt'%sys.argv[2],'w')
 for r in rows[last:]:
     if 'rocclr' in r['Kernel_Name']: break
