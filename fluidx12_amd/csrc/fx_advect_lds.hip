@@ -472,7 +472,7 @@ hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store,
 	// workgroups over the plume took several times longer than the rest and short chunks (2048 workgroups of 16 planes at 256^3)
 	// balanced that: 0.216 ms with 16, 0.219 with 8, 0.241 with 32, 0.258 with 64.  With those voxels deferred every workgroup costs
 	// the same: 16 / 32 / 64 planes measure 0.211 / 0.203 / 0.212 ms (fp32), 0.147 / 0.143 / 0.144 (fp16), within the noise -- 32.
-	const bool want_defer = far_scratch && env_i("FLUIDX_ADVECT_DEFER", 1) != 0;   // (slab contexts lend no scratch: they keep 16)
+	const bool want_defer = far_scratch && env_i("FLUIDX_ADVECT_DEFER", 1) != 0;
 	int zchunk = env_i("FLUIDX_ADVECT_ZCHUNK", want_defer ? 32 : 16);
 	if (zchunk < 4) zchunk = 4;
 	if (zchunk > nzp) zchunk = nzp;
@@ -482,7 +482,7 @@ hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store,
 	// [a segment of 64 * TY * zchunk ids per workgroup] (FLUIDX_ADVECT_DEFER=0: gathered inside the staged kernel, as before)
 	const uint32_t nwg = (uint32_t)(tiles_xy * nchunks), far_cap = (uint32_t)(TX * TY * zchunk);
 	const size_t flat_words = (size_t)g.X * g.Y * (size_t)nzp;
-	const bool defer = want_defer && far_words >= 2 + flat_words + (size_t)nwg * far_cap;
+	const bool defer = want_defer && far_words >= 2 + flat_words + (size_t)nwg * far_cap && ((uint64_t)g.Zg << (lgX + lgY)) <= ((uint64_t)1 << 32);   // (a note = x | y << lgX | z << lgP)
 	if (far_used) *far_used = defer;                              // (the caller alternates far_parity over the launches that did defer)
 	uint32_t* far_total = far_scratch ? far_scratch + (far_parity & 1) : nullptr;
 	uint32_t* far_total_next = far_scratch ? far_scratch + ((far_parity & 1) ^ 1) : nullptr;

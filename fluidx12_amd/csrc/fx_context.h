@@ -33,7 +33,8 @@ struct fx_ctx {
 	uint32_t* fz_counts = nullptr;  // list lengths of two solves [2][kFreezeSlots launches][8 sub-lists]
 	uint32_t* fz_stat = nullptr;
 	bool fz_fuse_div = false;          // this step's divergence is left to the sparse solver's dense sweep (set by simulate_impl, consumed by jacobi_freeze)
-	uint32_t* adv_far = nullptr;       // scratch of the staged advection: the far-tracing voxels it defers (single-domain contexts; allocated at first use)
+	uint32_t* adv_far = nullptr;       // scratch of the staged advection: the far-tracing voxels it defers (allocated at the first advection)
+	bool adv_far_tried = false;
 	size_t adv_far_words = 0;
 	uint32_t adv_far_turn = 0;        // which of the scratch's two totals the next advection appends through
 	uint32_t fz_gen = 0;            // solves so far (tags tile marks and stat words)

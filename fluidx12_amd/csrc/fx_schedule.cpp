@@ -87,17 +87,18 @@ int advect_range(fx_ctx* ctx, hipStream_t s, Range r, bool own_only)
 	// (with FX_OPT_ADAPTIVE_HALO: only the planes this step's exchange carried, adv_w_lo / adv_w_hi <= halo_advect)
 	g.zlo = std::max(g.zlo, g.z0 - ctx->adv_w_lo); g.zhi = std::min(g.zhi, g.z0 + g.nz - 1 + ctx->adv_w_hi);
 	if (own_only) { g.zlo = std::max(g.zlo, g.z0); g.zhi = std::min(g.zhi, g.z0 + g.nz - 1); }
-	// a single domain lends the staged kernel scratch to put far-tracing voxels aside (slab contexts advect ranges on several streams
-	// at once: they keep the gathers inside the kernel)
-	if (!multi_rank(ctx) && !ctx->adv_far) {
-		const size_t words = advect_far_words(g, r.hi - r.lo);
-		if (words && r.lo == g.z0 && r.hi == g.z0 + g.nz) {
+	// the context lends the staged kernel scratch to put far-tracing voxels aside (sized for its owned planes at the first advection that
+	// could use it; every advection of a context runs on its compute stream, one after the other, so one scratch serves all its ranges)
+	if (!ctx->adv_far && !ctx->adv_far_tried) {
+		ctx->adv_far_tried = true;
+		const size_t words = advect_far_words(g, g.nz);
+		if (words) {
 			FX_HIP(hipMalloc((void**)&ctx->adv_far, words * sizeof(uint32_t)));
 			FX_HIP(hipMemsetAsync(ctx->adv_far, 0, 2 * sizeof(uint32_t), s));       // the two alternating totals
 			ctx->adv_far_words = words;
 		}
 	}
-	const bool lend = !multi_rank(ctx) && ctx->adv_far && r.lo == g.z0 && r.hi == g.z0 + g.nz;
+	const bool lend = ctx->adv_far != nullptr;
 	bool far_used = false;
 	FX_HIP(launch_advect(g, sp, ctx->half, ctx->vel[0], ctx->col[1 - par], ctx->vel[1], ctx->col[par],
 		r.lo, r.hi, ctx->halo_overflow, s, lend ? ctx->adv_far : nullptr, lend ? ctx->adv_far_words : 0, (int)(ctx->adv_far_turn & 1u), &far_used));
