@@ -14,12 +14,15 @@
 // fills the fourth slot straight from HBM, lane-linear -- a slot is laid out in the order the lanes enumerate its cells,
 // addressing (CLAMP / MIRROR, slab range) is applied to the SOURCE address.  Per voxel: own velocity from the LDS, back-trace,
 // and if every lane of the wave lands inside the +-1 window (a wave-uniform ballot) the 24 + 8 taps are LDS reads
-// (ds_read2_b32 / ds_read_b128, lanes = consecutive cells, conflict-free); a wave with a longer trace takes the gathers of
-// k_advect_fast from global memory, arithmetic unchanged.  Fields are read from HBM 1.29 x (the tile border) instead of
-// being gathered 8 x through L1/L2.  73.9 KiB of LDS per workgroup: two workgroups (16 waves) per CU.
+// (ds_read2_b32 / ds_read_b128, lanes = consecutive cells, conflict-free).  A voxel with a longer trace is put on a list and advected
+// by k_advect_far right behind this kernel, one thread per noted voxel, with the gathers of k_advect_fast, arithmetic unchanged
+// (round 3; before, its wave gathered inside this kernel and held the workgroup's barrier meanwhile: FLUIDX_ADVECT_DEFER=0).  Fields
+// are read from HBM 1.29 x (the tile border) instead of being gathered 8 x through L1/L2.  73.9 KiB of LDS per workgroup: two
+// workgroups (16 waves) per CU.
 //
 // Arithmetic, association order and rounding are those of k_advect / k_advect_fast: bit-identical outputs
-// (tests/test_gpu_sim.py::test_advect_lds_path_bit_identical).  Power-of-two extents, X >= 64, Y >= 8, fp32 storage.
+// (tests/test_gpu_sim.py::test_advect_lds_path_bit_identical, ::test_advect_deferred_voxels_over_changing_flows).  Power-of-two
+// extents, X >= 64, Y >= 8; fp32 or binary16 storage.
 #include "fx_internal.h"
 #include <cstdlib>
 #include <cstdio>

@@ -10,7 +10,9 @@
 //
 //   launch 1   k_freeze_dense   level 1 for every cell, streaming like k_jacobi_v4 (thread = 4 x-cells): p1 goes to TWO buffers
 //                               (A and B; the input lives in a third), the freeze mask (one byte per 4-cell quad, low nibble) to
-//                               two as well, and every 32 x 8 x 8-cell TILE that still has a relaxing cell is marked for launch 2
+//                               two as well, and every 32 x 8 x 8-cell TILE that still has a relaxing cell is marked for launch 2.
+//                               In whole steps it also computes the divergence from the advected velocity (and stores it for the
+//                               tile launches) instead of reading it back from a launch of its own.
 //   launch L   k_freeze_tiles<T> T more levels, A -> B -> A ..., only on the marked tiles: a workgroup stages the tile's cone
 //                               (40 x (8 + 2T)^2 cells of p, b and mask) in the LDS, relaxes level by level there (halo cells are
 //                               RECOMPUTED, their freeze decisions included -- the same deterministic arithmetic the owner tile
