@@ -93,9 +93,13 @@ int advect_range(fx_ctx* ctx, hipStream_t s, Range r, bool own_only)
 		ctx->adv_far_tried = true;
 		const size_t words = advect_far_words(g, g.nz);
 		if (words) {
-			FX_HIP(hipMalloc((void**)&ctx->adv_far, words * sizeof(uint32_t)));
-			FX_HIP(hipMemsetAsync(ctx->adv_far, 0, 2 * sizeof(uint32_t), s));       // the two alternating totals
-			ctx->adv_far_words = words;
+			if (hipMalloc((void**)&ctx->adv_far, words * sizeof(uint32_t)) == hipSuccess) {
+				FX_HIP(hipMemsetAsync(ctx->adv_far, 0, 2 * sizeof(uint32_t), s));   // the two alternating totals
+				ctx->adv_far_words = words;
+			} else {                                         // no room for the scratch: the staged kernel gathers far-tracing voxels itself
+				(void)hipGetLastError();
+				ctx->adv_far = nullptr;
+			}
 		}
 	}
 	const bool lend = ctx->adv_far != nullptr;
