@@ -525,7 +525,9 @@ int simulate_impl(fx_ctx* ctx, hipStream_t s)
 		if ((rc = do_exchange(ctx, M, &uz, 1, s))) return rc;
 		if (takes_sparse_solver(ctx, ctx->desc.jacobi_iters) && jacobi_freeze_can_fuse_divergence(ctx->g)) ctx->fz_fuse_div = true;   // k_freeze_dense computes it
 		else for (fx_ctx* m : M) if ((rc = divergence_phase(m, s))) return rc;
-		if ((rc = jacobi_all(ctx, M, s, ctx->desc.jacobi_iters))) return rc;
+		rc = jacobi_all(ctx, M, s, ctx->desc.jacobi_iters);
+		ctx->fz_fuse_div = false;                      // (consumed by the dense sweep; never left standing for a later stage call)
+		if (rc) return rc;
 		for (fx_ctx* m : M) if ((rc = project_phase(m, s))) return rc;
 	} else {
 		for (fx_ctx* m : M) {
