@@ -662,10 +662,32 @@ __device__ __forceinline__ void stw(float* base, uint32_t cell, const CellsW<W>&
 	*reinterpret_cast<vu*>(base + cell) = t;
 }
 
-template <int W>
-__global__ __launch_bounds__(256) void k_divergence_vw(const Geom g, const float* __restrict__ vel, float* __restrict__ b,
+// W cells of a velocity component in its storage type (binary16: pairs only -- an even row keeps them 4-byte aligned)
+template <int W, bool HALF>
+__device__ __forceinline__ CellsW<W> ldwv(const typename Store<HALF>::S* base, uint32_t cell)
+{
+	if constexpr (HALF) {
+		static_assert(W == 2, "binary16 rows are read in pairs");
+		CellsW<W> c;
+		Store<true>::ld2(base, cell, c.v[0], c.v[1]);
+		return c;
+	} else return ldw<W>(base, cell);
+}
+template <int W, bool HALF>
+__device__ __forceinline__ void stwv(typename Store<HALF>::S* base, uint32_t cell, const CellsW<W>& c)
+{
+	if constexpr (HALF) {
+		F16Pair h;
+		h.a = (h16)Store<true>::rounded_f32(c.v[0]); h.b = (h16)Store<true>::rounded_f32(c.v[1]);   // RNE in a separate step, as Store<true>::st
+		*reinterpret_cast<F16Pair*>(base + cell) = h;
+	} else stw<W>(base, cell, c);
+}
+
+template <int W, bool HALF>
+__global__ __launch_bounds__(256) void k_divergence_vw(const Geom g, const typename Store<HALF>::S* __restrict__ vel, float* __restrict__ b,
 	int z_begin, int nzp, int remap, int rows_per_block)
 {
+	typedef Store<HALF> St;
 	const int XW = g.X / W;
 	const Tile3 tile = xcd_tile((XW + (int)blockDim.x - 1) / (int)blockDim.x, (g.Y + rows_per_block - 1) / rows_per_block, nzp, remap);
 	const int xw = tile.x * blockDim.x + threadIdx.x;
@@ -676,12 +698,12 @@ __global__ __launch_bounds__(256) void k_divergence_vw(const Geom g, const float
 	const int yu = max(y, 1) - 1, yd = min(y + 1, g.Y - 1);
 	const int zf = max(z, 1) - 1, zb = min(z + 1, g.Zg - 1);
 	const uint32_t zrow = (uint32_t)g.lz(z) * plane, col = (uint32_t)(W * xw), off = zrow + (uint32_t)y * g.X + col;
-	const CellsW<W> cx = ldw<W>(vel, off);
-	const float L = xw > 0 ? vel[off - 1] : cx.v[0];
-	const float R = xw < XW - 1 ? vel[off + W] : cx.v[W - 1];
-	const CellsW<W> U = ldw<W>(vel, stride + zrow + (uint32_t)yu * g.X + col), D = ldw<W>(vel, stride + zrow + (uint32_t)yd * g.X + col);
-	const CellsW<W> F = ldw<W>(vel, 2u * stride + (uint32_t)g.lz(zf) * plane + (uint32_t)y * g.X + col);
-	const CellsW<W> B = ldw<W>(vel, 2u * stride + (uint32_t)g.lz(zb) * plane + (uint32_t)y * g.X + col);
+	const CellsW<W> cx = ldwv<W, HALF>(vel, off);
+	const float L = xw > 0 ? St::ld(vel, off - 1) : cx.v[0];
+	const float R = xw < XW - 1 ? St::ld(vel, off + W) : cx.v[W - 1];
+	const CellsW<W> U = ldwv<W, HALF>(vel, stride + zrow + (uint32_t)yu * g.X + col), D = ldwv<W, HALF>(vel, stride + zrow + (uint32_t)yd * g.X + col);
+	const CellsW<W> F = ldwv<W, HALF>(vel, 2u * stride + (uint32_t)g.lz(zf) * plane + (uint32_t)y * g.X + col);
+	const CellsW<W> B = ldwv<W, HALF>(vel, 2u * stride + (uint32_t)g.lz(zb) * plane + (uint32_t)y * g.X + col);
 	CellsW<W> o;
 #pragma unroll
 	for (int i = 0; i < W; ++i) {
@@ -691,9 +713,9 @@ __global__ __launch_bounds__(256) void k_divergence_vw(const Geom g, const float
 	stw<W>(b, off, o);
 }
 
-template <int W>
-__global__ __launch_bounds__(256) void k_project_vw(const Geom g, const float* __restrict__ vel_in, const float* __restrict__ p,
-	float* __restrict__ vel_out, int z_begin, int nzp, int remap, int rows_per_block)
+template <int W, bool HALF>
+__global__ __launch_bounds__(256) void k_project_vw(const Geom g, const typename Store<HALF>::S* __restrict__ vel_in, const float* __restrict__ p,
+	typename Store<HALF>::S* __restrict__ vel_out, int z_begin, int nzp, int remap, int rows_per_block)
 {
 	const int XW = g.X / W;
 	const Tile3 tile = xcd_tile((XW + (int)blockDim.x - 1) / (int)blockDim.x, (g.Y + rows_per_block - 1) / rows_per_block, nzp, remap);
@@ -711,7 +733,7 @@ __global__ __launch_bounds__(256) void k_project_vw(const Geom g, const float* _
 	const CellsW<W> U = ldw<W>(p, zrow + (uint32_t)yu * g.X + col), D = ldw<W>(p, zrow + (uint32_t)yd * g.X + col);
 	const CellsW<W> F = ldw<W>(p, (uint32_t)g.lz(zf) * plane + (uint32_t)y * g.X + col);
 	const CellsW<W> B = ldw<W>(p, (uint32_t)g.lz(zb) * plane + (uint32_t)y * g.X + col);
-	const CellsW<W> ux = ldw<W>(vel_in, off), uy = ldw<W>(vel_in, stride + off), uz = ldw<W>(vel_in, 2u * stride + off);
+	const CellsW<W> ux = ldwv<W, HALF>(vel_in, off), uy = ldwv<W, HALF>(vel_in, stride + off), uz = ldwv<W, HALF>(vel_in, 2u * stride + off);
 	const float k = __uint_as_float(0x3f855556u);                          // 0.5f / 0.48f (g_density, CSProject3D.hlsl:26)
 	float py = ((float)y + 0.5f) / (float)g.Y, pz = ((float)z + 0.5f) / (float)g.Zg;
 	py = fmaf(py, 2.0f, -1.0f); pz = fmaf(pz, 2.0f, -1.0f);
@@ -732,9 +754,9 @@ __global__ __launch_bounds__(256) void k_project_vw(const Geom g, const float* _
 		oy.v[i] = wy_ * ((0.0f < wy_ * py) ? fy : 1.0f);
 		oz.v[i] = wz_ * ((0.0f < wz_ * pz) ? fz : 1.0f);
 	}
-	stw<W>(vel_out, off, ox);
-	stw<W>(vel_out, stride + off, oy);
-	stw<W>(vel_out, 2u * stride + off, oz);
+	stwv<W, HALF>(vel_out, off, ox);
+	stwv<W, HALF>(vel_out, stride + off, oy);
+	stwv<W, HALF>(vel_out, 2u * stride + off, oz);
 }
 
 static int env_int(const char* name, int dflt);
@@ -742,7 +764,8 @@ static int env_int(const char* name, int dflt);
 static int vw_width(const Geom& g, int half_store)
 {
 	static const int on = env_int("FLUIDX_ROW_VW", 1);
-	if (!on || half_store || g.Zg <= 1 || g.cells_local() * 3 >= ((size_t)1 << 30)) return 0;
+	if (!on || g.Zg <= 1 || g.cells_local() * 3 >= ((size_t)1 << 30)) return 0;
+	if (half_store) return g.X % 2 == 0 ? 2 : 0;               // binary16: pairs (4-byte aligned in an even row)
 	return g.X % 3 == 0 ? 3 : (g.X % 2 == 0 ? 2 : 0);
 }
 
@@ -916,8 +939,9 @@ hipError_t launch_divergence(const Geom& g, int half_store, const void* vel, flo
 		const int bx = XW < 64 ? XW : 64;
 		int by = 256 / bx; if (by > g.Y) by = g.Y;
 		const dim3 block(bx, by, 1), grid(((XW + bx - 1) / bx) * ((g.Y + by - 1) / by) * nzp, 1, 1);
-		if (w == 3) hipLaunchKernelGGL(k_divergence_vw<3>, grid, block, 0, s, g, (const float*)vel, b, z_begin, nzp, xcd_remap_for(REMAP_DIV, g), by);
-		else hipLaunchKernelGGL(k_divergence_vw<2>, grid, block, 0, s, g, (const float*)vel, b, z_begin, nzp, xcd_remap_for(REMAP_DIV, g), by);
+		if (half_store) hipLaunchKernelGGL((k_divergence_vw<2, true>), grid, block, 0, s, g, (const h16*)vel, b, z_begin, nzp, xcd_remap_for(REMAP_DIV, g), by);
+		else if (w == 3) hipLaunchKernelGGL((k_divergence_vw<3, false>), grid, block, 0, s, g, (const float*)vel, b, z_begin, nzp, xcd_remap_for(REMAP_DIV, g), by);
+		else hipLaunchKernelGGL((k_divergence_vw<2, false>), grid, block, 0, s, g, (const float*)vel, b, z_begin, nzp, xcd_remap_for(REMAP_DIV, g), by);
 		return hipGetLastError();
 	}
 	const dim3 grid = grid_xyz(g, z_end - z_begin), block(64, 4, 1);
@@ -1088,8 +1112,9 @@ hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, co
 		const int bx = XW < 64 ? XW : 64;
 		int by = 256 / bx; if (by > g.Y) by = g.Y;
 		const dim3 block(bx, by, 1), grid(((XW + bx - 1) / bx) * ((g.Y + by - 1) / by) * nzp, 1, 1);
-		if (w == 3) hipLaunchKernelGGL(k_project_vw<3>, grid, block, 0, s, g, (const float*)vel_in, p, (float*)vel_out, z_begin, nzp, xcd_remap_for(REMAP_PROJECT, g), by);
-		else hipLaunchKernelGGL(k_project_vw<2>, grid, block, 0, s, g, (const float*)vel_in, p, (float*)vel_out, z_begin, nzp, xcd_remap_for(REMAP_PROJECT, g), by);
+		if (half_store) hipLaunchKernelGGL((k_project_vw<2, true>), grid, block, 0, s, g, (const h16*)vel_in, p, (h16*)vel_out, z_begin, nzp, xcd_remap_for(REMAP_PROJECT, g), by);
+		else if (w == 3) hipLaunchKernelGGL((k_project_vw<3, false>), grid, block, 0, s, g, (const float*)vel_in, p, (float*)vel_out, z_begin, nzp, xcd_remap_for(REMAP_PROJECT, g), by);
+		else hipLaunchKernelGGL((k_project_vw<2, false>), grid, block, 0, s, g, (const float*)vel_in, p, (float*)vel_out, z_begin, nzp, xcd_remap_for(REMAP_PROJECT, g), by);
 		return hipGetLastError();
 	}
 	const dim3 grid = grid_xyz(g, z_end - z_begin), block(64, 4, 1);

@@ -554,7 +554,7 @@ def test_advect_deferred_voxels_over_changing_flows(monkeypatch):
         assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32)), k
 
 
-@pytest.mark.parametrize("grid,steps,storage", [(256, 40, "fp32"), (128, 60, "fp32"), (256, 24, "fp16"), (150, 30, "fp32")])
+@pytest.mark.parametrize("grid,steps,storage", [(256, 40, "fp32"), (128, 60, "fp32"), (256, 24, "fp16"), (150, 30, "fp32"), (150, 24, "fp16")])
 def test_round2_kernels_reproduce_the_round1_kernels_over_a_whole_run(grid, steps, storage):
     """the kernels added in round 2 (LDS-staged advection, cooperative three-sweep strips, the X = 128 block kernel, four-cell
     projection / divergence) against the ones they replaced, over a whole run from the zero state at full BASELINE size: the plume
