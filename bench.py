@@ -665,7 +665,7 @@ def main():
             design = 16.25 * cells
             # whole steps leave the divergence to this launch (no divergence launch was timed): SURVEY 8(d)'s V + S for it on top of the
             # sweep's 12 B -- the kernel reads the advected velocity instead of b and writes b for the tile launches
-            fused_div = timing.divergence_ms == 0 and GX % 4 == 0
+            fused_div = timing.divergence_ms == 0
             if fused_div:
                 Vb = 12.0 if args.storage == "fp32" else 6.0
                 algo += (Vb + 4.0) * cells

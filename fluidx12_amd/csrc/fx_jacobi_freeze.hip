@@ -139,6 +139,29 @@ __device__ __forceinline__ void stq(float* __restrict__ base_, uint32_t off, int
 	if (nv > 2) base[off + 2] = v.z;
 }
 
+// a velocity quad of a row of any length (AL = false: cell by cell where the quad is short or unaligned; the cells a short last quad
+// does not have repeat the wall cell, which is what the clamped stencil reads there)
+template <bool AL, int FUSE>
+__device__ __forceinline__ float4 ldvq(const void* vel, uint32_t comp_cells, int comp, uint32_t off, int nv)
+{
+	if (AL) return ldv4<FUSE>(vel, comp_cells, comp, off);
+	if (FUSE == 2) {
+		const fz_h16* h = static_cast<const fz_h16*>(vel) + (size_t)comp * comp_cells + off;
+		float4 c;
+		if (nv == 4) {
+			typedef fz_h16x4 __attribute__((aligned(2))) fz_h16x4u;
+			const fz_h16x4u t = *reinterpret_cast<const fz_h16x4u*>(h);
+			return make_float4((float)t.x, (float)t.y, (float)t.z, (float)t.w);
+		}
+		c.x = (float)h[0];
+		c.y = nv > 1 ? (float)h[1] : c.x;
+		c.z = nv > 2 ? (float)h[2] : c.y;
+		c.w = nv > 3 ? (float)h[3] : c.z;
+		return c;
+	}
+	return ldq<false>(static_cast<const float*>(vel) + (size_t)comp * comp_cells, off, nv);
+}
+
 // OR over the wave (every lane active), returned in every lane: four row rotations, then the four rows through SGPRs
 __device__ __forceinline__ uint32_t wave_or(uint32_t v)
 {
@@ -169,7 +192,7 @@ constexpr int kShards = 8;
 // ---------------------------------------------------------------------------------------------------------------------------
 // level 1, every cell.  Block = (bx quads, by rows), one plane per blockIdx slice, as k_jacobi_v4 (x neighbours by DPP).
 // ---------------------------------------------------------------------------------------------------------------------------
-// FUSE != 0 (whole steps, rows of whole quads): the divergence is computed here from the advected velocity -- k_divergence_v4's
+// FUSE != 0 (whole steps): the divergence is computed here from the advected velocity -- k_divergence_v4's
 // arithmetic, CSProject3D.hlsl:68-86 -- and written to `b_out` for the tile launches, instead of being read back from a launch of its own.
 template <bool AL, int FUSE>
 __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
@@ -211,11 +234,11 @@ __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float*
 		float4 bb;
 		if (FUSE) {
 			const uint32_t vcells = (uint32_t)g.cells_local();
-			const float4 cx = ldv4<FUSE>(vel, vcells, 0, c_off);
-			const float4 vU = ldv4<FUSE>(vel, vcells, 1, zrow + (uint32_t)yu * g.X + 4 * x4);
-			const float4 vD = ldv4<FUSE>(vel, vcells, 1, zrow + (uint32_t)yd * g.X + 4 * x4);
-			const float4 vF = ldv4<FUSE>(vel, vcells, 2, (uint32_t)zf * plane + (uint32_t)y * g.X + 4 * x4);
-			const float4 vB = ldv4<FUSE>(vel, vcells, 2, (uint32_t)zb * plane + (uint32_t)y * g.X + 4 * x4);
+			const float4 cx = ldvq<AL, FUSE>(vel, vcells, 0, c_off, nv);
+			const float4 vU = ldvq<AL, FUSE>(vel, vcells, 1, zrow + (uint32_t)yu * g.X + 4 * x4, nv);
+			const float4 vD = ldvq<AL, FUSE>(vel, vcells, 1, zrow + (uint32_t)yd * g.X + 4 * x4, nv);
+			const float4 vF = ldvq<AL, FUSE>(vel, vcells, 2, (uint32_t)zf * plane + (uint32_t)y * g.X + 4 * x4, nv);
+			const float4 vB = ldvq<AL, FUSE>(vel, vcells, 2, (uint32_t)zb * plane + (uint32_t)y * g.X + 4 * x4, nv);
 			float vL = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cx.w), 0x138, 0xf, 0xf, false));
 			float vR = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cx.x), 0x130, 0xf, 0xf, false));
 			if (x4 == 0) vL = cx.x; else if (wl == 0 || lane == 0) vL = ldv1<FUSE>(vel, c_off - 1);
@@ -224,7 +247,7 @@ __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float*
 			bb.y = 0.5f * ((-vF.y + vB.y) + ((-vU.y + vD.y) + (-cx.x + cx.z)));
 			bb.z = 0.5f * ((-vF.z + vB.z) + ((-vU.z + vD.z) + (-cx.y + cx.w)));
 			bb.w = 0.5f * ((-vF.w + vB.w) + ((-vU.w + vD.w) + (-cx.z + vR)));
-			*reinterpret_cast<float4*>(b_out + c_off) = bb;
+			stq<AL>(b_out, c_off, nv, bb);
 		} else bb = ldq<AL>(b, c_off, nv);
 		// x neighbours: the adjacent quad sits in the adjacent lane (DPP wave_shr:1 / wave_shl:1); only a wave's first / last lane
 		// inside a row still loads them
@@ -540,7 +563,7 @@ hipError_t launch_freeze_dense(const Geom& g, const float* p_in, const float* b,
 	float* b_out = const_cast<float*>(b);
 #define FX_DENSE(AL_, F_) hipLaunchKernelGGL((k_freeze_dense<AL_, F_>), grid, block, 0, s, g, p_in, b, pA, pB, mA, mB, w.tile_mark, w.gen, \
 		w.counts_next, kFreezeSlots * kShards, ntx, nty, by, vel, b_out)
-	if ((g.X & 3) != 0) { if (vel) return hipErrorInvalidValue; FX_DENSE(false, 0); }
+	if ((g.X & 3) != 0) { if (!vel) FX_DENSE(false, 0); else if (vel_half) FX_DENSE(false, 2); else FX_DENSE(false, 1); }
 	else if (!vel) FX_DENSE(true, 0);
 	else if (vel_half) FX_DENSE(true, 2);
 	else FX_DENSE(true, 1);
@@ -548,7 +571,7 @@ hipError_t launch_freeze_dense(const Geom& g, const float* p_in, const float* b,
 	return hipGetLastError();
 }
 
-bool jacobi_freeze_can_fuse_divergence(const Geom& g) { return (g.X & 3) == 0 && env_int("FLUIDX_FREEZE_FUSE_DIV", 1) != 0; }
+bool jacobi_freeze_can_fuse_divergence(const Geom& g) { (void)g; return env_int("FLUIDX_FREEZE_FUSE_DIV", 1) != 0; }
 
 // launch number `n` (0, 1, ...) of a solve reads list[n & 1] and writes list[(n + 1) & 1]
 hipError_t launch_freeze_tiles(const Geom& g, const float* p_src, const float* b, float* p_dst, const uint8_t* m_src, uint8_t* m_dst,
