@@ -60,7 +60,7 @@ def test_advect_lds_hands_over_behind_exactly_four_stores(tmp_path):
 
 def test_no_scratch_in_the_hot_kernels(tmp_path):
     """register-resident kernels must not spill (a spill turns a bandwidth-bound kernel into a scratch-bound one silently)"""
-    for source, prefix in (("fx_jacobi_freeze.hip", "k_freeze_"), ("fx_advect_lds.hip", "k_advect_lds")):
+    for source, prefix in (("fx_jacobi_freeze.hip", "k_freeze_"), ("fx_advect_lds.hip", "k_advect_lds"), ("fx_advect_lds.hip", "k_advect_far")):
         text = "\n".join(device_isa(source, tmp_path))
         for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
             if prefix in m.group(1):
