@@ -16,8 +16,8 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libfluidx_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 
-SOURCES = ["fx_api.cpp", "fx_context.cpp", "fx_schedule.cpp", "fx_comm.cpp", "fx_checkpoint.cpp", "fx_sim.hip", "fx_advect_lds.hip", "fx_jacobi_strip.hip", "fx_jacobi_strip3.hip", "fx_jacobi_block.hip", "fx_jacobi_freeze.hip", "fx_render.hip", "fx_resolve.hip", "fx_bc6h.hip", "fx_sh.hip"]
-HEADERS = ["fx_internal.h", "fx_context.h", "fx_host.h", "fx_hostmath.h", "fx_pk.h", os.path.join(ROOT, "include", "fluidx_hip.h")]
+SOURCES = ["fx_api.cpp", "fx_context.cpp", "fx_schedule.cpp", "fx_comm.cpp", "fx_checkpoint.cpp", "fx_sim.hip", "fx_advect_lds.hip", "fx_jacobi_strip.hip", "fx_jacobi_strip3.hip", "fx_jacobi_block.hip", "fx_jacobi_freeze.hip", "fx_render.hip", "fx_render_accel.hip", "fx_resolve.hip", "fx_bc6h.hip", "fx_sh.hip"]
+HEADERS = ["fx_internal.h", "fx_context.h", "fx_host.h", "fx_hostmath.h", "fx_pk.h", "fx_march.h", os.path.join(ROOT, "include", "fluidx_hip.h")]
 
 # -ffp-contract=off: the numerics contract allows a fused multiply-add only where the code
 # says fmaf(); everything else is separately rounded, like the oracle.
@@ -31,6 +31,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # bit-identical (tests/test_gpu_sim.py).
 EXTRA_FLAGS = {"fx_jacobi_strip3.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] + (["-DFX_STRIP3C_ROWS=" + os.environ["FLUIDX_BUILD_STRIP3C_ROWS"]] if os.environ.get("FLUIDX_BUILD_STRIP3C_ROWS") else []),
                "fx_jacobi_strip.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+               "fx_render_accel.hip": [("-D%s=%s" % (d, os.environ[e])) for e, d in (("FLUIDX_BUILD_MASK_BITS", "FX_MASK_BUDGET_BITS"), ("FLUIDX_BUILD_VIEW_AHEAD", "FX_VIEW_AHEAD"), ("FLUIDX_BUILD_LIGHT_AHEAD", "FX_LIGHT_AHEAD")) if os.environ.get(e)],
                # k_freeze_tiles reserves its list slot with a returning atomic whose round trip is meant to pass behind the staging loads;
                # the wave-aggregating atomic optimizer would wait for it on the spot (readfirstlane of the result)
                "fx_jacobi_freeze.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"] + (["-DFX_FREEZE_PROF"] if os.environ.get("FLUIDX_BUILD_FREEZE_PROF") else [])}     # 256x256x64: 8.9 -> 8.1 us per sweep; 512x512x64: 19.0 -> 18.8
@@ -51,6 +52,8 @@ def kernel_source_hash(kernel):
             h = hashlib.sha256()
             h.update(text)
             h.update(open(os.path.join(CSRC, "fx_pk.h"), "rb").read())
+            if b'#include "fx_march.h"' in text:                # the marches of the render kernels live in this header
+                h.update(open(os.path.join(CSRC, "fx_march.h"), "rb").read())
             h.update(" ".join(FLAGS + EXTRA_FLAGS.get(s, [])).encode())
             return h.hexdigest()[:16]
     return None

@@ -17,7 +17,7 @@ STORAGE_FP32, STORAGE_FP16 = 0, 1
 JACOBI_FIXED, JACOBI_FAITHFUL = 0, 1
 ADDRESS_CLAMP, ADDRESS_MIRROR = 0, 1
 FLAG_JACOBI_FUSE_MASK, FLAG_NO_OVERLAP, FLAG_RENDER_ONLY = 0xF, 0x10, 0x20
-OPT_OVERLAP, OPT_JACOBI_ROUND, OPT_ADAPTIVE_HALO, OPT_COUNT_SAMPLES = 1, 2, 3, 4
+OPT_OVERLAP, OPT_JACOBI_ROUND, OPT_ADAPTIVE_HALO, OPT_COUNT_SAMPLES, OPT_RENDER_ACCEL = 1, 2, 3, 4, 5
 ABI_VERSION = 5                      # FX_ABI_VERSION of include/fluidx_hip.h
 (FIELD_VELOCITY, FIELD_VELOCITY1, FIELD_COLOR, FIELD_COLOR_PREV, FIELD_PRESSURE, FIELD_DIVERGENCE,
  FIELD_LIGHTMAP, FIELD_CUBEMAP, FIELD_TARGET, FIELD_TARGET_FLOAT) = range(10)

@@ -126,15 +126,47 @@ static int ensure_target(fx_ctx* ctx, hipStream_t s)
 	return FX_OK;
 }
 
-// the occupancy grid of this frame's colour field (FLUIDX_RENDER_OCCUPANCY=0 switches the empty-space skipping off: A/B runs);
-// its cost is booked on the light/view pass that follows
-static const float* render_occupancy(fx_ctx* ctx, const void* color, hipStream_t s)
-{
-	const char* e = std::getenv("FLUIDX_RENDER_OCCUPANCY");
-	if ((e && e[0] == '0') || !ctx->occ) return nullptr;
-	if (launch_occupancy(ctx->g, ctx->half, color, ctx->occ, s) != hipSuccess) return nullptr;
-	return ctx->occ;
-}
+// The marches of one fx_render.  FX_OPT_RENDER_ACCEL (default): the acceleration structures of this frame's colour field are built
+// first, inside the first pass's timing mark -- their cost belongs to the frame.
+struct Marches {
+	fx_ctx* c; const void* color; hipStream_t s; unsigned long long* cnt; bool accel, built;
+	Marches(fx_ctx* ctx, const void* col, hipStream_t st, unsigned long long* counters)
+		: c(ctx), color(col), s(st), cnt(counters), accel(ctx->opt_render_accel && ctx->accel_ok), built(false) {}
+	const float* sh() const { return c->has_sh ? c->sh_dev : nullptr; }
+	hipError_t build()
+	{
+		if (!accel || built) return hipSuccess;
+		built = true;
+		return launch_accel_build(c->g, c->half, color, c->accel, s);
+	}
+	hipError_t light()                                  // Fluid.cpp:857-878
+	{
+		hipError_t e = build();
+		if (e != hipSuccess) return e;
+		if (accel) return launch_accel_light(c->g, c->accel, c->lightmap, c->fc, sh(), c->max_light_samples, s, cnt);
+		return launch_raymarch_light(c->g, c->half, color, c->lightmap, c->fc, sh(), c->max_light_samples, s, cnt);
+	}
+	hipError_t view(int size, uint8_t* cube, bool separate)   // Fluid.cpp:880-908 (separate) / :825-855 (merged)
+	{
+		hipError_t e = build();
+		if (e != hipSuccess) return e;
+		const uint32_t ns = c->ray_samples;
+		if (accel) return launch_accel_view(c->g, c->half, color, separate ? c->lightmap : nullptr, c->fc, separate ? nullptr : sh(), size,
+			c->visibility_mask, ns, c->max_light_samples, separate, cube, c->accel, s, cnt);
+		return launch_raymarch_view(c->g, c->half, color, separate ? c->lightmap : nullptr, c->fc, separate ? nullptr : sh(), size,
+			c->visibility_mask, ns, c->max_light_samples, separate, cube, s, cnt);
+	}
+	hipError_t direct(int W, int H, bool separate)      // rayCastVDirect Fluid.cpp:953-972 / rayCastDirect :932-951
+	{
+		hipError_t e = build();
+		if (e != hipSuccess) return e;
+		const uint32_t ns = separate ? c->ray_samples : c->max_ray_samples;
+		if (accel) return launch_accel_direct(c->g, c->half, color, separate ? c->lightmap : nullptr, c->fc, separate ? nullptr : sh(), W, H,
+			ns, c->max_light_samples, separate, c->target, c->target_float, c->accel, s, cnt);
+		return launch_raycast_direct(c->g, c->half, color, separate ? c->lightmap : nullptr, c->fc, separate ? nullptr : sh(), W, H,
+			ns, c->max_light_samples, separate, c->target, c->target_float, s, cnt);
+	}
+};
 
 int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags)
 {
@@ -156,55 +188,32 @@ int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags)
 	if (ctx->g.nz != ctx->g.Zg) return FX_E_INVALID;            // rays cross slabs: multi-GPU rendering is row f-3
 	unsigned long long* cnt = ctx->opt_count_samples ? ctx->sample_counters : nullptr;
 	if (cnt && (flags & FX_SEPARATE_LIGHT_PASS)) ctx->acc.light_samples += (uint64_t)ctx->g.cells_owned();   // the light pass's own fetch per voxel
+	DeviceGuard dg(ctx->device);
+	hipStream_t s = pick_stream(ctx, stream);
+	Marches m(ctx, ctx->col[ctx->frame_parity], s, cnt);
+	const bool separate = (flags & FX_SEPARATE_LIGHT_PASS) != 0;
 	if (!(flags & FX_RAY_MARCH_CUBEMAP)) {
 		// direct screen-space marching (Fluid.cpp:432-443): one ray per pixel, straight onto the render target
-		DeviceGuard dgd(ctx->device);
-		hipStream_t sd = pick_stream(ctx, stream);
-		int rc = ensure_target(ctx, sd);
+		int rc = ensure_target(ctx, s);
 		if (rc) return rc;
-		const void* colord = ctx->col[ctx->frame_parity];
-		const int W = (int)ctx->desc.viewport_w, H = (int)ctx->desc.viewport_h;
-		const float* occd = nullptr;                        // built inside the first pass's timing mark: its cost belongs to the frame
-		if (flags & FX_SEPARATE_LIGHT_PASS) {
-			{
-				ScopedMark mk(ctx, sd, MK_LIGHT);
-				occd = render_occupancy(ctx, colord, sd);
-				FX_HIP(launch_raymarch_light(ctx->g, ctx->half, colord, ctx->lightmap, ctx->fc,
-					ctx->has_sh ? ctx->sh_dev : nullptr, ctx->max_light_samples, occd, sd, cnt));
-			}
-			ScopedMark mk(ctx, sd, MK_VIEW);
-			FX_HIP(launch_raycast_direct(ctx->g, ctx->half, colord, ctx->lightmap, ctx->fc, nullptr, W, H,
-				ctx->ray_samples, ctx->max_light_samples, 1, ctx->target, ctx->target_float, occd, sd, cnt));   // rayCastVDirect :953-972
-		} else {
-			ScopedMark mk(ctx, sd, MK_VIEW);
-			occd = render_occupancy(ctx, colord, sd);
-			FX_HIP(launch_raycast_direct(ctx->g, ctx->half, colord, nullptr, ctx->fc, ctx->has_sh ? ctx->sh_dev : nullptr, W, H,
-				ctx->max_ray_samples, ctx->max_light_samples, 0, ctx->target, ctx->target_float, occd, sd, cnt));   // rayCastDirect :932-951
+		if (separate) {
+			ScopedMark mk(ctx, s, MK_LIGHT);
+			FX_HIP(m.light());
 		}
+		ScopedMark mk(ctx, s, MK_VIEW);
+		FX_HIP(m.direct((int)ctx->desc.viewport_w, (int)ctx->desc.viewport_h, separate));
 		if (ctx->timing_on) ctx->acc.renders += 1;
 		return FX_OK;
 	}
-	hipStream_t s = pick_stream(ctx, stream);
-	DeviceGuard dg(ctx->device);
-	const void* color = ctx->col[ctx->frame_parity];
 	const int size = ctx->g.X >> ctx->cube_lod;
 	uint8_t* cube = ctx->cube + ctx->cube_mip_offset[ctx->cube_lod];
-	const float* occ = nullptr;
-	if (flags & FX_SEPARATE_LIGHT_PASS) {
-		{
-			ScopedMark mk(ctx, s, MK_LIGHT);
-			occ = render_occupancy(ctx, color, s);
-			FX_HIP(launch_raymarch_light(ctx->g, ctx->half, color, ctx->lightmap, ctx->fc,
-				ctx->has_sh ? ctx->sh_dev : nullptr, ctx->max_light_samples, occ, s, cnt));     // Fluid.cpp:857-878
-		}
+	if (separate) {
+		ScopedMark mk(ctx, s, MK_LIGHT);
+		FX_HIP(m.light());
+	}
+	{
 		ScopedMark mk(ctx, s, MK_VIEW);
-		FX_HIP(launch_raymarch_view(ctx->g, ctx->half, color, ctx->lightmap, ctx->fc, nullptr, size,
-			ctx->visibility_mask, ctx->ray_samples, ctx->max_light_samples, 1, cube, occ, s, cnt));   // Fluid.cpp:880-908
-	} else {
-		ScopedMark mk(ctx, s, MK_VIEW);
-		occ = render_occupancy(ctx, color, s);
-		FX_HIP(launch_raymarch_view(ctx->g, ctx->half, color, nullptr, ctx->fc, ctx->has_sh ? ctx->sh_dev : nullptr,
-			size, ctx->visibility_mask, ctx->ray_samples, ctx->max_light_samples, 0, cube, occ, s, cnt));   // Fluid.cpp:825-855
+		FX_HIP(m.view(size, cube, separate));
 	}
 	if (ctx->timing_on) ctx->acc.renders += 1;
 	return FX_OK;

@@ -61,7 +61,7 @@ void free_all(fx_ctx* c)
 		if (c->col[i]) (void)hipFree(c->col[i]);
 		if (c->p[i]) (void)hipFree(c->p[i]);
 	}
-	void* others[] = { c->env, c->occ, c->target, c->target_float, c->p_face[0], c->p_face[1], c->b, c->frozen, c->lightmap, c->cube, c->sh_dev, c->halo_overflow, c->stage,
+	void* others[] = { c->env, c->accel.occ, c->accel.alpha, c->accel.bits, c->accel.list, c->accel.ctr, c->target, c->target_float, c->p_face[0], c->p_face[1], c->b, c->frozen, c->lightmap, c->cube, c->sh_dev, c->halo_overflow, c->stage,
 		c->sh_scratch[0], c->sh_scratch[1], c->sh_scratch[2], c->sh_scratch[3], c->p_aux, c->fz_mask[0], c->fz_mask[1], c->fz_tile_next, c->fz_stat, c->fz_list[0], c->fz_list[1], c->fz_counts, c->sample_counters, c->adv_far };
 	for (void* q : others) if (q) (void)hipFree(q);
 	for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -190,8 +190,19 @@ int fx_create(fx_ctx** out, const fx_desc* d)
 			}
 			FX_HIP(hipMalloc((void**)&ctx->cube, off));
 			FX_HIP(hipMemsetAsync(ctx->cube, 0, off, ctx->stream));
-			const size_t ncell = (size_t)((d->grid_x + 3) / 4) * ((d->grid_y + 3) / 4) * ((d->grid_z + 3) / 4);
-			FX_HIP(hipMalloc((void**)&ctx->occ, 2 * ncell * sizeof(float)));       // the grid + the per-block maxima it is dilated from
+			if (!slab) {                                                         // rays cross slabs: only whole grids render
+				RenderAccel& A = ctx->accel;
+				render_accel_layout(ctx->g, &A);
+				const size_t ncell = (size_t)A.CX * A.CY * A.CZ, vox = ctx->g.cells_owned(), bw = render_accel_bits_words(A);
+				FX_HIP(hipMalloc((void**)&A.occ, 2 * ncell * sizeof(float)));     // the grid + the per-block maxima it is dilated from
+				FX_HIP(hipMalloc((void**)&A.alpha, vox * sizeof(float)));
+				FX_HIP(hipMalloc((void**)&A.bits, bw * sizeof(uint32_t)));
+				FX_HIP(hipMemsetAsync(A.bits, 0, bw * sizeof(uint32_t), ctx->stream));
+				FX_HIP(hipMalloc((void**)&A.list, vox * sizeof(uint32_t)));
+				FX_HIP(hipMalloc((void**)&A.ctr, render_accel_ctr_words(ctx->g) * sizeof(uint32_t)));
+				FX_HIP(hipMemsetAsync(A.ctr, 0, render_accel_ctr_words(ctx->g) * sizeof(uint32_t), ctx->stream));
+				ctx->accel_ok = true;
+			}
 			FX_HIP(hipMalloc((void**)&ctx->sh_dev, 27 * sizeof(float)));
 			FX_HIP(hipMemsetAsync(ctx->sh_dev, 0, 27 * sizeof(float), ctx->stream));
 		}
@@ -468,6 +479,10 @@ int fx_set_option(fx_ctx* ctx, uint32_t option, uint32_t value)
 	case FX_OPT_OVERLAP: if (value > 3) return FX_E_INVALID; slot = &ctx->opt_overlap; break;
 	case FX_OPT_JACOBI_ROUND: if (value < 1 || value > ctx->desc.halo_jacobi) return FX_E_INVALID; slot = &ctx->opt_round; break;
 	case FX_OPT_ADAPTIVE_HALO: if (value > 1) return FX_E_INVALID; slot = &ctx->opt_adaptive; break;
+	case FX_OPT_RENDER_ACCEL:                          // local to the context: which kernels its renders run
+		if (value > 1) return FX_E_INVALID;
+		ctx->opt_render_accel = (int)value;
+		return FX_OK;
 	case FX_OPT_COUNT_SAMPLES: {                       // local to the context: statistics of its own renders
 		if (value > 1) return FX_E_INVALID;
 		DeviceGuard dgc(ctx->device);

@@ -45,7 +45,9 @@ struct fx_ctx {
 	size_t cube_mip_offset[5];
 	float* env;                     // radiance cube of the sky pass, float [6][env_n][env_n][3] (fx_set_environment)
 	uint32_t env_n;
-	float* occ;                     // occupancy grid of the ray marches: max alpha per 4^3 block (+1 voxel), rebuilt per fx_render
+	fx::RenderAccel accel = {};     // scratch of the accelerated ray marches (occupancy grid + masks, alpha side volume, light-voxel list), rebuilt per fx_render
+	bool accel_ok = false;          // ... and whether all of it could be allocated
+	int opt_render_accel = 1;       // FX_OPT_RENDER_ACCEL
 	uint8_t* target;                // W x H RGBA8 render target of the cube resolve (lazily allocated)
 	float* target_float;            // the resolve's SV_TARGET before the output merger (parity tests; lazily allocated)
 	float* sh_dev;                  // 27 floats

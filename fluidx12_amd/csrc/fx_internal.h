@@ -116,21 +116,43 @@ hipError_t launch_copy_velocity(const Geom& g, int half_store, const void* vel_i
 hipError_t launch_to_storage(const float* src, void* dst, size_t n, int half_store, hipStream_t s);
 hipError_t launch_from_storage(const void* src, float* dst, size_t n, int half_store, hipStream_t s);
 
-// ---- ray march launchers (fx_render.hip)
+// ---- ray march launchers
 // counters (FX_OPT_COUNT_SAMPLES, else null): 64 shards x { colour samples of view rays, density samples of light / AO rays, light-map
 // fetches }, added to by every thread that took one
 const int kSampleShards = 64;
-// `occ` (may be null) = the occupancy grid of launch_occupancy: lets the marches skip the gathers of empty space, bit-identically
-hipError_t launch_occupancy(const Geom& g, int half_store, const void* color, float* occ, hipStream_t s);
+// plain path (fx_render.hip): every sample gathers its taps
 hipError_t launch_raymarch_light(const Geom& g, int half_store, const void* color, uint32_t* lightmap,
-	const FrameConsts& fc, const float* sh, uint32_t num_samples, const float* occ, hipStream_t s, unsigned long long* counters = nullptr);
+	const FrameConsts& fc, const float* sh, uint32_t num_samples, hipStream_t s, unsigned long long* counters = nullptr);
 hipError_t launch_raymarch_view(const Geom& g, int half_store, const void* color, const uint32_t* lightmap,
 	const FrameConsts& fc, const float* sh, int cube_size, uint32_t mask, uint32_t num_samples,
-	uint32_t num_light_samples, int separate, uint8_t* cube, const float* occ, hipStream_t s, unsigned long long* counters = nullptr);
+	uint32_t num_light_samples, int separate, uint8_t* cube, hipStream_t s, unsigned long long* counters = nullptr);
 // direct screen-space march (row f-2): one ray per pixel, blended into the RGBA8 target (and/or kept as float4)
 hipError_t launch_raycast_direct(const Geom& g, int half_store, const void* color, const uint32_t* lightmap,
 	const FrameConsts& fc, const float* sh, int W, int H, uint32_t num_samples, uint32_t num_light_samples, int separate,
-	uint8_t* target, float* out_float, const float* occ, hipStream_t s, unsigned long long* counters = nullptr);
+	uint8_t* target, float* out_float, hipStream_t s, unsigned long long* counters = nullptr);
+// accelerated path (fx_render_accel.hip; the default, bit-identical to the plain one).  Device scratch, owned by the context:
+struct RenderAccel {
+	float* occ;          // per 4^3 block: max alpha over everything a sample based in the block can touch (n cells) + the maxima it is dilated from (n cells)
+	float* alpha;        // alpha-only fp32 copy of the colour volume, X * Y * Zg
+	uint32_t* bits;      // { pos, vis } masks of the fine level (fine_words each) [+ { pos, vis } of the LDS level (mask_words each) when msh > 0]
+	uint32_t* list;      // ids of the light-map voxels that cast rays, a segment of X * Y entries per z plane
+	uint32_t* ctr;       // per z plane (a cache line apart): length of the plane's segment of the list
+	int CX, CY, CZ;      // fine level: 4^3 blocks
+	int msh, MX, MY, MZ; // level held in the LDS: (4 << msh)^3 blocks, at most 262144 of them
+	uint32_t fine_words, mask_words;
+};
+void render_accel_layout(const Geom& g, RenderAccel* a);       // fills the dimensions
+size_t render_accel_bits_words(const RenderAccel& a);
+size_t render_accel_ctr_words(const Geom& g);
+hipError_t launch_accel_build(const Geom& g, int half_store, const void* color, const RenderAccel& a, hipStream_t s);
+hipError_t launch_accel_light(const Geom& g, const RenderAccel& a, uint32_t* lightmap, const FrameConsts& fc, const float* sh,
+	uint32_t num_samples, hipStream_t s, unsigned long long* counters = nullptr);
+hipError_t launch_accel_view(const Geom& g, int half_store, const void* color, const uint32_t* lightmap, const FrameConsts& fc, const float* sh,
+	int cube_size, uint32_t mask, uint32_t num_samples, uint32_t num_light_samples, int separate, uint8_t* cube, const RenderAccel& a, hipStream_t s,
+	unsigned long long* counters = nullptr);
+hipError_t launch_accel_direct(const Geom& g, int half_store, const void* color, const uint32_t* lightmap, const FrameConsts& fc, const float* sh,
+	int W, int H, uint32_t num_samples, uint32_t num_light_samples, int separate, uint8_t* target, float* out_float, const RenderAccel& a, hipStream_t s,
+	unsigned long long* counters = nullptr);
 // 2-D visualiser (PSVisualizeColor): colour[parity] of a Z = 1 grid onto the render target
 hipError_t launch_visualize_color(const Geom& g, int half_store, const void* color, int W, int H, uint8_t* target, float* out_float, hipStream_t s);
 hipError_t launch_lightmap_decode(const uint32_t* lightmap, float* out, size_t n, hipStream_t s);

@@ -252,11 +252,15 @@ int fx_comm_gather_color(fx_ctx* ctx, void* stream, fx_ctx* full, int root, cons
  *                        0 = always halo_advect planes.
  *   FX_OPT_COUNT_SAMPLES 1 = fx_render counts the samples its marches take (fx_timing.view_samples / light_samples / lightmap_fetches): every
  *                        thread adds its counts with atomics, so a counted render is for statistics, not for timing.  Local to the context.
+ *   FX_OPT_RENDER_ACCEL  1 = (default) fx_render runs the accelerated marches: occupancy masks of the colour field held in the LDS, an
+ *                        alpha-only side volume for the density taps, the lit light-map voxels compacted into a list.  0 = the plain
+ *                        kernels, where every sample gathers its taps like the reference's shaders.  Bit-identical pictures either
+ *                        way (the accelerated path only skips fetches whose result is known); local to the context.
  * On an RCCL chain fx_set_option (of the three schedule options) is COLLECTIVE: every rank calls it with the same arguments between two steps; the values are
  * compared across the chain and a disagreement returns FX_E_INVALID everywhere with nothing changed.  While FX_OPT_ADAPTIVE_HALO
  * is on and a step has run, fx_upload(FX_FIELD_VELOCITY) into an RCCL rank returns FX_E_STATE (its neighbours have sized the next
  * exchange from the old field); switch the option off first. */
-enum fx_option { FX_OPT_OVERLAP = 1, FX_OPT_JACOBI_ROUND = 2, FX_OPT_ADAPTIVE_HALO = 3, FX_OPT_COUNT_SAMPLES = 4 };
+enum fx_option { FX_OPT_OVERLAP = 1, FX_OPT_JACOBI_ROUND = 2, FX_OPT_ADAPTIVE_HALO = 3, FX_OPT_COUNT_SAMPLES = 4, FX_OPT_RENDER_ACCEL = 5 };
 int fx_set_option(fx_ctx* ctx, uint32_t option, uint32_t value);
 
 #ifdef __cplusplus

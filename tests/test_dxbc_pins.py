@@ -74,7 +74,10 @@ def test_oracle_constant_is_the_shipped_one(shader, value, literal, src):
 
 def test_kernels_use_the_same_constants():
     sim = open(os.path.join(ROOT, "fluidx12_amd", "csrc", "fx_sim.hip")).read()
-    ren = open(os.path.join(ROOT, "fluidx12_amd", "csrc", "fx_render.hip")).read()
+    ren = open(os.path.join(ROOT, "fluidx12_amd", "csrc", "fx_march.h")).read()      # the marches of both render paths
+    for path in ("fx_render.hip", "fx_render_accel.hip"):
+        assert "0.159154937f" in open(os.path.join(ROOT, "fluidx12_amd", "csrc", path)).read()
+    ren += "0.159154937f"
     sh = open(os.path.join(ROOT, "fluidx12_amd", "csrc", "fx_sh.hip")).read()
     for lit in ("0x3e2aaaabu", "0x3f855556u", "0.0183156393f", "1.44269502f", "33.3333359f", "0.970000029f", "192.0f"):
         assert lit in sim, lit

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import fluidx12_amd as fx
+from fluidx12_amd import capi
 from oracle import orc
 
 pytestmark = pytest.mark.gpu
@@ -353,16 +354,17 @@ def test_2d_visualiser_equals_oracle(storage):
 
 
 @pytest.mark.parametrize("storage,use_sh", [("fp32", False), ("fp16", True)])
-def test_empty_space_skipping_changes_no_bit(storage, use_sh, monkeypatch):
-    """the occupancy grid only replaces gathers whose result is known (all taps 0, or all taps <= the 0.01 threshold of the
-    view march): light map, both cube-map marches and the direct marches are bit-identical with and without it"""
+def test_empty_space_skipping_changes_no_bit(storage, use_sh):
+    """the accelerated marches (FX_OPT_RENDER_ACCEL, the default: occupancy masks in the LDS, alpha side volume, compacted light
+    voxels) only skip gathers whose result is known (all taps 0, or all taps <= the 0.01 threshold of the view march): light
+    map, both cube-map marches and the direct marches are bit-identical to the plain kernels, where every sample gathers"""
     X, vp = 48, (240, 180)
     col = smoke_state(X, 10, seed=11)
     sh = (np.random.default_rng(5).random((9, 3)) * np.array([[2.0]] + [[0.5]] * 8)).astype(f32) if use_sh else None
 
     def run(on):
-        monkeypatch.setenv("FLUIDX_RENDER_OCCUPANCY", "1" if on else "0")
         f, fr, lod, rs, mask = setup(X, col, *vp, storage=storage, sh=sh, max_samples=(64, 24))
+        f.set_option(capi.OPT_RENDER_ACCEL, 1 if on else 0)
         out = []
         for flags in (fx.Fluid.OPTIMIZED, fx.Fluid.RAY_MARCH_CUBEMAP):
             f.Render(0, flags)
@@ -409,3 +411,79 @@ def test_environment_pass_equals_oracle():
     fr2, wvp_i = oracle_frame_of(f, view, proj, eye, X)
     out, cov = orc.resolve_cube(cube_map, fr2, wvp_i, *vp)
     assert np.array_equal(f.download(fx.FIELD_TARGET), orc.blend_premultiplied(out, cov, sky8))
+
+
+# ---- full-size render parity (BASELINE configs 3 and 5) -------------------------------------------------
+def developed_plume(X, steps, storage, vp, sh=None, camera=None):
+    """`steps` frames of the HIP simulation from rest (the renderers' input is whatever the solver produced), then one paused
+    frame with the camera: returns the context, its colour field and the oracle's frame constants"""
+    f = fx.Fluid()
+    assert f.Init(vp[0], vp[1], (X, X, X), storage=storage)
+    view, proj, eye = camera if camera is not None else fx.default_camera(*vp)
+    for k in range(steps):
+        f.UpdateFrame(f32(f.default_time_step()), k % 3, view, proj, eye)
+        f.Simulate(k % 3)
+    if sh is not None:
+        f.SetSH(sh)
+    f.UpdateFrame(0.0, 0, view, proj, eye)
+    f.Synchronize()
+    col = f.download(fx.FIELD_COLOR)
+    fr, lod, rs, mask, _ = orc.update_frame(view, proj, eye, vp[0], vp[1], X, 192)
+    fi = f.frame_info()
+    assert (fi.cube_lod, fi.ray_samples, fi.visibility_mask) == (lod, rs, mask)
+    if sh is not None:
+        for i, v in enumerate(np.asarray(sh, f32).reshape(27)):
+            fr.sh[i] = v
+    return f, col, fr, lod, rs, mask
+
+
+def check_render_against_oracle(f, col, fr, X, lod, rs, mask, use_sh):
+    """OPTIMIZED (CSRayMarchL + CSRayMarchV) and the merged CSRayMarch of one state against the oracle's replay of the same state"""
+    f.Render(0, fx.Fluid.OPTIMIZED)
+    f.Synchronize()
+    lm_ref = orc.raymarch_light(col, fr, 64, use_sh, 2)
+    lm = f.download(fx.FIELD_LIGHTMAP)
+    lit = col[..., 3] >= f32(0.01)
+    assert 0.002 < lit.mean() < 0.5                                   # a plume, neither a puff nor fog
+    assert (lm != lm_ref).mean() < 1e-3                               # rare R11G11B10 rounding flips only
+    assert np.abs(lm - lm_ref).max() <= np.abs(lm_ref).max() * 2.0 ** -5
+    _, cu = orc.raymarch_view(col, lm_ref, fr, X >> lod, mask, rs, 64, use_sh, True)
+    cube = f.download(fx.FIELD_CUBEMAP)
+    assert cu[..., 3].max() > 100
+    cube_close(cube, cu, max_lsb=1, frac=0.01)
+    f.Render(0, fx.Fluid.RAY_MARCH_CUBEMAP)
+    f.Synchronize()
+    _, cu2 = orc.raymarch_view(col, None, fr, X >> lod, mask, rs, 64, use_sh, False)
+    cube_close(f.download(fx.FIELD_CUBEMAP), cu2, max_lsb=1, frac=0.01)
+    for face in range(6):
+        if not (mask >> face) & 1:
+            assert not cube[face].any()
+
+
+def test_config3_render_against_oracle():
+    """BASELINE configs[2] at full size: 256^3 fp32 after 64 simulated frames, default camera at 1920x1080 (LOD 0, 4 x 256^2 rays,
+    192 + 64 samples): light volume and cube map of both cube-map marches against the oracle -- light map equal up to rare
+    R11G11B10 rounding flips, cube map <= 1 LSB on < 1 % of the texels"""
+    X = 256
+    f, col, fr, lod, rs, mask = developed_plume(X, 64, "fp32", (1920, 1080))
+    assert (lod, rs, mask) == (0, 192, 0x1B)
+    check_render_against_oracle(f, col, fr, X, lod, rs, mask, False)
+
+
+def test_config5_render_against_oracle():
+    """BASELINE configs[4] at full size: 256^3 with RGBA16F fields and the SH light probe (hasSH = 1: GI + AO rays)"""
+    X = 256
+    sh = orc.sh_transform(synthetic_radiance(64))
+    f, col, fr, lod, rs, mask = developed_plume(X, 64, "fp16", (1920, 1080), sh=sh)
+    check_render_against_oracle(f, col, fr, X, lod, rs, mask, True)
+
+
+def test_render_at_coarser_cube_mip_against_oracle():
+    """the reference's default grid (128^3) seen from further away: UpdateFrame picks cube-map LOD >= 1, the view march runs
+    on a smaller mip with fewer samples; eye off the default axis so that another set of faces is visible"""
+    X, vp = 128, (640, 480)
+    eye = np.array([-50.0, 40.0, -100.0], f32)
+    cam = (fx.look_at_lh(eye, [0, 0, 0], [0, 1, 0]), fx.perspective_fov_lh(f32(np.pi) / f32(4.0), vp[0] / float(vp[1]), 1.0, 1000.0), eye)
+    f, col, fr, lod, rs, mask = developed_plume(X, 60, "fp32", vp, camera=cam)
+    assert lod >= 1 and mask != 0x1B
+    check_render_against_oracle(f, col, fr, X, lod, rs, mask, False)
