@@ -31,6 +31,8 @@ int fx_set_sh(fx_ctx* ctx, const float* coeffs27)
 	if (!coeffs27) { ctx->has_sh = false; return FX_OK; }
 	DeviceGuard dg(ctx->device);
 	FX_HIP(hipMemcpy(ctx->sh_dev, coeffs27, 27 * sizeof(float), hipMemcpyHostToDevice));
+	if (ctx->accel_ok && !ctx->accel.gi)               // scratch of the occlusion rays (fx_render_accel.hip); without it the render takes the chunked march
+		if (hipMalloc((void**)&ctx->accel.gi, 3 * ctx->g.cells_owned() * sizeof(float)) != hipSuccess) { ctx->accel.gi = nullptr; (void)hipGetLastError(); }
 	ctx->has_sh = true;
 	return FX_OK;
 }

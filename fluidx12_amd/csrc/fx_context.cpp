@@ -61,7 +61,7 @@ void free_all(fx_ctx* c)
 		if (c->col[i]) (void)hipFree(c->col[i]);
 		if (c->p[i]) (void)hipFree(c->p[i]);
 	}
-	void* others[] = { c->env, c->accel.occ, c->accel.alpha, c->accel.bits, c->accel.list, c->accel.cells, c->accel.ctr, c->target, c->target_float, c->p_face[0], c->p_face[1], c->b, c->frozen, c->lightmap, c->cube, c->sh_dev, c->halo_overflow, c->stage,
+	void* others[] = { c->env, c->accel.occ, c->accel.alpha, c->accel.bits, c->accel.list, c->accel.cells, c->accel.gi, c->accel.ctr, c->target, c->target_float, c->p_face[0], c->p_face[1], c->b, c->frozen, c->lightmap, c->cube, c->sh_dev, c->halo_overflow, c->stage,
 		c->sh_scratch[0], c->sh_scratch[1], c->sh_scratch[2], c->sh_scratch[3], c->p_aux, c->fz_mask[0], c->fz_mask[1], c->fz_tile_next, c->fz_stat, c->fz_list[0], c->fz_list[1], c->fz_counts, c->sample_counters, c->adv_far };
 	for (void* q : others) if (q) (void)hipFree(q);
 	for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);

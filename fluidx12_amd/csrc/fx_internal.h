@@ -136,6 +136,7 @@ struct RenderAccel {
 	float* alpha;        // alpha-only fp32 copy of the colour volume, X * Y * Zg
 	uint32_t* bits;      // { pos, vis } masks of the fine level (fine_words each) [+ { pos, vis } of the LDS level (mask_words each) when msh > 0]
 	uint32_t* list;      // ids of the light-map voxels that cast rays, a segment of X * Y entries per z plane
+	float* gi;           // light probe only (allocated by fx_set_sh): direction of each listed voxel's occlusion ray, 3 floats per list entry
 	uint32_t* cells;     // ids of the 4^3 cells that may hold a lit voxel, a segment of CX * CY entries per cell layer
 	uint32_t* ctr;       // counters, a cache line apart: list lengths per z plane, work heads of the view march, cell-list lengths per layer
 	int CX, CY, CZ;      // fine level: 4^3 blocks

@@ -31,6 +31,10 @@ static const uint32_t kMaskBudgetBits = FX_MASK_BUDGET_BITS;
 #define FX_LIGHT_AHEAD 2
 #endif
 static const int kViewAhead = FX_VIEW_AHEAD, kLightAhead = FX_LIGHT_AHEAD;
+#ifndef FX_LIGHT_RAY_WGS
+#define FX_LIGHT_RAY_WGS 2048
+#endif
+static const size_t kLightRayWorkgroups = FX_LIGHT_RAY_WGS;   // persistent workgroups of the refilling shadow-ray march
 // RenderAccel::ctr, one 128-byte line per counter: [Zg] lengths of the per-plane lists of lit voxels, [8] work heads of the view march,
 // [CZ] lengths of the per-layer lists of occupied 4^3 cells
 static const int kCntStride = 32;
@@ -354,6 +358,138 @@ __global__ __launch_bounds__(256) void k_light_march(const Geom g, const float* 
 	}
 }
 
+// pass 2 without the light probe: shadow rays only (:55) -- and a different way to fill the machine.  The lit voxels are few
+// (340 k of 16.8 M at frame 132 of the 256^3 run: 5 300 waves) and their rays take 1 .. 64 samples, so a wave that marches 64 rays
+// to the end runs as long as its longest ray with a third of its lanes busy (54 M instructions for 6.8 M samples).  Here a wave owns
+// every W-th block of 64 entries of the (flattened) lists and keeps refilling: whenever a quarter of its lanes have finished their
+// rays, those lanes write their results and take the next entries.  Every iteration each live lane takes exactly one sample.
+// With the light probe (:59-68) the voxel casts a second ray, along its density gradient: three launches -- the shadow rays
+// (RAYS_SHADOW_KEEP: the transmittance is parked in the voxel's light-map word), k_light_gi_dirs (GetDensityGradient for every
+// listed voxel, full waves), the occlusion rays (RAYS_AO: direction per lane; the finished lane evaluates the irradiance, picks the
+// shadow up again and writes the light-map value).
+enum { RAYS_SHADOW = 0, RAYS_SHADOW_KEEP = 1, RAYS_AO = 2 };
+
+template <bool COARSE, int MODE>
+__global__ __launch_bounds__(256) void k_light_rays(const Geom g, const float* __restrict__ alpha, const float* __restrict__ occ,
+	const uint32_t* __restrict__ pos_mask, uint32_t mask_words, int msh, int MX, int MY, int CX, int CY,
+	const uint32_t* __restrict__ list, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ lightmap, const FrameConsts fc,
+	const float* __restrict__ gi, const float* __restrict__ sh, uint32_t numSamples, unsigned long long* __restrict__ counters)
+{
+	extern __shared__ uint32_t lds[];
+	uint32_t* pre = lds + mask_words;                                              // pre[z] = lit voxels of the planes below z; pre[Zg] = all
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t Z = (uint32_t)g.Zg;
+	scan_counters(pre, cnt, Z, 0);
+	const uint32_t N = pre[Z];
+	if (blockIdx.x * 256u >= N) return;                                            // (uniform) more waves than blocks
+	fill_lds(lds, pos_mask, mask_words);
+	__syncthreads();
+	const AccelVol<false, COARSE> vol{ nullptr, alpha, occ, lds, lds, msh, MX, MY, CX, CY };
+	const float stepScale = 3.46410155f / (float)numSamples;                       // RayMarch.hlsli:29-30
+	float lx, ly, lz;                                                              // the ray's direction: the light's, or (RAYS_AO) the lane's own
+	light_dir_local(fc, lx, ly, lz);
+	float rx = 0.0f, ry = 0.0f, rz = 0.0f;                                         // RAYS_AO: the direction before it was normalised
+	const uint32_t XY = (uint32_t)g.X * (uint32_t)g.Y;
+	const uint32_t W = gridDim.x * 4u;
+	uint32_t cur = blockIdx.x * 4u + (threadIdx.x >> 6);                           // the block being handed out, entries [64 cur + pos, 64 cur + pos + avail)
+	uint32_t pos = 0, avail = 64u * cur < N ? min(64u, N - 64u * cur) : 0u;
+	bool live = false, pending = false;
+	uint32_t id = 0, i = 0, ns = 0;
+	float ox = 0.0f, oy = 0.0f, oz = 0.0f, t = 0.0f, prev = 0.0f, transm = 1.0f;
+	// what a finished ray leaves in the voxel's light-map word (:72-79)
+	auto finish = [&](uint32_t vid, float tr, float ax, float ay, float az) -> uint32_t {
+		if (MODE == RAYS_SHADOW_KEEP) return __float_as_uint(tr);
+		float irr[3] = { 0.0f, 0.0f, 0.0f };
+		if (MODE == RAYS_SHADOW) return light_value(fc, false, tr, 1.0f, irr);
+		float wx = dot3(ax, ay, az, fc.world[0], fc.world[1], fc.world[2]);       // RayMarch.hlsli:280 / CSRayMarchL.hlsl:65
+		float wy = dot3(ax, ay, az, fc.world[4], fc.world[5], fc.world[6]);
+		float wz = dot3(ax, ay, az, fc.world[8], fc.world[9], fc.world[10]);
+		const float rw = rsqf(dot3(wx, wy, wz, wx, wy, wz));
+		wx *= rw; wy *= rw; wz *= rw;
+		sh_irradiance(irr, sh, wx, wy, wz);
+		return light_value(fc, true, __uint_as_float(lightmap[vid]), tr, irr);
+	};
+	for (;;) {
+		const unsigned long long idle = __ballot(!live);
+		const uint32_t nidle = (uint32_t)__popcll(idle);
+		if (nidle == 64u && avail == 0u) break;
+		if (avail != 0u && nidle >= 16u) {
+			if (pending) {                                                         // (pending implies !live)
+				lightmap[id] = finish(id, transm, rx, ry, rz);
+				pending = false;
+			}
+			const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+			if (!live && rank < avail) {
+				const uint32_t flat = 64u * cur + pos + rank;
+				const uint32_t z = find_segment(pre, Z, flat);
+				id = list[z * XY + (flat - pre[z])];
+				const uint32_t y = (id - z * XY) / (uint32_t)g.X, x = id - z * XY - y * (uint32_t)g.X;
+				ox = fmaf(((float)x + 0.5f) / (float)g.X, 2.0f, -1.0f);            // CSRayMarchL.hlsl:22
+				oy = fmaf(((float)y + 0.5f) / (float)g.Y, 2.0f, -1.0f);
+				oz = fmaf(((float)z + 0.5f) / (float)g.Zg, 2.0f, -1.0f);
+				t = stepScale; prev = 0.0f; transm = 1.0f; i = 0;                  // CastLightRay, RayMarch.hlsli:215-221
+				if (MODE == RAYS_AO) {
+					rx = gi[3 * (size_t)flat]; ry = gi[3 * (size_t)flat + 1]; rz = gi[3 * (size_t)flat + 2];
+					const float rd = rsqf(dot3(rx, ry, rz, rx, ry, rz));           // CSRayMarchL.hlsl:66
+					lx = rx * rd; ly = ry * rd; lz = rz * rd;
+				}
+				live = true;
+			}
+			const uint32_t n = min(nidle, avail);
+			pos += n; avail -= n;
+			if (avail == 0u) { cur += W; pos = 0; avail = 64u * cur < N ? min(64u, N - 64u * cur) : 0u; }
+		}
+		if (live) {                                                                // one sample of the loop :222-246
+			const float px = fmaf(lx, t, ox), py = fmaf(ly, t, oy), pz = fmaf(lz, t, oz);
+			bool on = i < numSamples && !outside(px, py, pz);
+			if (on) {
+				++ns;
+				const Base b = make_base(g, fmaf(px, 0.5f, 0.5f), fmaf(py, 0.5f, 0.5f), fmaf(pz, 0.5f, 0.5f));
+				float density = 0.0f;
+				if (vol.dense(b)) density = vol.density(make_taps(g, b));
+				float fac;
+				on = light_step(density, stepScale, t, prev, transm, i, fac);
+			}
+			if (!on) { live = false; pending = true; }
+		}
+	}
+	if (pending) lightmap[id] = finish(id, transm, rx, ry, rz);
+	flush_counts(counters, 0u, ns, 0u);
+}
+
+// GetDensityGradient (RayMarch.hlsli:73-95) of every listed voxel: the occlusion ray's direction before normalisation -- minus the
+// gradient, or the voxel's position where the gradient vanishes (CSRayMarchL.hlsl:61-64) -- to gi[flat index][3]
+__global__ __launch_bounds__(256) void k_light_gi_dirs(const Geom g, const float* __restrict__ alpha, int CX, int CY,
+	const uint32_t* __restrict__ list, const uint32_t* __restrict__ cnt, float* __restrict__ gi, unsigned long long* __restrict__ counters)
+{
+	extern __shared__ uint32_t lds[];
+	uint32_t* pre = lds;
+	const uint32_t Z = (uint32_t)g.Zg;
+	scan_counters(pre, cnt, Z, 0);
+	const uint32_t N = pre[Z];
+	const uint32_t XY = (uint32_t)g.X * (uint32_t)g.Y;
+	const AccelVol<false, false> vol{ nullptr, alpha, nullptr, nullptr, nullptr, 0, CX, CY, CX, CY };
+	uint32_t ns = 0;
+	for (uint32_t flat = blockIdx.x * 256u + threadIdx.x; flat < N; flat += gridDim.x * 256u) {
+		const uint32_t z = find_segment(pre, Z, flat);
+		const uint32_t id = list[z * XY + (flat - pre[z])];
+		const uint32_t y = (id - z * XY) / (uint32_t)g.X, x = id - z * XY - y * (uint32_t)g.X;
+		const float ox = fmaf(((float)x + 0.5f) / (float)g.X, 2.0f, -1.0f);        // CSRayMarchL.hlsl:22
+		const float oy = fmaf(((float)y + 0.5f) / (float)g.Y, 2.0f, -1.0f);
+		const float oz = fmaf(((float)z + 0.5f) / (float)g.Zg, 2.0f, -1.0f);
+		const float u = fmaf(ox, 0.5f, 0.5f), v = fmaf(oy, 0.5f, 0.5f), w = fmaf(oz, 0.5f, 0.5f);
+		ns += 6;
+		// (the voxel is lit: its neighbourhood is smoke, so all 48 taps go out at once instead of asking the masks first -- same values)
+		const float qxm = vol.density(make_taps(g, make_base(g, u, v, w, -1, 0, 0))), qxp = vol.density(make_taps(g, make_base(g, u, v, w, 1, 0, 0)));
+		const float qym = vol.density(make_taps(g, make_base(g, u, v, w, 0, -1, 0))), qyp = vol.density(make_taps(g, make_base(g, u, v, w, 0, 1, 0)));
+		const float qzm = vol.density(make_taps(g, make_base(g, u, v, w, 0, 0, -1))), qzp = vol.density(make_taps(g, make_base(g, u, v, w, 0, 0, 1)));
+		const float gx = -qxm + qxp, gy = -qym + qyp, gz = -qzm + qzp;
+		const bool any = fabsf(gx) > 0.0f || fabsf(gy) > 0.0f || fabsf(gz) > 0.0f;
+		gi[3 * (size_t)flat] = any ? -gx : ox; gi[3 * (size_t)flat + 1] = any ? -gy : oy; gi[3 * (size_t)flat + 2] = any ? -gz : oz;
+	}
+	flush_counts(counters, 0u, ns, 0u);
+}
+
 hipError_t launch_accel_light(const Geom& g, const RenderAccel& a, uint32_t* lightmap, const FrameConsts& fc, const float* sh,
 	uint32_t num_samples, hipStream_t s, unsigned long long* counters)
 {
@@ -362,8 +498,23 @@ hipError_t launch_accel_light(const Geom& g, const RenderAccel& a, uint32_t* lig
 	hipLaunchKernelGGL(k_light_classify, dim3((unsigned)std::min(ncell / 4 + 1, 2048)), dim3(256), ((size_t)a.CZ + 1) * 4, s, g, a.alpha, a.bits, a.CX, a.CY, a.CZ,
 		a.cells, a.list, a.ctr, lightmap, fc, sh ? 1 : 0);
 	const size_t cells = (size_t)g.X * g.Y * g.Zg;
-	const unsigned wgs = (unsigned)std::min<size_t>((cells + 255) / 256, 2048);
 	const size_t lds = (size_t)a.mask_words * 4 + ((size_t)g.Zg + 1) * 4;
+	const unsigned wgs = (unsigned)std::min<size_t>((cells + 255) / 256, kLightRayWorkgroups);
+#define FX_RAYS(C, M) hipLaunchKernelGGL((k_light_rays<C, M>), dim3(wgs), dim3(256), lds, s, g, a.alpha, a.occ, mask_pos(a), a.mask_words, a.msh, a.MX, a.MY, a.CX, a.CY, \
+	a.list, a.ctr, lightmap, fc, a.gi, sh, num_samples, counters)
+	if (!sh) {
+		if (a.msh) FX_RAYS(true, RAYS_SHADOW); else FX_RAYS(false, RAYS_SHADOW);
+		return hipGetLastError();
+	}
+	if (a.gi) {
+		if (a.msh) FX_RAYS(true, RAYS_SHADOW_KEEP); else FX_RAYS(false, RAYS_SHADOW_KEEP);
+		hipLaunchKernelGGL(k_light_gi_dirs, dim3((unsigned)std::min<size_t>((cells + 255) / 256, 2048)), dim3(256), ((size_t)g.Zg + 1) * 4, s, g, a.alpha, a.CX, a.CY,
+			a.list, a.ctr, a.gi, counters);
+		if (a.msh) FX_RAYS(true, RAYS_AO); else FX_RAYS(false, RAYS_AO);
+		return hipGetLastError();
+	}
+#undef FX_RAYS
+	// (no scratch for the occlusion rays' directions: the chunked march, a wave per 64 listed voxels)
 	if (a.msh) hipLaunchKernelGGL(k_light_march<true>, dim3(wgs), dim3(256), lds, s, g, a.alpha, a.occ, mask_pos(a), a.mask_words, a.msh, a.MX, a.MY, a.CX, a.CY,
 		a.list, a.ctr, lightmap, fc, sh, num_samples, counters);
 	else hipLaunchKernelGGL(k_light_march<false>, dim3(wgs), dim3(256), lds, s, g, a.alpha, a.occ, mask_pos(a), a.mask_words, a.msh, a.MX, a.MY, a.CX, a.CY,
