@@ -80,6 +80,8 @@ SYMBOLS = {
     "fx_dds_decode_cube": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, _fp, C.c_size_t]),
     "fx_timing_enable": (C.c_int, [_vp, C.c_int]),
     "fx_set_option": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
+    "fx_set_knob": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "fx_knob_name": (C.c_char_p, [C.c_uint32]),
     "fx_comm_gather_color": (C.c_int, [_vp, _vp, _vp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "fx_timing_read": (C.c_int, [_vp, C.POINTER(Timing), C.c_int]),
     "fx_comm_id_bytes": (C.c_size_t, []),
@@ -117,7 +119,28 @@ def load():
     if lib.fx_abi_version() != ABI_VERSION:
         raise RuntimeError("fluidx ABI version mismatch")
     _lib = lib
+    # the launcher switches (fx_set_knob) are process-wide values inside the library, which reads no environment for them; the tools'
+    # habit of `FLUIDX_<NAME>=... python tools/...` is served here, once, by the harness
+    for name in knob_names():
+        v = os.environ.get("FLUIDX_" + name)
+        if v is not None:
+            set_knob(name, v)
     return lib
+
+
+def knob_names():
+    lib, out, i = load(), [], 0
+    while True:
+        n = lib.fx_knob_name(i)
+        if n is None:
+            return out
+        out.append(n.decode())
+        i += 1
+
+
+def set_knob(name, value):
+    """a measurement switch of the kernel launchers (include/fluidx_hip.h fx_set_knob); value None = back to the default"""
+    check(load().fx_set_knob(name.encode(), None if value is None else str(value).encode()), "set_knob(%s)" % name)
 
 
 class FluidxError(RuntimeError):

@@ -450,7 +450,6 @@ __global__ __launch_bounds__(256) void k_advect_far(const Geom g, const SimParam
 	}
 }
 
-static int env_i(const char* n, int d) { const char* v = getenv(n); return v && *v ? atoi(v) : d; }
 
 // hipErrorNotSupported: the geometry has no LDS path (the caller falls back to k_advect_fast / k_advect)
 hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const void* col_in,
@@ -461,12 +460,12 @@ hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store,
 	const int nzp = z_end - z_begin;
 	// rows per workgroup tile.  16 (one 1024-thread workgroup per CU, 1.16 x instead of 1.29 x border) measured 0.228 / 0.269 ms against
 	// 0.223 / 0.263 for 8 (256^3, states of step 25 / 110): the bytes it saves it loses to the single workgroup's barrier stalls
-	static const int TY = env_i("FLUIDX_ADVECT_TILE_ROWS", 8) == 16 ? 16 : 8;
+	const int TY = FX_KNOB_INT("ADVECT_TILE_ROWS", 8) == 16 ? 16 : 8;
 	if (g.Zg <= 1 || !pow2(g.X) || !pow2(g.Y) || !pow2(g.Zg) || g.X < TX || g.Y < TY || nzp < 12 ||
 		(!force && (size_t)g.X * g.Y * (size_t)nzp < ((size_t)1 << 22)) ||     // 128^3: 0.032-0.040 ms against 0.030 for k_advect_fast -- too few workgroups
 		g.cells_local() * 16 >= ((size_t)1 << 32))
 		return hipErrorNotSupported;
-	static const int half_on = env_i("FLUIDX_ADVECT_LDS_HALF", 1);
+	const int half_on = FX_KNOB_INT("ADVECT_LDS_HALF", 1);
 	if (half_store && !half_on) return hipErrorNotSupported;
 	auto lg = [](int v) { int k = 0; while ((1 << k) < v) ++k; return k; };
 	const int lgX = lg(g.X), lgY = lg(g.Y), lg_gx = lg(g.X / TX), lg_gy = lg(g.Y / TY);
@@ -475,8 +474,8 @@ hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store,
 	// workgroups over the plume took several times longer than the rest and short chunks (2048 workgroups of 16 planes at 256^3)
 	// balanced that: 0.216 ms with 16, 0.219 with 8, 0.241 with 32, 0.258 with 64.  With those voxels deferred every workgroup costs
 	// the same: 16 / 32 / 64 planes measure 0.211 / 0.203 / 0.212 ms (fp32), 0.147 / 0.143 / 0.144 (fp16), within the noise -- 32.
-	const bool want_defer = far_scratch && env_i("FLUIDX_ADVECT_DEFER", 1) != 0;
-	int zchunk = env_i("FLUIDX_ADVECT_ZCHUNK", want_defer ? 32 : 16);
+	const bool want_defer = far_scratch && FX_KNOB_INT("ADVECT_DEFER", 1) != 0;
+	int zchunk = FX_KNOB_INT("ADVECT_ZCHUNK", want_defer ? 32 : 16);
 	if (zchunk < 4) zchunk = 4;
 	if (zchunk > nzp) zchunk = nzp;
 	const int nchunks = (nzp + zchunk - 1) / zchunk;

@@ -419,7 +419,7 @@ static int make_comm_stream(fx_comm_group* g, int device)
 	// millisecond for the first group of a process (18 ms per step instead of 7.7, profiles/r01d_slab_schedule_loopback.txt);
 	// FLUIDX_COMM_PRIORITY=1 asks for the highest priority anyway (measurement knob).
 	int lo = 0, hi = 0, prio = 0;
-	const char* pe = std::getenv("FLUIDX_COMM_PRIORITY");
+	const char* pe = FX_KNOB("COMM_PRIORITY");
 	if (pe && pe[0] == '1' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) prio = hi;
 	if (hipStreamCreateWithPriority(&g->comm_stream, hipStreamNonBlocking, prio) != hipSuccess) return FX_E_DEVICE;
 	if (hipEventCreateWithFlags(&g->ev_ready, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;

@@ -79,7 +79,7 @@ struct LocalTransport : Transport {
 		const int n = (int)grp->members.size();
 		if ((int)segs.size() != n) return FX_E_STATE;
 		// timing experiments only (results become wrong): keep the streams/events of the schedule, drop the copies
-		static const bool no_copy = [] { const char* e = std::getenv("FLUIDX_DEBUG_NO_COPY"); return e && e[0] == '1'; }();
+		const bool no_copy = [] { const char* e = FX_KNOB("DEBUG_NO_COPY"); return e && e[0] == '1'; }();
 		if (no_copy) return FX_OK;
 		// every member "receives": its j-th segment from direction d pairs with the peer's j-th segment towards -d
 		for (int r = 0; r < n; ++r)
@@ -242,7 +242,7 @@ Transport* make_rccl_transport(const void* id, size_t bytes, int rank, int nrank
 	// the side channel: a second communicator from the second id, when the caller passed two (fx_comm_id_bytes); the plain
 	// ncclCommInitRank route, the one every framework exercises
 	t->comm2 = t->comm;
-	static const bool one_comm = [] { const char* e = std::getenv("FLUIDX_RCCL_ONE_COMM"); return e && e[0] == '1'; }();
+	const bool one_comm = [] { const char* e = FX_KNOB("RCCL_ONE_COMM"); return e && e[0] == '1'; }();
 	if (bytes >= 2 * sizeof(ncclUniqueId) && !one_comm) {
 		ncclUniqueId uid2;
 		std::memcpy(&uid2, static_cast<const char*>(id) + sizeof uid, sizeof uid2);

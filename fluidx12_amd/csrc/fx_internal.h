@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include "../../include/fluidx_hip.h"
+#include "fx_knobs.h"
 
 namespace fx {
 

@@ -251,13 +251,12 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_blockg(const Geom g, const fl
 	}
 }
 
-int env_b(const char* n, int d) { const char* v = getenv(n); return v && *v ? atoi(v) : d; }
 
 }  // namespace
 
 bool jacobi_block2_supported(const Geom& g)
 {
-	static const int on = env_b("FLUIDX_JACOBI_BLOCK", 1);
+	const int on = FX_KNOB_INT("JACOBI_BLOCK", 1);
 	return on && g.Zg > 1 && g.X == 128 && (g.Y & 3) == 0 && g.cells_local() < ((size_t)1 << 30);
 }
 
@@ -271,7 +270,7 @@ static int blockg_cpl(const Geom& g)
 
 bool jacobi_blockg_supported(const Geom& g)
 {
-	static const int on = env_b("FLUIDX_JACOBI_BLOCKG", 1);
+	const int on = FX_KNOB_INT("JACOBI_BLOCKG", 1);
 	return on && g.Zg > 1 && g.X >= 8 && blockg_cpl(g) != 0 && g.cells_local() < ((size_t)1 << 30);
 }
 
@@ -279,7 +278,7 @@ hipError_t launch_jacobi_blockg(const Geom& g, const float* p_in, const float* b
 {
 	if (z_end <= z_begin) return hipSuccess;
 	if (!jacobi_blockg_supported(g)) return hipErrorNotSupported;
-	static const int remap = env_b("FLUIDX_BLOCK_REMAP", 1);
+	const int remap = FX_KNOB_INT("BLOCK_REMAP", 1);
 	const int cpl = blockg_cpl(g);
 	// 3 rows x 2 planes per wave.  Measured in round 2 (Jacobi phase of a step, ms; single sweeps / 4 x 4 / 4 x 2 / 2 x 4 / 2 x 2 / 3 x 3 /
 	// 3 x 2 / 2 x 3 rows x planes per wave): 150^3 0.767 / 0.319 / 0.277 / 0.285 / 0.250 / 0.299 / 0.237 / 0.236, 192^3 0.581 / 0.533 / 0.485 /
@@ -302,7 +301,7 @@ hipError_t launch_jacobi_block2(const Geom& g, const float* p_in, const float* b
 {
 	if (z_end <= z_begin) return hipSuccess;
 	if (!jacobi_block2_supported(g)) return hipErrorNotSupported;
-	static const int remap = env_b("FLUIDX_BLOCK_REMAP", 1);
+	const int remap = FX_KNOB_INT("BLOCK_REMAP", 1);
 	// 4 rows x 4 planes per wave (224 VGPRs, one wave per SIMD, 1024 waves at 128^3); 4 x 2 7.1 us, 2 x 4 7.3, 2 x 2 8.1, 4 x 3 8.3 per launch
 	// against 6.6 -- the other shapes are no longer compiled
 	const int nby = g.Y / 4, nbz = (z_end - z_begin + 3) / 4;

@@ -522,18 +522,10 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(
 extern "C" void fx_debug_freeze_prof(unsigned long long* out, int reset) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(fz_prof), sizeof fz_prof); if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(fz_prof), z, sizeof z); } }
 extern "C" void fx_debug_freeze_passes(unsigned int* out, int reset) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(fz_passes), sizeof fz_passes); if (reset) { static unsigned int z[2][80]; (void)hipMemcpyToSymbol(HIP_SYMBOL(fz_passes), z, sizeof z); } }
 #endif
-namespace {
-int env_int(const char* name, int dflt)
-{
-	const char* v = getenv(name);
-	return v && *v ? atoi(v) : dflt;
-}
-
-}  // namespace
 
 bool jacobi_freeze_supported(const Geom& g)
 {
-	return env_int("FLUIDX_FREEZE_FAST", 1) != 0 && g.Zg > 1 && g.H == 0 && g.z0 == 0 && g.nz == g.Zg && g.X >= 4 &&
+	return FX_KNOB_INT("FREEZE_FAST", 1) != 0 && g.Zg > 1 && g.H == 0 && g.z0 == 0 && g.nz == g.Zg && g.X >= 4 &&
 		(uint64_t)g.X * g.Y < (1u << 24) && (uint64_t)g.X * g.Y * (uint64_t)g.Zg < (1u << 30);   // 24-bit row / plane multiplies, 32-bit byte offsets
 }
 
@@ -548,7 +540,7 @@ size_t jacobi_freeze_count_words() { return (size_t)kFreezeSlots * kShards; }
 
 int jacobi_freeze_levels_per_launch()
 {
-	const int v = env_int("FLUIDX_FREEZE_T", 4);        // read per call: the tests switch it inside one process
+	const int v = FX_KNOB_INT("FREEZE_T", 4);        // read per call: the tests switch it inside one process
 	return v < 1 ? 1 : (v > 4 ? 4 : v);
 }
 
@@ -571,17 +563,17 @@ hipError_t launch_freeze_dense(const Geom& g, const float* p_in, const float* b,
 	return hipGetLastError();
 }
 
-bool jacobi_freeze_can_fuse_divergence(const Geom& g) { (void)g; return env_int("FLUIDX_FREEZE_FUSE_DIV", 1) != 0; }
+bool jacobi_freeze_can_fuse_divergence(const Geom& g) { (void)g; return FX_KNOB_INT("FREEZE_FUSE_DIV", 1) != 0; }
 
 // launch number `n` (0, 1, ...) of a solve reads list[n & 1] and writes list[(n + 1) & 1]
 hipError_t launch_freeze_tiles(const Geom& g, const float* p_src, const float* b, float* p_dst, const uint8_t* m_src, uint8_t* m_dst,
 	const FreezeWork& w, int n, int levels, int level_base, uint32_t* stat, uint32_t stat_hi, hipStream_t s)
 {
-	int max_wgs = env_int("FLUIDX_FREEZE_WGS", 2048);
+	int max_wgs = FX_KNOB_INT("FREEZE_WGS", 2048);
 	max_wgs = max_wgs < kShards ? kShards : (max_wgs & ~(kShards - 1));
 	const int ntx = (g.X + TCX - 1) / TCX, nty = (g.Y + TCY - 1) / TCY, ntiles = jacobi_freeze_tiles(g);
 	const int want = (ntiles + kShards - 1) / kShards * kShards;
-	const int nt = env_int("FLUIDX_FREEZE_NT", 512);
+	const int nt = FX_KNOB_INT("FREEZE_NT", 512);
 	const dim3 block((g.X & 3) != 0 ? 512 : (nt == 256 ? 256 : (nt == 1024 ? 1024 : 512)), 1, 1), grid(want < max_wgs ? want : max_wgs, 1, 1);
 	const int ntz = (g.Zg + TCZ - 1) / TCZ;
 	const int scan_limit = (ntz + 7) / 8 * 8 * ntx * nty;   // the first launch's index space: (tile plane % 8 = XCD, plane / 8, tile in plane)

@@ -529,7 +529,6 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip2h(const Geom g, const f
 #undef FX_STRIPH_STEP
 #undef FX_RL
 
-int env_i(const char* n, int d) { const char* v = getenv(n); return v && *v ? atoi(v) : d; }
 
 }  // namespace
 
@@ -546,14 +545,14 @@ hipError_t launch_jacobi_strip(const Geom& g, const float* p_in, const float* b,
 {
 	if (z_end <= z_begin) return hipSuccess;
 	if (!jacobi_strip_supported(g)) return hipErrorNotSupported;
-	static const int forced_chunk = env_i("FLUIDX_STRIP_ZCHUNK", 0);   // measurement knobs
-	static const int remap = env_i("FLUIDX_STRIP_REMAP", 1);
-	static const int Rsel = env_i("FLUIDX_STRIP_R", 0);
+	const int forced_chunk = FX_KNOB_INT("STRIP_ZCHUNK", 0);   // measurement knobs
+	const int remap = FX_KNOB_INT("STRIP_REMAP", 1);
+	const int Rsel = FX_KNOB_INT("STRIP_R", 0);
 	const bool wide = jacobi_strip_wide(g);
 	if (wide && sweeps != 2) return hipErrorNotSupported;
 	// X = 512: half-row waves with a seam (k_jacobi_strip2h, R = 4) unless Y % 4 != 0 or FLUIDX_STRIP_WIDE=1 asks for the
 	// two-float4-per-lane kernel (k_jacobi_strip2w, R = 2): the A/B switch of DESIGN.md section 6
-	static const int force_w = env_i("FLUIDX_STRIP_WIDE", 0);
+	const int force_w = FX_KNOB_INT("STRIP_WIDE", 0);
 	const bool halves = wide && (g.Y & 3) == 0 && !force_w;
 	const int rows = halves ? 4 : wide ? 2 : (Rsel == 2 || Rsel == 4 ? Rsel : (sweeps == 3 ? 2 : 4));
 	const int R = rows;
@@ -561,7 +560,7 @@ hipError_t launch_jacobi_strip(const Geom& g, const float* p_in, const float* b,
 	const int nstrips = ((g.Y + R - 1) / R) * (halves ? 2 : 1);
 	const int ngroups = (nstrips + 4 * SPW - 1) / (4 * SPW);            // 4 waves per workgroup
 	const int nzp = z_end - z_begin;
-	static const int wg_target = env_i("FLUIDX_STRIP_WGS", 256);
+	const int wg_target = FX_KNOB_INT("STRIP_WGS", 256);
 	int nchunks = (wg_target + ngroups - 1) / ngroups;                  // one workgroup (= 1 wave per SIMD) per CU
 	int zchunk = forced_chunk > 0 ? forced_chunk : (nzp + nchunks - 1) / nchunks;
 	if (zchunk < 8) zchunk = 8;
@@ -569,7 +568,7 @@ hipError_t launch_jacobi_strip(const Geom& g, const float* p_in, const float* b,
 	nchunks = (nzp + zchunk - 1) / zchunk;
 	const dim3 grid(ngroups * nchunks), block(256);
 #define FX_STRIP(T_, R_) hipLaunchKernelGGL((k_jacobi_strip<T_, R_>), grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap)
-	static const int generic = env_i("FLUIDX_STRIP_GENERIC", 0);
+	const int generic = FX_KNOB_INT("STRIP_GENERIC", 0);
 	if (halves)
 		hipLaunchKernelGGL(k_jacobi_strip2h<4>, grid, block, 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
 	else if (wide)

@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip3c(const Geom g, const f
 
 bool jacobi_strip3_supported(const Geom& g)
 {
-	static const bool no_h = [] { const char* e = getenv("FLUIDX_STRIP3_NO512"); return e && e[0] == '1'; }();
+	const bool no_h = [] { const char* e = FX_KNOB("STRIP3_NO512"); return e && e[0] == '1'; }();
 	return g.Zg > 1 && (g.X == 256 || (g.X == 512 && !no_h)) && (g.Y & 3) == 0 && g.Y >= 8;
 }
 
@@ -697,15 +697,15 @@ hipError_t launch_jacobi_strip3(const Geom& g, const float* p_in, const float* b
 {
 	if (z_end <= z_begin) return hipSuccess;
 	if (!jacobi_strip3_supported(g)) return hipErrorNotSupported;
-	const char* ce = getenv("FLUIDX_STRIP3_ZCHUNK");
-	const char* re = getenv("FLUIDX_STRIP_REMAP");
+	const char* ce = FX_KNOB("STRIP3_ZCHUNK");
+	const char* re = FX_KNOB("STRIP_REMAP");
 	const int forced_chunk = ce && *ce ? atoi(ce) : 0;
 	const int remap = re && *re ? atoi(re) : 1;
 	const bool halves = g.X == 512;                                     // two half-row waves per strip (k_jacobi_strip3h)
-	static const int coop = [] { const char* e = getenv("FLUIDX_STRIP3_COOP"); return e && *e ? atoi(e) : 1; }();
+	const int coop = [] { const char* e = FX_KNOB("STRIP3_COOP"); return e && *e ? atoi(e) : 1; }();
 	const bool use_coop = !halves && coop && (g.Y % (2 * RC)) == 0;
 	const int nstrips = use_coop ? g.Y / RC : (g.Y / R3) * (halves ? 2 : 1);
-	static const int pair_wg = [] { const char* e = getenv("FLUIDX_STRIP3H_PAIRS"); return e ? atoi(e) : 0; }();
+	const int pair_wg = [] { const char* e = FX_KNOB("STRIP3H_PAIRS"); return e ? atoi(e) : 0; }();
 	const int wpg = halves && pair_wg ? 2 : 4;                          // X = 512: a workgroup = one pair of half-row waves (its barrier syncs only them)
 	const int ngroups = (nstrips + wpg - 1) / wpg;                      // waves (strips) per workgroup
 	const int nzp = z_end - z_begin;

@@ -166,9 +166,22 @@ static int consume_record(fx_ctx* ctx, std::vector<fx_ctx*>& M)
 	for (fx_ctx* m : M) { usable = usable && m->need_valid && m->time_step <= m->rec_dt; m->rec_pending = false; }
 	if (fault) {
 		// This return IS the chain-wide notice of the fault: every rank gets it once, from the same gathered record, and the step
-		// after it starts clean.  It does not block read-back again: the rank whose own advection overflowed still has its device
-		// flag up until its fx_synchronize acknowledges it (before or after this call), the other ranks have nothing to acknowledge.
-		// (Before: this set halo_fault on every rank, so the order fx_synchronize -> fx_simulate reported the same fault three times.)
+		// after it starts clean -- on every rank, whether or not anybody calls fx_synchronize in between: a rank whose own flag is
+		// still up takes it down here (nothing of the previous step is in flight any more: its record has arrived) and remembers the
+		// fault on the host instead, so that its read-back and checkpoints keep refusing until fx_synchronize acknowledges it.
+		// Left up, the flag would be copied into the record of every later step and the chain would alternate between one executed and
+		// one refused step for ever.
+		for (fx_ctx* m : M) {
+			if (!rec(m->rank)[3] || !m->halo_overflow) continue;
+			DeviceGuard dg(m->device);
+			FX_HIP(hipDeviceSynchronize());                            // (the overlapped schedule has enqueued this step's interior advection already: it may raise the flag again)
+			unsigned flag = 0;
+			FX_HIP(hipMemcpy(&flag, m->halo_overflow, sizeof flag, hipMemcpyDeviceToHost));
+			if (!flag) continue;                                       // acknowledged by an fx_synchronize since
+			FX_HIP(hipMemset(m->halo_overflow, 0, sizeof(unsigned)));
+			FX_HIP(hipDeviceSynchronize());                            // the context's streams do not order against the NULL stream
+			m->halo_fault = true;
+		}
 		ctx->last_error = "the previous step's advection left the exchanged halo on at least one rank";
 		return FX_E_HALO;
 	}

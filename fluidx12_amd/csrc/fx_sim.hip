@@ -759,11 +759,10 @@ __global__ __launch_bounds__(256) void k_project_vw(const Geom g, const typename
 	stwv<W, HALF>(vel_out, 2u * stride + off, oz);
 }
 
-static int env_int(const char* name, int dflt);
 // cells per thread of the vW kernels: 3 or 2 where that divides the row, 0 = none (the scalar kernels)
 static int vw_width(const Geom& g, int half_store)
 {
-	static const int on = env_int("FLUIDX_ROW_VW", 1);
+	const int on = FX_KNOB_INT("ROW_VW", 1);
 	if (!on || g.Zg <= 1 || g.cells_local() * 3 >= ((size_t)1 << 30)) return 0;
 	if (half_store) return g.X % 2 == 0 ? 2 : 0;               // binary16: pairs (4-byte aligned in an even row)
 	return g.X % 3 == 0 ? 3 : (g.X % 2 == 0 ? 2 : 0);
@@ -842,18 +841,14 @@ __global__ __launch_bounds__(256) void k_from_storage(const typename Store<HALF>
 // ---------------------------------------------------------------------------------------------
 static inline dim3 grid_xyz(const Geom& g, int nzp) { return dim3(((g.X + 63) / 64) * ((g.Y + 3) / 4) * nzp, 1, 1); }
 static inline unsigned grid_1d(size_t n) { return (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
-static int env_int(const char* name, int dflt);
 enum { REMAP_JACOBI = 0, REMAP_ADVECT = 1, REMAP_DIV = 2, REMAP_PROJECT = 3 };
 // per-kernel mapping mode (see xcd_tile).  FLUIDX_XCD_REMAP="j,a,d,p" overrides (measurement knob).
 static int xcd_remap_on(int which)
 {
-	static int mode[4] = { -1, 0, 0, 0 };
-	if (mode[0] < 0) {
-		mode[0] = 1; mode[1] = 0; mode[2] = 0; mode[3] = 0;   // measured: only the Jacobi sweeps gain (profiles/r01_xcd_remap.txt)
-		const char* e = getenv("FLUIDX_XCD_REMAP");
-		int a, b_, c, d;
-		if (e && sscanf(e, "%d,%d,%d,%d", &a, &b_, &c, &d) == 4) { mode[0] = a; mode[1] = b_; mode[2] = c; mode[3] = d; }
-	}
+	int mode[4] = { 1, 0, 0, 0 };                              // measured: only the Jacobi sweeps gain (docs/LAB.md)
+	const char* e = FX_KNOB("XCD_REMAP");
+	int a, b_, c, d;
+	if (e && sscanf(e, "%d,%d,%d,%d", &a, &b_, &c, &d) == 4) { mode[0] = a; mode[1] = b_; mode[2] = c; mode[3] = d; }
 	return mode[which];
 }
 
@@ -865,7 +860,8 @@ static int xcd_remap_on(int which)
 // no longer fits an L2 there).  FLUIDX_XCD_REMAP decides when set.
 static int xcd_remap_for(int which, const Geom& g)
 {
-	static const bool forced = [] { const char* e = getenv("FLUIDX_XCD_REMAP"); return e && *e; }();
+	const char* fe_ = FX_KNOB("XCD_REMAP");
+	const bool forced = fe_ && *fe_;
 	if (forced || which == REMAP_JACOBI) return xcd_remap_on(which);
 	return g.Zg > 1 && g.plane() <= 32768 && g.cells_local() < (size_t)6 << 20 ? 1 : 0;      // (measured at 128^3 and 150^3 only: planes up to 181^2)
 }
@@ -876,25 +872,23 @@ hipError_t launch_advect(const Geom& g, const SimParams& sp, int half_store, con
 	if (far_used) *far_used = false;
 	if (z_end <= z_begin) return hipSuccess;
 	// workgroup shape: FLUIDX_ADVECT_BLOCK="bx,by,bz" overrides (measurement knob)
-	static int bx = 0, by = 0, bz = 0;
-	if (!bx) {
-		bx = 64; by = 4; bz = 1;
-		const char* e = getenv("FLUIDX_ADVECT_BLOCK");
+	int bx = 64, by = 4, bz = 1;
+	if (const char* e = FX_KNOB("ADVECT_BLOCK")) {
 		int a, b_, c;
-		if (e && sscanf(e, "%d,%d,%d", &a, &b_, &c) == 3 && a > 0 && b_ > 0 && c > 0 && a * b_ * c <= 256) { bx = a; by = b_; bz = c; }
+		if (sscanf(e, "%d,%d,%d", &a, &b_, &c) == 3 && a > 0 && b_ > 0 && c > 0 && a * b_ * c <= 256) { bx = a; by = b_; bz = c; }
 	}
 	const int nzp = z_end - z_begin;
 	// taps from an LDS-staged tile (fx_advect_lds.hip) where the geometry allows it and the launch is large enough to pay;
 	// FLUIDX_ADVECT_LDS=0 switches it off, =2 takes it for small launches too (A/B and parity tests; read per launch)
 	{
-		const char* le = getenv("FLUIDX_ADVECT_LDS");
+		const char* le = FX_KNOB("ADVECT_LDS");
 		if (!(le && le[0] == '0') && bx == 64 && by == 4 && bz == 1 && !xcd_remap_on(REMAP_ADVECT)) {
 			const hipError_t e = launch_advect_lds(g, sp, half_store, vel_in, col_in, vel_out, col_out, z_begin, z_end, halo_overflow, far_scratch, far_words, far_parity, far_used, s, le && le[0] == '2');
 			if (e != hipErrorNotSupported) return e;
 		}
 	}
 	// lean path (see k_advect_fast): power-of-two extents, fields below 4 GiB, default workgroup shape and tile order
-	const char* fe = getenv("FLUIDX_ADVECT_FAST");                  // "0" = always the general kernel (A/B tests; read per launch)
+	const char* fe = FX_KNOB("ADVECT_FAST");                  // "0" = always the general kernel (A/B tests; read per launch)
 	const bool fast_off = fe && fe[0] == '0';
 	auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
 	if (!fast_off && pow2(g.X) && pow2(g.Y) && pow2(g.Zg) && g.X >= 2 && g.cells_local() * 16 < ((size_t)1 << 32) &&
@@ -983,11 +977,6 @@ hipError_t launch_jacobi_sweep2(const Geom& g, const float* p_in, const float* b
 // (The LDS tile kernel k_jacobi_tb<T> of round 1 -- z-streaming register windows + one LDS plane per level, two barriers per plane --
 // lost to the register strips in every shape measured, profiles/r01_jacobi_tile_sweep.txt, and was removed in round 3; with it went
 // four sweeps per launch: jacobi_fuse = 4 now runs threes.)
-static int env_int(const char* name, int dflt)
-{
-	const char* v = getenv(name);
-	return v && *v ? atoi(v) : dflt;
-}
 
 static bool tb_supported(const Geom& g)
 {
@@ -1007,7 +996,7 @@ static bool strip_profitable(const Geom& g, int nzp)
 
 int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp)
 {
-	static const int forced = env_int("FLUIDX_JACOBI_T", 0);
+	const int forced = FX_KNOB_INT("JACOBI_T", 0);
 	if (jacobi_strip_supported(g) && jacobi_strip_wide(g)) {            // X = 512: one fused shape (two sweeps, wide strips)
 		const int want = requested > 0 ? requested : (forced > 0 ? forced : (strip_profitable(g, nzp) ? 2 : 1));
 		return want >= 3 && jacobi_strip3_supported(g) ? 3 : (want >= 2 ? 2 : 1);
@@ -1029,9 +1018,9 @@ int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp)
 // request is always honoured as given.
 bool jacobi_prefers_three(const Geom& g, int requested, int nzp)
 {
-	static const int forced = env_int("FLUIDX_JACOBI_T", 0);
-	static const int prefer = env_int("FLUIDX_JACOBI_PREFER3", 1);
-	static const int no_lds3 = env_int("FLUIDX_STRIP3_OFF", 0);
+	const int forced = FX_KNOB_INT("JACOBI_T", 0);
+	const int prefer = FX_KNOB_INT("JACOBI_PREFER3", 1);
+	const int no_lds3 = FX_KNOB_INT("STRIP3_OFF", 0);
 	return prefer && !requested && !forced && !no_lds3 && jacobi_strip3_supported(g) &&
 		(size_t)g.X * g.Y * (size_t)nzp >= (g.X == 512 ? (size_t)1 << 24 : (size_t)3 << 22);
 	// X = 256: from 12.6 M cells (256x256x128 still loses, 11.3 against 11.0 us per sweep).  X = 512 (k_jacobi_strip3h): from 16.8 M
@@ -1053,7 +1042,7 @@ hipError_t launch_jacobi_fused(const Geom& g, const float* p_in, const float* b,
 		if (jacobi_block2_supported(g)) return launch_jacobi_block2(g, p_in, b, p_out, z_begin, z_end, s);
 		return launch_jacobi_strip(g, p_in, b, p_out, 2, z_begin, z_end, s);
 	case 3: {
-		static const int no_lds3 = env_int("FLUIDX_STRIP3_OFF", 0);    // 1 = the all-register three-sweep strips
+		const int no_lds3 = FX_KNOB_INT("STRIP3_OFF", 0);    // 1 = the all-register three-sweep strips
 		if (!no_lds3 && jacobi_strip3_supported(g)) return launch_jacobi_strip3(g, p_in, b, p_out, z_begin, z_end, s);
 		return launch_jacobi_strip(g, p_in, b, p_out, 3, z_begin, z_end, s);
 	}
@@ -1084,7 +1073,7 @@ hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, co
 {
 	if (rec_done) *rec_done = false;
 	if (z_end <= z_begin) return hipSuccess;
-	static const int v4_on = env_int("FLUIDX_PROJECT_V4", 1);
+	const int v4_on = FX_KNOB_INT("PROJECT_V4", 1);
 	if (v4_on && sp.is3d && (g.X & 3) == 0 && (g.cells_local() & 3) == 0 && g.cells_local() * 3 < ((size_t)1 << 30)) {
 		auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
 		const int nzp = z_end - z_begin, X4 = g.X >> 2;

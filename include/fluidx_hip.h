@@ -173,8 +173,10 @@ int fx_get_frame_info(fx_ctx* ctx, fx_frame_info* out);
  * step left the exchanged halo ON THIS RANK, and thereby acknowledges it.  Until then fx_download of a simulation field,
  * fx_checkpoint_save and fx_comm_gather_color of this rank return FX_E_HALO as well.  Independently the fault travels with the
  * per-step record: the next fx_simulate returns FX_E_HALO on EVERY rank of the chain, once, without stepping (its inputs are
- * untouched) -- the chain-wide notice, whichever of the two calls comes first; the fx_simulate after that starts clean.  No rank
- * runs on, or stores, fields that differ from the single-domain run without having been told. */
+ * untouched) -- the chain-wide notice, whichever of the two calls comes first; the fx_simulate after that starts clean on every
+ * rank, with or without an fx_synchronize in between (the notice takes the faulting rank's device flag down and keeps the fault on
+ * the host: that rank's read-back and checkpoints go on refusing until its fx_synchronize).  No rank runs on, or stores, fields that
+ * differ from the single-domain run without having been told. */
 int fx_synchronize(fx_ctx* ctx);
 
 /* checkpoint / parity access (no reference counterpart; the reference cannot read fields back) */
@@ -262,6 +264,14 @@ int fx_comm_gather_color(fx_ctx* ctx, void* stream, fx_ctx* full, int root, cons
  * exchange from the old field); switch the option off first. */
 enum fx_option { FX_OPT_OVERLAP = 1, FX_OPT_JACOBI_ROUND = 2, FX_OPT_ADAPTIVE_HALO = 3, FX_OPT_COUNT_SAMPLES = 4, FX_OPT_RENDER_ACCEL = 5 };
 int fx_set_option(fx_ctx* ctx, uint32_t option, uint32_t value);
+
+/* Measurement switches of the kernel launchers (no reference counterpart; docs/LAB.md lists them): which kernel serves a geometry,
+ * chunk sizes, tile orders -- A/B runs and the parity tests that pit one kernel of the library against another.  Process-wide,
+ * none changes a result.  name: e.g. "ADVECT_LDS", "JACOBI_T" (fx_knob_name enumerates them, NULL behind the last); value: the
+ * text the switch parses, NULL = back to the default.  FX_E_INVALID for an unknown name.  The library reads no environment variable
+ * for them (the one it reads: FLUIDX_RCCL_LIB, the path of librccl.so). */
+int fx_set_knob(const char* name, const char* value);
+const char* fx_knob_name(uint32_t index);
 
 #ifdef __cplusplus
 }

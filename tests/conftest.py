@@ -29,3 +29,19 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture
+def knob():
+    """sets measurement switches of the kernel launchers for one test (fx_set_knob: which kernel of the library serves a geometry);
+    usage: knob("ADVECT_LDS", "0"); every switch touched goes back to its default behind the test"""
+    from fluidx12_amd import capi
+    touched = []
+
+    def setter(name, value):
+        touched.append(name)
+        capi.set_knob(name, value)
+
+    yield setter
+    for name in touched:
+        capi.set_knob(name, None)

@@ -37,14 +37,12 @@ def plume_like(X, Y, Z, seed, amp=0.05):
 
 
 @pytest.fixture
-def knobs():
-    saved = {k: os.environ.get(k) for k in ("FLUIDX_FREEZE_T", "FLUIDX_FREEZE_NT", "FLUIDX_FREEZE_WGS", "FLUIDX_FREEZE_FAST")}
-    yield os.environ
-    for k, v in saved.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+def knobs(knob):
+    """dict-style access to the launcher switches (tests/conftest.py `knob`): knobs["FLUIDX_FREEZE_T"] = "2" """
+    class Setter:
+        def __setitem__(self, key, value):
+            knob(key[len("FLUIDX_"):] if key.startswith("FLUIDX_") else key, value)
+    return Setter()
 
 
 def solve(dims, p, b, iters):

@@ -471,12 +471,12 @@ def test_full_size_properties(X):
 @pytest.mark.parametrize("dims,storage,address", [((64, 64, 32), "fp32", "clamp"), ((32, 32, 64), "fp16", "mirror"),
                                                    ((128, 128, 1), "fp32", "clamp"), ((32, 32, 16), "fp32", "mirror"),
                                                    ((256, 256, 16), "fp32", "clamp")])
-def test_advect_fast_path_bit_identical(dims, storage, address, monkeypatch):
+def test_advect_fast_path_bit_identical(dims, storage, address, knob):
     """k_advect_fast (power-of-two grids: reciprocal multiplies, 32-bit tap offsets, shifts) against the general kernel"""
     import fluidx12_amd as fx
 
     def run(fast):
-        monkeypatch.setenv("FLUIDX_ADVECT_FAST", "1" if fast else "0")
+        knob("ADVECT_FAST", "1" if fast else "0")
         f = fx.Fluid()
         assert f.Init(320, 240, dims, storage=storage, advect_address=address, jacobi_iters=6)
         for k in range(5):
@@ -494,7 +494,7 @@ def test_advect_fast_path_bit_identical(dims, storage, address, monkeypatch):
 @pytest.mark.parametrize("storage", ["fp32", "fp16"])
 @pytest.mark.parametrize("dims,address,scale", [((64, 64, 64), "clamp", 0.2), ((64, 64, 64), "mirror", 3.0), ((128, 128, 32), "clamp", 1.0),
                                                  ((256, 256, 16), "mirror", 0.4), ((64, 64, 16), "clamp", 12.0)])
-def test_advect_lds_path_bit_identical(dims, address, scale, storage, monkeypatch):
+def test_advect_lds_path_bit_identical(dims, address, scale, storage, knob):
     """k_advect_lds (taps from an LDS-staged 66 x 10 x 3-plane window, global gathers for the waves that trace further) against
     k_advect_fast and the oracle: random velocities from well inside the window (scale 0.2: every wave on the LDS path) to far
     outside (12: every wave on the gather path), both addressing modes, grid borders in every direction"""
@@ -508,8 +508,8 @@ def test_advect_lds_path_bit_identical(dims, address, scale, storage, monkeypatc
         vel, col = vel.astype(np.float16).astype(f32), col.astype(np.float16).astype(f32)
     got = {}
     for lds in ("1", "inline", "0"):
-        monkeypatch.setenv("FLUIDX_ADVECT_LDS", "0" if lds == "0" else "2")      # 2 = the LDS path also below the size where it pays
-        monkeypatch.setenv("FLUIDX_ADVECT_DEFER", "0" if lds == "inline" else "1")   # far-tracing voxels: k_advect_far | gathers inside the kernel
+        knob("ADVECT_LDS", "0" if lds == "0" else "2")      # 2 = the LDS path also below the size where it pays
+        knob("ADVECT_DEFER", "0" if lds == "inline" else "1")   # far-tracing voxels: k_advect_far | gathers inside the kernel
         f = make(dims, advect_address=address, storage=storage)
         dt = f32(f.default_time_step())
         f.upload(fx.FIELD_VELOCITY, vel); f.upload(fx.FIELD_COLOR, col)
@@ -527,7 +527,7 @@ def test_advect_lds_path_bit_identical(dims, address, scale, storage, monkeypatc
     assert np.array_equal(got["1"][0][:, far], vo[:, far]) and np.array_equal(got["1"][1][far], co[far])
 
 
-def test_advect_deferred_voxels_over_changing_flows(monkeypatch):
+def test_advect_deferred_voxels_over_changing_flows(knob):
     """k_advect_lds puts the voxels that trace beyond its staged window on a list, k_advect_far advects them afterwards; the list's two
     totals alternate launch by launch.  Five advections of one context whose flow swings between "every voxel far" and "none", with a
     launch that does not defer in between: each equals the gather kernel's result bit for bit"""
@@ -535,17 +535,17 @@ def test_advect_deferred_voxels_over_changing_flows(monkeypatch):
     X, Y, Z = dims
     rng = np.random.default_rng(5)
     col = rng.random((Z, Y, X, 4)).astype(f32)
-    monkeypatch.setenv("FLUIDX_ADVECT_LDS", "2")
+    knob("ADVECT_LDS", "2")
     f = make(dims)
-    monkeypatch.setenv("FLUIDX_ADVECT_LDS", "0")
+    knob("ADVECT_LDS", "0")
     ref = make(dims)
     dt = f32(f.default_time_step())
     for k, (scale, defer) in enumerate([(12.0, "1"), (0.2, "1"), (3.0, "0"), (12.0, "1"), (1.0, "1"), (0.0, "1")]):
         vel = (rng.standard_normal((3, Z, Y, X)) * scale).astype(f32)
         out = []
         for g, lds in ((f, "2"), (ref, "0")):
-            monkeypatch.setenv("FLUIDX_ADVECT_LDS", lds)
-            monkeypatch.setenv("FLUIDX_ADVECT_DEFER", defer)
+            knob("ADVECT_LDS", lds)
+            knob("ADVECT_DEFER", defer)
             g.upload(fx.FIELD_VELOCITY, vel); g.upload(fx.FIELD_COLOR, col)
             g.UpdateFrame(dt, 0)
             g.Advect()

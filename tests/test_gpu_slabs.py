@@ -7,6 +7,7 @@ import pytest
 
 import fluidx12_amd as fx
 from fluidx12_amd import capi
+from oracle import orc          # checker only
 
 pytestmark = pytest.mark.gpu
 f32 = np.float32
@@ -262,6 +263,22 @@ def test_multi_gpu_render_by_colour_gather():
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
     assert np.array_equal(full.download(fx.FIELD_COLOR), ref.download(fx.FIELD_COLOR))
+    # ... and that picture is the ORACLE's: the gathered colour field marched, lit and resolved on the CPU (light map up to rare
+    # R11G11B10 rounding flips, cube map <= 1 LSB, the resolve of the gathered context's own cube map bit for bit)
+    col = full.download(fx.FIELD_COLOR)
+    fr, lod, rs, mask, _ = orc.update_frame(view, proj, eye, vp[0], vp[1], dims[0], 192)
+    fi = full.frame_info()
+    assert (fi.cube_lod, fi.ray_samples, fi.visibility_mask) == (lod, rs, mask)
+    lm_ref = orc.raymarch_light(col, fr, 64, False, 2)
+    assert (got[0] != lm_ref).mean() < 1e-3 and np.abs(got[0] - lm_ref).max() <= np.abs(lm_ref).max() * 2.0 ** -5
+    _, cu = orc.raymarch_view(col, lm_ref, fr, dims[0] >> lod, mask, rs, 64, False, True)
+    dcube = np.abs(got[1].astype(np.int32) - cu.astype(np.int32))
+    assert dcube.max() <= 1 and (dcube > 0).mean() <= 0.02
+    wvp_i = np.array(list(fi.world_view_proj_i), f32).reshape(4, 4)
+    out, cov = orc.resolve_cube(got[1], fr, wvp_i, vp[0], vp[1])
+    target = np.empty((vp[1], vp[0], 4), np.uint8)
+    target[...] = (51, 51, 51, 0)
+    assert np.array_equal(got[2], orc.blend_premultiplied(out, cov, target)) and cov.mean() > 0.01
     # a render-only context holds no simulation state
     with pytest.raises(fx.FluidxError):
         full.Simulate(0)
@@ -579,14 +596,14 @@ def test_bench_reference_configuration_line():
 
 
 @pytest.mark.parametrize("overlap", [2, 0])
-def test_slabs_with_lds_advection(overlap, monkeypatch):
+def test_slabs_with_lds_advection(overlap, knob):
     """k_advect_lds inside the slab schedule (interior range with own-planes-only back-traces, full range after the exchange,
     halo planes as the ring's z-1 / z+1): equal to the single domain advected by k_advect_fast, bit for bit"""
     dims = (64, 64, 96)
-    monkeypatch.setenv("FLUIDX_ADVECT_LDS", "0")
+    knob("ADVECT_LDS", "0")
     ref = run_single(dims, 6, jacobi_iters=10)
     want = (ref.download(fx.FIELD_VELOCITY), ref.download(fx.FIELD_COLOR), ref.download(fx.FIELD_PRESSURE))
-    monkeypatch.setenv("FLUIDX_ADVECT_LDS", "2")
+    knob("ADVECT_LDS", "2")
     fl = run_slabs(dims, 6, 2, jacobi_iters=10, halo_jacobi=4, halo_advect=6, overlap=overlap)
     assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), want[0])
     assert np.array_equal(gather(fl, fx.FIELD_COLOR, 0), want[1])
@@ -732,6 +749,40 @@ def test_an_overflow_on_one_rank_stops_every_rank_and_blocks_read_back():
         fl[0].Synchronize()
     assert e.value.status == capi.FX_E_HALO
     fl[0].Synchronize()                                      # acknowledged
+    assert fl[1].download(fx.FIELD_VELOCITY).shape == (3, 16, 32, 32)
+
+
+def test_the_fault_notice_acknowledges_itself_and_the_chain_runs_on():
+    """nobody calls fx_synchronize.  The step after the overflow is refused on every rank (the notice); the
+    notice takes the device flag down -- left up, every later step's record would carry it and the chain would alternate between
+    one executed and one refused step for ever -- so the two steps after it run.  The faulting ranks still refuse read-back until
+    their fx_synchronize has reported the fault."""
+    dims = (32, 32, 32)
+    fl = run_slabs(dims, 0, 2, jacobi_iters=4, halo_jacobi=1, halo_advect=3)     # (three planes: what the impulse's own flow needs later on)
+    vel = np.zeros((3, 16, 32, 32), f32)
+    vel[2] = 3.0                                             # traces six cells back
+    for f in fl:
+        f.set_option(capi.OPT_ADAPTIVE_HALO, 0)              # (the measured need of THIS field would stop step 0 before it overflows)
+        f.upload(fx.FIELD_VELOCITY, vel)
+    dt = f32(2.0 / 32)
+    fl[0].UpdateFrame(dt, 0)
+    fl[0].Simulate(0)                                        # overflows on the device
+    fl[0].UpdateFrame(dt, 1)
+    with pytest.raises(fx.FluidxError) as e:
+        fl[0].Simulate(1)                                    # the chain-wide notice
+    assert e.value.status == capi.FX_E_HALO
+    for f in fl:
+        f.upload(fx.FIELD_VELOCITY, np.zeros_like(vel))      # a slow field: nothing overflows any more
+    for k in (2, 3, 4):
+        fl[0].UpdateFrame(dt, k % 3)
+        fl[0].Simulate(k % 3)                                # (before: step 3 was refused again, then 5, 7, ...)
+    with pytest.raises(fx.FluidxError) as e:
+        fl[1].download(fx.FIELD_VELOCITY)                    # the fault of this rank has not been acknowledged yet
+    assert e.value.status == capi.FX_E_HALO
+    with pytest.raises(fx.FluidxError) as e:
+        fl[0].Synchronize()
+    assert e.value.status == capi.FX_E_HALO
+    fl[0].Synchronize()
     assert fl[1].download(fx.FIELD_VELOCITY).shape == (3, 16, 32, 32)
 
 

@@ -30,7 +30,8 @@ def main():
     f = fx.Fluid()
     assert f.Init(800, 800, (G, G, G), jacobi_iters=a.iters, storage=a.storage)
     dt = np.float32(f.default_time_step())
-    os.environ["FLUIDX_ADVECT_LDS"] = "0"
+    from fluidx12_amd import capi
+    capi.set_knob("ADVECT_LDS", "0")
     for k in range(a.steps):
         f.UpdateFrame(dt, k % 3)
         f.Simulate(k % 3)
@@ -40,13 +41,12 @@ def main():
     ref = None
     for var in a.variants.split(";"):
         opts = var.split(",")
-        os.environ["FLUIDX_ADVECT_LDS"] = "2" if opts[0] == "lds" else "0"
-        os.environ["FLUIDX_ADVECT_FAST"] = "0" if opts[0] == "generic" else "1"
-        for k in ("ZCHUNK", "DEPTH", "DBG"):
-            os.environ.pop("FLUIDX_ADVECT_" + k, None)
+        capi.set_knob("ADVECT_LDS", "2" if opts[0] == "lds" else "0")
+        capi.set_knob("ADVECT_FAST", "0" if opts[0] == "generic" else "1")
+        capi.set_knob("ADVECT_ZCHUNK", None)
         for o in opts[1:]:
             k, v = o.split("=")
-            os.environ["FLUIDX_ADVECT_" + k.upper()] = v
+            capi.set_knob("ADVECT_" + k.upper(), v)
         f.Advect(); f.Synchronize()
         f.timing_enable(True); f.timing_read(True)
         for _ in range(a.reps):

@@ -16,8 +16,9 @@ import fluidx12_amd as fx   # noqa: E402
 
 
 def run(grid, warm, steps, storage, env):
-    saved = {k: os.environ.get(k) for k in env}
-    os.environ.update({k: str(v) for k, v in env.items()})
+    from fluidx12_amd import capi
+    for k, v in env.items():                                  # launcher switches (fx_set_knob), named FLUIDX_<NAME> on the command line
+        capi.set_knob(k[len("FLUIDX_"):], v)
     try:
         f = fx.Fluid()
         assert f.Init(0, 0, (grid, grid, grid), storage=storage, jacobi_iters=64, jacobi_mode="faithful")
@@ -46,15 +47,15 @@ def run(grid, warm, steps, storage, env):
                     advect_ms=round(t.advect_ms / n, 4), divergence_ms=round(t.divergence_ms / n, 4), jacobi_ms=round(t.jacobi_ms / n, 4),
                     project_ms=round(t.project_ms / n, 4), jacobi_launches=t.jacobi_launches // n)
     finally:
-        for k, v in saved.items():
-            if v is None: os.environ.pop(k, None)
-            else: os.environ[k] = v
+        for k in env:
+            capi.set_knob(k[len("FLUIDX_"):], None)
 
 
 def all_active(grid, levels, env):
     """every tile listed, no cell ever freezing: what one tile launch of `levels` levels costs per tile"""
-    saved = {k: os.environ.get(k) for k in env}
-    os.environ.update({k: str(v) for k, v in env.items()})
+    from fluidx12_amd import capi
+    for k, v in env.items():                                  # launcher switches (fx_set_knob), named FLUIDX_<NAME> on the command line
+        capi.set_knob(k[len("FLUIDX_"):], v)
     try:
         f = fx.Fluid()
         assert f.Init(0, 0, (grid, grid, grid), storage="fp32", jacobi_iters=1 + levels, jacobi_mode="faithful")
@@ -72,9 +73,8 @@ def all_active(grid, levels, env):
         f.Release()
         return dict(env=env, grid=grid, levels=levels, dense_us_tiles_us_sweeps=out[2:])
     finally:
-        for k, v in saved.items():
-            if v is None: os.environ.pop(k, None)
-            else: os.environ[k] = v
+        for k in env:
+            capi.set_knob(k[len("FLUIDX_"):], None)
 
 
 if __name__ == "__main__":
