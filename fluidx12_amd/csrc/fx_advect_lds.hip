@@ -21,9 +21,12 @@
 // workgroups (16 waves) per CU.
 //
 // Arithmetic, association order and rounding are those of k_advect / k_advect_fast: bit-identical outputs
-// (tests/test_gpu_sim.py::test_advect_lds_path_bit_identical, ::test_advect_deferred_voxels_over_changing_flows).  Power-of-two
-// extents, X >= 64, Y >= 8; fp32 or binary16 storage.
+// (tests/test_gpu_sim.py::test_advect_lds_path_bit_identical, ::test_advect_deferred_voxels_over_changing_flows).  X >= 64, Y >= 8;
+// fp32 or binary16 storage.  P2 = power-of-two extents: reciprocal multiplies and shifts; otherwise (150^3, the reference's GI preset,
+// Bin/FluidGI.bat:1) divisions as in k_advect, rows and planes addressed by multiplies, and the last tile of a row / column of tiles
+// carries lanes without a voxel (they stage and keep the barriers, nothing else).
 #include "fx_internal.h"
+#include <algorithm>
 #include <cstdlib>
 #include <cstdio>
 
@@ -138,7 +141,11 @@ __device__ __forceinline__ T ldg32(const void* base, uint32_t byte_off)
 
 
 // the 24 + 8 taps of a voxel as gathers from global memory (k_advect_fast's): a trace that leaves the staged window
-template <bool HALF>
+// row / plane offsets in cells: shifts on power-of-two grids
+template <bool P2> __device__ __forceinline__ uint32_t rows(uint32_t y, int lgX, const Geom& g) { return P2 ? y << lgX : y * (uint32_t)g.X; }
+template <bool P2> __device__ __forceinline__ uint32_t planes(uint32_t z, int lgP, const Geom& g) { return P2 ? z << lgP : z * ((uint32_t)g.X * (uint32_t)g.Y); }
+
+template <bool HALF, bool P2>
 __device__ __forceinline__ void advect_gather(const Geom& g, const SimParams& sp, int ix, int iy, int z0, int z1, bool z_present, float fx, float fy, float fz,
 	const char* v0, const char* v1, const char* v2, const void* __restrict__ col_in, int lgX, int lgP, unsigned* halo_overflow, float (&u)[3], float (&c)[4])
 {
@@ -150,8 +157,8 @@ __device__ __forceinline__ void advect_gather(const Geom& g, const SimParams& sp
 		z0 = min(max(z0, g.zlo), g.zhi);
 		z1 = min(max(z1, g.zlo), g.zhi);
 	}
-	const uint32_t p0 = (uint32_t)g.lz(z0) << lgP, p1 = (uint32_t)g.lz(z1) << lgP;
-	const uint32_t ry0 = (uint32_t)ya0 << lgX, ry1 = (uint32_t)ya1 << lgX;
+	const uint32_t p0 = planes<P2>((uint32_t)g.lz(z0), lgP, g), p1 = planes<P2>((uint32_t)g.lz(z1), lgP, g);
+	const uint32_t ry0 = rows<P2>((uint32_t)ya0, lgX, g), ry1 = rows<P2>((uint32_t)ya1, lgX, g);
 	const uint32_t c000 = p0 + ry0 + (uint32_t)xa0, c100 = p0 + ry0 + (uint32_t)xa1;
 	const uint32_t c010 = p0 + ry1 + (uint32_t)xa0, c110 = p0 + ry1 + (uint32_t)xa1;
 	const uint32_t c001 = p1 + ry0 + (uint32_t)xa0, c101 = p1 + ry0 + (uint32_t)xa1;
@@ -229,7 +236,7 @@ __device__ __forceinline__ void advect_finish(const SimParams& sp, float (&u)[3]
 // DEFER: a voxel whose trace leaves the staged window is not gathered here -- its wave would issue 35 scattered loads for a few lanes and
 // hold the workgroup's barrier meanwhile -- but appended to the workgroup's segment of `far_list` (a placeholder is stored to its cell)
 // and advected by k_advect_far afterwards.  7 % of the waves of a developed plume (frame 132) have such a lane, 1.5 % of the voxels.
-template <bool HALF, int TY, bool DEFER>
+template <bool HALF, int TY, bool DEFER, bool P2>
 __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_advect_lds(const Geom g, const SimParams sp,
 	const void* __restrict__ vel_in, const void* __restrict__ col_in, void* __restrict__ vel_out, void* __restrict__ col_out,
 	int z_begin, int nzp, int zchunk, int nchunks, unsigned* halo_overflow, float rX, float rY, float rZ, float inv_rr,
@@ -241,13 +248,15 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	// tile order: XCD k (= workgroup index % 8) walks the k-th contiguous eighth of the (x, y, chunk)-ordered tile sequence, so
 	// that the tiles sharing a border row are neighbours in ONE L2
-	const int ntiles = (1 << (lg_gx + lg_gy)) * nchunks;
+	// (not P2: lg_gx / lg_gy carry the tile COUNTS per row / column of tiles)
+	const int ntx = P2 ? 1 << lg_gx : lg_gx, nty = P2 ? 1 << lg_gy : lg_gy;
+	const int ntiles = ntx * nty * nchunks;
 	int tl = (int)blockIdx.x;
 	{
 		const int q = ntiles >> 3, r = ntiles & 7, xcd = tl & 7, j = tl >> 3;
 		tl = xcd * q + min(xcd, r) + j;
 	}
-	const int tx = tl & ((1 << lg_gx) - 1), ty = (tl >> lg_gx) & ((1 << lg_gy) - 1), chunk = tl >> (lg_gx + lg_gy);
+	const int tx = P2 ? tl & (ntx - 1) : tl % ntx, ty = P2 ? (tl >> lg_gx) & (nty - 1) : (tl / ntx) % nty, chunk = P2 ? tl >> (lg_gx + lg_gy) : tl / (ntx * nty);
 	const int x0t = tx << 6, y0t = ty * TY;
 	const int zb = z_begin + chunk * zchunk, ze = min(zb + zchunk, z_begin + nzp);
 	if (zb >= ze) return;                                        // uniform for the workgroup
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
 	constexpr int COL_BYTES = Lay<HALF, TY>::COL_BYTES, SLOT_BYTES = Lay<HALF, TY>::SLOT_BYTES;
 	constexpr int NCELL = Lay<HALF, TY>::NCELL, VEL_BYTES = Lay<HALF, TY>::VEL_BYTES, NT = 64 * TY;
 	constexpr uint32_t ES = HALF ? 2 : 4, CS = HALF ? 8 : 16;    // bytes per velocity element / colour texel in HBM
-	const uint32_t stride = (uint32_t)g.nzl() << lgP;           // cells between velocity component planes
+	const uint32_t stride = planes<P2>((uint32_t)g.nzl(), lgP, g);   // cells between velocity component planes
 	const char* v0 = reinterpret_cast<const char*>(vel_in);
 	const char* v1 = v0 + (size_t)stride * ES;
 	const char* v2 = v1 + (size_t)stride * ES;
@@ -266,12 +275,12 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
 	uint32_t src_a, src_b = 0;
 	{
 		const int c = tid, r = c / HX, cc = c - r * HX;
-		src_a = ((uint32_t)addr_tap(y0t - 1 + r, g.Y, sp.address) << lgX) + (uint32_t)addr_tap(x0t - 1 + cc, g.X, sp.address);
+		src_a = rows<P2>((uint32_t)addr_tap(y0t - 1 + r, g.Y, sp.address), lgX, g) + (uint32_t)addr_tap(x0t - 1 + cc, g.X, sp.address);
 	}
 	const bool has_b = NT + tid < NCELL;
 	if (has_b) {
 		const int c = NT + tid, r = c / HX, cc = c - r * HX;
-		src_b = ((uint32_t)addr_tap(y0t - 1 + r, g.Y, sp.address) << lgX) + (uint32_t)addr_tap(x0t - 1 + cc, g.X, sp.address);
+		src_b = rows<P2>((uint32_t)addr_tap(y0t - 1 + r, g.Y, sp.address), lgX, g) + (uint32_t)addr_tap(x0t - 1 + cc, g.X, sp.address);
 	}
 	const bool wave_has_b = NT + wave * 64 < NCELL;              // waves 0, 1, 2
 
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
 	const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds;
 	auto fill = [&](int zq) {
 		const int za = min(max(addr_tap(zq, g.Zg, sp.address), g.zlo), g.zhi);   // voxels that would need a plane this slab lacks take the flagged path
-		const uint32_t pz = (uint32_t)g.lz(za) << lgP;
+		const uint32_t pz = planes<P2>((uint32_t)g.lz(za), lgP, g);
 		const uint32_t slot = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(((zq + 4) & 3) * SLOT_BYTES));
 		{
 			const size_t cell = pz + src_a;
@@ -307,16 +316,18 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
 	__syncthreads();
 
 	const int x = x0t + lane, y = y0t + wave;
+	const bool has_voxel = P2 || (x < g.X && y < g.Y);           // the last tiles of a row / column on other grids
 	const float dt = sp.dt;
-	const float px = ((float)x + 0.5f) * rX;                     // == / (float)g.X, exactly (power of two)
-	const float py = ((float)y + 0.5f) * rY;
+	const float px = P2 ? ((float)x + 0.5f) * rX : ((float)x + 0.5f) / (float)g.X;     // (== / (float)g.X exactly on a power of two; Simulation.hlsli:10)
+	const float py = P2 ? ((float)y + 0.5f) * rY : ((float)y + 0.5f) / (float)g.Y;
 	const float dx = px + -0.5f, dy = py + -0.100000001f;
 	const float dxy2 = fmaf(dy, dy, dx * dx);
 	const uint32_t own = (uint32_t)((wave + 1) * HX + lane + 1);  // this voxel's cell inside a slot
 	const float atten = fmaxf(fmaf(-dt, 0.200000003f, 1.0f), 0.0f);
 
 	auto compute = [&](int z) {
-		const float pz = ((float)z + 0.5f) * rZ;
+		if (!has_voxel) return;
+		const float pz = P2 ? ((float)z + 0.5f) * rZ : ((float)z + 0.5f) / (float)g.Zg;
 		const float dz = pz + -0.5f;
 		const float d2 = fmaf(dz, dz, dxy2);
 		const float ex = ((d2 * -4.0f) * inv_rr) * 1.44269502f;
@@ -338,7 +349,8 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
 		float u[3], c[4];
 		if (DEFER && !inwin) {                                   // noted for k_advect_far; below it reads the window like a voxel at rest
 			const uint32_t slot = atomicAdd(&far_n, 1u);
-			far_list[(size_t)blockIdx.x * far_cap + slot] = (uint32_t)x | (uint32_t)y << lgX | (uint32_t)z << lgP;
+			far_list[(size_t)blockIdx.x * far_cap + slot] = P2 ? (uint32_t)x | (uint32_t)y << lgX | (uint32_t)z << lgP
+				: ((uint32_t)z * (uint32_t)g.Y + (uint32_t)y) * (uint32_t)g.X + (uint32_t)x;
 		}
 		if (DEFER || inwin) {
 			// ---- the lanes that trace into the staged window: all 32 taps are LDS reads.  Without DEFER a mixed wave runs both
@@ -377,10 +389,10 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
 			c[0] = FX_TRI(x); c[1] = FX_TRI(y); c[2] = FX_TRI(z); c[3] = FX_TRI(w);
 #undef FX_TRI
 		} else {
-			advect_gather<HALF>(g, sp, ix, iy, z0, z1, z_present, fx, fy, fz, v0, v1, v2, col_in, lgX, lgP, halo_overflow, u, c);
+			advect_gather<HALF, P2>(g, sp, ix, iy, z0, z1, z_present, fx, fy, fz, v0, v1, v2, col_in, lgX, lgP, halo_overflow, u, c);
 		}
 
-		const uint32_t id = ((uint32_t)g.lz(z) << lgP) + ((uint32_t)y << lgX) + (uint32_t)x;
+		const uint32_t id = planes<P2>((uint32_t)g.lz(z), lgP, g) + rows<P2>((uint32_t)y, lgX, g) + (uint32_t)x;
 		advect_finish<HALF>(sp, u, c, ex, dx, dz, dt, atten, id, stride, vel_out, col_out);
 	};
 
@@ -390,7 +402,9 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
 		// the four stores of this step were issued after the LDS-DMA loads and complete after them: vmcnt(4) = "plane z+2 has
 		// landed" without waiting for the store acknowledgements.  That the compiler emits exactly four store instructions per
 		// step behind the fill is checked on the generated ISA by tests/test_isa_contract.py
-		asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+		// (a wave without a single voxel -- rows beyond Y in the last tile of a column -- has issued no store: it waits for everything)
+		if (P2 || y < g.Y) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+		else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__syncthreads();                                         // plane z+2 is in the ring; plane z-1's slot may be overwritten
 	}
 	// (behind the loop's last barrier: every append is in.)  The workgroup's notes move from its segment to ONE list every workgroup
@@ -410,7 +424,7 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
 
 // The voxels k_advect_lds<.., DEFER = true> put aside, one per thread off the common list: CSAdvect.hlsl:41-79 for one voxel with every tap a
 // gather (k_advect_fast's arithmetic, so the result is the one the staged path would have produced had the window been wide enough).
-template <bool HALF>
+template <bool HALF, bool P2>
 __global__ __launch_bounds__(256) void k_advect_far(const Geom g, const SimParams sp,
 	const void* __restrict__ vel_in, const void* __restrict__ col_in, void* __restrict__ vel_out, void* __restrict__ col_out,
 	const uint32_t* __restrict__ far_flat, const uint32_t* __restrict__ far_total, uint32_t* __restrict__ far_total_next, unsigned* halo_overflow,
@@ -420,7 +434,7 @@ __global__ __launch_bounds__(256) void k_advect_far(const Geom g, const SimParam
 	if (blockIdx.x == 0 && threadIdx.x == 0) *far_total_next = 0u;   // the counter the NEXT step's advection appends through (the two alternate)
 	const int lgP = lgX + lgY;
 	constexpr uint32_t ES = HALF ? 2 : 4;
-	const uint32_t stride = (uint32_t)g.nzl() << lgP;
+	const uint32_t stride = planes<P2>((uint32_t)g.nzl(), lgP, g);
 	const char* v0 = reinterpret_cast<const char*>(vel_in);
 	const char* v1 = v0 + (size_t)stride * ES;
 	const char* v2 = v1 + (size_t)stride * ES;
@@ -428,13 +442,17 @@ __global__ __launch_bounds__(256) void k_advect_far(const Geom g, const SimParam
 	const float atten = fmaxf(fmaf(-dt, 0.200000003f, 1.0f), 0.0f);
 	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
 		const uint32_t code = far_flat[i];
-		const int x = (int)(code & (uint32_t)(g.X - 1)), y = (int)((code >> lgX) & (uint32_t)(g.Y - 1)), z = (int)(code >> lgP);
-		const float px = ((float)x + 0.5f) * rX, py = ((float)y + 0.5f) * rY, pz = ((float)z + 0.5f) * rZ;
+		int x, y, z;
+		if (P2) { x = (int)(code & (uint32_t)(g.X - 1)); y = (int)((code >> lgX) & (uint32_t)(g.Y - 1)); z = (int)(code >> lgP); }
+		else { const uint32_t XY = (uint32_t)g.X * (uint32_t)g.Y, rem = code % XY; z = (int)(code / XY); y = (int)(rem / (uint32_t)g.X); x = (int)(rem % (uint32_t)g.X); }
+		const float px = P2 ? ((float)x + 0.5f) * rX : ((float)x + 0.5f) / (float)g.X;
+		const float py = P2 ? ((float)y + 0.5f) * rY : ((float)y + 0.5f) / (float)g.Y;
+		const float pz = P2 ? ((float)z + 0.5f) * rZ : ((float)z + 0.5f) / (float)g.Zg;
 		const float dx = px + -0.5f, dy = py + -0.100000001f, dz = pz + -0.5f;
 		const float dxy2 = fmaf(dy, dy, dx * dx);
 		const float d2 = fmaf(dz, dz, dxy2);
 		const float ex = ((d2 * -4.0f) * inv_rr) * 1.44269502f;
-		const uint32_t id = ((uint32_t)g.lz(z) << lgP) + ((uint32_t)y << lgX) + (uint32_t)x;
+		const uint32_t id = planes<P2>((uint32_t)g.lz(z), lgP, g) + rows<P2>((uint32_t)y, lgX, g) + (uint32_t)x;
 		auto gv = [](const char* b, uint32_t cell) -> float { return HALF ? (float)ldg32<h16>(b, cell * 2u) : ldg32<float>(b, cell * 4u); };
 		const float u0x = gv(v0, id), u0y = gv(v1, id), u0z = gv(v2, id);
 		const float ax = fmaf(-u0x, dt, px), ay = fmaf(-u0y, dt, py), az = fmaf(-u0z, dt, pz);
@@ -445,7 +463,7 @@ __global__ __launch_bounds__(256) void k_advect_far(const Geom g, const SimParam
 		const int z0 = addr_tap(iz, g.Zg, sp.address), z1 = addr_tap(iz + 1, g.Zg, sp.address);
 		const bool z_present = z0 >= g.zlo && z0 <= g.zhi && z1 >= g.zlo && z1 <= g.zhi;
 		float u[3], c[4];
-		advect_gather<HALF>(g, sp, ix, iy, z0, z1, z_present, fx, fy, fz, v0, v1, v2, col_in, lgX, lgP, halo_overflow, u, c);
+		advect_gather<HALF, P2>(g, sp, ix, iy, z0, z1, z_present, fx, fy, fz, v0, v1, v2, col_in, lgX, lgP, halo_overflow, u, c);
 		advect_finish<HALF>(sp, u, c, ex, dx, dz, dt, atten, id, stride, vel_out, col_out);
 	}
 }
@@ -460,22 +478,34 @@ hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store,
 	const int nzp = z_end - z_begin;
 	// rows per workgroup tile.  16 (one 1024-thread workgroup per CU, 1.16 x instead of 1.29 x border) measured 0.228 / 0.269 ms against
 	// 0.223 / 0.263 for 8 (256^3, states of step 25 / 110): the bytes it saves it loses to the single workgroup's barrier stalls
-	const int TY = FX_KNOB_INT("ADVECT_TILE_ROWS", 8) == 16 ? 16 : 8;
-	if (g.Zg <= 1 || !pow2(g.X) || !pow2(g.Y) || !pow2(g.Zg) || g.X < TX || g.Y < TY || nzp < 12 ||
-		(!force && (size_t)g.X * g.Y * (size_t)nzp < ((size_t)1 << 22)) ||     // 128^3: 0.032-0.040 ms against 0.030 for k_advect_fast -- too few workgroups
+	const bool p2 = pow2(g.X) && pow2(g.Y) && pow2(g.Zg);
+	const int TY = p2 && FX_KNOB_INT("ADVECT_TILE_ROWS", 8) == 16 ? 16 : 8;
+	// where it pays: from 4 M voxels per launch.  128^3 measured 0.032-0.040 ms against 0.030 for k_advect_fast, 150^3 0.049-0.053 against
+	// 0.057 for k_advect -- and inside whole steps, with the second launch for the far-tracing voxels, 0.0586 against 0.0555: too few
+	// workgroups either way
+	const size_t min_voxels = (size_t)1 << 22;
+	if (g.Zg <= 1 || g.X < TX || g.Y < TY || nzp < 12 || (!force && (size_t)g.X * g.Y * (size_t)nzp < min_voxels) ||
 		g.cells_local() * 16 >= ((size_t)1 << 32))
 		return hipErrorNotSupported;
 	const int half_on = FX_KNOB_INT("ADVECT_LDS_HALF", 1);
 	if (half_store && !half_on) return hipErrorNotSupported;
 	auto lg = [](int v) { int k = 0; while ((1 << k) < v) ++k; return k; };
-	const int lgX = lg(g.X), lgY = lg(g.Y), lg_gx = lg(g.X / TX), lg_gy = lg(g.Y / TY);
-	const int tiles_xy = (g.X / TX) * (g.Y / TY);
+	const int ntx = (g.X + TX - 1) / TX, nty = (g.Y + TY - 1) / TY;
+	const int lgX = lg(g.X), lgY = lg(g.Y), lg_gx = p2 ? lg(ntx) : ntx, lg_gy = p2 ? lg(nty) : nty;      // (other extents: the kernel gets the tile counts themselves)
+	const int tiles_xy = ntx * nty;
 	// planes per workgroup.  Every chunk re-reads two planes.  While the far-tracing voxels were gathered inside this kernel the
 	// workgroups over the plume took several times longer than the rest and short chunks (2048 workgroups of 16 planes at 256^3)
 	// balanced that: 0.216 ms with 16, 0.219 with 8, 0.241 with 32, 0.258 with 64.  With those voxels deferred every workgroup costs
 	// the same: 16 / 32 / 64 planes measure 0.211 / 0.203 / 0.212 ms (fp32), 0.147 / 0.143 / 0.144 (fp16), within the noise -- 32.
 	const bool want_defer = far_scratch && FX_KNOB_INT("ADVECT_DEFER", 1) != 0;
 	int zchunk = FX_KNOB_INT("ADVECT_ZCHUNK", want_defer ? 32 : 16);
+	// grids of a few million voxels (150^3: 57 tiles per plane) have too few workgroups for 32-plane chunks to fill the chip and too many
+	// with short ones for one resident round (two workgroups per CU): as many chunks as keep them all resident at once.  150^3, us per
+	// launch by planes per chunk: 6 49.8, 8 51.4, 12 51.2, 15 54.8, 19 49.0, 25 57.5, 32 67.5, 64 122 (k_advect: 57.3)
+	if (!p2 && !FX_KNOB("ADVECT_ZCHUNK")) {
+		const int chunks = std::max(1, 512 / tiles_xy);
+		zchunk = std::max(8, (nzp + chunks - 1) / chunks);
+	}
 	if (zchunk < 4) zchunk = 4;
 	if (zchunk > nzp) zchunk = nzp;
 	const int nchunks = (nzp + zchunk - 1) / zchunk;
@@ -484,27 +514,32 @@ hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store,
 	// [a segment of 64 * TY * zchunk ids per workgroup] (FLUIDX_ADVECT_DEFER=0: gathered inside the staged kernel, as before)
 	const uint32_t nwg = (uint32_t)(tiles_xy * nchunks), far_cap = (uint32_t)(TX * TY * zchunk);
 	const size_t flat_words = (size_t)g.X * g.Y * (size_t)nzp;
-	const bool defer = want_defer && far_words >= 2 + flat_words + (size_t)nwg * far_cap && ((uint64_t)g.Zg << (lgX + lgY)) <= ((uint64_t)1 << 32);   // (a note = x | y << lgX | z << lgP)
+	const bool defer = want_defer && far_words >= 2 + flat_words + (size_t)nwg * far_cap && ((uint64_t)g.Zg << (lgX + lgY)) <= ((uint64_t)1 << 32);   // (a note = x | y << lgX | z << lgP, or the voxel's index in the whole grid)
 	if (far_used) *far_used = defer;                              // (the caller alternates far_parity over the launches that did defer)
 	uint32_t* far_total = far_scratch ? far_scratch + (far_parity & 1) : nullptr;
 	uint32_t* far_total_next = far_scratch ? far_scratch + ((far_parity & 1) ^ 1) : nullptr;
 	uint32_t* far_flat = far_scratch ? far_scratch + 2 : nullptr;
 	uint32_t* far_list = far_scratch ? far_scratch + 2 + flat_words : nullptr;
-#define FX_ADV(H_, TY_, D_) do { \
+#define FX_ADV(H_, TY_, D_, P_) do { \
 		static bool attr_set = false; \
-		if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_advect_lds<H_, TY_, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * Lay<H_, TY_>::SLOT_BYTES); attr_set = true; } \
-		hipLaunchKernelGGL((k_advect_lds<H_, TY_, D_>), dim3(tiles_xy * nchunks), dim3(64 * TY_), (NSLOT * Lay<H_, TY_>::SLOT_BYTES), s, g, sp, vel_in, col_in, vel_out, col_out, \
+		if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_advect_lds<H_, TY_, D_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * Lay<H_, TY_>::SLOT_BYTES); attr_set = true; } \
+		hipLaunchKernelGGL((k_advect_lds<H_, TY_, D_, P_>), dim3(tiles_xy * nchunks), dim3(64 * TY_), (NSLOT * Lay<H_, TY_>::SLOT_BYTES), s, g, sp, vel_in, col_in, vel_out, col_out, \
 			z_begin, nzp, zchunk, nchunks, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY, lg_gx, lg_gy, far_list, far_flat, far_total, far_cap); } while (0)
-	if (defer) {
-		if (TY == 16) { if (half_store) FX_ADV(true, 16, true); else FX_ADV(false, 16, true); }
-		else { if (half_store) FX_ADV(true, 8, true); else FX_ADV(false, 8, true); }
-		const int far_wgs = 1024;                                   // 262144 threads: a developed 256^3 plume notes 250-400 thousand voxels
-		if (half_store) hipLaunchKernelGGL(k_advect_far<true>, dim3(far_wgs), dim3(256), 0, s, g, sp, vel_in, col_in, vel_out, col_out, far_flat, far_total, far_total_next, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY);
-		else hipLaunchKernelGGL(k_advect_far<false>, dim3(far_wgs), dim3(256), 0, s, g, sp, vel_in, col_in, vel_out, col_out, far_flat, far_total, far_total_next, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY);
+#define FX_FAR(H_, P_) hipLaunchKernelGGL((k_advect_far<H_, P_>), dim3(far_wgs), dim3(256), 0, s, g, sp, vel_in, col_in, vel_out, col_out, far_flat, far_total, far_total_next, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY)
+	const int far_wgs = 1024;                                       // 262144 threads: a developed 256^3 plume notes 250-400 thousand voxels
+	if (!p2) {
+		if (defer) {
+			if (half_store) { FX_ADV(true, 8, true, false); FX_FAR(true, false); } else { FX_ADV(false, 8, true, false); FX_FAR(false, false); }
+		} else { if (half_store) FX_ADV(true, 8, false, false); else FX_ADV(false, 8, false, false); }
+	} else if (defer) {
+		if (TY == 16) { if (half_store) FX_ADV(true, 16, true, true); else FX_ADV(false, 16, true, true); }
+		else { if (half_store) FX_ADV(true, 8, true, true); else FX_ADV(false, 8, true, true); }
+		if (half_store) FX_FAR(true, true); else FX_FAR(false, true);
 	} else {
-		if (TY == 16) { if (half_store) FX_ADV(true, 16, false); else FX_ADV(false, 16, false); }
-		else { if (half_store) FX_ADV(true, 8, false); else FX_ADV(false, 8, false); }
+		if (TY == 16) { if (half_store) FX_ADV(true, 16, false, true); else FX_ADV(false, 16, false, true); }
+		else { if (half_store) FX_ADV(true, 8, false, true); else FX_ADV(false, 8, false, true); }
 	}
+#undef FX_FAR
 #undef FX_ADV
 	return hipGetLastError();
 }
@@ -512,9 +547,9 @@ hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store,
 // scratch words launch_advect_lds needs to defer far-tracing voxels for planes [z_begin, z_end) of `g` (0: no staged path there)
 size_t advect_far_words(const Geom& g, int nzp)
 {
-	auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-	if (g.Zg <= 1 || !pow2(g.X) || !pow2(g.Y) || g.X < TX || g.Y < 16 || nzp < 12) return 0;
-	return 2 + (size_t)g.X * g.Y * (size_t)nzp + (size_t)g.X * g.Y * (size_t)(nzp + 32);   // two totals, the common list, the workgroups' segments (whole chunks)
+	if (g.Zg <= 1 || g.X < TX || g.Y < 16 || nzp < 12) return 0;
+	const size_t tiled = (size_t)((g.X + TX - 1) / TX * TX) * (size_t)((g.Y + 7) / 8 * 8);             // a plane as the 64 x 8 tiles cover it
+	return 2 + (size_t)g.X * g.Y * (size_t)nzp + tiled * (size_t)(nzp + 32);   // two totals, the common list, the workgroups' segments (whole chunks)
 }
 
 }  // namespace fx

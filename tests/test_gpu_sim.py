@@ -493,11 +493,14 @@ def test_advect_fast_path_bit_identical(dims, storage, address, knob):
 
 @pytest.mark.parametrize("storage", ["fp32", "fp16"])
 @pytest.mark.parametrize("dims,address,scale", [((64, 64, 64), "clamp", 0.2), ((64, 64, 64), "mirror", 3.0), ((128, 128, 32), "clamp", 1.0),
-                                                 ((256, 256, 16), "mirror", 0.4), ((64, 64, 16), "clamp", 12.0)])
+                                                 ((256, 256, 16), "mirror", 0.4), ((64, 64, 16), "clamp", 12.0),
+                                                 ((150, 150, 24), "clamp", 1.0), ((150, 150, 20), "mirror", 3.0), ((100, 100, 33), "clamp", 0.3),
+                                                 ((72, 72, 16), "mirror", 12.0)])
 def test_advect_lds_path_bit_identical(dims, address, scale, storage, knob):
     """k_advect_lds (taps from an LDS-staged 66 x 10 x 3-plane window, global gathers for the waves that trace further) against
     k_advect_fast and the oracle: random velocities from well inside the window (scale 0.2: every wave on the LDS path) to far
-    outside (12: every wave on the gather path), both addressing modes, grid borders in every direction"""
+    outside (12: every wave on the gather path), both addressing modes, grid borders in every direction; and extents that are no
+    power of two (150: the reference's GI preset, Bin/FluidGI.bat:1 -- tiles with lanes and whole waves beyond the grid)"""
     X, Y, Z = dims
     rng = np.random.default_rng(77)
     vel = (rng.standard_normal((3, Z, Y, X)) * scale).astype(f32)
