@@ -88,6 +88,7 @@ SYMBOLS = {
     "fx_comm_get_unique_id": (C.c_int, [_vp, C.c_size_t]),
     "fx_comm_init_rank": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_int]),
     "fx_comm_init_local": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "fx_comm_init_peer": (C.c_int, [C.POINTER(_vp), C.c_int]),
 }
 
 _lib = None

@@ -408,28 +408,25 @@ static int check_slab_chain(fx_ctx* c, int rank, int nranks)
 	return FX_OK;
 }
 
-// side stream (highest priority: the exchange kernels must get CUs while the interior sweeps fill the chip) + ordering events
-static int make_comm_stream(fx_comm_group* g, int device)
+// a lane: side streams + ordering events of one rank (fx_context.h); `compute` = the member's own stream in peer groups, else null
+static int make_lane(fx_comm_group* g, int device, hipStream_t compute)
 {
-	g->comm_stream = nullptr; g->ev_ready = nullptr; g->ev_done = nullptr;
-	g->shared_stream = nullptr; g->broken = false;
-	g->face_stream = nullptr; g->ev_int = nullptr; g->ev_face1 = nullptr; g->ev_col_ready = nullptr; g->ev_col_done = nullptr;
+	fx_lane l{};
+	l.device = device;
+	l.compute = compute;
 	DeviceGuard dg(device);
 	// DEFAULT priority.  A high-priority side stream made every dependency between it and the compute stream cost about a
-	// millisecond for the first group of a process (18 ms per step instead of 7.7, profiles/r01d_slab_schedule_loopback.txt);
-	// FLUIDX_COMM_PRIORITY=1 asks for the highest priority anyway (measurement knob).
+	// millisecond for the first group of a process (18 ms per step instead of 7.7, docs/LAB.md); the switch COMM_PRIORITY = 1
+	// asks for the highest priority anyway (measurement).
 	int lo = 0, hi = 0, prio = 0;
 	const char* pe = FX_KNOB("COMM_PRIORITY");
 	if (pe && pe[0] == '1' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) prio = hi;
-	if (hipStreamCreateWithPriority(&g->comm_stream, hipStreamNonBlocking, prio) != hipSuccess) return FX_E_DEVICE;
-	if (hipEventCreateWithFlags(&g->ev_ready, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;
-	if (hipEventCreateWithFlags(&g->ev_done, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;
-	if (hipStreamCreateWithFlags(&g->face_stream, hipStreamNonBlocking) != hipSuccess) return FX_E_DEVICE;
-	if (hipEventCreateWithFlags(&g->ev_int, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;
-	if (hipEventCreateWithFlags(&g->ev_face1, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;
-	if (hipEventCreateWithFlags(&g->ev_col_ready, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;
-	if (hipEventCreateWithFlags(&g->ev_col_done, hipEventDisableTiming) != hipSuccess) return FX_E_DEVICE;
-	return FX_OK;
+	bool ok = hipStreamCreateWithPriority(&l.comm, hipStreamNonBlocking, prio) == hipSuccess;
+	ok = ok && hipStreamCreateWithFlags(&l.face, hipStreamNonBlocking) == hipSuccess;
+	for (hipEvent_t* e : { &l.ev_ready, &l.ev_done, &l.ev_col_ready, &l.ev_col_done, &l.ev_int, &l.ev_face1, &l.x_ready, &l.x_done })
+		ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+	g->lanes.push_back(l);                             // (pushed even when incomplete: the group's teardown frees what exists)
+	return ok ? FX_OK : FX_E_DEVICE;
 }
 
 // buffers of the per-step record (fx_context.h); nrec = records the host copy holds (RCCL: every rank's; loop-back member: its own)
@@ -457,8 +454,9 @@ int fx_comm_init_rank(fx_ctx* ctx, const void* id, size_t bytes, int rank, int n
 	g->members.push_back(ctx);
 	g->transport = t;
 	g->refs = 1;
-	if ((rc = make_comm_stream(g, ctx->device))) { delete t; delete g; return rc; }
-	if ((rc = t->min_over_ranks(ctx->g.nz, ctx->stream, &g->min_nz))) { delete t; delete g; return rc; }
+	g->per_member = false; g->shared_stream = nullptr; g->broken = false;
+	if ((rc = make_lane(g, ctx->device, nullptr))) { destroy_lanes(g); delete t; delete g; return rc; }
+	if ((rc = t->min_over_ranks(ctx->g.nz, ctx->stream, &g->min_nz))) { destroy_lanes(g); delete t; delete g; return rc; }
 	{	// every rank must run the same schedule: same grid, halos, sweep count, Jacobi mode and storage (min == max of a digest)
 		const fx_desc& d = ctx->desc;
 		uint32_t h = 2166136261u;
@@ -469,15 +467,15 @@ int fx_comm_init_rank(fx_ctx* ctx, const void* id, size_t bytes, int rank, int n
 			h = (h ^ v) * 16777619u;
 		const int digest = (int)(h & 0x3FFFFFFFu);
 		int lo = 0, hi = 0;
-		if ((rc = t->min_over_ranks(digest, ctx->stream, &lo)) || (rc = t->min_over_ranks(-digest, ctx->stream, &hi))) { delete t; delete g; return rc; }
+		if ((rc = t->min_over_ranks(digest, ctx->stream, &lo)) || (rc = t->min_over_ranks(-digest, ctx->stream, &hi))) { destroy_lanes(g); delete t; delete g; return rc; }
 		if (lo != digest || -hi != digest) {
 			ctx->last_error = "fx_comm_init_rank: the ranks were created with different descriptors";
 			std::fprintf(stderr, "fluidx: %s\n", ctx->last_error.c_str());
-			delete t; delete g;
+			destroy_lanes(g); delete t; delete g;
 			return FX_E_INVALID;
 		}
 	}
-	if (!ctx->step_rec && (rc = make_step_record(ctx, nranks, true))) { delete t; delete g; return rc; }   // (kept from a refused earlier attempt)
+	if (!ctx->step_rec && (rc = make_step_record(ctx, nranks, true))) { destroy_lanes(g); delete t; delete g; return rc; }   // (kept from a refused earlier attempt)
 	{	// the slabs must tile the grid in rank order: rank 0 starts at plane 0, the last ends at Zg (check_slab_chain), and every
 		// slab starts where its lower neighbour ends -- gaps or overlaps between middle slabs would exchange the wrong planes
 		DeviceGuard dg(ctx->device);
@@ -492,7 +490,7 @@ int fx_comm_init_rank(fx_ctx* ctx, const void* id, size_t bytes, int rank, int n
 		if (!ok || !tiles) {
 			ctx->last_error = ok ? "fx_comm_init_rank: the slabs of the ranks do not tile the grid in rank order" : "fx_comm_init_rank: exchanging the slab ranges failed";
 			std::fprintf(stderr, "fluidx: %s\n", ctx->last_error.c_str());
-			delete t; delete g;
+			destroy_lanes(g); delete t; delete g;
 			return ok ? FX_E_INVALID : FX_E_COMM;
 		}
 	}
@@ -511,6 +509,7 @@ int fx_comm_gather_color(fx_ctx* ctx, void* stream, fx_ctx* full, int root, cons
 		if (!full || full->g.X != ctx->g.X || full->g.Y != ctx->g.Y || full->g.Zg != ctx->g.Zg || full->g.nz != full->g.Zg ||
 			full->half != ctx->half) return FX_E_INVALID;
 		if (!local && full->device != ctx->device) return FX_E_INVALID;
+		if (local && full->device != ctx->group->members[(size_t)root]->device) return FX_E_INVALID;   // the whole-grid context lives where the root does
 	}
 	if (!local && (!slab_z0 || !slab_nz)) return FX_E_INVALID;
 	const size_t plane_bytes = ctx->g.plane() * 4 * elem_size(ctx);
@@ -528,17 +527,25 @@ int fx_comm_gather_color(fx_ctx* ctx, void* stream, fx_ctx* full, int root, cons
 	DeviceGuard dg(ctx->device);
 	hipStream_t s = pick_stream(ctx, stream);
 	if (ctx->halo_fault) return FX_E_HALO;             // a colour field that is known to be off is not gathered into a picture
+	std::vector<hipStream_t> streams;                  // one; a peer group: every member's own, the copies ordered on the root's
+	if (ctx->group->per_member) for (fx_ctx* m : ctx->group->members) streams.push_back(m->stream);
+	else streams.push_back(s);
+	hipStream_t done_on = ctx->group->per_member ? streams[(size_t)root] : s;
 	ScopedMark mk(ctx, s, MK_EXCH);
-	int rc = ctx->group->transport->gather(ctx->group, parts, root, s);
+	int rc = ctx->group->transport->gather(ctx->group, parts, root, streams);
 	if (rc) return rc;
-	if (am_root && full->stream != s) {                // the render context's own stream must see the planes
-		FX_HIP(hipEventRecord(ctx->group->ev_done, s));
-		FX_HIP(hipStreamWaitEvent(full->stream, ctx->group->ev_done, 0));
+	if (am_root && full->stream != done_on) {          // the render context's own stream must see the planes
+		fx_lane& L = ctx->group->per_member ? ctx->group->lanes[(size_t)root] : ctx->group->lanes[0];
+		DeviceGuard dgr(L.device);
+		FX_HIP(hipEventRecord(L.ev_done, done_on));
+		DeviceGuard dgf(full->device);
+		FX_HIP(hipStreamWaitEvent(full->stream, L.ev_done, 0));
 	}
 	return FX_OK;
 }
 
-int fx_comm_init_local(fx_ctx** ctxs, int nranks)
+// the checks both kinds of in-process group share; one_device: every member must live on the first one's device
+static int check_local_members(fx_ctx** ctxs, int nranks, bool one_device)
 {
 	if (!ctxs || nranks < 1) return FX_E_INVALID;
 	int zexp = 0;
@@ -546,7 +553,7 @@ int fx_comm_init_local(fx_ctx** ctxs, int nranks)
 		if (!ctxs[r]) return FX_E_INVALID;
 		int rc = check_slab_chain(ctxs[r], r, nranks);
 		if (rc) return rc;
-		if (ctxs[r]->g.z0 != zexp || ctxs[r]->device != ctxs[0]->device) return FX_E_INVALID;   // contiguous chain, one device
+		if (ctxs[r]->g.z0 != zexp || (one_device && ctxs[r]->device != ctxs[0]->device)) return FX_E_INVALID;   // contiguous chain
 		// every member must describe the same run (the RCCL path checks a digest of the same fields across the ranks): members
 		// of different grids would exchange planes of different sizes
 		const fx_desc &a = ctxs[r]->desc, &b = ctxs[0]->desc;
@@ -557,18 +564,47 @@ int fx_comm_init_local(fx_ctx** ctxs, int nranks)
 		for (int q = 0; q < r; ++q) if (ctxs[q] == ctxs[r]) return FX_E_INVALID;
 		zexp += ctxs[r]->g.nz;
 	}
+	return FX_OK;
+}
+
+static int init_in_process_group(fx_ctx** ctxs, int nranks, bool peer)
+{
+	int rc = check_local_members(ctxs, nranks, !peer);
+	if (rc) return rc;
+	if (peer) {
+		// a receiver copies out of its neighbour's memory: across devices that needs peer access (one process owns them all: no IPC
+		// handles, which this pool's driver does not give out between processes)
+		for (int r = 0; r + 1 < nranks; ++r) {
+			const int a = ctxs[r]->device, b = ctxs[r + 1]->device;
+			if (a == b) continue;
+			int ab = 0, ba = 0;
+			if (hipDeviceCanAccessPeer(&ab, a, b) != hipSuccess || hipDeviceCanAccessPeer(&ba, b, a) != hipSuccess || !ab || !ba) {
+				ctxs[0]->last_error = "fx_comm_init_peer: two neighbouring slabs live on devices without peer access";
+				return FX_E_DEVICE;
+			}
+			for (int k = 0; k < 2; ++k) {
+				DeviceGuard dg(k ? b : a);
+				const hipError_t e = hipDeviceEnablePeerAccess(k ? a : b, 0);
+				if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return FX_E_DEVICE; }
+				(void)hipGetLastError();
+			}
+		}
+	}
 	for (int r = 0; r < nranks; ++r)
-		if (!ctxs[r]->step_rec) { if (int rc = make_step_record(ctxs[r], 1, false)) return rc; }
+		if (!ctxs[r]->step_rec) { if ((rc = make_step_record(ctxs[r], 1, false))) return rc; }
 	fx_comm_group* g = new fx_comm_group();
 	g->transport = make_local_transport();
 	g->refs = nranks;
-	if (int rc = make_comm_stream(g, ctxs[0]->device)) { delete g->transport; delete g; return rc; }
+	g->per_member = peer; g->shared_stream = nullptr; g->broken = false;
+	for (int r = 0; r < (peer ? nranks : 1); ++r)
+		if ((rc = make_lane(g, ctxs[r]->device, peer ? ctxs[r]->stream : nullptr))) { destroy_lanes(g); delete g->transport; delete g; return rc; }
 	g->min_nz = ctxs[0]->g.nz;
 	for (int r = 1; r < nranks; ++r) g->min_nz = std::min(g->min_nz, ctxs[r]->g.nz);
 	for (int r = 0; r < nranks; ++r) {
 		g->members.push_back(ctxs[r]);
 		ctxs[r]->group = g; ctxs[r]->rank = r; ctxs[r]->nranks = nranks;
-		// one stream for the whole loop-back group: phases of different members are ordered by it.  The group owns it, so
+		if (peer) continue;                                // every member keeps (and owns) its stream
+		// one stream for the whole shared-stream group: phases of different members are ordered by it.  The group owns it, so
 		// that the members can be destroyed in any order.
 		if (r > 0) {
 			if (ctxs[r]->owns_stream) (void)hipStreamDestroy(ctxs[r]->stream);
@@ -579,6 +615,9 @@ int fx_comm_init_local(fx_ctx** ctxs, int nranks)
 	}
 	return FX_OK;
 }
+
+int fx_comm_init_local(fx_ctx** ctxs, int nranks) { return init_in_process_group(ctxs, nranks, false); }
+int fx_comm_init_peer(fx_ctx** ctxs, int nranks) { return init_in_process_group(ctxs, nranks, true); }
 
 }  // extern "C"
 

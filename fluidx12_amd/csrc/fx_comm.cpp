@@ -5,8 +5,12 @@
 //                   ncclGroupStart/End per exchange.  xGMI is point-to-point, a slab chain loads two of the
 //                   seven links of a GPU, so there is no ring collective anywhere on the step path.
 //                   librccl is dlopen()ed on first use so that a single-GPU box never needs it.
-//   LocalTransport  several slab contexts in ONE process on ONE device; planes travel as device-to-device
-//                   hipMemcpyAsync.  Same halo geometry, used to verify the decomposition on a 1-GPU box.
+//   LocalTransport  several slab contexts in ONE process; same halo geometry and phase schedule.  Two kinds of group:
+//                   shared stream (fx_comm_init_local) -- one device, every member on one compute stream, planes travel as copy
+//                   kernels on it: the decomposition's arithmetic on a 1-GPU box;
+//                   peer (fx_comm_init_peer) -- every member on its own streams, on its own device if it likes: a receiver PULLS
+//                   its halo planes out of the neighbour's memory (hipMemcpyPeerAsync across devices; no IPC handles -- one
+//                   process owns all devices), ordered by a ready / done event pair per lane and exchange.
 #include "fx_context.h"
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -73,35 +77,97 @@ struct LocalTransport : Transport {
 	bool is_local() const override { return true; }
 	int min_over_ranks(int v, hipStream_t, int* out) override { *out = v; return FX_OK; }   // the caller sees every member
 	int allgather(const int*, int, int*, hipStream_t) override { return FX_OK; }
-	int exchange(fx_comm_group* grp, const std::vector<std::vector<Seg>>& segs, hipStream_t s, int channel) override
+	int exchange(fx_comm_group* grp, const std::vector<std::vector<Seg>>& segs, const std::vector<hipStream_t>& streams, int channel) override
 	{
-		(void)channel;                                   // one device: copies on the given stream either way
+		(void)channel;                                   // copies on the given streams either way
 		const int n = (int)grp->members.size();
-		if ((int)segs.size() != n) return FX_E_STATE;
+		if ((int)segs.size() != n || streams.empty()) return FX_E_STATE;
+		const bool peer = streams.size() > 1;
+		if (peer && ((int)streams.size() != n || (int)grp->lanes.size() != n)) return FX_E_STATE;
 		// timing experiments only (results become wrong): keep the streams/events of the schedule, drop the copies
 		const bool no_copy = [] { const char* e = FX_KNOB("DEBUG_NO_COPY"); return e && e[0] == '1'; }();
 		if (no_copy) return FX_OK;
+		int home = -1;
+		(void)hipGetDevice(&home);
+		int rc = FX_OK;
+		// peer groups: lane r may read its neighbours' planes once they are final there, and write its own halo once its own stream
+		// has got here
+		if (peer) {
+			for (int r = 0; r < n && rc == FX_OK; ++r)
+				if (hipSetDevice(grp->lanes[r].device) != hipSuccess || hipEventRecord(grp->lanes[r].x_ready, streams[r]) != hipSuccess) rc = FX_E_DEVICE;
+			for (int r = 0; r < n && rc == FX_OK; ++r)
+				for (int d = -1; d <= 1; d += 2) {
+					const int q = r + d;
+					if (q < 0 || q >= n) continue;
+					if (hipSetDevice(grp->lanes[r].device) != hipSuccess || hipStreamWaitEvent(streams[r], grp->lanes[q].x_ready, 0) != hipSuccess) rc = FX_E_DEVICE;
+				}
+		}
 		// every member "receives": its j-th segment from direction d pairs with the peer's j-th segment towards -d
-		for (int r = 0; r < n; ++r)
-			for (int d = -1; d <= 1; d += 2) {
-				const int peer = r + d;
-				if (peer < 0 || peer >= n) continue;
+		for (int r = 0; r < n && rc == FX_OK; ++r) {
+			hipStream_t s = peer ? streams[r] : streams[0];
+			if (peer && hipSetDevice(grp->lanes[r].device) != hipSuccess) { rc = FX_E_DEVICE; break; }
+			for (int d = -1; d <= 1 && rc == FX_OK; d += 2) {
+				const int q = r + d;
+				if (q < 0 || q >= n) continue;
 				size_t jp = 0;
 				for (const Seg& mine : segs[r]) {
 					if (mine.dir != d) continue;
-					while (jp < segs[peer].size() && segs[peer][jp].dir != -d) ++jp;
-					if (jp == segs[peer].size() || segs[peer][jp].bytes != mine.bytes) return FX_E_STATE;   // the lists must mirror
-					if (launch_copy_bytes(mine.recv, segs[peer][jp].send, mine.bytes, s) != hipSuccess) return FX_E_DEVICE;
+					while (jp < segs[q].size() && segs[q][jp].dir != -d) ++jp;
+					if (jp == segs[q].size() || segs[q][jp].bytes != mine.bytes) { rc = FX_E_STATE; break; }   // the lists must mirror
+					hipError_t e;
+					if (peer && grp->lanes[r].device != grp->lanes[q].device)
+						e = hipMemcpyPeerAsync(mine.recv, grp->lanes[r].device, segs[q][jp].send, grp->lanes[q].device, mine.bytes, s);
+					else e = launch_copy_bytes(mine.recv, segs[q][jp].send, mine.bytes, s);
+					if (e != hipSuccess) { rc = FX_E_DEVICE; break; }
 					++jp;
 				}
 			}
-		return FX_OK;
+		}
+		// ... and nobody moves on (to overwrite what a neighbour is still pulling) before both neighbours have pulled
+		if (peer) {
+			for (int r = 0; r < n && rc == FX_OK; ++r)
+				if (hipSetDevice(grp->lanes[r].device) != hipSuccess || hipEventRecord(grp->lanes[r].x_done, streams[r]) != hipSuccess) rc = FX_E_DEVICE;
+			for (int r = 0; r < n && rc == FX_OK; ++r)
+				for (int d = -1; d <= 1; d += 2) {
+					const int q = r + d;
+					if (q < 0 || q >= n) continue;
+					if (hipSetDevice(grp->lanes[r].device) != hipSuccess || hipStreamWaitEvent(streams[r], grp->lanes[q].x_done, 0) != hipSuccess) rc = FX_E_DEVICE;
+				}
+		}
+		if (home >= 0) (void)hipSetDevice(home);
+		return rc;
 	}
-	int gather(fx_comm_group*, const std::vector<GatherPart>& parts, int, hipStream_t s) override
+	int gather(fx_comm_group* grp, const std::vector<GatherPart>& parts, int root, const std::vector<hipStream_t>& streams) override
 	{
-		for (const GatherPart& p : parts)
-			if (p.bytes && launch_copy_bytes(p.dst, p.src, p.bytes, s) != hipSuccess) return FX_E_DEVICE;
-		return FX_OK;
+		const int n = (int)grp->members.size();
+		const bool peer = streams.size() > 1;
+		if (streams.empty() || (peer && ((int)streams.size() != n || root < 0 || root >= n))) return FX_E_STATE;
+		hipStream_t s = peer ? streams[root] : streams[0];
+		int home = -1;
+		(void)hipGetDevice(&home);
+		int rc = FX_OK;
+		if (peer) {                                      // the root's stream waits for what every member has enqueued
+			for (int r = 0; r < n && rc == FX_OK; ++r)
+				if (hipSetDevice(grp->lanes[r].device) != hipSuccess || hipEventRecord(grp->lanes[r].x_ready, streams[r]) != hipSuccess) rc = FX_E_DEVICE;
+			for (int r = 0; r < n && rc == FX_OK; ++r)
+				if (r != root && (hipSetDevice(grp->lanes[root].device) != hipSuccess || hipStreamWaitEvent(s, grp->lanes[r].x_ready, 0) != hipSuccess)) rc = FX_E_DEVICE;
+			if (rc == FX_OK && hipSetDevice(grp->lanes[root].device) != hipSuccess) rc = FX_E_DEVICE;
+		}
+		for (const GatherPart& p : parts) {
+			if (rc != FX_OK || !p.bytes) continue;
+			hipError_t e;
+			if (peer && grp->lanes[p.rank].device != grp->lanes[root].device)
+				e = hipMemcpyPeerAsync(p.dst, grp->lanes[root].device, p.src, grp->lanes[p.rank].device, p.bytes, s);
+			else e = launch_copy_bytes(p.dst, p.src, p.bytes, s);
+			if (e != hipSuccess) rc = FX_E_DEVICE;
+		}
+		if (peer && rc == FX_OK) {                       // the members must not overwrite their planes before the root has them
+			if (hipEventRecord(grp->lanes[root].x_done, s) != hipSuccess) rc = FX_E_DEVICE;
+			for (int r = 0; r < n && rc == FX_OK; ++r)
+				if (r != root && (hipSetDevice(grp->lanes[r].device) != hipSuccess || hipStreamWaitEvent(streams[r], grp->lanes[root].x_done, 0) != hipSuccess)) rc = FX_E_DEVICE;
+		}
+		if (home >= 0) (void)hipSetDevice(home);
+		return rc;
 	}
 };
 
@@ -188,10 +254,11 @@ struct RcclTransport : Transport {
 	{
 		return api->AllGather(send_dev, recv_dev, (size_t)count, ncclInt32, comm, s) == ncclSuccess ? FX_OK : FX_E_COMM;
 	}
-	int exchange(fx_comm_group* grp, const std::vector<std::vector<Seg>>& segs, hipStream_t s, int channel) override
+	int exchange(fx_comm_group* grp, const std::vector<std::vector<Seg>>& segs, const std::vector<hipStream_t>& streams, int channel) override
 	{
 		fx_ctx* c = grp->members[0];
-		if (segs.size() != 1) return FX_E_STATE;
+		if (segs.size() != 1 || streams.size() != 1) return FX_E_STATE;
+		hipStream_t s = streams[0];
 		ncclComm_t comm = channel == 1 ? this->comm2 : this->comm;
 		ncclResult_t r = api->GroupStart();
 		for (const Seg& sg : segs[0]) {
@@ -206,10 +273,11 @@ struct RcclTransport : Transport {
 		if (r != ncclSuccess) { c->last_error = std::string("rccl: ") + api->GetErrorString(r); return FX_E_COMM; }
 		return FX_OK;
 	}
-	int gather(fx_comm_group* grp, const std::vector<GatherPart>& parts, int root, hipStream_t s) override
+	int gather(fx_comm_group* grp, const std::vector<GatherPart>& parts, int root, const std::vector<hipStream_t>& streams) override
 	{
 		fx_ctx* c = grp->members[0];
-		if ((int)parts.size() != nranks || root < 0 || root >= nranks) return FX_E_INVALID;
+		if ((int)parts.size() != nranks || root < 0 || root >= nranks || streams.size() != 1) return FX_E_INVALID;
+		hipStream_t s = streams[0];
 		ncclResult_t r = api->GroupStart();
 		if (rank == root) {
 			for (const GatherPart& p : parts) {

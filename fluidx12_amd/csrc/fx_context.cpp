@@ -54,6 +54,28 @@ int ensure_stage(fx_ctx* ctx, size_t bytes)
 	return FX_OK;
 }
 
+void destroy_lanes(fx_comm_group* g)
+{
+	for (fx_lane& l : g->lanes) {
+		DeviceGuard dg(l.device);
+		if (l.comm) (void)hipStreamDestroy(l.comm);
+		if (l.face) (void)hipStreamDestroy(l.face);
+		for (hipEvent_t e : { l.ev_ready, l.ev_done, l.ev_col_ready, l.ev_col_done, l.ev_int, l.ev_face1, l.x_ready, l.x_done }) if (e) (void)hipEventDestroy(e);
+	}
+	g->lanes.clear();
+}
+
+void group_release(fx_comm_group* g)                // the last member is gone (fx_destroy)
+{
+	{
+		DeviceGuard dg(g->lanes.empty() ? 0 : g->lanes[0].device);
+		if (g->shared_stream) (void)hipStreamDestroy(g->shared_stream);
+	}
+	destroy_lanes(g);
+	delete g->transport;
+	delete g;
+}
+
 void free_all(fx_ctx* c)
 {
 	for (int i = 0; i < 2; ++i) {
@@ -224,19 +246,7 @@ int fx_destroy(fx_ctx* ctx)
 		fx_comm_group* g = ctx->group;
 		for (auto& m : g->members) if (m == ctx) m = nullptr;
 		g->broken = true;
-		if (--g->refs == 0) {
-			if (g->shared_stream) (void)hipStreamDestroy(g->shared_stream);
-			if (g->comm_stream) (void)hipStreamDestroy(g->comm_stream);
-			if (g->face_stream) (void)hipStreamDestroy(g->face_stream);
-			if (g->ev_int) (void)hipEventDestroy(g->ev_int);
-			if (g->ev_face1) (void)hipEventDestroy(g->ev_face1);
-			if (g->ev_col_ready) (void)hipEventDestroy(g->ev_col_ready);
-			if (g->ev_col_done) (void)hipEventDestroy(g->ev_col_done);
-			if (g->ev_ready) (void)hipEventDestroy(g->ev_ready);
-			if (g->ev_done) (void)hipEventDestroy(g->ev_done);
-			delete g->transport;
-			delete g;
-		}
+		if (--g->refs == 0) group_release(g);
 	}
 	free_all(ctx);
 	delete ctx;

@@ -7,6 +7,7 @@
 #include <string>
 
 struct fx_comm_group;
+struct fx_lane;
 
 struct fx_ctx {
 	fx_desc desc;
@@ -124,12 +125,14 @@ struct GatherPart { int rank; const char* src; char* dst; size_t bytes; };
 struct Transport {
 	virtual ~Transport() {}
 	// segs[i] = segments of grp->members[i] (RCCL: one member = this rank; loop-back: every rank)
+	// streams: the stream the exchange is ordered on, per lane of the group (one entry; a peer group: one per member)
 	// channel 1 = a second, independent communicator (RCCL: from the second unique id) for traffic that must not queue behind, or
 	// in front of, the step's own exchanges: the early colour halo of FX_OPT_OVERLAP 3.  Operations of ONE communicator are
 	// serialised in issue order even across streams.
-	virtual int exchange(fx_comm_group* grp, const std::vector<std::vector<Seg>>& segs, hipStream_t s, int channel = 0) = 0;
-	// parts[r] for every rank r of the chain (RCCL: only this rank's src and, on the root, every dst are meaningful)
-	virtual int gather(fx_comm_group* grp, const std::vector<GatherPart>& parts, int root, hipStream_t s) = 0;
+	virtual int exchange(fx_comm_group* grp, const std::vector<std::vector<Seg>>& segs, const std::vector<hipStream_t>& streams, int channel = 0) = 0;
+	// parts[r] for every rank r of the chain (RCCL: only this rank's src and, on the root, every dst are meaningful); `streams` as above:
+	// what the members wrote on them is what travels; the copies are ordered on streams[root lane]
+	virtual int gather(fx_comm_group* grp, const std::vector<GatherPart>& parts, int root, const std::vector<hipStream_t>& streams) = 0;
 	virtual bool is_local() const = 0;
 	// min of `v` over the ranks of the chain (RCCL: an all-reduce; loop-back: the caller combines its members itself)
 	virtual int min_over_ranks(int v, hipStream_t s, int* out) = 0;
@@ -140,22 +143,37 @@ struct Transport {
 
 }  // namespace fx
 
-struct fx_comm_group {
-	std::vector<fx_ctx*> members;   // local transport: every rank; RCCL: just this rank
-	fx::Transport* transport;
-	int refs;
-	// side stream the overlapped exchanges run on, and the two events that order it against the compute
-	// stream: ev_ready = "the planes to send are final" (compute -> comm), ev_done = "halos have arrived"
-	hipStream_t comm_stream;
+// The streams and ordering events of one rank of a slab group.  An RCCL group has one lane (its one member); so has a loop-back
+// group of the shared-stream kind, for ALL its members (their phases are ordered by the one compute stream); a loop-back group of
+// the peer kind (fx_comm_init_peer: contexts on their own streams, possibly on their own devices) has a lane per member.
+struct fx_lane {
+	int device;
+	hipStream_t compute;            // peer groups: the member's own stream.  Otherwise null: the stream the caller hands to fx_simulate
+	// side stream the overlapped exchanges run on, and the two events that order it against the compute stream:
+	// ev_ready = "the planes to send are final" (compute -> comm), ev_done = "halos have arrived"
+	hipStream_t comm;
 	hipEvent_t ev_ready, ev_done;
-	// the face chains of the overlapped pressure rounds run on their own stream, beside the interior sweeps
-	hipStream_t face_stream;
+	hipStream_t face;               // the face chains of the overlapped pressure rounds run on their own stream, beside the interior sweeps
 	hipEvent_t ev_col_ready, ev_col_done;   // FX_OPT_OVERLAP 3: "colour of this step is final" (compute -> comm), "its halo planes have arrived" (comm -> compute)
 	hipEvent_t ev_int, ev_face1;    // "interior + face copy of the round done" (compute -> face), "the chain has read its input" (face -> compute)
-	int min_nz;                     // thinnest slab of the chain: every rank takes the same schedule decisions from it
-	hipStream_t shared_stream;      // loop-back groups: the one compute stream of all members (owned by the group)
-	bool broken;                    // a member was destroyed: the survivors can only be destroyed
+	// peer groups, the handshake of an exchange with the neighbour lanes: x_ready = "what I send is final and my halo may be written",
+	// x_done = "I have pulled my halo planes" (a sender must not overwrite them before)
+	hipEvent_t x_ready, x_done;
 };
+
+struct fx_comm_group {
+	std::vector<fx_ctx*> members;   // local transports: every rank; RCCL: just this rank
+	fx::Transport* transport;
+	int refs;
+	std::vector<fx_lane> lanes;     // one, or one per member (per_member)
+	bool per_member;
+	int min_nz;                     // thinnest slab of the chain: every rank takes the same schedule decisions from it
+	hipStream_t shared_stream;      // shared-stream loop-back groups: the one compute stream of all members (owned by the group)
+	bool broken;                    // a member was destroyed: the survivors can only be destroyed
+	fx_lane& lane_of(const fx_ctx* m);
+};
+
+inline fx_lane& fx_comm_group::lane_of(const fx_ctx* m) { return per_member ? lanes[(size_t)m->rank] : lanes[0]; }
 
 namespace fx {
 enum ExchSet {

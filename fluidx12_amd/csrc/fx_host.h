@@ -66,6 +66,8 @@ struct ScopedMark {
 int drain_timing(fx_ctx* c);
 int ensure_stage(fx_ctx* ctx, size_t bytes);
 void free_all(fx_ctx* c);
+void destroy_lanes(fx_comm_group* g);
+void group_release(fx_comm_group* g);
 
 // planes of the local array a stage may compute / read, as global z ranges
 struct Range { int lo, hi; };   // [lo, hi)

@@ -30,21 +30,40 @@ int for_members(fx_ctx* ctx, std::vector<fx_ctx*>& out)
 }
 
 
+// ---- lanes (fx_context.h): where a member's work is enqueued.  One lane serves a whole shared-stream loop-back group and an RCCL rank;
+// a peer group has a lane per member, each with the member's own compute stream.
+static inline bool peer_group(const fx_ctx* c) { return c->group && c->group->per_member; }
+// the compute stream of member m in a step driven on stream s
+static inline hipStream_t CS(const fx_ctx* m, hipStream_t s) { return peer_group(m) ? m->group->lane_of(m).compute : s; }
+struct LaneRef { fx_lane* lane; hipStream_t compute; };
+static std::vector<LaneRef> lanes_of(fx_ctx* lead, const std::vector<fx_ctx*>& M, hipStream_t s)
+{
+	std::vector<LaneRef> out;
+	if (!lead->group) return out;
+	if (lead->group->per_member) for (fx_ctx* m : M) out.push_back(LaneRef{ &lead->group->lane_of(m), lead->group->lane_of(m).compute });
+	else out.push_back(LaneRef{ &lead->group->lanes[0], s });
+	return out;
+}
+enum StreamKind { ON_COMPUTE = 0, ON_COMM = 1 };
+
 // 0 = no side stream, 1 = advection halo overlapped, 2 = pressure rounds overlapped as well, 3 = and the colour half of the
 // next step's advection halo travels behind this step's pressure phase (fx_set_option)
 int overlap_level(const fx_ctx* lead)
 {
-	if (!multi_rank(lead) || !lead->group->comm_stream) return 0;
+	if (!multi_rank(lead) || lead->group->lanes.empty() || !lead->group->lanes[0].comm) return 0;
 	return lead->opt_overlap;
 }
 
 struct ExchSpec { int set, k, pidx; };
 
-static int do_exchange(fx_ctx* ctx, const std::vector<fx_ctx*>& M, const ExchSpec* specs, int nspec, hipStream_t s, int channel = 0)
+// one exchange of the chain, ordered on every lane's compute or comm stream
+static int do_exchange(fx_ctx* ctx, const std::vector<fx_ctx*>& M, const ExchSpec* specs, int nspec, StreamKind kind, hipStream_t s, int channel = 0)
 {
 	if (!multi_rank(ctx)) return FX_OK;
 	DeviceGuard dg(ctx->device);
-	ScopedMark mk(ctx, s, MK_EXCH);
+	std::vector<hipStream_t> streams;
+	for (const LaneRef& L : lanes_of(ctx, M, s)) streams.push_back(kind == ON_COMM ? L.lane->comm : L.compute);
+	ScopedMark mk(ctx, peer_group(ctx) ? streams[(size_t)ctx->rank] : streams[0], MK_EXCH);
 	std::vector<std::vector<Seg>> segs(M.size());
 	size_t total = 0;
 	for (size_t i = 0; i < M.size(); ++i) {
@@ -59,19 +78,19 @@ static int do_exchange(fx_ctx* ctx, const std::vector<fx_ctx*>& M, const ExchSpe
 	}
 	if (!total) return FX_OK;
 	for (fx_ctx* m : M) if (m->timing_on) m->acc.exchange_calls += 1;  // one group call (ncclGroupStart .. End) per exchange
-	return ctx->group->transport->exchange(ctx->group, segs, s, channel);
+	return ctx->group->transport->exchange(ctx->group, segs, streams, channel);
 }
 
+// on every lane: `to` picks up after everything queued on `from` so far
+#define FX_LANES(body) do { for (const LaneRef& L : lanes_of(ctx, M, s)) { DeviceGuard dgl_(L.lane->device); body } } while (0)
 // comm stream picks up after everything queued on the compute stream so far
-static int comm_fork(fx_ctx* ctx, hipStream_t s)
+static int comm_fork(fx_ctx* ctx, const std::vector<fx_ctx*>& M, hipStream_t s)
 {
-	fx_comm_group* g = ctx->group;
-	FX_HIP(hipEventRecord(g->ev_ready, s));
-	FX_HIP(hipStreamWaitEvent(g->comm_stream, g->ev_ready, 0));
+	FX_LANES(FX_HIP(hipEventRecord(L.lane->ev_ready, L.compute)); FX_HIP(hipStreamWaitEvent(L.lane->comm, L.lane->ev_ready, 0)););
 	return FX_OK;
 }
-static int comm_mark_done(fx_ctx* ctx) { FX_HIP(hipEventRecord(ctx->group->ev_done, ctx->group->comm_stream)); return FX_OK; }
-static int comm_join(fx_ctx* ctx, hipStream_t s) { FX_HIP(hipStreamWaitEvent(s, ctx->group->ev_done, 0)); return FX_OK; }
+static int comm_mark_done(fx_ctx* ctx, const std::vector<fx_ctx*>& M, hipStream_t s) { FX_LANES(FX_HIP(hipEventRecord(L.lane->ev_done, L.lane->comm));); return FX_OK; }
+static int comm_join(fx_ctx* ctx, const std::vector<fx_ctx*>& M, hipStream_t s) { FX_LANES(FX_HIP(hipStreamWaitEvent(L.compute, L.lane->ev_done, 0));); return FX_OK; }
 
 
 // advect planes [r.lo, r.hi); own_only: back-traces must stay inside the owned planes (the halo is still in flight)
@@ -126,16 +145,19 @@ static int record_step(fx_ctx* ctx, std::vector<fx_ctx*>& M, hipStream_t s)
 	for (fx_ctx* m : M) {
 		if (m->rec_in_project) { m->rec_in_project = false; continue; }       // k_project_v4 has already written it
 		DeviceGuard dg(m->device);
-		FX_HIP(launch_face_need(m->g, m->half, m->vel[0], m->time_step, (int)m->desc.advect_address, options_digest(m), m->halo_overflow, m->step_rec, s));
+		FX_HIP(launch_face_need(m->g, m->half, m->vel[0], m->time_step, (int)m->desc.advect_address, options_digest(m), m->halo_overflow, m->step_rec, CS(m, s)));
 	}
 	DeviceGuard dg(ctx->device);
 	if (ctx->group->transport->is_local()) {
-		for (fx_ctx* m : M) FX_HIP(hipMemcpyAsync(m->rec_host, m->step_rec, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-		FX_HIP(hipEventRecord(ctx->rec_ev, s));
+		for (fx_ctx* m : M) {                                                  // every member's record on its own stream, behind its own event
+			DeviceGuard dgm(m->device);
+			FX_HIP(hipMemcpyAsync(m->rec_host, m->step_rec, 4 * sizeof(int), hipMemcpyDeviceToHost, CS(m, s)));
+			FX_HIP(hipEventRecord(m->rec_ev, CS(m, s)));
+		}
 	} else {
 		// off the compute stream when there is a side stream: the next step's interior advection need not wait for the gather
 		hipStream_t cs = s;
-		if (overlap_level(ctx) >= 1) { int rc = comm_fork(ctx, s); if (rc) return rc; cs = ctx->group->comm_stream; }
+		if (overlap_level(ctx) >= 1) { int rc = comm_fork(ctx, M, s); if (rc) return rc; cs = ctx->group->lanes[0].comm; }
 		if (ctx->group->transport->allgather(ctx->step_rec, 4, ctx->gath_dev, cs) != FX_OK) { ctx->last_error = "rccl: all-gather of the step record failed"; return FX_E_COMM; }
 		FX_HIP(hipMemcpyAsync(ctx->rec_host, ctx->gath_dev, 4 * sizeof(int) * (size_t)ctx->nranks, hipMemcpyDeviceToHost, cs));
 		FX_HIP(hipEventRecord(ctx->rec_ev, cs));
@@ -154,11 +176,12 @@ static int consume_record(fx_ctx* ctx, std::vector<fx_ctx*>& M)
 	const int Ha = (int)ctx->desc.halo_advect;
 	for (fx_ctx* m : M) { m->adv_w_lo = has_lower(m) ? Ha : 0; m->adv_w_hi = has_upper(m) ? Ha : 0; }
 	if (!multi_rank(ctx) || !ctx->rec_pending) return FX_OK;
-	{
-		DeviceGuard dg(ctx->device);
-		FX_HIP(hipEventSynchronize(ctx->rec_ev));
-	}
 	const bool local = ctx->group->transport->is_local();
+	for (fx_ctx* m : M) {                                  // (in-process groups: every member's record; an RCCL rank: the gathered one)
+		DeviceGuard dg(m->device);
+		FX_HIP(hipEventSynchronize(m->rec_ev));
+		if (!local) break;
+	}
 	const int n = ctx->nranks;
 	auto rec = [&](int r) -> const int* { return local ? M[(size_t)r]->rec_host : ctx->rec_host + 4 * r; };
 	bool fault = false, mismatch = false, usable = ctx->opt_adaptive != 0;
@@ -215,36 +238,36 @@ int advect_all(fx_ctx* ctx, std::vector<fx_ctx*>& M, hipStream_t s)
 	if (ov && ctx->group->min_nz <= 2 * Ha) ov = false;        // decided on the thinnest slab of the chain: the same on every rank
 	if (!ov) {
 		if ((rc = consume_record(ctx, M))) return rc;
-		if (col_ready) FX_HIP(hipStreamWaitEvent(s, ctx->group->ev_col_done, 0));
+		if (col_ready) FX_LANES(FX_HIP(hipStreamWaitEvent(L.compute, L.lane->ev_col_done, 0)););
 		const ExchSpec spec{ col_ready ? EX_ADVECT_VEL : EX_ADVECT_IN, Ha, 0 };
-		if ((rc = do_exchange(ctx, M, &spec, 1, s))) return rc;
+		if ((rc = do_exchange(ctx, M, &spec, 1, ON_COMPUTE, s))) return rc;
 		for (fx_ctx* m : M) {
-			ScopedMark mk(m, s, MK_ADVECT);
+			ScopedMark mk(m, CS(m, s), MK_ADVECT);
 			if (m->timing_on) m->acc.advect_halo_planes += (uint64_t)(m->adv_w_lo + m->adv_w_hi);
-			if ((rc = advect_range(m, s, owned(m), false))) return rc;
+			if ((rc = advect_range(m, CS(m, s), owned(m), false))) return rc;
 		}
 		return FX_OK;
 	}
 	// the interior first (it reads owned planes only, whatever the exchange will carry): the device is busy while the host waits
 	// for the previous step's record, which sizes the exchange
-	if ((rc = comm_fork(ctx, s))) return rc;                   // the comm stream picks up behind the previous step
+	if ((rc = comm_fork(ctx, M, s))) return rc;                // the comm stream picks up behind the previous step
 	for (fx_ctx* m : M) {
-		ScopedMark mk(m, s, MK_ADVECT);
+		ScopedMark mk(m, CS(m, s), MK_ADVECT);
 		const Range o = owned(m);
-		if ((rc = advect_range(m, s, Range{ o.lo + (has_lower(m) ? Ha : 0), o.hi - (has_upper(m) ? Ha : 0) }, true))) return rc;
+		if ((rc = advect_range(m, CS(m, s), Range{ o.lo + (has_lower(m) ? Ha : 0), o.hi - (has_upper(m) ? Ha : 0) }, true))) return rc;
 	}
 	if ((rc = consume_record(ctx, M))) return rc;
-	if (col_ready) FX_HIP(hipStreamWaitEvent(ctx->group->comm_stream, ctx->group->ev_col_done, 0));
+	if (col_ready) FX_LANES(FX_HIP(hipStreamWaitEvent(L.lane->comm, L.lane->ev_col_done, 0)););
 	const ExchSpec spec{ col_ready ? EX_ADVECT_VEL : EX_ADVECT_IN, Ha, 0 };
-	if ((rc = do_exchange(ctx, M, &spec, 1, ctx->group->comm_stream))) return rc;
-	if ((rc = comm_mark_done(ctx))) return rc;
-	if ((rc = comm_join(ctx, s))) return rc;
+	if ((rc = do_exchange(ctx, M, &spec, 1, ON_COMM, s))) return rc;
+	if ((rc = comm_mark_done(ctx, M, s))) return rc;
+	if ((rc = comm_join(ctx, M, s))) return rc;
 	for (fx_ctx* m : M) {
-		ScopedMark mk(m, s, MK_ADVECT);
+		ScopedMark mk(m, CS(m, s), MK_ADVECT);
 		if (m->timing_on) m->acc.advect_halo_planes += (uint64_t)(m->adv_w_lo + m->adv_w_hi);
 		const Range o = owned(m);
-		if (has_lower(m) && (rc = advect_range(m, s, Range{ o.lo, o.lo + Ha }, false))) return rc;
-		if (has_upper(m) && (rc = advect_range(m, s, Range{ o.hi - Ha, o.hi }, false))) return rc;
+		if (has_lower(m) && (rc = advect_range(m, CS(m, s), Range{ o.lo, o.lo + Ha }, false))) return rc;
+		if (has_upper(m) && (rc = advect_range(m, CS(m, s), Range{ o.hi - Ha, o.hi }, false))) return rc;
 	}
 	return FX_OK;
 }
@@ -365,22 +388,22 @@ static int jacobi_serial(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 	const int k = multi ? lead->opt_round : (int)iters;
 	int rc;
 	if (takes_sparse_solver(lead, iters)) return jacobi_freeze(lead, s, iters);
-	if ((rc = clear_freeze_masks(M, s))) return rc;
+	for (fx_ctx* m : M) { std::vector<fx_ctx*> one{ m }; if ((rc = clear_freeze_masks(one, CS(m, s)))) return rc; }
 	const ExchSpec bspec{ EX_DIV, k - 1, 0 };
-	if ((rc = do_exchange(lead, M, &bspec, 1, s))) return rc;
+	if ((rc = do_exchange(lead, M, &bspec, 1, ON_COMPUTE, s))) return rc;
 	uint32_t done = 0;
 	while (done < iters) {
 		const int cnt = (int)std::min<uint32_t>(k, iters - done);
 		const ExchSpec pspec{ EX_PRESSURE, cnt, lead->p_cur };
-		if ((rc = do_exchange(lead, M, &pspec, 1, s))) return rc;
+		if ((rc = do_exchange(lead, M, &pspec, 1, ON_COMPUTE, s))) return rc;
 		for (fx_ctx* m : M) {
-			ScopedMark mk(m, s, MK_JACOBI);
-			if ((rc = jacobi_round(m, s, cnt, &mk))) return rc;
+			ScopedMark mk(m, CS(m, s), MK_JACOBI);
+			if ((rc = jacobi_round(m, CS(m, s), cnt, &mk))) return rc;
 		}
 		done += cnt;
 	}
 	const ExchSpec last{ EX_PRESSURE, 1, lead->p_cur };          // the projection's z-gradient reads one plane across the face
-	return do_exchange(lead, M, &last, 1, s);
+	return do_exchange(lead, M, &last, 1, ON_COMPUTE, s);
 }
 
 // Rounds of up to k sweeps with the pressure exchange of a round hidden behind its interior sweeps, on three streams.
@@ -403,16 +426,15 @@ static int jacobi_serial(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 static int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t iters, int t, int k)
 {
 	fx_comm_group* grp = lead->group;
-	hipStream_t fs = grp->face_stream, cs = grp->comm_stream;
 	int rc;
-	fx_ctx* ctx = lead;                                    // FX_HIP reports through `ctx`
+	fx_ctx* ctx = lead;                                    // FX_HIP / FX_LANES report through `ctx`
 	// The face chain runs one single-sweep launch (k_jacobi_v4: 60 registers, both faces) per level.  Groups of fused sweeps with the
 	// interior's register-strip kernels were built and measured slower (loop-back N = 4, 256^3 per rank, rounds of 9: 6.30 against 5.67 ms
-	// per step; profiles/r02c_chain_fuse_loopback4.txt): on a 9..27-plane zone the strips have 64..192 waves whose 310 registers shut
+	// per step; docs/LAB.md): on a 9..27-plane zone the strips have 64..192 waves whose 310 registers shut
 	// the interior's waves out of their SIMDs for a whole 14-step pipeline -- removed in round 3.
 	const ExchSpec first[2] = { { EX_DIV, k - 1, 0 }, { EX_PRESSURE, k, lead->p_cur } };
-	if ((rc = do_exchange(lead, M, first, 2, s))) return rc;
-	FX_HIP(hipEventRecord(grp->ev_int, s));
+	if ((rc = do_exchange(lead, M, first, 2, ON_COMPUTE, s))) return rc;
+	FX_LANES(FX_HIP(hipEventRecord(L.lane->ev_int, L.compute)););
 	bool in_flight = false;
 	uint32_t done = 0;
 	while (done < iters) {
@@ -421,9 +443,8 @@ static int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t 
 		const int src = lead->p_cur, fin = src ^ (m & 1);
 		int fbuf = 0;                                      // which scratch buffer holds the chain's last level (set below)
 		// ---- face stream: the chain (needs the previous round's interior + face copy, and its exchange)
-		FX_HIP(hipStreamWaitEvent(fs, grp->ev_int, 0));
-		if (in_flight) FX_HIP(hipStreamWaitEvent(fs, grp->ev_done, 0));
-		ScopedMark chain_mark(lead, fs, MK_CHAIN);         // one mark per chain (loop-back: all members' chains, booked on the first)
+		FX_LANES(FX_HIP(hipStreamWaitEvent(L.lane->face, L.lane->ev_int, 0)); if (in_flight) FX_HIP(hipStreamWaitEvent(L.lane->face, L.lane->ev_done, 0)););
+		ScopedMark chain_mark(lead, grp->lane_of(lead).face, MK_CHAIN);         // one mark per chain (shared stream: all members' chains, booked on the first)
 		{
 			// the chain: one sweep per launch over the two thin face zones
 			int grp_i = 0;
@@ -436,22 +457,21 @@ static int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t 
 					const float* in = grp_i == 0 ? mctx->p[src] : mctx->p_face[grp_i & 1];
 					const Range lo{ o.lo - rem, has_lower(mctx) ? o.lo + k + rem : o.lo - rem };
 					const Range hi{ has_upper(mctx) ? o.hi - k - rem : o.hi + rem, o.hi + rem };
-					FX_HIP(launch_jacobi_sweep2(mctx->g, in, mctx->b, mctx->p_face[ob], nullptr, lo.lo, lo.hi, hi.lo, hi.hi, fs));
+					FX_HIP(launch_jacobi_sweep2(mctx->g, in, mctx->b, mctx->p_face[ob], nullptr, lo.lo, lo.hi, hi.lo, hi.hi, grp->lane_of(mctx).face));
 				}
-				if (grp_i == 0) FX_HIP(hipEventRecord(grp->ev_face1, fs));
+				if (grp_i == 0) FX_LANES(FX_HIP(hipEventRecord(L.lane->ev_face1, L.lane->face)););
 			}
 			fbuf = grp_i & 1;                                  // the buffer the last group wrote
 		}
-		FX_HIP(hipEventRecord(grp->ev_ready, fs));
 		// ---- comm stream: the k final planes of the chain travel, the neighbour's land in the halo of p[fin]
-		FX_HIP(hipStreamWaitEvent(cs, grp->ev_ready, 0));
+		FX_LANES(FX_HIP(hipEventRecord(L.lane->ev_ready, L.lane->face)); FX_HIP(hipStreamWaitEvent(L.lane->comm, L.lane->ev_ready, 0)););
 		const ExchSpec pspec{ EX_PRESSURE_FACE, k, (fbuf << 1) | fin };
-		if ((rc = do_exchange(lead, M, &pspec, 1, cs))) return rc;
-		if ((rc = comm_mark_done(lead))) return rc;
+		if ((rc = do_exchange(lead, M, &pspec, 1, ON_COMM, s))) return rc;
+		if ((rc = comm_mark_done(lead, M, s))) return rc;
 		in_flight = true;
 		// ---- compute stream: the interior
 		for (fx_ctx* mctx : M) {
-			ScopedMark mk(mctx, s, MK_JACOBI);
+			ScopedMark mk(mctx, CS(mctx, s), MK_JACOBI);
 			const Range o = owned(mctx);
 			int lvl = 0, cur = src;
 			for (int j = 0; j < m; ++j) {
@@ -459,27 +479,30 @@ static int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t 
 				lvl += tj;
 				const int rem = cnt - lvl;
 				const Range in{ has_lower(mctx) ? o.lo + k - rem : o.lo, has_upper(mctx) ? o.hi - k + rem : o.hi };
-				if (j == 1 && mctx == M.front()) FX_HIP(hipStreamWaitEvent(s, grp->ev_face1, 0));   // launch 2 overwrites the chain's input
-				if ((rc = jacobi_launch(mctx, s, cur, tj, in, &mk))) return rc;
+				if (j == 1 && (grp->per_member || mctx == M.front())) {      // launch 2 overwrites the chain's input
+					DeviceGuard dg(mctx->device);
+					FX_HIP(hipStreamWaitEvent(CS(mctx, s), grp->lane_of(mctx).ev_face1, 0));
+				}
+				if ((rc = jacobi_launch(mctx, CS(mctx, s), cur, tj, in, &mk))) return rc;
 				cur ^= 1;
 			}
 		}
 		// the chain's final planes complete the owned range of p[fin]
-		FX_HIP(hipStreamWaitEvent(s, grp->ev_ready, 0));
+		FX_LANES(FX_HIP(hipStreamWaitEvent(L.compute, L.lane->ev_ready, 0)););
 		for (fx_ctx* mctx : M) {
 			DeviceGuard dg(mctx->device);
 			const size_t pl = mctx->g.plane(), kb = (size_t)k * pl * 4;
 			const Range o = owned(mctx);
 			if (has_lower(mctx))
-				FX_HIP(launch_copy_bytes(mctx->p[fin] + (size_t)mctx->g.lz(o.lo) * pl, mctx->p_face[fbuf] + (size_t)mctx->g.lz(o.lo) * pl, kb, s));
+				FX_HIP(launch_copy_bytes(mctx->p[fin] + (size_t)mctx->g.lz(o.lo) * pl, mctx->p_face[fbuf] + (size_t)mctx->g.lz(o.lo) * pl, kb, CS(mctx, s)));
 			if (has_upper(mctx))
-				FX_HIP(launch_copy_bytes(mctx->p[fin] + (size_t)mctx->g.lz(o.hi - k) * pl, mctx->p_face[fbuf] + (size_t)mctx->g.lz(o.hi - k) * pl, kb, s));
+				FX_HIP(launch_copy_bytes(mctx->p[fin] + (size_t)mctx->g.lz(o.hi - k) * pl, mctx->p_face[fbuf] + (size_t)mctx->g.lz(o.hi - k) * pl, kb, CS(mctx, s)));
 			mctx->p_cur = fin;
 		}
-		FX_HIP(hipEventRecord(grp->ev_int, s));
+		FX_LANES(FX_HIP(hipEventRecord(L.lane->ev_int, L.compute)););
 		done += cnt;
 	}
-	if (in_flight) rc = comm_join(lead, s);
+	if (in_flight) rc = comm_join(lead, M, s);
 	return rc;
 }
 
@@ -496,7 +519,7 @@ int jacobi_all(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t it
 		const int k = lead->opt_round;
 		// two face zones (<= 2k - 1 planes each) and an interior; decided on the thinnest slab of the chain and on the (chain-wide)
 		// Jacobi mode, so that every rank takes the same branch -- the two schedules exchange different things
-		const bool ok = lead->group->face_stream != nullptr && lead->group->min_nz >= 4 * k && lead->p_face[0] && !lead->frozen;
+		const bool ok = lead->group->lanes[0].face != nullptr && lead->group->min_nz >= 4 * k && lead->p_face[0] && !lead->frozen;
 		if (ok) return jacobi_overlapped(lead, M, s, iters, t, k);
 	}
 	return jacobi_serial(lead, M, s, iters);
@@ -525,28 +548,26 @@ int simulate_impl(fx_ctx* ctx, hipStream_t s)
 	if (overlap_level(ctx) >= 3) {
 		// colour[parity] is final for this step: its halo planes -- four of the seven plane-units the next advection needs --
 		// leave now on the side stream, behind divergence / pressure / projection
-		fx_comm_group* g = ctx->group;
-		FX_HIP(hipEventRecord(g->ev_col_ready, s));
-		FX_HIP(hipStreamWaitEvent(g->comm_stream, g->ev_col_ready, 0));
+		FX_LANES(FX_HIP(hipEventRecord(L.lane->ev_col_ready, L.compute)); FX_HIP(hipStreamWaitEvent(L.lane->comm, L.lane->ev_col_ready, 0)););
 		const ExchSpec cs{ EX_COLOR_CUR, (int)ctx->desc.halo_advect, 0 };
-		if ((rc = do_exchange(ctx, M, &cs, 1, g->comm_stream, 1))) return rc;       // side channel: not queued with the step's own exchanges
-		FX_HIP(hipEventRecord(g->ev_col_done, g->comm_stream));
+		if ((rc = do_exchange(ctx, M, &cs, 1, ON_COMM, s, 1))) return rc;           // side channel: not queued with the step's own exchanges
+		FX_LANES(FX_HIP(hipEventRecord(L.lane->ev_col_done, L.lane->comm)););
 		for (fx_ctx* m : M) m->col_halo_buf = (int)m->frame_parity;
 	}
 	if (ctx->time_step > 0.0f) {                       // CSProject3D.hlsl:88
 		const ExchSpec uz{ EX_UZ1, 1, 0 };
-		if ((rc = do_exchange(ctx, M, &uz, 1, s))) return rc;
+		if ((rc = do_exchange(ctx, M, &uz, 1, ON_COMPUTE, s))) return rc;
 		if (takes_sparse_solver(ctx, ctx->desc.jacobi_iters) && jacobi_freeze_can_fuse_divergence(ctx->g)) ctx->fz_fuse_div = true;   // k_freeze_dense computes it
-		else for (fx_ctx* m : M) if ((rc = divergence_phase(m, s))) return rc;
+		else for (fx_ctx* m : M) if ((rc = divergence_phase(m, CS(m, s)))) return rc;
 		rc = jacobi_all(ctx, M, s, ctx->desc.jacobi_iters);
 		ctx->fz_fuse_div = false;                      // (consumed by the dense sweep; never left standing for a later stage call)
 		if (rc) return rc;
-		for (fx_ctx* m : M) if ((rc = project_phase(m, s))) return rc;
+		for (fx_ctx* m : M) if ((rc = project_phase(m, CS(m, s)))) return rc;
 	} else {
 		for (fx_ctx* m : M) {
 			DeviceGuard dg(m->device);
 			m->rec_in_project = false;
-			if (launch_copy_velocity(m->g, m->half, m->vel[1], m->vel[0], s) != hipSuccess) return FX_E_DEVICE;
+			if (launch_copy_velocity(m->g, m->half, m->vel[1], m->vel[0], CS(m, s)) != hipSuccess) return FX_E_DEVICE;
 		}
 	}
 	if ((rc = record_step(ctx, M, s))) return rc;

@@ -287,11 +287,27 @@ def comm_unique_id():
     return bytes(buf)
 
 
-def comm_init_local(fluids):
-    """Loop-back slab group: several `Fluid` slab contexts of one process on one device."""
+#: what `comm_init_local` builds when the caller does not say: the shared-stream group, or (tests re-running the slab suite with
+#: real concurrency) the peer group
+default_local_group = "shared"
+
+
+def comm_init_local(fluids, peer=None):
+    """In-process slab group of several `Fluid` slab contexts, driven through the first.  peer=False: one device, every member on one
+    compute stream (fx_comm_init_local); peer=True: every member on its own streams and, if created so, its own device -- halo planes
+    are pulled out of the neighbour's memory (fx_comm_init_peer)."""
     lib = capi.load()
     arr = (C.c_void_p * len(fluids))(*[f._ctx for f in fluids])
-    capi.check(lib.fx_comm_init_local(arr, len(fluids)), "comm_init_local")
+    if peer is None:
+        peer = default_local_group == "peer"
+    if peer:
+        capi.check(lib.fx_comm_init_peer(arr, len(fluids)), "comm_init_peer")
+    else:
+        capi.check(lib.fx_comm_init_local(arr, len(fluids)), "comm_init_local")
+
+
+def comm_init_peer(fluids):
+    comm_init_local(fluids, peer=True)
 
 
 class LightProbe:

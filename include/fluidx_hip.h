@@ -215,14 +215,19 @@ int fx_timing_read(fx_ctx* ctx, fx_timing* out, int reset);
 
 /* ---- multi-GPU z-slabs (no reference counterpart) --------------------------------
  * One context per rank.  RCCL transport: fx_comm_id_bytes/fx_comm_get_unique_id on rank 0, broadcast
- * the bytes out of band, fx_comm_init_rank on every rank (rank r owns slab r).  Loop-back transport
- * (one process, one GPU, several slab contexts -- used by the tests): fx_comm_init_local.
+ * the bytes out of band, fx_comm_init_rank on every rank (rank r owns slab r).  In-process groups (one process, several slab
+ * contexts, rank 0 drives them all): fx_comm_init_local -- one device, every member on ONE compute stream (the decomposition's
+ * arithmetic on a 1-GPU box) -- and fx_comm_init_peer -- every member keeps its own streams and may live on its own device
+ * (fx_desc.device): a rank pulls its halo planes straight out of its neighbour's memory (hipDeviceEnablePeerAccess +
+ * hipMemcpyPeerAsync; no IPC handles, no RCCL), the members run concurrently, ordered by events per exchange.  With a peer group
+ * fx_simulate ignores its stream argument: each member's work goes to the member's own stream.
  * The id is TWO ncclUniqueIds (256 bytes): the communicator of the step's exchanges and a second one for traffic that must not
  * queue with them (FX_OPT_OVERLAP 3).  Passing only the first 128 bytes gives one communicator serving both. */
 size_t fx_comm_id_bytes(void);
 int fx_comm_get_unique_id(void* id_out, size_t bytes);
 int fx_comm_init_rank(fx_ctx* ctx, const void* id, size_t bytes, int rank, int nranks);
 int fx_comm_init_local(fx_ctx** ctxs, int nranks);
+int fx_comm_init_peer(fx_ctx** ctxs, int nranks);
 
 /* Multi-GPU rendering (row f-3 of SURVEY.md 8), the exact way: rays cross slabs, so the colour field is gathered.  Every
  * rank of the slab group sends its owned planes of colour[parity] to rank `root`, where they land in `full`, a whole-grid

@@ -13,6 +13,18 @@ pytestmark = pytest.mark.gpu
 f32 = np.float32
 
 
+@pytest.fixture(autouse=True, params=["shared", "peer"])
+def group_kind(request):
+    """every test of this module runs twice: on the shared-stream in-process group (fx_comm_init_local: all members on one stream) and
+    on the peer group (fx_comm_init_peer: every member on its own compute / comm / face streams, ordered by events only -- the members
+    really run concurrently, and an ordering bug shows as a wrong bit)"""
+    from fluidx12_amd import fluid as fluid_mod
+    old = fluid_mod.default_local_group
+    fluid_mod.default_local_group = request.param
+    yield request.param
+    fluid_mod.default_local_group = old
+
+
 def run_single(dims, steps, **kw):
     f = fx.Fluid()
     assert f.Init(800, 800, dims, **kw)
@@ -845,3 +857,26 @@ def test_fault_acknowledged_before_the_next_step_is_reported_once_more_and_no_fu
     fl[0].UpdateFrame(dt, 2)
     fl[0].Simulate(2)
     fl[0].Synchronize()
+
+
+def test_peer_group_across_two_devices():
+    """fx_comm_init_peer with the slabs on different devices: halo planes travel by hipMemcpyPeerAsync out of the neighbour's memory.
+    Needs a second GPU (the driver's boxes have one: skipped there)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one device")
+    dims, steps = (64, 64, 64), 6
+    ref = run_single(dims, steps, jacobi_iters=20)
+    fl = []
+    for r in range(2):
+        f = fx.Fluid()
+        assert f.Init(800, 800, dims, slab=(32 * r, 32), jacobi_iters=20, halo_jacobi=4, halo_advect=6, device=r), f.last_status
+        fl.append(f)
+    fx.comm_init_peer(fl)
+    for k in range(steps):
+        fl[0].UpdateFrame(f32(fl[0].default_time_step()), k % 3)
+        fl[0].Simulate(k % 3)
+    fl[0].Synchronize()
+    assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
+    assert np.array_equal(gather(fl, fx.FIELD_COLOR, 0), ref.download(fx.FIELD_COLOR))
+    assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
