@@ -244,6 +244,15 @@ def main():
     ap.add_argument("--loopback", type=int, default=0,
                     help="run the N-rank code path (grid, slabs, halos, schedule selection) with N slab contexts in THIS process on "
                          "one GPU through the loop-back transport: a functional check of the multi-rank path, never a scaling number")
+    ap.add_argument("--group", default="shared", choices=["shared", "peer"],
+                    help="--loopback: `shared` = every slab context on ONE compute stream (fx_comm_init_local); `peer` = every context on its "
+                         "own streams, halo planes pulled out of the neighbour's memory (fx_comm_init_peer)")
+    ap.add_argument("--peer-devices", action="store_true",
+                    help="--loopback N --group peer: slab r lives on device r -- ONE process driving N GPUs, planes travelling by "
+                         "hipMemcpyPeerAsync.  This is a measurement (n_gpus = N), unlike the one-GPU loop-back")
+    ap.add_argument("--no-peer-leg", action="store_true",
+                    help="--gpus N > 1: do not time the in-process peer transport (a child process of rank 0, after the RCCL measurement) "
+                         "beside the RCCL line")
     ap.add_argument("--shared-gpu", action="store_true",
                     help="functional check only: all ranks of a torch.distributed.run launch use GPU 0 (torch.distributed over gloo; "
                          "the product's RCCL calls must be redirected with FLUIDX_RCCL_LIB=tests/_build/libmockrccl.so, because "
@@ -359,7 +368,7 @@ def main():
             z0r, nzr = slab_for_rank(GZ, r, N)
             f_ = fx.Fluid()
             ok = f_.Init(1920, 1080, (GX, GY, GZ), storage=args.storage, jacobi_iters=args.iters, jacobi_mode=args.mode,
-                         advect_address=args.address, device=local_rank if (N > 1 and not loop) else -1,
+                         advect_address=args.address, device=local_rank if (N > 1 and not loop) else (r if (loop and args.peer_devices) else -1),
                          slab=(z0r, nzr) if N > 1 else None, halo_advect=halo_adv,
                          halo_jacobi=pressure_round(GX, GZ // N, args.iters) if N > 1 else 0)
             if not ok:
@@ -367,7 +376,7 @@ def main():
             members.append(f_)
         fluid = members[0]                        # loop-back: the first context drives the group
         if loop:
-            fx.comm_init_local(members)
+            fx.comm_init_local(members, peer=args.group == "peer")
 
     # ---- RCCL rendezvous: rank 0 creates the unique id, torch.distributed broadcasts the bytes ----
     if N > 1 and not loop:
@@ -740,6 +749,41 @@ def main():
                         "avg_launch_us": (timing.jacobi_ms - main_ms) * 1e3 / tail_l},
                     "cell_updates_per_s": cells * timing.jacobi_sweeps / (timing.jacobi_ms * 1e-3)}
 
+    # ---- N > 1 over RCCL: the same steps once more through the in-process peer transport (one process owning the N devices, halo planes
+    # by hipMemcpyPeerAsync, no RCCL), as a CHILD process of rank 0 with its own deadline -- whatever happens to it, the RCCL line
+    # stands.  The ranks give their memory back first and wait for rank 0 at the final barrier.
+    peer_leg = None
+    if N > 1 and not loop and dist is not None and not (args.dry_run or args.shared_gpu or args.no_peer_leg):
+        for m_ in members:
+            m_.Release()
+        members = []
+        dist.barrier()
+        if rank == 0:
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--loopback", str(N), "--group", "peer", "--peer-devices", "--grid", str(args.grid),
+                   "--iters", str(args.iters), "--storage", args.storage, "--mode", args.mode, "--address", args.address, "--scaling", args.scaling,
+                   "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-render", "--no-developed", "--no-cpu-baseline"]
+            if args.config:
+                cmd += ["--config", str(args.config)]
+            if schedule is not None and "overlap" in schedule:
+                cmd += ["--schedule", "%d,%d" % (schedule["overlap"], schedule["jacobi_round"])]
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE",
+                                                                     "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+            try:
+                r_ = subprocess.run(cmd, capture_output=True, text=True, timeout=float(os.environ.get("FLUIDX_BENCH_PEER_TIMEOUT_S", "300")), env=env)
+                line = [ln for ln in r_.stdout.splitlines() if ln.startswith("{")]
+                if r_.returncode == 0 and line:
+                    d_ = json.loads(line[-1])
+                    peer_leg = {"value": d_["value"], "unit": d_["unit"], "ms_per_step": d_["ms_per_step"], "devices_driven_by_one_process": N,
+                                "ranks_seen": 1, "transport": "fx_comm_init_peer: hipMemcpyPeerAsync between the slabs' devices, one process, no RCCL",
+                                "schedule": d_["config"].get("schedule"), "stage_ms_per_step": d_.get("stage_ms_per_step")}
+                else:
+                    peer_leg = {"error": "exit code %d" % r_.returncode, "stderr_tail": r_.stderr[-400:]}
+            except subprocess.TimeoutExpired:
+                peer_leg = {"error": "timeout"}
+            except Exception as e_:                          # never lets the RCCL line down
+                peer_leg = {"error": repr(e_)}
+
     if rank == 0:
         voxels = float(GX) * GY * GZ * args.steps
         out = {
@@ -747,13 +791,14 @@ def main():
                       "voxel-updates/sec (advect + the reference's <= %d-sweep early-out Jacobi) at %d^3; achieved HBM GB/s vs peak" % (args.iters, G),
             "value": voxels / elapsed if not args.dry_run else 0.0,
             "unit": "voxel-updates/s",
-            "n_gpus": 1 if loop else N, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": N if (not loop or args.peer_devices) else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
             "higher_is_better": True,
             "scaling": args.scaling if N > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.storage == "fp32" else "f32 arithmetic / f16 field storage",
-            "data": "synthetic" if not loop else "synthetic; LOOP-BACK: %d slab ranks share ONE GPU (functional check of the multi-rank path, not a scaling measurement)" % loop,
+            "data": "synthetic" if not loop else ("synthetic; IN-PROCESS PEER GROUP: one process drives %d GPUs, a slab each" % loop) if args.peer_devices else
+                    "synthetic; LOOP-BACK: %d slab ranks share ONE GPU (functional check of the multi-rank path, not a scaling measurement)" % loop,
             "config": {"workload": "%dx%dx%d 3D smoke (%.1f M voxels per GPU), %s, %s fields, %s sampler, "
                                    "advect+divergence+Jacobi+project per step; %s"
                                    % (GX, GY, GZ, GX * GY * GZ / N / 1e6,
@@ -763,7 +808,8 @@ def main():
                                       "the REFERENCE's own configuration (CSProject3D.hlsl:13, CSPoisson.hlsli:8-26%s), not a BASELINE.json config (those fix the sweep count)"
                                       % (", RGBA16F fields Fluid.cpp:207-213" if args.storage == "fp16" else "")),
                        "grid": [GX, GY, GZ], "jacobi_iters": args.iters, "jacobi_mode": args.mode, "storage": args.storage, "address": args.address,
-                       "parallelism": "single GPU" if N == 1 else ("z-slab x%d (%d planes per rank), " % (N, GZ // N)) + ("loop-back copies on one GPU" if loop else "RCCL send/recv halo exchange"),
+                       "parallelism": "single GPU" if N == 1 else ("z-slab x%d (%d planes per rank), " % (N, GZ // N)) + (("peer copies between the devices of one process (fx_comm_init_peer)" if args.peer_devices else "loop-back copies on one GPU, %s group" % args.group) if loop
+                                                                                                                             else "RCCL send/recv halo exchange, %d rank processes" % N),
                        "schedule": schedule,
                        "bytes_per_voxel_step": step_bytes_per_voxel(args.iters, args.storage)},
         }
@@ -799,6 +845,8 @@ def main():
             out["render"] = render
         if developed is not None:
             out["developed_plume"] = developed
+        if peer_leg is not None:
+            out["peer_transport"] = peer_leg              # beside the RCCL figure in `value`, never instead of it
         if N == 1 and not args.no_cpu_baseline and not args.dry_run:
             out["cpu_baseline"] = cpu_baseline(G, args.iters, args.cpu_budget, mode=int(args.mode == "faithful"), half=args.storage == "fp16",
                                                address=int(args.address == "mirror"))
