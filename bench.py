@@ -496,7 +496,7 @@ def main():
             m_.timing_read(reset=True)
     barrier_sync()
     # The library's HIP-event marks (two event records per phase, round and member: the stream drains at each) are instrumentation
-    # the product runs without; they cost a multi-rank step about a tenth (profiles/r02d_comm_priority.txt: 5.1 -> 5.6 ms in
+    # the product runs without; they cost a multi-rank step about a tenth (profiles/archive/r02d_comm_priority.txt: 5.1 -> 5.6 ms in
     # loop-back N = 4) and a single-GPU step 0.980 -> 0.947 ms at 256^3, 0.2047 -> 0.1814 ms at 128^3 (ten event records, ~2.5 us
     # each).  So only every fourth step of the timed region carries them; stage times, launch averages (roofline) and exchanged
     # bytes are per marked step, `value` is over all steps.  FLUIDX_BENCH_MARK_EVERY=1: every step.
@@ -593,6 +593,17 @@ def main():
                 fluid.Render(0, fx.Fluid.OPTIMIZED, to_target=True)     # + renderCube: cube map -> 1920x1080 RGBA8 target
             fluid.Synchronize()
             tr_ = fluid.timing_read(reset=True)
+            # the same passes by the PLAIN kernels (FX_OPT_RENDER_ACCEL 0: every sample gathers its taps, one lane per ray / voxel -- the
+            # reference's own shape): the yardstick the default path is bit-identical to
+            fluid.set_option(capi_.OPT_RENDER_ACCEL, 0)
+            fluid.Render(0, fx.Fluid.OPTIMIZED)
+            fluid.Synchronize()
+            fluid.timing_read(reset=True)
+            for _ in range(2):
+                fluid.Render(0, fx.Fluid.OPTIMIZED)
+            fluid.Synchronize()
+            tp_ = fluid.timing_read(reset=True)
+            fluid.set_option(capi_.OPT_RENDER_ACCEL, 1)
             # the paper's comparison (row f-2): the direct screen-space march of every pixel with the same light volume
             fluid.Render(0, fx.Fluid.SEPARATE_LIGHT_PASS)
             fluid.Synchronize()
@@ -616,6 +627,8 @@ def main():
                       "mode": "OPTIMIZED (CSRayMarchL + CSRayMarchV) + renderCube (PSRayCastCube, raster-free)", "viewport": [1920, 1080], "cube_lod": fi.cube_lod,
                       "cube_size": fi.cube_size, "ray_samples": fi.ray_samples, "light_samples": 64, "rays": rays,
                       "light_pass_ms": tr_.light_ms / nr, "view_pass_ms": tr_.view_ms / nr,
+                      "plain_kernels": {"light_pass_ms": tp_.light_ms / 2, "view_pass_ms": tp_.view_ms / 2,
+                                        "note": "FX_OPT_RENDER_ACCEL 0: same pictures, bit for bit (tests/test_gpu_render.py::test_empty_space_skipping_changes_no_bit)"},
                       "cube_resolve_ms": tr_.resolve_ms / nr,
                       "direct_march_ms": td_.view_ms / nr, "direct_rays": 1920 * 1080,
                       "rays_per_s": rays / (tr_.view_ms / nr * 1e-3) if tr_.view_ms > 0 else None,
@@ -627,7 +640,11 @@ def main():
                       "light_samples_per_s": tc_.light_samples / light_s if light_s > 0 else None,
                       "samples_per_s": (tc_.view_samples + tc_.light_samples + tc_.lightmap_fetches) / (view_s + light_s) if view_s + light_s > 0 else None,
                       "mean_samples_per_view_ray": tc_.view_samples / max(rays, 1),
-                      "bound": {"kind": "gather latency / L2; compulsory traffic is the lower bound the passes are held against, not an HBM target",
+                      # what bounds the passes ("render"): the light pass = an HBM-bound build (every alpha read out of the
+                      # colour texels once) + instruction issue of the ray kernels; the view pass = instruction issue (eight lanes per ray: the
+                      # dependent chain of a ray is no longer the launch's duration).  The compulsory bytes are the floor both are held against.
+                      "bound": {"kind": "light pass: HBM (k_occupancy_blocks reads the colour volume once) + VALU issue of the ray marches; view pass: VALU issue "
+                                        "(k_view_slots); compulsory traffic is the lower bound, not an HBM-fraction target",
                                 "light_pass": {"compulsory_bytes": light_bytes, "GBps": light_bytes / light_s / 1e9 if light_s > 0 else None,
                                                "frac_of_hbm_peak": light_bytes / light_s / 1e9 / HBM_PEAK_GBS if light_s > 0 else None},
                                 "view_pass": {"compulsory_bytes": view_bytes, "GBps": view_bytes / view_s / 1e9 if view_s > 0 else None,

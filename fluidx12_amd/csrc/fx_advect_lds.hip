@@ -2,7 +2,7 @@
 // LDS-staged tile instead of 35 per-lane gathers through the texture-address path.
 //
 // Why: k_advect_fast (fx_sim.hip) issues 3 + 24 + 8 vector loads per voxel whose addresses depend on the voxel's own
-// velocity.  rocprofv3 (profiles/r02a_sq_counters.json): its waves issue 10 % of their cycles, stand 36 % at a full vector-memory
+// velocity.  rocprofv3 (profiles/archive/r02a_sq_counters.json): its waves issue 10 % of their cycles, stand 36 % at a full vector-memory
 // queue and 54 % in s_waitcnt -- 19 cycles per wave-load against 6.7 for the L1's data path; every (row, plane) of the
 // fields is fetched by up to eight different gather instructions of neighbouring waves, out of a 32-KiB L1 that 24 resident
 // waves overflow.  But the back-trace is short almost everywhere: |u| dt N < 1 cell for 93-99 % of the 64-voxel rows of the

@@ -29,6 +29,7 @@
 // Scope: 3-D single-domain contexts (rows of any length >= 4: X % 4 != 0 -- 150^3, the reference's GI preset -- takes the cell-wise
 // path of ldq / stq for a row's last, short quad).  Slab contexts and 2-D grids keep k_jacobi_generic.
 #include "fx_internal.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace fx {
@@ -570,6 +571,9 @@ hipError_t launch_freeze_tiles(const Geom& g, const float* p_src, const float* b
 	const FreezeWork& w, int n, int levels, int level_base, uint32_t* stat, uint32_t stat_hi, hipStream_t s)
 {
 	int max_wgs = FX_KNOB_INT("FREEZE_WGS", 2048);
+	// the relaxing set only shrinks: later launches of a solve get smaller grids (an empty or nearly empty launch of 2048 workgroups of
+	// 512 threads costs 4-8 us just to start and retire them; a workgroup walks its list, so fewer workgroups still cover every entry)
+	if (FX_KNOB_INT("FREEZE_SHRINK", 1)) max_wgs = std::max(256, max_wgs >> std::min(n / 4, 3));
 	max_wgs = max_wgs < kShards ? kShards : (max_wgs & ~(kShards - 1));
 	const int ntx = (g.X + TCX - 1) / TCX, nty = (g.Y + TCY - 1) / TCY, ntiles = jacobi_freeze_tiles(g);
 	const int want = (ntiles + kShards - 1) / kShards * kShards;

@@ -6,7 +6,7 @@
 //
 // Why LDS now: a wave64 = one strip of R = 4 full-x rows streaming along z.  Level l (0 = input ... 3 = output) needs a
 // 3-plane window of R + 2(3 - l) rows, plus the b planes of three different z offsets: 116 float4 rows = 464 registers per
-// lane before temporaries -- the all-register version spilled and ran slower than two sweeps (profiles/r01c_jacobi_strip.txt).
+// lane before temporaries -- the all-register version spilled and ran slower than two sweeps (profiles/archive/r01c_jacobi_strip.txt).
 // Here only the windows of levels 1 and 2 (8 + 6 rows x 3 planes, rotated by NAME as in k_jacobi_strip2u) and the plane
 // in flight live in registers; the input window's older two planes (2 x 10 rows) and the b planes waiting for sweeps 2
 // and 3 (3 x 6 rows) live in the wave's private 38-KiB slice of the LDS (4 waves x 38 KiB = 152 of the CU's 160 KiB; no
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip3c(const Geom g, const f
 #undef FX_STRIP3C_STEP
 
 // (k_jacobi_strip3z -- two z streams per workgroup that meet in the middle: 11 % fewer bytes, 6 % fewer instructions, and 45.9 us per
-// launch against k_jacobi_strip3c's 43.0 -- was measured in round 2 (profiles/r03c_strip3z.txt) and removed in round 3.)
+// launch against k_jacobi_strip3c's 43.0 -- was measured in round 2 (profiles/archive/r03c_strip3z.txt) and removed in round 3.)
 
 }  // namespace
 

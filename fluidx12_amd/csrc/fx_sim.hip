@@ -975,7 +975,7 @@ hipError_t launch_jacobi_sweep2(const Geom& g, const float* p_in, const float* b
 // ---- temporal blocking: which geometry fuses how many sweeps ----------------------------------------
 // FLUIDX_JACOBI_T (1..3) overrides the sweeps fused per launch (measurement knob, DESIGN.md / profiles/).
 // (The LDS tile kernel k_jacobi_tb<T> of round 1 -- z-streaming register windows + one LDS plane per level, two barriers per plane --
-// lost to the register strips in every shape measured, profiles/r01_jacobi_tile_sweep.txt, and was removed in round 3; with it went
+// lost to the register strips in every shape measured, profiles/archive/r01_jacobi_tile_sweep.txt, and was removed in round 3; with it went
 // four sweeps per launch: jacobi_fuse = 4 now runs threes.)
 
 static bool tb_supported(const Geom& g)

@@ -22,7 +22,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fluidx12_amd.build import kernel_source_hash   # noqa: E402
 
-RENDER = ("k_raymarch_light", "k_raymarch_view", "k_raycast_direct", "k_occupancy_blocks", "k_occupancy_dilate", "k_resolve_cube")
+RENDER = ("k_occupancy_blocks", "k_occupancy_dilate", "k_mask_coarsen", "k_light_cells", "k_light_classify", "k_light_rays", "k_light_gi_dirs",
+          "k_light_march", "k_view_slots", "k_view_march", "k_direct_march", "k_raymarch_light", "k_raymarch_view", "k_raycast_direct", "k_resolve_cube")
 
 
 def short(name):
@@ -69,6 +70,8 @@ def main():
         h, m = l2.get(k, {}).get("TCC_HIT_sum"), l2.get(k, {}).get("TCC_MISS_sum")
         if h is not None and m is not None and h + m > 0:
             e["l2_requests"], e["l2_hit_rate"] = h + m, h / (h + m)
+            if e.get("avg_us"):
+                e["l2_request_GBps_at_128B"] = (h + m) * 128 / (e["avg_us"] * 1e-6) / 1e9      # what the L2 was asked for, against its ~34 TB/s
         acc, req = l1.get(k, {}).get("TCP_TOTAL_CACHE_ACCESSES_sum"), l1.get(k, {}).get("TCP_TCC_READ_REQ_sum")
         if acc and req is not None:
             e["l1_accesses"], e["l1_hit_rate"] = acc, 1.0 - req / acc
