@@ -698,7 +698,8 @@ def main():
                 design += (Vb + 4.0 - 4.0) * cells                     # + velocity, + b written, - b read
             tr = pmc_traffic("k_freeze_dense", G, args.iters, args.storage, "faithful") if N == 1 else None
             use_tr = tr is not None and not tr[2]
-            roof = {"bound": "hbm",
+            roof = {"schema": 2,      # 2 (round 3 on): achieved / frac = COMPULSORY bytes of the launch (12 B x cells, whatever it fuses); the per-sweep figure of schema 1 is *_algorithmic
+                    "bound": "hbm",
                     "kernel": "k_freeze_dense (%ssweep 1 of the reference's <= %d-sweep solve for every cell; sweeps 2.. run in %d tile launches of "
                               "k_freeze_tiles over the 32x8x8 tiles that still hold a relaxing cell: `sparse_solver`)" % ("the divergence + " if fused_div else "", args.iters, tile_l // steps_m),
                     "fused_divergence": fused_div,
@@ -743,7 +744,8 @@ def main():
             # as `achieved_algorithmic` / `frac_algorithmic`; it exceeds the peak by up to T x -- the temporal blocking, not a bound.
             compulsory = JACOBI_BYTES_PER_CELL_SWEEP * cells
             achieved = compulsory / avg_launch_s / 1e9
-            roof = {"bound": "hbm",
+            roof = {"schema": 2,      # 2 (round 3 on): achieved / frac = COMPULSORY bytes of the launch (12 B x cells, whatever it fuses); the per-sweep figure of schema 1 is *_algorithmic
+                    "bound": "hbm",
                     "kernel": "%s (one lock-step Jacobi sweep per launch)" % cands[0] if sweeps_per_launch == 1 else
                               "%s (%g lock-step Jacobi sweeps per launch, register/LDS-resident temporal blocking: p and b are read once "
                               "and p' written once per launch = the bytes `achieved` counts)" % (cands[0], sweeps_per_launch),

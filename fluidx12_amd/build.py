@@ -82,11 +82,16 @@ def build_lib(force=False, verbose=False):
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJDIR, s + ".o")
         objs.append(obj)
-        if force or _newer(obj, [src] + hdrs):
+        flags = " ".join(FLAGS + EXTRA_FLAGS.get(s, []))
+        stamp = obj + ".flags"                         # the flag string the object was built with: an object built under another
+        built_with = open(stamp).read() if os.path.exists(stamp) else None   # FLUIDX_BUILD_* setting is stale whatever its mtime says
+        if force or built_with != flags or _newer(obj, [src] + hdrs):
             cmd = [cc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-x", "hip", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
+            with open(stamp, "w") as fh:
+                fh.write(flags)
     if force or _newer(LIB, objs):
         cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
@@ -98,7 +103,9 @@ def build_lib(force=False, verbose=False):
 def ensure_built():
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    if _newer(LIB, srcs + hdrs):
+    stale_flags = any(not os.path.exists(os.path.join(OBJDIR, s + ".o.flags")) or
+                      open(os.path.join(OBJDIR, s + ".o.flags")).read() != " ".join(FLAGS + EXTRA_FLAGS.get(s, [])) for s in SOURCES)
+    if _newer(LIB, srcs + hdrs) or (stale_flags and os.path.isdir(OBJDIR) and shutil.which("hipcc")):
         build_lib()
     return LIB
 

@@ -18,7 +18,10 @@
 // plane it reads to carry the identity of the HEADER: a save that was interrupted on any rank, or that one rank of a chain never
 // made, leaves planes unmarked -- or, when the path held an older complete save (the periodic-checkpoint case: no O_TRUNC, the
 // other slabs write the same file), marked with the OLDER save's identity -- and fx_checkpoint_load refuses them instead of
-// resuming from zeros or from a mix of two time steps.  (Two saves at the same step count hold the same fields.)  A context whose
+// resuming from zeros or from a mix of two time steps.  The identity is the step count alone: it tells apart the saves of ONE run at
+// different steps (the periodic-checkpoint case).  It does NOT tell apart two runs that reach the same step count with other fields -- a
+// restart from an upload, another dt or option set -- writing to one path: a caller who reuses a path across runs removes the file
+// first (or gives each run its own).  A context whose
 // advection has left its halo (FX_E_HALO pending) writes nothing.  The loader reads all three fields into host memory before it
 // touches the context; on a chain it is called by every rank (like the save) and may follow any step.
 #include "fx_context.h"

@@ -201,6 +201,19 @@ int fx_create(fx_ctx** out, const fx_desc* d)
 		}
 		FX_HIP(hipMalloc((void**)&ctx->halo_overflow, sizeof(unsigned)));
 		FX_HIP(hipMemsetAsync(ctx->halo_overflow, 0, sizeof(unsigned), ctx->stream));
+		if (!(d->flags & FX_FLAG_RENDER_ONLY)) {
+			// scratch the staged advection puts far-tracing voxels aside in (fx_advect_lds.hip), for the owned planes: allocated here, not
+			// inside the first step (an allocation there is a device synchronisation on the step path).  Without it -- no staged path for
+			// this geometry, or no memory -- the staged kernel gathers those voxels itself.
+			ctx->adv_far_tried = true;
+			const size_t words = advect_far_words(ctx->g, ctx->g.nz);
+			if (words) {
+				if (hipMalloc((void**)&ctx->adv_far, words * sizeof(uint32_t)) == hipSuccess) {
+					FX_HIP(hipMemsetAsync(ctx->adv_far, 0, 2 * sizeof(uint32_t), ctx->stream));   // the two alternating totals
+					ctx->adv_far_words = words;
+				} else { (void)hipGetLastError(); ctx->adv_far = nullptr; }
+			}
+		}
 		if (d->grid_z > 1) {                                                 // rendering resources (Fluid.cpp:222-232)
 			FX_HIP(hipMalloc((void**)&ctx->lightmap, ctx->g.cells_owned() * 4));
 			FX_HIP(hipMemsetAsync(ctx->lightmap, 0, ctx->g.cells_owned() * 4, ctx->stream));

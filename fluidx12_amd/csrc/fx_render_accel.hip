@@ -495,6 +495,7 @@ hipError_t launch_accel_light(const Geom& g, const RenderAccel& a, uint32_t* lig
 {
 	const int ncell = a.CX * a.CY * a.CZ;
 	hipLaunchKernelGGL(k_light_cells, dim3((ncell + 255) / 256), dim3(256), 0, s, g, a.CX, a.CY, a.CZ, a.occ + ncell, a.cells, a.ctr, lightmap, fc, sh ? 1 : 0);
+	// (2048 persistent workgroups: 30 us at 256^3 / frame 132; 8192 -- a wave per listed cell -- 37 us)
 	hipLaunchKernelGGL(k_light_classify, dim3((unsigned)std::min(ncell / 4 + 1, 2048)), dim3(256), ((size_t)a.CZ + 1) * 4, s, g, a.alpha, a.bits, a.CX, a.CY, a.CZ,
 		a.cells, a.list, a.ctr, lightmap, fc, sh ? 1 : 0);
 	const size_t cells = (size_t)g.X * g.Y * g.Zg;

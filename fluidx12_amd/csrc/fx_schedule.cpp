@@ -106,8 +106,9 @@ int advect_range(fx_ctx* ctx, hipStream_t s, Range r, bool own_only)
 	// (with FX_OPT_ADAPTIVE_HALO: only the planes this step's exchange carried, adv_w_lo / adv_w_hi <= halo_advect)
 	g.zlo = std::max(g.zlo, g.z0 - ctx->adv_w_lo); g.zhi = std::min(g.zhi, g.z0 + g.nz - 1 + ctx->adv_w_hi);
 	if (own_only) { g.zlo = std::max(g.zlo, g.z0); g.zhi = std::min(g.zhi, g.z0 + g.nz - 1); }
-	// the context lends the staged kernel scratch to put far-tracing voxels aside (sized for its owned planes at the first advection that
-	// could use it; every advection of a context runs on its compute stream, one after the other, so one scratch serves all its ranges)
+	// the context lends the staged kernel scratch to put far-tracing voxels aside (allocated by fx_create for its owned planes -- the lazy
+	// branch below only serves contexts made before that; every advection of a context runs on its compute stream, one after the other,
+	// so one scratch serves all its ranges)
 	if (!ctx->adv_far && !ctx->adv_far_tried) {
 		ctx->adv_far_tried = true;
 		const size_t words = advect_far_words(g, g.nz);
