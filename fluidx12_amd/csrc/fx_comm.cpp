@@ -46,6 +46,10 @@ int exchange_items(fx_ctx* c, int which_set, int k, int pidx, ExchItem out[4])
 	case EX_COLOR_CUR:
 		out[0] = ExchItem{ (char*)c->col[c->frame_parity], plane * es * 4, 1, k, nullptr };
 		return 1;
+	case EX_FREEZE:                                      // (mask: a byte per 4-cell quad)
+		out[0] = ExchItem{ (char*)c->fz_x_p, plane * 4, 1, k, nullptr };
+		out[1] = ExchItem{ (char*)c->fz_x_m, (size_t)((c->g.X + 3) / 4) * c->g.Y, 1, k, nullptr };
+		return 2;
 	case EX_PRESSURE_FACE:
 		out[0] = ExchItem{ (char*)c->p_face[(pidx >> 1) & 1], plane * 4, 1, k, (char*)c->p[pidx & 1] };
 		return 1;

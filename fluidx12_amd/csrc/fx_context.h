@@ -33,6 +33,8 @@ struct fx_ctx {
 	void* fz_list[2] = { nullptr, nullptr };   // work lists of alternate launches
 	uint32_t* fz_counts = nullptr;  // list lengths of two solves [2][kFreezeSlots launches][8 sub-lists]
 	uint32_t* fz_stat = nullptr;
+	float* fz_x_p = nullptr;          // slab ranks: the buffers whose face planes the next EX_FREEZE exchange carries
+	uint8_t* fz_x_m = nullptr;
 	bool fz_fuse_div = false;          // this step's divergence is left to the sparse solver's dense sweep (set by simulate_impl, consumed by jacobi_freeze)
 	uint32_t* adv_far = nullptr;       // scratch of the staged advection: the far-tracing voxels it defers (allocated at the first advection)
 	bool adv_far_tried = false;
@@ -183,7 +185,8 @@ enum ExchSet {
 	EX_PRESSURE = 3,    // pressure buffer `pidx` (+ the freeze mask in faithful mode)
 	EX_PRESSURE_FACE = 4, // face planes leave from scratch buffer p_face[pidx >> 1], halos land in pressure buffer pidx & 1
 	EX_ADVECT_VEL = 5,   // velocity[0] only: the colour the advection gathers from was exchanged behind the previous step's pressure phase
-	EX_COLOR_CUR = 6     // colour[parity]: what the NEXT step's advection gathers from
+	EX_COLOR_CUR = 6,    // colour[parity]: what the NEXT step's advection gathers from
+	EX_FREEZE = 7        // the sparse faithful solver's current pressure buffer + quad-nibble mask (fx_ctx::fz_x_p / fz_x_m)
 };
 // items of one member for an exchange set; returns their number (<= 4)
 int exchange_items(fx_ctx* c, int which_set, int k, int pidx, ExchItem out[4]);

@@ -93,11 +93,14 @@ int jacobi_freeze_levels_per_launch();
 // list[0] and counts[0][8] (zero on entry); tile launch n reads list[n & 1] / counts[n] and appends its surviving tiles to
 // list[(n + 1) & 1] / counts[n + 1]; counts_next = the next solve's counters, cleared by this solve's dense launch
 struct FreezeWork { uint32_t* tile_mark; uint32_t gen; void* list[2]; int cap; uint32_t* counts; uint32_t* counts_next; };
+// a slab rank runs the solver on a view of the planes it holds (jacobi_freeze_view): `g` = the view, the field pointers advanced to its plane 0,
+// [z_begin, z_begin + nzp) = the owned planes in view coordinates (nzp = 0: all), vel_comp_cells = cells between velocity components (0: the view's)
+Geom jacobi_freeze_view(const Geom& g, int* first_plane, int* own_begin);
 hipError_t launch_freeze_dense(const Geom& g, const float* p_in, const float* b, float* pA, float* pB, uint8_t* mA, uint8_t* mB,
-	const FreezeWork& w, hipStream_t s, const void* vel = nullptr, int vel_half = 0);   // vel: compute (and store) the divergence of this velocity instead of reading b
+	const FreezeWork& w, hipStream_t s, const void* vel = nullptr, int vel_half = 0, int z_begin = 0, int nzp = 0, size_t vel_comp_cells = 0);   // vel: compute (and store) the divergence of this velocity instead of reading b
 bool jacobi_freeze_can_fuse_divergence(const Geom& g);
 hipError_t launch_freeze_tiles(const Geom& g, const float* p_src, const float* b, float* p_dst, const uint8_t* m_src, uint8_t* m_dst,
-	const FreezeWork& w, int n, int levels, int level_base, uint32_t* stat, uint32_t stat_hi, hipStream_t s);
+	const FreezeWork& w, int n, int levels, int level_base, uint32_t* stat, uint32_t stat_hi, hipStream_t s, int z_begin = 0, int nzp = 0);
 // sweeps fused per launch for this geometry (1 = no fused path); requested > 0 overrides the default
 int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp);
 bool jacobi_prefers_three(const Geom& g, int requested, int nzp);

@@ -26,8 +26,12 @@
 // The number of sweeps the reference's loop would have executed (1 + the last level that left a cell relaxing, capped at N) is
 // kept in a device word per step (`stat`), for fx_timing / bench.py's byte count.
 //
-// Scope: 3-D single-domain contexts (rows of any length >= 4: X % 4 != 0 -- 150^3, the reference's GI preset -- takes the cell-wise
-// path of ldq / stq for a row's last, short quad).  Slab contexts and 2-D grids keep k_jacobi_generic.
+// Scope: 3-D contexts (rows of any length >= 4: X % 4 != 0 -- 150^3, the reference's GI preset -- takes the cell-wise path of ldq / stq
+// for a row's last, short quad).  A z-slab rank (round 4) runs the same kernels on a VIEW of its local arrays: the planes it holds (owned
+// + exchanged halo) as a grid of their own -- jacobi_freeze_view -- whose ends are either the global boundary (the true clamp) or the
+// outermost halo plane (a cell T planes from an owned tile is only ever read); the dense sweep covers the owned planes, the cones of the
+// tile launches reach into the halo, and T planes of pressure + mask travel to the neighbours behind every launch (fx_schedule.cpp).
+// 2-D grids keep k_jacobi_generic.
 #include "fx_internal.h"
 #include <algorithm>
 #include <cstdlib>
@@ -199,7 +203,7 @@ template <bool AL, int FUSE>
 __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
 	float* __restrict__ pA, float* __restrict__ pB, uint8_t* __restrict__ mA, uint8_t* __restrict__ mB,
 	uint32_t* __restrict__ tile_mark, uint32_t gen, uint32_t* __restrict__ cnt_clear, int n_clear, int ntx, int nty, int rows_per_block,
-	const void* __restrict__ vel, float* __restrict__ b_out)
+	const void* __restrict__ vel, float* __restrict__ b_out, int z_begin, int nzp, uint32_t vel_comp_cells)
 {
 	const int X4 = (g.X + 3) >> 2;
 	const int lane = threadIdx.x;
@@ -209,12 +213,12 @@ __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float*
 	// XCD k walks the k-th contiguous eighth of the (x, y, z)-ordered block sequence (see xcd_tile in fx_sim.hip)
 	int t = (int)blockIdx.x;
 	{
-		const int n = gx * gy * g.Zg, q = n >> 3, r = n & 7, xcd = t & 7, j = t >> 3;
+		const int n = gx * gy * nzp, q = n >> 3, r = n & 7, xcd = t & 7, j = t >> 3;
 		t = xcd * q + min(xcd, r) + j;
 	}
 	const int x4 = (t % gx) * blockDim.x + lane;
 	const int y = ((t / gx) % gy) * rows_per_block + threadIdx.y;
-	const int z = t / (gx * gy);
+	const int z = z_begin + t / (gx * gy);                               // (a slab view: the owned planes only; z_begin = 0, nzp = Zg otherwise)
 	const int wl = (int)((threadIdx.y * blockDim.x + threadIdx.x) & 63);
 	const bool in = x4 < X4 && y < g.Y;
 	uint32_t nib = 0xFu;
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float*
 		const float4 Bk = ldq<AL>(p_in, (uint32_t)zb * plane + (uint32_t)y * g.X + 4 * x4, nv);
 		float4 bb;
 		if (FUSE) {
-			const uint32_t vcells = (uint32_t)g.cells_local();
+			const uint32_t vcells = vel_comp_cells;
 			const float4 cx = ldvq<AL, FUSE>(vel, vcells, 0, c_off, nv);
 			const float4 vU = ldvq<AL, FUSE>(vel, vcells, 1, zrow + (uint32_t)yu * g.X + 4 * x4, nv);
 			const float4 vD = ldvq<AL, FUSE>(vel, vcells, 1, zrow + (uint32_t)yd * g.X + 4 * x4, nv);
@@ -292,7 +296,8 @@ template <int T, int NT, bool AL>
 __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(const Geom g, const float* __restrict__ p_src, const float* __restrict__ b,
 	float* __restrict__ p_dst, const uint8_t* __restrict__ m_src, uint8_t* __restrict__ m_dst,
 	const uint4* __restrict__ list_in, const uint32_t* __restrict__ cnt_in, uint4* __restrict__ list_out, uint32_t* __restrict__ cnt_out, int cap,
-	int ntx, int nty, int level_base, uint32_t* __restrict__ stat, uint32_t stat_hi, const uint32_t* __restrict__ tile_flag, uint32_t flag_gen, int ntiles, int scan_limit)
+	int ntx, int nty, int level_base, uint32_t* __restrict__ stat, uint32_t stat_hi, const uint32_t* __restrict__ tile_flag, uint32_t flag_gen, int ntiles, int scan_limit,
+	int zo0, int zo1)                             // the planes whose cells count as this context's (a slab view: the owned ones; else all)
 {
 	constexpr int E = 8 + 2 * T;                 // staged rows per plane = staged planes
 	constexpr int NQ = E * E * TQ;               // staged quads
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 4 : NT / 128) void k_freeze_tiles(
 							const float R = x4 == X4 - 1 ? c.w : reinterpret_cast<const float*>(Pq)[4 * (idx + 2)];    // .x of quad idx + 1
 							const float4 bb = Bq[((zz - 1) * EB + (yy - 1)) * TQ + q];
 							nm[j] = relax_quad(c, L, R, U, D, F, Bk, bb, m, nv[j]) | (uint32_t)(idx << 9);
-							const bool core = q >= 1 && q <= 8 && yy >= T && yy < T + TCY && zz >= T && zz < T + TCZ;
+							const bool core = q >= 1 && q <= 8 && yy >= T && yy < T + TCY && zz >= T && zz < T + TCZ && z >= zo0 && z < zo1;
 							if (core && (nm[j] & 0xFu) != 0xFu) bits |= 1u << (q - 1) | 0x100u << (yy - T) | 0x10000u << (zz - T);
 						}
 					}
@@ -524,15 +529,29 @@ extern "C" void fx_debug_freeze_prof(unsigned long long* out, int reset) { (void
 extern "C" void fx_debug_freeze_passes(unsigned int* out, int reset) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(fz_passes), sizeof fz_passes); if (reset) { static unsigned int z[2][80]; (void)hipMemcpyToSymbol(HIP_SYMBOL(fz_passes), z, sizeof z); } }
 #endif
 
-bool jacobi_freeze_supported(const Geom& g)
+// The planes a context holds, as a grid of their own (the header's "view"): `first` = local plane index of the view's plane 0 (what the
+// field pointers are advanced by), `own0` = the view plane of the first owned plane.  A single-domain context is its own view.
+Geom jacobi_freeze_view(const Geom& g, int* first, int* own0)
 {
-	return FX_KNOB_INT("FREEZE_FAST", 1) != 0 && g.Zg > 1 && g.H == 0 && g.z0 == 0 && g.nz == g.Zg && g.X >= 4 &&
-		(uint64_t)g.X * g.Y < (1u << 24) && (uint64_t)g.X * g.Y * (uint64_t)g.Zg < (1u << 30);   // 24-bit row / plane multiplies, 32-bit byte offsets
+	const int n = g.zhi - g.zlo + 1;
+	if (first) *first = g.lz(g.zlo);
+	if (own0) *own0 = g.z0 - g.zlo;
+	return Geom{ g.X, g.Y, n, 0, n, 0, 0, n - 1 };
 }
 
-int jacobi_freeze_tiles(const Geom& g)
+bool jacobi_freeze_supported(const Geom& g)
 {
-	return ((g.X + TCX - 1) / TCX) * ((g.Y + TCY - 1) / TCY) * ((g.Zg + TCZ - 1) / TCZ);
+	const bool slab = g.nz != g.Zg;
+	// a slab's cones reach T <= 4 planes into the halo; its halo planes must be exchanged ones on every interior side
+	if (slab && (g.H < 4 || (g.z0 > 0 && g.z0 - g.zlo < 4) || (g.z0 + g.nz < g.Zg && g.zhi - (g.z0 + g.nz - 1) < 4))) return false;
+	const uint64_t planes = (uint64_t)g.nzl();
+	return FX_KNOB_INT("FREEZE_FAST", 1) != 0 && g.Zg > 1 && g.X >= 4 &&
+		(uint64_t)g.X * g.Y < (1u << 24) && (uint64_t)g.X * g.Y * planes < (1u << 30);   // 24-bit row / plane multiplies, 32-bit byte offsets
+}
+
+int jacobi_freeze_tiles(const Geom& g)                                // (sized for every plane the context allocates)
+{
+	return ((g.X + TCX - 1) / TCX) * ((g.Y + TCY - 1) / TCY) * ((g.nzl() + TCZ - 1) / TCZ);
 }
 
 size_t jacobi_freeze_mask_bytes(const Geom& g) { return (size_t)((g.X + 3) / 4) * g.Y * (size_t)g.nzl(); }
@@ -546,16 +565,18 @@ int jacobi_freeze_levels_per_launch()
 }
 
 hipError_t launch_freeze_dense(const Geom& g, const float* p_in, const float* b, float* pA, float* pB, uint8_t* mA, uint8_t* mB,
-	const FreezeWork& w, hipStream_t s, const void* vel, int vel_half)
+	const FreezeWork& w, hipStream_t s, const void* vel, int vel_half, int z_begin, int nzp, size_t vel_comp_cells)
 {
+	if (nzp <= 0) { z_begin = 0; nzp = g.Zg; }
+	if (!vel_comp_cells) vel_comp_cells = g.cells_local();
 	const int X4 = (g.X + 3) >> 2;
 	const int bx = X4 < 64 ? X4 : 64;
 	int by = 256 / bx; if (by < 1) by = 1; if (by > g.Y) by = g.Y;
 	const int ntx = (g.X + TCX - 1) / TCX, nty = (g.Y + TCY - 1) / TCY;
-	const dim3 block(bx, by, 1), grid(((X4 + bx - 1) / bx) * ((g.Y + by - 1) / by) * g.Zg, 1, 1);
+	const dim3 block(bx, by, 1), grid(((X4 + bx - 1) / bx) * ((g.Y + by - 1) / by) * nzp, 1, 1);
 	float* b_out = const_cast<float*>(b);
 #define FX_DENSE(AL_, F_) hipLaunchKernelGGL((k_freeze_dense<AL_, F_>), grid, block, 0, s, g, p_in, b, pA, pB, mA, mB, w.tile_mark, w.gen, \
-		w.counts_next, kFreezeSlots * kShards, ntx, nty, by, vel, b_out)
+		w.counts_next, kFreezeSlots * kShards, ntx, nty, by, vel, b_out, z_begin, nzp, (uint32_t)vel_comp_cells)
 	if ((g.X & 3) != 0) { if (!vel) FX_DENSE(false, 0); else if (vel_half) FX_DENSE(false, 2); else FX_DENSE(false, 1); }
 	else if (!vel) FX_DENSE(true, 0);
 	else if (vel_half) FX_DENSE(true, 2);
@@ -568,14 +589,15 @@ bool jacobi_freeze_can_fuse_divergence(const Geom& g) { (void)g; return FX_KNOB_
 
 // launch number `n` (0, 1, ...) of a solve reads list[n & 1] and writes list[(n + 1) & 1]
 hipError_t launch_freeze_tiles(const Geom& g, const float* p_src, const float* b, float* p_dst, const uint8_t* m_src, uint8_t* m_dst,
-	const FreezeWork& w, int n, int levels, int level_base, uint32_t* stat, uint32_t stat_hi, hipStream_t s)
+	const FreezeWork& w, int n, int levels, int level_base, uint32_t* stat, uint32_t stat_hi, hipStream_t s, int z_begin, int nzp)
 {
+	if (nzp <= 0) { z_begin = 0; nzp = g.Zg; }
 	int max_wgs = FX_KNOB_INT("FREEZE_WGS", 2048);
 	// the relaxing set only shrinks: later launches of a solve get smaller grids (an empty or nearly empty launch of 2048 workgroups of
 	// 512 threads costs 4-8 us just to start and retire them; a workgroup walks its list, so fewer workgroups still cover every entry)
 	if (FX_KNOB_INT("FREEZE_SHRINK", 1)) max_wgs = std::max(256, max_wgs >> std::min(n / 4, 3));
 	max_wgs = max_wgs < kShards ? kShards : (max_wgs & ~(kShards - 1));
-	const int ntx = (g.X + TCX - 1) / TCX, nty = (g.Y + TCY - 1) / TCY, ntiles = jacobi_freeze_tiles(g);
+	const int ntx = (g.X + TCX - 1) / TCX, nty = (g.Y + TCY - 1) / TCY, ntiles = ntx * nty * ((g.Zg + TCZ - 1) / TCZ);
 	const int want = (ntiles + kShards - 1) / kShards * kShards;
 	const int nt = FX_KNOB_INT("FREEZE_NT", 512);
 	const dim3 block((g.X & 3) != 0 ? 512 : (nt == 256 ? 256 : (nt == 1024 ? 1024 : 512)), 1, 1), grid(want < max_wgs ? want : max_wgs, 1, 1);
@@ -585,7 +607,7 @@ hipError_t launch_freeze_tiles(const Geom& g, const float* p_src, const float* b
 	uint4* lout = (uint4*)w.list[(n + 1) & 1];
 	const uint32_t* cin = w.counts + (size_t)n * kShards;
 	uint32_t* cout = w.counts + (size_t)(n + 1) * kShards;
-#define FX_FREEZE_ARGS grid, block, 0, s, g, p_src, b, p_dst, m_src, m_dst, lin, cin, lout, cout, w.cap, ntx, nty, level_base, stat, stat_hi, n == 0 ? w.tile_mark : nullptr, w.gen, ntiles, scan_limit
+#define FX_FREEZE_ARGS grid, block, 0, s, g, p_src, b, p_dst, m_src, m_dst, lin, cin, lout, cout, w.cap, ntx, nty, level_base, stat, stat_hi, n == 0 ? w.tile_mark : nullptr, w.gen, ntiles, scan_limit, z_begin, z_begin + nzp
 #define FX_FREEZE_LAUNCH(T) if ((g.X & 3) != 0) hipLaunchKernelGGL((k_freeze_tiles<T, 512, false>), FX_FREEZE_ARGS); \
 	else if (nt == 256) hipLaunchKernelGGL((k_freeze_tiles<T, 256, true>), FX_FREEZE_ARGS); \
 	else if (nt == 1024) hipLaunchKernelGGL((k_freeze_tiles<T, 1024, true>), FX_FREEZE_ARGS); \

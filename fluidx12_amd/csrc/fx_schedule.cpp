@@ -328,57 +328,92 @@ static int clear_freeze_masks(std::vector<fx_ctx*>& M, hipStream_t s)
 	return FX_OK;
 }
 
-// FX_JACOBI_FAITHFUL on a single domain: the sparse solver of fx_jacobi_freeze.hip.  Level 1 everywhere (into p[other] AND p_aux;
-// the input buffer becomes the spare), then ceil((iters - 1) / T) launches over the tiles that still relax, all enqueued; the
-// result is in the last launch's output buffer (settled tiles agree in both).  Bit-identical to `iters` generic sweeps with the
-// byte mask (tests/test_gpu_sim.py::test_freeze_fast_path_*).
+// FX_JACOBI_FAITHFUL: the sparse solver of fx_jacobi_freeze.hip.  Level 1 everywhere (into p[other] AND p_aux; the input buffer
+// becomes the spare), then ceil((iters - 1) / T) launches over the tiles that still relax, all enqueued; the result is in the last
+// launch's output buffer (settled tiles agree in both).  Bit-identical to `iters` generic sweeps with the byte mask
+// (tests/test_gpu_freeze.py).  A slab rank (round 4) runs it on the view of the planes it holds (jacobi_freeze_view): the dense sweep
+// over its owned planes, the tile cones reaching into the halo, and kFreezeHalo planes of pressure + mask travelling to the
+// neighbours behind every launch -- every rank enqueues the same launches and exchanges whatever its tiles do.
 // (a level fits the stat word's low byte, every launch has its counters)
+static const int kFreezeHalo = 4;                          // = the most levels a tile launch takes (jacobi_freeze_levels_per_launch)
 static bool takes_sparse_solver(const fx_ctx* c, uint32_t iters)
 {
-	return !multi_rank(c) && c->frozen && c->fz_tile_next && jacobi_freeze_supported(c->g) && iters <= 255 && (int)iters / jacobi_freeze_levels_per_launch() + 3 < kFreezeSlots;
+	if (!(c->frozen && c->fz_tile_next && jacobi_freeze_supported(c->g) && iters <= 255 && (int)iters / jacobi_freeze_levels_per_launch() + 3 < kFreezeSlots)) return false;
+	if (!multi_rank(c)) return true;
+	// chain-wide facts only (every rank must take the same branch): the grid, the halo, the thinnest slab
+	const uint64_t planes = (uint64_t)c->g.Zg + 2 * (uint64_t)c->g.H;
+	return c->g.H >= kFreezeHalo && c->group->min_nz >= kFreezeHalo && (uint64_t)c->g.X * c->g.Y * planes < (1u << 30);
 }
 
-static int jacobi_freeze(fx_ctx* ctx, hipStream_t s, uint32_t iters)
+static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t iters)
 {
-	DeviceGuard dg(ctx->device);
-	ScopedMark mk(ctx, s, MK_JACOBI);
-	if (++ctx->fz_gen >= (1u << 23)) {                                  // the tag (gen << 8 | level) of the stat words stays below 2^32: start over
-		FX_HIP(hipMemsetAsync(ctx->fz_tile_next, 0, (size_t)jacobi_freeze_tiles(ctx->g) * sizeof(uint32_t), s));
-		FX_HIP(hipMemsetAsync(ctx->fz_stat, 0, kFreezeStatRing * sizeof(uint32_t), s));
-		FX_HIP(hipMemsetAsync(ctx->fz_counts, 0, 2 * jacobi_freeze_count_words() * sizeof(uint32_t), s));
-		ctx->fz_gen = 2; ctx->fz_gen_mark = 0;
+	fx_ctx* ctx = lead;                                                 // FX_HIP reports through `ctx`
+	const bool multi = multi_rank(lead);
+	struct Run { Geom v; size_t off; int own0; FreezeWork w; float *src, *a, *d; uint8_t *ma, *md; uint32_t* stat; uint32_t stat_hi; };
+	std::vector<Run> R(M.size());
+	const bool fuse = lead->fz_fuse_div;
+	lead->fz_fuse_div = false;
+	for (size_t i = 0; i < M.size(); ++i) {
+		fx_ctx* m = M[i];
+		DeviceGuard dg(m->device);
+		hipStream_t ms = CS(m, s);
+		if (++m->fz_gen >= (1u << 23)) {                                // the tag (gen << 8 | level) of the stat words stays below 2^32: start over
+			FX_HIP(hipMemsetAsync(m->fz_tile_next, 0, (size_t)jacobi_freeze_tiles(m->g) * sizeof(uint32_t), ms));
+			FX_HIP(hipMemsetAsync(m->fz_stat, 0, kFreezeStatRing * sizeof(uint32_t), ms));
+			FX_HIP(hipMemsetAsync(m->fz_counts, 0, 2 * jacobi_freeze_count_words() * sizeof(uint32_t), ms));
+			m->fz_gen = 2; m->fz_gen_mark = 0;
+		}
+		Run& r = R[i];
+		int first = 0;
+		r.v = jacobi_freeze_view(m->g, &first, &r.own0);
+		r.off = (size_t)first * m->g.plane();
+		const uint32_t gen = m->fz_gen;
+		r.stat_hi = gen << 8;
+		r.stat = m->fz_stat + gen % kFreezeStatRing;
+		m->fz_iters[gen % kFreezeStatRing] = iters;
+		const size_t cw = jacobi_freeze_count_words();
+		r.w = FreezeWork{ m->fz_tile_next, gen, { m->fz_list[0], m->fz_list[1] }, jacobi_freeze_tiles(m->g),
+			m->fz_counts + (gen & 1u) * cw, m->fz_counts + ((gen & 1u) ^ 1u) * cw };
+		r.src = m->p[m->p_cur]; r.a = m->p[m->p_cur ^ 1]; r.d = m->p_aux;
+		r.ma = m->fz_mask[0]; r.md = m->fz_mask[1];
+		// (The dense sweep writes level 1 to BOTH buffers the tile launches alternate between.  Writing one and letting the first tile
+		// launch carry the unlisted tiles' border cells across was built and measured level: the dense sweep 75 -> 46 us at 256^3, the
+		// first tile launch slower by as much -- the shell of a 4-deep cone around ~3000 listed tiles is more bytes than the second copy.)
+		// whole steps (simulate_impl) leave the divergence to this launch: it computes b from the advected velocity and stores it for the
+		// tile launches, instead of reading it back from a launch of its own
+		const size_t moff = (size_t)first * (size_t)((m->g.X + 3) / 4) * m->g.Y, es = elem_size(m);
+		ScopedMark mk(m, ms, MK_JACOBI);
+		FX_HIP(launch_freeze_dense(r.v, r.src + r.off, m->b + r.off, r.a + r.off, r.d + r.off, r.ma + moff, r.md + moff, r.w, ms,
+			fuse ? (const char*)m->vel[1] + r.off * es : nullptr, m->half, r.own0, m->g.nz, m->g.cells_local()));
+		mk.launches = 1; mk.sweeps = 1;
 	}
-	const uint32_t gen = ctx->fz_gen, stat_hi = gen << 8;
-	uint32_t* stat = ctx->fz_stat + gen % kFreezeStatRing;
-	ctx->fz_iters[gen % kFreezeStatRing] = iters;
-	const size_t cw = jacobi_freeze_count_words();
-	const FreezeWork w{ ctx->fz_tile_next, gen, { ctx->fz_list[0], ctx->fz_list[1] }, jacobi_freeze_tiles(ctx->g),
-		ctx->fz_counts + (gen & 1u) * cw, ctx->fz_counts + ((gen & 1u) ^ 1u) * cw };
-	float* src = ctx->p[ctx->p_cur];
-	float* a = ctx->p[ctx->p_cur ^ 1];
-	float* d = ctx->p_aux;
-	uint8_t* ma = ctx->fz_mask[0];
-	uint8_t* md = ctx->fz_mask[1];
-	// (The dense sweep writes level 1 to BOTH buffers the tile launches alternate between.  Writing one and letting the first tile
-	// launch carry the unlisted tiles' border cells across was built and measured level: the dense sweep 75 -> 46 us at 256^3, the
-	// first tile launch slower by as much -- the shell of a 4-deep cone around ~3000 listed tiles is more bytes than the second copy.)
-	// whole steps (simulate_impl) leave the divergence to this launch: it computes b from the advected velocity and stores it for the
-	// tile launches, instead of reading it back from a launch of its own
-	const bool fuse = ctx->fz_fuse_div;
-	ctx->fz_fuse_div = false;
-	FX_HIP(launch_freeze_dense(ctx->g, src, ctx->b, a, d, ma, md, w, s, fuse ? ctx->vel[1] : nullptr, ctx->half));
-	mk.launches = 1; mk.sweeps = 1;
-	if (iters > 1) mk.split(MK_JACOBI_TAIL);                            // fx_timing books the dense sweep as the "main" launch, the tile launches beside it
+	auto exchange = [&](bool with_b) -> int {
+		if (!multi) return FX_OK;
+		for (size_t i = 0; i < M.size(); ++i) { M[i]->fz_x_p = R[i].a; M[i]->fz_x_m = R[i].ma; }
+		const ExchSpec specs[2] = { { EX_FREEZE, kFreezeHalo, 0 }, { EX_DIV, kFreezeHalo, 0 } };
+		return do_exchange(lead, M, specs, with_b ? 2 : 1, ON_COMPUTE, s);
+	};
+	int rc = exchange(true);                                            // level 1 and the divergence across the faces
+	if (rc) return rc;
 	const int T = jacobi_freeze_levels_per_launch();
 	int level = 1, n = 0;
 	for (uint32_t left = iters - 1; left > 0; ++n) {
 		const int t = (int)std::min<uint32_t>((uint32_t)T, left);
-		FX_HIP(launch_freeze_tiles(ctx->g, a, ctx->b, d, ma, md, w, n, t, level, stat, stat_hi, s));
-		std::swap(a, d); std::swap(ma, md);
+		for (size_t i = 0; i < M.size(); ++i) {
+			fx_ctx* m = M[i];
+			Run& r = R[i];
+			DeviceGuard dg(m->device);
+			const size_t moff = r.off / m->g.plane() * (size_t)((m->g.X + 3) / 4) * m->g.Y;
+			ScopedMark mk(m, CS(m, s), MK_JACOBI_TAIL);                    // fx_timing books the dense sweep as the "main" launch, the tile launches beside it
+			FX_HIP(launch_freeze_tiles(r.v, r.a + r.off, m->b + r.off, r.d + r.off, r.ma + moff, r.md + moff, r.w, n, t, level, r.stat, r.stat_hi, CS(m, s), r.own0, m->g.nz));
+			mk.launches = 1; mk.sweeps = (uint64_t)t;
+			std::swap(r.a, r.d); std::swap(r.ma, r.md);
+		}
 		left -= (uint32_t)t; level += t;
-		mk.launches += 1; mk.sweeps += (uint64_t)t;
+		if ((rc = exchange(false))) return rc;                          // the levels just made, kFreezeHalo planes deep (the last one serves the projection)
 	}
-	ctx->p[0] = a; ctx->p[1] = d; ctx->p_aux = src; ctx->p_cur = 0;
+	if (iters == 1 && multi) { /* the level-1 exchange above already carries the projection's plane */ }
+	for (size_t i = 0; i < M.size(); ++i) { fx_ctx* m = M[i]; m->p[0] = R[i].a; m->p[1] = R[i].d; m->p_aux = R[i].src; m->fz_mask[0] = R[i].ma; m->fz_mask[1] = R[i].md; m->p_cur = 0; }
 	return FX_OK;
 }
 
@@ -388,7 +423,7 @@ static int jacobi_serial(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 	const bool multi = multi_rank(lead);
 	const int k = multi ? lead->opt_round : (int)iters;
 	int rc;
-	if (takes_sparse_solver(lead, iters)) return jacobi_freeze(lead, s, iters);
+	if (takes_sparse_solver(lead, iters)) return jacobi_freeze(lead, M, s, iters);
 	for (fx_ctx* m : M) { std::vector<fx_ctx*> one{ m }; if ((rc = clear_freeze_masks(one, CS(m, s)))) return rc; }
 	const ExchSpec bspec{ EX_DIV, k - 1, 0 };
 	if ((rc = do_exchange(lead, M, &bspec, 1, ON_COMPUTE, s))) return rc;

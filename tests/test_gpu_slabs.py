@@ -133,6 +133,37 @@ def test_slabs_faithful_mode(overlap):
     assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
 
 
+@pytest.mark.parametrize("dims,nranks,hj,ha,storage,address,steps", [((64, 64, 96), 3, 8, 6, "fp16", "clamp", 8), ((48, 48, 64), 2, 4, 10, "fp32", "mirror", 6),
+                                                                     ((150, 150, 60), 3, 5, 8, "fp16", "clamp", 5), ((128, 128, 100), 4, 8, 8, "fp32", "clamp", 6),
+                                                                     ((64, 64, 45), 2, 6, 6, "fp32", "clamp", 9)])
+def test_slabs_run_the_reference_s_solve_on_the_sparse_solver(dims, nranks, hj, ha, storage, address, steps):
+    """the reference's own configuration (<= 64 sweeps, per-cell early-out) on slab ranks takes the sparse solver of fx_jacobi_freeze.hip
+    (a view of each rank's planes: dense sweep over the owned ones, tile cones reaching into the halo, four planes of pressure + mask
+    behind every launch) -- every field and the number of executed sweeps equal the single domain's, bit for bit; uneven slabs, halos that
+    are no multiple of the tile depth, rows of 150 cells, both storages and samplers"""
+    kw = dict(jacobi_mode="faithful", jacobi_iters=64, storage=storage, advect_address=address)
+    ref = run_single(dims, steps, **kw)
+    fl = run_slabs(dims, steps, nranks, halo_jacobi=hj, halo_advect=ha, **kw)
+    for f in [ref] + fl:
+        f.timing_read(True)
+    for f in (ref, fl[0]):                                   # one more step, counted: the fast path must be the one that runs
+        f.UpdateFrame(f32(f.default_time_step()), 0)
+        f.Simulate(0)
+    ref.Synchronize(); fl[0].Synchronize()
+    t = ref.timing_read()
+    assert t.freeze_solves == 1 and t.freeze_sweeps >= 2
+    most = 0
+    for f in fl:
+        tt = f.timing_read()
+        assert tt.freeze_solves == 1                          # (a slab's own count of sweeps covers its planes only: <= the domain's)
+        assert tt.freeze_sweeps <= t.freeze_sweeps
+        most = max(most, tt.freeze_sweeps)
+    assert most == t.freeze_sweeps                            # the chain's count (the last level that left a cell relaxing anywhere) = the domain's
+    assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
+    assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
+    assert np.array_equal(gather(fl, fx.FIELD_COLOR, 0), ref.download(fx.FIELD_COLOR))
+
+
 def test_uneven_slabs_and_fp16():
     dims = (48, 48, 40)
     ref = run_single(dims, 4, jacobi_iters=12, storage="fp16")
