@@ -101,6 +101,9 @@ hipError_t launch_freeze_dense(const Geom& g, const float* p_in, const float* b,
 bool jacobi_freeze_can_fuse_divergence(const Geom& g);
 hipError_t launch_freeze_tiles(const Geom& g, const float* p_src, const float* b, float* p_dst, const uint8_t* m_src, uint8_t* m_dst,
 	const FreezeWork& w, int n, int levels, int level_base, uint32_t* stat, uint32_t stat_hi, hipStream_t s, int z_begin = 0, int nzp = 0);
+// 2-D grids (fx_jacobi2d.hip): up to jacobi2d_max_sweeps (0: not a 2-D grid / switched off) lock-step sweeps per launch on LDS tiles, with or without the freeze bytes
+int jacobi2d_max_sweeps(const Geom& g);
+hipError_t launch_jacobi2d(const Geom& g, const float* p_in, const float* b, float* p_out, uint8_t* frozen, int sweeps, hipStream_t s);
 // sweeps fused per launch for this geometry (1 = no fused path); requested > 0 overrides the default
 int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp);
 bool jacobi_prefers_three(const Geom& g, int requested, int nzp);

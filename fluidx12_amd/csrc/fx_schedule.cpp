@@ -283,12 +283,18 @@ int divergence_phase(fx_ctx* ctx, hipStream_t s)
 }
 
 // t lock-step sweeps p[src] -> p[src ^ 1] on planes [r.lo, r.hi) in ONE launch
+// 2-D grids relax on LDS tiles (fx_jacobi2d.hip) unless the caller asked for one sweep per launch (jacobi_fuse = 1: the plainest kernels,
+// what the kernel-against-kernel parity tests compare with)
+static bool takes_2d_tiles(const fx_ctx* c) { return jacobi2d_max_sweeps(c->g) > 0 && (c->desc.flags & FX_FLAG_JACOBI_FUSE_MASK) != 1; }
+
 static int jacobi_launch(fx_ctx* ctx, hipStream_t s, int src, int t, Range r, ScopedMark* mk)
 {
 	r.lo = std::max(r.lo, 0); r.hi = std::min(r.hi, ctx->g.Zg);
 	if (r.hi <= r.lo) return FX_OK;
 	DeviceGuard dg(ctx->device);
-	if (t > 1) {
+	if (takes_2d_tiles(ctx)) {                             // 2-D grids: up to eight sweeps per launch on LDS tiles, freeze bytes included
+		FX_HIP(launch_jacobi2d(ctx->g, ctx->p[src], ctx->b, ctx->p[src ^ 1], ctx->frozen, t, s));
+	} else if (t > 1) {
 		FX_HIP(launch_jacobi_fused(ctx->g, ctx->p[src], ctx->b, ctx->p[src ^ 1], t, r.lo, r.hi, s));
 	} else {
 		FX_HIP(launch_jacobi_sweep(ctx->g, ctx->p[src], ctx->b, ctx->p[src ^ 1], ctx->frozen, r.lo, r.hi, s));
@@ -299,6 +305,7 @@ static int jacobi_launch(fx_ctx* ctx, hipStream_t s, int src, int t, Range r, Sc
 
 static int fused_sweeps(const fx_ctx* c)
 {
+	if (takes_2d_tiles(c)) return jacobi2d_max_sweeps(c->g);
 	return c->frozen ? 1 : jacobi_fused_max_sweeps(c->g, (int)(c->desc.flags & FX_FLAG_JACOBI_FUSE_MASK), c->g.nz);
 }
 
@@ -310,7 +317,7 @@ static int jacobi_round(fx_ctx* ctx, hipStream_t s, int count, ScopedMark* mk)
 	while (done < count) {
 		const int left = count - done;
 		int t = std::min(left, fused_sweeps(ctx));
-		if (!ctx->frozen && jacobi_prefers_three(ctx->g, (int)(ctx->desc.flags & FX_FLAG_JACOBI_FUSE_MASK), ctx->g.nz))
+		if (!ctx->frozen && !takes_2d_tiles(ctx) && jacobi_prefers_three(ctx->g, (int)(ctx->desc.flags & FX_FLAG_JACOBI_FUSE_MASK), ctx->g.nz))
 			t = left == 4 ? 2 : std::min(left, 3);           // threes, and a remainder of 4 as 2 + 2 rather than 3 + 1
 		if (mk && mk->kind == MK_JACOBI && mk->launches && t * mk->launches < mk->sweeps) mk->split(MK_JACOBI_TAIL);   // shorter launches from here on
 		const int rc = jacobi_launch(ctx, s, ctx->p_cur, t, grown(ctx, multi_rank(ctx) ? left - t : 0), mk);

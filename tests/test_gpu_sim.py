@@ -593,3 +593,35 @@ def test_round2_kernels_reproduce_the_round1_kernels_over_a_whole_run(grid, step
         assert r.returncode == 0, r.stderr[-2000:]
         digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
     assert digests[0] == digests[1] == digests[2]
+
+
+@pytest.mark.parametrize("dims,mode,iters", [((512, 512, 1), "faithful", 64), ((512, 512, 1), "fixed", 20), ((100, 100, 1), "faithful", 64),
+                                              ((70, 70, 1), "fixed", 13), ((64, 64, 1), "faithful", 9), ((33, 33, 1), "fixed", 40)])
+def test_2d_tile_kernel_equals_one_sweep_per_launch(dims, mode, iters):
+    """k_jacobi2d_tile (up to eight sweeps per launch on LDS tiles with recomputed halos; the reference's 2-D preset Bin/Fluid2D.bat is
+    512 x 512 x 1 with its 64-sweep early-out loop) against one sweep per launch in k_jacobi_generic (jacobi_fuse = 1) over whole
+    steps, and its solve alone against the oracle: bit-identical, freeze bytes included"""
+    kw = dict(jacobi_mode=mode, jacobi_iters=iters)
+    a, b_ = make(dims, **kw), make(dims, jacobi_fuse=1, **kw)
+    for k in range(10):
+        for f in (a, b_):
+            f.UpdateFrame(f32(f.default_time_step()), k % 3)
+            f.Simulate(k % 3)
+    for fld in (fx.FIELD_PRESSURE, fx.FIELD_VELOCITY, fx.FIELD_COLOR):
+        assert np.array_equal(a.download(fld).view(np.uint32), b_.download(fld).view(np.uint32)), fld
+    assert np.abs(a.download(fx.FIELD_PRESSURE)).max() > 0
+    # the launch count says which kernel ran
+    a.timing_enable(True); a.timing_read(True)
+    a.UpdateFrame(f32(a.default_time_step()), 1); a.Simulate(1); a.Synchronize()
+    t = a.timing_read()
+    assert t.jacobi_sweeps == iters and t.jacobi_launches == (iters + 7) // 8
+    # the solve alone, from a random state, against the oracle
+    X, Y, _ = dims
+    rng = np.random.default_rng(3)
+    p = (rng.standard_normal((1, Y, X)) * 0.05).astype(f32)
+    bb = (rng.standard_normal((1, Y, X)) * 0.02).astype(f32)
+    f = make(dims, **kw)
+    f.upload(fx.FIELD_PRESSURE, p); f.upload(fx.FIELD_DIVERGENCE, bb)
+    f.Jacobi(iters); f.Synchronize()
+    want, _ = orc.jacobi(p, bb, iters, mode=int(mode == "faithful"))
+    assert np.array_equal(f.download(fx.FIELD_PRESSURE).view(np.uint32), want.view(np.uint32))
