@@ -28,9 +28,9 @@ inline size_t elem_size(const fx_ctx* c) { return c->half ? 2 : 4; }
 
 struct DeviceGuard {
 	int prev = -1;
-	bool ok = true;
-	explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) ok = hipSetDevice(dev) == hipSuccess; }
-	~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+	bool ok = true, changed = false;
+	explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) { ok = hipSetDevice(dev) == hipSuccess; changed = true; } }
+	~DeviceGuard() { if (changed && prev >= 0) (void)hipSetDevice(prev); }     // (nothing to restore on the usual one-device path: a guard per launch costs one hipGetDevice)
 };
 
 // ---- timing ---------------------------------------------------------------------------------

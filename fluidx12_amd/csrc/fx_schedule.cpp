@@ -2,6 +2,7 @@
 // exchanges over a group of z-slab contexts: one code path serves the single-GPU case, the RCCL slabs and the in-process loop-back
 // slabs.  The C ABI entry points that drive it are in fx_api.cpp; contexts, fields and options in fx_context.cpp.
 #include "fx_host.h"
+#include <memory>
 
 using namespace fx;
 
@@ -358,6 +359,7 @@ static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 	const bool multi = multi_rank(lead);
 	struct Run { Geom v; size_t off; int own0; FreezeWork w; float *src, *a, *d; uint8_t *ma, *md; uint32_t* stat; uint32_t stat_hi; };
 	std::vector<Run> R(M.size());
+	std::vector<std::unique_ptr<ScopedMark>> mk(M.size());
 	const bool fuse = lead->fz_fuse_div;
 	lead->fz_fuse_div = false;
 	for (size_t i = 0; i < M.size(); ++i) {
@@ -389,10 +391,13 @@ static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 		// whole steps (simulate_impl) leave the divergence to this launch: it computes b from the advected velocity and stores it for the
 		// tile launches, instead of reading it back from a launch of its own
 		const size_t moff = (size_t)first * (size_t)((m->g.X + 3) / 4) * m->g.Y, es = elem_size(m);
-		ScopedMark mk(m, ms, MK_JACOBI);
+		// fx_timing books the dense sweep as the "main" launch and the tile launches beside it.  A single domain keeps ONE mark open over
+		// all of them (an event record between two launches is a 2-3 us gap, 17 of them a solve); slab ranks close it at every exchange
+		mk[i].reset(new ScopedMark(m, ms, MK_JACOBI));
 		FX_HIP(launch_freeze_dense(r.v, r.src + r.off, m->b + r.off, r.a + r.off, r.d + r.off, r.ma + moff, r.md + moff, r.w, ms,
 			fuse ? (const char*)m->vel[1] + r.off * es : nullptr, m->half, r.own0, m->g.nz, m->g.cells_local()));
-		mk.launches = 1; mk.sweeps = 1;
+		mk[i]->launches = 1; mk[i]->sweeps = 1;
+		if (multi || iters == 1) mk[i].reset(); else mk[i]->split(MK_JACOBI_TAIL);
 	}
 	auto exchange = [&](bool with_b) -> int {
 		if (!multi) return FX_OK;
@@ -411,15 +416,16 @@ static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 			Run& r = R[i];
 			DeviceGuard dg(m->device);
 			const size_t moff = r.off / m->g.plane() * (size_t)((m->g.X + 3) / 4) * m->g.Y;
-			ScopedMark mk(m, CS(m, s), MK_JACOBI_TAIL);                    // fx_timing books the dense sweep as the "main" launch, the tile launches beside it
+			if (!mk[i]) mk[i].reset(new ScopedMark(m, CS(m, s), MK_JACOBI_TAIL));
 			FX_HIP(launch_freeze_tiles(r.v, r.a + r.off, m->b + r.off, r.d + r.off, r.ma + moff, r.md + moff, r.w, n, t, level, r.stat, r.stat_hi, CS(m, s), r.own0, m->g.nz));
-			mk.launches = 1; mk.sweeps = (uint64_t)t;
+			mk[i]->launches += 1; mk[i]->sweeps += (uint64_t)t;
+			if (multi) mk[i].reset();
 			std::swap(r.a, r.d); std::swap(r.ma, r.md);
 		}
 		left -= (uint32_t)t; level += t;
 		if ((rc = exchange(false))) return rc;                          // the levels just made, kFreezeHalo planes deep (the last one serves the projection)
 	}
-	if (iters == 1 && multi) { /* the level-1 exchange above already carries the projection's plane */ }
+	mk.clear();
 	for (size_t i = 0; i < M.size(); ++i) { fx_ctx* m = M[i]; m->p[0] = R[i].a; m->p[1] = R[i].d; m->p_aux = R[i].src; m->fz_mask[0] = R[i].ma; m->fz_mask[1] = R[i].md; m->p_cur = 0; }
 	return FX_OK;
 }
