@@ -186,9 +186,11 @@ __device__ __forceinline__ void advect_gather(const Geom& g, const SimParams& sp
 }
 
 // impulse (CSAdvect.hlsl:59-68), attenuation and the stores of one voxel; u / c = the traced velocity / colour
-template <bool HALF>
+// ALPHA: the stored alpha once more, as fp32, into the render's alpha-only side volume (fx_render_accel.hip: every density tap of the
+// marches reads that volume; written here, the render's build pass no longer reads the whole colour field to extract it)
+template <bool HALF, bool ALPHA>
 __device__ __forceinline__ void advect_finish(const SimParams& sp, float (&u)[3], float (&c)[4], float ex, float dx, float dz, float dt, float atten,
-	uint32_t id, uint32_t stride, void* __restrict__ vel_out, void* __restrict__ col_out)
+	uint32_t id, uint32_t stride, void* __restrict__ vel_out, void* __restrict__ col_out, float* __restrict__ alpha_out)
 {
 	// ---- impulse (CSAdvect.hlsl:59-68).  exp2(ex) >= e^-4 needs ex >= -5.77: a wave whose lanes are all far below that
 	// skips the transcendental; the decision itself still uses the computed basis, exactly as before
@@ -219,14 +221,15 @@ __device__ __forceinline__ void advect_finish(const SimParams& sp, float (&u)[3]
 		h16x4 hc;
 		hc.x = to_h16(c[0] * atten); hc.y = to_h16(c[1] * atten); hc.z = to_h16(c[2] * atten); hc.w = to_h16(c[3] * atten);
 		static_cast<h16x4*>(col_out)[id] = hc;
+		if (ALPHA) alpha_out[id] = (float)hc.w;
 	} else {
 		float* vo = static_cast<float*>(vel_out);
 		vo[id] = u[0] * atten;
 		vo[(size_t)stride + id] = u[1] * atten;
 		vo[2 * (size_t)stride + id] = u[2] * atten;
 		static_cast<float4*>(col_out)[id] = make_float4(c[0] * atten, c[1] * atten, c[2] * atten, c[3] * atten);
+		if (ALPHA) alpha_out[id] = c[3] * atten;
 	}
-
 }
 
 }  // namespace
@@ -236,9 +239,9 @@ __device__ __forceinline__ void advect_finish(const SimParams& sp, float (&u)[3]
 // DEFER: a voxel whose trace leaves the staged window is not gathered here -- its wave would issue 35 scattered loads for a few lanes and
 // hold the workgroup's barrier meanwhile -- but appended to the workgroup's segment of `far_list` (a placeholder is stored to its cell)
 // and advected by k_advect_far afterwards.  7 % of the waves of a developed plume (frame 132) have such a lane, 1.5 % of the voxels.
-template <bool HALF, int TY, bool DEFER, bool P2>
+template <bool HALF, int TY, bool DEFER, bool P2, bool ALPHA>
 __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_advect_lds(const Geom g, const SimParams sp,
-	const void* __restrict__ vel_in, const void* __restrict__ col_in, void* __restrict__ vel_out, void* __restrict__ col_out,
+	const void* __restrict__ vel_in, const void* __restrict__ col_in, void* __restrict__ vel_out, void* __restrict__ col_out, float* __restrict__ alpha_out,
 	int z_begin, int nzp, int zchunk, int nchunks, unsigned* halo_overflow, float rX, float rY, float rZ, float inv_rr,
 	int lgX, int lgY, int lg_gx, int lg_gy, uint32_t* __restrict__ far_list, uint32_t* __restrict__ far_flat, uint32_t* __restrict__ far_total, uint32_t far_cap)
 {
@@ -393,18 +396,19 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
 		}
 
 		const uint32_t id = planes<P2>((uint32_t)g.lz(z), lgP, g) + rows<P2>((uint32_t)y, lgX, g) + (uint32_t)x;
-		advect_finish<HALF>(sp, u, c, ex, dx, dz, dt, atten, id, stride, vel_out, col_out);
+		advect_finish<HALF, ALPHA>(sp, u, c, ex, dx, dz, dt, atten, id, stride, vel_out, col_out, alpha_out);
 	};
 
 	for (int z = zb; z < ze; ++z) {
 		if (z + 2 <= ze) fill(z + 2);                           // plane ze is the z+1 of the chunk's last plane
 		compute(z);
-		// the four stores of this step were issued after the LDS-DMA loads and complete after them: vmcnt(4) = "plane z+2 has
-		// landed" without waiting for the store acknowledgements.  That the compiler emits exactly four store instructions per
-		// step behind the fill is checked on the generated ISA by tests/test_isa_contract.py
+		// the four stores of this step (five with ALPHA) were issued after the LDS-DMA loads and complete after them: vmcnt(4) = "plane
+		// z+2 has landed" without waiting for the store acknowledgements.  That the compiler emits exactly that many store instructions
+		// per step behind the fill is checked on the generated ISA by tests/test_isa_contract.py
 		// (a wave without a single voxel -- rows beyond Y in the last tile of a column -- has issued no store: it waits for everything)
-		if (P2 || y < g.Y) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-		else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		if (!(P2 || y < g.Y)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		else if (ALPHA) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+		else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 		__syncthreads();                                         // plane z+2 is in the ring; plane z-1's slot may be overwritten
 	}
 	// (behind the loop's last barrier: every append is in.)  The workgroup's notes move from its segment to ONE list every workgroup
@@ -424,9 +428,9 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
 
 // The voxels k_advect_lds<.., DEFER = true> put aside, one per thread off the common list: CSAdvect.hlsl:41-79 for one voxel with every tap a
 // gather (k_advect_fast's arithmetic, so the result is the one the staged path would have produced had the window been wide enough).
-template <bool HALF, bool P2>
+template <bool HALF, bool P2, bool ALPHA>
 __global__ __launch_bounds__(256) void k_advect_far(const Geom g, const SimParams sp,
-	const void* __restrict__ vel_in, const void* __restrict__ col_in, void* __restrict__ vel_out, void* __restrict__ col_out,
+	const void* __restrict__ vel_in, const void* __restrict__ col_in, void* __restrict__ vel_out, void* __restrict__ col_out, float* __restrict__ alpha_out,
 	const uint32_t* __restrict__ far_flat, const uint32_t* __restrict__ far_total, uint32_t* __restrict__ far_total_next, unsigned* halo_overflow,
 	float rX, float rY, float rZ, float inv_rr, int lgX, int lgY)
 {
@@ -464,16 +468,18 @@ __global__ __launch_bounds__(256) void k_advect_far(const Geom g, const SimParam
 		const bool z_present = z0 >= g.zlo && z0 <= g.zhi && z1 >= g.zlo && z1 <= g.zhi;
 		float u[3], c[4];
 		advect_gather<HALF, P2>(g, sp, ix, iy, z0, z1, z_present, fx, fy, fz, v0, v1, v2, col_in, lgX, lgP, halo_overflow, u, c);
-		advect_finish<HALF>(sp, u, c, ex, dx, dz, dt, atten, id, stride, vel_out, col_out);
+		advect_finish<HALF, ALPHA>(sp, u, c, ex, dx, dz, dt, atten, id, stride, vel_out, col_out, alpha_out);
 	}
 }
 
 
 // hipErrorNotSupported: the geometry has no LDS path (the caller falls back to k_advect_fast / k_advect)
 hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const void* col_in,
-	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, uint32_t* far_scratch, size_t far_words, int far_parity, bool* far_used, hipStream_t s, bool force)
+	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, uint32_t* far_scratch, size_t far_words, int far_parity, bool* far_used, hipStream_t s, bool force,
+	AdvectAlpha* alpha)
 {
 	if (far_used) *far_used = false;
+	if (alpha) alpha->written = false;
 	auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
 	const int nzp = z_end - z_begin;
 	// rows per workgroup tile.  16 (one 1024-thread workgroup per CU, 1.16 x instead of 1.29 x border) measured 0.228 / 0.269 ms against
@@ -520,24 +526,31 @@ hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store,
 	uint32_t* far_total_next = far_scratch ? far_scratch + ((far_parity & 1) ^ 1) : nullptr;
 	uint32_t* far_flat = far_scratch ? far_scratch + 2 : nullptr;
 	uint32_t* far_list = far_scratch ? far_scratch + 2 + flat_words : nullptr;
-#define FX_ADV(H_, TY_, D_, P_) do { \
+#define FX_ADV(H_, TY_, D_, P_, A_) do { \
 		static bool attr_set = false; \
-		if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_advect_lds<H_, TY_, D_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * Lay<H_, TY_>::SLOT_BYTES); attr_set = true; } \
-		hipLaunchKernelGGL((k_advect_lds<H_, TY_, D_, P_>), dim3(tiles_xy * nchunks), dim3(64 * TY_), (NSLOT * Lay<H_, TY_>::SLOT_BYTES), s, g, sp, vel_in, col_in, vel_out, col_out, \
+		if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_advect_lds<H_, TY_, D_, P_, A_>), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * Lay<H_, TY_>::SLOT_BYTES); attr_set = true; } \
+		hipLaunchKernelGGL((k_advect_lds<H_, TY_, D_, P_, A_>), dim3(tiles_xy * nchunks), dim3(64 * TY_), (NSLOT * Lay<H_, TY_>::SLOT_BYTES), s, g, sp, vel_in, col_in, vel_out, col_out, alpha_out, \
 			z_begin, nzp, zchunk, nchunks, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY, lg_gx, lg_gy, far_list, far_flat, far_total, far_cap); } while (0)
-#define FX_FAR(H_, P_) hipLaunchKernelGGL((k_advect_far<H_, P_>), dim3(far_wgs), dim3(256), 0, s, g, sp, vel_in, col_in, vel_out, col_out, far_flat, far_total, far_total_next, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY)
+#define FX_FAR(H_, P_, A_) hipLaunchKernelGGL((k_advect_far<H_, P_, A_>), dim3(far_wgs), dim3(256), 0, s, g, sp, vel_in, col_in, vel_out, col_out, alpha_out, far_flat, far_total, far_total_next, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY)
 	const int far_wgs = 1024;                                       // 262144 threads: a developed 256^3 plume notes 250-400 thousand voxels
-	if (!p2) {
+	// the render's alpha side volume rides along on the default path (8-row tiles, far voxels deferred) of a context whose local planes
+	// are the whole grid (the side volume is indexed by global voxel)
+	float* alpha_out = alpha && alpha->out && defer && TY == 8 && g.nzl() == g.Zg && z_begin == 0 && z_end == g.Zg ? alpha->out : nullptr;
+	if (alpha_out) {
+		if (half_store) { if (p2) { FX_ADV(true, 8, true, true, true); FX_FAR(true, true, true); } else { FX_ADV(true, 8, true, false, true); FX_FAR(true, false, true); } }
+		else { if (p2) { FX_ADV(false, 8, true, true, true); FX_FAR(false, true, true); } else { FX_ADV(false, 8, true, false, true); FX_FAR(false, false, true); } }
+		alpha->written = true;
+	} else if (!p2) {
 		if (defer) {
-			if (half_store) { FX_ADV(true, 8, true, false); FX_FAR(true, false); } else { FX_ADV(false, 8, true, false); FX_FAR(false, false); }
-		} else { if (half_store) FX_ADV(true, 8, false, false); else FX_ADV(false, 8, false, false); }
+			if (half_store) { FX_ADV(true, 8, true, false, false); FX_FAR(true, false, false); } else { FX_ADV(false, 8, true, false, false); FX_FAR(false, false, false); }
+		} else { if (half_store) FX_ADV(true, 8, false, false, false); else FX_ADV(false, 8, false, false, false); }
 	} else if (defer) {
-		if (TY == 16) { if (half_store) FX_ADV(true, 16, true, true); else FX_ADV(false, 16, true, true); }
-		else { if (half_store) FX_ADV(true, 8, true, true); else FX_ADV(false, 8, true, true); }
-		if (half_store) FX_FAR(true, true); else FX_FAR(false, true);
+		if (TY == 16) { if (half_store) FX_ADV(true, 16, true, true, false); else FX_ADV(false, 16, true, true, false); }
+		else { if (half_store) FX_ADV(true, 8, true, true, false); else FX_ADV(false, 8, true, true, false); }
+		if (half_store) FX_FAR(true, true, false); else FX_FAR(false, true, false);
 	} else {
-		if (TY == 16) { if (half_store) FX_ADV(true, 16, false, true); else FX_ADV(false, 16, false, true); }
-		else { if (half_store) FX_ADV(true, 8, false, true); else FX_ADV(false, 8, false, true); }
+		if (TY == 16) { if (half_store) FX_ADV(true, 16, false, true, false); else FX_ADV(false, 16, false, true, false); }
+		else { if (half_store) FX_ADV(true, 8, false, true, false); else FX_ADV(false, 8, false, true, false); }
 	}
 #undef FX_FAR
 #undef FX_ADV

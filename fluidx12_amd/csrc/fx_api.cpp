@@ -139,7 +139,12 @@ struct Marches {
 	{
 		if (!accel || built) return hipSuccess;
 		built = true;
-		return launch_accel_build(c->g, c->half, color, c->accel, s);
+		// (the side volume counts as current only when the advection that made this field wrote it: a full build also leaves it current,
+		// but a render loop over a paused field would then time a cheaper build than a frame behind its own step gets -- not worth the ambiguity)
+		const bool current = c->accel_alpha_of == color;
+		if (!current) c->accel_alpha_of = nullptr;                   // the build overwrites the side volume with this field's alpha
+		c->rendered_since_step = true; c->rendered_on = s;
+		return launch_accel_build(c->g, c->half, color, c->accel, s, current);
 	}
 	hipError_t light()                                  // Fluid.cpp:857-878
 	{
@@ -523,6 +528,7 @@ int fx_comm_gather_color(fx_ctx* ctx, void* stream, fx_ctx* full, int root, cons
 		parts[r].bytes = (size_t)nz * plane_bytes;
 		parts[r].src = m ? (const char*)m->col[m->frame_parity] + (size_t)m->g.H * plane_bytes : nullptr;
 		parts[r].dst = am_root ? (char*)full->col[full->frame_parity] + (size_t)z0 * plane_bytes : nullptr;
+		if (am_root) full->accel_alpha_of = nullptr;
 	}
 	DeviceGuard dg(ctx->device);
 	hipStream_t s = pick_stream(ctx, stream);

@@ -367,6 +367,7 @@ int fx_upload(fx_ctx* ctx, int field, const void* host, size_t bytes)
 			else ctx->col_halo_buf = -1;                   // collective load: every rank forgets the early halo, the next step exchanges the colour again
 		}
 		char* dst = (char*)ctx->col[field == FX_FIELD_COLOR ? ctx->frame_parity : 1 - ctx->frame_parity];
+		if (ctx->accel_alpha_of == dst) ctx->accel_alpha_of = nullptr;      // the render's side volume no longer mirrors this buffer
 		if ((rc = ensure_stage(ctx, need))) return rc;
 		FX_HIP(hipMemcpy(ctx->stage, host, need, hipMemcpyHostToDevice));
 		FX_HIP(launch_to_storage(ctx->stage, dst + off * 4 * es, 4 * n, ctx->half, ctx->stream));

@@ -50,6 +50,9 @@ struct fx_ctx {
 	uint32_t env_n;
 	fx::RenderAccel accel = {};     // scratch of the accelerated ray marches (occupancy grid + masks, alpha side volume, light-voxel list), rebuilt per fx_render
 	bool accel_ok = false;          // ... and whether all of it could be allocated
+	const void* accel_alpha_of = nullptr;   // the colour buffer whose alpha the side volume holds already (written by the advection that made the field), or null
+	bool rendered_since_step = false;       // a context that renders its frames has the NEXT advection write the side volume (one more store per voxel); one that only simulates does not pay for it
+	hipStream_t rendered_on = nullptr;      // ... provided that advection runs on the stream the render ran on (the side volume is not double-buffered like the colour)
 	int opt_render_accel = 1;       // FX_OPT_RENDER_ACCEL
 	uint8_t* target;                // W x H RGBA8 render target of the cube resolve (lazily allocated)
 	float* target_float;            // the resolve's SV_TARGET before the output merger (parity tests; lazily allocated)

@@ -46,11 +46,16 @@ struct SimParams {
 
 // ---- simulation launchers (fx_sim.hip); `half_store` selects __half storage of velocity/colour
 // z_begin/z_end: global plane range to compute (within the locally present range)
+// alpha: when the launch writes every voxel of an unsliced grid on the staged path it also writes the stored alpha, as fp32, to `out`
+// (the render's side volume, fx_render_accel.hip) and says so in `written`
+struct AdvectAlpha { float* out; bool written; };
 hipError_t launch_advect(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const void* col_in,
-	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, hipStream_t s, uint32_t* far_scratch = nullptr, size_t far_words = 0, int far_parity = 0, bool* far_used = nullptr);
+	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, hipStream_t s, uint32_t* far_scratch = nullptr, size_t far_words = 0, int far_parity = 0, bool* far_used = nullptr,
+	AdvectAlpha* alpha = nullptr);
 // LDS-staged variant (fx_advect_lds.hip); hipErrorNotSupported when the geometry has no such path (force: also below the size where it pays)
 hipError_t launch_advect_lds(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const void* col_in,
-	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, uint32_t* far_scratch, size_t far_words, int far_parity, bool* far_used, hipStream_t s, bool force);
+	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, uint32_t* far_scratch, size_t far_words, int far_parity, bool* far_used, hipStream_t s, bool force,
+	AdvectAlpha* alpha = nullptr);
 // far_scratch: advect_far_words(g, planes) words lent by the caller (its first two words ZEROED once; far_parity alternates over the launches that report *far_used) let the staged kernel
 // defer far-tracing voxels to a second, small launch
 size_t advect_far_words(const Geom& g, int nzp);
@@ -153,7 +158,8 @@ struct RenderAccel {
 void render_accel_layout(const Geom& g, RenderAccel* a);       // fills the dimensions
 size_t render_accel_bits_words(const RenderAccel& a);
 size_t render_accel_ctr_words(const Geom& g);
-hipError_t launch_accel_build(const Geom& g, int half_store, const void* color, const RenderAccel& a, hipStream_t s);
+// alpha_current: a.alpha holds this colour field's alpha already (AdvectAlpha)
+hipError_t launch_accel_build(const Geom& g, int half_store, const void* color, const RenderAccel& a, hipStream_t s, bool alpha_current = false);
 hipError_t launch_accel_light(const Geom& g, const RenderAccel& a, uint32_t* lightmap, const FrameConsts& fc, const float* sh,
 	uint32_t num_samples, hipStream_t s, unsigned long long* counters = nullptr);
 hipError_t launch_accel_view(const Geom& g, int half_store, const void* color, const uint32_t* lightmap, const FrameConsts& fc, const float* sh,

@@ -69,7 +69,9 @@ static const uint32_t* mask_vis(const RenderAccel& a) { return a.msh ? a.bits + 
 // 1 x 4 x 4 column, four lanes fold into one 4^3 block: no atomics) and writes it to the alpha side volume on the way;
 // k_occupancy_dilate takes the max over the 2 x 2 x 2 blocks c .. c + 1 (a superset of [4c, 4c + 4]: conservative, which only
 // skips less) and stores the two masks of the fine level by wave ballot.
-template <bool HALF>
+// FROM_ALPHA: the side volume holds this colour field's alpha already (the advection that made the field wrote it, fx_advect_lds.hip
+// <ALPHA>): 4 bytes per voxel to read instead of the texel, nothing to write but the block maxima.
+template <bool HALF, bool FROM_ALPHA>
 __global__ __launch_bounds__(256) void k_occupancy_blocks(const Geom g, const typename ColTex<HALF>::T* __restrict__ col, float* __restrict__ blk,
 	float* __restrict__ alpha, uint32_t* __restrict__ cnt)
 {
@@ -81,23 +83,24 @@ __global__ __launch_bounds__(256) void k_occupancy_blocks(const Geom g, const ty
 	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 72) cnt[ctr_cells(g) + blockIdx.z * kCntStride] = 0u;   // ... and the cell lists empty
 	const int x = blockIdx.x * 64 + (threadIdx.x & 63);
 	const int cy = blockIdx.y * 4 + (threadIdx.x >> 6), cz = blockIdx.z;
+	auto fetch = [&](size_t i) -> float { return FROM_ALPHA ? alpha[i] : ColTex<HALF>::ldw(col, i); };
 	float m = 0.0f;
 	if (x < g.X && cy < CY) {
 		if (4 * cz + 4 <= g.Zg && 4 * cy + 4 <= g.Y) {                             // the whole column: 16 independent loads in flight
 			float a[16];
 #pragma unroll
-			for (int k = 0; k < 16; ++k) a[k] = ColTex<HALF>::ldw(col, ((size_t)(4 * cz + (k >> 2)) * g.Y + (4 * cy + (k & 3))) * g.X + x);
+			for (int k = 0; k < 16; ++k) a[k] = fetch(((size_t)(4 * cz + (k >> 2)) * g.Y + (4 * cy + (k & 3))) * g.X + x);
 #pragma unroll
 			for (int k = 0; k < 16; ++k) {
-				alpha[((size_t)(4 * cz + (k >> 2)) * g.Y + (4 * cy + (k & 3))) * g.X + x] = a[k];
+				if (!FROM_ALPHA) alpha[((size_t)(4 * cz + (k >> 2)) * g.Y + (4 * cy + (k & 3))) * g.X + x] = a[k];
 				m = fmaxf(m, a[k]);
 			}
 		} else {
 			for (int z = 4 * cz; z < min(4 * cz + 4, g.Zg); ++z)
 				for (int y = 4 * cy; y < min(4 * cy + 4, g.Y); ++y) {
 					const size_t i = ((size_t)z * g.Y + y) * g.X + x;
-					const float a = ColTex<HALF>::ldw(col, i);
-					alpha[i] = a;
+					const float a = fetch(i);
+					if (!FROM_ALPHA) alpha[i] = a;
 					m = fmaxf(m, a);
 				}
 		}
@@ -105,6 +108,31 @@ __global__ __launch_bounds__(256) void k_occupancy_blocks(const Geom g, const ty
 	m = fmaxf(m, __shfl_xor(m, 1));
 	m = fmaxf(m, __shfl_xor(m, 2));
 	if (x < g.X && cy < CY && (x & 3) == 0) blk[((size_t)cz * CY + cy) * CX + (x >> 2)] = m;
+}
+
+// the same from the side volume for rows of whole quads: a lane folds a whole 4^3 block from 16 float4s
+__global__ __launch_bounds__(256) void k_occupancy_blocks_a4(const Geom g, float* __restrict__ blk, const float* __restrict__ alpha, uint32_t* __restrict__ cnt)
+{
+	const int CX = g.X >> 2, CY = (g.Y + 3) >> 2;
+	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4 && 4 * (int)blockIdx.z + (int)threadIdx.x < g.Zg)
+		cnt[(4 * blockIdx.z + threadIdx.x) * kCntStride] = 0u;
+	if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x >= 64 && threadIdx.x < 72)
+		cnt[ctr_heads(g) + (threadIdx.x - 64) * kCntStride] = 0u;
+	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 72) cnt[ctr_cells(g) + blockIdx.z * kCntStride] = 0u;
+	const int cx = blockIdx.x * 64 + (threadIdx.x & 63);
+	const int cy = blockIdx.y * 4 + (threadIdx.x >> 6), cz = blockIdx.z;
+	if (cx >= CX || cy >= CY) return;
+	const int ny = min(4, g.Y - 4 * cy), nz = min(4, g.Zg - 4 * cz);
+	float4 a[16];
+#pragma unroll
+	for (int k = 0; k < 16; ++k) {
+		const int dz = min(k >> 2, nz - 1), dy = min(k & 3, ny - 1);             // (short blocks at the far faces fold a voxel twice)
+		a[k] = *reinterpret_cast<const float4*>(alpha + ((size_t)(4 * cz + dz) * g.Y + (4 * cy + dy)) * g.X + 4 * cx);
+	}
+	float m = 0.0f;
+#pragma unroll
+	for (int k = 0; k < 16; ++k) m = fmaxf(m, fmaxf(fmaxf(a[k].x, a[k].y), fmaxf(a[k].z, a[k].w)));
+	blk[((size_t)cz * CY + cy) * CX + cx] = m;
 }
 
 __global__ __launch_bounds__(256) void k_occupancy_dilate(int CX, int CY, int CZ, const float* __restrict__ blk, float* __restrict__ occ,
@@ -152,13 +180,15 @@ __global__ __launch_bounds__(256) void k_mask_coarsen(int CX, int CY, int CZ, in
 	if ((threadIdx.x & 63) == 0 && (uint32_t)(c >> 6) < words64) { pos64[c >> 6] = bp; vis64[c >> 6] = bv; }
 }
 
-hipError_t launch_accel_build(const Geom& g, int half_store, const void* color, const RenderAccel& a, hipStream_t s)
+hipError_t launch_accel_build(const Geom& g, int half_store, const void* color, const RenderAccel& a, hipStream_t s, bool alpha_current)
 {
 	const int n = a.CX * a.CY * a.CZ;
 	float* blk = a.occ + n;
 	const dim3 grid((g.X + 63) / 64, (a.CY + 3) / 4, a.CZ), block(256);
-	if (half_store) hipLaunchKernelGGL(k_occupancy_blocks<true>, grid, block, 0, s, g, (const h16x4*)color, blk, a.alpha, a.ctr);
-	else hipLaunchKernelGGL(k_occupancy_blocks<false>, grid, block, 0, s, g, (const float4*)color, blk, a.alpha, a.ctr);
+	if (alpha_current && (g.X & 3) == 0) hipLaunchKernelGGL(k_occupancy_blocks_a4, dim3((a.CX + 63) / 64, (a.CY + 3) / 4, a.CZ), block, 0, s, g, blk, a.alpha, a.ctr);
+	else if (alpha_current) hipLaunchKernelGGL((k_occupancy_blocks<false, true>), grid, block, 0, s, g, (const float4*)color, blk, a.alpha, a.ctr);
+	else if (half_store) hipLaunchKernelGGL((k_occupancy_blocks<true, false>), grid, block, 0, s, g, (const h16x4*)color, blk, a.alpha, a.ctr);
+	else hipLaunchKernelGGL((k_occupancy_blocks<false, false>), grid, block, 0, s, g, (const float4*)color, blk, a.alpha, a.ctr);
 	hipLaunchKernelGGL(k_occupancy_dilate, dim3((n + 255) / 256), dim3(256), 0, s, a.CX, a.CY, a.CZ, blk, a.occ,
 		reinterpret_cast<unsigned long long*>(a.bits), reinterpret_cast<unsigned long long*>(a.bits + a.fine_words), a.fine_words / 2);
 	if (a.msh) {

@@ -125,8 +125,15 @@ int advect_range(fx_ctx* ctx, hipStream_t s, Range r, bool own_only)
 	}
 	const bool lend = ctx->adv_far != nullptr;
 	bool far_used = false;
+	// the render's alpha-only side volume (fx_render_accel.hip) is written by the launch that makes the colour field, where that is one
+	// staged launch over the whole grid: the render's build pass then reads 4 bytes per voxel instead of the whole texel
+	const bool frame_was_rendered = ctx->rendered_since_step && ctx->rendered_on == s;
+	ctx->rendered_since_step = false;
+	AdvectAlpha aa{ frame_was_rendered && ctx->accel_ok && ctx->opt_render_accel && FX_KNOB_INT("ADVECT_ALPHA", 1) ? ctx->accel.alpha : nullptr, false };
+	if (ctx->accel_alpha_of == ctx->col[par]) ctx->accel_alpha_of = nullptr;          // that buffer is about to change
 	FX_HIP(launch_advect(g, sp, ctx->half, ctx->vel[0], ctx->col[1 - par], ctx->vel[1], ctx->col[par],
-		r.lo, r.hi, ctx->halo_overflow, s, lend ? ctx->adv_far : nullptr, lend ? ctx->adv_far_words : 0, (int)(ctx->adv_far_turn & 1u), &far_used));
+		r.lo, r.hi, ctx->halo_overflow, s, lend ? ctx->adv_far : nullptr, lend ? ctx->adv_far_words : 0, (int)(ctx->adv_far_turn & 1u), &far_used, &aa));
+	if (aa.written) ctx->accel_alpha_of = ctx->col[par];
 	if (far_used) ++ctx->adv_far_turn;
 	return FX_OK;
 }

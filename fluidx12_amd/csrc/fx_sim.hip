@@ -867,9 +867,11 @@ static int xcd_remap_for(int which, const Geom& g)
 }
 
 hipError_t launch_advect(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const void* col_in,
-	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, hipStream_t s, uint32_t* far_scratch, size_t far_words, int far_parity, bool* far_used)
+	void* vel_out, void* col_out, int z_begin, int z_end, unsigned* halo_overflow, hipStream_t s, uint32_t* far_scratch, size_t far_words, int far_parity, bool* far_used,
+	AdvectAlpha* alpha)
 {
 	if (far_used) *far_used = false;
+	if (alpha) alpha->written = false;
 	if (z_end <= z_begin) return hipSuccess;
 	// workgroup shape: FLUIDX_ADVECT_BLOCK="bx,by,bz" overrides (measurement knob)
 	int bx = 64, by = 4, bz = 1;
@@ -883,7 +885,7 @@ hipError_t launch_advect(const Geom& g, const SimParams& sp, int half_store, con
 	{
 		const char* le = FX_KNOB("ADVECT_LDS");
 		if (!(le && le[0] == '0') && bx == 64 && by == 4 && bz == 1 && !xcd_remap_on(REMAP_ADVECT)) {
-			const hipError_t e = launch_advect_lds(g, sp, half_store, vel_in, col_in, vel_out, col_out, z_begin, z_end, halo_overflow, far_scratch, far_words, far_parity, far_used, s, le && le[0] == '2');
+			const hipError_t e = launch_advect_lds(g, sp, half_store, vel_in, col_in, vel_out, col_out, z_begin, z_end, halo_overflow, far_scratch, far_words, far_parity, far_used, s, le && le[0] == '2', alpha);
 			if (e != hipErrorNotSupported) return e;
 		}
 	}

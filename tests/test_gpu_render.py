@@ -487,3 +487,48 @@ def test_render_at_coarser_cube_mip_against_oracle():
     f, col, fr, lod, rs, mask = developed_plume(X, 60, "fp32", vp, camera=cam)
     assert lod >= 1 and mask != 0x1B
     check_render_against_oracle(f, col, fr, X, lod, rs, mask, False)
+
+
+@pytest.mark.parametrize("dims,storage", [((64, 64, 64), "fp32"), ((64, 64, 64), "fp16"), ((72, 72, 40), "fp32"), ((128, 128, 32), "fp16")])
+def test_alpha_side_volume_written_by_the_advection_changes_no_bit(dims, storage, knob):
+    """the staged advection writes the stored alpha, as fp32, into the render's side volume (k_advect_lds / k_advect_far <ALPHA>) and the
+    render's build pass then folds the block maxima from those 4 bytes per voxel instead of reading the texels: same light map, cube
+    map and direct picture as with the side volume extracted by the build pass (ADVECT_ALPHA=0) and as the plain kernels; an upload
+    over the colour field takes the mirror away"""
+    knob("ADVECT_LDS", "2")                                           # the staged path below the size where it pays
+    vp = (320, 240)
+    view, proj, eye = fx.default_camera(*vp)
+
+    def run(alpha, accel=1):
+        knob("ADVECT_ALPHA", "1" if alpha else "0")
+        f = fx.Fluid()
+        assert f.Init(vp[0], vp[1], dims, storage=storage)
+        f.SetMaxSamples(96, 32)
+        f.set_option(capi.OPT_RENDER_ACCEL, accel)
+        out = []
+        for k in range(14):
+            f.UpdateFrame(f32(f.default_time_step()), k % 3, view, proj, eye)
+            f.Simulate(k % 3)
+            if k in (6, 7, 12, 13):                                   # the step behind a rendered frame is the one that writes the side volume
+                f.Render(k % 3, fx.Fluid.OPTIMIZED)
+                f.Synchronize()
+                if k in (7, 13):
+                    out += [f.download(fx.FIELD_LIGHTMAP), f.download(fx.FIELD_CUBEMAP)]
+        f.ClearRenderTarget()
+        f.Render(0, fx.Fluid.RAY_MARCH_DIRECT)
+        f.Synchronize()
+        out.append(f.download(fx.FIELD_TARGET_FLOAT))
+        # another colour field over the current one: the side volume must be rebuilt from it
+        col = f.download(fx.FIELD_COLOR)
+        col2 = np.ascontiguousarray(col[::-1, :, ::-1])
+        f.upload(fx.FIELD_COLOR, col2)
+        f.Render(0, fx.Fluid.OPTIMIZED)
+        f.Synchronize()
+        out += [f.download(fx.FIELD_LIGHTMAP), f.download(fx.FIELD_CUBEMAP), f.download(fx.FIELD_VELOCITY), col]
+        return out
+
+    a, b, c = run(True), run(False), run(True, accel=0)
+    assert a[1][..., 3].max() > 20 and a[3][..., 3].max() > 20
+    for u, v, w in zip(a, b, c):
+        assert np.array_equal(u.view(np.uint8), v.view(np.uint8))
+        assert np.array_equal(u.view(np.uint8), w.view(np.uint8))

@@ -34,12 +34,17 @@ def kernels(lines, prefix):
     return out
 
 
-def test_advect_lds_hands_over_behind_exactly_four_stores(tmp_path):
+def test_advect_lds_hands_over_behind_exactly_its_stores(tmp_path):
     ks = kernels(device_isa("fx_advect_lds.hip", tmp_path), "k_advect_lds")
     assert len(ks) >= 8                                         # <HALF> x <tile rows> x <DEFER>
     for name, body in ks.items():
-        waits = [i for i, ln in enumerate(body) if ln.startswith("s_waitcnt vmcnt(4)") and body[i - 1].startswith(";;#ASMSTART")]   # the hand-written ones
+        # <HALF, TY, DEFER, P2, ALPHA>: with ALPHA a fifth store (the render's alpha side volume) sits behind the fill and the wait says vmcnt(5)
+        m = re.search(r"k_advect_ldsILb[01]ELi\d+ELb([01])ELb[01]ELb([01])E", name)
+        assert m, name
+        deferring, n_st = m.group(1) == "1", 5 if m.group(2) == "1" else 4
+        waits = [i for i, ln in enumerate(body) if ln.startswith("s_waitcnt vmcnt(%d)" % n_st) and body[i - 1].startswith(";;#ASMSTART")]   # the hand-written ones
         assert waits, name
+        assert not [i for i, ln in enumerate(body) if ln.startswith("s_waitcnt vmcnt(%d)" % (9 - n_st)) and body[i - 1].startswith(";;#ASMSTART")], name
         for w in waits:
             stores = 0
             for ln in reversed(body[:w]):
@@ -50,8 +55,7 @@ def test_advect_lds_hands_over_behind_exactly_four_stores(tmp_path):
             # DEFER kernels note a far-tracing voxel with one more (older, lane-masked) store somewhere in front of the four (the compiler
             # rotates the loop, so it may sit behind the loop head): the wait then also covers that store -- never fewer operations
             # than the LDS-DMA loads
-            deferring = re.search(r"k_advect_ldsILb[01]ELi\d+ELb1E", name) is not None
-            assert stores in ((4, 5) if deferring else (4,)), (name, w, stores)
+            assert stores in ((n_st, n_st + 1) if deferring else (n_st,)), (name, w, stores)
         # the LDS-DMA statements change SCC (s_add_u32 m0): they must say so
         assert any("global_load_lds" in ln for ln in body)
     src = open(os.path.join(b.CSRC, "fx_advect_lds.hip")).read()
