@@ -193,6 +193,8 @@ int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags)
 	if (!ctx->desc.viewport_w || !ctx->desc.viewport_h) return FX_E_INVALID;   // created without a viewport: nothing to project the cube onto
 	if (!ctx->view_valid) return FX_E_STATE;
 	if (ctx->g.nz != ctx->g.Zg) return FX_E_INVALID;            // rays cross slabs: multi-GPU rendering is row f-3
+	// (tap indices are 32 bits wide and put together by 24-bit multiplies, fx_march.h make_taps)
+	if ((uint64_t)ctx->g.Y * ((uint64_t)ctx->g.Zg + 1) >= (1u << 24) || ctx->g.cells_owned() >= ((size_t)1 << 32)) return FX_E_INVALID;
 	unsigned long long* cnt = ctx->opt_count_samples ? ctx->sample_counters : nullptr;
 	if (cnt && (flags & FX_SEPARATE_LIGHT_PASS)) ctx->acc.light_samples += (uint64_t)ctx->g.cells_owned();   // the light pass's own fetch per voxel
 	DeviceGuard dg(ctx->device);

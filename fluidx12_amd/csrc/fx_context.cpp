@@ -225,7 +225,9 @@ int fx_create(fx_ctx** out, const fx_desc* d)
 			}
 			FX_HIP(hipMalloc((void**)&ctx->cube, off));
 			FX_HIP(hipMemsetAsync(ctx->cube, 0, off, ctx->stream));
-			if (!slab) {                                                         // rays cross slabs: only whole grids render
+			// rays cross slabs: only whole grids render.  The accelerated marches address their volumes by 32-bit byte offsets (16-byte texels:
+			// 2^28 voxels, 645^3); larger grids keep the plain kernels
+			if (!slab && ctx->g.cells_owned() <= ((size_t)1 << 28)) {
 				RenderAccel& A = ctx->accel;
 				render_accel_layout(ctx->g, &A);
 				const size_t ncell = (size_t)A.CX * A.CY * A.CZ, vox = ctx->g.cells_owned(), bw = render_accel_bits_words(A);

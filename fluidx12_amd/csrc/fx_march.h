@@ -105,17 +105,39 @@ __device__ __forceinline__ Base make_base(const Geom& g, float u, float v, float
 	return b;
 }
 
+// Voxel indices of the eight taps.  Index arithmetic is most of what a sample costs besides its loads, so: 24-bit multiplies (full rate;
+// v_mul_lo_u32 / v_mad_u64_u32 issue at a quarter of it) -- fx_render refuses grids with Y (Z + 1) >= 2^24 -- and the clamped "+ 1"
+// neighbours as a conditional stride: clamp(i + 1) differs from clamp(i) exactly where 0 <= i < N - 1, one unsigned compare.
+// (inline assembly: where the compiler can bound the operands it turns __umul24(a, b) + c back into a plain multiply-add and selects
+// v_mad_u64_u32 for it)
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)
+{
+	uint32_t r;
+	asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+}
+
 __device__ __forceinline__ Taps make_taps(const Geom& g, const Base& b)
 {
 	Taps t;
 	t.fx = b.fx; t.fy = b.fy; t.fz = b.fz;
-	const int x1 = min(max(b.ix + 1, 0), g.X - 1), y1 = min(max(b.iy + 1, 0), g.Y - 1), z1 = min(max(b.iz + 1, 0), g.Zg - 1);
 	const uint32_t X = (uint32_t)g.X, XY = (uint32_t)g.X * (uint32_t)g.Y;
-	const uint32_t r00 = (uint32_t)b.z0 * XY + (uint32_t)b.y0 * X, r01 = (uint32_t)b.z0 * XY + (uint32_t)y1 * X;
-	const uint32_t r10 = (uint32_t)z1 * XY + (uint32_t)b.y0 * X, r11 = (uint32_t)z1 * XY + (uint32_t)y1 * X;
-	t.i[0] = r00 + b.x0; t.i[1] = r00 + x1; t.i[2] = r01 + b.x0; t.i[3] = r01 + x1;
-	t.i[4] = r10 + b.x0; t.i[5] = r10 + x1; t.i[6] = r11 + b.x0; t.i[7] = r11 + x1;
+	const uint32_t dx = (uint32_t)b.ix < (uint32_t)(g.X - 1) ? 1u : 0u;
+	const uint32_t dy = (uint32_t)b.iy < (uint32_t)(g.Y - 1) ? X : 0u;
+	const uint32_t dz = (uint32_t)b.iz < (uint32_t)(g.Zg - 1) ? XY : 0u;
+	t.i[0] = mad24(mad24((uint32_t)b.z0, (uint32_t)g.Y, (uint32_t)b.y0), X, (uint32_t)b.x0);
+	t.i[1] = t.i[0] + dx; t.i[2] = t.i[0] + dy; t.i[3] = t.i[2] + dx;
+	t.i[4] = t.i[0] + dz; t.i[5] = t.i[4] + dx; t.i[6] = t.i[2] + dz; t.i[7] = t.i[6] + dx;
 	return t;
+}
+
+// a load at a 32-bit byte offset from a uniform base: `global_load v, v_offset, s[base:base+1]` -- no 64-bit address to put together per
+// tap (a v_mov for the high half and a v_lshl_add_u64 each).  For volumes below 4 GiB: the accelerated path's (fx_create gives a grid
+// its scratch only up to 2^28 voxels)
+template <typename T>
+__device__ __forceinline__ T ld_off32(const void* base, uint32_t byte_off)
+{
+	return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off);
 }
 
 __device__ __forceinline__ float blend8(const float q[8], const Taps& t)
@@ -169,6 +191,7 @@ template <bool HALF> struct PlainVol {
 #pragma unroll
 		for (int k = 0; k < 8; ++k) c[k] = ColTex<HALF>::ld(col, t.i[k]);
 	}
+	__device__ __forceinline__ void light_taps(const uint32_t* __restrict__ lm, const Taps& t, uint32_t raw[8]) const { fx::light_taps(lm, t, raw); }
 	__device__ __forceinline__ float density(const Taps& t) const { float q[8]; density_taps(t, q); return blend8(q, t); }
 	__device__ __forceinline__ float4 color(const Taps& t) const { float4 c[8]; color_taps(t, c); return blend8x4(c, t); }
 };
@@ -186,9 +209,9 @@ template <bool HALF, bool COARSE> struct AccelVol {
 	int msh, MX, MY, CX, CY;
 	__device__ __forceinline__ uint32_t mcell(const Base& b) const
 	{
-		return (uint32_t)(((b.z0 >> (2 + msh)) * MY + (b.y0 >> (2 + msh))) * MX + (b.x0 >> (2 + msh)));
+		return mad24(mad24((uint32_t)b.z0 >> (2 + msh), (uint32_t)MY, (uint32_t)b.y0 >> (2 + msh)), (uint32_t)MX, (uint32_t)b.x0 >> (2 + msh));
 	}
-	__device__ __forceinline__ uint32_t fcell(const Base& b) const { return (uint32_t)(((b.z0 >> 2) * CY + (b.y0 >> 2)) * CX + (b.x0 >> 2)); }
+	__device__ __forceinline__ uint32_t fcell(const Base& b) const { return mad24(mad24((uint32_t)b.z0 >> 2, (uint32_t)CY, (uint32_t)b.y0 >> 2), (uint32_t)CX, (uint32_t)b.x0 >> 2); }
 	__device__ __forceinline__ bool dense(const Base& b) const
 	{
 		const uint32_t c = mcell(b);
@@ -206,12 +229,20 @@ template <bool HALF, bool COARSE> struct AccelVol {
 	__device__ __forceinline__ void density_taps(const Taps& t, float q[8]) const
 	{
 #pragma unroll
-		for (int k = 0; k < 8; ++k) q[k] = alpha[t.i[k]];
+		for (int k = 0; k < 8; ++k) q[k] = ld_off32<float>(alpha, t.i[k] << 2);
 	}
 	__device__ __forceinline__ void color_taps(const Taps& t, float4 c[8]) const
 	{
 #pragma unroll
-		for (int k = 0; k < 8; ++k) c[k] = ColTex<HALF>::ld(col, t.i[k]);
+		for (int k = 0; k < 8; ++k) {
+			if (HALF) { const h16x4 h = ld_off32<h16x4>(col, t.i[k] << 3); c[k] = make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w); }
+			else c[k] = ld_off32<float4>(col, t.i[k] << 4);
+		}
+	}
+	__device__ __forceinline__ void light_taps(const uint32_t* __restrict__ lm, const Taps& t, uint32_t raw[8]) const
+	{
+#pragma unroll
+		for (int k = 0; k < 8; ++k) raw[k] = ld_off32<uint32_t>(lm, t.i[k] << 2);
 	}
 	__device__ __forceinline__ float density(const Taps& t) const { float q[8]; density_taps(t, q); return blend8(q, t); }
 	__device__ __forceinline__ float4 color(const Taps& t) const { float4 c[8]; color_taps(t, c); return blend8x4(c, t); }
@@ -222,7 +253,9 @@ __device__ __forceinline__ bool outside(float x, float y, float z) { return fabs
 // GetStep (RayMarch.hlsli:200-210) as compiled
 __device__ __forceinline__ float step_factor(float dDensity, float transm, float density)
 {
-	const float ev = fminf(0.00390625f / fabsf(dDensity), 2.0f);
+	// (a wave marching through empty space -- every lane's density difference 0 -- skips the division: 0.0039 / 0 = +inf, min(inf, 2) = 2)
+	float ev = 2.0f;
+	if (__builtin_amdgcn_ballot_w64(dDensity != 0.0f) != 0) ev = fminf(0.00390625f / fabsf(dDensity), 2.0f);
 	const float ui = fminf(-density + 1.0f, 1.0f);
 	const float th = -transm + 1.0f;
 	return fmaxf(th * (ui * (ev * 1.5f)), 1.0f);
@@ -501,7 +534,7 @@ __device__ __forceinline__ void march_ray(const Geom& g, const V& vol, const uin
 			for (int k = 0; k < K; ++k)
 				if (kind[k] == 2) {
 					vol.color_taps(tp[k], c8[k]);                                  // :157
-					if (SEPARATE) light_taps(lightmap, tp[k], l8[k]);              // RayMarch.hlsli:253-258 (used only behind :161)
+					if (SEPARATE) vol.light_taps(lightmap, tp[k], l8[k]);              // RayMarch.hlsli:253-258 (used only behind :161)
 				}
 			float newStep = stepScale;
 			bool cont = true;

@@ -32,7 +32,7 @@ static const uint32_t kMaskBudgetBits = FX_MASK_BUDGET_BITS;
 #endif
 static const int kViewAhead = FX_VIEW_AHEAD, kLightAhead = FX_LIGHT_AHEAD;
 #ifndef FX_LIGHT_RAY_WGS
-#define FX_LIGHT_RAY_WGS 2048
+#define FX_LIGHT_RAY_WGS 1024
 #endif
 static const size_t kLightRayWorkgroups = FX_LIGHT_RAY_WGS;   // persistent workgroups of the refilling shadow-ray march
 // RenderAccel::ctr, one 128-byte line per counter: [Zg] lengths of the per-plane lists of lit voxels, [8] work heads of the view march,
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void k_light_march(const Geom g, const float* 
 enum { RAYS_SHADOW = 0, RAYS_SHADOW_KEEP = 1, RAYS_AO = 2 };
 
 template <bool COARSE, int MODE>
-__global__ __launch_bounds__(256) void k_light_rays(const Geom g, const float* __restrict__ alpha, const float* __restrict__ occ,
+__global__ __launch_bounds__(1024) void k_light_rays(const Geom g, const float* __restrict__ alpha, const float* __restrict__ occ,
 	const uint32_t* __restrict__ pos_mask, uint32_t mask_words, int msh, int MX, int MY, int CX, int CY,
 	const uint32_t* __restrict__ list, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ lightmap, const FrameConsts fc,
 	const float* __restrict__ gi, const float* __restrict__ sh, uint32_t numSamples, unsigned long long* __restrict__ counters)
@@ -411,7 +411,8 @@ __global__ __launch_bounds__(256) void k_light_rays(const Geom g, const float* _
 	const uint32_t Z = (uint32_t)g.Zg;
 	scan_counters(pre, cnt, Z, 0);
 	const uint32_t N = pre[Z];
-	if (blockIdx.x * 256u >= N) return;                                            // (uniform) more waves than blocks
+	const uint32_t wpg = blockDim.x >> 6;                                           // waves per workgroup (they share one copy of the mask)
+	if (blockIdx.x * blockDim.x >= N) return;                                      // (uniform) more waves than blocks
 	fill_lds(lds, pos_mask, mask_words);
 	__syncthreads();
 	const AccelVol<false, COARSE> vol{ nullptr, alpha, occ, lds, lds, msh, MX, MY, CX, CY };
@@ -420,8 +421,8 @@ __global__ __launch_bounds__(256) void k_light_rays(const Geom g, const float* _
 	light_dir_local(fc, lx, ly, lz);
 	float rx = 0.0f, ry = 0.0f, rz = 0.0f;                                         // RAYS_AO: the direction before it was normalised
 	const uint32_t XY = (uint32_t)g.X * (uint32_t)g.Y;
-	const uint32_t W = gridDim.x * 4u;
-	uint32_t cur = blockIdx.x * 4u + (threadIdx.x >> 6);                           // the block being handed out, entries [64 cur + pos, 64 cur + pos + avail)
+	const uint32_t W = gridDim.x * wpg;
+	uint32_t cur = blockIdx.x * wpg + (threadIdx.x >> 6);                          // the block being handed out, entries [64 cur + pos, 64 cur + pos + avail)
 	uint32_t pos = 0, avail = 64u * cur < N ? min(64u, N - 64u * cur) : 0u;
 	bool live = false, pending = false;
 	uint32_t id = 0, i = 0, ns = 0;
@@ -509,10 +510,24 @@ __global__ __launch_bounds__(256) void k_light_gi_dirs(const Geom g, const float
 		const float oz = fmaf(((float)z + 0.5f) / (float)g.Zg, 2.0f, -1.0f);
 		const float u = fmaf(ox, 0.5f, 0.5f), v = fmaf(oy, 0.5f, 0.5f), w = fmaf(oz, 0.5f, 0.5f);
 		ns += 6;
-		// (the voxel is lit: its neighbourhood is smoke, so all 48 taps go out at once instead of asking the masks first -- same values)
-		const float qxm = vol.density(make_taps(g, make_base(g, u, v, w, -1, 0, 0))), qxp = vol.density(make_taps(g, make_base(g, u, v, w, 1, 0, 0)));
-		const float qym = vol.density(make_taps(g, make_base(g, u, v, w, 0, -1, 0))), qyp = vol.density(make_taps(g, make_base(g, u, v, w, 0, 1, 0)));
-		const float qzm = vol.density(make_taps(g, make_base(g, u, v, w, 0, 0, -1))), qzp = vol.density(make_taps(g, make_base(g, u, v, w, 0, 0, 1)));
+		float qxm, qxp, qym, qyp, qzm, qzp;
+		const Base c = make_base(g, u, v, w);
+		if (__builtin_amdgcn_ballot_w64(c.fx != 0.0f || c.fy != 0.0f || c.fz != 0.0f) == 0) {
+			// The six samples sit at the voxel's own centre, shifted by whole texels: where the centre's texel coordinate comes out exact
+			// (extents that are powers of two: (x + 0.5) / X * X - 0.5 = x) all three filter weights are 0 and every lerp returns its first
+			// operand, fma(0, b - a, a) = a for the finite alphas of a saturated field -- the sample IS its base tap: 6 loads, not 48.
+			const uint32_t X = (uint32_t)g.X, XY = X * (uint32_t)g.Y;
+			auto tap = [&](int ox_, int oy_, int oz_) -> float {
+				const int x0 = min(max(c.ix + ox_, 0), g.X - 1), y0 = min(max(c.iy + oy_, 0), g.Y - 1), z0 = min(max(c.iz + oz_, 0), g.Zg - 1);
+				return alpha[(uint32_t)z0 * XY + (uint32_t)y0 * X + (uint32_t)x0];
+			};
+			qxm = tap(-1, 0, 0); qxp = tap(1, 0, 0); qym = tap(0, -1, 0); qyp = tap(0, 1, 0); qzm = tap(0, 0, -1); qzp = tap(0, 0, 1);
+		} else {
+			// (the voxel is lit: its neighbourhood is smoke, so all 48 taps go out at once instead of asking the masks first -- same values)
+			qxm = vol.density(make_taps(g, make_base(g, u, v, w, -1, 0, 0))); qxp = vol.density(make_taps(g, make_base(g, u, v, w, 1, 0, 0)));
+			qym = vol.density(make_taps(g, make_base(g, u, v, w, 0, -1, 0))); qyp = vol.density(make_taps(g, make_base(g, u, v, w, 0, 1, 0)));
+			qzm = vol.density(make_taps(g, make_base(g, u, v, w, 0, 0, -1))); qzp = vol.density(make_taps(g, make_base(g, u, v, w, 0, 0, 1)));
+		}
 		const float gx = -qxm + qxp, gy = -qym + qyp, gz = -qzm + qzp;
 		const bool any = fabsf(gx) > 0.0f || fabsf(gy) > 0.0f || fabsf(gz) > 0.0f;
 		gi[3 * (size_t)flat] = any ? -gx : ox; gi[3 * (size_t)flat + 1] = any ? -gy : oy; gi[3 * (size_t)flat + 2] = any ? -gz : oz;
@@ -530,8 +545,11 @@ hipError_t launch_accel_light(const Geom& g, const RenderAccel& a, uint32_t* lig
 		a.cells, a.list, a.ctr, lightmap, fc, sh ? 1 : 0);
 	const size_t cells = (size_t)g.X * g.Y * g.Zg;
 	const size_t lds = (size_t)a.mask_words * 4 + ((size_t)g.Zg + 1) * 4;
-	const unsigned wgs = (unsigned)std::min<size_t>((cells + 255) / 256, kLightRayWorkgroups);
-#define FX_RAYS(C, M) hipLaunchKernelGGL((k_light_rays<C, M>), dim3(wgs), dim3(256), lds, s, g, a.alpha, a.occ, mask_pos(a), a.mask_words, a.msh, a.MX, a.MY, a.CX, a.CY, \
+	// (workgroups of 8 waves around one copy of the mask: 8 instead of 5 waves per SIMD fit beside it.  256^3 frame 132, light pass by
+	// threads x workgroups: 256 x 2048 0.118, 512 x 1024 0.113, 1024 x 512 0.118 ms)
+	const int ray_nt = FX_KNOB_INT("LIGHT_RAY_NT", 512);
+	const unsigned wgs = (unsigned)std::min<size_t>((cells + ray_nt - 1) / ray_nt, (size_t)FX_KNOB_INT("LIGHT_RAY_WGS", (int)kLightRayWorkgroups));
+#define FX_RAYS(C, M) hipLaunchKernelGGL((k_light_rays<C, M>), dim3(wgs), dim3(ray_nt), lds, s, g, a.alpha, a.occ, mask_pos(a), a.mask_words, a.msh, a.MX, a.MY, a.CX, a.CY, \
 	a.list, a.ctr, lightmap, fc, a.gi, sh, num_samples, counters)
 	if (!sh) {
 		if (a.msh) FX_RAYS(true, RAYS_SHADOW); else FX_RAYS(false, RAYS_SHADOW);
@@ -705,7 +723,7 @@ __global__ __launch_bounds__(256) void k_view_slots(const Geom g, const typename
 					float4 c8[8];
 					uint32_t l8[8];
 					vol.color_taps(tp, c8);                                        // :157
-					light_taps(lightmap, tp, l8);                                  // RayMarch.hlsli:253-258 (used only behind :161)
+					vol.light_taps(lightmap, tp, l8);                                  // RayMarch.hlsli:253-258 (used only behind :161)
 					const float4 c = blend8x4(c8, tp);
 					cw = c.w;
 					if (0.00999999978f < c.w) {                                    // :161
