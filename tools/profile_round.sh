@@ -12,19 +12,7 @@ TAG=${1:-r06}
 cd "${GRAFT_REPO_ROOT:-.}" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O
-python bench.py > $O/bench.json 2> $O/bench.err
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_steps20_warmup5.json 2>> $O/bench.err
-python bench.py --config 2 --steps 100 --warmup 16 --no-cpu-baseline > $O/bench_128.json 2>> $O/bench.err
-python bench.py --config 4 --steps 10 --warmup 3 --no-cpu-baseline --no-render > $O/bench_512_80.json 2>> $O/bench.err
-python bench.py --config 5 --no-cpu-baseline > $O/bench_fp16.json 2>> $O/bench.err
-python bench.py --grid 150 --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_150.json 2>> $O/bench.err
-python bench.py --reference-config > $O/bench_reference.json 2>> $O/bench.err
-python bench.py --reference-config --grid 128 --no-cpu-baseline > $O/bench_reference_128.json 2>> $O/bench.err
-python bench.py --reference-config --grid 150 --no-cpu-baseline > $O/bench_reference_150.json 2>> $O/bench.err
-for g in shared peer; do
-  for n in 2 4; do python bench.py --loopback $n --group $g --steps 25 --warmup 5 --no-cpu-baseline --no-render --no-developed > $O/bench_loopback${n}_$g.json 2>> $O/bench.err; done
-  python bench.py --config 4 --loopback 8 --group $g --steps 6 --warmup 2 --no-cpu-baseline --no-render --no-developed > $O/bench_loopback8_config4_$g.json 2>> $O/bench.err
-done
+rm -f profiles/${TAG}_pmc_traffic_*.json profiles/${TAG}_sq_counters_*.json profiles/${TAG}_render_pmc_*.json
 prof() {  # tag, summary args, bench args...
   tag=$1; sargs=$2; shift 2
   B="python3 bench.py --no-cpu-baseline --no-render --no-developed $*"
@@ -55,6 +43,23 @@ render() {  # tag, summary args, bench args...
 }
 render config3 "--grid 256 --storage fp32" --config 3
 render config5 "--grid 256 --storage fp16 --has-sh" --config 5
+# the counter summaries become the committed ones of this round BEFORE the bench lines run: bench.py quotes `roofline.traffic` and the
+# render cache figures from profiles/ (on the box: in the snapshot; copy the same files into profiles/ at home)
+mkdir -p profiles
+for f in $O/pmc_traffic_*.json $O/sq_counters_*.json $O/render_pmc_*.json; do cp $f profiles/${TAG}_$(basename $f); done
+python bench.py > $O/bench.json 2> $O/bench.err
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_steps20_warmup5.json 2>> $O/bench.err
+python bench.py --config 2 --steps 100 --warmup 16 --no-cpu-baseline > $O/bench_128.json 2>> $O/bench.err
+python bench.py --config 4 --steps 10 --warmup 3 --no-cpu-baseline --no-render > $O/bench_512_80.json 2>> $O/bench.err
+python bench.py --config 5 --no-cpu-baseline > $O/bench_fp16.json 2>> $O/bench.err
+python bench.py --grid 150 --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_150.json 2>> $O/bench.err
+python bench.py --reference-config > $O/bench_reference.json 2>> $O/bench.err
+python bench.py --reference-config --grid 128 --no-cpu-baseline > $O/bench_reference_128.json 2>> $O/bench.err
+python bench.py --reference-config --grid 150 --no-cpu-baseline > $O/bench_reference_150.json 2>> $O/bench.err
+for g in shared peer; do
+  for n in 2 4; do python bench.py --loopback $n --group $g --steps 25 --warmup 5 --no-cpu-baseline --no-render --no-developed > $O/bench_loopback${n}_$g.json 2>> $O/bench.err; done
+  python bench.py --config 4 --loopback 8 --group $g --steps 6 --warmup 2 --no-cpu-baseline --no-render --no-developed > $O/bench_loopback8_config4_$g.json 2>> $O/bench.err
+done
 python - "$O" <<'PY'
 import json, glob, sys
 for f in sorted(glob.glob(sys.argv[1] + '/bench*.json')):
