@@ -227,7 +227,7 @@ int fx_create(fx_ctx** out, const fx_desc* d)
 			FX_HIP(hipMemsetAsync(ctx->cube, 0, off, ctx->stream));
 			// rays cross slabs: only whole grids render.  The accelerated marches address their volumes by 32-bit byte offsets (16-byte texels:
 			// 2^28 voxels, 645^3); larger grids keep the plain kernels
-			if (!slab && ctx->g.cells_owned() <= ((size_t)1 << 28)) {
+			if (!slab && ctx->g.cells_owned() <= ((size_t)1 << 28) && ctx->g.X >= 4) {        // (rows of >= 2 voxels: the x taps travel in pairs)
 				RenderAccel& A = ctx->accel;
 				render_accel_layout(ctx->g, &A);
 				const size_t ncell = (size_t)A.CX * A.CY * A.CZ, vox = ctx->g.cells_owned(), bw = render_accel_bits_words(A);

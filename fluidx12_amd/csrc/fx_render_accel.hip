@@ -31,6 +31,9 @@ static const uint32_t kMaskBudgetBits = FX_MASK_BUDGET_BITS;
 #define FX_LIGHT_AHEAD 2
 #endif
 static const int kViewAhead = FX_VIEW_AHEAD, kLightAhead = FX_LIGHT_AHEAD;
+#ifndef FX_LIGHT_RAY_UNROLL
+#define FX_LIGHT_RAY_UNROLL 2           // samples a live lane takes between two looks at the refill state
+#endif
 #ifndef FX_LIGHT_RAY_WGS
 #define FX_LIGHT_RAY_WGS 1024
 #endif
@@ -470,6 +473,8 @@ __global__ __launch_bounds__(1024) void k_light_rays(const Geom g, const float* 
 			pos += n; avail -= n;
 			if (avail == 0u) { cur += W; pos = 0; avail = 64u * cur < N ? min(64u, N - 64u * cur) : 0u; }
 		}
+#pragma unroll
+		for (int rep = 0; rep < FX_LIGHT_RAY_UNROLL; ++rep)
 		if (live) {                                                                // one sample of the loop :222-246
 			const float px = fmaf(lx, t, ox), py = fmaf(ly, t, oy), pz = fmaf(lz, t, oz);
 			bool on = i < numSamples && !outside(px, py, pz);
