@@ -323,12 +323,24 @@ __global__ __launch_bounds__(256) void k_light_classify(const Geom g, const floa
 		const int x = 4 * cx + (int)(lane & 3u), y = 4 * cy + (int)((lane >> 2) & 3u), z = 4 * cz + (int)(lane >> 4);
 		const bool valid = x < g.X && y < g.Y && z < g.Zg;
 		const uint32_t id = (uint32_t)z * XY + (uint32_t)y * (uint32_t)g.X + (uint32_t)x;
-		bool lit = false;
+		bool lit = false, exact = true;
+		uint32_t centre = 0;
+		float pu = 0.0f, pv = 0.0f, pw = 0.0f;
 		if (valid) {
 			const float ox = fmaf(((float)x + 0.5f) / (float)g.X, 2.0f, -1.0f);    // CSRayMarchL.hlsl:22
 			const float oy = fmaf(((float)y + 0.5f) / (float)g.Y, 2.0f, -1.0f);
 			const float oz = fmaf(((float)z + 0.5f) / (float)g.Zg, 2.0f, -1.0f);
-			const float density = density_at(vol, g, fmaf(ox, 0.5f, 0.5f), fmaf(oy, 0.5f, 0.5f), fmaf(oz, 0.5f, 0.5f));   // :36-37
+			// :36-37.  Where the voxel centre's texel coordinate comes out exact (extents that are powers of two) all filter weights are 0 and
+			// the trilinear sample IS its base tap (fma(0, b - a, a) = a): one coalesced load per voxel instead of a mask word and 8 taps
+			pu = fmaf(ox, 0.5f, 0.5f); pv = fmaf(oy, 0.5f, 0.5f); pw = fmaf(oz, 0.5f, 0.5f);
+			const Base bc = make_base(g, pu, pv, pw);
+			exact = bc.fx == 0.0f && bc.fy == 0.0f && bc.fz == 0.0f;
+			centre = mad24(mad24((uint32_t)bc.z0, (uint32_t)g.Y, (uint32_t)bc.y0), (uint32_t)g.X, (uint32_t)bc.x0);
+		}
+		const bool all_exact = __ballot(valid && !exact) == 0;
+		if (valid) {
+			float density;
+			if (all_exact) density = alpha[centre]; else density = density_at(vol, g, pu, pv, pw);
 			lit = density >= 0.00999999978f;                                       // :44
 			if (!lit) {
 				const float irr[3] = { 0.0f, 0.0f, 0.0f };
@@ -545,7 +557,9 @@ hipError_t launch_accel_light(const Geom& g, const RenderAccel& a, uint32_t* lig
 {
 	const int ncell = a.CX * a.CY * a.CZ;
 	hipLaunchKernelGGL(k_light_cells, dim3((ncell + 255) / 256), dim3(256), 0, s, g, a.CX, a.CY, a.CZ, a.occ + ncell, a.cells, a.ctr, lightmap, fc, sh ? 1 : 0);
-	// (2048 persistent workgroups: 30 us at 256^3 / frame 132; 8192 -- a wave per listed cell -- 37 us)
+	// (2048 persistent workgroups: 30 us at 256^3 / frame 132; 8192 -- a wave per listed cell -- 37 us.  Of today's 25.6 us: 4 the
+	// prologue, 12.5 list entry + alpha + arithmetic, 2.4 the stores, 6.6 the list atomics -- measured by leaving each out; two cells in
+	// flight per wave changed nothing: more than half of the 262 k cells of frame 132 are listed, the pass moves ~75 MB)
 	hipLaunchKernelGGL(k_light_classify, dim3((unsigned)std::min(ncell / 4 + 1, 2048)), dim3(256), ((size_t)a.CZ + 1) * 4, s, g, a.alpha, a.bits, a.CX, a.CY, a.CZ,
 		a.cells, a.list, a.ctr, lightmap, fc, sh ? 1 : 0);
 	const size_t cells = (size_t)g.X * g.Y * g.Zg;
