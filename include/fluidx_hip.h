@@ -151,6 +151,7 @@ int fx_simulate(fx_ctx* ctx, void* stream, uint8_t frame_index);
  *                                  writes the cube map (and light map); fx_render_cube below puts it on the screen
  *   otherwise                      direct screen-space march, one ray per pixel of the viewport (PSRayCast / PSRayCastV,
  *                                  Fluid.cpp:932-972), blended straight into the render target (PREMULTIPLIED) */
+/* (FX_E_INVALID also for a 3-D grid with grid_y * (grid_z + 1) >= 2^24 or 2^32 voxels: tap indices are 32 bits wide.) */
 int fx_render(fx_ctx* ctx, void* stream, uint8_t frame_index, uint8_t flags);
 /* The caller-side half of the cube path (row f-1 of SURVEY.md 8): the render target the reference's caller binds.
  * fx_clear_render_target = ClearRenderTargetView (FluidX12.cpp:471-472; the demo clears to (0.2, 0.2, 0.2, 0));
@@ -262,7 +263,11 @@ int fx_comm_gather_color(fx_ctx* ctx, void* stream, fx_ctx* full, int root, cons
  *   FX_OPT_RENDER_ACCEL  1 = (default) fx_render runs the accelerated marches: occupancy masks of the colour field held in the LDS, an
  *                        alpha-only side volume for the density taps, the lit light-map voxels compacted into a list.  0 = the plain
  *                        kernels, where every sample gathers its taps like the reference's shaders.  Bit-identical pictures either
- *                        way (the accelerated path only skips fetches whose result is known); local to the context.
+ *                        way (the accelerated path only skips fetches whose result is known); local to the context.  Grids of more
+ *                        than 2^28 voxels always take the plain kernels (the accelerated ones address by 32-bit byte offsets).  While
+ *                        it is on, a context that renders its frames has the advection of the NEXT fx_simulate -- when that runs on
+ *                        the stream the render ran on -- store the side volume along with the colour field (one more 4-byte store
+ *                        per voxel), so that the render does not read the field a second time to extract it.
  * On an RCCL chain fx_set_option (of the three schedule options) is COLLECTIVE: every rank calls it with the same arguments between two steps; the values are
  * compared across the chain and a disagreement returns FX_E_INVALID everywhere with nothing changed.  While FX_OPT_ADAPTIVE_HALO
  * is on and a step has run, fx_upload(FX_FIELD_VELOCITY) into an RCCL rank returns FX_E_STATE (its neighbours have sized the next
