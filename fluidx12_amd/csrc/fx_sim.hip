@@ -126,7 +126,7 @@ template <bool HALF>
 __global__ __launch_bounds__(256) void k_advect(const Geom g, const SimParams sp,
 	const typename Store<HALF>::S* __restrict__ vel_in, const typename Store<HALF>::S4* __restrict__ col_in,
 	typename Store<HALF>::S* __restrict__ vel_out, typename Store<HALF>::S4* __restrict__ col_out,
-	int z_begin, int nzp, int remap, unsigned* halo_overflow)
+	int z_begin, int nzp, int remap, unsigned* halo_overflow, float* __restrict__ alpha_out)
 {
 	typedef Store<HALF> St;
 	const int BX = blockDim.x, BY = blockDim.y, BZ = blockDim.z;
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void k_advect(const Geom g, const SimParams sp
 	St::st(vel_out, stride + id, u[1] * atten);
 	St::st(vel_out, 2 * stride + id, u[2] * atten);
 	St::st4(col_out, id, make_float4(c[0] * atten, c[1] * atten, c[2] * atten, c[3] * atten));   // :78
+	if (alpha_out) alpha_out[id] = St::stored(c[3] * atten);                  // the render's alpha side volume (fx_render_accel.hip), unsliced grids only
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -266,7 +267,7 @@ template <bool HALF>
 __global__ __launch_bounds__(256) void k_advect_fast(const Geom g, const SimParams sp,
 	const typename Store<HALF>::S* __restrict__ vel_in, const typename Store<HALF>::S4* __restrict__ col_in,
 	typename Store<HALF>::S* __restrict__ vel_out, typename Store<HALF>::S4* __restrict__ col_out,
-	int z_begin, int nzp, unsigned* halo_overflow, float rX, float rY, float rZ, float inv_rr, int lgX, int lgY, int lg_gx, int lg_gy)
+	int z_begin, int nzp, unsigned* halo_overflow, float rX, float rY, float rZ, float inv_rr, int lgX, int lgY, int lg_gx, int lg_gy, float* __restrict__ alpha_out)
 {
 	typedef Store<HALF> St;
 	typedef Fetch<HALF> Ft;
@@ -356,6 +357,7 @@ __global__ __launch_bounds__(256) void k_advect_fast(const Geom g, const SimPara
 	St::st(vel_out, (size_t)stride + id, u[1] * atten);
 	St::st(vel_out, 2 * (size_t)stride + id, u[2] * atten);
 	St::st4(col_out, id, make_float4(c[0] * atten, c[1] * atten, c[2] * atten, c[3] * atten));
+	if (alpha_out) alpha_out[id] = St::stored(c[3] * atten);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -889,6 +891,9 @@ hipError_t launch_advect(const Geom& g, const SimParams& sp, int half_store, con
 			if (e != hipErrorNotSupported) return e;
 		}
 	}
+	// (the gather kernels write the render's side volume on the same terms as the staged ones: one launch over a whole unsliced grid)
+	float* alpha_out = alpha && alpha->out && g.nzl() == g.Zg && z_begin == 0 && z_end == g.Zg ? alpha->out : nullptr;
+	if (alpha_out) alpha->written = true;
 	// lean path (see k_advect_fast): power-of-two extents, fields below 4 GiB, default workgroup shape and tile order
 	const char* fe = FX_KNOB("ADVECT_FAST");                  // "0" = always the general kernel (A/B tests; read per launch)
 	const bool fast_off = fe && fe[0] == '0';
@@ -901,20 +906,20 @@ hipError_t launch_advect(const Geom& g, const SimParams& sp, int half_store, con
 		const int lgX = lg(g.X), lgY = lg(g.Y), lg_gx = lg((g.X + 63) / 64), lg_gy = lg((g.Y + 3) / 4);
 		if (half_store)
 			hipLaunchKernelGGL(k_advect_fast<true>, grid, block, 0, s, g, sp, (const h16*)vel_in, (const h16x4*)col_in,
-				(h16*)vel_out, (h16x4*)col_out, z_begin, nzp, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY, lg_gx, lg_gy);
+				(h16*)vel_out, (h16x4*)col_out, z_begin, nzp, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY, lg_gx, lg_gy, alpha_out);
 		else
 			hipLaunchKernelGGL(k_advect_fast<false>, grid, block, 0, s, g, sp, (const float*)vel_in, (const float4*)col_in,
-				(float*)vel_out, (float4*)col_out, z_begin, nzp, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY, lg_gx, lg_gy);
+				(float*)vel_out, (float4*)col_out, z_begin, nzp, halo_overflow, rX, rY, rZ, inv_rr, lgX, lgY, lg_gx, lg_gy, alpha_out);
 		return hipGetLastError();
 	}
 	const int cbz = g.Zg > 1 ? bz : 1;
 	const dim3 block(bx, by, cbz), grid(((g.X + bx - 1) / bx) * ((g.Y + by - 1) / by) * ((nzp + cbz - 1) / cbz), 1, 1);
 	if (half_store)
 		hipLaunchKernelGGL(k_advect<true>, grid, block, 0, s, g, sp, (const h16*)vel_in, (const h16x4*)col_in,
-			(h16*)vel_out, (h16x4*)col_out, z_begin, nzp, xcd_remap_for(REMAP_ADVECT, g), halo_overflow);
+			(h16*)vel_out, (h16x4*)col_out, z_begin, nzp, xcd_remap_for(REMAP_ADVECT, g), halo_overflow, alpha_out);
 	else
 		hipLaunchKernelGGL(k_advect<false>, grid, block, 0, s, g, sp, (const float*)vel_in, (const float4*)col_in,
-			(float*)vel_out, (float4*)col_out, z_begin, nzp, xcd_remap_for(REMAP_ADVECT, g), halo_overflow);
+			(float*)vel_out, (float4*)col_out, z_begin, nzp, xcd_remap_for(REMAP_ADVECT, g), halo_overflow, alpha_out);
 	return hipGetLastError();
 }
 

@@ -489,13 +489,14 @@ def test_render_at_coarser_cube_mip_against_oracle():
     check_render_against_oracle(f, col, fr, X, lod, rs, mask, False)
 
 
-@pytest.mark.parametrize("dims,storage", [((64, 64, 64), "fp32"), ((64, 64, 64), "fp16"), ((72, 72, 40), "fp32"), ((128, 128, 32), "fp16")])
-def test_alpha_side_volume_written_by_the_advection_changes_no_bit(dims, storage, knob):
-    """the staged advection writes the stored alpha, as fp32, into the render's side volume (k_advect_lds / k_advect_far <ALPHA>) and the
+@pytest.mark.parametrize("dims,storage,lds", [((64, 64, 64), "fp32", "2"), ((64, 64, 64), "fp16", "2"), ((72, 72, 40), "fp32", "2"), ((128, 128, 32), "fp16", "2"),
+                                              ((64, 64, 64), "fp32", "0"), ((32, 32, 64), "fp16", "0"), ((72, 72, 40), "fp16", "0"), ((50, 50, 30), "fp32", "0")])
+def test_alpha_side_volume_written_by_the_advection_changes_no_bit(dims, storage, lds, knob):
+    """the advection writes the stored alpha, as fp32, into the render's side volume (k_advect_lds / k_advect_far <ALPHA>, k_advect_fast, k_advect) and the
     render's build pass then folds the block maxima from those 4 bytes per voxel instead of reading the texels: same light map, cube
     map and direct picture as with the side volume extracted by the build pass (ADVECT_ALPHA=0) and as the plain kernels; an upload
     over the colour field takes the mirror away"""
-    knob("ADVECT_LDS", "2")                                           # the staged path below the size where it pays
+    knob("ADVECT_LDS", lds)                                           # "2": the staged path below the size where it pays; "0": the gather kernels (k_advect_fast / k_advect)
     vp = (320, 240)
     view, proj, eye = fx.default_camera(*vp)
 
