@@ -131,11 +131,11 @@ static int ensure_target(fx_ctx* ctx, hipStream_t s)
 // The marches of one fx_render.  FX_OPT_RENDER_ACCEL (default): the acceleration structures of this frame's colour field are built
 // first, inside the first pass's timing mark -- their cost belongs to the frame.
 struct Marches {
-	fx_ctx* c; const void* color; hipStream_t s; unsigned long long* cnt; bool accel, built;
+	fx_ctx* c; const void* color; hipStream_t s; unsigned long long* cnt; bool accel, built, filled;
 	Marches(fx_ctx* ctx, const void* col, hipStream_t st, unsigned long long* counters)
-		: c(ctx), color(col), s(st), cnt(counters), accel(ctx->opt_render_accel && ctx->accel_ok), built(false) {}
+		: c(ctx), color(col), s(st), cnt(counters), accel(ctx->opt_render_accel && ctx->accel_ok), built(false), filled(false) {}
 	const float* sh() const { return c->has_sh ? c->sh_dev : nullptr; }
-	hipError_t build()
+	hipError_t build(bool for_light = false)
 	{
 		if (!accel || built) return hipSuccess;
 		built = true;
@@ -144,13 +144,15 @@ struct Marches {
 		const bool current = c->accel_alpha_of == color;
 		if (!current) c->accel_alpha_of = nullptr;                   // the build overwrites the side volume with this field's alpha
 		c->rendered_since_step = true; c->rendered_on = s;
-		return launch_accel_build(c->g, c->half, color, c->accel, s, current);
+		c->accel.frame += 1;                                         // this render's set of counters
+		const LightFill lf{ c->lightmap, &c->fc, c->has_sh ? 1 : 0 };
+		return launch_accel_build(c->g, c->half, color, c->accel, s, current, for_light ? &lf : nullptr, &filled);
 	}
 	hipError_t light()                                  // Fluid.cpp:857-878
 	{
-		hipError_t e = build();
+		hipError_t e = build(true);
 		if (e != hipSuccess) return e;
-		if (accel) return launch_accel_light(c->g, c->accel, c->lightmap, c->fc, sh(), c->max_light_samples, s, cnt);
+		if (accel) return launch_accel_light(c->g, c->accel, c->lightmap, c->fc, sh(), c->max_light_samples, s, cnt, filled);
 		return launch_raymarch_light(c->g, c->half, color, c->lightmap, c->fc, sh(), c->max_light_samples, s, cnt);
 	}
 	hipError_t view(int size, uint8_t* cube, bool separate)   // Fluid.cpp:880-908 (separate) / :825-855 (merged)

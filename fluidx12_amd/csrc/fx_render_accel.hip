@@ -43,6 +43,12 @@ static const size_t kLightRayWorkgroups = FX_LIGHT_RAY_WGS;   // persistent work
 static const int kCntStride = 32;
 __host__ __device__ static inline size_t ctr_heads(const Geom& g) { return (size_t)g.Zg * kCntStride; }
 __host__ __device__ static inline size_t ctr_cells(const Geom& g) { return ((size_t)g.Zg + 8) * kCntStride; }
+// (two sets, RenderAccel::frame & 1: every build pass clears the list lengths of the next render's set, so that a pass which appends
+// while it sweeps -- k_build_fill -- finds its own set empty)
+static size_t ctr_set_words(const Geom& g) { return ctr_cells(g) + (size_t)((g.Zg + 3) >> 2) * kCntStride; }
+size_t render_accel_ctr_words(const Geom& g) { return 2 * ctr_set_words(g); }
+static uint32_t* ctr_now(const RenderAccel& a, const Geom& g) { return a.ctr + (a.frame & 1u) * ctr_set_words(g); }
+static uint32_t* ctr_next(const RenderAccel& a, const Geom& g) { return a.ctr + ((a.frame & 1u) ^ 1u) * ctr_set_words(g); }
 
 void render_accel_layout(const Geom& g, RenderAccel* a)
 {
@@ -76,11 +82,13 @@ static const uint32_t* mask_vis(const RenderAccel& a) { return a.msh ? a.bits + 
 // <ALPHA>): 4 bytes per voxel to read instead of the texel, nothing to write but the block maxima.
 template <bool HALF, bool FROM_ALPHA>
 __global__ __launch_bounds__(256) void k_occupancy_blocks(const Geom g, const typename ColTex<HALF>::T* __restrict__ col, float* __restrict__ blk,
-	float* __restrict__ alpha, uint32_t* __restrict__ cnt)
+	float* __restrict__ alpha, uint32_t* __restrict__ cnt, uint32_t* __restrict__ cnt_next)
 {
 	const int CX = (g.X + 3) >> 2, CY = (g.Y + 3) >> 2;
-	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4 && 4 * (int)blockIdx.z + (int)threadIdx.x < g.Zg)
+	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4 && 4 * (int)blockIdx.z + (int)threadIdx.x < g.Zg) {
 		cnt[(4 * blockIdx.z + threadIdx.x) * kCntStride] = 0u;                     // the light-voxel lists of this frame start empty
+		cnt_next[(4 * blockIdx.z + threadIdx.x) * kCntStride] = 0u;                // ... and so will the next frame's (its build pass may append while it sweeps)
+	}
 	if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x >= 64 && threadIdx.x < 72)
 		cnt[ctr_heads(g) + (threadIdx.x - 64) * kCntStride] = 0u;                  // ... the eight work heads of the view march at zero
 	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 72) cnt[ctr_cells(g) + blockIdx.z * kCntStride] = 0u;   // ... and the cell lists empty
@@ -114,11 +122,14 @@ __global__ __launch_bounds__(256) void k_occupancy_blocks(const Geom g, const ty
 }
 
 // the same from the side volume for rows of whole quads: a lane folds a whole 4^3 block from 16 float4s
-__global__ __launch_bounds__(256) void k_occupancy_blocks_a4(const Geom g, float* __restrict__ blk, const float* __restrict__ alpha, uint32_t* __restrict__ cnt)
+__global__ __launch_bounds__(256) void k_occupancy_blocks_a4(const Geom g, float* __restrict__ blk, const float* __restrict__ alpha, uint32_t* __restrict__ cnt,
+	uint32_t* __restrict__ cnt_next)
 {
 	const int CX = g.X >> 2, CY = (g.Y + 3) >> 2;
-	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4 && 4 * (int)blockIdx.z + (int)threadIdx.x < g.Zg)
+	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4 && 4 * (int)blockIdx.z + (int)threadIdx.x < g.Zg) {
 		cnt[(4 * blockIdx.z + threadIdx.x) * kCntStride] = 0u;
+		cnt_next[(4 * blockIdx.z + threadIdx.x) * kCntStride] = 0u;
+	}
 	if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x >= 64 && threadIdx.x < 72)
 		cnt[ctr_heads(g) + (threadIdx.x - 64) * kCntStride] = 0u;
 	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 72) cnt[ctr_cells(g) + blockIdx.z * kCntStride] = 0u;
@@ -136,6 +147,65 @@ __global__ __launch_bounds__(256) void k_occupancy_blocks_a4(const Geom g, float
 #pragma unroll
 	for (int k = 0; k < 16; ++k) m = fmaxf(m, fmaxf(fmaxf(a[k].x, a[k].y), fmaxf(a[k].z, a[k].w)));
 	blk[((size_t)cz * CY + cy) * CX + cx] = m;
+}
+
+// Build pass and light-map fill in one sweep over the side volume (grids whose extents are powers of two: a voxel's centre sample --
+// CSRayMarchL.hlsl:36-37 -- has all filter weights 0 and IS the voxel's alpha): a lane folds a 4^3 cell from 16 float4s like
+// k_occupancy_blocks_a4, stores the unlit light-map value over the whole cell (the ray kernels overwrite the lit voxels behind it) and
+// appends the voxels with alpha >= 0.01 (:44) to the list of their z plane -- what k_light_cells and k_light_classify did in two more
+// passes.  The lists of this frame's counter set were cleared by the previous frame's build pass.
+__global__ __launch_bounds__(256) void k_build_fill(const Geom g, float* __restrict__ blk, const float* __restrict__ alpha, uint32_t* __restrict__ cnt,
+	uint32_t* __restrict__ cnt_next, uint32_t* __restrict__ list, uint32_t* __restrict__ lightmap, const FrameConsts fc, int has_sh)
+{
+	const int CX = g.X >> 2, CY = g.Y >> 2;
+	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4 && 4 * (int)blockIdx.z + (int)threadIdx.x < g.Zg)
+		cnt_next[(4 * blockIdx.z + threadIdx.x) * kCntStride] = 0u;
+	if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x >= 64 && threadIdx.x < 72)
+		cnt[ctr_heads(g) + (threadIdx.x - 64) * kCntStride] = 0u;
+	const int cx = blockIdx.x * 64 + (threadIdx.x & 63);
+	const int cy = blockIdx.y * 4 + (threadIdx.x >> 6), cz = blockIdx.z;
+	const uint32_t lane = threadIdx.x & 63u;
+	const bool valid = cx < CX && cy < CY;                                         // (uniform per wave in y; x only on rows shorter than 256)
+	const uint32_t X = (uint32_t)g.X, XY = X * (uint32_t)g.Y;
+	float4 a[16];
+	uint32_t lit[4] = { 0u, 0u, 0u, 0u };                                          // per plane of the cell: 16 bits, x fastest
+	if (valid) {
+#pragma unroll
+		for (int k = 0; k < 16; ++k) a[k] = *reinterpret_cast<const float4*>(alpha + (uint32_t)(4 * cz + (k >> 2)) * XY + (uint32_t)(4 * cy + (k & 3)) * X + 4u * (uint32_t)cx);
+		float m = 0.0f;
+#pragma unroll
+		for (int k = 0; k < 16; ++k) {
+			m = fmaxf(m, fmaxf(fmaxf(a[k].x, a[k].y), fmaxf(a[k].z, a[k].w)));
+			const uint32_t b4 = (a[k].x >= 0.00999999978f ? 1u : 0u) | (a[k].y >= 0.00999999978f ? 2u : 0u) | (a[k].z >= 0.00999999978f ? 4u : 0u) | (a[k].w >= 0.00999999978f ? 8u : 0u);
+			lit[k >> 2] |= b4 << (4 * (k & 3));
+		}
+		blk[((size_t)cz * CY + cy) * CX + cx] = m;
+		const float irr[3] = { 0.0f, 0.0f, 0.0f };
+		const uint32_t e = light_value(fc, has_sh != 0, 1.0f, 1.0f, irr);
+		const uint4 e4 = make_uint4(e, e, e, e);
+#pragma unroll
+		for (int k = 0; k < 16; ++k) *reinterpret_cast<uint4*>(lightmap + (uint32_t)(4 * cz + (k >> 2)) * XY + (uint32_t)(4 * cy + (k & 3)) * X + 4u * (uint32_t)cx) = e4;
+	}
+	if (__ballot((lit[0] | lit[1] | lit[2] | lit[3]) != 0u) == 0) return;         // most waves: nothing lit
+#pragma unroll
+	for (int p = 0; p < 4; ++p) {
+		const uint32_t n = (uint32_t)__popc(lit[p]);
+		if (__ballot(n != 0u) == 0) continue;
+		uint32_t incl = n;                                                         // inclusive scan over the lanes
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)incl, d); if ((int)lane >= d) incl += up; }
+		const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+		const uint32_t z = (uint32_t)(4 * cz + p);
+		uint32_t base = 0;
+		if (lane == 0) base = atomicAdd(&cnt[z * kCntStride], total);
+		base = (uint32_t)__shfl((int)base, 0) + incl - n;
+		uint32_t bits = lit[p];
+		while (bits) {
+			const int j = __ffs((int)bits) - 1;
+			bits &= bits - 1u;
+			list[z * XY + base++] = z * XY + (uint32_t)(4 * cy + (j >> 2)) * X + 4u * (uint32_t)cx + (uint32_t)(j & 3);
+		}
+	}
 }
 
 __global__ __launch_bounds__(256) void k_occupancy_dilate(int CX, int CY, int CZ, const float* __restrict__ blk, float* __restrict__ occ,
@@ -183,15 +253,21 @@ __global__ __launch_bounds__(256) void k_mask_coarsen(int CX, int CY, int CZ, in
 	if ((threadIdx.x & 63) == 0 && (uint32_t)(c >> 6) < words64) { pos64[c >> 6] = bp; vis64[c >> 6] = bv; }
 }
 
-hipError_t launch_accel_build(const Geom& g, int half_store, const void* color, const RenderAccel& a, hipStream_t s, bool alpha_current)
+hipError_t launch_accel_build(const Geom& g, int half_store, const void* color, const RenderAccel& a, hipStream_t s, bool alpha_current, const LightFill* fill, bool* filled)
 {
 	const int n = a.CX * a.CY * a.CZ;
 	float* blk = a.occ + n;
 	const dim3 grid((g.X + 63) / 64, (a.CY + 3) / 4, a.CZ), block(256);
-	if (alpha_current && (g.X & 3) == 0) hipLaunchKernelGGL(k_occupancy_blocks_a4, dim3((a.CX + 63) / 64, (a.CY + 3) / 4, a.CZ), block, 0, s, g, blk, a.alpha, a.ctr);
-	else if (alpha_current) hipLaunchKernelGGL((k_occupancy_blocks<false, true>), grid, block, 0, s, g, (const float4*)color, blk, a.alpha, a.ctr);
-	else if (half_store) hipLaunchKernelGGL((k_occupancy_blocks<true, false>), grid, block, 0, s, g, (const h16x4*)color, blk, a.alpha, a.ctr);
-	else hipLaunchKernelGGL((k_occupancy_blocks<false, false>), grid, block, 0, s, g, (const float4*)color, blk, a.alpha, a.ctr);
+	uint32_t* cnt = ctr_now(a, g);
+	uint32_t* nxt = ctr_next(a, g);
+	auto pow2 = [](int v) { return v >= 4 && (v & (v - 1)) == 0; };
+	const bool fused = fill && alpha_current && pow2(g.X) && pow2(g.Y) && pow2(g.Zg) && FX_KNOB_INT("LIGHT_FILL", 1);
+	if (filled) *filled = fused;
+	if (fused) hipLaunchKernelGGL(k_build_fill, dim3((a.CX + 63) / 64, (a.CY + 3) / 4, a.CZ), block, 0, s, g, blk, a.alpha, cnt, nxt, a.list, fill->lightmap, *fill->fc, fill->has_sh);
+	else if (alpha_current && (g.X & 3) == 0) hipLaunchKernelGGL(k_occupancy_blocks_a4, dim3((a.CX + 63) / 64, (a.CY + 3) / 4, a.CZ), block, 0, s, g, blk, a.alpha, cnt, nxt);
+	else if (alpha_current) hipLaunchKernelGGL((k_occupancy_blocks<false, true>), grid, block, 0, s, g, (const float4*)color, blk, a.alpha, cnt, nxt);
+	else if (half_store) hipLaunchKernelGGL((k_occupancy_blocks<true, false>), grid, block, 0, s, g, (const h16x4*)color, blk, a.alpha, cnt, nxt);
+	else hipLaunchKernelGGL((k_occupancy_blocks<false, false>), grid, block, 0, s, g, (const float4*)color, blk, a.alpha, cnt, nxt);
 	hipLaunchKernelGGL(k_occupancy_dilate, dim3((n + 255) / 256), dim3(256), 0, s, a.CX, a.CY, a.CZ, blk, a.occ,
 		reinterpret_cast<unsigned long long*>(a.bits), reinterpret_cast<unsigned long long*>(a.bits + a.fine_words), a.fine_words / 2);
 	if (a.msh) {
@@ -553,15 +629,18 @@ __global__ __launch_bounds__(256) void k_light_gi_dirs(const Geom g, const float
 }
 
 hipError_t launch_accel_light(const Geom& g, const RenderAccel& a, uint32_t* lightmap, const FrameConsts& fc, const float* sh,
-	uint32_t num_samples, hipStream_t s, unsigned long long* counters)
+	uint32_t num_samples, hipStream_t s, unsigned long long* counters, bool filled)
 {
 	const int ncell = a.CX * a.CY * a.CZ;
-	hipLaunchKernelGGL(k_light_cells, dim3((ncell + 255) / 256), dim3(256), 0, s, g, a.CX, a.CY, a.CZ, a.occ + ncell, a.cells, a.ctr, lightmap, fc, sh ? 1 : 0);
+	uint32_t* ctr = ctr_now(a, g);
+	if (!filled) {                                                                 // (else k_build_fill has written the constants and the lists)
+	hipLaunchKernelGGL(k_light_cells, dim3((ncell + 255) / 256), dim3(256), 0, s, g, a.CX, a.CY, a.CZ, a.occ + ncell, a.cells, ctr, lightmap, fc, sh ? 1 : 0);
 	// (2048 persistent workgroups: 30 us at 256^3 / frame 132; 8192 -- a wave per listed cell -- 37 us.  Of today's 25.6 us: 4 the
 	// prologue, 12.5 list entry + alpha + arithmetic, 2.4 the stores, 6.6 the list atomics -- measured by leaving each out; two cells in
 	// flight per wave changed nothing: more than half of the 262 k cells of frame 132 are listed, the pass moves ~75 MB)
 	hipLaunchKernelGGL(k_light_classify, dim3((unsigned)std::min(ncell / 4 + 1, 2048)), dim3(256), ((size_t)a.CZ + 1) * 4, s, g, a.alpha, a.bits, a.CX, a.CY, a.CZ,
-		a.cells, a.list, a.ctr, lightmap, fc, sh ? 1 : 0);
+		a.cells, a.list, ctr, lightmap, fc, sh ? 1 : 0);
+	}
 	const size_t cells = (size_t)g.X * g.Y * g.Zg;
 	const size_t lds = (size_t)a.mask_words * 4 + ((size_t)g.Zg + 1) * 4;
 	// (workgroups of 8 waves around one copy of the mask: 8 instead of 5 waves per SIMD fit beside it.  256^3 frame 132, light pass by
@@ -569,7 +648,7 @@ hipError_t launch_accel_light(const Geom& g, const RenderAccel& a, uint32_t* lig
 	const int ray_nt = FX_KNOB_INT("LIGHT_RAY_NT", 512);
 	const unsigned wgs = (unsigned)std::min<size_t>((cells + ray_nt - 1) / ray_nt, (size_t)FX_KNOB_INT("LIGHT_RAY_WGS", (int)kLightRayWorkgroups));
 #define FX_RAYS(C, M) hipLaunchKernelGGL((k_light_rays<C, M>), dim3(wgs), dim3(ray_nt), lds, s, g, a.alpha, a.occ, mask_pos(a), a.mask_words, a.msh, a.MX, a.MY, a.CX, a.CY, \
-	a.list, a.ctr, lightmap, fc, a.gi, sh, num_samples, counters)
+	a.list, ctr, lightmap, fc, a.gi, sh, num_samples, counters)
 	if (!sh) {
 		if (a.msh) FX_RAYS(true, RAYS_SHADOW); else FX_RAYS(false, RAYS_SHADOW);
 		return hipGetLastError();
@@ -577,20 +656,20 @@ hipError_t launch_accel_light(const Geom& g, const RenderAccel& a, uint32_t* lig
 	if (a.gi) {
 		if (a.msh) FX_RAYS(true, RAYS_SHADOW_KEEP); else FX_RAYS(false, RAYS_SHADOW_KEEP);
 		hipLaunchKernelGGL(k_light_gi_dirs, dim3((unsigned)std::min<size_t>((cells + 255) / 256, 2048)), dim3(256), ((size_t)g.Zg + 1) * 4, s, g, a.alpha, a.CX, a.CY,
-			a.list, a.ctr, a.gi, counters);
+			a.list, ctr, a.gi, counters);
 		if (a.msh) FX_RAYS(true, RAYS_AO); else FX_RAYS(false, RAYS_AO);
 		return hipGetLastError();
 	}
 #undef FX_RAYS
 	// (no scratch for the occlusion rays' directions: the chunked march, a wave per 64 listed voxels)
 	if (a.msh) hipLaunchKernelGGL(k_light_march<true>, dim3(wgs), dim3(256), lds, s, g, a.alpha, a.occ, mask_pos(a), a.mask_words, a.msh, a.MX, a.MY, a.CX, a.CY,
-		a.list, a.ctr, lightmap, fc, sh, num_samples, counters);
+		a.list, ctr, lightmap, fc, sh, num_samples, counters);
 	else hipLaunchKernelGGL(k_light_march<false>, dim3(wgs), dim3(256), lds, s, g, a.alpha, a.occ, mask_pos(a), a.mask_words, a.msh, a.MX, a.MY, a.CX, a.CY,
-		a.list, a.ctr, lightmap, fc, sh, num_samples, counters);
+		a.list, ctr, lightmap, fc, sh, num_samples, counters);
 	return hipGetLastError();
 }
 
-size_t render_accel_ctr_words(const Geom& g) { return ctr_cells(g) + (size_t)((g.Zg + 3) >> 2) * kCntStride; }
+
 
 // ---- view marches ---------------------------------------------------------------------------------------------------------
 // A workgroup = TX x TY tiles of 8 x 8 rays (one tile per wave, so a wave's taps stay spatially coherent) sharing one copy of the
@@ -845,7 +924,7 @@ hipError_t launch_accel_view(const Geom& g, int half_store, const void* color, c
 		const dim3 pgrid((unsigned)std::min<size_t>((groups + 3) / 4, kViewWorkgroups));
 		const size_t plds = (size_t)a.mask_words * 4 + 4 * kXchgFloats * sizeof(float);
 #define FX_SLOTS(H, C) hipLaunchKernelGGL((k_view_slots<H, C>), pgrid, block, plds, s, g, (const typename ColTex<H>::T*)color, a.alpha, a.occ, m, \
-	lightmap, fc, cube_size, mask, num_samples, out, a.ctr + ctr_heads(g), counters)
+	lightmap, fc, cube_size, mask, num_samples, out, ctr_now(a, g) + ctr_heads(g), counters)
 		if (half_store) { if (a.msh) FX_SLOTS(true, true); else FX_SLOTS(true, false); }
 		else { if (a.msh) FX_SLOTS(false, true); else FX_SLOTS(false, false); }
 #undef FX_SLOTS

@@ -423,6 +423,8 @@ def developed_plume(X, steps, storage, vp, sh=None, camera=None):
     for k in range(steps):
         f.UpdateFrame(f32(f.default_time_step()), k % 3, view, proj, eye)
         f.Simulate(k % 3)
+        if k == steps - 2:
+            f.Render(k % 3, fx.Fluid.OPTIMIZED)       # a context that renders its frames: the last step's advection writes the render's side volume (the product's default flow)
     if sh is not None:
         f.SetSH(sh)
     f.UpdateFrame(0.0, 0, view, proj, eye)
