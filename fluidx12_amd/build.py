@@ -31,7 +31,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # bit-identical (tests/test_gpu_sim.py).
 EXTRA_FLAGS = {"fx_jacobi_strip3.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] + (["-DFX_STRIP3C_ROWS=" + os.environ["FLUIDX_BUILD_STRIP3C_ROWS"]] if os.environ.get("FLUIDX_BUILD_STRIP3C_ROWS") else []),
                "fx_jacobi_strip.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
-               "fx_render_accel.hip": [("-D%s=%s" % (d, os.environ[e])) for e, d in (("FLUIDX_BUILD_MASK_BITS", "FX_MASK_BUDGET_BITS"), ("FLUIDX_BUILD_VIEW_AHEAD", "FX_VIEW_AHEAD"), ("FLUIDX_BUILD_LIGHT_AHEAD", "FX_LIGHT_AHEAD"), ("FLUIDX_BUILD_LIGHT_RAY_WGS", "FX_LIGHT_RAY_WGS"), ("FLUIDX_BUILD_LIGHT_RAY_UNROLL", "FX_LIGHT_RAY_UNROLL")) if os.environ.get(e)],
+               "fx_render_accel.hip": [("-D%s=%s" % (d, os.environ[e])) for e, d in (("FLUIDX_BUILD_MASK_BITS", "FX_MASK_BUDGET_BITS"), ("FLUIDX_BUILD_VIEW_AHEAD", "FX_VIEW_AHEAD"), ("FLUIDX_BUILD_LIGHT_AHEAD", "FX_LIGHT_AHEAD"), ("FLUIDX_BUILD_LIGHT_RAY_WGS", "FX_LIGHT_RAY_WGS"), ("FLUIDX_BUILD_LIGHT_RAY_UNROLL", "FX_LIGHT_RAY_UNROLL"), ("FLUIDX_BUILD_VIEW_NT", "FX_VIEW_NT"), ("FLUIDX_BUILD_VIEW_WPE", "FX_VIEW_WPE")) if os.environ.get(e)],
                # k_freeze_tiles reserves its list slot with a returning atomic whose round trip is meant to pass behind the staging loads;
                # the wave-aggregating atomic optimizer would wait for it on the spot (readfirstlane of the result)
                "fx_jacobi_freeze.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"] + (["-DFX_FREEZE_PROF"] if os.environ.get("FLUIDX_BUILD_FREEZE_PROF") else [])}     # 256x256x64: 8.9 -> 8.1 us per sweep; 512x512x64: 19.0 -> 18.8

@@ -753,10 +753,21 @@ static const size_t kViewWorkgroups = 1024;                    // persistent: 25
 static const int kXchgFloats = 5 * kSlots * (64 / kSlots);       // per wave: [ray][kind, alpha, r, g, b][slot]
 
 template <bool HALF, bool COARSE>
-__global__ __launch_bounds__(256) void k_view_slots(const Geom g, const typename ColTex<HALF>::T* __restrict__ col, const float* __restrict__ alpha,
+#ifndef FX_VIEW_NT
+#define FX_VIEW_NT 256
+#endif
+#ifndef FX_VIEW_WPE
+#define FX_VIEW_WPE 0
+#endif
+#if FX_VIEW_WPE
+#define FX_VIEW_ATTR __attribute__((amdgpu_waves_per_eu(FX_VIEW_WPE, FX_VIEW_WPE)))
+#else
+#define FX_VIEW_ATTR
+#endif
+__global__ __launch_bounds__(FX_VIEW_NT) FX_VIEW_ATTR void k_view_slots(const Geom g, const typename ColTex<HALF>::T* __restrict__ col, const float* __restrict__ alpha,
 	const float* __restrict__ occ, const MaskArgs m, const uint32_t* __restrict__ lightmap, const FrameConsts fc,
 	int size, uint32_t mask, uint32_t numSamples, uint32_t* __restrict__ cube, uint32_t* __restrict__ heads,
-	unsigned long long* __restrict__ counters)
+	unsigned long long* __restrict__ counters, int order)
 {
 	extern __shared__ uint32_t lds[];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 3, s = lane & 7;
@@ -789,8 +800,19 @@ __global__ __launch_bounds__(256) void k_view_slots(const Geom g, const typename
 		}
 		const uint32_t grp = ((blockIdx.x & 7u) + 8u * cur) * run + sub;
 		if (grp >= total) break;
-		uint32_t j = grp / gpf, mm = mask & 63u;
-		const uint32_t rem = grp - j * gpf;
+		// Which group a ticket stands for.  The launch ends with its last wave, and a group of rays through the plume costs a hundred times
+		// a group beside it: the plume rises around the volume's vertical axis (the source sits at (0.5, 0.1, 0.5), CSAdvect.hlsl:11-14), i.e.
+		// behind the middle columns of a cube face, so the columns are dealt out from the middle outwards -- the expensive groups start
+		// first and the cheap ones fill the tail (view pass 0.117 -> 0.102 ms at frame 132; any order is correct).  order 0: as numbered.
+		uint32_t g2 = grp;
+		if (order) {
+			const uint32_t per_col = total / gx, cr = grp / per_col, rest = grp - cr * per_col;     // rest = face * gy + row
+			const uint32_t c0 = gx >> 1, col = (cr & 1u) ? c0 - ((cr + 1u) >> 1) : c0 + (cr >> 1);
+			const uint32_t fj = rest / gy, row = rest - fj * gy;
+			g2 = fj * gpf + row * gx + col;
+		}
+		uint32_t j = g2 / gpf, mm = mask & 63u;
+		const uint32_t rem = g2 - j * gpf;
 		for (; j; --j) mm &= mm - 1u;                                              // the j-th visible face (CSRayMarch.hlsl:102)
 		const int face = __ffs((int)mm) - 1;
 		const int x = (int)(rem % gx) * 4 + (r & 3), y = (int)(rem / gx) * 2 + (r >> 2);
@@ -921,10 +943,11 @@ hipError_t launch_accel_view(const Geom& g, int half_store, const void* color, c
 	const MaskArgs m = mask_args(a);
 	if (separate) {
 		const size_t groups = (size_t)((cube_size + 3) / 4) * ((cube_size + 1) / 2) * 6;
-		const dim3 pgrid((unsigned)std::min<size_t>((groups + 3) / 4, kViewWorkgroups));
-		const size_t plds = (size_t)a.mask_words * 4 + 4 * kXchgFloats * sizeof(float);
-#define FX_SLOTS(H, C) hipLaunchKernelGGL((k_view_slots<H, C>), pgrid, block, plds, s, g, (const typename ColTex<H>::T*)color, a.alpha, a.occ, m, \
-	lightmap, fc, cube_size, mask, num_samples, out, ctr_now(a, g) + ctr_heads(g), counters)
+		const int vw = FX_VIEW_NT / 64;
+		const dim3 pgrid((unsigned)std::min<size_t>((groups + vw - 1) / vw, (size_t)FX_KNOB_INT("VIEW_WGS", (int)kViewWorkgroups)));
+		const size_t plds = (size_t)a.mask_words * 4 + vw * kXchgFloats * sizeof(float);
+#define FX_SLOTS(H, C) hipLaunchKernelGGL((k_view_slots<H, C>), pgrid, dim3(FX_VIEW_NT), plds, s, g, (const typename ColTex<H>::T*)color, a.alpha, a.occ, m, \
+	lightmap, fc, cube_size, mask, num_samples, out, ctr_now(a, g) + ctr_heads(g), counters, FX_KNOB_INT("VIEW_ORDER", 1))
 		if (half_store) { if (a.msh) FX_SLOTS(true, true); else FX_SLOTS(true, false); }
 		else { if (a.msh) FX_SLOTS(false, true); else FX_SLOTS(false, false); }
 #undef FX_SLOTS
