@@ -535,3 +535,40 @@ def test_alpha_side_volume_written_by_the_advection_changes_no_bit(dims, storage
     for u, v, w in zip(a, b, c):
         assert np.array_equal(u.view(np.uint8), v.view(np.uint8))
         assert np.array_equal(u.view(np.uint8), w.view(np.uint8))
+
+
+def test_light_fill_paths_alternate_without_a_trace(knob):
+    """the build pass that also fills the light map (k_build_fill) appends to this render's list counters, which the PREVIOUS render's
+    build pass cleared: alternate it with the three-pass path, the plain kernels, a light probe switched on and off and an upload, frame
+    by frame -- every light map and cube map equals the plain kernels' of the same frame"""
+    X, vp = 64, (320, 240)
+    view, proj, eye = fx.default_camera(*vp)
+    sh = (np.random.default_rng(3).random((9, 3)) * np.array([[2.0]] + [[0.5]] * 8)).astype(f32)
+
+    def run(script):
+        f = fx.Fluid()
+        assert f.Init(vp[0], vp[1], (X, X, X), storage="fp32")
+        f.SetMaxSamples(96, 32)
+        out = []
+        for k, (accel, fill, use_sh, upload) in enumerate(script):
+            knob("LIGHT_FILL", "1" if fill else "0")
+            f.set_option(capi.OPT_RENDER_ACCEL, 1 if accel else 0)
+            f.SetSH(sh if use_sh else None)
+            f.UpdateFrame(f32(f.default_time_step()), k % 3, view, proj, eye)
+            f.Simulate(k % 3)
+            if upload:
+                col = f.download(fx.FIELD_COLOR)
+                f.upload(fx.FIELD_COLOR, np.ascontiguousarray(col[:, ::-1]))
+            f.Render(k % 3, fx.Fluid.OPTIMIZED)
+            f.Synchronize()
+            out += [f.download(fx.FIELD_LIGHTMAP), f.download(fx.FIELD_CUBEMAP)]
+        return out
+
+    #          accel fill   sh     upload
+    script = [(1, 1, False, 0), (1, 1, False, 0), (1, 0, False, 0), (1, 1, False, 0), (0, 1, False, 0), (1, 1, False, 0), (1, 1, True, 0), (1, 1, True, 0),
+              (1, 0, True, 0), (1, 1, True, 1), (1, 1, True, 0), (1, 1, False, 0), (1, 1, False, 0), (1, 1, False, 0)] + [(1, 1, False, 0)] * 6
+    a = run(script)
+    b = run([(0, 0, s_[2], s_[3]) for s_ in script])
+    assert a[-1][..., 3].max() > 20
+    for k, (u, v) in enumerate(zip(a, b)):
+        assert np.array_equal(u.view(np.uint8), v.view(np.uint8)), k
