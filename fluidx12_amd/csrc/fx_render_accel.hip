@@ -946,8 +946,12 @@ hipError_t launch_accel_view(const Geom& g, int half_store, const void* color, c
 		const int vw = FX_VIEW_NT / 64;
 		const dim3 pgrid((unsigned)std::min<size_t>((groups + vw - 1) / vw, (size_t)FX_KNOB_INT("VIEW_WGS", (int)kViewWorkgroups)));
 		const size_t plds = (size_t)a.mask_words * 4 + vw * kXchgFloats * sizeof(float);
+		// middle-out (see the kernel) where a wave gets through many groups; with two or three groups per wave (cube maps of 128 / 150 texels)
+		// the order as numbered measured better: 128^3 0.094 against 0.116 ms, 150^3 0.102 / 0.111; 256-texel cubes 0.116 / 0.102
+		const size_t visible_groups = groups / 6 * (size_t)__builtin_popcount(mask & 63u);
+		const int view_order = FX_KNOB_INT("VIEW_ORDER", visible_groups >= 6 * (size_t)pgrid.x * vw ? 1 : 0);
 #define FX_SLOTS(H, C) hipLaunchKernelGGL((k_view_slots<H, C>), pgrid, dim3(FX_VIEW_NT), plds, s, g, (const typename ColTex<H>::T*)color, a.alpha, a.occ, m, \
-	lightmap, fc, cube_size, mask, num_samples, out, ctr_now(a, g) + ctr_heads(g), counters, FX_KNOB_INT("VIEW_ORDER", 1))
+	lightmap, fc, cube_size, mask, num_samples, out, ctr_now(a, g) + ctr_heads(g), counters, view_order)
 		if (half_store) { if (a.msh) FX_SLOTS(true, true); else FX_SLOTS(true, false); }
 		else { if (a.msh) FX_SLOTS(false, true); else FX_SLOTS(false, false); }
 #undef FX_SLOTS
