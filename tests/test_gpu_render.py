@@ -572,3 +572,27 @@ def test_light_fill_paths_alternate_without_a_trace(knob):
     assert a[-1][..., 3].max() > 20
     for k, (u, v) in enumerate(zip(a, b)):
         assert np.array_equal(u.view(np.uint8), v.view(np.uint8)), k
+
+
+@pytest.mark.parametrize("X,storage,use_sh", [(288, "fp32", False), (512, "fp16", True)])
+def test_grids_whose_cell_mask_exceeds_the_lds_change_no_bit(X, storage, use_sh):
+    """above 256^3 the 4^3-cell masks no longer fit the LDS budget: the marches hold a coarser level there and confirm a set bit against the
+    fine occupancy grid (AccelVol<.., COARSE>); 288^3 takes the three-pass light volume, 512^3 the filling build pass.  Light map, cube
+    map and the direct picture equal the plain kernels' bit for bit"""
+    vp = (640, 360)
+    sh = (np.random.default_rng(9).random((9, 3)) * np.array([[2.0]] + [[0.5]] * 8)).astype(f32) if use_sh else None
+    f, col, fr, lod, rs, mask = developed_plume(X, 40, storage, vp, sh=sh)
+    out = []
+    for accel in (1, 0):
+        f.set_option(capi.OPT_RENDER_ACCEL, accel)
+        f.Render(0, fx.Fluid.OPTIMIZED)
+        f.Synchronize()
+        res = [f.download(fx.FIELD_LIGHTMAP), f.download(fx.FIELD_CUBEMAP)]
+        f.ClearRenderTarget()
+        f.Render(0, fx.Fluid.SEPARATE_LIGHT_PASS)
+        f.Synchronize()
+        res.append(f.download(fx.FIELD_TARGET_FLOAT))
+        out.append(res)
+    assert out[0][1][..., 3].max() > 20
+    for u, v in zip(*out):
+        assert np.array_equal(u.view(np.uint8), v.view(np.uint8))
