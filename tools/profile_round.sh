@@ -11,8 +11,8 @@
 TAG=${1:-r06}
 cd "${GRAFT_REPO_ROOT:-.}" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O
-rm -f profiles/${TAG}_pmc_traffic_*.json profiles/${TAG}_sq_counters_*.json profiles/${TAG}_render_pmc_*.json
+O=gpurun_out/$TAG; if [ -z "$ONLY_RENDER" ]; then rm -rf $O; rm -f profiles/${TAG}_pmc_traffic_*.json profiles/${TAG}_sq_counters_*.json; fi; mkdir -p $O
+rm -f profiles/${TAG}_render_pmc_*.json
 prof() {  # tag, summary args, bench args...
   tag=$1; sargs=$2; shift 2
   B="python3 bench.py --no-cpu-baseline --no-render --no-developed $*"
@@ -26,11 +26,13 @@ prof() {  # tag, summary args, bench args...
   cp $(find $O/kt_$tag -name "*kernel_stats.csv" | head -1) $O/kernel_stats_$tag.csv
   rm -rf $O/kt_$tag $O/pmcf_$tag $O/pmcw_$tag $O/sq1_$tag $O/sq2_$tag
 }
+if [ -z "$ONLY_RENDER" ]; then
 prof 256 "--grid 256 --iters 40 --storage fp32" --steps 4 --warmup 1 --config 3
 prof 128 "--grid 128 --iters 40 --storage fp32" --steps 4 --warmup 1 --config 2
 prof 512_80 "--grid 512 --iters 80 --storage fp32" --steps 4 --warmup 1 --config 4
 prof 150 "--grid 150 --iters 40 --storage fp32" --steps 4 --warmup 1 --grid 150
 prof reference "--grid 256 --iters 64 --storage fp16 --mode faithful --steps-profiled 44" --steps 4 --warmup 40 --reference-config
+fi
 render() {  # tag, summary args, bench args...
   tag=$1; sargs=$2; shift 2
   B="python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-developed $*"
@@ -46,6 +48,7 @@ render config5 "--grid 256 --storage fp16 --has-sh" --config 5
 # the counter summaries become the committed ones of this round BEFORE the bench lines run: bench.py quotes `roofline.traffic` and the
 # render cache figures from profiles/ (on the box: in the snapshot; copy the same files into profiles/ at home)
 mkdir -p profiles
+if [ -n "$ONLY_RENDER" ]; then cp $O/render_pmc_*.json profiles/ 2>/dev/null; for f in $O/render_pmc_*.json; do cp $f profiles/${TAG}_$(basename $f); done; exit 0; fi
 for f in $O/pmc_traffic_*.json $O/sq_counters_*.json $O/render_pmc_*.json; do cp $f profiles/${TAG}_$(basename $f); done
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_steps20_warmup5.json 2>> $O/bench.err

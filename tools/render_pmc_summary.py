@@ -22,7 +22,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fluidx12_amd.build import kernel_source_hash   # noqa: E402
 
-RENDER = ("k_occupancy_blocks", "k_occupancy_dilate", "k_mask_coarsen", "k_light_cells", "k_light_classify", "k_light_rays", "k_light_gi_dirs",
+RENDER = ("k_build_fill", "k_occupancy_blocks", "k_occupancy_blocks_a4", "k_occupancy_dilate", "k_mask_coarsen", "k_light_cells", "k_light_classify", "k_light_rays", "k_light_gi_dirs",
           "k_light_march", "k_view_slots", "k_view_march", "k_direct_march", "k_raymarch_light", "k_raymarch_view", "k_raycast_direct", "k_resolve_cube")
 
 
@@ -58,8 +58,8 @@ def main():
     for r in csv.DictReader(open(a.stats_csv)):
         k = short(r["Name"])
         if k in RENDER:
-            e = stats.setdefault(k, [0, 0.0])
-            e[0] += int(r["Calls"]); e[1] += float(r["TotalDurationNs"])
+            e = stats.setdefault(k, [0, 0.0, float("inf")])
+            e[0] += int(r["Calls"]); e[1] += float(r["TotalDurationNs"]); e[2] = min(e[2], float(r["MinNs"]))
     l2, l1 = counters(a.l2_csv), counters(a.l1_csv)
     for k in RENDER:
         if k not in stats and k not in l2:
@@ -67,6 +67,8 @@ def main():
         e = {"source_hash": kernel_source_hash(k)}
         if k in stats:
             e["calls"], e["avg_us"] = stats[k][0], stats[k][1] / stats[k][0] / 1e3
+            e["min_us"] = stats[k][2] / 1e3                          # (a kernel's first call of a process costs several hundred us more: the average of a dozen calls carries it)
+            e["l1_accesses_per_cycle_and_cu_at_min"] = None
         h, m = l2.get(k, {}).get("TCC_HIT_sum"), l2.get(k, {}).get("TCC_MISS_sum")
         if h is not None and m is not None and h + m > 0:
             e["l2_requests"], e["l2_hit_rate"] = h + m, h / (h + m)
@@ -75,6 +77,8 @@ def main():
         acc, req = l1.get(k, {}).get("TCP_TOTAL_CACHE_ACCESSES_sum"), l1.get(k, {}).get("TCP_TCC_READ_REQ_sum")
         if acc and req is not None:
             e["l1_accesses"], e["l1_hit_rate"] = acc, 1.0 - req / acc
+            if e.get("min_us"):
+                e["l1_accesses_per_cycle_and_cu_at_min"] = acc / 256.0 / (e["min_us"] * 1e-6 * 2.4e9)   # the gathers' bound: ~0.6 tag look-ups per cycle and CU
         out["kernels"][k] = e
     print(json.dumps(out, indent=1))
 
