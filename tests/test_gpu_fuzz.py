@@ -645,3 +645,54 @@ def test_random_dds_mip_chains_decode_like_the_oracle(seed):
         assert got is not None and got.shape == want.shape == (6, max(n >> mip, 1), max(n >> mip, 1), 3), (n, mips, mip)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (n, mips, mip)
     assert probe.decode_dds(dds, mips) is None
+
+
+@pytest.mark.parametrize("seed", range(SOAK or 24))
+def test_random_frame_sequences_render_alike_on_both_paths(seed, knob):
+    """simulate-and-render sequences as a caller would run them -- random grid (powers of two and not), storage, light probe, camera, which
+    advection kernel family serves the grid, which frames are rendered and how, an upload in between: the accelerated marches (side volume
+    written by the advection of a rendered frame, the filling build pass, the three-pass light volume) give every frame the picture the
+    plain kernels give it, bit for bit, and leave the simulation alone"""
+    c = draw_camera(seed)
+    rng = np.random.default_rng(77000 + seed)
+    X = int(rng.choice([32, 40, 64, 64, 48]))
+    Z = int(rng.choice([32, 64, 24, 40]))
+    knob("ADVECT_LDS", str(rng.choice(["0", "2"])))
+    if rng.random() < 0.3:
+        knob("LIGHT_FILL", "0")
+    vw, vh = c["vp"]
+    view = fx.look_at_lh(c["eye"], c["focus"], c["up"])
+    proj = fx.perspective_fov_lh(f32(c["fov"]), vw / float(vh), 1.0, 1000.0)
+    sh = (rng.random((9, 3)) * np.array([[2.0]] + [[0.5]] * 8)).astype(f32) if c["use_sh"] else None
+    n = int(rng.integers(10, 18))
+    plan = [int(rng.choice([-1, fx.Fluid.OPTIMIZED, fx.Fluid.OPTIMIZED, fx.Fluid.RAY_MARCH_CUBEMAP, fx.Fluid.SEPARATE_LIGHT_PASS, fx.Fluid.RAY_MARCH_DIRECT])) for _ in range(n)]
+    plan[-1] = fx.Fluid.OPTIMIZED
+    upload_at = int(rng.integers(4, n)) if rng.random() < 0.4 else -1
+
+    def run(accel):
+        f = fx.Fluid()
+        assert f.Init(vw, vh, (X, X, Z), storage=c["storage"])
+        f.SetMaxSamples(*c["samples"])
+        f.set_option(capi.OPT_RENDER_ACCEL, accel)
+        if sh is not None:
+            f.SetSH(sh)
+        out = []
+        for k in range(n):
+            f.UpdateFrame(f32(f.default_time_step() * 2.0), k % 3, view, proj, c["eye"])
+            f.Simulate(k % 3)
+            if k == upload_at:
+                f.upload(fx.FIELD_COLOR, np.ascontiguousarray(f.download(fx.FIELD_COLOR)[::-1]))
+            if plan[k] >= 0:
+                f.ClearRenderTarget()
+                f.Render(k % 3, plan[k])
+                f.Synchronize()
+                out.append(f.download(fx.FIELD_CUBEMAP) if plan[k] & fx.Fluid.RAY_MARCH_CUBEMAP else f.download(fx.FIELD_TARGET_FLOAT))
+                if plan[k] & fx.Fluid.SEPARATE_LIGHT_PASS:
+                    out.append(f.download(fx.FIELD_LIGHTMAP))
+        out += [f.download(fx.FIELD_VELOCITY), f.download(fx.FIELD_COLOR), f.download(fx.FIELD_PRESSURE)]
+        return out
+
+    a, b = run(1), run(0)
+    assert len(a) == len(b)
+    for k, (u, v) in enumerate(zip(a, b)):
+        assert np.array_equal(u.view(np.uint8), v.view(np.uint8)), (seed, k, X, Z, c["storage"], plan)
