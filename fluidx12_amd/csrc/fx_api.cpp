@@ -6,6 +6,7 @@
 //
 // No CPU fallback and nothing from oracle/: every field operation is a HIP kernel.
 #include "fx_host.h"
+#include <cstring>
 #include "fx_hostmath.h"
 
 using namespace fx;
@@ -145,14 +146,27 @@ struct Marches {
 		if (!current) c->accel_alpha_of = nullptr;                   // the build overwrites the side volume with this field's alpha
 		c->rendered_since_step = true; c->rendered_on = s;
 		c->accel.frame += 1;                                         // this render's set of counters
-		const LightFill lf{ c->lightmap, &c->fc, c->has_sh ? 1 : 0 };
-		return launch_accel_build(c->g, c->half, color, c->accel, s, current, for_light ? &lf : nullptr, &filled);
+		// the filling pass may skip the cells whose light-map words nobody has touched since the last one wrote the same constant there
+		float key[9];
+		for (int i = 0; i < 4; ++i) { key[i] = c->fc.light_color[i]; key[4 + i] = c->fc.ambient[i]; }
+		key[8] = c->has_sh ? 1.0f : 0.0f;
+		const bool same = c->lightmap_filled && std::memcmp(key, c->lightmap_key, sizeof key) == 0;
+		const LightFill lf{ c->lightmap, &c->fc, c->has_sh ? 1 : 0, same };
+		if (for_light) c->accel.fill_frame += 1;
+		const hipError_t e = launch_accel_build(c->g, c->half, color, c->accel, s, current, for_light ? &lf : nullptr, &filled);
+		if (for_light) {
+			if (!filled) c->accel.fill_frame -= 1;
+			c->lightmap_filled = filled && e == hipSuccess;          // (another light path writes every word: no record)
+			std::memcpy(c->lightmap_key, key, sizeof key);
+		}
+		return e;
 	}
 	hipError_t light()                                  // Fluid.cpp:857-878
 	{
 		hipError_t e = build(true);
 		if (e != hipSuccess) return e;
 		if (accel) return launch_accel_light(c->g, c->accel, c->lightmap, c->fc, sh(), c->max_light_samples, s, cnt, filled);
+		c->lightmap_filled = false;
 		return launch_raymarch_light(c->g, c->half, color, c->lightmap, c->fc, sh(), c->max_light_samples, s, cnt);
 	}
 	hipError_t view(int size, uint8_t* cube, bool separate)   // Fluid.cpp:880-908 (separate) / :825-855 (merged)

@@ -52,6 +52,8 @@ struct fx_ctx {
 	bool accel_ok = false;          // ... and whether all of it could be allocated
 	const void* accel_alpha_of = nullptr;   // the colour buffer whose alpha the side volume holds already (written by the advection that made the field), or null
 	bool rendered_since_step = false;       // a context that renders its frames has the NEXT advection write the side volume (one more store per voxel); one that only simulates does not pay for it
+	bool lightmap_filled = false;           // the light map holds what a filling build pass (k_build_fill) and its ray kernels left, nothing else has written it since
+	float lightmap_key[9] = {};             // ... with these constants behind the unlit value (light colour, ambient, light probe on / off)
 	hipStream_t rendered_on = nullptr;      // ... provided that advection runs on the stream the render ran on (the side volume is not double-buffered like the colour)
 	int opt_render_accel = 1;       // FX_OPT_RENDER_ACCEL
 	uint8_t* target;                // W x H RGBA8 render target of the cube resolve (lazily allocated)

@@ -155,6 +155,7 @@ struct RenderAccel {
 	int msh, MX, MY, MZ; // level held in the LDS: (4 << msh)^3 blocks, at most 262144 of them
 	uint32_t fine_words, mask_words;
 	uint32_t frame;      // renders built so far: the counters are double-buffered (set frame & 1), every build pass clears the list lengths of the NEXT render's set
+	uint32_t fill_frame; // filling build passes so far: each leaves a bit per cell "holds a lit voxel" (in `cells`, two sets) for the next one
 };
 void render_accel_layout(const Geom& g, RenderAccel* a);       // fills the dimensions
 size_t render_accel_bits_words(const RenderAccel& a);
@@ -163,7 +164,9 @@ size_t render_accel_ctr_words(const Geom& g);
 // fill (with alpha_current, on grids whose extents are powers of two -- a voxel's centre sample is then its own alpha): the pass also writes the
 // unlit voxels' light-map constant and lists the lit voxels, i.e. it does k_light_cells' and k_light_classify's work in the same sweep over
 // the side volume; *filled says whether it did (launch_accel_light is then told so)
-struct LightFill { uint32_t* lightmap; const FrameConsts* fc; int has_sh; };
+// incremental: the light map still holds what the previous filling pass and its ray kernels left, and the unlit value is the same -- only
+// the cells that held a lit voxel then need the constant again
+struct LightFill { uint32_t* lightmap; const FrameConsts* fc; int has_sh; bool incremental; };
 hipError_t launch_accel_build(const Geom& g, int half_store, const void* color, const RenderAccel& a, hipStream_t s, bool alpha_current = false,
 	const LightFill* fill = nullptr, bool* filled = nullptr);
 hipError_t launch_accel_light(const Geom& g, const RenderAccel& a, uint32_t* lightmap, const FrameConsts& fc, const float* sh,
