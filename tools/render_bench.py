@@ -34,6 +34,8 @@ def main():
     for k in range(a.frame):
         f.UpdateFrame(np.float32(f.default_time_step()), k % 3, view, proj, eye)
         f.Simulate(k % 3)
+        if k == a.frame - 2:
+            f.Render(k % 3, fx.Fluid.OPTIMIZED)   # a context that renders its frames: the last step's advection writes the render's side volume (bench.py does the same)
     if a.sh:
         sh = (np.random.default_rng(5).random((9, 3)) * np.array([[2.0]] + [[0.5]] * 8)).astype(np.float32)
         f.SetSH(sh)
