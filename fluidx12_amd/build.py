@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libfluidx_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 
-SOURCES = ["fx_api.cpp", "fx_knobs.cpp", "fx_context.cpp", "fx_schedule.cpp", "fx_comm.cpp", "fx_checkpoint.cpp", "fx_sim.hip", "fx_advect_lds.hip", "fx_jacobi_strip.hip", "fx_jacobi_strip3.hip", "fx_jacobi_block.hip", "fx_jacobi_freeze.hip", "fx_jacobi2d.hip", "fx_render.hip", "fx_render_accel.hip", "fx_resolve.hip", "fx_bc6h.hip", "fx_sh.hip"]
+SOURCES = ["fx_api.cpp", "fx_knobs.cpp", "fx_context.cpp", "fx_schedule.cpp", "fx_comm.cpp", "fx_checkpoint.cpp", "fx_sim.hip", "fx_advect_lds.hip", "fx_jacobi_strip.hip", "fx_jacobi_strip3.hip", "fx_jacobi_block.hip", "fx_jacobi_freeze.hip", "fx_jacobi_stripm.hip", "fx_jacobi2d.hip", "fx_render.hip", "fx_render_accel.hip", "fx_resolve.hip", "fx_bc6h.hip", "fx_sh.hip"]
 HEADERS = ["fx_internal.h", "fx_context.h", "fx_host.h", "fx_hostmath.h", "fx_pk.h", "fx_march.h", "fx_knobs.h", os.path.join(ROOT, "include", "fluidx_hip.h")]
 
 # -ffp-contract=off: the numerics contract allows a fused multiply-add only where the code

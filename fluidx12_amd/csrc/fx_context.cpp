@@ -84,12 +84,13 @@ void free_all(fx_ctx* c)
 		if (c->p[i]) (void)hipFree(c->p[i]);
 	}
 	void* others[] = { c->env, c->accel.occ, c->accel.alpha, c->accel.bits, c->accel.list, c->accel.cells, c->accel.gi, c->accel.ctr, c->target, c->target_float, c->p_face[0], c->p_face[1], c->b, c->frozen, c->lightmap, c->cube, c->sh_dev, c->halo_overflow, c->stage,
-		c->sh_scratch[0], c->sh_scratch[1], c->sh_scratch[2], c->sh_scratch[3], c->p_aux, c->fz_mask[0], c->fz_mask[1], c->fz_tile_next, c->fz_stat, c->fz_list[0], c->fz_list[1], c->fz_counts, c->sample_counters, c->adv_far };
+		c->sh_scratch[0], c->sh_scratch[1], c->sh_scratch[2], c->sh_scratch[3], c->p_aux, c->fz_mask[0], c->fz_mask[1], c->fz_mask[2], c->fz_tile_next, c->fz_stat, c->fz_list[0], c->fz_list[1], c->fz_counts, c->sample_counters, c->adv_far };
 	for (void* q : others) if (q) (void)hipFree(q);
 	for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
 	if (c->step_rec) (void)hipFree(c->step_rec);
 	if (c->gath_dev) (void)hipFree(c->gath_dev);
 	if (c->rec_host) (void)hipHostFree(c->rec_host);
+	if (c->fz_active_host) (void)hipHostFree(c->fz_active_host);
 	if (c->rec_ev) (void)hipEventDestroy(c->rec_ev);
 	if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
 }
@@ -185,7 +186,7 @@ int fx_create(fx_ctx** out, const fx_desc* d)
 				const size_t mb = jacobi_freeze_mask_bytes(ctx->g), nt = (size_t)jacobi_freeze_tiles(ctx->g);
 				FX_HIP(hipMalloc((void**)&ctx->p_aux, cells * 4));
 				FX_HIP(hipMemsetAsync(ctx->p_aux, 0, cells * 4, ctx->stream));
-				for (int i = 0; i < 2; ++i) {
+				for (int i = 0; i < 3; ++i) {
 					FX_HIP(hipMalloc((void**)&ctx->fz_mask[i], mb));
 					FX_HIP(hipMemsetAsync(ctx->fz_mask[i], 0, mb, ctx->stream));
 				}
@@ -197,6 +198,10 @@ int fx_create(fx_ctx** out, const fx_desc* d)
 				FX_HIP(hipMalloc((void**)&ctx->fz_stat, kFreezeStatRing * sizeof(uint32_t)));
 				FX_HIP(hipMemsetAsync(ctx->fz_stat, 0, kFreezeStatRing * sizeof(uint32_t), ctx->stream));
 				ctx->fz_iters.assign(kFreezeStatRing, 0);
+				if (jacobi_freeze_strip_supported(ctx->g) && hipHostMalloc((void**)&ctx->fz_active_host, 64, hipHostMallocMapped) == hipSuccess) {
+					ctx->fz_active_host[0] = 0u;
+					if (hipHostGetDevicePointer((void**)&ctx->fz_active_dev, ctx->fz_active_host, 0) != hipSuccess) ctx->fz_active_dev = nullptr;
+				} else (void)hipGetLastError();
 			}
 		}
 		FX_HIP(hipMalloc((void**)&ctx->halo_overflow, sizeof(unsigned)));

@@ -28,7 +28,9 @@ struct fx_ctx {
 	// faithful mode, single-domain fast path (fx_jacobi_freeze.hip): third pressure buffer, two quad-nibble freeze masks, tile marks,
 	// and a ring of per-step "last level that left a cell relaxing" words
 	float* p_aux = nullptr;
-	uint8_t* fz_mask[2] = { nullptr, nullptr };
+	uint32_t* fz_active_host = nullptr;   // pinned, device-visible: tiles the last dense sweeps left relaxing (written by k_count_marks, read late and without waiting)
+	uint32_t* fz_active_dev = nullptr;
+	uint8_t* fz_mask[3] = { nullptr, nullptr, nullptr };   // [2]: the third one of the masked strip launches (three pressure buffers rotate, so do the masks)
 	uint32_t* fz_tile_next = nullptr;  // per tile: tag of the solve that listed it last
 	void* fz_list[2] = { nullptr, nullptr };   // work lists of alternate launches
 	uint32_t* fz_counts = nullptr;  // list lengths of two solves [2][kFreezeSlots launches][8 sub-lists]

@@ -104,8 +104,16 @@ Geom jacobi_freeze_view(const Geom& g, int* first_plane, int* own_begin);
 hipError_t launch_freeze_dense(const Geom& g, const float* p_in, const float* b, float* pA, float* pB, uint8_t* mA, uint8_t* mB,
 	const FreezeWork& w, hipStream_t s, const void* vel = nullptr, int vel_half = 0, int z_begin = 0, int nzp = 0, size_t vel_comp_cells = 0);   // vel: compute (and store) the divergence of this velocity instead of reading b
 bool jacobi_freeze_can_fuse_divergence(const Geom& g);
+// flag_tag (first tile launch only, n == 0): the value a tile's mark must hold to be taken -- w.gen as k_freeze_dense writes it, or the tag the
+// last masked strip launch wrote (0: w.gen)
 hipError_t launch_freeze_tiles(const Geom& g, const float* p_src, const float* b, float* p_dst, const uint8_t* m_src, uint8_t* m_dst,
-	const FreezeWork& w, int n, int levels, int level_base, uint32_t* stat, uint32_t stat_hi, hipStream_t s, int z_begin = 0, int nzp = 0);
+	const FreezeWork& w, int n, int levels, int level_base, uint32_t* stat, uint32_t stat_hi, hipStream_t s, int z_begin = 0, int nzp = 0, uint32_t flag_tag = 0);
+// three more levels for EVERY cell on the streaming strip pipeline (fx_jacobi_stripm.hip; X = 256, single domain): level_in in p_in / m_in ->
+// level_in + 3 in p_outA = p_outB, nibbles in m_outA = m_outB; tiles that still relax get `tag` in tile_mark
+bool jacobi_freeze_strip_supported(const Geom& g);
+hipError_t launch_count_marks(const uint32_t* tile_mark, uint32_t gen, int ntiles, uint32_t* out, hipStream_t s);   // tiles with tile_mark == gen, into *out (a host-visible word)
+hipError_t launch_freeze_strip3(const Geom& g, const float* p_in, const float* b, float* p_outA, float* p_outB, const uint8_t* m_in, uint8_t* m_outA, uint8_t* m_outB,
+	uint32_t* tile_mark, uint32_t tag, uint32_t* stat, uint32_t stat_hi, int level_in, hipStream_t s);
 // 2-D grids (fx_jacobi2d.hip): up to jacobi2d_max_sweeps (0: not a 2-D grid / switched off) lock-step sweeps per launch on LDS tiles, with or without the freeze bytes
 int jacobi2d_max_sweeps(const Geom& g);
 hipError_t launch_jacobi2d(const Geom& g, const float* p_in, const float* b, float* p_out, uint8_t* frozen, int sweeps, hipStream_t s);

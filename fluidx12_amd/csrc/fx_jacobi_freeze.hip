@@ -589,9 +589,10 @@ bool jacobi_freeze_can_fuse_divergence(const Geom& g) { (void)g; return FX_KNOB_
 
 // launch number `n` (0, 1, ...) of a solve reads list[n & 1] and writes list[(n + 1) & 1]
 hipError_t launch_freeze_tiles(const Geom& g, const float* p_src, const float* b, float* p_dst, const uint8_t* m_src, uint8_t* m_dst,
-	const FreezeWork& w, int n, int levels, int level_base, uint32_t* stat, uint32_t stat_hi, hipStream_t s, int z_begin, int nzp)
+	const FreezeWork& w, int n, int levels, int level_base, uint32_t* stat, uint32_t stat_hi, hipStream_t s, int z_begin, int nzp, uint32_t flag_tag)
 {
 	if (nzp <= 0) { z_begin = 0; nzp = g.Zg; }
+	if (!flag_tag) flag_tag = w.gen;
 	int max_wgs = FX_KNOB_INT("FREEZE_WGS", 2048);
 	// the relaxing set only shrinks: later launches of a solve get smaller grids (an empty or nearly empty launch of 2048 workgroups of
 	// 512 threads costs 4-8 us just to start and retire them; a workgroup walks its list, so fewer workgroups still cover every entry)
@@ -607,7 +608,7 @@ hipError_t launch_freeze_tiles(const Geom& g, const float* p_src, const float* b
 	uint4* lout = (uint4*)w.list[(n + 1) & 1];
 	const uint32_t* cin = w.counts + (size_t)n * kShards;
 	uint32_t* cout = w.counts + (size_t)(n + 1) * kShards;
-#define FX_FREEZE_ARGS grid, block, 0, s, g, p_src, b, p_dst, m_src, m_dst, lin, cin, lout, cout, w.cap, ntx, nty, level_base, stat, stat_hi, n == 0 ? w.tile_mark : nullptr, w.gen, ntiles, scan_limit, z_begin, z_begin + nzp
+#define FX_FREEZE_ARGS grid, block, 0, s, g, p_src, b, p_dst, m_src, m_dst, lin, cin, lout, cout, w.cap, ntx, nty, level_base, stat, stat_hi, n == 0 ? w.tile_mark : nullptr, flag_tag, ntiles, scan_limit, z_begin, z_begin + nzp
 #define FX_FREEZE_LAUNCH(T) if ((g.X & 3) != 0) hipLaunchKernelGGL((k_freeze_tiles<T, 512, false>), FX_FREEZE_ARGS); \
 	else if (nt == 256) hipLaunchKernelGGL((k_freeze_tiles<T, 256, true>), FX_FREEZE_ARGS); \
 	else if (nt == 1024) hipLaunchKernelGGL((k_freeze_tiles<T, 1024, true>), FX_FREEZE_ARGS); \

@@ -364,7 +364,7 @@ static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 {
 	fx_ctx* ctx = lead;                                                 // FX_HIP reports through `ctx`
 	const bool multi = multi_rank(lead);
-	struct Run { Geom v; size_t off; int own0; FreezeWork w; float *src, *a, *d; uint8_t *ma, *md; uint32_t* stat; uint32_t stat_hi; };
+	struct Run { Geom v; size_t off; int own0; FreezeWork w; float *src, *a, *d; uint8_t *ma, *md, *mx; uint32_t* stat; uint32_t stat_hi; };
 	std::vector<Run> R(M.size());
 	std::vector<std::unique_ptr<ScopedMark>> mk(M.size());
 	const bool fuse = lead->fz_fuse_div;
@@ -391,7 +391,7 @@ static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 		r.w = FreezeWork{ m->fz_tile_next, gen, { m->fz_list[0], m->fz_list[1] }, jacobi_freeze_tiles(m->g),
 			m->fz_counts + (gen & 1u) * cw, m->fz_counts + ((gen & 1u) ^ 1u) * cw };
 		r.src = m->p[m->p_cur]; r.a = m->p[m->p_cur ^ 1]; r.d = m->p_aux;
-		r.ma = m->fz_mask[0]; r.md = m->fz_mask[1];
+		r.ma = m->fz_mask[0]; r.md = m->fz_mask[1]; r.mx = m->fz_mask[2];
 		// (The dense sweep writes level 1 to BOTH buffers the tile launches alternate between.  Writing one and letting the first tile
 		// launch carry the unlisted tiles' border cells across was built and measured level: the dense sweep 75 -> 46 us at 256^3, the
 		// first tile launch slower by as much -- the shell of a 4-deep cone around ~3000 listed tiles is more bytes than the second copy.)
@@ -416,7 +416,39 @@ static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 	if (rc) return rc;
 	const int T = jacobi_freeze_levels_per_launch();
 	int level = 1, n = 0;
-	for (uint32_t left = iters - 1; left > 0; ++n) {
+	uint32_t left = iters - 1, flag_tag = 0;
+	// While most tiles still relax the tile launches are dense sweeps in all but name (43 us per level at 256^3, a cone five times the
+	// core per tile): the levels right behind the dense sweep go through the masked strip pipeline instead (fx_jacobi_stripm.hip: three
+	// levels per launch for every cell, ~15 us per level), which leaves level + 3 in two of the three pressure buffers -- they rotate --
+	// and the tile marks for the first tile launch.  Single domain, X = 256.
+	if (!multi && jacobi_freeze_strip_supported(M[0]->g) && M[0]->fz_mask[2]) {
+		fx_ctx* m = M[0];
+		Run& r = R[0];
+		// FREEZE_DENSE_LEVELS: how many (0, 3, 6 ...); default -1 = by what the dense sweeps of the last steps left relaxing -- the count
+		// k_count_marks put into a host-visible word behind the previous solves' dense sweep, read here without waiting (it may be a
+		// step or two old; either choice gives the same fields): three levels once half of the tiles relax.  Young plumes (a fifth of the
+		// tiles) stay on the tile launches, where a masked launch would cost 0.07 ms for nothing.
+		int want = FX_KNOB_INT("FREEZE_DENSE_LEVELS", -1);
+		if (want < 0) {
+			want = 0;
+			if (m->fz_active_dev) {
+				const uint32_t active = *(volatile uint32_t*)m->fz_active_host;
+				if (2u * active >= (uint32_t)jacobi_freeze_tiles(m->g)) want = 3;
+				if ((r.w.gen & 3u) == 0u)                                          // (every fourth solve: the plume changes slowly, the count is a 5-us launch)
+					FX_HIP(launch_count_marks(r.w.tile_mark, r.w.gen, jacobi_freeze_tiles(m->g), m->fz_active_dev, CS(m, s)));
+			}
+		}
+		for (int k = 0; want >= 3 && left > 3; ++k, want -= 3) {
+			DeviceGuard dg(m->device);
+			flag_tag = r.w.gen | ((uint32_t)(k + 1) << 24);
+			FX_HIP(launch_freeze_strip3(r.v, r.a, m->b, r.d, r.src, r.ma, r.md, r.mx, r.w.tile_mark, flag_tag, r.stat, r.stat_hi, level, CS(m, s)));
+			if (mk[0]) { mk[0]->launches += 1; mk[0]->sweeps += 3; }
+			float* na = r.d; r.d = r.src; r.src = r.a; r.a = na;                  // level + 3 now sits in (a, d); the buffer it was read from is the spare
+			uint8_t* nm = r.md; r.md = r.mx; r.mx = r.ma; r.ma = nm;
+			level += 3; left -= 3;
+		}
+	}
+	for (; left > 0; ++n) {
 		const int t = (int)std::min<uint32_t>((uint32_t)T, left);
 		for (size_t i = 0; i < M.size(); ++i) {
 			fx_ctx* m = M[i];
@@ -424,7 +456,7 @@ static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 			DeviceGuard dg(m->device);
 			const size_t moff = r.off / m->g.plane() * (size_t)((m->g.X + 3) / 4) * m->g.Y;
 			if (!mk[i]) mk[i].reset(new ScopedMark(m, CS(m, s), MK_JACOBI_TAIL));
-			FX_HIP(launch_freeze_tiles(r.v, r.a + r.off, m->b + r.off, r.d + r.off, r.ma + moff, r.md + moff, r.w, n, t, level, r.stat, r.stat_hi, CS(m, s), r.own0, m->g.nz));
+			FX_HIP(launch_freeze_tiles(r.v, r.a + r.off, m->b + r.off, r.d + r.off, r.ma + moff, r.md + moff, r.w, n, t, level, r.stat, r.stat_hi, CS(m, s), r.own0, m->g.nz, n == 0 ? flag_tag : 0u));
 			mk[i]->launches += 1; mk[i]->sweeps += (uint64_t)t;
 			if (multi) mk[i].reset();
 			std::swap(r.a, r.d); std::swap(r.ma, r.md);
@@ -433,7 +465,7 @@ static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 		if ((rc = exchange(false))) return rc;                          // the levels just made, kFreezeHalo planes deep (the last one serves the projection)
 	}
 	mk.clear();
-	for (size_t i = 0; i < M.size(); ++i) { fx_ctx* m = M[i]; m->p[0] = R[i].a; m->p[1] = R[i].d; m->p_aux = R[i].src; m->fz_mask[0] = R[i].ma; m->fz_mask[1] = R[i].md; m->p_cur = 0; }
+	for (size_t i = 0; i < M.size(); ++i) { fx_ctx* m = M[i]; m->p[0] = R[i].a; m->p[1] = R[i].d; m->p_aux = R[i].src; m->fz_mask[0] = R[i].ma; m->fz_mask[1] = R[i].md; m->fz_mask[2] = R[i].mx; m->p_cur = 0; }
 	return FX_OK;
 }
 

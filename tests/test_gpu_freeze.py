@@ -155,3 +155,61 @@ def test_freeze_rollout_matches_oracle_128():
     f.Project()
     assert np.array_equal(f.download(fx.FIELD_VELOCITY), orc.project(f.download(fx.FIELD_VELOCITY1), q, True))
     assert np.abs(f.download(fx.FIELD_VELOCITY1) - vo).max() < 1e-3
+
+
+@pytest.mark.parametrize("dims", [(256, 256, 16), (256, 256, 41), (256, 256, 9), (256, 256, 24)])
+@pytest.mark.parametrize("iters,levels", [(5, 3), (7, 6), (17, 3), (17, 9), (64, 3), (64, 12), (4, 3)])
+def test_masked_strip_levels_equal_oracle(dims, iters, levels, knobs):
+    """the levels right behind the dense sweep on the masked strip pipeline (fx_jacobi_stripm.hip: three levels per launch for every cell,
+    freeze nibbles carried along, both output buffers and the tile marks for the first tile launch) instead of tile launches: the
+    oracle's fields and its executed-sweep count, whatever the number of strip launches"""
+    knobs["FLUIDX_FREEZE_DENSE_LEVELS"] = str(levels)
+    X, Y, Z = dims
+    p, b = plume_like(X, Y, Z, 900 + Z + iters, amp=0.08)
+    want, k = orc.jacobi(p, b, iters, mode=1)
+    got, t = solve(dims, p, b, iters)
+    assert np.array_equal(got, want)
+    assert (t.freeze_solves, t.freeze_sweeps) == (1, k)
+
+
+def test_masked_strip_levels_on_frozen_and_on_restless_fields(knobs):
+    knobs["FLUIDX_FREEZE_DENSE_LEVELS"] = "6"
+    dims = (256, 256, 12)
+    z = np.zeros(dims[::-1], f32)
+    got, t = solve(dims, z, z, 64)                       # nothing ever moves: one sweep
+    assert not got.any() and t.freeze_sweeps == 1
+    rng = np.random.default_rng(3)
+    p = rng.standard_normal(dims[::-1]).astype(f32)
+    b = (rng.standard_normal(dims[::-1]) * 0.5).astype(f32)
+    want, k = orc.jacobi(p, b, 20, mode=1)               # nothing freezes early
+    got, t = solve(dims, p, b, 20)
+    assert np.array_equal(got, want) and t.freeze_sweeps == k
+
+
+@pytest.mark.parametrize("storage", ["fp16", "fp32"])
+def test_masked_strip_levels_change_no_step(storage, knobs):
+    """whole steps (divergence fused into the dense sweep, three pressure and three mask buffers rotating from step to step): forced on,
+    chosen by the activity count, or off -- the same fields and the same executed sweeps after 30 steps of a 256 x 256 x 48 plume"""
+    dims, steps = (256, 256, 48), 30
+
+    def run(levels):
+        knobs["FLUIDX_FREEZE_DENSE_LEVELS"] = levels
+        f = make(dims, jacobi_iters=64, jacobi_mode="faithful", storage=storage)
+        f.timing_enable(True)
+        dt = f32(f.default_time_step() * 3.0)
+        for k in range(steps):
+            f.UpdateFrame(dt, k % 3)
+            f.Simulate(k % 3)
+        f.Synchronize()
+        t = f.timing_read(True)
+        out = [f.download(i) for i in (fx.FIELD_VELOCITY, fx.FIELD_COLOR, fx.FIELD_PRESSURE)] + [t.freeze_sweeps, t.freeze_solves]
+        f.Release()
+        return out
+
+    ref = run("0")
+    assert ref[3] > 2 * steps
+    for levels in ("3", "6", "-1"):
+        got = run(levels)
+        for u, v in zip(ref[:3], got[:3]):
+            assert np.array_equal(u.view(np.uint8), v.view(np.uint8)), levels
+        assert ref[3:] == got[3:], levels

@@ -64,7 +64,7 @@ def test_advect_lds_hands_over_behind_exactly_its_stores(tmp_path):
 
 def test_no_scratch_in_the_hot_kernels(tmp_path):
     """register-resident kernels must not spill (a spill turns a bandwidth-bound kernel into a scratch-bound one silently)"""
-    for source, prefix in (("fx_jacobi_freeze.hip", "k_freeze_"), ("fx_advect_lds.hip", "k_advect_lds"), ("fx_advect_lds.hip", "k_advect_far"),
+    for source, prefix in (("fx_jacobi_freeze.hip", "k_freeze_"), ("fx_advect_lds.hip", "k_advect_lds"), ("fx_advect_lds.hip", "k_advect_far"), ("fx_jacobi_stripm.hip", "k_freeze_strip3"),
                            ("fx_render_accel.hip", "k_view_slots"), ("fx_render_accel.hip", "k_light_rays"), ("fx_render_accel.hip", "k_build_fill"),
                            ("fx_render_accel.hip", "k_direct_march")):
         text = "\n".join(device_isa(source, tmp_path))
