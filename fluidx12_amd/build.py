@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libfluidx_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 
-SOURCES = ["fx_api.cpp", "fx_knobs.cpp", "fx_context.cpp", "fx_schedule.cpp", "fx_comm.cpp", "fx_checkpoint.cpp", "fx_sim.hip", "fx_advect_lds.hip", "fx_jacobi_strip.hip", "fx_jacobi_strip3.hip", "fx_jacobi_block.hip", "fx_jacobi_freeze.hip", "fx_jacobi_stripm.hip", "fx_jacobi2d.hip", "fx_render.hip", "fx_render_accel.hip", "fx_resolve.hip", "fx_bc6h.hip", "fx_sh.hip"]
+SOURCES = ["fx_api.cpp", "fx_knobs.cpp", "fx_context.cpp", "fx_schedule.cpp", "fx_comm.cpp", "fx_checkpoint.cpp", "fx_sim.hip", "fx_advect_lds.hip", "fx_jacobi_strip.hip", "fx_jacobi_strip3.hip", "fx_jacobi_strip4.hip", "fx_jacobi_block.hip", "fx_jacobi_freeze.hip", "fx_jacobi_stripm.hip", "fx_jacobi2d.hip", "fx_render.hip", "fx_render_accel.hip", "fx_resolve.hip", "fx_bc6h.hip", "fx_sh.hip"]
 HEADERS = ["fx_internal.h", "fx_context.h", "fx_host.h", "fx_hostmath.h", "fx_pk.h", "fx_march.h", "fx_knobs.h", os.path.join(ROOT, "include", "fluidx_hip.h")]
 
 # -ffp-contract=off: the numerics contract allows a fused multiply-add only where the code
@@ -31,6 +31,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # bit-identical (tests/test_gpu_sim.py).
 EXTRA_FLAGS = {"fx_jacobi_strip3.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] + (["-DFX_STRIP3C_ROWS=" + os.environ["FLUIDX_BUILD_STRIP3C_ROWS"]] if os.environ.get("FLUIDX_BUILD_STRIP3C_ROWS") else []),
                "fx_jacobi_strip.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+               "fx_jacobi_strip4.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] + (["-DFX_STRIP4_OUTER_ROWS=" + os.environ["FLUIDX_BUILD_STRIP4_OUTER_ROWS"]] if os.environ.get("FLUIDX_BUILD_STRIP4_OUTER_ROWS") else []) + os.environ.get("FLUIDX_BUILD_STRIP4_DEFS", "").split(),
                "fx_render_accel.hip": [("-D%s=%s" % (d, os.environ[e])) for e, d in (("FLUIDX_BUILD_MASK_BITS", "FX_MASK_BUDGET_BITS"), ("FLUIDX_BUILD_VIEW_AHEAD", "FX_VIEW_AHEAD"), ("FLUIDX_BUILD_LIGHT_AHEAD", "FX_LIGHT_AHEAD"), ("FLUIDX_BUILD_LIGHT_RAY_WGS", "FX_LIGHT_RAY_WGS"), ("FLUIDX_BUILD_LIGHT_RAY_UNROLL", "FX_LIGHT_RAY_UNROLL"), ("FLUIDX_BUILD_VIEW_NT", "FX_VIEW_NT"), ("FLUIDX_BUILD_VIEW_WPE", "FX_VIEW_WPE")) if os.environ.get(e)],
                # k_freeze_tiles reserves its list slot with a returning atomic whose round trip is meant to pass behind the staging loads;
                # the wave-aggregating atomic optimizer would wait for it on the spot (readfirstlane of the result)

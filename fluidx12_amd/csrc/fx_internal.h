@@ -78,6 +78,9 @@ hipError_t launch_jacobi_strip(const Geom& g, const float* p_in, const float* b,
 // three sweeps per launch, register strips + the LDS as a second register file (fx_jacobi_strip3.hip; X = 256)
 bool jacobi_strip3_supported(const Geom& g);
 hipError_t launch_jacobi_strip3(const Geom& g, const float* p_in, const float* b, float* p_out, int z_begin, int z_end, hipStream_t s);
+// four sweeps per launch, a workgroup's four waves as a quad over 16 rows (fx_jacobi_strip4.hip; X = 256, Y % 16 == 0)
+bool jacobi_strip4_supported(const Geom& g);
+hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b, float* p_out, int z_begin, int z_end, hipStream_t s);
 // two sweeps per launch, one 4 x 4-row block per wave (fx_jacobi_block.hip; X = 128)
 bool jacobi_block2_supported(const Geom& g);
 hipError_t launch_jacobi_block2(const Geom& g, const float* p_in, const float* b, float* p_out, int z_begin, int z_end, hipStream_t s);
@@ -120,6 +123,7 @@ hipError_t launch_jacobi2d(const Geom& g, const float* p_in, const float* b, flo
 // sweeps fused per launch for this geometry (1 = no fused path); requested > 0 overrides the default
 int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp);
 bool jacobi_prefers_three(const Geom& g, int requested, int nzp);
+bool jacobi_prefers_four(const Geom& g, int requested, int nzp);
 // rec (optional, slab ranks): the step record of launch_face_need is produced by this launch when it can be (fp32 3-D kernel
 // over exactly the owned planes); *rec_done tells whether it was
 hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const float* p,

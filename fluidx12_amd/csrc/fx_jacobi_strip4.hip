@@ -1,0 +1,432 @@
+// fx_jacobi_strip4.hip -- FOUR lock-step Jacobi sweeps per launch (X = 256): k_jacobi_strip3c's streaming register / LDS windows, with a
+// workgroup's four waves as a QUAD that shares 16 rows.
+//
+// Restates CSPoisson.hlsli:8-26 (/root/reference/FluidX12/Content/Shaders/) like every Jacobi kernel here: the per-cell arithmetic and its
+// association order, ((((((L - b) + R) + U) + D) + F) + B) * (1/6), are unchanged (relax4_pairs, fx_pk.h), so four fused sweeps are
+// bit-identical to four single ones.
+//
+// Why a quad.  k_jacobi_strip3c (fx_jacobi_strip3.hip) is a PAIR design: two 4-row strips, each recomputing its outer y-halo.  A fourth
+// level in that design needs 22 row updates per z step and wave for 16 useful ones, 36 LDS rows per wave + a 24-KiB mailbox (168 KiB: more
+// than the CU has) and ~400 registers.  Here the workgroup's waves take 3 + 5 + 5 + 3 rows of a 16-row band: only the two OUTER waves
+// recompute a halo (their outer side: 6 + 5 + 4 + 3 = 18 row updates per z step), the two INNER waves recompute nothing (4 x 5 = 20) --
+// every row a wave needs across an inner boundary is its neighbour's own edge row of the previous z step, handed over through a 1-KiB LDS
+// mailbox per level, direction and step parity, ordered by per-wave step counters exactly as in k_jacobi_strip3c (wait for the neighbour's
+// step q - 1, read, only then publish step q: a wave may run a step ahead of its neighbours).  76 row updates per z step and workgroup for
+// 64 useful ones (1.19; the pair design with four levels: 1.375, with three: 1.25), windows of 45 float4 per wave (three planes of levels
+// 1..3), LDS 2 x 31 + 2 x 29 rows + 36 mailbox rows = 156 KiB.
+//
+// Per z step q (input plane q in registers, prefetched during step q - 1); level-l plane q - l is produced by sweep l:
+//   sweep 1   from input planes q-2, q-1 (LDS) and q (registers), b[q-1] (registers); then the plane in flight and the b rows later
+//             levels need go to the LDS and the prefetch of plane q + 1 / b[q] is issued
+//   sweep l   (2..4) from the level l-1 window (registers) and b[q-l] (LDS); the neighbours' edge rows of level l-1 come from the mailbox
+//   sweep 4   is the output, stored if plane q - 4 lies inside the chunk
+// Traffic: p and b are read once (+ 8 halo planes per chunk of 16) and the result written once per FOUR sweeps.
+#include "fx_internal.h"
+#include "fx_pk.h"
+#include <climits>
+#include <cstdlib>
+
+namespace fx {
+
+namespace {
+
+#ifndef FX_STRIP4_OUTER_ROWS
+#define FX_STRIP4_OUTER_ROWS 3
+#endif
+constexpr int NRO = FX_STRIP4_OUTER_ROWS;   // rows of an outer wave
+constexpr int NRI = 8 - NRO;                // rows of an inner wave (a workgroup = 2 x (NRO + NRI) = 16 rows)
+
+// A: the wave recomputes a halo ABOVE its rows (the quad's top wave), W: below (the bottom wave).
+template <int NR_, bool A_, bool W_> struct Role4 {
+	static constexpr int NR = NR_;
+	static constexpr bool A = A_, W = W_;
+	static constexpr int NI = NR + (A ? 4 : 1) + (W ? 4 : 1);                 // input rows per plane; row i <-> y0 - (A ? 4 : 1) + i
+	static constexpr int N1 = NR + (A ? 3 : 0) + (W ? 3 : 0);                 // level-l rows; row j <-> y0 - (A ? 4 - l : 0) + j
+	static constexpr int N2 = NR + (A ? 2 : 0) + (W ? 2 : 0);
+	static constexpr int N3 = NR + (A ? 1 : 0) + (W ? 1 : 0);
+	static constexpr int UP = A ? 1 : 0;                                      // index shift between consecutive levels
+	static constexpr int LDS_ROWS = 2 * NI + 3 * N2;                          // two input planes, three parked b planes (rows of level 2)
+};
+typedef Role4<NRO, true, false> RoleTop;
+typedef Role4<NRI, false, false> RoleMid;
+typedef Role4<NRO, false, true> RoleBot;
+constexpr int Q_LDS_ROWS = RoleTop::LDS_ROWS + 2 * RoleMid::LDS_ROWS + RoleBot::LDS_ROWS;
+constexpr int Q_XROWS = 2 * 3 * 3 * 2;          // [step parity][boundary][level 1..3][0: the upper wave's row, 1: the lower wave's]
+static_assert((Q_LDS_ROWS + Q_XROWS) * 1024 + 64 <= 160 * 1024, "the quad's windows must fit the CU's LDS");
+
+__device__ __forceinline__ constexpr int xrow(int par, int bnd, int lv, int dir) { return ((((par * 3 + bnd) * 3 + lv) * 2 + dir)) * 64; }
+
+// the windows are native vectors, not HIP's float4 struct: a struct copied under a condition becomes a select of POINTERS into the window
+// array, which keeps the whole array out of registers
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 f4(v4f v) { return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ v4f relax4q(v4f c, v4f U, v4f D, v4f F, v4f Bk, v4f bb)
+{
+	const float4 r = relax4_pairs(f4(c), f4(U), f4(D), f4(F), f4(Bk), f4(bb), 0.0f, true, true);
+	return v4f{ r.x, r.y, r.z, r.w };
+}
+
+__device__ __forceinline__ uint32_t opaque32q(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
+
+// counter and row in ONE LDS round trip (see k_jacobi_strip3c): a counter that is high enough vouches for the row read behind it
+__device__ __forceinline__ v4f lds_wait_read4(uint32_t flag_byte_addr, int need, uint32_t row_byte_addr)
+{
+	int f;
+	v4f d;
+	for (int spins = 0;; ++spins) {
+		asm volatile("ds_read_b32 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f), "=&v"(d) : "v"(flag_byte_addr), "v"(row_byte_addr) : "memory");
+		if (f >= need || spins > (1 << 16)) break;                       // (bounded: a neighbour is a z step away, ~2 us; a protocol error must not hang the device)
+		__builtin_amdgcn_s_sleep(1);
+	}
+	return d;
+}
+__device__ __forceinline__ void lds_post4(uint32_t lds_byte_addr, int v)
+{
+	asm volatile("ds_write_b32 %0, %1" :: "v"(lds_byte_addr), "v"(v) : "memory");
+}
+
+// what a wave carries along z
+// (the register windows are separate local arrays of run4: one aggregate of all of them is not split into registers by the compiler)
+template <class R> struct Strip4 {
+	int s_ctr, s_old, s_b2, s_b3, s_b4;            // LDS slots (v4f offsets into the wave's slice): input planes q-1, q-2; b[q-2], b[q-3], b[q-4]
+	const char* pp; const char* pbq; char* po; char* po_zb;     // plane bases walking along with q: input plane q+1, b plane q+1, output plane q-4
+	size_t plane_bytes;
+	v4f* lds; v4f* xbuf; int* xflag;
+	uint32_t xf0, xb0;                             // LDS byte addresses of the step counters and of the mailbox
+	int q, zb, ze, q_load_last, b_load_last, Zg, wave, lane;
+	bool wall_top, wall_bot;                       // the strip's first own row is y = 0 / its last own row is y = Y - 1
+};
+
+#define FXQ_LDS(st, slot, r) (st).lds[(slot) + (r) * 64]
+
+// Hand-over of level L (1..3).  The neighbours' edge rows of THEIR step q - 1 (plane q - 1 - L: the centre plane of this step's sweep
+// L + 1) come in, mine of this step (plane q - L) go out.  Order per level: read the neighbours' rows, make sure they were there
+// (their counter), only then publish mine and my counter -- a wave that sees my counter at q knows I have read what it wrote two steps
+// ago into the slot it is about to reuse, so two slots (step parity) suffice and a wave may run ahead of its neighbours.
+// The read is ISSUED one sweep early (mail_fetch4: level 1 at the top of the step, level L behind hand-over L - 1) as compiler-visible
+// LDS loads and only checked here: issued where it is needed, each hand-over is an exposed LDS round trip per neighbour -- six per step
+// for an inner wave, 12.5 us of a 58-us launch (measured by leaving the hand-overs out).  A row fetched before its owner had published
+// it (its counter says so) is fetched again by the waiting loop.
+template <class R> struct Mail4 { int fu, fd; v4f hu, hd; };
+
+template <class R, int L>
+__device__ __forceinline__ void mail_fetch4(const Strip4<R>& st, Mail4<R>& m)
+{
+#ifdef FX_S4_NOHAND
+	return;
+#endif
+	const int q = st.q, w = st.wave, pr = (q - 1) & 1;
+	const int* flags = reinterpret_cast<const int*>(st.xflag);
+	// counter first, row behind it: a wave's LDS operations execute in order, so a counter that is high enough vouches for the row
+	if (!R::A) m.fu = __hip_atomic_load(flags + (L - 1) * 4 + w - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	if (!R::W) m.fd = __hip_atomic_load(flags + (L - 1) * 4 + w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	asm volatile("" ::: "memory");
+	__builtin_amdgcn_sched_barrier(0);
+	if (!R::A) m.hu = st.xbuf[xrow(pr, w - 1, L - 1, 0) + st.lane];
+	if (!R::W) m.hd = st.xbuf[xrow(pr, w, L - 1, 1) + st.lane];
+	asm volatile("" ::: "memory");
+	__builtin_amdgcn_sched_barrier(0);                                  // (the machine scheduler would otherwise sink the row loads to their use)
+}
+
+template <class R, int L>
+__device__ __forceinline__ void hand_over4(const Strip4<R>& st, Mail4<R>& m, const v4f mine_top, const v4f mine_bot, v4f& HU, v4f& HD)
+{
+#ifdef FX_S4_NOHAND
+	return;
+#endif
+	const int q = st.q, w = st.wave;
+	const int pr = (q - 1) & 1, pw = q & 1;
+	if (!R::A) {
+		if (__builtin_expect(m.fu < q - 1, 0)) m.hu = lds_wait_read4(st.xf0 + 4u * (uint32_t)((L - 1) * 4 + w - 1), q - 1, st.xb0 + 16u * (uint32_t)(xrow(pr, w - 1, L - 1, 0) + st.lane));
+		HU = m.hu;
+	}
+	if (!R::W) {
+		if (__builtin_expect(m.fd < q - 1, 0)) m.hd = lds_wait_read4(st.xf0 + 4u * (uint32_t)((L - 1) * 4 + w + 1), q - 1, st.xb0 + 16u * (uint32_t)(xrow(pr, w, L - 1, 1) + st.lane));
+		HD = m.hd;
+	}
+	asm volatile("" ::: "memory");
+	if (!R::A) st.xbuf[xrow(pw, w - 1, L - 1, 1) + st.lane] = mine_top;
+	if (!R::W) st.xbuf[xrow(pw, w, L - 1, 0) + st.lane] = mine_bot;
+	if (st.lane == 0) lds_post4(st.xf0 + 4u * (uint32_t)((L - 1) * 4 + w), q);        // LDS operations of a wave execute in order
+}
+
+// sweep L + 1 from the window of level L (NL rows) into NN rows; b rows from `Brow`
+template <class R, int L, int NL, int NN>
+__device__ __forceinline__ void relax_level4(const Strip4<R>& st, const v4f (&Pold)[NL], const v4f (&Pctr)[NL], const v4f (&Pnew)[NL],
+	const v4f (&Bq)[NN], v4f HU, v4f HD, v4f (&out)[NN])
+{
+#pragma unroll
+	for (int k = 0; k < NN; ++k) {
+		constexpr int UP = R::UP;
+		const int jc = k + UP;                                           // level-L index of this row
+		const v4f c = Pctr[jc];
+		v4f u = jc >= 1 ? Pctr[jc >= 1 ? jc - 1 : 0] : HU;
+		v4f d = jc + 1 < NL ? Pctr[jc + 1 < NL ? jc + 1 : 0] : HD;
+		if (R::A && k == 3 - L && st.wall_top) u = c;                    // rows outside the domain hold no data
+		if (R::W && k == R::NR - 1 && st.wall_bot) d = c;
+		out[k] = relax4q(c, u, d, Pold[jc], Pnew[jc], Bq[k]);
+	}
+}
+
+template <class R, int PH, bool S1, bool S2, bool S3, bool S4>
+__device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&P2)[3][R::N2], v4f (&P3)[3][R::N3], v4f (&NP)[R::NI], v4f (&NB)[R::N1], v4f (&NBn)[R::N1], const uint32_t (&roff)[R::NI])
+{
+	constexpr int NEW = PH % 3, CTR = (PH + 2) % 3, OLD = (PH + 1) % 3;
+	constexpr int NI = R::NI, N1 = R::N1, N2 = R::N2, N3 = R::N3, NR = R::NR, UP = R::UP;
+	const int q = st.q;
+	const v4f zero = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+	Mail4<R> M1, M2, M3;
+	M1.fu = M1.fd = M2.fu = M2.fd = M3.fu = M3.fd = INT_MIN; M1.hu = M1.hd = M2.hu = M2.hd = M3.hu = M3.hd = zero;
+	if (S1) mail_fetch4<R, 1>(st, M1);
+	// ---- sweep 1: level-1 plane q-1 -----------------------------------------------------------------------------------
+	if (q == 0) {                                                       // input plane -1 := plane 0, once (clamped front neighbour)
+#pragma unroll
+		for (int i = 0; i < NI; ++i) FXQ_LDS(st, st.s_ctr, i) = NP[i];
+	}
+	if (S1) {
+		// (the new plane goes through a local first and into the window by unconditional stores: stores to different window slots in the two
+		// arms of a branch are merged by the compiler into one store through a selected POINTER, which keeps those slots in scratch)
+		v4f T_[N1];
+		if (q - 1 == st.Zg) {                                            // level-1 plane Zg := plane Zg-1
+#pragma unroll
+			for (int j = 0; j < N1; ++j) T_[j] = P1[CTR][j];
+		} else {
+			v4f C_[NI], F_[N1];                                           // all LDS rows first: one wave per SIMD cannot hide a ds_read next to its use
+#pragma unroll
+			for (int i = 0; i < NI; ++i) C_[i] = FXQ_LDS(st, st.s_ctr, i);
+#pragma unroll
+			for (int j = 0; j < N1; ++j) F_[j] = FXQ_LDS(st, st.s_old, j + 1);
+#pragma unroll
+			for (int j = 0; j < N1; ++j) T_[j] = relax4q(C_[j + 1], C_[j], C_[j + 2], F_[j], NP[j + 1], NB[j]);
+		}
+#pragma unroll
+		for (int j = 0; j < N1; ++j) P1[NEW][j] = T_[j];
+		if (q - 1 == 0) {                                               // level-1 plane -1 := plane 0
+#pragma unroll
+			for (int j = 0; j < N1; ++j) P1[CTR][j] = T_[j];
+		}
+	}
+	// b[q-4] (the output rows) leaves its slot before b[q-1] moves in; b[q-2] (rows of level 2) is wanted next
+	v4f B4_[NR], B2_[N2];
+#pragma unroll
+	for (int m = 0; m < NR; ++m) B4_[m] = FXQ_LDS(st, st.s_b4, m + 2 * UP);
+#pragma unroll
+	for (int k = 0; k < N2; ++k) B2_[k] = FXQ_LDS(st, st.s_b2, k);
+	// the plane in flight moves to the LDS (over input plane q-2, dead now); the rows of b[q-1] later levels need over b[q-4]
+#pragma unroll
+	for (int i = 0; i < NI; ++i) FXQ_LDS(st, st.s_old, i) = NP[i];
+#pragma unroll
+	for (int k = 0; k < N2; ++k) FXQ_LDS(st, st.s_b4, k) = NB[k + UP];
+	{ const int t_ = st.s_old; st.s_old = st.s_ctr; st.s_ctr = t_; }
+	{ const int t_ = st.s_b4; st.s_b4 = st.s_b3; st.s_b3 = st.s_b2; st.s_b2 = t_; }     // after this: s_b2 = b[q-1], s_b3 = b[q-2], s_b4 = b[q-3]
+	// b is what a sweep 1 needs FIRST (L - b opens every cell's sum): it is fetched TWO steps ahead -- b[q + 1] is issued here, into its own
+	// registers, and moves into NB a step later -- and ahead of the input plane, which sweep 1 adds last
+#pragma unroll
+	for (int j = 0; j < N1; ++j) NB[j] = NBn[j];
+#ifdef FX_S4_NOLOAD
+	if (q + 1 <= st.b_load_last && q < -1000) {
+#else
+	if (q + 1 <= st.b_load_last) {
+#endif
+#pragma unroll
+		for (int j = 0; j < N1; ++j) NBn[j] = *reinterpret_cast<const v4f*>(st.pbq + opaque32q(roff[j + 1]));
+	}
+#ifdef FX_S4_NOLOAD
+	if (q + 1 <= st.q_load_last && q < -1000) {
+#else
+	if (q + 1 <= st.q_load_last) {
+#endif
+#pragma unroll
+		for (int i = 0; i < NI; ++i) NP[i] = *reinterpret_cast<const v4f*>(st.pp + opaque32q(roff[i]));
+	}
+	st.pp += st.plane_bytes; st.pbq += st.plane_bytes;
+	// hand-over 1, BEHIND the prefetch issue: a wait here must not delay the loads
+	v4f HU1 = zero, HD1 = zero;
+	if (S1) hand_over4<R, 1>(st, M1, P1[NEW][0], P1[NEW][N1 - 1], HU1, HD1);
+	if (S2) mail_fetch4<R, 2>(st, M2);
+	// ---- sweep 2: level-2 plane q-2 -----------------------------------------------------------------------------------
+	if (S2) {
+		v4f T_[N2];
+		if (q - 2 == st.Zg) {
+#pragma unroll
+			for (int k = 0; k < N2; ++k) T_[k] = P2[CTR][k];
+		} else {
+			relax_level4<R, 1, N1, N2>(st, P1[OLD], P1[CTR], P1[NEW], B2_, HU1, HD1, T_);
+		}
+#pragma unroll
+		for (int k = 0; k < N2; ++k) P2[NEW][k] = T_[k];
+		if (q - 2 == 0) {                                               // level-2 plane -1 := plane 0
+#pragma unroll
+			for (int k = 0; k < N2; ++k) P2[CTR][k] = T_[k];
+		}
+	}
+	v4f B3_[N3];                                                     // b[q-3] (after the rotation: s_b4), rows of level 3
+#pragma unroll
+	for (int m = 0; m < N3; ++m) B3_[m] = FXQ_LDS(st, st.s_b4, m + UP);
+	v4f HU2 = zero, HD2 = zero;
+	if (S2) hand_over4<R, 2>(st, M2, P2[NEW][0], P2[NEW][N2 - 1], HU2, HD2);
+	if (S3) mail_fetch4<R, 3>(st, M3);
+	// ---- sweep 3: level-3 plane q-3 -----------------------------------------------------------------------------------
+	if (S3) {
+		v4f T_[N3];
+		if (q - 3 == st.Zg) {
+#pragma unroll
+			for (int m = 0; m < N3; ++m) T_[m] = P3[CTR][m];
+		} else {
+			relax_level4<R, 2, N2, N3>(st, P2[OLD], P2[CTR], P2[NEW], B3_, HU2, HD2, T_);
+		}
+#pragma unroll
+		for (int m = 0; m < N3; ++m) P3[NEW][m] = T_[m];
+		if (q - 3 == 0) {                                               // level-3 plane -1 := plane 0
+#pragma unroll
+			for (int m = 0; m < N3; ++m) P3[CTR][m] = T_[m];
+		}
+	}
+	v4f HU3 = zero, HD3 = zero;
+	if (S3) hand_over4<R, 3>(st, M3, P3[NEW][0], P3[NEW][N3 - 1], HU3, HD3);
+	// ---- sweep 4: output plane q-4 ------------------------------------------------------------------------------------
+	if (S4) {
+		// UNCONDITIONAL stores: behind a branch the compiler counts no store when it waits for the prefetched rows of the next step, and each
+		// of those waits then drains a store as well.  A step whose output plane lies below the chunk (the first steps of a chunk that starts at
+		// the first present plane) writes its rows over plane zb instead, which this wave stores for good a few steps later (the stores of a
+		// wave to one address keep their order); no step of the loop lies above the chunk (q <= ze + 3).
+		v4f X_[NR];
+		relax_level4<R, 3, N3, NR>(st, P3[OLD], P3[CTR], P3[NEW], B4_, HU3, HD3, X_);
+		char* dst_ = q - 4 >= st.zb ? st.po : st.po_zb;
+#ifdef FX_S4_NOSTORE
+		if (q < -1000)                                                   // (experiment: the arithmetic stays, the stores never execute)
+#endif
+#pragma unroll
+		for (int m = 0; m < NR; ++m) *reinterpret_cast<v4f*>(dst_ + opaque32q(roff[m + (R::A ? 4 : 1)])) = X_[m];
+	}
+	st.po += st.plane_bytes;
+	++st.q;
+}
+
+template <class R>
+__device__ __forceinline__ void run4(const Geom& g, const float* __restrict__ p_in, const float* __restrict__ b, float* __restrict__ p_out,
+	int zb, int ze, int y0, int wave, int lane, v4f* lds_slice, v4f* xbuf, int* xflag)
+{
+	Strip4<R> st;
+	v4f P1[3][R::N1], P2[3][R::N2], P3[3][R::N3], NP[R::NI], NB[R::N1], NBn[R::N1];
+	uint32_t roff[R::NI];
+	const v4f zero = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+	const int qs = max(zb - 4, g.zlo), q_last = ze - 1 + 4;
+	st.q_load_last = min(q_last, g.zhi);
+	st.b_load_last = min(q_last - 1, g.zhi);
+	st.zb = zb; st.ze = ze; st.Zg = g.Zg; st.wave = wave; st.lane = lane;
+	st.wall_top = y0 == 0; st.wall_bot = y0 + R::NR >= g.Y;
+	st.lds = lds_slice + lane; st.xbuf = xbuf; st.xflag = xflag;
+	st.xf0 = (uint32_t)(size_t)(__attribute__((address_space(3))) int*)xflag;
+	st.xb0 = (uint32_t)(size_t)(__attribute__((address_space(3))) v4f*)xbuf;
+	const int yb = y0 - (R::A ? 4 : 1);
+#pragma unroll
+	for (int i = 0; i < R::NI; ++i) roff[i] = ((uint32_t)min(max(yb + i, 0), g.Y - 1) * (uint32_t)g.X + 4u * (uint32_t)lane) * 4u;
+	st.s_ctr = 0; st.s_old = R::NI * 64;
+	st.s_b2 = 2 * R::NI * 64; st.s_b3 = st.s_b2 + R::N2 * 64; st.s_b4 = st.s_b3 + R::N2 * 64;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+#pragma unroll
+		for (int i = 0; i < R::N1; ++i) P1[k][i] = zero;
+#pragma unroll
+		for (int i = 0; i < R::N2; ++i) P2[k][i] = zero;
+#pragma unroll
+		for (int i = 0; i < R::N3; ++i) P3[k][i] = zero;
+	}
+#pragma unroll
+	for (int i = 0; i < R::LDS_ROWS; ++i) st.lds[i * 64] = zero;
+	const size_t plane = g.plane();
+	st.plane_bytes = plane * 4;
+	{
+		const char* pb = reinterpret_cast<const char*>(p_in + (size_t)g.lz(min(qs, st.q_load_last)) * plane);
+#pragma unroll
+		for (int i = 0; i < R::NI; ++i) NP[i] = *reinterpret_cast<const v4f*>(pb + roff[i]);
+		const char* bbase = reinterpret_cast<const char*>(b + (size_t)g.lz(min(max(qs - 1, g.zlo), g.zhi)) * plane);
+#pragma unroll
+		for (int j = 0; j < R::N1; ++j) NB[j] = *reinterpret_cast<const v4f*>(bbase + roff[j + 1]);
+		const char* bnext = reinterpret_cast<const char*>(b + (size_t)g.lz(min(max(qs, g.zlo), g.zhi)) * plane);
+#pragma unroll
+		for (int j = 0; j < R::N1; ++j) NBn[j] = *reinterpret_cast<const v4f*>(bnext + roff[j + 1]);
+	}
+	st.q = qs;
+	st.pp = reinterpret_cast<const char*>(p_in) + ((ptrdiff_t)g.lz(qs) + 1) * (ptrdiff_t)st.plane_bytes;
+	st.pbq = reinterpret_cast<const char*>(b) + ((ptrdiff_t)g.lz(qs) + 1) * (ptrdiff_t)st.plane_bytes;
+	st.po_zb = reinterpret_cast<char*>(p_out) + (ptrdiff_t)g.lz(zb) * (ptrdiff_t)st.plane_bytes;
+	st.po = reinterpret_cast<char*>(p_out) + ((ptrdiff_t)g.lz(qs) - 4) * (ptrdiff_t)st.plane_bytes;      // (only dereferenced for planes inside the chunk)
+	// the pipeline's fill, peeled as in k_jacobi_strip3c: level-l planes below zb - 4 + l feed nothing that is stored
+	if (qs == zb - 4) {
+		step4<R, 1, false, false, false, false>(st, P1, P2, P3, NP, NB, NBn, roff);
+		step4<R, 2, false, false, false, false>(st, P1, P2, P3, NP, NB, NBn, roff);
+		step4<R, 0, true, false, false, false>(st, P1, P2, P3, NP, NB, NBn, roff);
+		step4<R, 1, true, false, false, false>(st, P1, P2, P3, NP, NB, NBn, roff);
+		step4<R, 2, true, true, false, false>(st, P1, P2, P3, NP, NB, NBn, roff);
+		step4<R, 0, true, true, false, false>(st, P1, P2, P3, NP, NB, NBn, roff);
+		step4<R, 1, true, true, true, false>(st, P1, P2, P3, NP, NB, NBn, roff);
+		step4<R, 2, true, true, true, false>(st, P1, P2, P3, NP, NB, NBn, roff);
+	}
+	for (;;) {
+		step4<R, 0, true, true, true, true>(st, P1, P2, P3, NP, NB, NBn, roff);
+		if (st.q > q_last) break;
+		step4<R, 1, true, true, true, true>(st, P1, P2, P3, NP, NB, NBn, roff);
+		if (st.q > q_last) break;
+		step4<R, 2, true, true, true, true>(st, P1, P2, P3, NP, NB, NBn, roff);
+		if (st.q > q_last) break;
+	}
+}
+
+__global__ __launch_bounds__(256, 1) void k_jacobi_strip4q(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
+	float* __restrict__ p_out, int z_begin, int z_end, int zchunk, int ngroups, int nchunks, int remap)
+{
+	__shared__ v4f lds_all[Q_LDS_ROWS * 64];
+	__shared__ v4f xbuf[Q_XROWS * 64];
+	__shared__ int xflag[16];                                          // [level 1..3][wave]: the last z step whose edge rows the wave has published
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	int tile = (int)blockIdx.x;
+	if (remap) {                                                        // XCD k walks the k-th contiguous eighth of the tile sequence
+		const int n = ngroups * nchunks, qn = n >> 3, r = n & 7;
+		const int xcd = tile & 7, j = tile >> 3;
+		tile = xcd * qn + min(xcd, r) + j;
+	}
+	const int grp = tile % ngroups, chunk = tile / ngroups;
+	const int zb = z_begin + chunk * zchunk, ze = min(zb + zchunk, z_end);
+	const int qs = max(zb - 4, g.zlo);
+	const bool fill = qs == zb - 4;
+	// the counters start where the first active hand-over of each level expects them (level l: step qs + 2 l)
+	if (threadIdx.x < 12) xflag[threadIdx.x] = fill ? qs + 2 * ((int)threadIdx.x / 4 + 1) - 1 : qs - 1;
+	for (int i = (int)threadIdx.x; i < Q_XROWS * 64; i += 256) xbuf[i] = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+	__syncthreads();
+	const int yg = grp * 16;
+#ifdef FX_S4_ALLMID
+	run4<RoleMid>(g, p_in, b, p_out, zb, ze, yg + 4 * wave, wave, lane, lds_all + (wave * RoleTop::LDS_ROWS) * 64, xbuf, xflag);
+	return;
+#endif
+	if (wave == 0) run4<RoleTop>(g, p_in, b, p_out, zb, ze, yg, wave, lane, lds_all, xbuf, xflag);
+	else if (wave == 3) run4<RoleBot>(g, p_in, b, p_out, zb, ze, yg + NRO + 2 * NRI, wave, lane, lds_all + (RoleTop::LDS_ROWS + 2 * RoleMid::LDS_ROWS) * 64, xbuf, xflag);
+	else run4<RoleMid>(g, p_in, b, p_out, zb, ze, yg + NRO + (wave - 1) * NRI, wave, lane, lds_all + (RoleTop::LDS_ROWS + (wave - 1) * RoleMid::LDS_ROWS) * 64, xbuf, xflag);
+}
+
+}  // namespace
+
+bool jacobi_strip4_supported(const Geom& g)
+{
+	return g.Zg > 1 && g.X == 256 && (g.Y & 15) == 0 && g.Y >= 16;
+}
+
+hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b, float* p_out, int z_begin, int z_end, hipStream_t s)
+{
+	if (z_end <= z_begin) return hipSuccess;
+	if (!jacobi_strip4_supported(g)) return hipErrorNotSupported;
+	const int forced_chunk = FX_KNOB_INT("STRIP4_ZCHUNK", 0);
+	const int remap = FX_KNOB_INT("STRIP_REMAP", 1);
+	const int ngroups = g.Y / 16;
+	const int nzp = z_end - z_begin;
+	int nchunks = (256 + ngroups - 1) / ngroups;                        // 256 workgroups of four waves: one wave per SIMD
+	int zchunk = forced_chunk > 0 ? forced_chunk : (nzp + nchunks - 1) / nchunks;
+	if (zchunk < 8) zchunk = 8;
+	if (zchunk > nzp) zchunk = nzp;
+	nchunks = (nzp + zchunk - 1) / zchunk;
+	hipLaunchKernelGGL(k_jacobi_strip4q, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
+	return hipGetLastError();
+}
+
+}  // namespace fx

@@ -327,6 +327,8 @@ static int jacobi_round(fx_ctx* ctx, hipStream_t s, int count, ScopedMark* mk)
 		int t = std::min(left, fused_sweeps(ctx));
 		if (!ctx->frozen && !takes_2d_tiles(ctx) && jacobi_prefers_three(ctx->g, (int)(ctx->desc.flags & FX_FLAG_JACOBI_FUSE_MASK), ctx->g.nz))
 			t = left == 4 ? 2 : std::min(left, 3);           // threes, and a remainder of 4 as 2 + 2 rather than 3 + 1
+		if (!ctx->frozen && !takes_2d_tiles(ctx) && jacobi_prefers_four(ctx->g, (int)(ctx->desc.flags & FX_FLAG_JACOBI_FUSE_MASK), ctx->g.nz))
+			t = left >= 7 || left == 4 ? 4 : std::min(left, 3);   // fours; a remainder of 5 / 6 as 3 + 2 / 3 + 3
 		if (mk && mk->kind == MK_JACOBI && mk->launches && t * mk->launches < mk->sweeps) mk->split(MK_JACOBI_TAIL);   // shorter launches from here on
 		const int rc = jacobi_launch(ctx, s, ctx->p_cur, t, grown(ctx, multi_rank(ctx) ? left - t : 0), mk);
 		if (rc) return rc;

@@ -1016,7 +1016,17 @@ int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp)
 	// default: two sweeps per launch in the register-strip kernel (fx_jacobi_strip.hip) where the geometry allows it,
 	// else one sweep per launch
 	const int t = requested > 0 ? requested : (forced > 0 ? forced : (strip_profitable(g, nzp) ? 2 : 1));
+	if (t >= 4 && jacobi_strip4_supported(g) && nzp >= 2) return 4;     // four sweeps: the quad kernel (fx_jacobi_strip4.hip)
 	return t < 1 ? 1 : (t > 3 ? 3 : t);
+}
+
+// FOUR sweeps per launch (k_jacobi_strip4q) where that kernel exists and the launch is large enough to fill the chip with 16-plane chunks:
+// 40 sweeps = 10 launches.  JACOBI_PREFER4=0 keeps the threes; an explicit jacobi_fuse / JACOBI_T request is always honoured as given.
+bool jacobi_prefers_four(const Geom& g, int requested, int nzp)
+{
+	const int forced = FX_KNOB_INT("JACOBI_T", 0);
+	const int prefer = FX_KNOB_INT("JACOBI_PREFER4", 1);
+	return prefer && !requested && !forced && jacobi_strip4_supported(g) && (size_t)g.X * g.Y * (size_t)nzp >= (size_t)3 << 22;
 }
 
 // Default schedule of the serial rounds (single domain, and slab ranks thick enough): THREE sweeps per launch (k_jacobi_strip3) where that kernel exists and the grid is large
@@ -1053,7 +1063,8 @@ hipError_t launch_jacobi_fused(const Geom& g, const float* p_in, const float* b,
 		if (!no_lds3 && jacobi_strip3_supported(g)) return launch_jacobi_strip3(g, p_in, b, p_out, z_begin, z_end, s);
 		return launch_jacobi_strip(g, p_in, b, p_out, 3, z_begin, z_end, s);
 	}
-	default: return hipErrorNotSupported;            // (jacobi_fused_max_sweeps never offers more than three)
+	case 4: return launch_jacobi_strip4(g, p_in, b, p_out, z_begin, z_end, s);     // (hipErrorNotSupported where the quad kernel does not exist)
+	default: return hipErrorNotSupported;            // (jacobi_fused_max_sweeps never offers more than four)
 	}
 }
 

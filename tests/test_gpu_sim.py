@@ -186,6 +186,46 @@ def test_x256_three_sweeps_at_odd_depths_bit_exact(depth):
     assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
 
 
+@pytest.mark.parametrize("depth", [2, 4, 5, 9, 17, 33, 50, 128])
+def test_x256_four_sweeps_at_odd_depths_bit_exact(depth):
+    """X = 256, FOUR sweeps per launch (k_jacobi_strip4q: a workgroup's four waves as a quad over 16 rows, edge rows handed over through
+    LDS mailboxes) on odd and tiny depths: chunks of unequal length, the pipeline's fill and drain next to both domain faces, the y
+    walls in the first and last quad; == oracle, bit for bit"""
+    rows = 256
+    dims = (256, rows, depth)
+    _, _, p = rand_state(*dims, 41)
+    b = np.random.default_rng(42).uniform(-1, 1, (depth, rows, 256)).astype(f32)
+    f = make(dims, jacobi_iters=8, jacobi_fuse=4)
+    f.upload(fx.FIELD_PRESSURE, p)
+    f.upload(fx.FIELD_DIVERGENCE, b)
+    f.timing_enable(True); f.timing_read(True)
+    f.Jacobi(8)
+    f.Synchronize()
+    assert f.timing_read(True).jacobi_launches == 2
+    q, _ = orc.jacobi(p, b, 8)
+    assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
+
+
+def test_x256_default_schedule_runs_fours_bit_exact():
+    """the default schedule at 256^3-class sizes: 40 sweeps = ten launches of k_jacobi_strip4q; 256 x 256 x 200 against the oracle, and odd
+    sweep counts (remainders of 5 / 6 / 7 as 3 + 2 / 3 + 3 / 4 + 3)"""
+    dims = (256, 256, 200)
+    _, _, p = rand_state(*dims, 43)
+    b = np.random.default_rng(44).uniform(-1, 1, (200, 256, 256)).astype(f32)
+    for iters, launches in ((40, 10), (13, 4), (14, 4), (15, 4), (9, 3)):
+        f = make(dims, jacobi_iters=iters)
+        f.upload(fx.FIELD_PRESSURE, p)
+        f.upload(fx.FIELD_DIVERGENCE, b)
+        f.timing_enable(True); f.timing_read(True)
+        f.Jacobi(iters)
+        f.Synchronize()
+        t = f.timing_read(True)
+        assert t.jacobi_sweeps == iters and t.jacobi_launches == launches, (iters, t.jacobi_launches)
+        q, _ = orc.jacobi(p, b, iters)
+        assert np.array_equal(f.download(fx.FIELD_PRESSURE), q), iters
+        f.Release()
+
+
 @pytest.mark.parametrize("overlap", [0, 2])
 def test_x256_three_sweeps_in_slabs(overlap):
     """the same kernels on the shrinking ranges of z-slabs (halo planes included, ranges that start and end inside the slab)"""
