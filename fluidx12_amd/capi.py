@@ -18,7 +18,7 @@ JACOBI_FIXED, JACOBI_FAITHFUL = 0, 1
 ADDRESS_CLAMP, ADDRESS_MIRROR = 0, 1
 FLAG_JACOBI_FUSE_MASK, FLAG_NO_OVERLAP, FLAG_RENDER_ONLY = 0xF, 0x10, 0x20
 OPT_OVERLAP, OPT_JACOBI_ROUND, OPT_ADAPTIVE_HALO, OPT_COUNT_SAMPLES, OPT_RENDER_ACCEL = 1, 2, 3, 4, 5
-ABI_VERSION = 5                      # FX_ABI_VERSION of include/fluidx_hip.h
+ABI_VERSION = 6                      # FX_ABI_VERSION of include/fluidx_hip.h
 (FIELD_VELOCITY, FIELD_VELOCITY1, FIELD_COLOR, FIELD_COLOR_PREV, FIELD_PRESSURE, FIELD_DIVERGENCE,
  FIELD_LIGHTMAP, FIELD_CUBEMAP, FIELD_TARGET, FIELD_TARGET_FLOAT) = range(10)
 
@@ -113,12 +113,15 @@ def load():
     if not os.path.exists(path):
         raise RuntimeError("libfluidx_hip.so is missing and could not be built")
     lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    # the version first: an older library lacks symbols, and "ABI version 5, this harness speaks 6" says more than an AttributeError
+    lib.fx_abi_version.restype, lib.fx_abi_version.argtypes = C.c_int, []
+    have = lib.fx_abi_version()
+    if have != ABI_VERSION:
+        raise RuntimeError("fluidx ABI version mismatch: %s speaks version %d, this harness version %d" % (path, have, ABI_VERSION))
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.fx_abi_version() != ABI_VERSION:
-        raise RuntimeError("fluidx ABI version mismatch")
     _lib = lib
     # the launcher switches (fx_set_knob) are process-wide values inside the library, which reads no environment for them; the tools'
     # habit of `FLUIDX_<NAME>=... python tools/...` is served here, once, by the harness

@@ -112,7 +112,8 @@ int fx_simulate(fx_ctx* ctx, void* stream, uint8_t frame_index)
 	if (!ctx || frame_index >= FX_FRAME_COUNT) return FX_E_INVALID;
 	if (!ctx->frame_valid || (ctx->desc.flags & FX_FLAG_RENDER_ONLY) || group_broken(ctx)) return FX_E_STATE;
 	if (!is_driver(ctx)) return FX_OK;             // loop-back group: rank 0 drives every member
-	return simulate_impl(ctx, pick_stream(ctx, stream));
+	ctx->last_step_stream = pick_stream(ctx, stream);
+	return simulate_impl(ctx, ctx->last_step_stream);
 }
 
 // the zero fill is ordered on the stream the target is about to be used on (the context's streams do not synchronise

@@ -88,9 +88,12 @@ struct LocalTransport : Transport {
 		if ((int)segs.size() != n || streams.empty()) return FX_E_STATE;
 		const bool peer = streams.size() > 1;
 		if (peer && ((int)streams.size() != n || (int)grp->lanes.size() != n)) return FX_E_STATE;
-		// timing experiments only (results become wrong): keep the streams/events of the schedule, drop the copies
+#ifdef FX_LAB
+		// lab builds only (-DFX_LAB; results become WRONG): keep the streams / events of the schedule, drop the copies -- what the copies
+		// themselves cost in loop-back.  Not in the shipped library: every fx_set_knob name leaves results unchanged.
 		const bool no_copy = [] { const char* e = FX_KNOB("DEBUG_NO_COPY"); return e && e[0] == '1'; }();
 		if (no_copy) return FX_OK;
+#endif
 		int home = -1;
 		(void)hipGetDevice(&home);
 		int rc = FX_OK;
@@ -190,6 +193,8 @@ struct RcclApi {
 	decltype(&ncclAllReduce) AllReduce = nullptr;
 	decltype(&ncclAllGather) AllGather = nullptr;
 	decltype(&ncclGetErrorString) GetErrorString = nullptr;
+	decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;     // optional: a library without them is never polled / aborted
+	decltype(&ncclCommAbort) CommAbort = nullptr;
 };
 
 static RcclApi* rccl(std::string* err)
@@ -215,6 +220,8 @@ static RcclApi* rccl(std::string* err)
 	FX_SYM(GetUniqueId) FX_SYM(CommInitRank) FX_SYM(CommDestroy) FX_SYM(Send) FX_SYM(Recv)
 	FX_SYM(GroupStart) FX_SYM(GroupEnd) FX_SYM(AllReduce) FX_SYM(AllGather) FX_SYM(GetErrorString)
 #undef FX_SYM
+	api.CommGetAsyncError = (decltype(api.CommGetAsyncError))dlsym(api.handle, "ncclCommGetAsyncError");
+	api.CommAbort = (decltype(api.CommAbort))dlsym(api.handle, "ncclCommAbort");
 	return &api;
 }
 
@@ -240,11 +247,53 @@ struct RcclTransport : Transport {
 	RcclApi* api;
 	ncclComm_t comm, comm2;                          // comm2: the side channel (== comm when it could not be split off)
 	int rank, nranks;
+	bool dead = false;                               // aborted after an asynchronous error: nothing may be enqueued on the communicators any more
+	std::string dead_why;
 	bool is_local() const override { return false; }
 	~RcclTransport() override { if (comm2 && comm2 != comm) api->CommDestroy(comm2); if (comm) api->CommDestroy(comm); }
+	bool can_poll() const override { return api->CommGetAsyncError != nullptr; }
+	// ncclCommGetAsyncError of both communicators.  Anything but success / in-progress: abort both (ncclCommAbort ends the kernels RCCL
+	// has on the device, so the streams drain instead of spinning on a peer that will never answer) and stay dead.
+	int poll_error(std::string* err) override
+	{
+		if (!dead && api->CommGetAsyncError) {
+			ncclComm_t cs[2] = { comm, comm2 != comm ? comm2 : nullptr };
+			for (ncclComm_t c : cs) {
+				if (!c || dead) continue;
+				ncclResult_t st = ncclSuccess;
+				const ncclResult_t r = api->CommGetAsyncError(c, &st);
+				if (r != ncclSuccess) st = r;
+				if (st != ncclSuccess && st != ncclInProgress) {
+					dead = true;
+					dead_why = std::string("rccl: asynchronous communicator error (") + api->GetErrorString(st) + "); the communicators were aborted -- destroy the context and rejoin from a fresh process";
+				}
+			}
+			if (dead) {
+				if (api->CommAbort) {
+					if (comm2 && comm2 != comm) (void)api->CommAbort(comm2);
+					if (comm) (void)api->CommAbort(comm);
+				}
+				comm = comm2 = nullptr;                    // (aborted communicators are freed by ncclCommAbort: the destructor must not touch them)
+			}
+		}
+		if (dead) { if (err) *err = dead_why; return FX_E_COMM; }
+		return FX_OK;
+	}
+	int fail(fx_ctx* c, const char* what, ncclResult_t r)
+	{
+		c->last_error = std::string(what) + api->GetErrorString(r);
+		// a failed call leaves the communicator in an undefined state (RCCL's own rule): abort it, so that neither this rank's streams nor
+		// -- through the closed connections -- its neighbours wait on it for ever
+		if (!dead) {
+			dead = true; dead_why = c->last_error + "; the communicators were aborted";
+			if (api->CommAbort) { if (comm2 && comm2 != comm) (void)api->CommAbort(comm2); if (comm) (void)api->CommAbort(comm); comm = comm2 = nullptr; }
+		}
+		return FX_E_COMM;
+	}
 	// smallest value of `v` over the ranks (one-time set-up traffic: the ranks must take the same schedule decisions)
 	int min_over_ranks(int v, hipStream_t s, int* out) override
 	{
+		if (poll_error(nullptr)) return FX_E_COMM;
 		int* d = nullptr;
 		if (hipMalloc((void**)&d, sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return FX_E_NOMEM; }   // (clears the sticky last error)
 		int rc = FX_OK;
@@ -256,12 +305,14 @@ struct RcclTransport : Transport {
 	}
 	int allgather(const int* send_dev, int count, int* recv_dev, hipStream_t s) override
 	{
+		if (poll_error(nullptr)) return FX_E_COMM;
 		return api->AllGather(send_dev, recv_dev, (size_t)count, ncclInt32, comm, s) == ncclSuccess ? FX_OK : FX_E_COMM;
 	}
 	int exchange(fx_comm_group* grp, const std::vector<std::vector<Seg>>& segs, const std::vector<hipStream_t>& streams, int channel) override
 	{
 		fx_ctx* c = grp->members[0];
 		if (segs.size() != 1 || streams.size() != 1) return FX_E_STATE;
+		if (poll_error(&c->last_error)) return FX_E_COMM;                    // before anything new is enqueued behind a broken link
 		hipStream_t s = streams[0];
 		ncclComm_t comm = channel == 1 ? this->comm2 : this->comm;
 		ncclResult_t r = api->GroupStart();
@@ -274,13 +325,14 @@ struct RcclTransport : Transport {
 		}
 		const ncclResult_t e = api->GroupEnd();
 		if (r == ncclSuccess) r = e;
-		if (r != ncclSuccess) { c->last_error = std::string("rccl: ") + api->GetErrorString(r); return FX_E_COMM; }
+		if (r != ncclSuccess) return fail(c, "rccl: ", r);
 		return FX_OK;
 	}
 	int gather(fx_comm_group* grp, const std::vector<GatherPart>& parts, int root, const std::vector<hipStream_t>& streams) override
 	{
 		fx_ctx* c = grp->members[0];
 		if ((int)parts.size() != nranks || root < 0 || root >= nranks || streams.size() != 1) return FX_E_INVALID;
+		if (poll_error(&c->last_error)) return FX_E_COMM;
 		hipStream_t s = streams[0];
 		ncclResult_t r = api->GroupStart();
 		if (rank == root) {
@@ -294,7 +346,7 @@ struct RcclTransport : Transport {
 		}
 		const ncclResult_t e = api->GroupEnd();
 		if (r == ncclSuccess) r = e;
-		if (r != ncclSuccess) { c->last_error = std::string("rccl gather: ") + api->GetErrorString(r); return FX_E_COMM; }
+		if (r != ncclSuccess) return fail(c, "rccl gather: ", r);
 		return FX_OK;
 	}
 };

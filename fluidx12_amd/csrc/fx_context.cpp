@@ -2,6 +2,7 @@
 // Fluid.cpp:168-270) set up -- XUSG resources become hipMalloc'd fields owned by the context -- plus field read-back / upload,
 // HIP-event timing and the option switches.  No CPU fallback: without a HIP device fx_create returns FX_E_DEVICE.
 #include "fx_host.h"
+#include <time.h>
 
 using namespace fx;
 using namespace fxh;
@@ -83,7 +84,7 @@ void free_all(fx_ctx* c)
 		if (c->col[i]) (void)hipFree(c->col[i]);
 		if (c->p[i]) (void)hipFree(c->p[i]);
 	}
-	void* others[] = { c->env, c->accel.occ, c->accel.alpha, c->accel.bits, c->accel.list, c->accel.cells, c->accel.gi, c->accel.ctr, c->target, c->target_float, c->p_face[0], c->p_face[1], c->b, c->frozen, c->lightmap, c->cube, c->sh_dev, c->halo_overflow, c->stage,
+	void* others[] = { c->env, c->accel.occ, c->accel.alpha, c->accel.bits, c->accel.list, c->accel.cells, c->accel.gi, c->accel.ctr, c->target, c->target_float, c->p_face[0], c->p_face[1], c->b, c->frozen, c->frozen_alt, c->lightmap, c->cube, c->sh_dev, c->halo_overflow, c->stage,
 		c->sh_scratch[0], c->sh_scratch[1], c->sh_scratch[2], c->sh_scratch[3], c->p_aux, c->fz_mask[0], c->fz_mask[1], c->fz_mask[2], c->fz_tile_next, c->fz_stat, c->fz_list[0], c->fz_list[1], c->fz_counts, c->sample_counters, c->adv_far };
 	for (void* q : others) if (q) (void)hipFree(q);
 	for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -182,6 +183,10 @@ int fx_create(fx_ctx** out, const fx_desc* d)
 		if (d->jacobi_mode == FX_JACOBI_FAITHFUL && !(d->flags & FX_FLAG_RENDER_ONLY)) {
 			FX_HIP(hipMalloc((void**)&ctx->frozen, cells));
 			FX_HIP(hipMemsetAsync(ctx->frozen, 0, cells, ctx->stream));
+			if (ctx->g.Zg == 1) {                                            // 2-D: the LDS-tile kernel double-buffers the mask
+				FX_HIP(hipMalloc((void**)&ctx->frozen_alt, cells));
+				FX_HIP(hipMemsetAsync(ctx->frozen_alt, 0, cells, ctx->stream));
+			}
 			if (jacobi_freeze_supported(ctx->g)) {                           // the sparse solver of fx_jacobi_freeze.hip
 				const size_t mb = jacobi_freeze_mask_bytes(ctx->g), nt = (size_t)jacobi_freeze_tiles(ctx->g);
 				FX_HIP(hipMalloc((void**)&ctx->p_aux, cells * 4));
@@ -284,6 +289,36 @@ static int halo_fault_status(fx_ctx* c)
 	return c->halo_fault ? FX_E_HALO : FX_OK;
 }
 
+// An RCCL rank waits for its device in polls: a neighbour that died leaves this rank's receive kernels spinning for ever, and
+// hipDeviceSynchronize behind them would never return.  Between polls the communicators' asynchronous error is read
+// (Transport::poll_error); on a failure they are aborted -- RCCL's kernels end -- and the call returns FX_E_COMM.
+static int wait_for_device(fx_ctx* c)
+{
+	Transport* t = c->group && c->group->transport && !c->group->transport->is_local() ? c->group->transport : nullptr;
+	if (!t || !t->can_poll()) return hipDeviceSynchronize() == hipSuccess ? FX_OK : FX_E_DEVICE;
+	std::vector<hipStream_t> streams{ c->stream, c->last_step_stream };
+	for (const fx_lane& L : c->group->lanes) { streams.push_back(L.comm); streams.push_back(L.face); }
+	std::vector<hipEvent_t> evs;
+	int rc = FX_OK;
+	for (hipStream_t s : streams) {
+		if (!s) continue;
+		hipEvent_t e;
+		if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess || hipEventRecord(e, s) != hipSuccess) { rc = FX_E_DEVICE; break; }
+		evs.push_back(e);
+	}
+	for (size_t i = 0; i < evs.size() && rc == FX_OK;) {
+		const hipError_t q = hipEventQuery(evs[i]);
+		if (q == hipSuccess) { ++i; continue; }
+		if (q != hipErrorNotReady) { rc = FX_E_DEVICE; break; }
+		if ((rc = t->poll_error(&c->last_error))) break;
+		struct timespec ts = { 0, 200000 };                                 // 0.2 ms between polls
+		nanosleep(&ts, nullptr);
+	}
+	for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+	if (rc == FX_OK && (rc = t->poll_error(&c->last_error)) == FX_OK && hipDeviceSynchronize() != hipSuccess) rc = FX_E_DEVICE;
+	return rc;
+}
+
 int fx_synchronize(fx_ctx* ctx)
 {
 	if (!ctx) return FX_E_INVALID;
@@ -292,7 +327,7 @@ int fx_synchronize(fx_ctx* ctx)
 	int rc = FX_OK;
 	for (fx_ctx* c : M) {
 		DeviceGuard dg(c->device);
-		if (hipDeviceSynchronize() != hipSuccess) return FX_E_DEVICE;
+		if (const int w = wait_for_device(c)) return w;
 		const int st = halo_fault_status(c);
 		if (st == FX_E_DEVICE) return st;
 		if (st == FX_E_HALO) {                 // reported here, and acknowledged: the next step starts clean

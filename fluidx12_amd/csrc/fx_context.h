@@ -25,6 +25,7 @@ struct fx_ctx {
 	float* p_face[2];               // slab contexts: scratch levels of the Jacobi face chains (same geometry as p)
 	float* b;                       // divergence
 	uint8_t* frozen;                // faithful-mode freeze mask (null in fixed mode)
+	uint8_t* frozen_alt = nullptr;  // 2-D grids: the tile kernel's output mask (fx_jacobi2d.hip reads one and writes the other; they swap per launch)
 	// faithful mode, single-domain fast path (fx_jacobi_freeze.hip): third pressure buffer, two quad-nibble freeze masks, tile marks,
 	// and a ring of per-step "last level that left a cell relaxing" words
 	float* p_aux = nullptr;
@@ -56,6 +57,7 @@ struct fx_ctx {
 	bool rendered_since_step = false;       // a context that renders its frames has the NEXT advection write the side volume (one more store per voxel); one that only simulates does not pay for it
 	bool lightmap_filled = false;           // the light map holds what a filling build pass (k_build_fill) and its ray kernels left, nothing else has written it since
 	float lightmap_key[9] = {};             // ... with these constants behind the unlit value (light colour, ambient, light probe on / off)
+	hipStream_t last_step_stream = nullptr;  // the stream the last fx_simulate was driven on (fx_synchronize of an RCCL rank polls it)
 	hipStream_t rendered_on = nullptr;      // ... provided that advection runs on the stream the render ran on (the side volume is not double-buffered like the colour)
 	int opt_render_accel = 1;       // FX_OPT_RENDER_ACCEL
 	uint8_t* target;                // W x H RGBA8 render target of the cube resolve (lazily allocated)
@@ -148,6 +150,11 @@ struct Transport {
 	// every rank contributes `count` device ints, every rank receives all of them in rank order (RCCL: ncclAllGather; the
 	// loop-back transport has no use for it: its driver sees every member)
 	virtual int allgather(const int* send_dev, int count, int* recv_dev, hipStream_t s) = 0;
+	// asynchronous failure of the link layer (RCCL: ncclCommGetAsyncError -- a peer that died, a network error -- polled; on a failure
+	// the communicators are aborted with ncclCommAbort, which ends their device kernels, and every later call on this transport returns
+	// FX_E_COMM at once).  FX_OK while healthy or where the transport has nothing to poll; *err gets the reason.
+	virtual int poll_error(std::string* err) { (void)err; return FX_OK; }
+	virtual bool can_poll() const { return false; }
 };
 
 }  // namespace fx

@@ -119,7 +119,7 @@ hipError_t launch_freeze_strip3(const Geom& g, const float* p_in, const float* b
 	uint32_t* tile_mark, uint32_t tag, uint32_t* stat, uint32_t stat_hi, int level_in, hipStream_t s);
 // 2-D grids (fx_jacobi2d.hip): up to jacobi2d_max_sweeps (0: not a 2-D grid / switched off) lock-step sweeps per launch on LDS tiles, with or without the freeze bytes
 int jacobi2d_max_sweeps(const Geom& g);
-hipError_t launch_jacobi2d(const Geom& g, const float* p_in, const float* b, float* p_out, uint8_t* frozen, int sweeps, hipStream_t s);
+hipError_t launch_jacobi2d(const Geom& g, const float* p_in, const float* b, float* p_out, const uint8_t* frozen_in, uint8_t* frozen_out, int sweeps, hipStream_t s);
 // sweeps fused per launch for this geometry (1 = no fused path); requested > 0 overrides the default
 int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp);
 bool jacobi_prefers_three(const Geom& g, int requested, int nzp);

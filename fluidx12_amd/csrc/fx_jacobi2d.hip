@@ -5,7 +5,11 @@
 // boundary -- 64 launches of ~3 us for the reference's loop.  Here a workgroup owns a 64 x 16-cell tile, stages it with a halo of T
 // cells (p, b and -- reference configuration -- the freeze bytes) in the LDS and relaxes T times there: level k on the tile grown by
 // T - k cells, halo cells RECOMPUTED with their freeze decisions (the same deterministic arithmetic their owner tile does), then
-// stores its core.  Per cell: s = (((L - b) + R) + U) + D, x = s * 1/4, frozen for good once |fma(s, 1/4, -x0)| < 1e-3 -- the
+// stores its core.  The freeze bytes are DOUBLE-BUFFERED like the pressure (frozen_in -> frozen_out): a workgroup stages the bytes of its
+// halo, which its neighbours own and rewrite -- in place, a workgroup that starts after a neighbour has finished would see halo cells
+// frozen from level 0 instead of from the level at which they froze (every tile of a 512 x 512 grid is co-resident and stages before any
+// stores, so only grids of more tiles than the chip holds showed it; tests/test_gpu_sim.py::test_2d_tile_kernel_on_more_tiles_than_fit).
+// Per cell: s = (((L - b) + R) + U) + D, x = s * 1/4, frozen for good once |fma(s, 1/4, -x0)| < 1e-3 -- the
 // arithmetic and order of k_jacobi_generic, so T sweeps here equal T launches of it bit for bit (tests/test_gpu_sim.py, the
 // CSProject2D goldens, the 2-D fuzz family).
 #include "fx_internal.h"
@@ -20,7 +24,7 @@ constexpr int NC2 = EX2 * EY2;                  // staged cells (80 x 32 = 2560)
 
 template <bool MASK>
 __global__ __launch_bounds__(256) void k_jacobi2d_tile(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
-	float* __restrict__ p_out, uint8_t* __restrict__ frozen, int T)
+	float* __restrict__ p_out, const uint8_t* __restrict__ frozen_in, uint8_t* __restrict__ frozen_out, int T)
 {
 	__shared__ float P[2][NC2];
 	__shared__ float Bs[NC2];
@@ -34,7 +38,7 @@ __global__ __launch_bounds__(256) void k_jacobi2d_tile(const Geom g, const float
 		const size_t id = (size_t)gy * g.X + gx;
 		P[0][i] = p_in[id];
 		Bs[i] = b[id];
-		M[i] = MASK ? frozen[id] : (uint8_t)0;
+		M[i] = MASK ? frozen_in[id] : (uint8_t)0;
 	}
 	__syncthreads();
 	int cur = 0;
@@ -64,20 +68,22 @@ __global__ __launch_bounds__(256) void k_jacobi2d_tile(const Geom g, const float
 		if (gx >= g.X || gy >= g.Y) continue;
 		const size_t id = (size_t)gy * g.X + gx;
 		p_out[id] = P[cur][ey * EX2 + ex];
-		if (MASK) frozen[id] = M[ey * EX2 + ex];
+		if (MASK) frozen_out[id] = M[ey * EX2 + ex];
 	}
 }
 }  // namespace
 
 int jacobi2d_max_sweeps(const Geom& g) { return g.Zg == 1 && g.nz == 1 && FX_KNOB_INT("JACOBI2D_TILE", 1) ? kT : 0; }
 
-// `sweeps` (1 .. jacobi2d_max_sweeps) lock-step sweeps p_in -> p_out of a 2-D grid; frozen (may be null): the freeze bytes, read and updated
-hipError_t launch_jacobi2d(const Geom& g, const float* p_in, const float* b, float* p_out, uint8_t* frozen, int sweeps, hipStream_t s)
+// `sweeps` (1 .. jacobi2d_max_sweeps) lock-step sweeps p_in -> p_out of a 2-D grid; frozen_in / frozen_out (both null, or two DIFFERENT
+// buffers): the freeze bytes before and after
+hipError_t launch_jacobi2d(const Geom& g, const float* p_in, const float* b, float* p_out, const uint8_t* frozen_in, uint8_t* frozen_out, int sweeps, hipStream_t s)
 {
 	if (g.Zg != 1 || sweeps < 1 || sweeps > kT) return hipErrorNotSupported;
+	if ((frozen_in == nullptr) != (frozen_out == nullptr) || (frozen_in && frozen_in == frozen_out)) return hipErrorInvalidValue;
 	const dim3 grid((g.X + TX2 - 1) / TX2, (g.Y + TY2 - 1) / TY2, 1), block(256);
-	if (frozen) hipLaunchKernelGGL(k_jacobi2d_tile<true>, grid, block, 0, s, g, p_in, b, p_out, frozen, sweeps);
-	else hipLaunchKernelGGL(k_jacobi2d_tile<false>, grid, block, 0, s, g, p_in, b, p_out, frozen, sweeps);
+	if (frozen_in) hipLaunchKernelGGL(k_jacobi2d_tile<true>, grid, block, 0, s, g, p_in, b, p_out, frozen_in, frozen_out, sweeps);
+	else hipLaunchKernelGGL(k_jacobi2d_tile<false>, grid, block, 0, s, g, p_in, b, p_out, frozen_in, frozen_out, sweeps);
 	return hipGetLastError();
 }
 

@@ -6,7 +6,11 @@
 namespace {
 const char* const kNames[] = {
 	"ADVECT_ALPHA", "ADVECT_BLOCK", "ADVECT_DEFER", "ADVECT_FAST", "ADVECT_LDS", "ADVECT_LDS_HALF", "ADVECT_TILE_ROWS", "ADVECT_ZCHUNK",
-	"BLOCK_REMAP", "BLOCK_SHAPE", "COMM_PRIORITY", "DEBUG_NO_COPY", "FREEZE_DENSE_LEVELS", "FREEZE_FAST", "FREEZE_FUSE_DIV", "FREEZE_NT", "FREEZE_SHRINK", "FREEZE_T", "FREEZE_WGS",
+	"BLOCK_REMAP", "BLOCK_SHAPE", "COMM_PRIORITY",
+#ifdef FX_LAB
+	"DEBUG_NO_COPY",
+#endif
+	"FREEZE_DENSE_LEVELS", "FREEZE_FAST", "FREEZE_FUSE_DIV", "FREEZE_NT", "FREEZE_SHRINK", "FREEZE_T", "FREEZE_WGS",
 	"JACOBI2D_TILE", "JACOBI_BLOCK", "JACOBI_BLOCKG", "JACOBI_PREFER3", "JACOBI_PREFER4", "JACOBI_T", "LIGHT_FILL", "LIGHT_FILL_DIRTY", "LIGHT_RAY_NT", "LIGHT_RAY_WGS", "PROJECT_V4", "RCCL_ONE_COMM", "ROW_VW",
 	"STRIP3H_PAIRS", "STRIP3_COOP", "STRIP3_NO512", "STRIP3_OFF", "STRIP3_ZCHUNK", "STRIP4_ZCHUNK", "STRIP_GENERIC", "STRIP_R", "STRIP_REMAP", "STRIP_WGS", "STRIP_WIDE",
 	"STRIP_ZCHUNK", "VIEW_ORDER", "VIEW_WGS", "XCD_REMAP" };

@@ -293,7 +293,7 @@ int divergence_phase(fx_ctx* ctx, hipStream_t s)
 // t lock-step sweeps p[src] -> p[src ^ 1] on planes [r.lo, r.hi) in ONE launch
 // 2-D grids relax on LDS tiles (fx_jacobi2d.hip) unless the caller asked for one sweep per launch (jacobi_fuse = 1: the plainest kernels,
 // what the kernel-against-kernel parity tests compare with)
-static bool takes_2d_tiles(const fx_ctx* c) { return jacobi2d_max_sweeps(c->g) > 0 && (c->desc.flags & FX_FLAG_JACOBI_FUSE_MASK) != 1; }
+static bool takes_2d_tiles(const fx_ctx* c) { return jacobi2d_max_sweeps(c->g) > 0 && (c->desc.flags & FX_FLAG_JACOBI_FUSE_MASK) != 1 && (!c->frozen || c->frozen_alt); }
 
 static int jacobi_launch(fx_ctx* ctx, hipStream_t s, int src, int t, Range r, ScopedMark* mk)
 {
@@ -301,7 +301,8 @@ static int jacobi_launch(fx_ctx* ctx, hipStream_t s, int src, int t, Range r, Sc
 	if (r.hi <= r.lo) return FX_OK;
 	DeviceGuard dg(ctx->device);
 	if (takes_2d_tiles(ctx)) {                             // 2-D grids: up to eight sweeps per launch on LDS tiles, freeze bytes included
-		FX_HIP(launch_jacobi2d(ctx->g, ctx->p[src], ctx->b, ctx->p[src ^ 1], ctx->frozen, t, s));
+		FX_HIP(launch_jacobi2d(ctx->g, ctx->p[src], ctx->b, ctx->p[src ^ 1], ctx->frozen, ctx->frozen ? ctx->frozen_alt : nullptr, t, s));
+		if (ctx->frozen) std::swap(ctx->frozen, ctx->frozen_alt);       // the mask ping-pongs with the pressure
 	} else if (t > 1) {
 		FX_HIP(launch_jacobi_fused(ctx->g, ctx->p[src], ctx->b, ctx->p[src ^ 1], t, r.lo, r.hi, s));
 	} else {

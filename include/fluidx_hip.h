@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 5
+#define FX_ABI_VERSION 6   /* 6: fx_comm_init_peer, fx_set_knob / fx_knob_name, FX_OPT_RENDER_ACCEL; the launcher switches no longer come from FLUIDX_* environment variables */
 
 enum fx_status {
 	FX_OK = 0,

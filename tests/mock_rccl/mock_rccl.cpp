@@ -13,6 +13,12 @@
 //   ncclAllReduce                                  int32 / float, min / max / sum, by the same file exchange.
 //   ncclAllGather                                  any of the element types above, by the same file exchange.
 //
+//   ncclCommGetAsyncError / ncclCommAbort         the failure path: every rank leaves <dir>/pid_<rank> at init; a wait that sees its peer's
+//       process gone (kill(pid, 0)), or the peer's <dir>/dead_<rank> marker (written by ncclCommAbort), ends at once with
+//       ncclRemoteError -- the stand-in for RCCL noticing a closed connection -- instead of running into the time-out.
+//       FXMOCK_ASYNC_ERROR="<rank>:<n>" makes ncclCommGetAsyncError on that rank report ncclSystemError from its n-th completed group on
+//       (an injected link failure).  After ncclCommAbort the handle is gone.
+//
 // It is deliberately STRICTER than RCCL: host-synchronous, every wait times out (FXMOCK_TIMEOUT_S, default 60 s) and
 // returns ncclSystemError, so a schedule that makes ranks disagree fails a test instead of hanging a node.  It says
 // nothing about link time.  Selected with FLUIDX_RCCL_LIB=<this .so>; FXMOCK_DIR is where the rendezvous
@@ -32,6 +38,8 @@
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <signal.h>
+#include <errno.h>
 
 namespace {
 
@@ -41,7 +49,8 @@ struct Comm {
 	std::string dir;
 	int rank = 0, nranks = 0;
 	std::vector<unsigned long> send_seq, recv_seq;
-	unsigned long ar_seq = 0, ag_seq = 0;
+	unsigned long ar_seq = 0, ag_seq = 0, groups_done = 0;
+	std::vector<long> peer_pid;                      // read lazily from <dir>/pid_<rank>
 };
 
 thread_local int g_depth = 0;
@@ -63,14 +72,52 @@ bool write_file(const std::string& path, const void* data, size_t bytes)
 	return ok && std::rename(tmp.c_str(), path.c_str()) == 0;
 }
 
-// waits until `path` exists, then reads it whole; false on time-out
-bool read_file(const std::string& path, std::vector<char>& out)
+// is rank `peer` of this communicator gone?  (its abort marker, or its process no longer exists)
+bool peer_dead(Comm* c, int peer)
+{
+	if (!c || peer < 0 || peer >= c->nranks || peer == c->rank) return false;
+	struct stat st;
+	char b[64];
+	std::snprintf(b, sizeof b, "/dead_%d", peer);
+	if (stat((c->dir + b).c_str(), &st) == 0) return true;
+	if (c->peer_pid.empty()) c->peer_pid.assign((size_t)c->nranks, 0);
+	if (!c->peer_pid[(size_t)peer]) {
+		std::snprintf(b, sizeof b, "/pid_%d", peer);
+		if (FILE* f = std::fopen((c->dir + b).c_str(), "r")) { long v = 0; if (std::fscanf(f, "%ld", &v) == 1) c->peer_pid[(size_t)peer] = v; std::fclose(f); }
+	}
+	const long pid = c->peer_pid[(size_t)peer];
+	if (pid <= 0) return false;
+	if (kill((pid_t)pid, 0) != 0 && errno == ESRCH) return true;
+	// a process that has ended but was not reaped yet (a zombie) still answers kill(pid, 0): look at its state
+	std::snprintf(b, sizeof b, "/proc/%ld/stat", pid);
+	if (FILE* f = std::fopen(b, "r")) {
+		char line[512] = {};
+		const size_t n = std::fread(line, 1, sizeof line - 1, f);
+		std::fclose(f);
+		line[n] = 0;
+		const char* p = std::strrchr(line, ')');
+		if (p && p[1] == ' ' && (p[2] == 'Z' || p[2] == 'X')) return true;
+	}
+	return false;
+}
+
+thread_local bool g_remote_dead = false;             // the last failed wait ended because the peer is gone
+
+// waits until `path` exists, then reads it whole; false on time-out or when the rank that should write it is gone
+bool read_file(const std::string& path, std::vector<char>& out, Comm* c = nullptr, int from = -1)
 {
 	const auto t0 = std::chrono::steady_clock::now();
 	struct stat st;
+	unsigned long spins = 0;
+	g_remote_dead = false;
 	while (stat(path.c_str(), &st) != 0) {
 		if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s()) {
 			std::fprintf(stderr, "mock_rccl: timed out waiting for %s\n", path.c_str());
+			return false;
+		}
+		if ((++spins & 1023u) == 0 && peer_dead(c, from) && stat(path.c_str(), &st) != 0) {   // every ~50 ms
+			std::fprintf(stderr, "mock_rccl: rank %d is gone; giving up on %s\n", from, path.c_str());
+			g_remote_dead = true;
 			return false;
 		}
 		std::this_thread::sleep_for(std::chrono::microseconds(50));
@@ -115,7 +162,7 @@ ncclResult_t flush()
 		Comm* c = co.first; const Op& o = co.second;
 		if (o.send) continue;
 		const std::string name = msg_name(c, o.peer, c->rank, c->recv_seq[o.peer]++);
-		if (!read_file(name, host)) return ncclSystemError;
+		if (!read_file(name, host, c, o.peer)) return g_remote_dead ? ncclRemoteError : ncclSystemError;
 		if (host.size() != o.bytes) {
 			std::fprintf(stderr, "mock_rccl: rank %d posted a %zu-byte recv from %d, the matching send has %zu bytes (%s)\n",
 			             c->rank, o.bytes, o.peer, host.size(), name.c_str());
@@ -124,6 +171,7 @@ ncclResult_t flush()
 		if (o.bytes && hipMemcpy(o.ptr, host.data(), o.bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
 		unlink(name.c_str());
 	}
+	for (auto& co : ops) co.first->groups_done += 1;     // (per operation; only its growth matters)
 	return ncclSuccess;
 }
 
@@ -170,6 +218,12 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
 	mkdir(c->dir.c_str(), 0700);                       // every rank tries; EEXIST is the normal case
 	struct stat st;
 	if (stat(c->dir.c_str(), &st) != 0) { delete c; return ncclSystemError; }
+	{
+		char b[64], pid[32];
+		std::snprintf(b, sizeof b, "/pid_%d", rank);
+		const int n = std::snprintf(pid, sizeof pid, "%ld", (long)getpid());
+		if (!write_file(c->dir + b, pid, (size_t)n)) { delete c; return ncclSystemError; }
+	}
 	*comm = reinterpret_cast<ncclComm_t>(c);
 	return ncclSuccess;
 }
@@ -191,7 +245,38 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
 		}
 		closedir(d);
 	}
+	char pf[64];
+	std::snprintf(pf, sizeof pf, "/pid_%d", c->rank);
+	unlink((c->dir + pf).c_str());
 	rmdir(c->dir.c_str());                              // succeeds for the last rank out
+	delete c;
+	return ncclSuccess;
+}
+
+// the asynchronous state of a communicator: an injected failure (FXMOCK_ASYNC_ERROR = "<rank>:<operations completed before it shows>"),
+// or a neighbour that is gone
+ncclResult_t ncclCommGetAsyncError(ncclComm_t comm, ncclResult_t* asyncError)
+{
+	Comm* c = reinterpret_cast<Comm*>(comm);
+	if (!c || !asyncError) return ncclInvalidArgument;
+	*asyncError = ncclSuccess;
+	if (const char* e = std::getenv("FXMOCK_ASYNC_ERROR")) {
+		int r = -1; unsigned long n = 0;
+		if (std::sscanf(e, "%d:%lu", &r, &n) == 2 && r == c->rank && c->groups_done >= n) *asyncError = ncclSystemError;
+	}
+	for (int d = -1; d <= 1 && *asyncError == ncclSuccess; d += 2)
+		if (peer_dead(c, c->rank + d)) *asyncError = ncclRemoteError;
+	return ncclSuccess;
+}
+
+// leaves the marker the neighbours' waits look for, and frees the handle (what it published stays: nobody may rely on it any more)
+ncclResult_t ncclCommAbort(ncclComm_t comm)
+{
+	Comm* c = reinterpret_cast<Comm*>(comm);
+	if (!c) return ncclSuccess;
+	char b[64];
+	std::snprintf(b, sizeof b, "/dead_%d", c->rank);
+	(void)write_file(c->dir + b, "x", 1);
 	delete c;
 	return ncclSuccess;
 }
@@ -238,7 +323,7 @@ ncclResult_t ncclAllReduce(const void* sendbuf, void* recvbuf, size_t count, ncc
 	for (int r = 0; r < c->nranks; ++r) {
 		if (r == c->rank) continue;
 		std::snprintf(b, sizeof b, "/ar_%lu_r%d", seq, r);
-		if (!read_file(c->dir + b, other)) return ncclSystemError;
+		if (!read_file(c->dir + b, other, c, r)) return g_remote_dead ? ncclRemoteError : ncclSystemError;
 		if (other.size() != acc.size()) return ncclInvalidUsage;
 		if (type == ncclInt32) reduce(reinterpret_cast<int*>(acc.data()), reinterpret_cast<const int*>(other.data()), count, op);
 		else reduce(reinterpret_cast<float*>(acc.data()), reinterpret_cast<const float*>(other.data()), count, op);
@@ -264,7 +349,7 @@ ncclResult_t ncclAllGather(const void* sendbuf, void* recvbuf, size_t count, ncc
 	for (int r = 0; r < c->nranks; ++r) {
 		if (r == c->rank) { std::memcpy(all.data() + (size_t)r * mine.size(), mine.data(), mine.size()); continue; }
 		std::snprintf(b, sizeof b, "/ag_%lu_r%d", seq, r);
-		if (!read_file(c->dir + b, other)) return ncclSystemError;
+		if (!read_file(c->dir + b, other, c, r)) return g_remote_dead ? ncclRemoteError : ncclSystemError;
 		if (other.size() != mine.size()) return ncclInvalidUsage;
 		std::memcpy(all.data() + (size_t)r * mine.size(), other.data(), other.size());
 	}
@@ -281,6 +366,7 @@ const char* ncclGetErrorString(ncclResult_t r)
 	case ncclSystemError: return "mock_rccl: rendezvous timed out or file error (ranks disagree on the exchange sequence?)";
 	case ncclInvalidArgument: return "mock_rccl: invalid argument";
 	case ncclInvalidUsage: return "mock_rccl: send/recv byte counts do not match";
+	case ncclRemoteError: return "mock_rccl: a peer rank is gone (its process ended or it aborted its communicator)";
 	default: return "mock_rccl: error";
 	}
 }

@@ -196,3 +196,40 @@ def test_a_stalled_peer_ends_the_bench_with_an_error_instead_of_a_hang(mock_lib,
     assert r.returncode != 0 and took < 140, (r.returncode, took, r.stderr[-2000:])
     assert "watchdog: rank 0 stuck in phase 'schedule candidate overlap=1" in r.stderr, r.stderr[-3000:]
     assert r.stderr.count("bench.py candidate: {") == 2 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.parametrize("mode", ["async", "die"])
+def test_a_failed_link_or_a_dead_peer_returns_comm_errors_instead_of_hanging(mode, mock_lib, tmp_path):
+    """VERDICT r4 item 8.  Two rank processes on the mock; `async`: rank 1's ncclCommGetAsyncError turns bad after some exchanges
+    (FXMOCK_ASYNC_ERROR) -- the product's poll in front of the next exchange sees it, aborts both communicators (ncclCommAbort) and
+    returns FX_E_COMM; rank 0's wait ends on the abort marker.  `die`: rank 1 ends with os._exit in the middle of the run; rank 0's
+    next wait (or its poll) notices the missing process.  In both cases every surviving rank reports FX_E_COMM (-5) within seconds -- the
+    mock's own time-out is set to ten minutes --, the call after that fails at once too, and the process releases its context and exits."""
+    import time
+    env = dict(os.environ, OMP_NUM_THREADS="1", FLUIDX_RCCL_LIB=mock_lib, FXMOCK_DIR=str(tmp_path), FXMOCK_TIMEOUT_S="600",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if mode == "async":
+        env["FXMOCK_ASYNC_ERROR"] = "1:60"
+    idf = str(tmp_path / "uid.bin")
+    t0 = time.monotonic()
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_fault_worker.py"), str(r), idf, mode], cwd=ROOT, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=240))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                                  # (exactly the children started above)
+    took = time.monotonic() - t0
+    shutil.rmtree(tmp_path, ignore_errors=True)
+    assert took < 200, took
+    lines = [l for o, _ in outs for l in o.splitlines() if l.startswith("RANK")]
+    survivors = [0, 1] if mode == "async" else [0]
+    assert len(lines) == len(survivors), (outs,)
+    for l in lines:
+        w = l.split()
+        assert int(w[3]) == -5 and int(w[-1]) == -5, l           # FX_E_COMM, and again FX_E_COMM
+        assert float(w[w.index("after") + 1]) < 60, l
+    assert all(p.returncode == 0 for p in procs), [(p.returncode, e[-800:]) for p, (_, e) in zip(procs, outs)]

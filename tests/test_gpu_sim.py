@@ -665,3 +665,27 @@ def test_2d_tile_kernel_equals_one_sweep_per_launch(dims, mode, iters):
     f.Jacobi(iters); f.Synchronize()
     want, _ = orc.jacobi(p, bb, iters, mode=int(mode == "faithful"))
     assert np.array_equal(f.download(fx.FIELD_PRESSURE).view(np.uint32), want.view(np.uint32))
+
+
+def test_2d_tile_kernel_on_more_tiles_than_fit():
+    """k_jacobi2d_tile in the reference's mode (freeze bytes) on a 2048 x 2048 grid: 4096 workgroups, far more than are resident at once,
+    so late workgroups stage their halos after early ones have stored their cores -- with the freeze bytes updated in place that made a
+    halo cell look frozen from level 0; they are double-buffered now.  The solve from a random state against one sweep per
+    launch (jacobi_fuse = 1: every cell reads only its own byte), bit for bit, pressure and the number of sweeps that left a cell relaxing."""
+    dims, iters = (2048, 2048, 1), 64
+    rng = np.random.default_rng(5)
+    p = (rng.standard_normal((1, 2048, 2048)) * 0.05).astype(f32)
+    bb = (rng.standard_normal((1, 2048, 2048)) * 0.02).astype(f32)
+    out = []
+    for fuse in (0, 1):
+        f = make(dims, jacobi_mode="faithful", jacobi_iters=iters, jacobi_fuse=fuse)
+        f.upload(fx.FIELD_PRESSURE, p); f.upload(fx.FIELD_DIVERGENCE, bb)
+        f.timing_enable(True); f.timing_read(True)
+        for _ in range(3):                       # three solves in a row: the mask is cleared in between and the buffers have swapped an odd number of times
+            f.Jacobi(iters)
+        f.Synchronize()
+        t = f.timing_read()
+        assert t.jacobi_launches == (3 * 8 if fuse == 0 else 3 * iters)
+        out.append(f.download(fx.FIELD_PRESSURE).view(np.uint32))
+        f.Release()
+    assert np.array_equal(out[0], out[1])
