@@ -337,26 +337,41 @@ __device__ __forceinline__ void run4(const Geom& g, const float* __restrict__ p_
 	for (int i = 0; i < R::LDS_ROWS; ++i) st.lds[i * 64] = zero;
 	const size_t plane = g.plane();
 	st.plane_bytes = plane * 4;
+	const bool fill = qs == zb - 4;
+	// q0: the step the walk starts with.  A chunk that starts four planes below its first output plane has nothing to compute in its first
+	// two steps (level-1 planes below zb - 3 feed nothing that is stored): their planes are fetched in ONE burst with the third and
+	// parked, instead of two steps that each wait out a memory round trip with nothing to do meanwhile.
+	const int q0 = fill ? qs + 2 : qs;
 	{
-		const char* pb = reinterpret_cast<const char*>(p_in + (size_t)g.lz(min(qs, st.q_load_last)) * plane);
+		const char* pb = reinterpret_cast<const char*>(p_in + (size_t)g.lz(min(q0, st.q_load_last)) * plane);
 #pragma unroll
 		for (int i = 0; i < R::NI; ++i) NP[i] = *reinterpret_cast<const v4f*>(pb + roff[i]);
-		const char* bbase = reinterpret_cast<const char*>(b + (size_t)g.lz(min(max(qs - 1, g.zlo), g.zhi)) * plane);
+		const char* bbase = reinterpret_cast<const char*>(b + (size_t)g.lz(min(max(q0 - 1, g.zlo), g.zhi)) * plane);
 #pragma unroll
 		for (int j = 0; j < R::N1; ++j) NB[j] = *reinterpret_cast<const v4f*>(bbase + roff[j + 1]);
-		const char* bnext = reinterpret_cast<const char*>(b + (size_t)g.lz(min(max(qs, g.zlo), g.zhi)) * plane);
+		const char* bnext = reinterpret_cast<const char*>(b + (size_t)g.lz(min(max(q0, g.zlo), g.zhi)) * plane);
 #pragma unroll
 		for (int j = 0; j < R::N1; ++j) NBn[j] = *reinterpret_cast<const v4f*>(bnext + roff[j + 1]);
+		if (fill) {                                                       // input planes q0 - 2 and q0 - 1 straight into their LDS slots
+			const char* pa = reinterpret_cast<const char*>(p_in + (size_t)g.lz(qs) * plane);
+			v4f A_[R::NI], B_[R::NI];
+#pragma unroll
+			for (int i = 0; i < R::NI; ++i) A_[i] = *reinterpret_cast<const v4f*>(pa + roff[i]);
+#pragma unroll
+			for (int i = 0; i < R::NI; ++i) B_[i] = *reinterpret_cast<const v4f*>(pa + st.plane_bytes + roff[i]);
+#pragma unroll
+			for (int i = 0; i < R::NI; ++i) FXQ_LDS(st, st.s_old, i) = A_[i];
+#pragma unroll
+			for (int i = 0; i < R::NI; ++i) FXQ_LDS(st, st.s_ctr, i) = B_[i];
+		}
 	}
-	st.q = qs;
-	st.pp = reinterpret_cast<const char*>(p_in) + ((ptrdiff_t)g.lz(qs) + 1) * (ptrdiff_t)st.plane_bytes;
-	st.pbq = reinterpret_cast<const char*>(b) + ((ptrdiff_t)g.lz(qs) + 1) * (ptrdiff_t)st.plane_bytes;
+	st.q = q0;
+	st.pp = reinterpret_cast<const char*>(p_in) + ((ptrdiff_t)g.lz(q0) + 1) * (ptrdiff_t)st.plane_bytes;
+	st.pbq = reinterpret_cast<const char*>(b) + ((ptrdiff_t)g.lz(q0) + 1) * (ptrdiff_t)st.plane_bytes;
 	st.po_zb = reinterpret_cast<char*>(p_out) + (ptrdiff_t)g.lz(zb) * (ptrdiff_t)st.plane_bytes;
-	st.po = reinterpret_cast<char*>(p_out) + ((ptrdiff_t)g.lz(qs) - 4) * (ptrdiff_t)st.plane_bytes;      // (only dereferenced for planes inside the chunk)
-	// the pipeline's fill, peeled as in k_jacobi_strip3c: level-l planes below zb - 4 + l feed nothing that is stored
-	if (qs == zb - 4) {
-		step4<R, 1, false, false, false, false>(st, P1, P2, P3, NP, NB, NBn, roff);
-		step4<R, 2, false, false, false, false>(st, P1, P2, P3, NP, NB, NBn, roff);
+	st.po = reinterpret_cast<char*>(p_out) + ((ptrdiff_t)g.lz(q0) - 4) * (ptrdiff_t)st.plane_bytes;      // (only dereferenced for planes inside the chunk)
+	// the rest of the pipeline's fill, peeled as in k_jacobi_strip3c: level-l planes below zb - 4 + l feed nothing that is stored
+	if (fill) {
 		step4<R, 0, true, false, false, false>(st, P1, P2, P3, NP, NB, NBn, roff);
 		step4<R, 1, true, false, false, false>(st, P1, P2, P3, NP, NB, NBn, roff);
 		step4<R, 2, true, true, false, false>(st, P1, P2, P3, NP, NB, NBn, roff);
