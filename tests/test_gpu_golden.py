@@ -186,3 +186,106 @@ def test_sh_transform_vs_reference_binaries():
     assert lp.Init(SH["cube"])
     lp.TransformSH()
     assert np.allclose(lp.GetSH(), SH["sh"], rtol=1e-5, atol=1e-6)
+
+
+# ---- round 5: tests/golden/dxbc_wide.npz (over-covered grids, an 8-frame rollout, cube LOD 1, the SH chain at 256^2) ----------------
+WIDE = np.load(os.path.join(GOLD, "dxbc_wide.npz"))
+
+
+@pytest.mark.parametrize("tag,dims", [("3d", (20, 20, 10)), ("2d", (12, 12, 1))])
+@pytest.mark.parametrize("address", ["clamp", "mirror"])
+def test_advect_on_over_covered_grids_vs_reference_binary(tag, dims, address):
+    """grids that are no multiple of the reference's 8 x 8 thread group (its surplus threads load zeros and drop their stores)"""
+    k = "advect_%s_%s" % (tag, address)
+    f = make(dims, advect_address=address)
+    f.upload(fx.FIELD_VELOCITY, WIDE[k + "_vel_in"])
+    f.upload(fx.FIELD_COLOR, WIDE[k + "_col_in"])
+    f.UpdateFrame(f32(f.default_time_step()), 0)
+    f.Advect()
+    f.Synchronize()
+    gv, gc = f.download(fx.FIELD_VELOCITY1), f.download(fx.FIELD_COLOR)
+    assert rel_l2(gv, WIDE[k + "_vel_out"]) < 1e-6 and rel_l2(gc, WIDE[k + "_col_out"]) < 1e-6
+    assert np.mean(gv != WIDE[k + "_vel_out"]) < 2e-3 and np.mean(gc != WIDE[k + "_col_out"]) < 2e-3
+
+
+@pytest.mark.parametrize("tag,dims", [("3d", (20, 20, 10)), ("2d", (12, 12, 1))])
+def test_project_on_over_covered_grids_vs_reference_binary(tag, dims):
+    k = "project_%s" % tag
+    f = make(dims, jacobi_iters=64, jacobi_mode="faithful")
+    f.upload(fx.FIELD_VELOCITY1, WIDE[k + "_vel_in"])
+    f.upload(fx.FIELD_PRESSURE, WIDE[k + "_p_in"])
+    f.UpdateFrame(f32(f.default_time_step()), 0)
+    f.Divergence()
+    f.Jacobi(64)
+    f.Project()
+    f.Synchronize()
+    assert np.array_equal(f.download(fx.FIELD_PRESSURE), WIDE[k + "_p_out"])
+    assert np.array_equal(f.download(fx.FIELD_VELOCITY), WIDE[k + "_vel_out"])
+
+
+def test_eight_frame_rollout_vs_reference_binaries():
+    """8 frames of class Fluid's configuration (MIRROR, RGBA16F, ITER 64 + early-out) at 20 x 20 x 12"""
+    f = make((20, 20, 12), storage="fp16", jacobi_iters=64, jacobi_mode="faithful", advect_address="mirror")
+    for st in range(1, 9):
+        f.UpdateFrame(f32(f.default_time_step()), (st - 1) % 3)
+        f.Simulate((st - 1) % 3)
+        if st in (2, 5, 8):
+            f.Synchronize()
+            for field, key in ((fx.FIELD_VELOCITY, "vel"), (fx.FIELD_COLOR, "col"), (fx.FIELD_PRESSURE, "p")):
+                got, ref = f.download(field), WIDE["rollout8_step%d_%s" % (st, key)]
+                assert rel_l2(got, ref) < 1e-4, (st, key)              # north_star tolerance
+                assert np.mean(got != ref) < 1e-2, (st, key)
+
+
+def test_light_volume_on_an_over_covered_grid_vs_reference_binary():
+    """CSRayMarchL.cso on 18^3 voxels (ceil(18 / 4) groups per axis), through fx_render's separate light pass"""
+    X = 18
+    f = make((X, X, X), storage="fp16")
+    view, proj, eye = fx.default_camera(640, 480)
+    f.upload(fx.FIELD_COLOR, WIDE["light18_color"])
+    f.SetMaxSamples(24, 16)
+    f.UpdateFrame(0.0, 0, view, proj, eye)
+    f.Render(0, fx.Fluid.OPTIMIZED)
+    f.Synchronize()
+    lm, ref = f.download(fx.FIELD_LIGHTMAP), WIDE["light18_lightmap"]
+    assert np.mean(lm != ref) < 2e-3 and np.abs(lm - ref).max() <= np.abs(ref).max() * 2.0 ** -5
+
+
+def test_view_march_into_a_coarser_cube_mip_vs_reference_binaries():
+    """the 16^3 volume of dxbc_render.npz behind a 20 x 15 viewport: UpdateFrame derives cube LOD 1 (8^2 texels) and 7 samples"""
+    X, S, nl, ns, nml, mask, vw, vh = (int(v) for v in WIDE["cube_lod1_params"])
+    f = fx.Fluid()
+    assert f.Init(vw, vh, (X, X, X), storage="fp16"), f.last_status
+    view, proj, eye = fx.default_camera(vw, vh)
+    f.upload(fx.FIELD_COLOR, REN["color"])
+
+    def cube_close(got, ref):
+        d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 0.02, (int(d.max()), float((d > 0).mean()))
+
+    f.SetMaxSamples(48, nl)
+    f.UpdateFrame(0.0, 0, view, proj, eye)
+    fi = f.frame_info()
+    assert (fi.cube_lod, fi.ray_samples, fi.visibility_mask, fi.cube_size) == (1, ns, mask, S)
+    f.Render(0, fx.Fluid.OPTIMIZED)
+    f.Synchronize()
+    cube_close(f.download(fx.FIELD_CUBEMAP), WIDE["cube_lod1_separate"])
+    f.SetMaxSamples(48, nml)
+    f.UpdateFrame(0.0, 0, view, proj, eye)
+    f.Render(0, fx.Fluid.RAY_MARCH_CUBEMAP)
+    f.Synchronize()
+    cube_close(f.download(fx.FIELD_CUBEMAP), WIDE["cube_lod1_merged"])
+
+
+def test_sh_transform_at_the_reference_size_vs_reference_binaries():
+    """CSSHCubeMap + CSSHSum x 3 + CSSHNormalize at SH_TEX_SIZE = 256: the product computes the INTENDED reduction (every pass its own
+    element count); the as-shipped one (LightProbeEZ.cpp:245-246) differs from it by the fixture's 1.4e-3 of the largest coefficient"""
+    cube = np.repeat(np.repeat(WIDE["sh256_base32"], 8, axis=1), 8, axis=2)
+    f = make((16, 16, 16))
+    lp = fx.LightProbe(f)
+    assert lp.Init(cube)
+    lp.TransformSH()
+    got = lp.GetSH()
+    assert np.allclose(got, WIDE["sh256_intended"], rtol=2e-5, atol=2e-6)
+    scale = np.abs(WIDE["sh256_intended"]).max()
+    assert np.abs(got - WIDE["sh256_as_shipped"]).max() / scale > 1e-4

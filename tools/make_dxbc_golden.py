@@ -332,8 +332,116 @@ def make_sh():
     np.savez_compressed(os.path.join(OUT, "dxbc_sh.npz"), **out)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# round 5: where the pin was blind -- over-covered grids, a longer rollout, a coarser cube mip, the real SH size and the as-shipped
+# SH reduction (tests/golden/dxbc_wide.npz)
+# ---------------------------------------------------------------------------------------------------------
+def run_sh_chain(cube, order=3, as_shipped=False):
+    """CSSHCubeMap -> CSSHSum x k -> CSSHNormalize exactly as LightProbeEZ.cpp:183-278 issues them.  as_shipped: every CSSHSum pass
+    reads constant-buffer slice 0 (LightProbeEZ.cpp:245-246 binds the buffer's first slice for all passes), i.e. g_pixelCount of the
+    FIRST pass; otherwise each pass sees its own element count (what the host code fills into the slices, :101-102)."""
+    N = cube.shape[1]
+    total = 6 * N * N
+    groups = divup(total, 32)
+    sums = divup(groups, 32)
+    sh0, w0 = di.Structured(groups * 9, 12), di.Structured(groups, 4)
+    sh1, w1 = di.Structured(max(sums, 1) * 9 + 9, 12), di.Structured(max(sums, 1) + 1, 4)
+    di.run_shader(os.path.join(BIN, "CSSHCubeMap.cso"), (groups, 1, 1),
+                  {"t0": di.CubePoint(cube), "u0": sh0, "u1": w0}, {0: np.array([[order, N, 0, 0]], U32)}, {"s0": di.Sampler("WRAP")})
+    S, W = [sh0, sh1], [w0, w1]
+    src, n, passes = 0, groups, 0
+    while n > 1:
+        count = groups if as_shipped else n
+        di.run_shader(os.path.join(BIN, "CSSHSum.cso"), (divup(n, 32), order * order, 1),
+                      {"t0": S[src], "t1": W[src], "u0": S[src ^ 1], "u1": W[src ^ 1]}, {0: np.array([[order, count, 0, 0]], U32)})
+        src ^= 1
+        n = divup(n, 32)
+        passes += 1
+    res = di.Structured(32, 12)
+    di.run_shader(os.path.join(BIN, "CSSHNormalize.cso"), (1, 1, 1), {"t0": S[src], "t1": W[src], "u0": res}, {})
+    return res.words.view(F32)[:9].copy(), passes
+
+
+def make_wide():
+    out = {}
+    # ---- grids the dispatch OVER-COVERS (the reference launches ceil(N / 8) or ceil(N / 4) groups and relies on out-of-range loads
+    #      returning 0 and out-of-range stores being dropped: CSProject3D.hlsl:68-113 at the 150^3 of Bin/FluidGI.bat)
+    for tag, dims in (("3d", (20, 20, 10)), ("2d", (12, 12, 1))):
+        X, Y, Z = dims
+        dt = F32((2.0 if Z > 1 else 1.0) / Y)
+        vel, col, p = rand_state(X, Y, Z, 201, 1.2)
+        for address in ("CLAMP", "MIRROR"):
+            vo, co = run_advect(vel, col, dt, address, "R32G32B32A32_FLOAT")
+            k = "advect_%s_%s" % (tag, address.lower())
+            out[k + "_vel_in"], out[k + "_col_in"], out[k + "_vel_out"], out[k + "_col_out"] = vel, col, vo, co
+        v0, pp, n = run_project(vel, p, dt, "R32G32B32A32_FLOAT")
+        k = "project_%s" % tag
+        out[k + "_vel_in"], out[k + "_p_in"], out[k + "_vel_out"], out[k + "_p_out"] = vel, p, v0, pp
+        print("wide", k, dims, "instructions executed:", n)
+    # ---- 8 frames of the reference's own configuration (class Fluid: MIRROR, RGBA16F, the 64-sweep early-out loop) on such a grid
+    X, Y, Z = 20, 20, 12
+    dt = F32(2.0 / Y)
+    vel0 = np.zeros((3, Z, Y, X), F32)
+    cols = [np.zeros((Z, Y, X, 4), F32), np.zeros((Z, Y, X, 4), F32)]
+    p = np.zeros((Z, Y, X), F32)
+    parity = 0
+    for step in range(8):
+        parity ^= 1
+        vel1, cols[parity] = run_advect(vel0, cols[1 - parity], dt, "MIRROR", "R16G16B16A16_FLOAT")
+        vel0, p, _ = run_project(vel1, p, dt, "R16G16B16A16_FLOAT")
+        if step + 1 in (2, 5, 8):
+            out["rollout8_step%d_vel" % (step + 1)] = vel0
+            out["rollout8_step%d_col" % (step + 1)] = cols[parity]
+            out["rollout8_step%d_p" % (step + 1)] = p
+    print("wide rollout 20x20x12, 8 frames: max|u|", float(np.abs(vel0).max()), "sum alpha", float(cols[parity][..., 3].sum()))
+    # ---- light volume on a grid of 18^3 voxels (ceil(18 / 4) = 5 groups per axis: two idle threads per row) and the view march into a
+    #      cube map one mip BELOW the grid (8^2 texels for 16^3: cube LOD 1, Fluid.cpp:324-333)
+    X = 18
+    cb0, cb1 = frame_constants(X, 640, 480)
+    col = smoke_volume(X, 17)
+    lm = di.Texture(np.zeros((X, X, X, 3), F32), "R11G11B10_FLOAT")
+    di.run_shader(os.path.join(BIN, "CSRayMarchL.cso"), (divup(X, 4),) * 3,
+                  {"t0": di.Texture(col), "t1": di.Structured(9, 12, np.zeros((9, 3), F32)), "u0": lm},
+                  {0: cb0.view(U32), 1: cb1.view(U32), 2: np.array([[16, 0, 0, 0]], U32)}, {"s0": di.Sampler("CLAMP")})
+    out["light18_color"], out["light18_cb_per_object"], out["light18_cb_per_frame"], out["light18_lightmap"] = col, cb0, cb1, lm.data.copy()
+    print("wide light 18^3: lightmap range %.3f..%.3f" % (lm.data.min(), lm.data.max()))
+    ren = np.load(os.path.join(OUT, "dxbc_render.npz"))
+    X, S = 16, 8
+    NS1 = 7                                                            # what Fluid::UpdateFrame derives for the 20 x 15 viewport that gives this volume cube LOD 1
+    cb0, cb1 = ren["cb_per_object"], ren["cb_per_frame"]
+    out["cube_lod1_params"] = np.array([X, S, 16, NS1, 8, 0x1B, 20, 15], np.int64)   # grid, cube, light samples, view, merged light, mask, viewport
+    cube = di.Texture(np.zeros((6, S, S, 4), F32), "R8G8B8A8_UNORM")
+    di.run_shader(os.path.join(BIN, "CSRayMarchV.cso"), (S // 8, S // 8, 6),
+                  {"t0": di.Texture(ren["color"]), "t1": di.Texture(ren["lightmap_sh0"]), "u0": cube},
+                  {0: cb0.view(U32), 1: cb1.view(U32), 2: np.array([[NS1, 0, 0, 0]], U32), 3: np.array([[0x1B, 0, 0, 0]], U32)},
+                  {"s0": di.Sampler("CLAMP")})
+    out["cube_lod1_separate"] = np.rint(cube.data * 255).astype(np.uint8)
+    cube = di.Texture(np.zeros((6, S, S, 4), F32), "R8G8B8A8_UNORM")
+    di.run_shader(os.path.join(BIN, "CSRayMarch.cso"), (S // 8, S // 8, 6),
+                  {"t0": di.Texture(ren["color"]), "t1": di.Structured(9, 12, ren["sh"]), "u0": cube},
+                  {0: cb0.view(U32), 1: cb1.view(U32), 2: np.array([[NS1, 0, 8, 0]], U32), 3: np.array([[0x1B, 0, 0, 0]], U32)},
+                  {"s0": di.Sampler("CLAMP")})
+    out["cube_lod1_merged"] = np.rint(cube.data * 255).astype(np.uint8)
+    print("wide cube LOD 1: alpha max", out["cube_lod1_separate"][..., 3].max(), out["cube_lod1_merged"][..., 3].max())
+    # ---- the SH chain at the reference's real size (SH_TEX_SIZE 256: 12288 partials, three CSSHSum passes), as intended and AS SHIPPED
+    rng = np.random.default_rng(19)
+    N = 256
+    base = (rng.random((6, 32, 32, 3)) * np.array([1.0, 0.8, 0.6])).astype(F32)   # HDR-ish radiance on a 32^2 pattern ...
+    base[2, 8:16, 8:16] *= F32(20.0)                                  # ... with a bright window in one face
+    cube = np.repeat(np.repeat(base, N // 32, axis=1), N // 32, axis=2)   # every pattern texel covers 8 x 8 cube texels: the fixture keeps the pattern
+    sh_i, passes = run_sh_chain(cube, 3, False)
+    sh_s, _ = run_sh_chain(cube, 3, True)
+    out["sh256_base32"] = base
+    out["sh256_intended"], out["sh256_as_shipped"], out["sh256_passes"] = sh_i, sh_s, np.array([passes], np.int64)
+    dev = np.abs(sh_s - sh_i).max() / np.abs(sh_i).max()
+    print("wide SH %d^2: %d CSSHSum passes; as-shipped vs intended: max |d| / max |sh| = %.3e" % (N, passes, dev))
+    print("   intended  ", sh_i.ravel()[:6])
+    print("   as shipped", sh_s.ravel()[:6])
+    np.savez_compressed(os.path.join(OUT, "dxbc_wide.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sim", "render", "sh", "resolve", "direct", "env"]
+    which = sys.argv[1:] or ["sim", "render", "sh", "resolve", "direct", "env", "wide"]
     if "sim" in which:
         make_sim()
     if "render" in which:
@@ -346,3 +454,5 @@ if __name__ == "__main__":
         make_direct()
     if "env" in which:
         make_environment()
+    if "wide" in which:
+        make_wide()
