@@ -94,8 +94,9 @@ def test_jacobi_sweep_counts(iters):
 
 @pytest.mark.parametrize("dims", [(256, 256, 200), (512, 512, 100), (256, 256, 193), (256, 256, 257), (512, 512, 97), (512, 512, 131)])
 def test_default_schedule_of_large_grids_is_bit_identical(dims):
-    """grids large enough for the three-sweep kernels run N sweeps as threes + twos (+ a single): 4 = 2 + 2, 5 = 3 + 2,
-    7 = 3 + 2 + 2, ...; every count equals N launches of one sweep bit for bit"""
+    """grids large enough for the multi-sweep strip kernels: X = 512 runs N sweeps as threes + twos (+ a single): 4 = 2 + 2, 5 = 3 + 2,
+    7 = 3 + 2 + 2, ...; X = 256 as fours (k_jacobi_strip4q) with remainders 5 = 3 + 2, 6 = 3 + 3, 7 = 4 + 3; every count equals N launches
+    of one sweep bit for bit"""
     X, Y, Z = dims
     rng = np.random.default_rng(31)
     p = rng.standard_normal((Z, Y, X)).astype(f32)
@@ -103,6 +104,8 @@ def test_default_schedule_of_large_grids_is_bit_identical(dims):
     ref = make(dims, jacobi_fuse=1)
     dut = make(dims)                                     # default schedule
     expect = {1: (1, 1), 2: (1, 2), 3: (1, 3), 4: (2, 4), 5: (2, 5), 7: (3, 7), 8: (3, 8), 10: (4, 10)}
+    if X == 256:
+        expect = {1: (1, 1), 2: (1, 2), 3: (1, 3), 4: (1, 4), 5: (2, 5), 6: (2, 6), 7: (2, 7), 8: (2, 8), 10: (3, 10), 13: (4, 13)}
     for iters, (launches, sweeps) in expect.items():
         for f in (ref, dut):
             f.upload(fx.FIELD_PRESSURE, p)
@@ -421,7 +424,7 @@ def test_x256_full_step_against_oracle(storage, address):
     """The headline grid itself (BASELINE configs[2], and configs[4] with fp16 storage): one whole step at 256^3 from a DEVELOPED state
     -- 48 steps of the plume plus a patch of fast random flow, so that k_advect_lds serves lanes from its LDS tile and lanes through its
     gather path -- stage by stage against the oracle on the same inputs: advection (k_advect_lds), divergence, 40 sweeps in the default
-    schedule (12 x k_jacobi_strip3c + 2 x k_jacobi_strip2u), projection; then fx_simulate as a whole against the staged run."""
+    schedule (10 x k_jacobi_strip4q), projection; then fx_simulate as a whole against the staged run."""
     dims = (256, 256, 256)
     X, Y, Z = dims
     half = storage == "fp16"
@@ -457,7 +460,7 @@ def test_x256_full_step_against_oracle(storage, address):
     f.Synchronize()
     t = f.timing_read(True)
     f.timing_enable(False)
-    assert t.jacobi_sweeps == 40 and t.jacobi_launches == 14 and t.jacobi_main_sweeps == 36      # 12 x 3 + 2 x 2
+    assert t.jacobi_sweeps == 40 and t.jacobi_launches == 10 and t.jacobi_main_sweeps == 40      # 10 x 4 (k_jacobi_strip4q)
     q, _ = orc.jacobi(p, b, 40)
     assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
     f.Project()
