@@ -1026,7 +1026,7 @@ bool jacobi_prefers_four(const Geom& g, int requested, int nzp)
 {
 	const int forced = FX_KNOB_INT("JACOBI_T", 0);
 	const int prefer = FX_KNOB_INT("JACOBI_PREFER4", 1);
-	return prefer && !requested && !forced && jacobi_strip4_supported(g) && (size_t)g.X * g.Y * (size_t)nzp >= (size_t)3 << 22;
+	return prefer && !requested && !forced && jacobi_strip4_supported(g) && (size_t)g.X * g.Y * (size_t)nzp >= (size_t)9 << 20;   // from 144 planes of 256 x 256 (table above)
 }
 
 // Default schedule of the serial rounds (single domain, and slab ranks thick enough): THREE sweeps per launch (k_jacobi_strip3) where that kernel exists and the grid is large
@@ -1039,10 +1039,11 @@ bool jacobi_prefers_three(const Geom& g, int requested, int nzp)
 	const int prefer = FX_KNOB_INT("JACOBI_PREFER3", 1);
 	const int no_lds3 = FX_KNOB_INT("STRIP3_OFF", 0);
 	return prefer && !requested && !forced && !no_lds3 && jacobi_strip3_supported(g) &&
-		(size_t)g.X * g.Y * (size_t)nzp >= (g.X == 512 ? (size_t)1 << 24 : (size_t)3 << 22);
-	// X = 256: from 12.6 M cells (256x256x128 still loses, 11.3 against 11.0 us per sweep).  X = 512 (k_jacobi_strip3h): from 16.8 M
-	// cells since the round-2 hand-over order -- 512x512x64 (a rank of BASELINE configs[3]) 18.7 against 19.5 us per sweep,
-	// 512x512x128 36.2 against 43.7, 512^3 117.6 against 152 (before: 20.3 / 39.6 / 129)
+		(size_t)g.X * g.Y * (size_t)nzp >= (g.X == 512 ? (size_t)1 << 24 : (size_t)7 << 19);
+	// X = 256 (k_jacobi_strip3c): wherever the strips pay at all -- round 5, us per sweep in twos / threes / fours: 256 x 256 x 64 8.1 / 7.2 / 7.5,
+	// x 96 9.0 / 7.8 / 7.9, x 128 10.8 / 8.9 / 8.9, x 192 14.2 / 11.3 / 11.1 (the 12.6 M-cell threshold dated from the kernel before the
+	// cooperative pairs).  X = 512 (k_jacobi_strip3h): from 16.8 M cells since the round-2 hand-over order -- 512x512x64 (a rank of
+	// BASELINE configs[3]) 18.7 against 19.5 us per sweep, 512x512x128 36.2 against 43.7, 512^3 117.6 against 152 (before: 20.3 / 39.6 / 129)
 }
 
 hipError_t launch_jacobi_fused(const Geom& g, const float* p_in, const float* b, float* p_out, int sweeps,
