@@ -45,7 +45,8 @@ class Timing(C.Structure):
                 ("jacobi_main_ms", C.c_double), ("jacobi_main_launches", C.c_uint64), ("jacobi_main_sweeps", C.c_uint64),
                 ("exchange_bytes", C.c_uint64), ("advect_halo_planes", C.c_uint64), ("chain_ms", C.c_double),
                 ("freeze_solves", C.c_uint64), ("freeze_sweeps", C.c_uint64), ("exchange_calls", C.c_uint64),
-                ("view_samples", C.c_uint64), ("light_samples", C.c_uint64), ("lightmap_fetches", C.c_uint64)]
+                ("view_samples", C.c_uint64), ("light_samples", C.c_uint64), ("lightmap_fetches", C.c_uint64),
+                ("freeze_strip_launches", C.c_uint64)]
 
 
 # every symbol include/fluidx_hip.h declares: name -> (restype, argtypes)

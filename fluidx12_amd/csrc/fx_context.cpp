@@ -92,6 +92,7 @@ void free_all(fx_ctx* c)
 	if (c->gath_dev) (void)hipFree(c->gath_dev);
 	if (c->rec_host) (void)hipHostFree(c->rec_host);
 	if (c->fz_active_host) (void)hipHostFree(c->fz_active_host);
+	if (c->fz_active_ev) (void)hipEventDestroy(c->fz_active_ev);
 	if (c->rec_ev) (void)hipEventDestroy(c->rec_ev);
 	if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
 }

@@ -31,6 +31,9 @@ struct fx_ctx {
 	float* p_aux = nullptr;
 	uint32_t* fz_active_host = nullptr;   // pinned, device-visible: tiles the last dense sweeps left relaxing (written by k_count_marks, read late and without waiting)
 	uint32_t* fz_active_dev = nullptr;
+	hipEvent_t fz_active_ev = nullptr;    // recorded behind k_count_marks; the count is taken over two solves later, behind this event: the same on every run
+	bool fz_active_pending = false;
+	bool fz_dense_on = false;             // the masked strip launches are in use (hysteresis: on from half of the tiles, off below two fifths)
 	uint8_t* fz_mask[3] = { nullptr, nullptr, nullptr };   // [2]: the third one of the masked strip launches (three pressure buffers rotate, so do the masks)
 	uint32_t* fz_tile_next = nullptr;  // per tile: tag of the solve that listed it last
 	void* fz_list[2] = { nullptr, nullptr };   // work lists of alternate launches
@@ -133,6 +136,9 @@ struct Seg { char* send; char* recv; size_t bytes; int dir; };
 struct GatherPart { int rank; const char* src; char* dst; size_t bytes; };
 
 // transport behind a group of slab contexts
+// A group (fx_comm_group: its members, lanes, events) must be driven from ONE host thread: the x_ready / x_done event pair of a lane is shared
+// by the exchanges issued on its compute, comm and face streams, and it is the order in which that one thread enqueues them that keeps
+// a record from overtaking the wait it belongs to.  Nothing in the library locks a group.
 struct Transport {
 	virtual ~Transport() {}
 	// segs[i] = segments of grp->members[i] (RCCL: one member = this rank; loop-back: every rank)

@@ -435,10 +435,24 @@ static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 		if (want < 0) {
 			want = 0;
 			if (m->fz_active_dev) {
-				const uint32_t active = *(volatile uint32_t*)m->fz_active_host;
-				if (2u * active >= (uint32_t)jacobi_freeze_tiles(m->g)) want = 3;
-				if ((r.w.gen & 3u) == 0u)                                          // (every fourth solve: the plume changes slowly, the count is a 5-us launch)
+				// every fourth solve counts (the plume changes slowly, the count is a 5-us launch); the solve TWO after it takes the count over,
+				// behind the event recorded with it -- by then it has long arrived, so nothing waits, and which solve switches is a function
+				// of the step sequence, not of when the host happened to look (the unsynchronised read made launch sequences,
+				// step times and kernel statistics vary from run to run around the threshold)
+				if ((r.w.gen & 3u) == 2u && m->fz_active_pending) {
+					FX_HIP(hipEventSynchronize(m->fz_active_ev));
+					m->fz_active_pending = false;
+					const uint32_t active = *(volatile uint32_t*)m->fz_active_host, tiles = (uint32_t)jacobi_freeze_tiles(m->g);
+					if (!m->fz_dense_on && 2u * active >= tiles) m->fz_dense_on = true;
+					else if (m->fz_dense_on && 5u * active < 2u * tiles) m->fz_dense_on = false;
+				}
+				if (m->fz_dense_on) want = 3;
+				if ((r.w.gen & 3u) == 0u) {
 					FX_HIP(launch_count_marks(r.w.tile_mark, r.w.gen, jacobi_freeze_tiles(m->g), m->fz_active_dev, CS(m, s)));
+					if (!m->fz_active_ev) FX_HIP(hipEventCreateWithFlags(&m->fz_active_ev, hipEventDisableTiming));
+					FX_HIP(hipEventRecord(m->fz_active_ev, CS(m, s)));
+					m->fz_active_pending = true;
+				}
 			}
 		}
 		for (int k = 0; want >= 3 && left > 3; ++k, want -= 3) {
@@ -446,6 +460,7 @@ static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 			flag_tag = r.w.gen | ((uint32_t)(k + 1) << 24);
 			FX_HIP(launch_freeze_strip3(r.v, r.a, m->b, r.d, r.src, r.ma, r.md, r.mx, r.w.tile_mark, flag_tag, r.stat, r.stat_hi, level, CS(m, s)));
 			if (mk[0]) { mk[0]->launches += 1; mk[0]->sweeps += 3; }
+			if (m->timing_on) m->acc.freeze_strip_launches += 1;
 			float* na = r.d; r.d = r.src; r.src = r.a; r.a = na;                  // level + 3 now sits in (a, d); the buffer it was read from is the spare
 			uint8_t* nm = r.md; r.md = r.mx; r.mx = r.ma; r.ma = nm;
 			level += 3; left -= 3;

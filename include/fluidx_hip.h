@@ -127,6 +127,9 @@ typedef struct fx_timing {
 	/* FX_OPT_COUNT_SAMPLES: trilinear colour fetches of the view rays, density fetches of the light / AO rays (the light pass's one
 	 * fetch per voxel included), light-map fetches -- summed over the renders since the last reset */
 	uint64_t view_samples, light_samples, lightmap_fetches;
+	/* ABI 6 (FX_JACOBI_FAITHFUL, single domain, X = 256): launches of the masked strip pipeline among jacobi_launches -- which of the two
+	 * launch sequences the solves took (decided per solve from a tile count measured two solves earlier: a function of the step sequence) */
+	uint64_t freeze_strip_launches;
 } fx_timing;
 
 int fx_abi_version(void);
