@@ -178,47 +178,15 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 	Mail4<R> M1, M2, M3;
 	M1.fu = M1.fd = M2.fu = M2.fd = M3.fu = M3.fd = INT_MIN; M1.hu = M1.hd = M2.hu = M2.hd = M3.hu = M3.hd = zero;
 	if (S1) mail_fetch4<R, 1>(st, M1);
-	// ---- sweep 1: level-1 plane q-1 -----------------------------------------------------------------------------------
-	if (q == 0) {                                                       // input plane -1 := plane 0, once (clamped front neighbour)
+#ifndef FX_S4_LATE_PREFETCH
+	// The plane and the b rows that arrived go into their own registers and the NEXT prefetch is issued at once, a whole step ahead of its
+	// use: issued behind sweep 1 it had three quarters of a step, and what the memory system took longer than that stood exposed (one wave
+	// per SIMD hides nothing).
+	v4f NPc[NI], NBc[N1];
 #pragma unroll
-		for (int i = 0; i < NI; ++i) FXQ_LDS(st, st.s_ctr, i) = NP[i];
-	}
-	if (S1) {
-		// (the new plane goes through a local first and into the window by unconditional stores: stores to different window slots in the two
-		// arms of a branch are merged by the compiler into one store through a selected POINTER, which keeps those slots in scratch)
-		v4f T_[N1];
-		if (q - 1 == st.Zg) {                                            // level-1 plane Zg := plane Zg-1
+	for (int i = 0; i < NI; ++i) NPc[i] = NP[i];
 #pragma unroll
-			for (int j = 0; j < N1; ++j) T_[j] = P1[CTR][j];
-		} else {
-			v4f C_[NI], F_[N1];                                           // all LDS rows first: one wave per SIMD cannot hide a ds_read next to its use
-#pragma unroll
-			for (int i = 0; i < NI; ++i) C_[i] = FXQ_LDS(st, st.s_ctr, i);
-#pragma unroll
-			for (int j = 0; j < N1; ++j) F_[j] = FXQ_LDS(st, st.s_old, j + 1);
-#pragma unroll
-			for (int j = 0; j < N1; ++j) T_[j] = relax4q(C_[j + 1], C_[j], C_[j + 2], F_[j], NP[j + 1], NB[j]);
-		}
-#pragma unroll
-		for (int j = 0; j < N1; ++j) P1[NEW][j] = T_[j];
-		if (q - 1 == 0) {                                               // level-1 plane -1 := plane 0
-#pragma unroll
-			for (int j = 0; j < N1; ++j) P1[CTR][j] = T_[j];
-		}
-	}
-	// b[q-4] (the output rows) leaves its slot before b[q-1] moves in; b[q-2] (rows of level 2) is wanted next
-	v4f B4_[NR], B2_[N2];
-#pragma unroll
-	for (int m = 0; m < NR; ++m) B4_[m] = FXQ_LDS(st, st.s_b4, m + 2 * UP);
-#pragma unroll
-	for (int k = 0; k < N2; ++k) B2_[k] = FXQ_LDS(st, st.s_b2, k);
-	// the plane in flight moves to the LDS (over input plane q-2, dead now); the rows of b[q-1] later levels need over b[q-4]
-#pragma unroll
-	for (int i = 0; i < NI; ++i) FXQ_LDS(st, st.s_old, i) = NP[i];
-#pragma unroll
-	for (int k = 0; k < N2; ++k) FXQ_LDS(st, st.s_b4, k) = NB[k + UP];
-	{ const int t_ = st.s_old; st.s_old = st.s_ctr; st.s_ctr = t_; }
-	{ const int t_ = st.s_b4; st.s_b4 = st.s_b3; st.s_b3 = st.s_b2; st.s_b2 = t_; }     // after this: s_b2 = b[q-1], s_b3 = b[q-2], s_b4 = b[q-3]
+	for (int j = 0; j < N1; ++j) NBc[j] = NB[j];
 	// b is what a sweep 1 needs FIRST (L - b opens every cell's sum): it is fetched TWO steps ahead -- b[q + 1] is issued here, into its own
 	// registers, and moves into NB a step later -- and ahead of the input plane, which sweep 1 adds last
 #pragma unroll
@@ -239,6 +207,73 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 #pragma unroll
 		for (int i = 0; i < NI; ++i) NP[i] = *reinterpret_cast<const v4f*>(st.pp + opaque32q(roff[i]));
 	}
+#else
+	v4f (&NPc)[NI] = NP;
+	v4f (&NBc)[N1] = NB;
+#endif
+	// ---- sweep 1: level-1 plane q-1 -----------------------------------------------------------------------------------
+	if (q == 0) {                                                       // input plane -1 := plane 0, once (clamped front neighbour)
+#pragma unroll
+		for (int i = 0; i < NI; ++i) FXQ_LDS(st, st.s_ctr, i) = NPc[i];
+	}
+	if (S1) {
+		// (the new plane goes through a local first and into the window by unconditional stores: stores to different window slots in the two
+		// arms of a branch are merged by the compiler into one store through a selected POINTER, which keeps those slots in scratch)
+		v4f T_[N1];
+		if (q - 1 == st.Zg) {                                            // level-1 plane Zg := plane Zg-1
+#pragma unroll
+			for (int j = 0; j < N1; ++j) T_[j] = P1[CTR][j];
+		} else {
+			v4f C_[NI], F_[N1];                                           // all LDS rows first: one wave per SIMD cannot hide a ds_read next to its use
+#pragma unroll
+			for (int i = 0; i < NI; ++i) C_[i] = FXQ_LDS(st, st.s_ctr, i);
+#pragma unroll
+			for (int j = 0; j < N1; ++j) F_[j] = FXQ_LDS(st, st.s_old, j + 1);
+#pragma unroll
+			for (int j = 0; j < N1; ++j) T_[j] = relax4q(C_[j + 1], C_[j], C_[j + 2], F_[j], NPc[j + 1], NBc[j]);
+		}
+#pragma unroll
+		for (int j = 0; j < N1; ++j) P1[NEW][j] = T_[j];
+		if (q - 1 == 0) {                                               // level-1 plane -1 := plane 0
+#pragma unroll
+			for (int j = 0; j < N1; ++j) P1[CTR][j] = T_[j];
+		}
+	}
+	// b[q-4] (the output rows) leaves its slot before b[q-1] moves in; b[q-2] (rows of level 2) is wanted next
+	v4f B4_[NR], B2_[N2];
+#pragma unroll
+	for (int m = 0; m < NR; ++m) B4_[m] = FXQ_LDS(st, st.s_b4, m + 2 * UP);
+#pragma unroll
+	for (int k = 0; k < N2; ++k) B2_[k] = FXQ_LDS(st, st.s_b2, k);
+	// the plane in flight moves to the LDS (over input plane q-2, dead now); the rows of b[q-1] later levels need over b[q-4]
+#pragma unroll
+	for (int i = 0; i < NI; ++i) FXQ_LDS(st, st.s_old, i) = NPc[i];
+#pragma unroll
+	for (int k = 0; k < N2; ++k) FXQ_LDS(st, st.s_b4, k) = NBc[k + UP];
+	{ const int t_ = st.s_old; st.s_old = st.s_ctr; st.s_ctr = t_; }
+	{ const int t_ = st.s_b4; st.s_b4 = st.s_b3; st.s_b3 = st.s_b2; st.s_b2 = t_; }     // after this: s_b2 = b[q-1], s_b3 = b[q-2], s_b4 = b[q-3]
+#ifdef FX_S4_LATE_PREFETCH
+	// b is what a sweep 1 needs FIRST (L - b opens every cell's sum): it is fetched TWO steps ahead -- b[q + 1] is issued here, into its own
+	// registers, and moves into NB a step later -- and ahead of the input plane, which sweep 1 adds last
+#pragma unroll
+	for (int j = 0; j < N1; ++j) NB[j] = NBn[j];
+#ifdef FX_S4_NOLOAD
+	if (q + 1 <= st.b_load_last && q < -1000) {
+#else
+	if (q + 1 <= st.b_load_last) {
+#endif
+#pragma unroll
+		for (int j = 0; j < N1; ++j) NBn[j] = *reinterpret_cast<const v4f*>(st.pbq + opaque32q(roff[j + 1]));
+	}
+#ifdef FX_S4_NOLOAD
+	if (q + 1 <= st.q_load_last && q < -1000) {
+#else
+	if (q + 1 <= st.q_load_last) {
+#endif
+#pragma unroll
+		for (int i = 0; i < NI; ++i) NP[i] = *reinterpret_cast<const v4f*>(st.pp + opaque32q(roff[i]));
+	}
+#endif
 	st.pp += st.plane_bytes; st.pbq += st.plane_bytes;
 	// hand-over 1, BEHIND the prefetch issue: a wait here must not delay the loads
 	v4f HU1 = zero, HD1 = zero;

@@ -1,8 +1,10 @@
-O=gpurun_out/r5i; mkdir -p $O
-timeout 3000 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; tail -12 $O/pytest_gpu.txt
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-render > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err
-python - <<'PY'
-import json
-d=json.loads([l for l in open("gpurun_out/r5i/bench.json") if l.startswith("{")][-1])
-print(d["value"], d["ms_per_step"], d.get("stage_ms_per_step"), d["roofline"].get("avg_launch_us"), d.get("developed_plume",{}).get("ms_per_step"))
-PY
+O=gpurun_out/r5j; mkdir -p $O
+MB="tools/jacobi_microbench.py --grid 256 --iters 40 --reps 10 --fuse 4"
+run() { export FLUIDX_BUILD_STRIP4_DEFS="$1"; python -m fluidx12_amd.build > $O/build.log 2>&1 || tail -5 $O/build.log; echo "== defs='$1'"; python $MB 2>&1 | grep us_per;  python $MB 2>&1 | grep us_per; }
+{
+run ""
+timeout 600 python -m pytest tests/test_gpu_sim.py -x -q -k "four_sweeps or runs_fours" 2>&1 | tail -2
+run "-DFX_S4_LATE_PREFETCH"
+run ""
+} > $O/variants.txt 2>&1
+cat $O/variants.txt
