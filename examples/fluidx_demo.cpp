@@ -2,8 +2,8 @@
 // OnUpdate's time-step rule (:266) and default camera (:243-253), PopulateCommandList's Simulate + Render
 // (:465,489-490), minus the window.  Build (after `python -m fluidx12_amd.build`):
 //   hipcc -std=c++17 examples/fluidx_demo.cpp -o fluidx_demo -Lfluidx12_amd -lfluidx_hip -Wl,-rpath,$PWD/fluidx12_amd
-// Usage: fluidx_demo [-gridSize X Y Z] [-maxRaySamples N] [-maxLightSamples N] [-radiance cube.dds] [-frames N] [-screenshot out.ppm] [-resume in.fxck] [-checkpoint out.fxck]
-// (FluidX12.cpp:398-433; the screen shot replaces the stb_image_write path of FluidX12.cpp:640-660 with a binary PPM)
+// Usage: fluidx_demo [-gridSize X Y Z] [-maxRaySamples N] [-maxLightSamples N] [-radiance cube.dds] [-frames N] [-screenshot out.png|out.ppm] [-resume in.fxck] [-checkpoint out.fxck]
+// (FluidX12.cpp:398-433; the screen shot is a PNG like the reference's (FluidX12.cpp:640-660), written without a compression library, or a binary PPM by extension)
 #include "../fluidx12_amd/csrc/Fluid.hpp"
 #include <chrono>
 #include <cmath>
@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 
 using namespace fluidx;
 
@@ -33,6 +34,52 @@ static XMFLOAT4X4 PerspectiveFovLH(float fovy, float aspect, float zn, float zf)
 	const float h = std::cos(0.5f * fovy) / std::sin(0.5f * fovy), w = h / aspect, q = zf / (zf - zn);
 	XMFLOAT4X4 m = { { { w, 0, 0, 0 }, { 0, h, 0, 0 }, { 0, 0, q, 1 }, { 0, 0, -q * zn, 0 } } };
 	return m;
+}
+
+// A PNG of the RGBA8 render target, as FluidX12.cpp:640-660 saves one (8-bit RGBA, no interlace).  The pixel rows go into the zlib
+// stream as STORED deflate blocks: every PNG reader takes that, and the demo needs no compression library.
+static uint32_t crc32_of(const uint8_t* d, size_t n, uint32_t c = 0)
+{
+	static uint32_t table[256];
+	if (!table[1]) for (uint32_t i = 0; i < 256; ++i) { uint32_t v = i; for (int k = 0; k < 8; ++k) v = (v & 1u) ? 0xEDB88320u ^ (v >> 1) : v >> 1; table[i] = v; }
+	c = ~c;
+	for (size_t i = 0; i < n; ++i) c = table[(c ^ d[i]) & 255u] ^ (c >> 8);
+	return ~c;
+}
+static void png_chunk(FILE* fp, const char type[5], const std::vector<uint8_t>& body)
+{
+	std::vector<uint8_t> b(4 + body.size());
+	std::memcpy(b.data(), type, 4);
+	if (!body.empty()) std::memcpy(b.data() + 4, body.data(), body.size());
+	const uint32_t len = (uint32_t)body.size(), crc = crc32_of(b.data(), b.size());
+	const uint8_t l[4] = { (uint8_t)(len >> 24), (uint8_t)(len >> 16), (uint8_t)(len >> 8), (uint8_t)len };
+	const uint8_t c[4] = { (uint8_t)(crc >> 24), (uint8_t)(crc >> 16), (uint8_t)(crc >> 8), (uint8_t)crc };
+	std::fwrite(l, 1, 4, fp); std::fwrite(b.data(), 1, b.size(), fp); std::fwrite(c, 1, 4, fp);
+}
+static void write_png(FILE* fp, const uint8_t* rgba, uint32_t w, uint32_t h)
+{
+	static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
+	std::fwrite(sig, 1, 8, fp);
+	std::vector<uint8_t> ihdr = { (uint8_t)(w >> 24), (uint8_t)(w >> 16), (uint8_t)(w >> 8), (uint8_t)w, (uint8_t)(h >> 24), (uint8_t)(h >> 16), (uint8_t)(h >> 8), (uint8_t)h, 8, 6, 0, 0, 0 };
+	png_chunk(fp, "IHDR", ihdr);
+	std::vector<uint8_t> raw;                                            // filter byte 0 + the row
+	raw.reserve((size_t)h * (1 + 4 * (size_t)w));
+	for (uint32_t y = 0; y < h; ++y) { raw.push_back(0); raw.insert(raw.end(), rgba + (size_t)y * w * 4, rgba + (size_t)(y + 1) * w * 4); }
+	std::vector<uint8_t> z = { 0x78, 0x01 };
+	uint32_t a = 1, b = 0;                                               // Adler-32 of the raw bytes
+	for (size_t pos = 0; pos < raw.size() || pos == 0;) {
+		const size_t n = std::min<size_t>(65535, raw.size() - pos);
+		z.push_back(pos + n >= raw.size() ? 1 : 0);                       // BFINAL, BTYPE = 00 (stored)
+		z.push_back((uint8_t)n); z.push_back((uint8_t)(n >> 8)); z.push_back((uint8_t)~n); z.push_back((uint8_t)(~n >> 8));
+		z.insert(z.end(), raw.begin() + (ptrdiff_t)pos, raw.begin() + (ptrdiff_t)(pos + n));
+		for (size_t i = pos; i < pos + n; ++i) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+		pos += n;
+		if (!n) break;
+	}
+	const uint32_t ad = (b << 16) | a;
+	z.push_back((uint8_t)(ad >> 24)); z.push_back((uint8_t)(ad >> 16)); z.push_back((uint8_t)(ad >> 8)); z.push_back((uint8_t)ad);
+	png_chunk(fp, "IDAT", z);
+	png_chunk(fp, "IEND", {});
 }
 
 int main(int argc, char** argv)
@@ -94,8 +141,12 @@ int main(int argc, char** argv)
 		if (!fluid.ReadRenderTarget(rgba)) { std::fprintf(stderr, "read-back failed\n"); return 1; }
 		FILE* fp = std::fopen(screenshot, "wb");
 		if (!fp) { std::perror(screenshot); return 1; }
-		std::fprintf(fp, "P6\n%u %u\n255\n", width, height);
-		for (size_t p = 0; p < (size_t)width * height; ++p) std::fwrite(&rgba[4 * p], 1, 3, fp);
+		const size_t nl = std::strlen(screenshot);
+		if (nl > 4 && !std::strcmp(screenshot + nl - 4, ".png")) write_png(fp, rgba.data(), width, height);      // FluidX12.cpp:640-660 writes a PNG (stbi_write_png)
+		else {
+			std::fprintf(fp, "P6\n%u %u\n255\n", width, height);
+			for (size_t p = 0; p < (size_t)width * height; ++p) std::fwrite(&rgba[4 * p], 1, 3, fp);
+		}
 		std::fclose(fp);
 	}
 	const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -31,7 +31,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # bit-identical (tests/test_gpu_sim.py).
 EXTRA_FLAGS = {"fx_jacobi_strip3.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] + (["-DFX_STRIP3C_ROWS=" + os.environ["FLUIDX_BUILD_STRIP3C_ROWS"]] if os.environ.get("FLUIDX_BUILD_STRIP3C_ROWS") else []),
                "fx_jacobi_strip.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
-               "fx_jacobi_strip4.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] + (["-DFX_STRIP4_OUTER_ROWS=" + os.environ["FLUIDX_BUILD_STRIP4_OUTER_ROWS"]] if os.environ.get("FLUIDX_BUILD_STRIP4_OUTER_ROWS") else []) + os.environ.get("FLUIDX_BUILD_STRIP4_DEFS", "").split(),
+               "fx_jacobi_strip4.hip": (os.environ["FLUIDX_BUILD_STRIP4_SCHED"].split() if os.environ.get("FLUIDX_BUILD_STRIP4_SCHED") is not None else ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]) + (["-DFX_STRIP4_OUTER_ROWS=" + os.environ["FLUIDX_BUILD_STRIP4_OUTER_ROWS"]] if os.environ.get("FLUIDX_BUILD_STRIP4_OUTER_ROWS") else []) + os.environ.get("FLUIDX_BUILD_STRIP4_DEFS", "").split(),
                "fx_render_accel.hip": [("-D%s=%s" % (d, os.environ[e])) for e, d in (("FLUIDX_BUILD_MASK_BITS", "FX_MASK_BUDGET_BITS"), ("FLUIDX_BUILD_VIEW_AHEAD", "FX_VIEW_AHEAD"), ("FLUIDX_BUILD_LIGHT_AHEAD", "FX_LIGHT_AHEAD"), ("FLUIDX_BUILD_LIGHT_RAY_WGS", "FX_LIGHT_RAY_WGS"), ("FLUIDX_BUILD_LIGHT_RAY_UNROLL", "FX_LIGHT_RAY_UNROLL"), ("FLUIDX_BUILD_VIEW_NT", "FX_VIEW_NT"), ("FLUIDX_BUILD_VIEW_WPE", "FX_VIEW_WPE")) if os.environ.get(e)],
                # k_freeze_tiles reserves its list slot with a returning atomic whose round trip is meant to pass behind the staging loads;
                # the wave-aggregating atomic optimizer would wait for it on the spot (readfirstlane of the result)

@@ -379,23 +379,26 @@ int fx_sh_transform(fx_ctx* ctx, const float* cube, uint32_t n, float* out27)
 // ---- timing ---------------------------------------------------------------------------------------------
 int fx_dds_cube_info(const void* dds, size_t bytes, uint32_t* size, uint32_t* mips)
 {
-	size_t fo[6], mo[16];
-	uint32_t sz = 0, nm = 0;
-	if (!dds_bc6h_cube_layout(dds, bytes, &sz, &nm, fo, mo)) return FX_E_INVALID;
-	if (size) *size = sz;
-	if (mips) *mips = nm;
+	DdsCube d;
+	if (!dds_cube_layout(dds, bytes, &d)) return FX_E_INVALID;
+	if (size) *size = d.size;
+	if (mips) *mips = d.mips;
 	return FX_OK;
 }
 
 int fx_dds_decode_cube(fx_ctx* ctx, const void* dds, size_t bytes, uint32_t mip, float* out_cube, size_t out_floats)
 {
 	if (!ctx || !out_cube) return FX_E_INVALID;
-	size_t fo[6], mo[16];
-	uint32_t sz = 0, nm = 0;
-	if (!dds_bc6h_cube_layout(dds, bytes, &sz, &nm, fo, mo) || mip >= nm) return FX_E_INVALID;
-	const uint32_t n = std::max<uint32_t>(sz >> mip, 1), nb = (n + 3) / 4;
+	DdsCube d;
+	if (!dds_cube_layout(dds, bytes, &d) || mip >= d.mips) return FX_E_INVALID;
+	const size_t* fo = d.face_offset; const size_t* mo = d.mip_offset;
+	const uint32_t n = std::max<uint32_t>(d.size >> mip, 1), nb = (n + 3) / 4;
 	const size_t face_floats = (size_t)n * n * 3, face_blocks = (size_t)nb * nb * 16;
 	if (out_floats != 6 * face_floats) return FX_E_INVALID;
+	if (d.kind != DDS_BC6H_UF16) {                                          // uncompressed: a host-side format conversion
+		for (int f = 0; f < 6; ++f) dds_linear_face_to_rgb(static_cast<const char*>(dds) + fo[f] + mo[mip], d.kind, n, out_cube + f * face_floats);
+		return FX_OK;
+	}
 	DeviceGuard dg(ctx->device);
 	const size_t float_bytes = (6 * face_floats * 4 + 15) & ~(size_t)15;     // the blocks are read as 16-byte words
 	int rc = ensure_stage(ctx, float_bytes + 6 * face_blocks);

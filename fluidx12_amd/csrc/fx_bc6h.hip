@@ -203,28 +203,80 @@ hipError_t launch_bc6h_decode(const void* blocks_dev, int nbx, int nby, int n, f
 }
 
 // DDS container: magic, DDS_HEADER (124 B), DDS_HEADER_DXT10 (20 B); cube faces +X -X +Y -Y +Z -Z, each with its mip chain
-bool dds_bc6h_cube_layout(const void* dds, size_t bytes, uint32_t* size, uint32_t* mips, size_t face_offset[6], size_t mip_offset[16])
+// The DDS cube maps LightProbe::Init can be handed (LightProbe.cpp:41-46 goes through XUSG's DDS loader, which takes any DXGI format):
+// DX10-header files in BC6H_UF16 (the reference's own asset) and in the uncompressed formats an HDR or LDR cube is commonly saved in --
+// R32G32B32A32_FLOAT, R32G32B32_FLOAT, R16G16B16A16_FLOAT, R8G8B8A8_UNORM --, and legacy headers whose FourCC is D3DFMT_A16B16G16R16F (113)
+// or D3DFMT_A32B32G32R32F (116).  Faces +X -X +Y -Y +Z -Z, each followed by its mip chain.
+bool dds_cube_layout(const void* dds, size_t bytes, DdsCube* out)
 {
 	const uint8_t* p = static_cast<const uint8_t*>(dds);
-	if (!p || bytes < 148 || std::memcmp(p, "DDS ", 4) != 0) return false;
-	uint32_t h[31], dx[5];
+	if (!p || !out || bytes < 128 || std::memcmp(p, "DDS ", 4) != 0) return false;
+	uint32_t h[31];
 	std::memcpy(h, p + 4, sizeof h);
-	std::memcpy(dx, p + 128, sizeof dx);
-	if (h[0] != 124 || h[18] != 32 || std::memcmp(&h[20], "DX10", 4) != 0) return false;
+	if (h[0] != 124 || h[18] != 32) return false;
 	const uint32_t height = h[2], width = h[3], nm = h[6] ? h[6] : 1;
-	if (dx[0] != 95 /* DXGI_FORMAT_BC6H_UF16 */ || !(dx[2] & 4u) /* TEXTURECUBE */ || width != height || !width || nm > 15) return false;
+	size_t data = 128;
+	int kind = -1;
+	if (std::memcmp(&h[20], "DX10", 4) == 0) {
+		if (bytes < 148) return false;
+		uint32_t dx[5];
+		std::memcpy(dx, p + 128, sizeof dx);
+		if (!(dx[2] & 4u) /* TEXTURECUBE */ || dx[1] != 3 /* TEXTURE2D */) return false;
+		switch (dx[0]) {
+		case 95: kind = DDS_BC6H_UF16; break;
+		case 2: kind = DDS_RGBA32F; break;
+		case 6: kind = DDS_RGB32F; break;
+		case 10: kind = DDS_RGBA16F; break;
+		case 28: kind = DDS_RGBA8; break;
+		default: return false;
+		}
+		data = 148;
+	} else if ((h[19] & 4u) /* DDPF_FOURCC */ && (h[27] & 0x200u) /* DDSCAPS2_CUBEMAP */ && (h[27] & 0xFC00u) == 0xFC00u /* all six faces */) {
+		if (h[20] == 113) kind = DDS_RGBA16F;
+		else if (h[20] == 116) kind = DDS_RGBA32F;
+		else return false;
+	} else return false;
+	if (width != height || !width || nm > 15) return false;
 	// D3D11's largest texture extent; also keeps (width + 3) inside 32 bits (0xFFFFFFFF used to wrap to a zero-block face and pass)
 	if (width > 16384u || (nm > 1 && (width >> (nm - 1)) == 0)) return false;
+	static const size_t texel[] = { 0, 16, 12, 8, 4 };
 	size_t per_face = 0;
 	for (uint32_t m = 0; m < nm; ++m) {
-		const size_t nb = ((width >> m ? width >> m : 1) + 3) / 4;
-		mip_offset[m] = per_face;
-		per_face += nb * nb * 16;
+		const size_t n = width >> m ? width >> m : 1, nb = (n + 3) / 4;
+		out->mip_offset[m] = per_face;
+		per_face += kind == DDS_BC6H_UF16 ? nb * nb * 16 : n * n * texel[kind];
 	}
-	if (148 + 6 * per_face > bytes) return false;
-	for (int f = 0; f < 6; ++f) face_offset[f] = 148 + (size_t)f * per_face;
-	*size = width; *mips = nm;
+	if (data + 6 * per_face > bytes) return false;
+	for (int f = 0; f < 6; ++f) out->face_offset[f] = data + (size_t)f * per_face;
+	out->size = width; out->mips = nm; out->kind = kind;
 	return true;
+}
+
+static float half_bits_to_float(uint16_t v)
+{
+	const uint32_t s = (uint32_t)(v & 0x8000u) << 16, e = (v >> 10) & 31u, m = v & 1023u;
+	uint32_t u;
+	if (e == 0) {
+		if (!m) u = s;
+		else { int k = 0; uint32_t mm = m; while (!(mm & 1024u)) { mm <<= 1; ++k; } u = s | ((uint32_t)(113 - k) << 23) | ((mm & 1023u) << 13); }
+	} else if (e == 31) u = s | 0x7F800000u | (m << 13);
+	else u = s | ((e + 112u) << 23) | (m << 13);
+	float f;
+	std::memcpy(&f, &u, 4);
+	return f;
+}
+
+// one face of an uncompressed mip -> float rgb (host; a light probe is a few hundred kilobytes)
+void dds_linear_face_to_rgb(const void* texels, int kind, size_t n, float* out)
+{
+	const uint8_t* p = static_cast<const uint8_t*>(texels);
+	for (size_t i = 0; i < n * n; ++i) {
+		float c[3];
+		if (kind == DDS_RGBA32F || kind == DDS_RGB32F) std::memcpy(c, p + i * (kind == DDS_RGBA32F ? 16 : 12), 12);
+		else if (kind == DDS_RGBA16F) { uint16_t hh[3]; std::memcpy(hh, p + i * 8, 6); for (int k = 0; k < 3; ++k) c[k] = half_bits_to_float(hh[k]); }
+		else for (int k = 0; k < 3; ++k) c[k] = (float)p[i * 4 + k] / 255.0f;
+		out[3 * i] = c[0]; out[3 * i + 1] = c[1]; out[3 * i + 2] = c[2];
+	}
 }
 
 }  // namespace fx

@@ -202,7 +202,10 @@ hipError_t launch_environment(const float* cube, int n, const FrameConsts& fc, i
 
 // ---- BC6H_UF16 / DDS cube (fx_bc6h.hip; row f-4)
 hipError_t launch_bc6h_decode(const void* blocks_dev, int nbx, int nby, int n, float* out_dev, hipStream_t s);
-bool dds_bc6h_cube_layout(const void* dds, size_t bytes, uint32_t* size, uint32_t* mips, size_t face_offset[6], size_t mip_offset[16]);
+enum { DDS_BC6H_UF16 = 0, DDS_RGBA32F = 1, DDS_RGB32F = 2, DDS_RGBA16F = 3, DDS_RGBA8 = 4 };
+struct DdsCube { uint32_t size, mips; int kind; size_t face_offset[6], mip_offset[16]; };
+bool dds_cube_layout(const void* dds, size_t bytes, DdsCube* out);
+void dds_linear_face_to_rgb(const void* texels, int kind, size_t n, float* out);
 
 // ---- SH light probe (fx_sh.hip): cube float[6][n][n][3] (device) -> out float[27] (device)
 hipError_t launch_sh_transform(const float* cube, int n, float* scratch0, float* scratch1, float* w0, float* w1,

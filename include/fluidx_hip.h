@@ -206,10 +206,12 @@ int fx_project(fx_ctx* ctx, void* stream);
  * order-3 SH of a radiance cube float[6][N][N][3] (host), coefficients to out27 (host) */
 int fx_sh_transform(fx_ctx* ctx, const float* cube, uint32_t n, float* out27);
 
-/* LightProbe::Init's asset path (LightProbe.cpp:41-46, row f-4): a DDS cube map in DXGI_FORMAT_BC6H_UF16 with a DX10
- * header -- the reference's Bin/Assets/rnl_cross.dds -- to linear float radiance.  fx_dds_cube_info: edge of mip 0 and mip
- * count (FX_E_INVALID for any other container/format); fx_dds_decode_cube: mip `mip` of all six faces (order +X -X +Y -Y
- * +Z -Z) decoded on the device into out_cube float[6][n][n][3] (n = max(size >> mip, 1); out_floats must be 18 n^2). */
+/* LightProbe::Init's asset path (LightProbe.cpp:41-46 hands a DDS file to XUSG's loader, row f-4): a DDS cube map to linear float
+ * radiance.  Accepted: DX10-header files in DXGI_FORMAT_BC6H_UF16 (the reference's Bin/Assets/rnl_cross.dds; decoded on the device),
+ * R32G32B32A32_FLOAT, R32G32B32_FLOAT, R16G16B16A16_FLOAT, R8G8B8A8_UNORM, and legacy headers with FourCC 113 / 116
+ * (D3DFMT_A16B16G16R16F / A32B32G32R32F); every face carries its whole mip chain.  fx_dds_cube_info: edge of mip 0 and mip count
+ * (FX_E_INVALID for any other container / format); fx_dds_decode_cube: mip `mip` of all six faces (order +X -X +Y -Y +Z -Z) as
+ * out_cube float[6][n][n][3] (n = max(size >> mip, 1); out_floats must be 18 n^2; alpha is dropped). */
 int fx_dds_cube_info(const void* dds, size_t bytes, uint32_t* size, uint32_t* mips);
 int fx_dds_decode_cube(fx_ctx* ctx, const void* dds, size_t bytes, uint32_t mip, float* out_cube, size_t out_floats);
 

@@ -43,6 +43,29 @@ def test_cxx_demo_leaves_the_python_path_s_fields_and_picture(tmp_path, grid, fr
         assert fp.readline() == b"P6\n" and fp.readline() == b"800 800\n" and fp.readline() == b"255\n"
         shot = np.frombuffer(fp.read(), np.uint8).reshape(800, 800, 3)
 
+    # the same run saved as a PNG (the reference's screen-shot format, FluidX12.cpp:640-660): a valid file -- signature, chunk CRCs, a zlib
+    # stream any inflater takes -- holding exactly the PPM's pixels
+    if frames == 5:
+        import struct
+        import zlib
+        png = str(tmp_path / "shot.png")
+        r = subprocess.run([exe, "-gridSize", *(str(v) for v in grid), "-frames", str(frames), "-screenshot", png], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        raw = open(png, "rb").read()
+        assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+        pos, chunks = 8, []
+        while pos < len(raw):
+            n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+            body = raw[pos + 8:pos + 8 + n]
+            assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + body)
+            chunks.append((typ, body))
+            pos += 12 + n
+        assert [t for t, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+        assert struct.unpack(">IIBBBBB", chunks[0][1]) == (800, 800, 8, 6, 0, 0, 0)
+        rows = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(800, 1 + 4 * 800)
+        assert not rows[:, 0].any()                                   # filter type 0 on every row
+        assert np.array_equal(rows[:, 1:].reshape(800, 800, 4)[..., :3], shot)
+
     # the same frames through the Python mirror of the operator surface (what every other GPU test drives)
     f = fx.Fluid()
     assert f.Init(800, 800, grid, storage="fp16", jacobi_iters=64, jacobi_mode="faithful", advect_address="clamp")
