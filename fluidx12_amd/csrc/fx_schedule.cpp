@@ -460,7 +460,7 @@ static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 			flag_tag = r.w.gen | ((uint32_t)(k + 1) << 24);
 			FX_HIP(launch_freeze_strip3(r.v, r.a, m->b, r.d, r.src, r.ma, r.md, r.mx, r.w.tile_mark, flag_tag, r.stat, r.stat_hi, level, CS(m, s)));
 			if (mk[0]) { mk[0]->launches += 1; mk[0]->sweeps += 3; }
-			if (m->timing_on) m->acc.freeze_strip_launches += 1;
+			m->acc.freeze_strip_launches += 1;                                  // (counted like the solves: with or without the timing marks)
 			float* na = r.d; r.d = r.src; r.src = r.a; r.a = na;                  // level + 3 now sits in (a, d); the buffer it was read from is the spare
 			uint8_t* nm = r.md; r.md = r.mx; r.mx = r.ma; r.ma = nm;
 			level += 3; left -= 3;

@@ -1,2 +1,7 @@
-O=gpurun_out/r5k; mkdir -p $O
-timeout 1500 python -m pytest tests/test_gpu_bc6h.py tests/test_gpu_cxx_dropin.py tests/test_gpu_golden.py tests/test_gpu_freeze.py -x -q > $O/t.log 2>&1; tail -12 $O/t.log
+O=gpurun_out/r5l; mkdir -p $O
+for L in -1 0 3; do FLUIDX_FREEZE_DENSE_LEVELS=$L python bench.py --reference-config --no-cpu-baseline --no-render > $O/ref_$L.json 2> $O/ref_$L.err; python - $O/ref_$L.json $L <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("levels", sys.argv[2], "ms", round(d["ms_per_step"],4), "developed", d.get("developed_plume"))
+PY
+done
