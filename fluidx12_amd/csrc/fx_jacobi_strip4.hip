@@ -116,6 +116,12 @@ __device__ __forceinline__ void mail_fetch4(const Strip4<R>& st, Mail4<R>& m)
 	return;
 #endif
 	const int q = st.q, w = st.wave, pr = (q - 1) & 1;
+#ifdef FX_S4_BARRIER
+	if (!R::A) m.hu = st.xbuf[xrow(pr, w - 1, L - 1, 0) + st.lane];     // (behind the step's barrier every neighbour's rows of step q - 1 are there)
+	if (!R::W) m.hd = st.xbuf[xrow(pr, w, L - 1, 1) + st.lane];
+	m.fu = m.fd = INT_MAX;
+	return;
+#endif
 	const int* flags = reinterpret_cast<const int*>(st.xflag);
 	// counter first, row behind it: a wave's LDS operations execute in order, so a counter that is high enough vouches for the row
 	if (!R::A) m.fu = __hip_atomic_load(flags + (L - 1) * 4 + w - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -147,7 +153,9 @@ __device__ __forceinline__ void hand_over4(const Strip4<R>& st, Mail4<R>& m, con
 	asm volatile("" ::: "memory");
 	if (!R::A) st.xbuf[xrow(pw, w - 1, L - 1, 1) + st.lane] = mine_top;
 	if (!R::W) st.xbuf[xrow(pw, w, L - 1, 0) + st.lane] = mine_bot;
+#ifndef FX_S4_BARRIER
 	if (st.lane == 0) lds_post4(st.xf0 + 4u * (uint32_t)((L - 1) * 4 + w), q);        // LDS operations of a wave execute in order
+#endif
 }
 
 // sweep L + 1 from the window of level L (NL rows) into NN rows; b rows from `Brow`
@@ -177,6 +185,11 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 	const v4f zero = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
 	Mail4<R> M1, M2, M3;
 	M1.fu = M1.fd = M2.fu = M2.fd = M3.fu = M3.fd = INT_MIN; M1.hu = M1.hd = M2.hu = M2.hd = M3.hu = M3.hd = zero;
+#ifdef FX_S4_BARRIER
+	// one workgroup barrier per z step instead of the per-level counters: behind it every wave has published its rows of step q - 1
+	// (its LDS writes are complete: lgkmcnt(0); the prefetch and the output stores in flight are NOT waited for)
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 	if (S1) mail_fetch4<R, 1>(st, M1);
 #ifndef FX_S4_LATE_PREFETCH
 	// The plane and the b rows that arrived go into their own registers and the NEXT prefetch is issued at once, a whole step ahead of its
