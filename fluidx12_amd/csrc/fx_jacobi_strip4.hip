@@ -37,15 +37,16 @@ constexpr int NRO = FX_STRIP4_OUTER_ROWS;   // rows of an outer wave
 constexpr int NRI = 8 - NRO;                // rows of an inner wave (a workgroup = 2 x (NRO + NRI) = 16 rows)
 
 // A: the wave recomputes a halo ABOVE its rows (the quad's top wave), W: below (the bottom wave).
-template <int NR_, bool A_, bool W_> struct Role4 {
+template <int NR_, bool A_, bool W_, int NW_ = 4> struct Role4 {
 	static constexpr int NR = NR_;
+	static constexpr int NW = NW_;                                            // waves per workgroup: NW - 1 inner boundaries, NW counters per level
 	static constexpr bool A = A_, W = W_;
 	static constexpr int NI = NR + (A ? 4 : 1) + (W ? 4 : 1);                 // input rows per plane; row i <-> y0 - (A ? 4 : 1) + i
 	static constexpr int N1 = NR + (A ? 3 : 0) + (W ? 3 : 0);                 // level-l rows; row j <-> y0 - (A ? 4 - l : 0) + j
 	static constexpr int N2 = NR + (A ? 2 : 0) + (W ? 2 : 0);
 	static constexpr int N3 = NR + (A ? 1 : 0) + (W ? 1 : 0);
 	static constexpr int UP = A ? 1 : 0;                                      // index shift between consecutive levels
-	static constexpr int LDS_ROWS = 2 * NI + 3 * N2;                          // two input planes, three parked b planes (rows of level 2)
+	static constexpr int LDS_ROWS = 2 * NI + (NW == 4 ? 3 : 2) * N2;           // two input planes; three parked b planes (rows of level 2) -- two for the octet's lean waves, which keep b[q-2] in registers
 };
 typedef Role4<NRO, true, false> RoleTop;
 typedef Role4<NRI, false, false> RoleMid;
@@ -54,7 +55,15 @@ constexpr int Q_LDS_ROWS = RoleTop::LDS_ROWS + 2 * RoleMid::LDS_ROWS + RoleBot::
 constexpr int Q_XROWS = 2 * 3 * 3 * 2;          // [step parity][boundary][level 1..3][0: the upper wave's row, 1: the lower wave's]
 static_assert((Q_LDS_ROWS + Q_XROWS) * 1024 + 64 <= 160 * 1024, "the quad's windows must fit the CU's LDS");
 
-__device__ __forceinline__ constexpr int xrow(int par, int bnd, int lv, int dir) { return ((((par * 3 + bnd) * 3 + lv) * 2 + dir)) * 64; }
+#ifdef FX_O_ONLYMID
+#define FX_WU(w) (((w) + 7) & 7)
+#define FX_WD(w) (((w) + 1) & 7)
+template <int NW> __device__ __forceinline__ constexpr int xrow(int par, int bnd, int lv, int dir) { return ((((par * NW + bnd) * 3 + lv) * 2 + dir)) * 64; }
+#else
+#define FX_WU(w) ((w) - 1)
+#define FX_WD(w) ((w) + 1)
+template <int NW> __device__ __forceinline__ constexpr int xrow(int par, int bnd, int lv, int dir) { return ((((par * (NW - 1) + bnd) * 3 + lv) * 2 + dir)) * 64; }
+#endif
 
 // the windows are native vectors, not HIP's float4 struct: a struct copied under a condition becomes a select of POINTERS into the window
 // array, which keeps the whole array out of registers
@@ -117,19 +126,19 @@ __device__ __forceinline__ void mail_fetch4(const Strip4<R>& st, Mail4<R>& m)
 #endif
 	const int q = st.q, w = st.wave, pr = (q - 1) & 1;
 #ifdef FX_S4_BARRIER
-	if (!R::A) m.hu = st.xbuf[xrow(pr, w - 1, L - 1, 0) + st.lane];     // (behind the step's barrier every neighbour's rows of step q - 1 are there)
-	if (!R::W) m.hd = st.xbuf[xrow(pr, w, L - 1, 1) + st.lane];
+	if (!R::A) m.hu = st.xbuf[xrow<R::NW>(pr, FX_WU(w), L - 1, 0) + st.lane];     // (behind the step's barrier every neighbour's rows of step q - 1 are there)
+	if (!R::W) m.hd = st.xbuf[xrow<R::NW>(pr, w, L - 1, 1) + st.lane];
 	m.fu = m.fd = INT_MAX;
 	return;
 #endif
 	const int* flags = reinterpret_cast<const int*>(st.xflag);
 	// counter first, row behind it: a wave's LDS operations execute in order, so a counter that is high enough vouches for the row
-	if (!R::A) m.fu = __hip_atomic_load(flags + (L - 1) * 4 + w - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-	if (!R::W) m.fd = __hip_atomic_load(flags + (L - 1) * 4 + w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	if (!R::A) m.fu = __hip_atomic_load(flags + (L - 1) * R::NW + FX_WU(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	if (!R::W) m.fd = __hip_atomic_load(flags + (L - 1) * R::NW + FX_WD(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	asm volatile("" ::: "memory");
 	__builtin_amdgcn_sched_barrier(0);
-	if (!R::A) m.hu = st.xbuf[xrow(pr, w - 1, L - 1, 0) + st.lane];
-	if (!R::W) m.hd = st.xbuf[xrow(pr, w, L - 1, 1) + st.lane];
+	if (!R::A) m.hu = st.xbuf[xrow<R::NW>(pr, FX_WU(w), L - 1, 0) + st.lane];
+	if (!R::W) m.hd = st.xbuf[xrow<R::NW>(pr, w, L - 1, 1) + st.lane];
 	asm volatile("" ::: "memory");
 	__builtin_amdgcn_sched_barrier(0);                                  // (the machine scheduler would otherwise sink the row loads to their use)
 }
@@ -143,18 +152,18 @@ __device__ __forceinline__ void hand_over4(const Strip4<R>& st, Mail4<R>& m, con
 	const int q = st.q, w = st.wave;
 	const int pr = (q - 1) & 1, pw = q & 1;
 	if (!R::A) {
-		if (__builtin_expect(m.fu < q - 1, 0)) m.hu = lds_wait_read4(st.xf0 + 4u * (uint32_t)((L - 1) * 4 + w - 1), q - 1, st.xb0 + 16u * (uint32_t)(xrow(pr, w - 1, L - 1, 0) + st.lane));
+		if (__builtin_expect(m.fu < q - 1, 0)) m.hu = lds_wait_read4(st.xf0 + 4u * (uint32_t)((L - 1) * R::NW + FX_WU(w)), q - 1, st.xb0 + 16u * (uint32_t)(xrow<R::NW>(pr, FX_WU(w), L - 1, 0) + st.lane));
 		HU = m.hu;
 	}
 	if (!R::W) {
-		if (__builtin_expect(m.fd < q - 1, 0)) m.hd = lds_wait_read4(st.xf0 + 4u * (uint32_t)((L - 1) * 4 + w + 1), q - 1, st.xb0 + 16u * (uint32_t)(xrow(pr, w, L - 1, 1) + st.lane));
+		if (__builtin_expect(m.fd < q - 1, 0)) m.hd = lds_wait_read4(st.xf0 + 4u * (uint32_t)((L - 1) * R::NW + FX_WD(w)), q - 1, st.xb0 + 16u * (uint32_t)(xrow<R::NW>(pr, w, L - 1, 1) + st.lane));
 		HD = m.hd;
 	}
 	asm volatile("" ::: "memory");
-	if (!R::A) st.xbuf[xrow(pw, w - 1, L - 1, 1) + st.lane] = mine_top;
-	if (!R::W) st.xbuf[xrow(pw, w, L - 1, 0) + st.lane] = mine_bot;
+	if (!R::A) st.xbuf[xrow<R::NW>(pw, FX_WU(w), L - 1, 1) + st.lane] = mine_top;
+	if (!R::W) st.xbuf[xrow<R::NW>(pw, w, L - 1, 0) + st.lane] = mine_bot;
 #ifndef FX_S4_BARRIER
-	if (st.lane == 0) lds_post4(st.xf0 + 4u * (uint32_t)((L - 1) * 4 + w), q);        // LDS operations of a wave execute in order
+	if (st.lane == 0) lds_post4(st.xf0 + 4u * (uint32_t)((L - 1) * R::NW + w), q);        // LDS operations of a wave execute in order
 #endif
 }
 
@@ -177,7 +186,7 @@ __device__ __forceinline__ void relax_level4(const Strip4<R>& st, const v4f (&Po
 }
 
 template <class R, int PH, bool S1, bool S2, bool S3, bool S4>
-__device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&P2)[3][R::N2], v4f (&P3)[3][R::N3], v4f (&NP)[R::NI], v4f (&NB)[R::N1], v4f (&NBn)[R::N1], const uint32_t (&roff)[R::NI])
+__device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&P2)[3][R::N2], v4f (&P3)[3][R::N3], v4f (&NP)[R::NI], v4f (&NB)[R::N1], v4f (&NBn)[R::N1], v4f (&Bk)[R::N2], const uint32_t (&roff)[R::NI])
 {
 	constexpr int NEW = PH % 3, CTR = (PH + 2) % 3, OLD = (PH + 1) % 3;
 	constexpr int NI = R::NI, N1 = R::N1, N2 = R::N2, N3 = R::N3, NR = R::NR, UP = R::UP;
@@ -191,43 +200,52 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 	if (S1) mail_fetch4<R, 1>(st, M1);
-#ifndef FX_S4_LATE_PREFETCH
-	// The plane and the b rows that arrived go into their own registers and the NEXT prefetch is issued at once, a whole step ahead of its
-	// use: issued behind sweep 1 it had three quarters of a step, and what the memory system took longer than that stood exposed (one wave
-	// per SIMD hides nothing).
-	v4f NPc[NI], NBc[N1];
+	// EARLY (the quad): the plane and the b rows that arrived go into their own registers and the NEXT prefetch is issued at once, a whole
+	// step ahead of its use; b is fetched two steps ahead into NBn (L - b opens every cell's sum).  LEAN (the octet's outer waves, two waves
+	// per SIMD: every register counts, the other wave of the SIMD covers the waits): no copies, no second b buffer, the prefetch goes out
+	// behind sweep 1 into the registers that sweep has just read.
+#ifdef FX_S4_LATE_PREFETCH
+	constexpr bool EARLY = false;
+#else
+	constexpr bool EARLY = R::NW == 4;
+#endif
+	constexpr bool LEAN = R::NW != 4;
+	v4f NPc[EARLY ? NI : 1], NBc[EARLY ? N1 : 1];
+	auto issue_prefetch = [&]() __attribute__((always_inline)) {
+		if (!LEAN) {
 #pragma unroll
-	for (int i = 0; i < NI; ++i) NPc[i] = NP[i];
-#pragma unroll
-	for (int j = 0; j < N1; ++j) NBc[j] = NB[j];
-	// b is what a sweep 1 needs FIRST (L - b opens every cell's sum): it is fetched TWO steps ahead -- b[q + 1] is issued here, into its own
-	// registers, and moves into NB a step later -- and ahead of the input plane, which sweep 1 adds last
-#pragma unroll
-	for (int j = 0; j < N1; ++j) NB[j] = NBn[j];
+			for (int j = 0; j < N1; ++j) NB[j] = NBn[j];
+		}
 #ifdef FX_S4_NOLOAD
-	if (q + 1 <= st.b_load_last && q < -1000) {
+		if (q + 1 <= st.b_load_last && q < -1000) {
 #else
-	if (q + 1 <= st.b_load_last) {
+		if (LEAN ? q <= st.b_load_last : q + 1 <= st.b_load_last) {
 #endif
 #pragma unroll
-		for (int j = 0; j < N1; ++j) NBn[j] = *reinterpret_cast<const v4f*>(st.pbq + opaque32q(roff[j + 1]));
-	}
+			for (int j = 0; j < N1; ++j) (LEAN ? NB[j] : NBn[j]) = *reinterpret_cast<const v4f*>(st.pbq + opaque32q(roff[j + 1]));
+		}
 #ifdef FX_S4_NOLOAD
-	if (q + 1 <= st.q_load_last && q < -1000) {
+		if (q + 1 <= st.q_load_last && q < -1000) {
 #else
-	if (q + 1 <= st.q_load_last) {
+		if (q + 1 <= st.q_load_last) {
 #endif
 #pragma unroll
-		for (int i = 0; i < NI; ++i) NP[i] = *reinterpret_cast<const v4f*>(st.pp + opaque32q(roff[i]));
+			for (int i = 0; i < NI; ++i) NP[i] = *reinterpret_cast<const v4f*>(st.pp + opaque32q(roff[i]));
+		}
+	};
+	if (EARLY) {
+#pragma unroll
+		for (int i = 0; i < NI; ++i) NPc[i] = NP[i];
+#pragma unroll
+		for (int j = 0; j < N1; ++j) NBc[j] = NB[j];
+		issue_prefetch();
 	}
-#else
-	v4f (&NPc)[NI] = NP;
-	v4f (&NBc)[N1] = NB;
-#endif
+	auto np = [&](int i) __attribute__((always_inline)) -> v4f { return EARLY ? NPc[EARLY ? i : 0] : NP[i]; };
+	auto nb = [&](int j) __attribute__((always_inline)) -> v4f { return EARLY ? NBc[EARLY ? j : 0] : NB[j]; };
 	// ---- sweep 1: level-1 plane q-1 -----------------------------------------------------------------------------------
 	if (q == 0) {                                                       // input plane -1 := plane 0, once (clamped front neighbour)
 #pragma unroll
-		for (int i = 0; i < NI; ++i) FXQ_LDS(st, st.s_ctr, i) = NPc[i];
+		for (int i = 0; i < NI; ++i) FXQ_LDS(st, st.s_ctr, i) = np(i);
 	}
 	if (S1) {
 		// (the new plane goes through a local first and into the window by unconditional stores: stores to different window slots in the two
@@ -237,13 +255,26 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 #pragma unroll
 			for (int j = 0; j < N1; ++j) T_[j] = P1[CTR][j];
 		} else {
-			v4f C_[NI], F_[N1];                                           // all LDS rows first: one wave per SIMD cannot hide a ds_read next to its use
+			if (!LEAN) {
+				v4f C_[NI], F_[N1];                                       // all LDS rows first: one wave per SIMD cannot hide a ds_read next to its use
 #pragma unroll
-			for (int i = 0; i < NI; ++i) C_[i] = FXQ_LDS(st, st.s_ctr, i);
+				for (int i = 0; i < NI; ++i) C_[i] = FXQ_LDS(st, st.s_ctr, i);
 #pragma unroll
-			for (int j = 0; j < N1; ++j) F_[j] = FXQ_LDS(st, st.s_old, j + 1);
+				for (int j = 0; j < N1; ++j) F_[j] = FXQ_LDS(st, st.s_old, j + 1);
 #pragma unroll
-			for (int j = 0; j < N1; ++j) T_[j] = relax4q(C_[j + 1], C_[j], C_[j + 2], F_[j], NPc[j + 1], NBc[j]);
+				for (int j = 0; j < N1; ++j) T_[j] = relax4q(C_[j + 1], C_[j], C_[j + 2], F_[j], np(j + 1), nb(j));
+			} else {                                                      // lean: a sliding window of three rows (the SIMD's other wave covers the LDS latency; registers are what is short)
+				v4f u_ = FXQ_LDS(st, st.s_ctr, 0), c_ = FXQ_LDS(st, st.s_ctr, 1);
+#pragma unroll
+				for (int j = 0; j < N1; ++j) {
+					const v4f d_ = FXQ_LDS(st, st.s_ctr, j + 2), f_ = FXQ_LDS(st, st.s_old, j + 1);
+					T_[j] = relax4q(c_, u_, d_, f_, np(j + 1), nb(j));
+					u_ = c_; c_ = d_;
+#ifdef FX_O_SCHEDBAR
+					__builtin_amdgcn_sched_barrier(0);
+#endif
+				}
+			}
 		}
 #pragma unroll
 		for (int j = 0; j < N1; ++j) P1[NEW][j] = T_[j];
@@ -256,37 +287,29 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 	v4f B4_[NR], B2_[N2];
 #pragma unroll
 	for (int m = 0; m < NR; ++m) B4_[m] = FXQ_LDS(st, st.s_b4, m + 2 * UP);
+	if (!LEAN) {
 #pragma unroll
-	for (int k = 0; k < N2; ++k) B2_[k] = FXQ_LDS(st, st.s_b2, k);
+		for (int k = 0; k < N2; ++k) B2_[k] = FXQ_LDS(st, st.s_b2, k);
+	} else {                                                            // lean: b[q-2] waited in registers; it goes to the LDS now (over b[q-4]), b[q-1] takes its place
+#pragma unroll
+		for (int k = 0; k < N2; ++k) B2_[k] = Bk[k];
+	}
 	// the plane in flight moves to the LDS (over input plane q-2, dead now); the rows of b[q-1] later levels need over b[q-4]
 #pragma unroll
-	for (int i = 0; i < NI; ++i) FXQ_LDS(st, st.s_old, i) = NPc[i];
+	for (int i = 0; i < NI; ++i) FXQ_LDS(st, st.s_old, i) = np(i);
+	if (!LEAN) {
 #pragma unroll
-	for (int k = 0; k < N2; ++k) FXQ_LDS(st, st.s_b4, k) = NBc[k + UP];
+		for (int k = 0; k < N2; ++k) FXQ_LDS(st, st.s_b4, k) = nb(k + UP);
+		{ const int t_ = st.s_b4; st.s_b4 = st.s_b3; st.s_b3 = st.s_b2; st.s_b2 = t_; }     // after this: s_b2 = b[q-1], s_b3 = b[q-2], s_b4 = b[q-3]
+	} else {
+#pragma unroll
+		for (int k = 0; k < N2; ++k) FXQ_LDS(st, st.s_b4, k) = B2_[k];
+#pragma unroll
+		for (int k = 0; k < N2; ++k) Bk[k] = nb(k + UP);
+		{ const int t_ = st.s_b4; st.s_b4 = st.s_b3; st.s_b3 = t_; }                       // two slots: s_b3 = b[q-2] (just written), s_b4 = b[q-3]
+	}
 	{ const int t_ = st.s_old; st.s_old = st.s_ctr; st.s_ctr = t_; }
-	{ const int t_ = st.s_b4; st.s_b4 = st.s_b3; st.s_b3 = st.s_b2; st.s_b2 = t_; }     // after this: s_b2 = b[q-1], s_b3 = b[q-2], s_b4 = b[q-3]
-#ifdef FX_S4_LATE_PREFETCH
-	// b is what a sweep 1 needs FIRST (L - b opens every cell's sum): it is fetched TWO steps ahead -- b[q + 1] is issued here, into its own
-	// registers, and moves into NB a step later -- and ahead of the input plane, which sweep 1 adds last
-#pragma unroll
-	for (int j = 0; j < N1; ++j) NB[j] = NBn[j];
-#ifdef FX_S4_NOLOAD
-	if (q + 1 <= st.b_load_last && q < -1000) {
-#else
-	if (q + 1 <= st.b_load_last) {
-#endif
-#pragma unroll
-		for (int j = 0; j < N1; ++j) NBn[j] = *reinterpret_cast<const v4f*>(st.pbq + opaque32q(roff[j + 1]));
-	}
-#ifdef FX_S4_NOLOAD
-	if (q + 1 <= st.q_load_last && q < -1000) {
-#else
-	if (q + 1 <= st.q_load_last) {
-#endif
-#pragma unroll
-		for (int i = 0; i < NI; ++i) NP[i] = *reinterpret_cast<const v4f*>(st.pp + opaque32q(roff[i]));
-	}
-#endif
+	if (!EARLY) issue_prefetch();
 	st.pp += st.plane_bytes; st.pbq += st.plane_bytes;
 	// hand-over 1, BEHIND the prefetch issue: a wait here must not delay the loads
 	v4f HU1 = zero, HD1 = zero;
@@ -356,7 +379,10 @@ __device__ __forceinline__ void run4(const Geom& g, const float* __restrict__ p_
 	int zb, int ze, int y0, int wave, int lane, v4f* lds_slice, v4f* xbuf, int* xflag)
 {
 	Strip4<R> st;
-	v4f P1[3][R::N1], P2[3][R::N2], P3[3][R::N3], NP[R::NI], NB[R::N1], NBn[R::N1];
+#ifndef FX_O_NOPRIO
+	if (R::NW != 4) __builtin_amdgcn_s_setprio(2);                      // the octet's outer waves have the longest z step: they go first on their SIMD
+#endif
+	v4f P1[3][R::N1], P2[3][R::N2], P3[3][R::N3], NP[R::NI], NB[R::N1], NBn[R::N1], Bk[R::N2];
 	uint32_t roff[R::NI];
 	const v4f zero = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
 	const int qs = max(zb - 4, g.zlo), q_last = ze - 1 + 4;
@@ -371,7 +397,7 @@ __device__ __forceinline__ void run4(const Geom& g, const float* __restrict__ p_
 #pragma unroll
 	for (int i = 0; i < R::NI; ++i) roff[i] = ((uint32_t)min(max(yb + i, 0), g.Y - 1) * (uint32_t)g.X + 4u * (uint32_t)lane) * 4u;
 	st.s_ctr = 0; st.s_old = R::NI * 64;
-	st.s_b2 = 2 * R::NI * 64; st.s_b3 = st.s_b2 + R::N2 * 64; st.s_b4 = st.s_b3 + R::N2 * 64;
+	st.s_b2 = 2 * R::NI * 64; st.s_b3 = st.s_b2 + (R::NW == 4 ? R::N2 * 64 : 0); st.s_b4 = st.s_b3 + R::N2 * 64;      // (lean waves: two b slots, s_b3 and s_b4)
 #pragma unroll
 	for (int k = 0; k < 3; ++k) {
 #pragma unroll
@@ -383,6 +409,8 @@ __device__ __forceinline__ void run4(const Geom& g, const float* __restrict__ p_
 	}
 #pragma unroll
 	for (int i = 0; i < R::LDS_ROWS; ++i) st.lds[i * 64] = zero;
+#pragma unroll
+	for (int k = 0; k < R::N2; ++k) Bk[k] = zero;
 	const size_t plane = g.plane();
 	st.plane_bytes = plane * 4;
 	const bool fill = qs == zb - 4;
@@ -415,26 +443,255 @@ __device__ __forceinline__ void run4(const Geom& g, const float* __restrict__ p_
 	}
 	st.q = q0;
 	st.pp = reinterpret_cast<const char*>(p_in) + ((ptrdiff_t)g.lz(q0) + 1) * (ptrdiff_t)st.plane_bytes;
-	st.pbq = reinterpret_cast<const char*>(b) + ((ptrdiff_t)g.lz(q0) + 1) * (ptrdiff_t)st.plane_bytes;
+	st.pbq = reinterpret_cast<const char*>(b) + ((ptrdiff_t)g.lz(q0) + (R::NW == 4 ? 1 : 0)) * (ptrdiff_t)st.plane_bytes;   // (the quad fetches b[q + 1] in step q, a lean wave b[q])
 	st.po_zb = reinterpret_cast<char*>(p_out) + (ptrdiff_t)g.lz(zb) * (ptrdiff_t)st.plane_bytes;
 	st.po = reinterpret_cast<char*>(p_out) + ((ptrdiff_t)g.lz(q0) - 4) * (ptrdiff_t)st.plane_bytes;      // (only dereferenced for planes inside the chunk)
 	// the rest of the pipeline's fill, peeled as in k_jacobi_strip3c: level-l planes below zb - 4 + l feed nothing that is stored
 	if (fill) {
-		step4<R, 0, true, false, false, false>(st, P1, P2, P3, NP, NB, NBn, roff);
-		step4<R, 1, true, false, false, false>(st, P1, P2, P3, NP, NB, NBn, roff);
-		step4<R, 2, true, true, false, false>(st, P1, P2, P3, NP, NB, NBn, roff);
-		step4<R, 0, true, true, false, false>(st, P1, P2, P3, NP, NB, NBn, roff);
-		step4<R, 1, true, true, true, false>(st, P1, P2, P3, NP, NB, NBn, roff);
-		step4<R, 2, true, true, true, false>(st, P1, P2, P3, NP, NB, NBn, roff);
+		step4<R, 0, true, false, false, false>(st, P1, P2, P3, NP, NB, NBn, Bk, roff);
+		step4<R, 1, true, false, false, false>(st, P1, P2, P3, NP, NB, NBn, Bk, roff);
+		step4<R, 2, true, true, false, false>(st, P1, P2, P3, NP, NB, NBn, Bk, roff);
+		step4<R, 0, true, true, false, false>(st, P1, P2, P3, NP, NB, NBn, Bk, roff);
+		step4<R, 1, true, true, true, false>(st, P1, P2, P3, NP, NB, NBn, Bk, roff);
+		step4<R, 2, true, true, true, false>(st, P1, P2, P3, NP, NB, NBn, Bk, roff);
 	}
 	for (;;) {
-		step4<R, 0, true, true, true, true>(st, P1, P2, P3, NP, NB, NBn, roff);
+		step4<R, 0, true, true, true, true>(st, P1, P2, P3, NP, NB, NBn, Bk, roff);
 		if (st.q > q_last) break;
-		step4<R, 1, true, true, true, true>(st, P1, P2, P3, NP, NB, NBn, roff);
+		step4<R, 1, true, true, true, true>(st, P1, P2, P3, NP, NB, NBn, Bk, roff);
 		if (st.q > q_last) break;
-		step4<R, 2, true, true, true, true>(st, P1, P2, P3, NP, NB, NBn, roff);
+		step4<R, 2, true, true, true, true>(st, P1, P2, P3, NP, NB, NBn, Bk, roff);
 		if (st.q > q_last) break;
 	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The OCTET (k_jacobi_strip4o): the same pipeline with EIGHT waves of two rows per workgroup, two per SIMD.  A lone wave pays ~5 cycles
+// per instruction whatever it is (tools/micro/issue_rate.cpp) and leaves the VALU pipe half idle; a second wave per SIMD takes the other
+// half -- if every wave fits 256 registers and the workgroup the LDS.  So the six inner waves keep EVERYTHING in registers (the input
+// window is a level-0 register window of three planes rotated by name, the b planes waiting for sweeps 2..4 a ring of three); only the two
+// outer waves (two rows + the recomputed halo) park their input and b planes in the LDS as the quad's waves do.  LDS: 2 x 26 rows + 84
+// mailbox rows (seven inner boundaries) = 136 KiB.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <class R, int PH, bool S1, bool S2, bool S3, bool S4>
+__device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&P1)[3][R::NR], v4f (&P2)[3][R::NR], v4f (&P3)[3][R::NR],
+	v4f (&NB)[R::NR], v4f (&Bp)[3][R::NR], const uint32_t (&roff)[R::NI])
+{
+	static_assert(!R::A && !R::W, "the register-window step serves inner waves");
+	constexpr int NEW = PH % 3, CTR = (PH + 2) % 3, OLD = (PH + 1) % 3;
+	constexpr int NI = R::NI, NR = R::NR;
+	const int q = st.q;
+	const v4f zero = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+	Mail4<R> M1, M2, M3;
+	M1.fu = M1.fd = M2.fu = M2.fd = M3.fu = M3.fd = INT_MIN; M1.hu = M1.hd = M2.hu = M2.hd = M3.hu = M3.hd = zero;
+	if (S1) mail_fetch4<R, 1>(st, M1);
+	// ---- sweep 1: level-1 plane q-1 from input planes q-2 (OLD), q-1 (CTR), q (NEW: arrived) and b[q-1] (NB) ----
+	if (q == 0) {                                                       // input plane -1 := plane 0, once
+#pragma unroll
+		for (int i = 0; i < NI; ++i) I[CTR][i] = I[NEW][i];
+	}
+	if (S1) {
+		v4f T_[NR];
+		if (q - 1 == st.Zg) {
+#pragma unroll
+			for (int j = 0; j < NR; ++j) T_[j] = P1[CTR][j];
+		} else {
+#pragma unroll
+			for (int j = 0; j < NR; ++j) T_[j] = relax4q(I[CTR][j + 1], I[CTR][j], I[CTR][j + 2], I[OLD][j + 1], I[NEW][j + 1], NB[j]);
+		}
+#pragma unroll
+		for (int j = 0; j < NR; ++j) P1[NEW][j] = T_[j];
+		if (q - 1 == 0) {
+#pragma unroll
+			for (int j = 0; j < NR; ++j) P1[CTR][j] = T_[j];
+		}
+	}
+	// the b ring: [NEW] = b[q-2], [CTR] = b[q-3], [OLD] = b[q-4] on entry (named like the windows: they rotate with them)
+	v4f B2_[NR], B3_[NR], B4_[NR];
+#pragma unroll
+	for (int j = 0; j < NR; ++j) { B2_[j] = Bp[NEW][j]; B3_[j] = Bp[CTR][j]; B4_[j] = Bp[OLD][j]; }
+#pragma unroll
+	for (int j = 0; j < NR; ++j) Bp[OLD][j] = NB[j];                     // b[q-1] takes the place of b[q-4]: [OLD] is the next step's [NEW]
+	// the prefetch: input plane q+1 into the registers of plane q-2 (dead: [OLD] is the next step's [NEW]), b[q] into NB
+	if (q + 1 <= st.q_load_last) {
+#pragma unroll
+		for (int i = 0; i < NI; ++i) I[OLD][i] = *reinterpret_cast<const v4f*>(st.pp + opaque32q(roff[i]));
+	} else {                                                            // past the last present plane the window keeps plane zhi
+#pragma unroll
+		for (int i = 0; i < NI; ++i) I[OLD][i] = I[NEW][i];
+	}
+	if (q <= st.b_load_last) {
+#pragma unroll
+		for (int j = 0; j < NR; ++j) NB[j] = *reinterpret_cast<const v4f*>(st.pbq + opaque32q(roff[j + 1]));
+	}
+	st.pp += st.plane_bytes; st.pbq += st.plane_bytes;
+	v4f HU1 = zero, HD1 = zero;
+	if (S1) hand_over4<R, 1>(st, M1, P1[NEW][0], P1[NEW][NR - 1], HU1, HD1);
+	if (S2) mail_fetch4<R, 2>(st, M2);
+	// ---- sweep 2 ----
+	if (S2) {
+		v4f T_[NR];
+		if (q - 2 == st.Zg) {
+#pragma unroll
+			for (int k = 0; k < NR; ++k) T_[k] = P2[CTR][k];
+		} else {
+			relax_level4<R, 1, NR, NR>(st, P1[OLD], P1[CTR], P1[NEW], B2_, HU1, HD1, T_);
+		}
+#pragma unroll
+		for (int k = 0; k < NR; ++k) P2[NEW][k] = T_[k];
+		if (q - 2 == 0) {
+#pragma unroll
+			for (int k = 0; k < NR; ++k) P2[CTR][k] = T_[k];
+		}
+	}
+	v4f HU2 = zero, HD2 = zero;
+	if (S2) hand_over4<R, 2>(st, M2, P2[NEW][0], P2[NEW][NR - 1], HU2, HD2);
+	if (S3) mail_fetch4<R, 3>(st, M3);
+	// ---- sweep 3 ----
+	if (S3) {
+		v4f T_[NR];
+		if (q - 3 == st.Zg) {
+#pragma unroll
+			for (int m = 0; m < NR; ++m) T_[m] = P3[CTR][m];
+		} else {
+			relax_level4<R, 2, NR, NR>(st, P2[OLD], P2[CTR], P2[NEW], B3_, HU2, HD2, T_);
+		}
+#pragma unroll
+		for (int m = 0; m < NR; ++m) P3[NEW][m] = T_[m];
+		if (q - 3 == 0) {
+#pragma unroll
+			for (int m = 0; m < NR; ++m) P3[CTR][m] = T_[m];
+		}
+	}
+	v4f HU3 = zero, HD3 = zero;
+	if (S3) hand_over4<R, 3>(st, M3, P3[NEW][0], P3[NEW][NR - 1], HU3, HD3);
+	// ---- sweep 4: the output ----
+	if (S4) {
+		v4f X_[NR];
+		relax_level4<R, 3, NR, NR>(st, P3[OLD], P3[CTR], P3[NEW], B4_, HU3, HD3, X_);
+		char* dst_ = q - 4 >= st.zb ? st.po : st.po_zb;
+#pragma unroll
+		for (int m = 0; m < NR; ++m) *reinterpret_cast<v4f*>(dst_ + opaque32q(roff[m + 1])) = X_[m];
+	}
+	st.po += st.plane_bytes;
+	++st.q;
+}
+
+template <class R>
+__device__ __forceinline__ void run4r(const Geom& g, const float* __restrict__ p_in, const float* __restrict__ b, float* __restrict__ p_out,
+	int zb, int ze, int y0, int wave, int lane, v4f* xbuf, int* xflag)
+{
+	Strip4<R> st;
+	v4f I[3][R::NI], P1[3][R::NR], P2[3][R::NR], P3[3][R::NR], NB[R::NR], Bp[3][R::NR];
+	uint32_t roff[R::NI];
+	const v4f zero = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+	const int qs = max(zb - 4, g.zlo), q_last = ze - 1 + 4;
+	st.q_load_last = min(q_last, g.zhi);
+	st.b_load_last = min(q_last - 1, g.zhi);
+	st.zb = zb; st.ze = ze; st.Zg = g.Zg; st.wave = wave; st.lane = lane;
+	st.wall_top = false; st.wall_bot = false;
+	st.lds = nullptr; st.xbuf = xbuf; st.xflag = xflag;
+	st.xf0 = (uint32_t)(size_t)(__attribute__((address_space(3))) int*)xflag;
+	st.xb0 = (uint32_t)(size_t)(__attribute__((address_space(3))) v4f*)xbuf;
+	st.s_ctr = st.s_old = st.s_b2 = st.s_b3 = st.s_b4 = 0;
+	const int yb = y0 - 1;
+#pragma unroll
+	for (int i = 0; i < R::NI; ++i) roff[i] = ((uint32_t)min(max(yb + i, 0), g.Y - 1) * (uint32_t)g.X + 4u * (uint32_t)lane) * 4u;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+#pragma unroll
+		for (int i = 0; i < R::NR; ++i) { P1[k][i] = zero; P2[k][i] = zero; P3[k][i] = zero; Bp[k][i] = zero; }
+#pragma unroll
+		for (int i = 0; i < R::NI; ++i) I[k][i] = zero;
+	}
+	const size_t plane = g.plane();
+	st.plane_bytes = plane * 4;
+	const bool fill = qs == zb - 4;
+	const int q0 = fill ? qs + 2 : qs;
+	// the walk starts with phase 0: [NEW] = slot 0 takes plane q0, [CTR] = slot 2 plane q0 - 1, [OLD] = slot 1 plane q0 - 2 (a chunk that starts
+	// four planes below its first output plane fetches all three at once: its first two steps have nothing to compute)
+	{
+		const char* pb = reinterpret_cast<const char*>(p_in + (size_t)g.lz(min(q0, st.q_load_last)) * plane);
+#pragma unroll
+		for (int i = 0; i < R::NI; ++i) I[0][i] = *reinterpret_cast<const v4f*>(pb + roff[i]);
+		const char* bbase = reinterpret_cast<const char*>(b + (size_t)g.lz(min(max(q0 - 1, g.zlo), g.zhi)) * plane);
+#pragma unroll
+		for (int j = 0; j < R::NR; ++j) NB[j] = *reinterpret_cast<const v4f*>(bbase + roff[j + 1]);
+		if (fill) {
+			const char* pa = reinterpret_cast<const char*>(p_in + (size_t)g.lz(qs) * plane);
+#pragma unroll
+			for (int i = 0; i < R::NI; ++i) I[1][i] = *reinterpret_cast<const v4f*>(pa + roff[i]);
+#pragma unroll
+			for (int i = 0; i < R::NI; ++i) I[2][i] = *reinterpret_cast<const v4f*>(pa + st.plane_bytes + roff[i]);
+		}
+	}
+	st.q = q0;
+	st.pp = reinterpret_cast<const char*>(p_in) + ((ptrdiff_t)g.lz(q0) + 1) * (ptrdiff_t)st.plane_bytes;
+	st.pbq = reinterpret_cast<const char*>(b) + (ptrdiff_t)g.lz(q0) * (ptrdiff_t)st.plane_bytes;          // (this walk fetches b[q] in step q)
+	st.po_zb = reinterpret_cast<char*>(p_out) + (ptrdiff_t)g.lz(zb) * (ptrdiff_t)st.plane_bytes;
+	st.po = reinterpret_cast<char*>(p_out) + ((ptrdiff_t)g.lz(q0) - 4) * (ptrdiff_t)st.plane_bytes;
+	if (fill) {
+		step4r<R, 0, true, false, false, false>(st, I, P1, P2, P3, NB, Bp, roff);
+		step4r<R, 1, true, false, false, false>(st, I, P1, P2, P3, NB, Bp, roff);
+		step4r<R, 2, true, true, false, false>(st, I, P1, P2, P3, NB, Bp, roff);
+		step4r<R, 0, true, true, false, false>(st, I, P1, P2, P3, NB, Bp, roff);
+		step4r<R, 1, true, true, true, false>(st, I, P1, P2, P3, NB, Bp, roff);
+		step4r<R, 2, true, true, true, false>(st, I, P1, P2, P3, NB, Bp, roff);
+	}
+	for (;;) {
+		step4r<R, 0, true, true, true, true>(st, I, P1, P2, P3, NB, Bp, roff);
+		if (st.q > q_last) break;
+		step4r<R, 1, true, true, true, true>(st, I, P1, P2, P3, NB, Bp, roff);
+		if (st.q > q_last) break;
+		step4r<R, 2, true, true, true, true>(st, I, P1, P2, P3, NB, Bp, roff);
+		if (st.q > q_last) break;
+	}
+}
+
+// rows per wave, top to bottom: 1 2 2 2 2 2 2 1 -- a band of FOURTEEN rows.  The outer waves (one row + the recomputed halo: 4 + 3 + 2 + 1 = 10
+// row updates per step) park their input planes and two b planes in the LDS, the six 2-row waves (8 updates) live in registers.  What a
+// step costs is its slowest wave: with two rows in the outer waves (14 updates + the LDS traffic) the octet ran at the quad's speed, and a
+// 3-row inner wave does not fit 256 registers.  Bands of 14 do not tile 256 rows: the last band is shifted up to end at the last row and
+// recomputes the rows it shares with its neighbour -- the same inputs through the same arithmetic, so both store the same bits.
+typedef Role4<1, true, false, 8> OctTop;
+typedef Role4<2, false, false, 8> OctMid;
+typedef Role4<1, false, true, 8> OctBot;
+constexpr int O_BAND = 14;
+constexpr int O_LDS_ROWS = OctTop::LDS_ROWS + OctBot::LDS_ROWS;
+#ifdef FX_O_ONLYMID
+constexpr int O_XROWS = 2 * 8 * 3 * 2;
+#else
+constexpr int O_XROWS = 2 * 7 * 3 * 2;
+#endif
+static_assert((O_LDS_ROWS + O_XROWS) * 1024 + 128 <= 160 * 1024, "the octet's windows must fit the CU's LDS");
+
+__global__ __launch_bounds__(512, 2) void k_jacobi_strip4o(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
+	float* __restrict__ p_out, int z_begin, int z_end, int zchunk, int ngroups, int nchunks, int remap)
+{
+	__shared__ v4f lds_all[O_LDS_ROWS * 64];
+	__shared__ v4f xbuf[O_XROWS * 64];
+	__shared__ int xflag[24];                                          // [level 1..3][wave]
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	int tile = (int)blockIdx.x;
+	if (remap) {
+		const int n = ngroups * nchunks, qn = n >> 3, r = n & 7;
+		const int xcd = tile & 7, j = tile >> 3;
+		tile = xcd * qn + min(xcd, r) + j;
+	}
+	const int grp = tile % ngroups, chunk = tile / ngroups;
+	const int zb = z_begin + chunk * zchunk, ze = min(zb + zchunk, z_end);
+	const int qs = max(zb - 4, g.zlo);
+	const bool fill = qs == zb - 4;
+	if (threadIdx.x < 24) xflag[threadIdx.x] = fill ? qs + 2 * ((int)threadIdx.x / 8 + 1) - 1 : qs - 1;
+	for (int i = (int)threadIdx.x; i < O_XROWS * 64; i += 512) xbuf[i] = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+	__syncthreads();
+	const int yg = min(grp * O_BAND, g.Y - O_BAND);                     // (the last band is shifted up to end at the last row)
+#ifdef FX_O_ONLYMID
+	run4r<OctMid>(g, p_in, b, p_out, zb, ze, yg + 2 * wave, wave, lane, xbuf, xflag); return;   // (timing experiment: eight register-window waves in a ring; results are wrong)
+#endif
+	if (wave == 0) run4<OctTop>(g, p_in, b, p_out, zb, ze, yg, wave, lane, lds_all, xbuf, xflag);
+	else if (wave == 7) run4<OctBot>(g, p_in, b, p_out, zb, ze, yg + O_BAND - 1, wave, lane, lds_all + OctTop::LDS_ROWS * 64, xbuf, xflag);
+	else run4r<OctMid>(g, p_in, b, p_out, zb, ze, yg + 2 * wave - 1, wave, lane, xbuf, xflag);
 }
 
 __global__ __launch_bounds__(256, 1) void k_jacobi_strip4q(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
@@ -472,7 +729,9 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip4q(const Geom g, const f
 
 bool jacobi_strip4_supported(const Geom& g)
 {
-	return g.Zg > 1 && g.X == 256 && (g.Y & 15) == 0 && g.Y >= 16;
+	// the octet takes any Y >= 14 (bands of 14 rows, the last one shifted); the quad (STRIP4_OCTET=0) whole bands of 16
+	if (g.Zg <= 1 || g.X != 256) return false;
+	return FX_KNOB_INT("STRIP4_OCTET", 1) ? g.Y >= O_BAND : ((g.Y & 15) == 0 && g.Y >= 16);
 }
 
 hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b, float* p_out, int z_begin, int z_end, hipStream_t s)
@@ -488,7 +747,17 @@ hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b
 	if (zchunk < 8) zchunk = 8;
 	if (zchunk > nzp) zchunk = nzp;
 	nchunks = (nzp + zchunk - 1) / zchunk;
-	hipLaunchKernelGGL(k_jacobi_strip4q, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
+	if (FX_KNOB_INT("STRIP4_OCTET", 1) && g.Y >= O_BAND) {     // the octet (two waves per SIMD) is the default; 0 = the quad
+		const int bands = (g.Y + O_BAND - 1) / O_BAND;                  // 19 bands of 14 rows at Y = 256 (the last one shifted)
+		int nch = 256 / bands;                                          // one workgroup of eight waves per CU
+		if (nch < 1) nch = 1;
+		int zc = forced_chunk > 0 ? forced_chunk : (nzp + nch - 1) / nch;
+		if (zc < 8) zc = 8;
+		if (zc > nzp) zc = nzp;
+		nch = (nzp + zc - 1) / zc;
+		hipLaunchKernelGGL(k_jacobi_strip4o, dim3(bands * nch), dim3(512), 0, s, g, p_in, b, p_out, z_begin, z_end, zc, bands, nch, remap);
+	} else
+		hipLaunchKernelGGL(k_jacobi_strip4q, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
 	return hipGetLastError();
 }
 

@@ -1020,13 +1020,17 @@ int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp)
 	return t < 1 ? 1 : (t > 3 ? 3 : t);
 }
 
-// FOUR sweeps per launch (k_jacobi_strip4q) where that kernel exists and the launch is large enough to fill the chip with 16-plane chunks:
-// 40 sweeps = 10 launches.  JACOBI_PREFER4=0 keeps the threes; an explicit jacobi_fuse / JACOBI_T request is always honoured as given.
+// FOUR sweeps per launch (fx_jacobi_strip4.hip) where the kernels exist: 40 sweeps = 10 launches.  With the octet kernel (k_jacobi_strip4o,
+// the default) from 24 planes of 256 x 256 -- round 5, us per sweep at 256 x 256 x D in ones / twos / threes / fours: D = 24 5.7 / 7.4 / 6.8 / 5.3,
+// 32 6.2 / 7.7 / 6.9 / 5.2, 64 9.6 / 8.1 / 7.3 / 5.6, 96 - / - / 7.7 / 6.1, 128 8.8 (threes) / 7.1, 192 11.3 / 9.6, 256 14.0 / 12.1, 400 23.3 / 19.0;
+// with the quad kernel (STRIP4_OCTET=0) from 144 planes.  JACOBI_PREFER4=0 keeps the threes; an explicit jacobi_fuse / JACOBI_T request is
+// always honoured as given.
 bool jacobi_prefers_four(const Geom& g, int requested, int nzp)
 {
 	const int forced = FX_KNOB_INT("JACOBI_T", 0);
 	const int prefer = FX_KNOB_INT("JACOBI_PREFER4", 1);
-	return prefer && !requested && !forced && jacobi_strip4_supported(g) && (size_t)g.X * g.Y * (size_t)nzp >= (size_t)9 << 20;   // from 144 planes of 256 x 256 (table above)
+	const bool octet = FX_KNOB_INT("STRIP4_OCTET", 1) != 0;
+	return prefer && !requested && !forced && jacobi_strip4_supported(g) && (size_t)g.X * g.Y * (size_t)nzp >= (octet ? (size_t)3 << 19 : (size_t)9 << 20);
 }
 
 // Default schedule of the serial rounds (single domain, and slab ranks thick enough): THREE sweeps per launch (k_jacobi_strip3) where that kernel exists and the grid is large

@@ -189,11 +189,14 @@ def test_x256_three_sweeps_at_odd_depths_bit_exact(depth):
     assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
 
 
+@pytest.mark.parametrize("kernel", ["octet", "quad"])
 @pytest.mark.parametrize("depth", [2, 4, 5, 9, 17, 33, 50, 128])
-def test_x256_four_sweeps_at_odd_depths_bit_exact(depth):
-    """X = 256, FOUR sweeps per launch (k_jacobi_strip4q: a workgroup's four waves as a quad over 16 rows, edge rows handed over through
-    LDS mailboxes) on odd and tiny depths: chunks of unequal length, the pipeline's fill and drain next to both domain faces, the y
-    walls in the first and last quad; == oracle, bit for bit"""
+def test_x256_four_sweeps_at_odd_depths_bit_exact(depth, kernel, knob):
+    """X = 256, FOUR sweeps per launch on odd and tiny depths: chunks of unequal length, the pipeline's fill and drain next to both domain
+    faces, the y walls in the first and last band; == oracle, bit for bit.  Both kernels: k_jacobi_strip4o (the default: eight waves of
+    a workgroup, two per SIMD, over a band of 14 rows -- the inner six with every window in registers --, the last band shifted up over
+    its neighbour) and k_jacobi_strip4q (four waves as a quad over 16 rows); edge rows handed over through LDS mailboxes in both"""
+    knob("STRIP4_OCTET", "1" if kernel == "octet" else "0")
     rows = 256
     dims = (256, rows, depth)
     _, _, p = rand_state(*dims, 41)
@@ -209,9 +212,11 @@ def test_x256_four_sweeps_at_odd_depths_bit_exact(depth):
     assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
 
 
-def test_x256_default_schedule_runs_fours_bit_exact():
-    """the default schedule at 256^3-class sizes: 40 sweeps = ten launches of k_jacobi_strip4q; 256 x 256 x 200 against the oracle, and odd
-    sweep counts (remainders of 5 / 6 / 7 as 3 + 2 / 3 + 3 / 4 + 3)"""
+@pytest.mark.parametrize("kernel", ["octet", "quad"])
+def test_x256_default_schedule_runs_fours_bit_exact(kernel, knob):
+    """the default schedule at 256^3-class sizes: 40 sweeps = ten launches of four sweeps (k_jacobi_strip4o, or k_jacobi_strip4q with
+    STRIP4_OCTET=0); 256 x 256 x 200 against the oracle, and odd sweep counts (remainders of 5 / 6 / 7 as 3 + 2 / 3 + 3 / 4 + 3)"""
+    knob("STRIP4_OCTET", "1" if kernel == "octet" else "0")
     dims = (256, 256, 200)
     _, _, p = rand_state(*dims, 43)
     b = np.random.default_rng(44).uniform(-1, 1, (200, 256, 256)).astype(f32)

@@ -916,12 +916,14 @@ def test_peer_group_across_two_devices():
     assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
 
 
+@pytest.mark.parametrize("kernel", ["octet", "quad"])
 @pytest.mark.parametrize("hj,iters,overlap", [(9, 23, 1), (7, 16, 1), (5, 11, 0), (9, 20, 2)])
-def test_four_sweep_kernel_on_uneven_slab_ranges(hj, iters, overlap):
-    """k_jacobi_strip4q on the trapezoid ranges of slab ranks: three slabs of 256 x 256 x 470 (156 / 157 / 157 planes: above the 9.4 M cells
+def test_four_sweep_kernel_on_uneven_slab_ranges(hj, iters, overlap, kernel, knob):
+    """k_jacobi_strip4o / k_jacobi_strip4q on the trapezoid ranges of slab ranks: three slabs of 256 x 256 x 470 (156 / 157 / 157 planes: above the 9.4 M cells
     from which fours are the default), rounds of 9 / 7 / 5 sweeps = 4 + 3 + 2, 4 + 3, 3 + 2 -- launch ranges that start and end inside the
     halo, chunks cut off by the first / last present plane (no fill), the global faces in the outer ranks; bit-identical to one sweep
     per launch on the single domain"""
+    knob("STRIP4_OCTET", "1" if kernel == "octet" else "0")
     dims = (256, 256, 470)
     ref = run_single(dims, 2, jacobi_iters=iters, jacobi_fuse=1)
     fl = run_slabs(dims, 2, 3, jacobi_iters=iters, halo_jacobi=hj, halo_advect=8, overlap=overlap)
