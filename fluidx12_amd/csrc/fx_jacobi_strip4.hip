@@ -1,26 +1,37 @@
-// fx_jacobi_strip4.hip -- FOUR lock-step Jacobi sweeps per launch (X = 256): k_jacobi_strip3c's streaming register / LDS windows, with a
-// workgroup's four waves as a QUAD that shares 16 rows.
+// fx_jacobi_strip4.hip -- FOUR lock-step Jacobi sweeps per launch (X = 256): k_jacobi_strip3c's streaming register / LDS windows with the
+// waves of a workgroup sharing a band of rows, every inner boundary an LDS mailbox.  Two kernels:
+//   k_jacobi_strip4o  (the default) EIGHT waves per workgroup, two per SIMD, over a band of 14 rows (1 + 2 + 2 + 2 + 2 + 2 + 2 + 1);
+//   k_jacobi_strip4q  (STRIP4_OCTET=0) four waves, one per SIMD, over a band of 16 rows (3 + 5 + 5 + 3).
 //
 // Restates CSPoisson.hlsli:8-26 (/root/reference/FluidX12/Content/Shaders/) like every Jacobi kernel here: the per-cell arithmetic and its
 // association order, ((((((L - b) + R) + U) + D) + F) + B) * (1/6), are unchanged (relax4_pairs, fx_pk.h), so four fused sweeps are
 // bit-identical to four single ones.
 //
-// Why a quad.  k_jacobi_strip3c (fx_jacobi_strip3.hip) is a PAIR design: two 4-row strips, each recomputing its outer y-halo.  A fourth
+// Why bands.  k_jacobi_strip3c (fx_jacobi_strip3.hip) is a PAIR design: two 4-row strips, each recomputing its outer y-halo.  A fourth
 // level in that design needs 22 row updates per z step and wave for 16 useful ones, 36 LDS rows per wave + a 24-KiB mailbox (168 KiB: more
-// than the CU has) and ~400 registers.  Here the workgroup's waves take 3 + 5 + 5 + 3 rows of a 16-row band: only the two OUTER waves
-// recompute a halo (their outer side: 6 + 5 + 4 + 3 = 18 row updates per z step), the two INNER waves recompute nothing (4 x 5 = 20) --
-// every row a wave needs across an inner boundary is its neighbour's own edge row of the previous z step, handed over through a 1-KiB LDS
-// mailbox per level, direction and step parity, ordered by per-wave step counters exactly as in k_jacobi_strip3c (wait for the neighbour's
-// step q - 1, read, only then publish step q: a wave may run a step ahead of its neighbours).  76 row updates per z step and workgroup for
-// 64 useful ones (1.19; the pair design with four levels: 1.375, with three: 1.25), windows of 45 float4 per wave (three planes of levels
-// 1..3), LDS 2 x 31 + 2 x 29 rows + 36 mailbox rows = 156 KiB.
+// than the CU has) and ~400 registers.  In a band only the two OUTER waves recompute a halo (their outer side), the inner waves
+// recompute nothing -- every row a wave needs across an inner boundary is its neighbour's own edge row of the previous z step, handed over
+// through a 1-KiB LDS mailbox per level, direction and step parity, ordered by per-wave step counters as in k_jacobi_strip3c (wait for
+// the neighbour's step q - 1, read, only then publish step q: a wave may run a step ahead of its neighbours; the rows are fetched a
+// sweep EARLY and only checked at the hand-over).
+//
+// Why eight waves.  The quad (round 5, first half) made a z step as long as its ~570 instructions: a lone wave on a SIMD pays ~5 cycles
+// per instruction whatever it is (tools/micro/issue_rate.cpp) and leaves the VALU pipe half idle.  With two waves per SIMD the same
+// arithmetic runs at the fabric's rate: 256 registers per wave are enough once the inner waves take two rows and keep EVERYTHING in
+// registers (the input window is a level-0 register window of three planes rotated by name with the level windows, the b planes waiting
+// for sweeps 2..4 a ring of three), and the LDS (123 KiB) holds only the 84 mailbox rows of the seven inner boundaries and the outer
+// waves' parked planes.  What a z step costs is its slowest wave: the outer waves take ONE row (+ halo: 4 + 3 + 2 + 1 = 10 row updates
+// against 8), run at raised priority, and a 3-row inner wave does not fit 256 registers -- hence bands of 14, and the last band of a
+// plane shifted up over its neighbour (the shared rows are computed twice, from the same inputs by the same arithmetic: both
+// workgroups store the same bits).  256^3: 45.4-46.1 us per launch = 11.3-11.5 us per sweep (the quad: 53.1; k_jacobi_strip3c: 13.5 per
+// sweep), 265 MB of fabric traffic per launch = 5.8 TB/s: the kernel is bandwidth-bound again, on a third fewer bytes per sweep.
 //
 // Per z step q (input plane q in registers, prefetched during step q - 1); level-l plane q - l is produced by sweep l:
-//   sweep 1   from input planes q-2, q-1 (LDS) and q (registers), b[q-1] (registers); then the plane in flight and the b rows later
-//             levels need go to the LDS and the prefetch of plane q + 1 / b[q] is issued
-//   sweep l   (2..4) from the level l-1 window (registers) and b[q-l] (LDS); the neighbours' edge rows of level l-1 come from the mailbox
-//   sweep 4   is the output, stored if plane q - 4 lies inside the chunk
-// Traffic: p and b are read once (+ 8 halo planes per chunk of 16) and the result written once per FOUR sweeps.
+//   sweep 1   from input planes q-2, q-1, q and b[q-1]; then the prefetch of plane q + 1 / b[q] is issued
+//   sweep l   (2..4) from the level l-1 window (registers) and b[q-l]; the neighbours' edge rows of level l-1 come from the mailbox
+//   sweep 4   is the output (stored unconditionally: a step of the first chunk whose plane lies below it writes over plane zb, which
+//             the same wave stores for good four steps later)
+// Traffic: p and b are read once (+ 8 halo planes per chunk of 20) and the result written once per FOUR sweeps.
 #include "fx_internal.h"
 #include "fx_pk.h"
 #include <climits>
