@@ -616,12 +616,14 @@ int jacobi_all(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t it
 {
 	if (overlap_level(lead) >= 2) {
 		int t = fused_sweeps(lead);
-		bool three = true;
+		bool three = true, four = true;
 		for (fx_ctx* m : M) {
 			t = std::min(t, fused_sweeps(m));
 			three = three && !m->frozen && jacobi_prefers_three(m->g, (int)(m->desc.flags & FX_FLAG_JACOBI_FUSE_MASK), m->g.nz);
+			four = four && !m->frozen && jacobi_prefers_four(m->g, (int)(m->desc.flags & FX_FLAG_JACOBI_FUSE_MASK), m->g.nz);
 		}
 		if (three) t = 3;                              // the interior launches of a round as threes (k = 9: 3 + 3 + 3); local choice, the exchanges do not depend on it
+		if (four) t = 4;                               // ... as fours where the four-sweep kernel serves the slab (k = 9: 1 + 4 + 4)
 		const int k = lead->opt_round;
 		// two face zones (<= 2k - 1 planes each) and an interior; decided on the thinnest slab of the chain and on the (chain-wide)
 		// Jacobi mode, so that every rank takes the same branch -- the two schedules exchange different things
