@@ -117,6 +117,9 @@ bool jacobi_freeze_strip_supported(const Geom& g);
 hipError_t launch_count_marks(const uint32_t* tile_mark, uint32_t gen, int ntiles, uint32_t* out, hipStream_t s);   // tiles with tile_mark == gen, into *out (a host-visible word)
 hipError_t launch_freeze_strip3(const Geom& g, const float* p_in, const float* b, float* p_outA, float* p_outB, const uint8_t* m_in, uint8_t* m_outA, uint8_t* m_outB,
 	uint32_t* tile_mark, uint32_t tag, uint32_t* stat, uint32_t stat_hi, int level_in, hipStream_t s);
+bool jacobi_freeze_strip4_supported(const Geom& g);
+hipError_t launch_freeze_strip4(const Geom& g, const float* p_in, const float* b, float* p_outA, float* p_outB, const uint8_t* m_in, uint8_t* m_outA, uint8_t* m_outB,
+	uint32_t* tile_mark, uint32_t tag, uint32_t* stat, uint32_t stat_hi, int level_in, hipStream_t s);
 // 2-D grids (fx_jacobi2d.hip): up to jacobi2d_max_sweeps (0: not a 2-D grid / switched off) lock-step sweeps per launch on LDS tiles, with or without the freeze bytes
 int jacobi2d_max_sweeps(const Geom& g);
 hipError_t launch_jacobi2d(const Geom& g, const float* p_in, const float* b, float* p_out, const uint8_t* frozen_in, uint8_t* frozen_out, int sweeps, hipStream_t s);

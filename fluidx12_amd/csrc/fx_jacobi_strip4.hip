@@ -88,6 +88,52 @@ __device__ __forceinline__ v4f relax4q(v4f c, v4f U, v4f D, v4f F, v4f Bk, v4f b
 
 __device__ __forceinline__ uint32_t opaque32q(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 
+// ---- the reference's own loop (k_freeze_strip4o; CSPoisson.hlsli:8-26: a cell leaves the loop for good once a sweep changes it by less
+// than 1e-3): relax4m of fx_jacobi_stripm.hip on native vectors -- relax4_pairs' sum, kept for the freeze test; nib = the quad's frozen
+// bits on entry, returned updated; a cell frozen on entry keeps its value
+constexpr float kBelow4 = 0.00100000005f;                            // CSPoisson.hlsli:24 as compiled (0x3a83126f)
+__device__ __forceinline__ v4f relax4qm(v4f c, v4f U, v4f D, v4f F, v4f Bk, v4f bb, uint32_t nib, uint32_t& nib_out)
+{
+	const fx_f2 c01 = { c.x, c.y }, c23 = { c.z, c.w };
+	fx_f2 lx = pk_mov(c01, c01, 0);
+	const fx_f2 mid = pk_mov(c01, c23, 1);
+	fx_f2 rx = pk_mov(c23, c23, 2);
+	// (scalars first: __builtin_bit_cast of an ELEMENT of a native vector, `c.w`, reads the vector's first element with this compiler)
+	const float cx_ = c.x, cw_ = c.w, lx0_ = lx.x, rx1_ = rx.y;
+	lx.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, lx0_), __builtin_bit_cast(int, cw_), 0x138, 0xf, 0xf, false));
+	rx.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, rx1_), __builtin_bit_cast(int, cx_), 0x130, 0xf, 0xf, false));
+	const fx_f2 b01 = { bb.x, bb.y }, b23 = { bb.z, bb.w }, U01 = { U.x, U.y }, U23 = { U.z, U.w }, D01 = { D.x, D.y }, D23 = { D.z, D.w };
+	const fx_f2 F01 = { F.x, F.y }, F23 = { F.z, F.w }, B01 = { Bk.x, Bk.y }, B23 = { Bk.z, Bk.w };
+	const fx_f2 s01 = (((((lx - b01) + mid) + U01) + D01) + F01) + B01;
+	const fx_f2 s23 = (((((mid - b23) + rx) + U23) + D23) + F23) + B23;
+	const float inv = __uint_as_float(0x3e2aaaabu);
+	const bool f0 = fabsf(fmaf(s01.x, inv, -c.x)) < kBelow4, f1 = fabsf(fmaf(s01.y, inv, -c.y)) < kBelow4;
+	const bool f2 = fabsf(fmaf(s23.x, inv, -c.z)) < kBelow4, f3 = fabsf(fmaf(s23.y, inv, -c.w)) < kBelow4;
+	fx_f2 x01 = s01, x23 = s23;
+	x01 *= inv; x23 *= inv;
+	nib_out = nib | (f0 ? 1u : 0u) | (f1 ? 2u : 0u) | (f2 ? 4u : 0u) | (f3 ? 8u : 0u);
+	return v4f{ (nib & 1u) ? c.x : x01.x, (nib & 2u) ? c.y : x01.y, (nib & 4u) ? c.z : x23.x, (nib & 8u) ? c.w : x23.y };
+}
+#define FXQ_NIB(m, r) (((m) >> (4 * (r))) & 15u)
+
+// what the masked kernel's launch carries besides the three fields (one kernel argument)
+struct FrzArgs {
+	float* p_outB; const uint8_t* m_in; uint8_t* m_outA; uint8_t* m_outB;
+	uint32_t* tile_mark; uint32_t tag; int ntx, nty;
+	uint32_t* stat; uint32_t stat_hi; int level_in;
+};
+// ... and what a wave of it carries along z besides the pressure windows (scalars only: the nibble windows are local arrays of the run
+// functions, like the pressure windows).  A nibble word holds a plane's rows in the indexing of its level, row r at bits 4 r.
+struct Frz4 {
+	const uint8_t* pm;                  // nibble plane walking with Strip4::pp (input plane q + 1)
+	char* outA; ptrdiff_t dB;           // p_outA; p_outB - p_outA in bytes
+	uint8_t* mA; uint8_t* mB;
+	uint32_t* tile_mark; uint32_t tag; int ntx, nty, y_own;
+	uint32_t M0c;                       // nibbles of input plane q - 1 (the centre plane of sweep 1) in level-1 row indexing
+	uint32_t rel;                       // bit l: one of the wave's own cells (planes of its chunk) still relaxed after level l (l = 0: on entry)
+	uint32_t act;                       // bit m: own row m has a cell that still relaxes after the last level, in the current group of 8 planes
+};
+
 // counter and row in ONE LDS round trip (see k_jacobi_strip3c): a counter that is high enough vouches for the row read behind it
 __device__ __forceinline__ v4f lds_wait_read4(uint32_t flag_byte_addr, int need, uint32_t row_byte_addr)
 {
@@ -179,10 +225,12 @@ __device__ __forceinline__ void hand_over4(const Strip4<R>& st, Mail4<R>& m, con
 }
 
 // sweep L + 1 from the window of level L (NL rows) into NN rows; b rows from `Brow`
-template <class R, int L, int NL, int NN>
+// (MK: the masked loop -- mctr = the nibbles of the centre plane in level-L indexing, mout = those of the new plane in level-(L+1) indexing)
+template <class R, int L, int NL, int NN, bool MK = false>
 __device__ __forceinline__ void relax_level4(const Strip4<R>& st, const v4f (&Pold)[NL], const v4f (&Pctr)[NL], const v4f (&Pnew)[NL],
-	const v4f (&Bq)[NN], v4f HU, v4f HD, v4f (&out)[NN])
+	const v4f (&Bq)[NN], v4f HU, v4f HD, v4f (&out)[NN], uint32_t mctr, uint32_t& mout)
 {
+	uint32_t m_ = 0u;
 #pragma unroll
 	for (int k = 0; k < NN; ++k) {
 		constexpr int UP = R::UP;
@@ -192,16 +240,68 @@ __device__ __forceinline__ void relax_level4(const Strip4<R>& st, const v4f (&Po
 		v4f d = jc + 1 < NL ? Pctr[jc + 1 < NL ? jc + 1 : 0] : HD;
 		if (R::A && k == 3 - L && st.wall_top) u = c;                    // rows outside the domain hold no data
 		if (R::W && k == R::NR - 1 && st.wall_bot) d = c;
-		out[k] = relax4q(c, u, d, Pold[jc], Pnew[jc], Bq[k]);
+		if (MK) {
+			uint32_t n_;
+			out[k] = relax4qm(c, u, d, Pold[jc], Pnew[jc], Bq[k], FXQ_NIB(mctr, jc), n_);
+			m_ |= n_ << (4 * k);
+		} else
+			out[k] = relax4q(c, u, d, Pold[jc], Pnew[jc], Bq[k]);
+	}
+	if (MK) mout = m_;
+}
+
+// The masked loop's output plane q - 4 besides its pressure rows (stored by the caller to p_outA): the same rows to p_outB, the nibbles to
+// both mask buffers (the tile launches alternate between two buffers and expect the tiles they do not list to agree in them), and the
+// tile marks: a 32 x 8 x 8 tile with a cell that still relaxes gets `tag`, one plain store per tile behind the last plane of its group of
+// eight (or of the chunk).  A wave's two rows may lie in two tile rows, so the activity is kept per row.
+template <class R>
+__device__ __forceinline__ void frz_out4(const Strip4<R>& st, Frz4& fz, char* dst_, const v4f (&X_)[R::NR], uint32_t m4_, const uint32_t (&roff)[R::NI])
+{
+	constexpr int NR = R::NR, RB = R::A ? 4 : 1;
+	const int z = st.q - 4;
+	const ptrdiff_t mo_ = (dst_ - fz.outA) >> 4;                         // a plane of nibble bytes is a sixteenth of a pressure plane
+#pragma unroll
+	for (int m = 0; m < NR; ++m) *reinterpret_cast<v4f*>(dst_ + fz.dB + opaque32q(roff[m + RB])) = X_[m];
+#pragma unroll
+	for (int m = 0; m < NR; ++m) {
+		const uint32_t o_ = opaque32q(roff[m + RB] >> 4);
+		fz.mA[mo_ + o_] = (uint8_t)FXQ_NIB(m4_, m);
+		fz.mB[mo_ + o_] = (uint8_t)FXQ_NIB(m4_, m);
+	}
+	if (z >= st.zb) {                                                    // (a step below the chunk has written over plane zb, see step4: nothing of it counts)
+#pragma unroll
+		for (int m = 0; m < NR; ++m) if (FXQ_NIB(m4_, m) != 15u) { fz.rel |= 16u; fz.act |= 1u << m; }
+		if ((z & 7) == 7 || z == st.ze - 1) {
+#pragma unroll
+			for (int m = 0; m < NR; ++m) {
+				const unsigned long long bal_ = __ballot((fz.act >> m) & 1u);
+				if ((st.lane & 7) == 0 && ((bal_ >> st.lane) & 0xFFull) != 0ull)
+					fz.tile_mark[((z >> 3) * fz.nty + ((fz.y_own + m) >> 3)) * fz.ntx + (st.lane >> 3)] = fz.tag;
+			}
+			fz.act = 0u;
+		}
 	}
 }
 
-template <class R, int PH, bool S1, bool S2, bool S3, bool S4>
-__device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&P2)[3][R::N2], v4f (&P3)[3][R::N3], v4f (&NP)[R::NI], v4f (&NB)[R::N1], v4f (&NBn)[R::N1], v4f (&Bk)[R::N2], const uint32_t (&roff)[R::NI])
+// MK: the masked loop (k_freeze_strip4o) -- the nibble windows MW[level 1..3][slot] rotate with the pressure windows, NM = the nibble
+// bytes of the plane in flight (rows of level 1), fz the rest; without MK none of them is touched
+template <class R, int PH, bool S1, bool S2, bool S3, bool S4, bool MK = false>
+__device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&P2)[3][R::N2], v4f (&P3)[3][R::N3], v4f (&NP)[R::NI], v4f (&NB)[R::N1], v4f (&NBn)[R::N1], v4f (&Bk)[R::N2], const uint32_t (&roff)[R::NI],
+	Frz4& fz, uint32_t (&MW)[3][3], uint32_t (&NM)[R::N1])
 {
 	constexpr int NEW = PH % 3, CTR = (PH + 2) % 3, OLD = (PH + 1) % 3;
 	constexpr int NI = R::NI, N1 = R::N1, N2 = R::N2, N3 = R::N3, NR = R::NR, UP = R::UP;
+	static_assert(!MK || R::NW != 4, "the masked loop runs in the octet");
+	constexpr int O1 = R::A ? 3 : 0, O2 = R::A ? 2 : 0, O3 = R::A ? 1 : 0;      // the first own row in the indexing of levels 1..3
+	constexpr uint32_t OWN = (1u << (4 * NR)) - 1u;
 	const int q = st.q;
+	uint32_t M0n = 0u;
+	if (MK) {                                                           // the input plane's nibbles have arrived with it
+#pragma unroll
+		for (int j = 0; j < N1; ++j) M0n |= (NM[j] & 15u) << (4 * j);
+		if (q >= st.zb && q < st.ze && (~(M0n >> (4 * O1)) & OWN) != 0u) fz.rel |= 1u;
+		if (q == 0) fz.M0c = M0n;
+	}
 	const v4f zero = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
 	Mail4<R> M1, M2, M3;
 	M1.fu = M1.fd = M2.fu = M2.fd = M3.fu = M3.fd = INT_MIN; M1.hu = M1.hd = M2.hu = M2.hd = M3.hu = M3.hd = zero;
@@ -242,6 +342,10 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 #endif
 #pragma unroll
 			for (int i = 0; i < NI; ++i) NP[i] = *reinterpret_cast<const v4f*>(st.pp + opaque32q(roff[i]));
+			if (MK) {
+#pragma unroll
+				for (int j = 0; j < N1; ++j) NM[j] = fz.pm[opaque32q(roff[j + 1] >> 4)];
+			}
 		}
 	};
 	if (EARLY) {
@@ -262,9 +366,11 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 		// (the new plane goes through a local first and into the window by unconditional stores: stores to different window slots in the two
 		// arms of a branch are merged by the compiler into one store through a selected POINTER, which keeps those slots in scratch)
 		v4f T_[N1];
+		uint32_t m1_ = 0u;
 		if (q - 1 == st.Zg) {                                            // level-1 plane Zg := plane Zg-1
 #pragma unroll
 			for (int j = 0; j < N1; ++j) T_[j] = P1[CTR][j];
+			if (MK) m1_ = MW[0][CTR];
 		} else {
 			if (!LEAN) {
 				v4f C_[NI], F_[N1];                                       // all LDS rows first: one wave per SIMD cannot hide a ds_read next to its use
@@ -279,21 +385,30 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 #pragma unroll
 				for (int j = 0; j < N1; ++j) {
 					const v4f d_ = FXQ_LDS(st, st.s_ctr, j + 2), f_ = FXQ_LDS(st, st.s_old, j + 1);
-					T_[j] = relax4q(c_, u_, d_, f_, np(j + 1), nb(j));
+					if (MK) {
+						uint32_t n_;
+						T_[j] = relax4qm(c_, u_, d_, f_, np(j + 1), nb(j), FXQ_NIB(fz.M0c, j), n_);
+						m1_ |= n_ << (4 * j);
+					} else
+						T_[j] = relax4q(c_, u_, d_, f_, np(j + 1), nb(j));
 					u_ = c_; c_ = d_;
 #ifdef FX_O_SCHEDBAR
 					__builtin_amdgcn_sched_barrier(0);
 #endif
 				}
+				if (MK && q - 1 >= st.zb && q - 1 < st.ze && (~(m1_ >> (4 * O1)) & OWN) != 0u) fz.rel |= 2u;
 			}
 		}
 #pragma unroll
 		for (int j = 0; j < N1; ++j) P1[NEW][j] = T_[j];
+		if (MK) MW[0][NEW] = m1_;
 		if (q - 1 == 0) {                                               // level-1 plane -1 := plane 0
 #pragma unroll
 			for (int j = 0; j < N1; ++j) P1[CTR][j] = T_[j];
+			if (MK) MW[0][CTR] = m1_;
 		}
 	}
+	if (MK) fz.M0c = M0n;                                               // plane q is the next step's centre
 	// b[q-4] (the output rows) leaves its slot before b[q-1] moves in; b[q-2] (rows of level 2) is wanted next
 	v4f B4_[NR], B2_[N2];
 #pragma unroll
@@ -322,6 +437,7 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 	{ const int t_ = st.s_old; st.s_old = st.s_ctr; st.s_ctr = t_; }
 	if (!EARLY) issue_prefetch();
 	st.pp += st.plane_bytes; st.pbq += st.plane_bytes;
+	if (MK) fz.pm += st.plane_bytes >> 4;
 	// hand-over 1, BEHIND the prefetch issue: a wait here must not delay the loads
 	v4f HU1 = zero, HD1 = zero;
 	if (S1) hand_over4<R, 1>(st, M1, P1[NEW][0], P1[NEW][N1 - 1], HU1, HD1);
@@ -329,17 +445,22 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 	// ---- sweep 2: level-2 plane q-2 -----------------------------------------------------------------------------------
 	if (S2) {
 		v4f T_[N2];
+		uint32_t m2_ = 0u;
 		if (q - 2 == st.Zg) {
 #pragma unroll
 			for (int k = 0; k < N2; ++k) T_[k] = P2[CTR][k];
+			if (MK) m2_ = MW[1][CTR];
 		} else {
-			relax_level4<R, 1, N1, N2>(st, P1[OLD], P1[CTR], P1[NEW], B2_, HU1, HD1, T_);
+			relax_level4<R, 1, N1, N2, MK>(st, P1[OLD], P1[CTR], P1[NEW], B2_, HU1, HD1, T_, MK ? MW[0][CTR] : 0u, m2_);
+			if (MK && q - 2 >= st.zb && q - 2 < st.ze && (~(m2_ >> (4 * O2)) & OWN) != 0u) fz.rel |= 4u;
 		}
 #pragma unroll
 		for (int k = 0; k < N2; ++k) P2[NEW][k] = T_[k];
+		if (MK) MW[1][NEW] = m2_;
 		if (q - 2 == 0) {                                               // level-2 plane -1 := plane 0
 #pragma unroll
 			for (int k = 0; k < N2; ++k) P2[CTR][k] = T_[k];
+			if (MK) MW[1][CTR] = m2_;
 		}
 	}
 	v4f B3_[N3];                                                     // b[q-3] (after the rotation: s_b4), rows of level 3
@@ -351,17 +472,22 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 	// ---- sweep 3: level-3 plane q-3 -----------------------------------------------------------------------------------
 	if (S3) {
 		v4f T_[N3];
+		uint32_t m3_ = 0u;
 		if (q - 3 == st.Zg) {
 #pragma unroll
 			for (int m = 0; m < N3; ++m) T_[m] = P3[CTR][m];
+			if (MK) m3_ = MW[2][CTR];
 		} else {
-			relax_level4<R, 2, N2, N3>(st, P2[OLD], P2[CTR], P2[NEW], B3_, HU2, HD2, T_);
+			relax_level4<R, 2, N2, N3, MK>(st, P2[OLD], P2[CTR], P2[NEW], B3_, HU2, HD2, T_, MK ? MW[1][CTR] : 0u, m3_);
+			if (MK && q - 3 >= st.zb && q - 3 < st.ze && (~(m3_ >> (4 * O3)) & OWN) != 0u) fz.rel |= 8u;
 		}
 #pragma unroll
 		for (int m = 0; m < N3; ++m) P3[NEW][m] = T_[m];
+		if (MK) MW[2][NEW] = m3_;
 		if (q - 3 == 0) {                                               // level-3 plane -1 := plane 0
 #pragma unroll
 			for (int m = 0; m < N3; ++m) P3[CTR][m] = T_[m];
+			if (MK) MW[2][CTR] = m3_;
 		}
 	}
 	v4f HU3 = zero, HD3 = zero;
@@ -373,23 +499,57 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 		// the first present plane) writes its rows over plane zb instead, which this wave stores for good a few steps later (the stores of a
 		// wave to one address keep their order); no step of the loop lies above the chunk (q <= ze + 3).
 		v4f X_[NR];
-		relax_level4<R, 3, N3, NR>(st, P3[OLD], P3[CTR], P3[NEW], B4_, HU3, HD3, X_);
+		uint32_t m4_ = 0u;
+		relax_level4<R, 3, N3, NR, MK>(st, P3[OLD], P3[CTR], P3[NEW], B4_, HU3, HD3, X_, MK ? MW[2][CTR] : 0u, m4_);
 		char* dst_ = q - 4 >= st.zb ? st.po : st.po_zb;
 #ifdef FX_S4_NOSTORE
 		if (q < -1000)                                                   // (experiment: the arithmetic stays, the stores never execute)
 #endif
 #pragma unroll
 		for (int m = 0; m < NR; ++m) *reinterpret_cast<v4f*>(dst_ + opaque32q(roff[m + (R::A ? 4 : 1)])) = X_[m];
+		if (MK) frz_out4<R>(st, fz, dst_, X_, m4_, roff);
 	}
 	st.po += st.plane_bytes;
 	++st.q;
 }
 
-template <class R>
+// the masked loop's set-up shared by both walks: the nibble bytes of the first plane in flight (q0), and of the plane before it (the
+// centre of the first sweep) where the walk starts inside the field
+template <class R, int NM_>
+__device__ __forceinline__ void frz_begin4(const Geom& g, const FrzArgs& fa, const Strip4<R>& st, Frz4& fz, uint32_t (&MW)[3][3], uint32_t (&NM)[NM_],
+	const uint32_t (&roff)[R::NI], float* p_out, int y0, int q0, bool fill)
+{
+	const size_t plane4 = st.plane_bytes >> 4;
+	fz.outA = reinterpret_cast<char*>(p_out); fz.dB = reinterpret_cast<char*>(fa.p_outB) - reinterpret_cast<char*>(p_out);
+	fz.mA = fa.m_outA; fz.mB = fa.m_outB; fz.tile_mark = fa.tile_mark; fz.tag = fa.tag; fz.ntx = fa.ntx; fz.nty = fa.nty; fz.y_own = y0;
+	fz.M0c = 0u; fz.rel = 0u; fz.act = 0u;
+#pragma unroll
+	for (int l = 0; l < 3; ++l) MW[l][0] = MW[l][1] = MW[l][2] = 0u;
+	const uint8_t* mb = fa.m_in + (size_t)g.lz(min(q0, st.q_load_last)) * plane4;
+#pragma unroll
+	for (int j = 0; j < NM_; ++j) NM[j] = mb[roff[j + 1] >> 4];
+	if (fill) {
+		const uint8_t* mc = fa.m_in + (size_t)g.lz(q0 - 1) * plane4;
+#pragma unroll
+		for (int j = 0; j < NM_; ++j) fz.M0c |= ((uint32_t)mc[roff[j + 1] >> 4] & 15u) << (4 * j);
+	}
+	fz.pm = fa.m_in + ((ptrdiff_t)g.lz(q0) + 1) * (ptrdiff_t)plane4;
+}
+// ... and its end: the last level that left one of the wave's own cells relaxing (level_in itself: a cell that came in relaxing), into
+// fx_jacobi_freeze.hip's statistics word
+__device__ __forceinline__ void frz_end4(const FrzArgs& fa, const Frz4& fz, int lane)
+{
+	const int lvl = __any(fz.rel & 16u) ? 4 : __any(fz.rel & 8u) ? 3 : __any(fz.rel & 4u) ? 2 : __any(fz.rel & 2u) ? 1 : __any(fz.rel & 1u) ? 0 : -1;
+	if (lane == 0 && lvl >= 0) atomicMax(fa.stat, fa.stat_hi + (uint32_t)(fa.level_in + lvl));
+}
+
+template <class R, bool MK = false>
 __device__ __forceinline__ void run4(const Geom& g, const float* __restrict__ p_in, const float* __restrict__ b, float* __restrict__ p_out,
-	int zb, int ze, int y0, int wave, int lane, v4f* lds_slice, v4f* xbuf, int* xflag)
+	int zb, int ze, int y0, int wave, int lane, v4f* lds_slice, v4f* xbuf, int* xflag, const FrzArgs& fa)
 {
 	Strip4<R> st;
+	Frz4 fz;
+	uint32_t MW[3][3], NM[R::N1];
 #ifndef FX_O_NOPRIO
 	if (R::NW != 4) __builtin_amdgcn_s_setprio(2);                      // the octet's outer waves have the longest z step: they go first on their SIMD
 #endif
@@ -457,23 +617,25 @@ __device__ __forceinline__ void run4(const Geom& g, const float* __restrict__ p_
 	st.pbq = reinterpret_cast<const char*>(b) + ((ptrdiff_t)g.lz(q0) + (R::NW == 4 ? 1 : 0)) * (ptrdiff_t)st.plane_bytes;   // (the quad fetches b[q + 1] in step q, a lean wave b[q])
 	st.po_zb = reinterpret_cast<char*>(p_out) + (ptrdiff_t)g.lz(zb) * (ptrdiff_t)st.plane_bytes;
 	st.po = reinterpret_cast<char*>(p_out) + ((ptrdiff_t)g.lz(q0) - 4) * (ptrdiff_t)st.plane_bytes;      // (only dereferenced for planes inside the chunk)
+	if (MK) frz_begin4<R, R::N1>(g, fa, st, fz, MW, NM, roff, p_out, y0, q0, fill);
 	// the rest of the pipeline's fill, peeled as in k_jacobi_strip3c: level-l planes below zb - 4 + l feed nothing that is stored
 	if (fill) {
-		step4<R, 0, true, false, false, false>(st, P1, P2, P3, NP, NB, NBn, Bk, roff);
-		step4<R, 1, true, false, false, false>(st, P1, P2, P3, NP, NB, NBn, Bk, roff);
-		step4<R, 2, true, true, false, false>(st, P1, P2, P3, NP, NB, NBn, Bk, roff);
-		step4<R, 0, true, true, false, false>(st, P1, P2, P3, NP, NB, NBn, Bk, roff);
-		step4<R, 1, true, true, true, false>(st, P1, P2, P3, NP, NB, NBn, Bk, roff);
-		step4<R, 2, true, true, true, false>(st, P1, P2, P3, NP, NB, NBn, Bk, roff);
+		step4<R, 0, true, false, false, false, MK>(st, P1, P2, P3, NP, NB, NBn, Bk, roff, fz, MW, NM);
+		step4<R, 1, true, false, false, false, MK>(st, P1, P2, P3, NP, NB, NBn, Bk, roff, fz, MW, NM);
+		step4<R, 2, true, true, false, false, MK>(st, P1, P2, P3, NP, NB, NBn, Bk, roff, fz, MW, NM);
+		step4<R, 0, true, true, false, false, MK>(st, P1, P2, P3, NP, NB, NBn, Bk, roff, fz, MW, NM);
+		step4<R, 1, true, true, true, false, MK>(st, P1, P2, P3, NP, NB, NBn, Bk, roff, fz, MW, NM);
+		step4<R, 2, true, true, true, false, MK>(st, P1, P2, P3, NP, NB, NBn, Bk, roff, fz, MW, NM);
 	}
 	for (;;) {
-		step4<R, 0, true, true, true, true>(st, P1, P2, P3, NP, NB, NBn, Bk, roff);
+		step4<R, 0, true, true, true, true, MK>(st, P1, P2, P3, NP, NB, NBn, Bk, roff, fz, MW, NM);
 		if (st.q > q_last) break;
-		step4<R, 1, true, true, true, true>(st, P1, P2, P3, NP, NB, NBn, Bk, roff);
+		step4<R, 1, true, true, true, true, MK>(st, P1, P2, P3, NP, NB, NBn, Bk, roff, fz, MW, NM);
 		if (st.q > q_last) break;
-		step4<R, 2, true, true, true, true>(st, P1, P2, P3, NP, NB, NBn, Bk, roff);
+		step4<R, 2, true, true, true, true, MK>(st, P1, P2, P3, NP, NB, NBn, Bk, roff, fz, MW, NM);
 		if (st.q > q_last) break;
 	}
+	if (MK) frz_end4(fa, fz, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -484,14 +646,22 @@ __device__ __forceinline__ void run4(const Geom& g, const float* __restrict__ p_
 // outer waves (two rows + the recomputed halo) park their input and b planes in the LDS as the quad's waves do.  LDS: 2 x 26 rows + 84
 // mailbox rows (seven inner boundaries) = 136 KiB.
 // ---------------------------------------------------------------------------------------------------------------------------
-template <class R, int PH, bool S1, bool S2, bool S3, bool S4>
+template <class R, int PH, bool S1, bool S2, bool S3, bool S4, bool MK = false>
 __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&P1)[3][R::NR], v4f (&P2)[3][R::NR], v4f (&P3)[3][R::NR],
-	v4f (&NB)[R::NR], v4f (&Bp)[3][R::NR], const uint32_t (&roff)[R::NI])
+	v4f (&NB)[R::NR], v4f (&Bp)[3][R::NR], const uint32_t (&roff)[R::NI], Frz4& fz, uint32_t (&MW)[3][3], uint32_t (&NM)[R::NR])
 {
 	static_assert(!R::A && !R::W, "the register-window step serves inner waves");
 	constexpr int NEW = PH % 3, CTR = (PH + 2) % 3, OLD = (PH + 1) % 3;
 	constexpr int NI = R::NI, NR = R::NR;
+	constexpr uint32_t OWN = (1u << (4 * NR)) - 1u;
 	const int q = st.q;
+	uint32_t M0n = 0u;
+	if (MK) {                                                           // the input plane's nibbles have arrived with it
+#pragma unroll
+		for (int j = 0; j < NR; ++j) M0n |= (NM[j] & 15u) << (4 * j);
+		if (q >= st.zb && q < st.ze && (~M0n & OWN) != 0u) fz.rel |= 1u;
+		if (q == 0) fz.M0c = M0n;
+	}
 	const v4f zero = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
 	Mail4<R> M1, M2, M3;
 	M1.fu = M1.fd = M2.fu = M2.fd = M3.fu = M3.fd = INT_MIN; M1.hu = M1.hd = M2.hu = M2.hd = M3.hu = M3.hd = zero;
@@ -503,20 +673,33 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 	}
 	if (S1) {
 		v4f T_[NR];
+		uint32_t m1_ = 0u;
 		if (q - 1 == st.Zg) {
 #pragma unroll
 			for (int j = 0; j < NR; ++j) T_[j] = P1[CTR][j];
+			if (MK) m1_ = MW[0][CTR];
 		} else {
 #pragma unroll
-			for (int j = 0; j < NR; ++j) T_[j] = relax4q(I[CTR][j + 1], I[CTR][j], I[CTR][j + 2], I[OLD][j + 1], I[NEW][j + 1], NB[j]);
+			for (int j = 0; j < NR; ++j) {
+				if (MK) {
+					uint32_t n_;
+					T_[j] = relax4qm(I[CTR][j + 1], I[CTR][j], I[CTR][j + 2], I[OLD][j + 1], I[NEW][j + 1], NB[j], FXQ_NIB(fz.M0c, j), n_);
+					m1_ |= n_ << (4 * j);
+				} else
+					T_[j] = relax4q(I[CTR][j + 1], I[CTR][j], I[CTR][j + 2], I[OLD][j + 1], I[NEW][j + 1], NB[j]);
+			}
+			if (MK && q - 1 >= st.zb && q - 1 < st.ze && (~m1_ & OWN) != 0u) fz.rel |= 2u;
 		}
 #pragma unroll
 		for (int j = 0; j < NR; ++j) P1[NEW][j] = T_[j];
+		if (MK) MW[0][NEW] = m1_;
 		if (q - 1 == 0) {
 #pragma unroll
 			for (int j = 0; j < NR; ++j) P1[CTR][j] = T_[j];
+			if (MK) MW[0][CTR] = m1_;
 		}
 	}
+	if (MK) fz.M0c = M0n;                                               // plane q is the next step's centre
 	// the b ring: [NEW] = b[q-2], [CTR] = b[q-3], [OLD] = b[q-4] on entry (named like the windows: they rotate with them)
 	v4f B2_[NR], B3_[NR], B4_[NR];
 #pragma unroll
@@ -527,6 +710,10 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 	if (q + 1 <= st.q_load_last) {
 #pragma unroll
 		for (int i = 0; i < NI; ++i) I[OLD][i] = *reinterpret_cast<const v4f*>(st.pp + opaque32q(roff[i]));
+		if (MK) {
+#pragma unroll
+			for (int j = 0; j < NR; ++j) NM[j] = fz.pm[opaque32q(roff[j + 1] >> 4)];
+		}
 	} else {                                                            // past the last present plane the window keeps plane zhi
 #pragma unroll
 		for (int i = 0; i < NI; ++i) I[OLD][i] = I[NEW][i];
@@ -536,23 +723,29 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 		for (int j = 0; j < NR; ++j) NB[j] = *reinterpret_cast<const v4f*>(st.pbq + opaque32q(roff[j + 1]));
 	}
 	st.pp += st.plane_bytes; st.pbq += st.plane_bytes;
+	if (MK) fz.pm += st.plane_bytes >> 4;
 	v4f HU1 = zero, HD1 = zero;
 	if (S1) hand_over4<R, 1>(st, M1, P1[NEW][0], P1[NEW][NR - 1], HU1, HD1);
 	if (S2) mail_fetch4<R, 2>(st, M2);
 	// ---- sweep 2 ----
 	if (S2) {
 		v4f T_[NR];
+		uint32_t m2_ = 0u;
 		if (q - 2 == st.Zg) {
 #pragma unroll
 			for (int k = 0; k < NR; ++k) T_[k] = P2[CTR][k];
+			if (MK) m2_ = MW[1][CTR];
 		} else {
-			relax_level4<R, 1, NR, NR>(st, P1[OLD], P1[CTR], P1[NEW], B2_, HU1, HD1, T_);
+			relax_level4<R, 1, NR, NR, MK>(st, P1[OLD], P1[CTR], P1[NEW], B2_, HU1, HD1, T_, MK ? MW[0][CTR] : 0u, m2_);
+			if (MK && q - 2 >= st.zb && q - 2 < st.ze && (~m2_ & OWN) != 0u) fz.rel |= 4u;
 		}
 #pragma unroll
 		for (int k = 0; k < NR; ++k) P2[NEW][k] = T_[k];
+		if (MK) MW[1][NEW] = m2_;
 		if (q - 2 == 0) {
 #pragma unroll
 			for (int k = 0; k < NR; ++k) P2[CTR][k] = T_[k];
+			if (MK) MW[1][CTR] = m2_;
 		}
 	}
 	v4f HU2 = zero, HD2 = zero;
@@ -561,17 +754,22 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 	// ---- sweep 3 ----
 	if (S3) {
 		v4f T_[NR];
+		uint32_t m3_ = 0u;
 		if (q - 3 == st.Zg) {
 #pragma unroll
 			for (int m = 0; m < NR; ++m) T_[m] = P3[CTR][m];
+			if (MK) m3_ = MW[2][CTR];
 		} else {
-			relax_level4<R, 2, NR, NR>(st, P2[OLD], P2[CTR], P2[NEW], B3_, HU2, HD2, T_);
+			relax_level4<R, 2, NR, NR, MK>(st, P2[OLD], P2[CTR], P2[NEW], B3_, HU2, HD2, T_, MK ? MW[1][CTR] : 0u, m3_);
+			if (MK && q - 3 >= st.zb && q - 3 < st.ze && (~m3_ & OWN) != 0u) fz.rel |= 8u;
 		}
 #pragma unroll
 		for (int m = 0; m < NR; ++m) P3[NEW][m] = T_[m];
+		if (MK) MW[2][NEW] = m3_;
 		if (q - 3 == 0) {
 #pragma unroll
 			for (int m = 0; m < NR; ++m) P3[CTR][m] = T_[m];
+			if (MK) MW[2][CTR] = m3_;
 		}
 	}
 	v4f HU3 = zero, HD3 = zero;
@@ -579,20 +777,24 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 	// ---- sweep 4: the output ----
 	if (S4) {
 		v4f X_[NR];
-		relax_level4<R, 3, NR, NR>(st, P3[OLD], P3[CTR], P3[NEW], B4_, HU3, HD3, X_);
+		uint32_t m4_ = 0u;
+		relax_level4<R, 3, NR, NR, MK>(st, P3[OLD], P3[CTR], P3[NEW], B4_, HU3, HD3, X_, MK ? MW[2][CTR] : 0u, m4_);
 		char* dst_ = q - 4 >= st.zb ? st.po : st.po_zb;
 #pragma unroll
 		for (int m = 0; m < NR; ++m) *reinterpret_cast<v4f*>(dst_ + opaque32q(roff[m + 1])) = X_[m];
+		if (MK) frz_out4<R>(st, fz, dst_, X_, m4_, roff);
 	}
 	st.po += st.plane_bytes;
 	++st.q;
 }
 
-template <class R>
+template <class R, bool MK = false>
 __device__ __forceinline__ void run4r(const Geom& g, const float* __restrict__ p_in, const float* __restrict__ b, float* __restrict__ p_out,
-	int zb, int ze, int y0, int wave, int lane, v4f* xbuf, int* xflag)
+	int zb, int ze, int y0, int wave, int lane, v4f* xbuf, int* xflag, const FrzArgs& fa)
 {
 	Strip4<R> st;
+	Frz4 fz;
+	uint32_t MW[3][3], NM[R::NR];
 	v4f I[3][R::NI], P1[3][R::NR], P2[3][R::NR], P3[3][R::NR], NB[R::NR], Bp[3][R::NR];
 	uint32_t roff[R::NI];
 	const v4f zero = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
@@ -641,22 +843,24 @@ __device__ __forceinline__ void run4r(const Geom& g, const float* __restrict__ p
 	st.pbq = reinterpret_cast<const char*>(b) + (ptrdiff_t)g.lz(q0) * (ptrdiff_t)st.plane_bytes;          // (this walk fetches b[q] in step q)
 	st.po_zb = reinterpret_cast<char*>(p_out) + (ptrdiff_t)g.lz(zb) * (ptrdiff_t)st.plane_bytes;
 	st.po = reinterpret_cast<char*>(p_out) + ((ptrdiff_t)g.lz(q0) - 4) * (ptrdiff_t)st.plane_bytes;
+	if (MK) frz_begin4<R, R::NR>(g, fa, st, fz, MW, NM, roff, p_out, y0, q0, fill);
 	if (fill) {
-		step4r<R, 0, true, false, false, false>(st, I, P1, P2, P3, NB, Bp, roff);
-		step4r<R, 1, true, false, false, false>(st, I, P1, P2, P3, NB, Bp, roff);
-		step4r<R, 2, true, true, false, false>(st, I, P1, P2, P3, NB, Bp, roff);
-		step4r<R, 0, true, true, false, false>(st, I, P1, P2, P3, NB, Bp, roff);
-		step4r<R, 1, true, true, true, false>(st, I, P1, P2, P3, NB, Bp, roff);
-		step4r<R, 2, true, true, true, false>(st, I, P1, P2, P3, NB, Bp, roff);
+		step4r<R, 0, true, false, false, false, MK>(st, I, P1, P2, P3, NB, Bp, roff, fz, MW, NM);
+		step4r<R, 1, true, false, false, false, MK>(st, I, P1, P2, P3, NB, Bp, roff, fz, MW, NM);
+		step4r<R, 2, true, true, false, false, MK>(st, I, P1, P2, P3, NB, Bp, roff, fz, MW, NM);
+		step4r<R, 0, true, true, false, false, MK>(st, I, P1, P2, P3, NB, Bp, roff, fz, MW, NM);
+		step4r<R, 1, true, true, true, false, MK>(st, I, P1, P2, P3, NB, Bp, roff, fz, MW, NM);
+		step4r<R, 2, true, true, true, false, MK>(st, I, P1, P2, P3, NB, Bp, roff, fz, MW, NM);
 	}
 	for (;;) {
-		step4r<R, 0, true, true, true, true>(st, I, P1, P2, P3, NB, Bp, roff);
+		step4r<R, 0, true, true, true, true, MK>(st, I, P1, P2, P3, NB, Bp, roff, fz, MW, NM);
 		if (st.q > q_last) break;
-		step4r<R, 1, true, true, true, true>(st, I, P1, P2, P3, NB, Bp, roff);
+		step4r<R, 1, true, true, true, true, MK>(st, I, P1, P2, P3, NB, Bp, roff, fz, MW, NM);
 		if (st.q > q_last) break;
-		step4r<R, 2, true, true, true, true>(st, I, P1, P2, P3, NB, Bp, roff);
+		step4r<R, 2, true, true, true, true, MK>(st, I, P1, P2, P3, NB, Bp, roff, fz, MW, NM);
 		if (st.q > q_last) break;
 	}
+	if (MK) frz_end4(fa, fz, lane);
 }
 
 // rows per wave, top to bottom: 1 2 2 2 2 2 2 1 -- a band of FOURTEEN rows.  The outer waves (one row + the recomputed halo: 4 + 3 + 2 + 1 = 10
@@ -697,12 +901,44 @@ __global__ __launch_bounds__(512, 2) void k_jacobi_strip4o(const Geom g, const f
 	for (int i = (int)threadIdx.x; i < O_XROWS * 64; i += 512) xbuf[i] = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
 	__syncthreads();
 	const int yg = min(grp * O_BAND, g.Y - O_BAND);                     // (the last band is shifted up to end at the last row)
+	const FrzArgs none{};
 #ifdef FX_O_ONLYMID
-	run4r<OctMid>(g, p_in, b, p_out, zb, ze, yg + 2 * wave, wave, lane, xbuf, xflag); return;   // (timing experiment: eight register-window waves in a ring; results are wrong)
+	run4r<OctMid>(g, p_in, b, p_out, zb, ze, yg + 2 * wave, wave, lane, xbuf, xflag, none); return;   // (timing experiment: eight register-window waves in a ring; results are wrong)
 #endif
-	if (wave == 0) run4<OctTop>(g, p_in, b, p_out, zb, ze, yg, wave, lane, lds_all, xbuf, xflag);
-	else if (wave == 7) run4<OctBot>(g, p_in, b, p_out, zb, ze, yg + O_BAND - 1, wave, lane, lds_all + OctTop::LDS_ROWS * 64, xbuf, xflag);
-	else run4r<OctMid>(g, p_in, b, p_out, zb, ze, yg + 2 * wave - 1, wave, lane, xbuf, xflag);
+	if (wave == 0) run4<OctTop>(g, p_in, b, p_out, zb, ze, yg, wave, lane, lds_all, xbuf, xflag, none);
+	else if (wave == 7) run4<OctBot>(g, p_in, b, p_out, zb, ze, yg + O_BAND - 1, wave, lane, lds_all + OctTop::LDS_ROWS * 64, xbuf, xflag, none);
+	else run4r<OctMid>(g, p_in, b, p_out, zb, ze, yg + 2 * wave - 1, wave, lane, xbuf, xflag, none);
+}
+
+// FOUR levels of the reference's own pressure loop for every cell, per launch: the octet with the freeze nibbles of fx_jacobi_freeze.hip
+// carried along (k_freeze_strip3 of fx_jacobi_stripm.hip is the same idea on the three-sweep pipeline, one wave per SIMD).  Input: level L in
+// p_in with its nibbles in fa.m_in; output: level L + 4 to BOTH p_outA and fa.p_outB and the nibbles to both mask buffers, the tile marks
+// and the statistics word as k_freeze_strip3 leaves them.  The mailbox rows are pressures only: a neighbour's edge row arrives with its
+// freeze decisions applied, and a sweep needs the nibbles of its CENTRE cells alone.  Single domain (Zg = nz, no halo planes).
+__global__ __launch_bounds__(512, 2) void k_freeze_strip4o(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
+	float* __restrict__ p_outA, const FrzArgs fa, int zchunk, int ngroups, int nchunks)
+{
+	__shared__ v4f lds_all[O_LDS_ROWS * 64];
+	__shared__ v4f xbuf[O_XROWS * 64];
+	__shared__ int xflag[24];
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	int tile = (int)blockIdx.x;
+	{
+		const int n = ngroups * nchunks, qn = n >> 3, r = n & 7;
+		const int xcd = tile & 7, j = tile >> 3;
+		tile = xcd * qn + min(xcd, r) + j;
+	}
+	const int grp = tile % ngroups, chunk = tile / ngroups;
+	const int zb = chunk * zchunk, ze = min(zb + zchunk, g.Zg);
+	const int qs = max(zb - 4, 0);
+	const bool fill = qs == zb - 4;
+	if (threadIdx.x < 24) xflag[threadIdx.x] = fill ? qs + 2 * ((int)threadIdx.x / 8 + 1) - 1 : qs - 1;
+	for (int i = (int)threadIdx.x; i < O_XROWS * 64; i += 512) xbuf[i] = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+	__syncthreads();
+	const int yg = min(grp * O_BAND, g.Y - O_BAND);
+	if (wave == 0) run4<OctTop, true>(g, p_in, b, p_outA, zb, ze, yg, wave, lane, lds_all, xbuf, xflag, fa);
+	else if (wave == 7) run4<OctBot, true>(g, p_in, b, p_outA, zb, ze, yg + O_BAND - 1, wave, lane, lds_all + OctTop::LDS_ROWS * 64, xbuf, xflag, fa);
+	else run4r<OctMid, true>(g, p_in, b, p_outA, zb, ze, yg + 2 * wave - 1, wave, lane, xbuf, xflag, fa);
 }
 
 __global__ __launch_bounds__(256, 1) void k_jacobi_strip4q(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
@@ -727,13 +963,14 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip4q(const Geom g, const f
 	for (int i = (int)threadIdx.x; i < Q_XROWS * 64; i += 256) xbuf[i] = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
 	__syncthreads();
 	const int yg = grp * 16;
+	const FrzArgs none{};
 #ifdef FX_S4_ALLMID
-	run4<RoleMid>(g, p_in, b, p_out, zb, ze, yg + 4 * wave, wave, lane, lds_all + (wave * RoleTop::LDS_ROWS) * 64, xbuf, xflag);
+	run4<RoleMid>(g, p_in, b, p_out, zb, ze, yg + 4 * wave, wave, lane, lds_all + (wave * RoleTop::LDS_ROWS) * 64, xbuf, xflag, none);
 	return;
 #endif
-	if (wave == 0) run4<RoleTop>(g, p_in, b, p_out, zb, ze, yg, wave, lane, lds_all, xbuf, xflag);
-	else if (wave == 3) run4<RoleBot>(g, p_in, b, p_out, zb, ze, yg + NRO + 2 * NRI, wave, lane, lds_all + (RoleTop::LDS_ROWS + 2 * RoleMid::LDS_ROWS) * 64, xbuf, xflag);
-	else run4<RoleMid>(g, p_in, b, p_out, zb, ze, yg + NRO + (wave - 1) * NRI, wave, lane, lds_all + (RoleTop::LDS_ROWS + (wave - 1) * RoleMid::LDS_ROWS) * 64, xbuf, xflag);
+	if (wave == 0) run4<RoleTop>(g, p_in, b, p_out, zb, ze, yg, wave, lane, lds_all, xbuf, xflag, none);
+	else if (wave == 3) run4<RoleBot>(g, p_in, b, p_out, zb, ze, yg + NRO + 2 * NRI, wave, lane, lds_all + (RoleTop::LDS_ROWS + 2 * RoleMid::LDS_ROWS) * 64, xbuf, xflag, none);
+	else run4<RoleMid>(g, p_in, b, p_out, zb, ze, yg + NRO + (wave - 1) * NRI, wave, lane, lds_all + (RoleTop::LDS_ROWS + (wave - 1) * RoleMid::LDS_ROWS) * 64, xbuf, xflag, none);
 }
 
 }  // namespace
@@ -769,6 +1006,30 @@ hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b
 		hipLaunchKernelGGL(k_jacobi_strip4o, dim3(bands * nch), dim3(512), 0, s, g, p_in, b, p_out, z_begin, z_end, zc, bands, nch, remap);
 	} else
 		hipLaunchKernelGGL(k_jacobi_strip4q, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
+	return hipGetLastError();
+}
+
+bool jacobi_freeze_strip4_supported(const Geom& g)
+{
+	return g.nz == g.Zg && g.H == 0 && g.X == 256 && g.Y >= O_BAND && g.Zg >= 8 && (uint64_t)g.X * g.Y * (uint64_t)g.Zg < (1u << 30);
+}
+
+// levels level_in + 1 .. level_in + 4 for every cell: p_in / m_in -> p_outA = p_outB, m_outA = m_outB; tiles that still relax get `tag`
+hipError_t launch_freeze_strip4(const Geom& g, const float* p_in, const float* b, float* p_outA, float* p_outB, const uint8_t* m_in, uint8_t* m_outA, uint8_t* m_outB,
+	uint32_t* tile_mark, uint32_t tag, uint32_t* stat, uint32_t stat_hi, int level_in, hipStream_t s)
+{
+	if (!jacobi_freeze_strip4_supported(g)) return hipErrorNotSupported;
+	const int bands = (g.Y + O_BAND - 1) / O_BAND;
+	int nch = 256 / bands;
+	if (nch < 1) nch = 1;
+	int zc = (g.Zg + nch - 1) / nch;
+	if (zc < 8) zc = 8;
+	if (zc > g.Zg) zc = g.Zg;
+	nch = (g.Zg + zc - 1) / zc;
+	FrzArgs fa;
+	fa.p_outB = p_outB; fa.m_in = m_in; fa.m_outA = m_outA; fa.m_outB = m_outB; fa.tile_mark = tile_mark; fa.tag = tag;
+	fa.ntx = (g.X + 31) / 32; fa.nty = (g.Y + 7) / 8; fa.stat = stat; fa.stat_hi = stat_hi; fa.level_in = level_in;
+	hipLaunchKernelGGL(k_freeze_strip4o, dim3(bands * nch), dim3(512), 0, s, g, p_in, b, p_outA, fa, zc, bands, nch);
 	return hipGetLastError();
 }
 

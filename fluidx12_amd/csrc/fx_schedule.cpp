@@ -432,6 +432,7 @@ static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 		// step or two old; either choice gives the same fields): three levels once half of the tiles relax.  Young plumes (a fifth of the
 		// tiles) stay on the tile launches, where a masked launch would cost 0.07 ms for nothing.
 		int want = FX_KNOB_INT("FREEZE_DENSE_LEVELS", -1);
+		const bool strip4 = FX_KNOB_INT("FREEZE_STRIP4", 1) && jacobi_freeze_strip4_supported(m->g);
 		if (want < 0) {
 			want = 0;
 			if (m->fz_active_dev) {
@@ -446,7 +447,7 @@ static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 					if (!m->fz_dense_on && 2u * active >= tiles) m->fz_dense_on = true;
 					else if (m->fz_dense_on && 5u * active < 2u * tiles) m->fz_dense_on = false;
 				}
-				if (m->fz_dense_on) want = 3;
+				if (m->fz_dense_on) want = strip4 ? 4 : 3;
 				if ((r.w.gen & 3u) == 0u) {
 					FX_HIP(launch_count_marks(r.w.tile_mark, r.w.gen, jacobi_freeze_tiles(m->g), m->fz_active_dev, CS(m, s)));
 					if (!m->fz_active_ev) FX_HIP(hipEventCreateWithFlags(&m->fz_active_ev, hipEventDisableTiming));
@@ -455,15 +456,19 @@ static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 				}
 			}
 		}
-		for (int k = 0; want >= 3 && left > 3; ++k, want -= 3) {
+		// a launch takes FOUR levels where the octet serves the grid (k_freeze_strip4o, fx_jacobi_strip4.hip; FREEZE_STRIP4=0: never), else three
+		const bool four = strip4;
+		for (int k = 0; want >= 3 && left > 3; ++k) {
 			DeviceGuard dg(m->device);
+			const int lv = four && want >= 4 && left > 4 ? 4 : 3;
 			flag_tag = r.w.gen | ((uint32_t)(k + 1) << 24);
-			FX_HIP(launch_freeze_strip3(r.v, r.a, m->b, r.d, r.src, r.ma, r.md, r.mx, r.w.tile_mark, flag_tag, r.stat, r.stat_hi, level, CS(m, s)));
-			if (mk[0]) { mk[0]->launches += 1; mk[0]->sweeps += 3; }
+			if (lv == 4) FX_HIP(launch_freeze_strip4(r.v, r.a, m->b, r.d, r.src, r.ma, r.md, r.mx, r.w.tile_mark, flag_tag, r.stat, r.stat_hi, level, CS(m, s)));
+			else FX_HIP(launch_freeze_strip3(r.v, r.a, m->b, r.d, r.src, r.ma, r.md, r.mx, r.w.tile_mark, flag_tag, r.stat, r.stat_hi, level, CS(m, s)));
+			if (mk[0]) { mk[0]->launches += 1; mk[0]->sweeps += (uint64_t)lv; }
 			m->acc.freeze_strip_launches += 1;                                  // (counted like the solves: with or without the timing marks)
-			float* na = r.d; r.d = r.src; r.src = r.a; r.a = na;                  // level + 3 now sits in (a, d); the buffer it was read from is the spare
+			float* na = r.d; r.d = r.src; r.src = r.a; r.a = na;                  // level + lv now sits in (a, d); the buffer it was read from is the spare
 			uint8_t* nm = r.md; r.md = r.mx; r.mx = r.ma; r.ma = nm;
-			level += 3; left -= 3;
+			level += lv; left -= (uint32_t)lv; want -= lv;
 		}
 	}
 	for (; left > 0; ++n) {

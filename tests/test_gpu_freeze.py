@@ -158,22 +158,33 @@ def test_freeze_rollout_matches_oracle_128():
 
 
 @pytest.mark.parametrize("dims", [(256, 256, 16), (256, 256, 41), (256, 256, 9), (256, 256, 24)])
-@pytest.mark.parametrize("iters,levels", [(5, 3), (7, 6), (17, 3), (17, 9), (64, 3), (64, 12), (4, 3)])
-def test_masked_strip_levels_equal_oracle(dims, iters, levels, knobs):
-    """the levels right behind the dense sweep on the masked strip pipeline (fx_jacobi_stripm.hip: three levels per launch for every cell,
-    freeze nibbles carried along, both output buffers and the tile marks for the first tile launch) instead of tile launches: the
-    oracle's fields and its executed-sweep count, whatever the number of strip launches"""
+@pytest.mark.parametrize("iters,levels", [(5, 3), (7, 6), (17, 3), (17, 9), (64, 3), (64, 12), (4, 3), (5, 4), (6, 4), (9, 8), (17, 7), (17, 11), (64, 16)])
+@pytest.mark.parametrize("strip4", [1, 0])
+def test_masked_strip_levels_equal_oracle(dims, iters, levels, strip4, knobs):
+    """the levels right behind the dense sweep on the masked strip pipelines (k_freeze_strip4o of fx_jacobi_strip4.hip: four levels per
+    launch for every cell in the octet; FREEZE_STRIP4=0: k_freeze_strip3 of fx_jacobi_stripm.hip, three; freeze nibbles carried along, both
+    output buffers and the tile marks for the first tile launch) instead of tile launches: the oracle's fields and its executed-sweep
+    count, whatever the number and the mix of strip launches (7 = 4 + 3, 11 = 4 + 4 + 3)"""
+    if not strip4 and levels % 3:
+        pytest.skip("three levels per launch")
     knobs["FLUIDX_FREEZE_DENSE_LEVELS"] = str(levels)
+    knobs["FLUIDX_FREEZE_STRIP4"] = str(strip4)
     X, Y, Z = dims
     p, b = plume_like(X, Y, Z, 900 + Z + iters, amp=0.08)
     want, k = orc.jacobi(p, b, iters, mode=1)
     got, t = solve(dims, p, b, iters)
     assert np.array_equal(got, want)
     assert (t.freeze_solves, t.freeze_sweeps) == (1, k)
+    launches, left, w = 0, iters - 1, levels                 # fx_schedule.cpp jacobi_freeze: fours while four levels are wanted and left behind them
+    while w >= 3 and left > 3:
+        lv = 4 if strip4 and w >= 4 and left > 4 else 3
+        launches, left, w = launches + 1, left - lv, w - lv
+    assert t.freeze_strip_launches == launches
 
 
-def test_masked_strip_levels_on_frozen_and_on_restless_fields(knobs):
-    knobs["FLUIDX_FREEZE_DENSE_LEVELS"] = "6"
+@pytest.mark.parametrize("levels", [6, 8])
+def test_masked_strip_levels_on_frozen_and_on_restless_fields(levels, knobs):
+    knobs["FLUIDX_FREEZE_DENSE_LEVELS"] = str(levels)
     dims = (256, 256, 12)
     z = np.zeros(dims[::-1], f32)
     got, t = solve(dims, z, z, 64)                       # nothing ever moves: one sweep
@@ -208,7 +219,7 @@ def test_masked_strip_levels_change_no_step(storage, knobs):
 
     ref = run("0")
     assert ref[3] > 2 * steps
-    for levels in ("3", "6", "-1"):
+    for levels in ("3", "6", "4", "8", "-1"):
         got = run(levels)
         for u, v in zip(ref[:3], got[:3]):
             assert np.array_equal(u.view(np.uint8), v.view(np.uint8)), levels
