@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float*
 		float4 o;
 		nib = relax_quad(c, L, R, U, D, F, Bk, bb, (0xFu << nv) & 0xFu, o);     // (cells a short last quad does not have: frozen)
 		stq<AL>(pA, c_off, nv, o);
-		stq<AL>(pB, c_off, nv, o);
+		if (pB) stq<AL>(pB, c_off, nv, o);                                // (null: a masked strip launch follows, which reads one copy and writes both)
 		qi = ((uint32_t)z * g.Y + y) * X4 + x4;
 		tile = ((z >> 3) * nty + (y >> 3)) * ntx + (x4 >> 3);
 	}
@@ -275,9 +275,9 @@ __global__ __launch_bounds__(256) void k_freeze_dense(const Geom g, const float*
 			(uint32_t)__builtin_amdgcn_update_dpp(0, v, 0xAA, 0xf, 0xf, false) << 16 | (uint32_t)__builtin_amdgcn_update_dpp(0, v, 0xFF, 0xf, 0xf, false) << 24;
 		if (in && (wl & 3) == 0) {
 			*reinterpret_cast<uint32_t*>(mA + qi) = packed;
-			*reinterpret_cast<uint32_t*>(mB + qi) = packed;
+			if (mB) *reinterpret_cast<uint32_t*>(mB + qi) = packed;
 		}
-	} else if (in) { mA[qi] = (uint8_t)nib; mB[qi] = (uint8_t)nib; }
+	} else if (in) { mA[qi] = (uint8_t)nib; if (mB) mB[qi] = (uint8_t)nib; }
 	// a tile with a relaxing cell is flagged for the first tile launch: one plain store per run of lanes that share a tile (every
 	// writer stores the same tag; no atomics, no list here -- with them the sweep took 72 us on a young plume and 95 us on a developed
 	// one, the difference being the marking)

@@ -107,8 +107,12 @@ __device__ __forceinline__ v4f relax4qm(v4f c, v4f U, v4f D, v4f F, v4f Bk, v4f 
 	const fx_f2 s01 = (((((lx - b01) + mid) + U01) + D01) + F01) + B01;
 	const fx_f2 s23 = (((((mid - b23) + rx) + U23) + D23) + F23) + B23;
 	const float inv = __uint_as_float(0x3e2aaaabu);
+#ifdef FX_M_NOTEST
+	const bool f0 = false, f1 = false, f2 = false, f3 = false;
+#else
 	const bool f0 = fabsf(fmaf(s01.x, inv, -c.x)) < kBelow4, f1 = fabsf(fmaf(s01.y, inv, -c.y)) < kBelow4;
 	const bool f2 = fabsf(fmaf(s23.x, inv, -c.z)) < kBelow4, f3 = fabsf(fmaf(s23.y, inv, -c.w)) < kBelow4;
+#endif
 	fx_f2 x01 = s01, x23 = s23;
 	x01 *= inv; x23 *= inv;
 	nib_out = nib | (f0 ? 1u : 0u) | (f1 ? 2u : 0u) | (f2 ? 4u : 0u) | (f3 ? 8u : 0u);
@@ -260,8 +264,13 @@ __device__ __forceinline__ void frz_out4(const Strip4<R>& st, Frz4& fz, char* ds
 	constexpr int NR = R::NR, RB = R::A ? 4 : 1;
 	const int z = st.q - 4;
 	const ptrdiff_t mo_ = (dst_ - fz.outA) >> 4;                         // a plane of nibble bytes is a sixteenth of a pressure plane
+#ifndef FX_M_ONEP
 #pragma unroll
 	for (int m = 0; m < NR; ++m) *reinterpret_cast<v4f*>(dst_ + fz.dB + opaque32q(roff[m + RB])) = X_[m];
+#endif
+#ifdef FX_M_NOBYTES
+	if (st.q < -1000)
+#endif
 #pragma unroll
 	for (int m = 0; m < NR; ++m) {
 		const uint32_t o_ = opaque32q(roff[m + RB] >> 4);

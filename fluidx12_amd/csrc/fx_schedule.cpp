@@ -372,6 +372,8 @@ static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 	std::vector<std::unique_ptr<ScopedMark>> mk(M.size());
 	const bool fuse = lead->fz_fuse_div;
 	lead->fz_fuse_div = false;
+	int strip_want = 0;                                                 // levels wanted from the masked strip pipelines (single domain, X = 256)
+	bool strip_four = false, count_marks_now = false;
 	for (size_t i = 0; i < M.size(); ++i) {
 		fx_ctx* m = M[i];
 		DeviceGuard dg(m->device);
@@ -403,8 +405,37 @@ static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 		const size_t moff = (size_t)first * (size_t)((m->g.X + 3) / 4) * m->g.Y, es = elem_size(m);
 		// fx_timing books the dense sweep as the "main" launch and the tile launches beside it.  A single domain keeps ONE mark open over
 		// all of them (an event record between two launches is a 2-3 us gap, 17 of them a solve); slab ranks close it at every exchange
+		// While most tiles still relax the tile launches are dense sweeps in all but name: the levels right behind the dense sweep then go
+		// through a masked strip pipeline (see below), decided HERE because the dense sweep itself depends on it -- a strip launch reads one
+		// copy of level 1 and writes both buffers, so the dense sweep in front of it leaves its second copy (and second mask copy) away.
+		// FREEZE_DENSE_LEVELS: how many levels (0, 3, 4, 6, 7, 8 ...); default -1 = by what the dense sweeps of the last steps left relaxing
+		// -- the count k_count_marks put into a host-visible word behind an earlier solve's dense sweep: one strip launch once half of the
+		// tiles relax.  Young plumes (a fifth of the tiles) stay on the tile launches, where a masked launch would cost 0.07 ms for nothing.
+		if (!multi && jacobi_freeze_strip_supported(m->g) && m->fz_mask[2]) {
+			strip_want = FX_KNOB_INT("FREEZE_DENSE_LEVELS", -1);
+			strip_four = FX_KNOB_INT("FREEZE_STRIP4", 1) && jacobi_freeze_strip4_supported(m->g);
+			if (strip_want < 0) {
+				strip_want = 0;
+				if (m->fz_active_dev) {
+					// every fourth solve counts (the plume changes slowly, the count is a 5-us launch); the solve TWO after it takes the count over,
+					// behind the event recorded with it -- by then it has long arrived, so nothing waits, and which solve switches is a function
+					// of the step sequence, not of when the host happened to look (the unsynchronised read made launch sequences,
+					// step times and kernel statistics vary from run to run around the threshold)
+					if ((gen & 3u) == 2u && m->fz_active_pending) {
+						FX_HIP(hipEventSynchronize(m->fz_active_ev));
+						m->fz_active_pending = false;
+						const uint32_t active = *(volatile uint32_t*)m->fz_active_host, tiles = (uint32_t)jacobi_freeze_tiles(m->g);
+						if (!m->fz_dense_on && 2u * active >= tiles) m->fz_dense_on = true;
+						else if (m->fz_dense_on && 5u * active < 2u * tiles) m->fz_dense_on = false;
+					}
+					if (m->fz_dense_on) strip_want = strip_four ? 4 : 3;
+					count_marks_now = (gen & 3u) == 0u;
+				}
+			}
+		}
+		const bool one_copy = strip_want >= 3 && iters - 1 > 3 && FX_KNOB_INT("FREEZE_DENSE_ONE", 1);   // a strip launch follows (the loop below)
 		mk[i].reset(new ScopedMark(m, ms, MK_JACOBI));
-		FX_HIP(launch_freeze_dense(r.v, r.src + r.off, m->b + r.off, r.a + r.off, r.d + r.off, r.ma + moff, r.md + moff, r.w, ms,
+		FX_HIP(launch_freeze_dense(r.v, r.src + r.off, m->b + r.off, r.a + r.off, one_copy ? nullptr : r.d + r.off, r.ma + moff, one_copy ? nullptr : r.md + moff, r.w, ms,
 			fuse ? (const char*)m->vel[1] + r.off * es : nullptr, m->half, r.own0, m->g.nz, m->g.cells_local()));
 		mk[i]->launches = 1; mk[i]->sweeps = 1;
 		if (multi || iters == 1) mk[i].reset(); else mk[i]->split(MK_JACOBI_TAIL);
@@ -421,40 +452,20 @@ static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 	int level = 1, n = 0;
 	uint32_t left = iters - 1, flag_tag = 0;
 	// While most tiles still relax the tile launches are dense sweeps in all but name (43 us per level at 256^3, a cone five times the
-	// core per tile): the levels right behind the dense sweep go through the masked strip pipeline instead (fx_jacobi_stripm.hip: three
-	// levels per launch for every cell, ~15 us per level), which leaves level + 3 in two of the three pressure buffers -- they rotate --
-	// and the tile marks for the first tile launch.  Single domain, X = 256.
+	// core per tile): the levels right behind the dense sweep go through a masked strip pipeline instead -- k_freeze_strip4o
+	// (fx_jacobi_strip4.hip: four levels per launch for every cell, 22 us per level) or k_freeze_strip3 (fx_jacobi_stripm.hip: three, 30 us
+	// per level) -- which leaves its last level in two of the three pressure buffers -- they rotate -- and the tile marks for the first
+	// tile launch.  Single domain, X = 256; how many levels was decided in front of the dense sweep.
 	if (!multi && jacobi_freeze_strip_supported(M[0]->g) && M[0]->fz_mask[2]) {
 		fx_ctx* m = M[0];
 		Run& r = R[0];
-		// FREEZE_DENSE_LEVELS: how many (0, 3, 6 ...); default -1 = by what the dense sweeps of the last steps left relaxing -- the count
-		// k_count_marks put into a host-visible word behind the previous solves' dense sweep, read here without waiting (it may be a
-		// step or two old; either choice gives the same fields): three levels once half of the tiles relax.  Young plumes (a fifth of the
-		// tiles) stay on the tile launches, where a masked launch would cost 0.07 ms for nothing.
-		int want = FX_KNOB_INT("FREEZE_DENSE_LEVELS", -1);
-		const bool strip4 = FX_KNOB_INT("FREEZE_STRIP4", 1) && jacobi_freeze_strip4_supported(m->g);
-		if (want < 0) {
-			want = 0;
-			if (m->fz_active_dev) {
-				// every fourth solve counts (the plume changes slowly, the count is a 5-us launch); the solve TWO after it takes the count over,
-				// behind the event recorded with it -- by then it has long arrived, so nothing waits, and which solve switches is a function
-				// of the step sequence, not of when the host happened to look (the unsynchronised read made launch sequences,
-				// step times and kernel statistics vary from run to run around the threshold)
-				if ((r.w.gen & 3u) == 2u && m->fz_active_pending) {
-					FX_HIP(hipEventSynchronize(m->fz_active_ev));
-					m->fz_active_pending = false;
-					const uint32_t active = *(volatile uint32_t*)m->fz_active_host, tiles = (uint32_t)jacobi_freeze_tiles(m->g);
-					if (!m->fz_dense_on && 2u * active >= tiles) m->fz_dense_on = true;
-					else if (m->fz_dense_on && 5u * active < 2u * tiles) m->fz_dense_on = false;
-				}
-				if (m->fz_dense_on) want = strip4 ? 4 : 3;
-				if ((r.w.gen & 3u) == 0u) {
-					FX_HIP(launch_count_marks(r.w.tile_mark, r.w.gen, jacobi_freeze_tiles(m->g), m->fz_active_dev, CS(m, s)));
-					if (!m->fz_active_ev) FX_HIP(hipEventCreateWithFlags(&m->fz_active_ev, hipEventDisableTiming));
-					FX_HIP(hipEventRecord(m->fz_active_ev, CS(m, s)));
-					m->fz_active_pending = true;
-				}
-			}
+		int want = strip_want;
+		const bool strip4 = strip_four;
+		if (count_marks_now) {
+			FX_HIP(launch_count_marks(r.w.tile_mark, r.w.gen, jacobi_freeze_tiles(m->g), m->fz_active_dev, CS(m, s)));
+			if (!m->fz_active_ev) FX_HIP(hipEventCreateWithFlags(&m->fz_active_ev, hipEventDisableTiming));
+			FX_HIP(hipEventRecord(m->fz_active_ev, CS(m, s)));
+			m->fz_active_pending = true;
 		}
 		// a launch takes FOUR levels where the octet serves the grid (k_freeze_strip4o, fx_jacobi_strip4.hip; FREEZE_STRIP4=0: never), else three
 		const bool four = strip4;

@@ -182,9 +182,11 @@ def test_masked_strip_levels_equal_oracle(dims, iters, levels, strip4, knobs):
     assert t.freeze_strip_launches == launches
 
 
-@pytest.mark.parametrize("levels", [6, 8])
-def test_masked_strip_levels_on_frozen_and_on_restless_fields(levels, knobs):
+@pytest.mark.parametrize("levels,one_copy", [(6, 1), (8, 1), (8, 0), (3, 0)])
+def test_masked_strip_levels_on_frozen_and_on_restless_fields(levels, one_copy, knobs):
+    """(FREEZE_DENSE_ONE=0: the dense sweep in front of a strip launch writes both copies of level 1 as it does in front of tile launches)"""
     knobs["FLUIDX_FREEZE_DENSE_LEVELS"] = str(levels)
+    knobs["FLUIDX_FREEZE_DENSE_ONE"] = str(one_copy)
     dims = (256, 256, 12)
     z = np.zeros(dims[::-1], f32)
     got, t = solve(dims, z, z, 64)                       # nothing ever moves: one sweep

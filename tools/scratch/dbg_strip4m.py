@@ -26,7 +26,7 @@ def sweep(p, b, m):
     t = (s.astype(np.float64) * np.float64(INV) - p.astype(np.float64)).astype(f32)
     fr = np.abs(t) < KB
     return np.where(m, p, x).astype(f32), m | fr
-def run(Z, levels, seed=1, which=4, frac=0.3, amp=1.0, flat=False):
+def run(Z, levels, seed=1, which=4, frac=0.3, amp=1.0, flat=False, time_it=False):
     X = Y = 256
     rng = np.random.default_rng(seed)
     zz, yy, xx = np.meshgrid(np.arange(Z), np.arange(Y), np.arange(X), indexing="ij")
@@ -56,6 +56,15 @@ def run(Z, levels, seed=1, which=4, frac=0.3, amp=1.0, flat=False):
     rc = fn(ctypes.byref(g), vp(tp.data_ptr()), vp(tb.data_ptr()), vp(tA.data_ptr()), vp(tB.data_ptr()), vp(tm.data_ptr()), vp(tmA.data_ptr()), vp(tmB.data_ptr()),
             vp(marks.data_ptr()), ctypes.c_uint(77), vp(stat.data_ptr()), ctypes.c_uint(0), ctypes.c_int(10), vp(0))
     torch.cuda.synchronize()
+    if time_it:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            fn(ctypes.byref(g), vp(tp.data_ptr()), vp(tb.data_ptr()), vp(tA.data_ptr()), vp(tB.data_ptr()), vp(tm.data_ptr()), vp(tmA.data_ptr()), vp(tmB.data_ptr()),
+               vp(marks.data_ptr()), ctypes.c_uint(77), vp(stat.data_ptr()), ctypes.c_uint(0), ctypes.c_int(10), vp(0))
+        e1.record(); torch.cuda.synchronize()
+        print("TIME which", which, "Z", Z, "%.1f us per launch" % (e0.elapsed_time(e1) * 1e3 / 50))
+        return
     A, B, mA, mB = tA.cpu().numpy(), tB.cpu().numpy(), tmA.cpu().numpy(), tmB.cpu().numpy()
     mk = marks.cpu().numpy().reshape(-1, 32, 8)
     print("Z", Z, "which", which, "rc", rc, "pA ok", np.array_equal(A, pe), "pB ok", np.array_equal(B, pe), "mA ok", np.array_equal(mA, mbe), "mB ok", np.array_equal(mB, mbe), "stat", stat.cpu().numpy()[:1])
@@ -72,8 +81,11 @@ def run(Z, levels, seed=1, which=4, frac=0.3, amp=1.0, flat=False):
             print("  ", name, "ndiff", len(d), "z", np.unique(d[:, 0]), "y%14", np.bincount(d[:, 1] % 14, minlength=14), "first", d[:5].tolist())
             for c in d[:5]: print("     got", G[tuple(c)], "want", E[tuple(c)])
 
-run(16, 4, frac=0.0, amp=1000.0, flat=True)      # nothing frozen, nothing freezes: four plain sweeps
-run(16, 4, frac=0.3, amp=1000.0, flat=True)      # random frozen cells, nothing new freezes
-run(16, 4, frac=0.0, amp=1.0, flat=False)        # nothing frozen on entry, the loop freezes
-for Z in (8, 9, 16, 27, 64):
-    run(Z, 4, frac=0.3)
+import os
+if os.environ.get("DBG_TIME"):
+    run(256, 4, frac=0.3, time_it=True)
+    run(256, 3, which=3, frac=0.3, time_it=True)
+else:
+    run(16, 4, frac=0.0, amp=1000.0, flat=True)
+    for Z in (8, 9, 16, 27, 64):
+        run(Z, 4, frac=0.3)
