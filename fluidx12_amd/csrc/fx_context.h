@@ -33,7 +33,7 @@ struct fx_ctx {
 	uint32_t* fz_active_dev = nullptr;
 	hipEvent_t fz_active_ev = nullptr;    // recorded behind k_count_marks; the count is taken over two solves later, behind this event: the same on every run
 	bool fz_active_pending = false;
-	bool fz_dense_on = false;             // the masked strip launches are in use (hysteresis: on from half of the tiles, off below two fifths)
+	int fz_dense_n = 0;                   // masked strip launches per solve in use (0..2; chosen with hysteresis from the count of relaxing tiles, fx_schedule.cpp)
 	uint8_t* fz_mask[3] = { nullptr, nullptr, nullptr };   // [2]: the third one of the masked strip launches (three pressure buffers rotate, so do the masks)
 	uint32_t* fz_tile_next = nullptr;  // per tile: tag of the solve that listed it last
 	void* fz_list[2] = { nullptr, nullptr };   // work lists of alternate launches

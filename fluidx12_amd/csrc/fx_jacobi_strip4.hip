@@ -120,6 +120,51 @@ __device__ __forceinline__ v4f relax4qm(v4f c, v4f U, v4f D, v4f F, v4f Bk, v4f 
 }
 #define FXQ_NIB(m, r) (((m) >> (4 * (r))) & 15u)
 
+// The same update with the bookkeeping in fewer instructions (the masked kernel is bound by what it issues: 51 VALU per quad above, 39 here;
+// FX_M_PLAIN builds the plain form).  mword / pos: a nibble word and the bit of the quad's first cell in it; a frozen cell is kept by a
+// bit-field insert under the sign-extended flag (v_bfe_i32 + v_bfi_b32 instead of and + compare + select).  facc collects the sweep's
+// freeze decisions: the compare's carry is shifted in by an add-with-carry (facc = 2 facc + vcc), cell 3 first, so that a caller that
+// walks its rows from the LAST to the first ends up with row r's new bits in nibble r; the bits a cell came in with are OR-ed in by the
+// caller, once per plane.  The difference |s/6 - c| of two cells comes from one v_pk_fma_f32 (fused like fmaf).
+__device__ __forceinline__ void frz_shift_in4(uint32_t& facc, float t3, float t2, float t1, float t0, float below)
+{
+	// (one statement: between two asm statements that pass a register on the compiler puts a wait state)
+	asm("v_cmp_lt_f32_e64 vcc, |%1|, %5\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+		"v_cmp_lt_f32_e64 vcc, |%2|, %5\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+		"v_cmp_lt_f32_e64 vcc, |%3|, %5\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+		"v_cmp_lt_f32_e64 vcc, |%4|, %5\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+		: "+v"(facc) : "v"(t3), "v"(t2), "v"(t1), "v"(t0), "s"(below) : "vcc");
+}
+__device__ __forceinline__ float frz_keep(uint32_t mword, int bit, float c, float x)
+{
+	uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)mword, bit, 1);             // 0 / ~0
+	asm("" : "+v"(m));                                                              // (seen through, the compiler turns the insert back into and + compare + select)
+	return __uint_as_float((m & __float_as_uint(c)) | (~m & __float_as_uint(x)));
+}
+__device__ __forceinline__ v4f relax4qf(v4f c, v4f U, v4f D, v4f F, v4f Bk, v4f bb, uint32_t mword, int pos, uint32_t& facc)
+{
+	const fx_f2 c01 = { c.x, c.y }, c23 = { c.z, c.w };
+	fx_f2 lx = pk_mov(c01, c01, 0);
+	const fx_f2 mid = pk_mov(c01, c23, 1);
+	fx_f2 rx = pk_mov(c23, c23, 2);
+	const float cx_ = c.x, cw_ = c.w, lx0_ = lx.x, rx1_ = rx.y;
+	lx.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, lx0_), __builtin_bit_cast(int, cw_), 0x138, 0xf, 0xf, false));
+	rx.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, rx1_), __builtin_bit_cast(int, cx_), 0x130, 0xf, 0xf, false));
+	const fx_f2 b01 = { bb.x, bb.y }, b23 = { bb.z, bb.w }, U01 = { U.x, U.y }, U23 = { U.z, U.w }, D01 = { D.x, D.y }, D23 = { D.z, D.w };
+	const fx_f2 F01 = { F.x, F.y }, F23 = { F.z, F.w }, B01 = { Bk.x, Bk.y }, B23 = { Bk.z, Bk.w };
+	const fx_f2 s01 = (((((lx - b01) + mid) + U01) + D01) + F01) + B01;
+	const fx_f2 s23 = (((((mid - b23) + rx) + U23) + D23) + F23) + B23;
+	const float inv = __uint_as_float(0x3e2aaaabu);
+	fx_f2 t01, t23;
+	const fx_f2 inv2 = { inv, inv };
+	asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(t01) : "v"(s01), "s"(inv2), "v"(c01));
+	asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(t23) : "v"(s23), "s"(inv2), "v"(c23));
+	fx_f2 x01 = s01, x23 = s23;
+	x01 *= inv; x23 *= inv;
+	frz_shift_in4(facc, t23.y, t23.x, t01.y, t01.x, kBelow4);
+	return v4f{ frz_keep(mword, pos, c.x, x01.x), frz_keep(mword, pos + 1, c.y, x01.y), frz_keep(mword, pos + 2, c.z, x23.x), frz_keep(mword, pos + 3, c.w, x23.y) };
+}
+
 // what the masked kernel's launch carries besides the three fields (one kernel argument)
 struct FrzArgs {
 	float* p_outB; const uint8_t* m_in; uint8_t* m_outA; uint8_t* m_outB;
@@ -236,8 +281,13 @@ __device__ __forceinline__ void relax_level4(const Strip4<R>& st, const v4f (&Po
 {
 	uint32_t m_ = 0u;
 #pragma unroll
-	for (int k = 0; k < NN; ++k) {
+	for (int kk = 0; kk < NN; ++kk) {
 		constexpr int UP = R::UP;
+#ifdef FX_M_PLAIN
+		const int k = kk;
+#else
+		const int k = MK ? NN - 1 - kk : kk;                             // (the masked loop: last row first, see relax4qf)
+#endif
 		const int jc = k + UP;                                           // level-L index of this row
 		const v4f c = Pctr[jc];
 		v4f u = jc >= 1 ? Pctr[jc >= 1 ? jc - 1 : 0] : HU;
@@ -245,13 +295,21 @@ __device__ __forceinline__ void relax_level4(const Strip4<R>& st, const v4f (&Po
 		if (R::A && k == 3 - L && st.wall_top) u = c;                    // rows outside the domain hold no data
 		if (R::W && k == R::NR - 1 && st.wall_bot) d = c;
 		if (MK) {
+#ifdef FX_M_PLAIN
 			uint32_t n_;
 			out[k] = relax4qm(c, u, d, Pold[jc], Pnew[jc], Bq[k], FXQ_NIB(mctr, jc), n_);
 			m_ |= n_ << (4 * k);
+#else
+			out[k] = relax4qf(c, u, d, Pold[jc], Pnew[jc], Bq[k], mctr, 4 * jc, m_);
+#endif
 		} else
 			out[k] = relax4q(c, u, d, Pold[jc], Pnew[jc], Bq[k]);
 	}
+#ifdef FX_M_PLAIN
 	if (MK) mout = m_;
+#else
+	if (MK) mout = ((mctr >> (4 * R::UP)) & ((1u << (4 * NN)) - 1u)) | m_;   // the bits the rows came in with + this sweep's
+#endif
 }
 
 // The masked loop's output plane q - 4 besides its pressure rows (stored by the caller to p_outA): the same rows to p_outB, the nibbles to
@@ -390,6 +448,19 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 #pragma unroll
 				for (int j = 0; j < N1; ++j) T_[j] = relax4q(C_[j + 1], C_[j], C_[j + 2], F_[j], np(j + 1), nb(j));
 			} else {                                                      // lean: a sliding window of three rows (the SIMD's other wave covers the LDS latency; registers are what is short)
+#ifndef FX_M_PLAIN
+				if (MK) {                                                  // the masked loop walks the window upwards (last row first, see relax4qf)
+					v4f d_ = FXQ_LDS(st, st.s_ctr, N1 + 1), c_ = FXQ_LDS(st, st.s_ctr, N1);
+#pragma unroll
+					for (int j = N1 - 1; j >= 0; --j) {
+						const v4f u_ = FXQ_LDS(st, st.s_ctr, j), f_ = FXQ_LDS(st, st.s_old, j + 1);
+						T_[j] = relax4qf(c_, u_, d_, f_, np(j + 1), nb(j), fz.M0c, 4 * j, m1_);
+						d_ = c_; c_ = u_;
+					}
+					m1_ |= fz.M0c & ((1u << (4 * N1)) - 1u);
+				} else
+#endif
+				{
 				v4f u_ = FXQ_LDS(st, st.s_ctr, 0), c_ = FXQ_LDS(st, st.s_ctr, 1);
 #pragma unroll
 				for (int j = 0; j < N1; ++j) {
@@ -404,6 +475,7 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 #ifdef FX_O_SCHEDBAR
 					__builtin_amdgcn_sched_barrier(0);
 #endif
+				}
 				}
 				if (MK && q - 1 >= st.zb && q - 1 < st.ze && (~(m1_ >> (4 * O1)) & OWN) != 0u) fz.rel |= 2u;
 			}
@@ -689,14 +761,26 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 			if (MK) m1_ = MW[0][CTR];
 		} else {
 #pragma unroll
-			for (int j = 0; j < NR; ++j) {
+			for (int jj = 0; jj < NR; ++jj) {
+#ifdef FX_M_PLAIN
+				const int j = jj;
+#else
+				const int j = MK ? NR - 1 - jj : jj;
+#endif
 				if (MK) {
+#ifdef FX_M_PLAIN
 					uint32_t n_;
 					T_[j] = relax4qm(I[CTR][j + 1], I[CTR][j], I[CTR][j + 2], I[OLD][j + 1], I[NEW][j + 1], NB[j], FXQ_NIB(fz.M0c, j), n_);
 					m1_ |= n_ << (4 * j);
+#else
+					T_[j] = relax4qf(I[CTR][j + 1], I[CTR][j], I[CTR][j + 2], I[OLD][j + 1], I[NEW][j + 1], NB[j], fz.M0c, 4 * j, m1_);
+#endif
 				} else
 					T_[j] = relax4q(I[CTR][j + 1], I[CTR][j], I[CTR][j + 2], I[OLD][j + 1], I[NEW][j + 1], NB[j]);
 			}
+#ifndef FX_M_PLAIN
+			if (MK) m1_ |= fz.M0c & OWN;
+#endif
 			if (MK && q - 1 >= st.zb && q - 1 < st.ze && (~m1_ & OWN) != 0u) fz.rel |= 2u;
 		}
 #pragma unroll

@@ -425,10 +425,24 @@ static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 						FX_HIP(hipEventSynchronize(m->fz_active_ev));
 						m->fz_active_pending = false;
 						const uint32_t active = *(volatile uint32_t*)m->fz_active_host, tiles = (uint32_t)jacobi_freeze_tiles(m->g);
-						if (!m->fz_dense_on && 2u * active >= tiles) m->fz_dense_on = true;
-						else if (m->fz_dense_on && 5u * active < 2u * tiles) m->fz_dense_on = false;
+						// how many strip launches, with hysteresis.  Four levels per launch (k_freeze_strip4o behind a one-copy dense sweep): one
+						// launch pays from a fifth of the tiles (256^3 plume: frame ~70, 0.600 -> 0.585 ms per step; at a half, frame 110: 0.747 ->
+						// 0.671), a second one from two thirds (frame ~140; frame 190: 0.790 -> 0.759).  Three levels per launch
+						// (k_freeze_strip3, 30 us per level): one launch from half of the tiles.
+						int n = m->fz_dense_n;
+						if (strip_four) {
+							if (n == 0 && 5u * active >= tiles) n = 1;
+							else if (n >= 1 && 6u * active < tiles) n = 0;
+							if (n == 1 && 16u * active >= 11u * tiles) n = 2;
+							else if (n == 2 && 8u * active < 5u * tiles) n = 1;
+						} else {
+							if (n == 0 && 2u * active >= tiles) n = 1;
+							else if (n >= 1 && 5u * active < 2u * tiles) n = 0;
+							if (n > 1) n = 1;
+						}
+						m->fz_dense_n = n;
 					}
-					if (m->fz_dense_on) strip_want = strip_four ? 4 : 3;
+					strip_want = m->fz_dense_n * (strip_four ? 4 : 3);
 					count_marks_now = (gen & 3u) == 0u;
 				}
 			}
