@@ -66,7 +66,7 @@ def test_no_scratch_in_the_hot_kernels(tmp_path):
     """register-resident kernels must not spill (a spill turns a bandwidth-bound kernel into a scratch-bound one silently)"""
     for source, prefix in (("fx_jacobi_freeze.hip", "k_freeze_"), ("fx_advect_lds.hip", "k_advect_lds"), ("fx_advect_lds.hip", "k_advect_far"), ("fx_jacobi_stripm.hip", "k_freeze_strip3"),
                            ("fx_render_accel.hip", "k_view_slots"), ("fx_render_accel.hip", "k_light_rays"), ("fx_render_accel.hip", "k_build_fill"),
-                           ("fx_render_accel.hip", "k_direct_march"), ("fx_jacobi_strip4.hip", "k_jacobi_strip4"), ("fx_jacobi_strip3.hip", "k_jacobi_strip3c")):
+                           ("fx_render_accel.hip", "k_direct_march"), ("fx_jacobi_strip4.hip", "k_jacobi_strip4"), ("fx_jacobi_strip4.hip", "k_freeze_strip4"), ("fx_jacobi_strip3.hip", "k_jacobi_strip3c")):
         text = "\n".join(device_isa(source, tmp_path))
         for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
             if prefix in m.group(1):
@@ -86,4 +86,6 @@ def test_the_octet_kernel_fits_two_waves_per_simd(tmp_path):
     quad = [v for k, v in seen.items() if "k_jacobi_strip4q" in k]
     assert len(octet) == 1 and len(quad) == 1, list(seen)
     assert octet[0][0] <= 256 and octet[0][1] <= 160 * 1024 and octet[0][2] == 0, octet
+    masked = [v for k, v in seen.items() if "k_freeze_strip4o" in k]          # the same octet with the freeze nibbles carried along
+    assert len(masked) == 1 and masked[0][0] <= 256 and masked[0][1] <= 160 * 1024 and masked[0][2] == 0, masked
     assert 256 < quad[0][0] <= 512 and quad[0][1] <= 160 * 1024 and quad[0][2] == 0, quad
