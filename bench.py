@@ -258,6 +258,8 @@ def main():
     ap.add_argument("--peer-devices", action="store_true",
                     help="--loopback N --group peer: slab r lives on device r -- ONE process driving N GPUs, planes travelling by "
                          "hipMemcpyPeerAsync.  This is a measurement (n_gpus = N), unlike the one-GPU loop-back")
+    ap.add_argument("--no-preheat", action="store_true",
+                    help="skip the device wake-up in front of the warm-up steps (`device_preheat` in the line): the cold figure")
     ap.add_argument("--no-peer-leg", action="store_true",
                     help="--gpus N > 1: do not time the in-process peer transport (a child process of rank 0, after the RCCL measurement) "
                          "beside the RCCL line")
@@ -494,6 +496,32 @@ def main():
                     schedule["link_model"] = {"group_call_latency_us": lat_ms * 1e3, "GBps_per_rank_both_faces": (1.0 / per_mb) if per_mb > 0 else None,
                                               "from": "exchange_ms = calls x latency + MB / bandwidth over the serial candidates (0, %d) and (0, %d); "
                                                       "loop-back and mock runs measure copies, not links" % (a_["jacobi_round"], b_["jacobi_round"])}
+
+    # Device wake-up.  A GPU that has idled through library load and context creation runs its first ~40 ms of work 3-5 % slower than
+    # later (tools/step_time_profile.py: 256^3 steps 5..29 at 0.78-0.79 ms, from step 35 on 0.745-0.76; a SECOND context started from the
+    # zero state in the same process runs 0.742-0.759 from its first step -- the device, not the data).  `--steps 20 --warmup 5` is 20 ms
+    # of work: all of it inside that ramp.  So the same step runs on a scratch context (same grid, zero state, single domain) for 80 ms
+    # first; the contract's W warm-up steps and K timed steps follow on the fresh context, frames W .. W + K - 1 as before.  Reported
+    # as `device_preheat`; --no-preheat gives the cold figure.
+    preheat = None
+    if fluid is not None and not loop and not args.no_preheat:
+        watch.arm("device wake-up", 2.0)
+        import fluidx12_amd as fx_
+        scratch = fx_.Fluid()
+        if scratch.Init(1920, 1080, (GX, GY, nz if N > 1 else GZ), storage=args.storage, jacobi_iters=args.iters, jacobi_mode=args.mode,
+                        advect_address=args.address, device=local_rank if N > 1 else -1):
+            t_p, n_p = time.perf_counter(), 0
+            while time.perf_counter() - t_p < 0.080 and n_p < 400:
+                for _ in range(4):
+                    scratch.UpdateFrame(dt, n_p % 3)
+                    scratch.Simulate(n_p % 3)
+                    n_p += 1
+                scratch.Synchronize()
+            preheat = {"steps": n_p, "ms": (time.perf_counter() - t_p) * 1e3,
+                       "what": "the same step on a scratch context of the same grid before the warm-up steps: a device that has idled runs its first "
+                               "~40 ms of work 3-5 % slower (tools/step_time_profile.py); --no-preheat = the cold figure"}
+            scratch.Release()
+        watch.disarm()
 
     watch.arm("warm-up", 1.0 + args.warmup / 50.0)
     for k in range(args.warmup):
@@ -858,6 +886,7 @@ def main():
             "scaling": args.scaling if N > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.storage == "fp32" else "f32 arithmetic / f16 field storage",
+            "device_preheat": preheat,
             "data": "synthetic" if not loop else ("synthetic; IN-PROCESS PEER GROUP: one process drives %d GPUs, a slab each" % loop) if args.peer_devices else
                     "synthetic; LOOP-BACK: %d slab ranks share ONE GPU (functional check of the multi-rank path, not a scaling measurement)" % loop,
             "config": {"workload": "%dx%dx%d 3D smoke (%.1f M voxels per GPU), %s, %s fields, %s sampler, "
