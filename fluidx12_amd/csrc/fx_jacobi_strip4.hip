@@ -2,6 +2,9 @@
 // waves of a workgroup sharing a band of rows, every inner boundary an LDS mailbox.  Two kernels:
 //   k_jacobi_strip4o  (the default) EIGHT waves per workgroup, two per SIMD, over a band of 14 rows (1 + 2 + 2 + 2 + 2 + 2 + 2 + 1);
 //   k_jacobi_strip4q  (STRIP4_OCTET=0) four waves, one per SIMD, over a band of 16 rows (3 + 5 + 5 + 3).
+// and the octet once more as k_freeze_strip4o: four levels of the reference's OWN loop (a cell leaves it for good once a sweep changes it by
+// less than 1e-3) for every cell, the freeze nibbles carried along the windows -- the masked strip launch of the sparse solver
+// (fx_schedule.cpp jacobi_freeze; k_freeze_strip3 of fx_jacobi_stripm.hip is the three-level, one-wave-per-SIMD predecessor).
 //
 // Restates CSPoisson.hlsli:8-26 (/root/reference/FluidX12/Content/Shaders/) like every Jacobi kernel here: the per-cell arithmetic and its
 // association order, ((((((L - b) + R) + U) + D) + F) + B) * (1/6), are unchanged (relax4_pairs, fx_pk.h), so four fused sweeps are
