@@ -803,7 +803,11 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 #pragma unroll
 	for (int j = 0; j < NR; ++j) Bp[OLD][j] = NB[j];                     // b[q-1] takes the place of b[q-4]: [OLD] is the next step's [NEW]
 	// the prefetch: input plane q+1 into the registers of plane q-2 (dead: [OLD] is the next step's [NEW]), b[q] into NB
+#ifdef FX_S4_NOLOAD
+	if (q + 1 <= st.q_load_last && q < -1000) {                        // (timing experiment: the loads never execute)
+#else
 	if (q + 1 <= st.q_load_last) {
+#endif
 #pragma unroll
 		for (int i = 0; i < NI; ++i) I[OLD][i] = *reinterpret_cast<const v4f*>(st.pp + opaque32q(roff[i]));
 		if (MK) {
@@ -814,7 +818,11 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 #pragma unroll
 		for (int i = 0; i < NI; ++i) I[OLD][i] = I[NEW][i];
 	}
+#ifdef FX_S4_NOLOAD
+	if (q <= st.b_load_last && q < -1000) {
+#else
 	if (q <= st.b_load_last) {
+#endif
 #pragma unroll
 		for (int j = 0; j < NR; ++j) NB[j] = *reinterpret_cast<const v4f*>(st.pbq + opaque32q(roff[j + 1]));
 	}
@@ -876,6 +884,9 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 		uint32_t m4_ = 0u;
 		relax_level4<R, 3, NR, NR, MK>(st, P3[OLD], P3[CTR], P3[NEW], B4_, HU3, HD3, X_, MK ? MW[2][CTR] : 0u, m4_);
 		char* dst_ = q - 4 >= st.zb ? st.po : st.po_zb;
+#ifdef FX_S4_NOSTORE
+		if (q < -1000)
+#endif
 #pragma unroll
 		for (int m = 0; m < NR; ++m) *reinterpret_cast<v4f*>(dst_ + opaque32q(roff[m + 1])) = X_[m];
 		if (MK) frz_out4<R>(st, fz, dst_, X_, m4_, roff);
