@@ -5,6 +5,7 @@ is smooth (a blob that shrinks), and an x-neighbour taken from the wrong cell of
 random flags next to relaxing cells show it in the first quad.  Checked: both pressure copies, both mask copies, the tile marks and the
 statistics word, bit for bit."""
 import ctypes
+import os
 import re
 import subprocess
 
@@ -103,3 +104,16 @@ def test_masked_strip_kernel_against_a_numpy_model(levels, depth, frac, amp, fla
     # the statistics word: the last level that left a cell relaxing (LEVEL_IN itself: a cell that came in relaxing); untouched if none did
     last = max([l for l, r in enumerate(relaxing_after) if r], default=-1)
     assert int(stat.cpu().numpy()[0]) == (LEVEL_IN + last if last >= 0 else 0)
+
+
+SOAK = int(os.environ.get("FLUIDX_MASKED_SOAK", "6"))       # random cases per kernel (a soak run: FLUIDX_MASKED_SOAK=200)
+
+
+@pytest.mark.parametrize("levels", [4, 3])
+@pytest.mark.parametrize("case", range(SOAK))
+def test_masked_strip_kernel_on_random_cases(levels, case):
+    rng = np.random.default_rng(7000 + case)
+    depth = int(rng.integers(8, 70))
+    frac = float(rng.choice([0.0, 0.05, 0.3, 0.6, 0.95]))
+    amp = float(rng.choice([0.3, 1.0, 3.0, 1000.0]))
+    test_masked_strip_kernel_against_a_numpy_model(levels, depth, frac, amp, bool(rng.integers(0, 2)))
