@@ -597,6 +597,34 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 	++st.q;
 }
 
+// In front of the loop: as many stores as a step of the loop issues, to plane zb (which the wave stores for good four steps later; stores of
+// a wave to one address keep their order).  Why: the compiler's `s_waitcnt vmcnt(N)` in front of the first use of a prefetched row counts
+// the YOUNGER operations that may stay in flight -- a step's output stores -- and at the loop's head it takes the smaller count of the two
+// ways in.  Coming from the prologue there were none, so every third step (the head of the three-phase loop) drained the previous step's
+// stores before it touched its rows: vmcnt(1), vmcnt(0) where the other two phases say vmcnt(3), vmcnt(2).  (41.3 -> 40.9 us per launch:
+// the stores' cost is the fabric's, not this wait.)
+template <class R, bool MK>
+__device__ __forceinline__ void head_stores4(const Strip4<R>& st, const Frz4& fz, const uint32_t (&roff)[R::NI])
+{
+#ifndef FX_S4_NOHEADSTORES
+	constexpr int RB = R::A ? 4 : 1;
+	const v4f zero = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+	for (int m = 0; m < R::NR; ++m) *reinterpret_cast<v4f*>(st.po_zb + opaque32q(roff[m + RB])) = zero;
+	if (MK) {
+		const ptrdiff_t mo_ = (st.po_zb - fz.outA) >> 4;
+#pragma unroll
+		for (int m = 0; m < R::NR; ++m) *reinterpret_cast<v4f*>(st.po_zb + fz.dB + opaque32q(roff[m + RB])) = zero;
+#pragma unroll
+		for (int m = 0; m < R::NR; ++m) {
+			const uint32_t o_ = opaque32q(roff[m + RB] >> 4);
+			fz.mA[mo_ + o_] = (uint8_t)0;
+			fz.mB[mo_ + o_] = (uint8_t)0;
+		}
+	}
+#endif
+}
+
 // the masked loop's set-up shared by both walks: the nibble bytes of the first plane in flight (q0), and of the plane before it (the
 // centre of the first sweep) where the walk starts inside the field
 template <class R, int NM_>
@@ -711,6 +739,7 @@ __device__ __forceinline__ void run4(const Geom& g, const float* __restrict__ p_
 		step4<R, 1, true, true, true, false, MK>(st, P1, P2, P3, NP, NB, NBn, Bk, roff, fz, MW, NM);
 		step4<R, 2, true, true, true, false, MK>(st, P1, P2, P3, NP, NB, NBn, Bk, roff, fz, MW, NM);
 	}
+	head_stores4<R, MK>(st, fz, roff);
 	for (;;) {
 		step4<R, 0, true, true, true, true, MK>(st, P1, P2, P3, NP, NB, NBn, Bk, roff, fz, MW, NM);
 		if (st.q > q_last) break;
@@ -959,6 +988,7 @@ __device__ __forceinline__ void run4r(const Geom& g, const float* __restrict__ p
 		step4r<R, 1, true, true, true, false, MK>(st, I, P1, P2, P3, NB, Bp, roff, fz, MW, NM);
 		step4r<R, 2, true, true, true, false, MK>(st, I, P1, P2, P3, NB, Bp, roff, fz, MW, NM);
 	}
+	head_stores4<R, MK>(st, fz, roff);
 	for (;;) {
 		step4r<R, 0, true, true, true, true, MK>(st, I, P1, P2, P3, NB, Bp, roff, fz, MW, NM);
 		if (st.q > q_last) break;
