@@ -216,6 +216,11 @@ template <class R> struct Strip4 {
 };
 
 #define FXQ_LDS(st, slot, r) (st).lds[(slot) + (r) * 64]
+// The plane behind the last one of the field is a copy of the last (clamped neighbour): once per field and level.  Written as
+// `if (top) copy; else relax;` the compiler turns it into relax + four v_cndmask per row on EVERY step (24 of an inner wave's 239 VALU
+// per z step); the relaxation now runs unconditionally (register and LDS operands only) and the copy sits behind a branch that an asm
+// statement keeps from being turned into selects again.
+#define FXQ_RARE_BRANCH asm volatile("; rare path")
 
 // Hand-over of level L (1..3).  The neighbours' edge rows of THEIR step q - 1 (plane q - 1 - L: the centre plane of this step's sweep
 // L + 1) come in, mine of this step (plane q - L) go out.  Order per level: read the neighbours' rows, make sure they were there
@@ -437,11 +442,7 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 		// arms of a branch are merged by the compiler into one store through a selected POINTER, which keeps those slots in scratch)
 		v4f T_[N1];
 		uint32_t m1_ = 0u;
-		if (q - 1 == st.Zg) {                                            // level-1 plane Zg := plane Zg-1
-#pragma unroll
-			for (int j = 0; j < N1; ++j) T_[j] = P1[CTR][j];
-			if (MK) m1_ = MW[0][CTR];
-		} else {
+		{
 			if (!LEAN) {
 				v4f C_[NI], F_[N1];                                       // all LDS rows first: one wave per SIMD cannot hide a ds_read next to its use
 #pragma unroll
@@ -483,10 +484,17 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 				if (MK && q - 1 >= st.zb && q - 1 < st.ze && (~(m1_ >> (4 * O1)) & OWN) != 0u) fz.rel |= 2u;
 			}
 		}
+		if (__builtin_expect(q - 1 == st.Zg, 0)) {                         // level-1 plane Zg := plane Zg-1
+			FXQ_RARE_BRANCH;
+#pragma unroll
+			for (int j = 0; j < N1; ++j) T_[j] = P1[CTR][j];
+			if (MK) m1_ = MW[0][CTR];
+		}
 #pragma unroll
 		for (int j = 0; j < N1; ++j) P1[NEW][j] = T_[j];
 		if (MK) MW[0][NEW] = m1_;
-		if (q - 1 == 0) {                                               // level-1 plane -1 := plane 0
+		if (__builtin_expect(q - 1 == 0, 0)) {                                               // level-1 plane -1 := plane 0
+			FXQ_RARE_BRANCH;
 #pragma unroll
 			for (int j = 0; j < N1; ++j) P1[CTR][j] = T_[j];
 			if (MK) MW[0][CTR] = m1_;
@@ -530,18 +538,19 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 	if (S2) {
 		v4f T_[N2];
 		uint32_t m2_ = 0u;
-		if (q - 2 == st.Zg) {
+		relax_level4<R, 1, N1, N2, MK>(st, P1[OLD], P1[CTR], P1[NEW], B2_, HU1, HD1, T_, MK ? MW[0][CTR] : 0u, m2_);
+		if (MK && q - 2 >= st.zb && q - 2 < st.ze && (~(m2_ >> (4 * O2)) & OWN) != 0u) fz.rel |= 4u;
+		if (__builtin_expect(q - 2 == st.Zg, 0)) {
+			FXQ_RARE_BRANCH;
 #pragma unroll
 			for (int k = 0; k < N2; ++k) T_[k] = P2[CTR][k];
 			if (MK) m2_ = MW[1][CTR];
-		} else {
-			relax_level4<R, 1, N1, N2, MK>(st, P1[OLD], P1[CTR], P1[NEW], B2_, HU1, HD1, T_, MK ? MW[0][CTR] : 0u, m2_);
-			if (MK && q - 2 >= st.zb && q - 2 < st.ze && (~(m2_ >> (4 * O2)) & OWN) != 0u) fz.rel |= 4u;
 		}
 #pragma unroll
 		for (int k = 0; k < N2; ++k) P2[NEW][k] = T_[k];
 		if (MK) MW[1][NEW] = m2_;
-		if (q - 2 == 0) {                                               // level-2 plane -1 := plane 0
+		if (__builtin_expect(q - 2 == 0, 0)) {                                               // level-2 plane -1 := plane 0
+			FXQ_RARE_BRANCH;
 #pragma unroll
 			for (int k = 0; k < N2; ++k) P2[CTR][k] = T_[k];
 			if (MK) MW[1][CTR] = m2_;
@@ -557,18 +566,19 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 	if (S3) {
 		v4f T_[N3];
 		uint32_t m3_ = 0u;
-		if (q - 3 == st.Zg) {
+		relax_level4<R, 2, N2, N3, MK>(st, P2[OLD], P2[CTR], P2[NEW], B3_, HU2, HD2, T_, MK ? MW[1][CTR] : 0u, m3_);
+		if (MK && q - 3 >= st.zb && q - 3 < st.ze && (~(m3_ >> (4 * O3)) & OWN) != 0u) fz.rel |= 8u;
+		if (__builtin_expect(q - 3 == st.Zg, 0)) {
+			FXQ_RARE_BRANCH;
 #pragma unroll
 			for (int m = 0; m < N3; ++m) T_[m] = P3[CTR][m];
 			if (MK) m3_ = MW[2][CTR];
-		} else {
-			relax_level4<R, 2, N2, N3, MK>(st, P2[OLD], P2[CTR], P2[NEW], B3_, HU2, HD2, T_, MK ? MW[1][CTR] : 0u, m3_);
-			if (MK && q - 3 >= st.zb && q - 3 < st.ze && (~(m3_ >> (4 * O3)) & OWN) != 0u) fz.rel |= 8u;
 		}
 #pragma unroll
 		for (int m = 0; m < N3; ++m) P3[NEW][m] = T_[m];
 		if (MK) MW[2][NEW] = m3_;
-		if (q - 3 == 0) {                                               // level-3 plane -1 := plane 0
+		if (__builtin_expect(q - 3 == 0, 0)) {                                               // level-3 plane -1 := plane 0
+			FXQ_RARE_BRANCH;
 #pragma unroll
 			for (int m = 0; m < N3; ++m) P3[CTR][m] = T_[m];
 			if (MK) MW[2][CTR] = m3_;
@@ -780,18 +790,15 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 	M1.fu = M1.fd = M2.fu = M2.fd = M3.fu = M3.fd = INT_MIN; M1.hu = M1.hd = M2.hu = M2.hd = M3.hu = M3.hd = zero;
 	if (S1) mail_fetch4<R, 1>(st, M1);
 	// ---- sweep 1: level-1 plane q-1 from input planes q-2 (OLD), q-1 (CTR), q (NEW: arrived) and b[q-1] (NB) ----
-	if (q == 0) {                                                       // input plane -1 := plane 0, once
+	if (__builtin_expect(q == 0, 0)) {                                  // input plane -1 := plane 0, once
+		FXQ_RARE_BRANCH;
 #pragma unroll
 		for (int i = 0; i < NI; ++i) I[CTR][i] = I[NEW][i];
 	}
 	if (S1) {
 		v4f T_[NR];
 		uint32_t m1_ = 0u;
-		if (q - 1 == st.Zg) {
-#pragma unroll
-			for (int j = 0; j < NR; ++j) T_[j] = P1[CTR][j];
-			if (MK) m1_ = MW[0][CTR];
-		} else {
+		{
 #pragma unroll
 			for (int jj = 0; jj < NR; ++jj) {
 #ifdef FX_M_PLAIN
@@ -815,10 +822,17 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 #endif
 			if (MK && q - 1 >= st.zb && q - 1 < st.ze && (~m1_ & OWN) != 0u) fz.rel |= 2u;
 		}
+		if (__builtin_expect(q - 1 == st.Zg, 0)) {
+			FXQ_RARE_BRANCH;
+#pragma unroll
+			for (int j = 0; j < NR; ++j) T_[j] = P1[CTR][j];
+			if (MK) m1_ = MW[0][CTR];
+		}
 #pragma unroll
 		for (int j = 0; j < NR; ++j) P1[NEW][j] = T_[j];
 		if (MK) MW[0][NEW] = m1_;
-		if (q - 1 == 0) {
+		if (__builtin_expect(q - 1 == 0, 0)) {
+			FXQ_RARE_BRANCH;
 #pragma unroll
 			for (int j = 0; j < NR; ++j) P1[CTR][j] = T_[j];
 			if (MK) MW[0][CTR] = m1_;
@@ -864,18 +878,19 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 	if (S2) {
 		v4f T_[NR];
 		uint32_t m2_ = 0u;
-		if (q - 2 == st.Zg) {
+		relax_level4<R, 1, NR, NR, MK>(st, P1[OLD], P1[CTR], P1[NEW], B2_, HU1, HD1, T_, MK ? MW[0][CTR] : 0u, m2_);
+		if (MK && q - 2 >= st.zb && q - 2 < st.ze && (~m2_ & OWN) != 0u) fz.rel |= 4u;
+		if (__builtin_expect(q - 2 == st.Zg, 0)) {
+			FXQ_RARE_BRANCH;
 #pragma unroll
 			for (int k = 0; k < NR; ++k) T_[k] = P2[CTR][k];
 			if (MK) m2_ = MW[1][CTR];
-		} else {
-			relax_level4<R, 1, NR, NR, MK>(st, P1[OLD], P1[CTR], P1[NEW], B2_, HU1, HD1, T_, MK ? MW[0][CTR] : 0u, m2_);
-			if (MK && q - 2 >= st.zb && q - 2 < st.ze && (~m2_ & OWN) != 0u) fz.rel |= 4u;
 		}
 #pragma unroll
 		for (int k = 0; k < NR; ++k) P2[NEW][k] = T_[k];
 		if (MK) MW[1][NEW] = m2_;
-		if (q - 2 == 0) {
+		if (__builtin_expect(q - 2 == 0, 0)) {
+			FXQ_RARE_BRANCH;
 #pragma unroll
 			for (int k = 0; k < NR; ++k) P2[CTR][k] = T_[k];
 			if (MK) MW[1][CTR] = m2_;
@@ -888,18 +903,19 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 	if (S3) {
 		v4f T_[NR];
 		uint32_t m3_ = 0u;
-		if (q - 3 == st.Zg) {
+		relax_level4<R, 2, NR, NR, MK>(st, P2[OLD], P2[CTR], P2[NEW], B3_, HU2, HD2, T_, MK ? MW[1][CTR] : 0u, m3_);
+		if (MK && q - 3 >= st.zb && q - 3 < st.ze && (~m3_ & OWN) != 0u) fz.rel |= 8u;
+		if (__builtin_expect(q - 3 == st.Zg, 0)) {
+			FXQ_RARE_BRANCH;
 #pragma unroll
 			for (int m = 0; m < NR; ++m) T_[m] = P3[CTR][m];
 			if (MK) m3_ = MW[2][CTR];
-		} else {
-			relax_level4<R, 2, NR, NR, MK>(st, P2[OLD], P2[CTR], P2[NEW], B3_, HU2, HD2, T_, MK ? MW[1][CTR] : 0u, m3_);
-			if (MK && q - 3 >= st.zb && q - 3 < st.ze && (~m3_ & OWN) != 0u) fz.rel |= 8u;
 		}
 #pragma unroll
 		for (int m = 0; m < NR; ++m) P3[NEW][m] = T_[m];
 		if (MK) MW[2][NEW] = m3_;
-		if (q - 3 == 0) {
+		if (__builtin_expect(q - 3 == 0, 0)) {
+			FXQ_RARE_BRANCH;
 #pragma unroll
 			for (int m = 0; m < NR; ++m) P3[CTR][m] = T_[m];
 			if (MK) MW[2][CTR] = m3_;
