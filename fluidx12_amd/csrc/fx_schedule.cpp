@@ -409,8 +409,8 @@ static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 		// through a masked strip pipeline (see below), decided HERE because the dense sweep itself depends on it -- a strip launch reads one
 		// copy of level 1 and writes both buffers, so the dense sweep in front of it leaves its second copy (and second mask copy) away.
 		// FREEZE_DENSE_LEVELS: how many levels (0, 3, 4, 6, 7, 8 ...); default -1 = by what the dense sweeps of the last steps left relaxing
-		// -- the count k_count_marks put into a host-visible word behind an earlier solve's dense sweep: one strip launch once half of the
-		// tiles relax.  Young plumes (a fifth of the tiles) stay on the tile launches, where a masked launch would cost 0.07 ms for nothing.
+		// -- the count k_count_marks put into a host-visible word behind an earlier solve's dense sweep (thresholds below).  Young plumes
+		// stay on the tile launches, where a masked launch would cost 0.08 ms for nothing.
 		if (!multi && jacobi_freeze_strip_supported(m->g) && m->fz_mask[2]) {
 			strip_want = FX_KNOB_INT("FREEZE_DENSE_LEVELS", -1);
 			strip_four = FX_KNOB_INT("FREEZE_STRIP4", 1) && jacobi_freeze_strip4_supported(m->g);
@@ -487,8 +487,8 @@ static int jacobi_freeze(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, u
 			DeviceGuard dg(m->device);
 			const int lv = four && want >= 4 && left > 4 ? 4 : 3;
 			flag_tag = r.w.gen | ((uint32_t)(k + 1) << 24);
-			if (lv == 4) FX_HIP(launch_freeze_strip4(r.v, r.a, m->b, r.d, r.src, r.ma, r.md, r.mx, r.w.tile_mark, flag_tag, r.stat, r.stat_hi, level, CS(m, s)));
-			else FX_HIP(launch_freeze_strip3(r.v, r.a, m->b, r.d, r.src, r.ma, r.md, r.mx, r.w.tile_mark, flag_tag, r.stat, r.stat_hi, level, CS(m, s)));
+			if (lv == 4) { FX_HIP(launch_freeze_strip4(r.v, r.a, m->b, r.d, r.src, r.ma, r.md, r.mx, r.w.tile_mark, flag_tag, r.stat, r.stat_hi, level, CS(m, s))); }
+			else { FX_HIP(launch_freeze_strip3(r.v, r.a, m->b, r.d, r.src, r.ma, r.md, r.mx, r.w.tile_mark, flag_tag, r.stat, r.stat_hi, level, CS(m, s))); }
 			if (mk[0]) { mk[0]->launches += 1; mk[0]->sweeps += (uint64_t)lv; }
 			m->acc.freeze_strip_launches += 1;                                  // (counted like the solves: with or without the timing marks)
 			float* na = r.d; r.d = r.src; r.src = r.a; r.a = na;                  // level + lv now sits in (a, d); the buffer it was read from is the spare
