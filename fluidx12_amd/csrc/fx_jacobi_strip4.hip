@@ -90,6 +90,17 @@ __device__ __forceinline__ v4f relax4q(v4f c, v4f U, v4f D, v4f F, v4f Bk, v4f b
 }
 
 __device__ __forceinline__ uint32_t opaque32q(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
+// an output row.  FX_S4_SC1: as a write-through store (`sc0 sc1`: the line leaves the XCD's L2 instead of staying there dirty) --
+// a volatile store through a global-address-space pointer is how the compiler is told (it keeps counting the store in its vmcnt waits)
+typedef __attribute__((address_space(1))) v4f g_v4f;
+__device__ __forceinline__ void store_row4(char* base, uint32_t off, v4f v)
+{
+#ifdef FX_S4_SC1
+	*(volatile g_v4f*)(g_v4f*)(base + off) = v;
+#else
+	*reinterpret_cast<v4f*>(base + off) = v;
+#endif
+}
 
 // ---- the reference's own loop (k_freeze_strip4o; CSPoisson.hlsli:8-26: a cell leaves the loop for good once a sweep changes it by less
 // than 1e-3): relax4m of fx_jacobi_stripm.hip on native vectors -- relax4_pairs' sum, kept for the freeze test; nib = the quad's frozen
@@ -332,7 +343,7 @@ __device__ __forceinline__ void frz_out4(const Strip4<R>& st, Frz4& fz, char* ds
 	const ptrdiff_t mo_ = (dst_ - fz.outA) >> 4;                         // a plane of nibble bytes is a sixteenth of a pressure plane
 #ifndef FX_M_ONEP
 #pragma unroll
-	for (int m = 0; m < NR; ++m) *reinterpret_cast<v4f*>(dst_ + fz.dB + opaque32q(roff[m + RB])) = X_[m];
+	for (int m = 0; m < NR; ++m) store_row4(dst_ + fz.dB, opaque32q(roff[m + RB]), X_[m]);
 #endif
 #ifdef FX_M_NOBYTES
 	if (st.q < -1000)
@@ -600,7 +611,7 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 		if (q < -1000)                                                   // (experiment: the arithmetic stays, the stores never execute)
 #endif
 #pragma unroll
-		for (int m = 0; m < NR; ++m) *reinterpret_cast<v4f*>(dst_ + opaque32q(roff[m + (R::A ? 4 : 1)])) = X_[m];
+		for (int m = 0; m < NR; ++m) store_row4(dst_, opaque32q(roff[m + (R::A ? 4 : 1)]), X_[m]);
 		if (MK) frz_out4<R>(st, fz, dst_, X_, m4_, roff);
 	}
 	st.po += st.plane_bytes;
@@ -620,11 +631,11 @@ __device__ __forceinline__ void head_stores4(const Strip4<R>& st, const Frz4& fz
 	constexpr int RB = R::A ? 4 : 1;
 	const v4f zero = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
-	for (int m = 0; m < R::NR; ++m) *reinterpret_cast<v4f*>(st.po_zb + opaque32q(roff[m + RB])) = zero;
+	for (int m = 0; m < R::NR; ++m) store_row4(st.po_zb, opaque32q(roff[m + RB]), zero);
 	if (MK) {
 		const ptrdiff_t mo_ = (st.po_zb - fz.outA) >> 4;
 #pragma unroll
-		for (int m = 0; m < R::NR; ++m) *reinterpret_cast<v4f*>(st.po_zb + fz.dB + opaque32q(roff[m + RB])) = zero;
+		for (int m = 0; m < R::NR; ++m) store_row4(st.po_zb + fz.dB, opaque32q(roff[m + RB]), zero);
 #pragma unroll
 		for (int m = 0; m < R::NR; ++m) {
 			const uint32_t o_ = opaque32q(roff[m + RB] >> 4);
@@ -933,7 +944,7 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 		if (q < -1000)
 #endif
 #pragma unroll
-		for (int m = 0; m < NR; ++m) *reinterpret_cast<v4f*>(dst_ + opaque32q(roff[m + 1])) = X_[m];
+		for (int m = 0; m < NR; ++m) store_row4(dst_, opaque32q(roff[m + 1]), X_[m]);
 		if (MK) frz_out4<R>(st, fz, dst_, X_, m4_, roff);
 	}
 	st.po += st.plane_bytes;
