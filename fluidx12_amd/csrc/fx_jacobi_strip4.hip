@@ -684,7 +684,10 @@ __device__ __forceinline__ void run4(const Geom& g, const float* __restrict__ p_
 	Frz4 fz;
 	uint32_t MW[3][3], NM[R::N1];
 #ifndef FX_O_NOPRIO
-	if (R::NW != 4) __builtin_amdgcn_s_setprio(2);                      // the octet's outer waves have the longest z step: they go first on their SIMD
+#ifndef FX_O_PRIO
+#define FX_O_PRIO 2                                                  // (1, 2, 3: 40.3-41.4 us per launch, alike; none, -DFX_O_NOPRIO: 43.3-44.2)
+#endif
+	if (R::NW != 4) __builtin_amdgcn_s_setprio(FX_O_PRIO);              // the octet's outer waves have the longest z step: they go first on their SIMD
 #endif
 	v4f P1[3][R::N1], P2[3][R::N2], P3[3][R::N3], NP[R::NI], NB[R::N1], NBn[R::N1], Bk[R::N2];
 	uint32_t roff[R::NI];
