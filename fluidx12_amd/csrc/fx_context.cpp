@@ -329,6 +329,14 @@ int fx_synchronize(fx_ctx* ctx)
 	for (fx_ctx* c : M) {
 		DeviceGuard dg(c->device);
 		if (const int w = wait_for_device(c)) return w;
+		// a strip kernel whose LDS hand-over timed out has left a pressure field that is not the solver's: loud, never silent
+		unsigned f3 = 0, f4 = 0;
+		if (strip3_fault_take(&f3) != hipSuccess || strip4_fault_take(&f4) != hipSuccess) return FX_E_DEVICE;
+		if (f3 | f4) {
+			c->last_error = f4 ? "k_jacobi_strip4o / k_freeze_strip4o: an LDS hand-over wait ran out (pressure field invalid)"
+			                   : "k_jacobi_strip3c / k_jacobi_strip3h: an LDS hand-over wait ran out (pressure field invalid)";
+			return FX_E_DEVICE;
+		}
 		const int st = halo_fault_status(c);
 		if (st == FX_E_DEVICE) return st;
 		if (st == FX_E_HALO) {                 // reported here, and acknowledged: the next step starts clean

@@ -127,6 +127,10 @@ hipError_t launch_jacobi2d(const Geom& g, const float* p_in, const float* b, flo
 int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp);
 bool jacobi_prefers_three(const Geom& g, int requested, int nzp);
 bool jacobi_prefers_four(const Geom& g, int requested, int nzp);
+// The LDS hand-overs of the strip kernels wait in bounded loops; a wait that runs out raises a device word (per translation unit) instead
+// of hanging the device or continuing silently.  Read-and-clear on the current device; fx_synchronize turns a raised word into FX_E_DEVICE.
+hipError_t strip3_fault_take(unsigned* out);
+hipError_t strip4_fault_take(unsigned* out);
 // rec (optional, slab ranks): the step record of launch_face_need is produced by this launch when it can be (fp32 3-D kernel
 // over exactly the owned planes); *rec_done tells whether it was
 hipError_t launch_project(const Geom& g, const SimParams& sp, int half_store, const void* vel_in, const float* p,

@@ -119,9 +119,26 @@ __device__ __forceinline__ void lds_post(uint32_t lds_byte_addr, int v)
 {
 	asm volatile("ds_write_b32 %0, %1" :: "v"(lds_byte_addr), "v"(v) : "memory");
 }
+// Every hand-over wait of this file is BOUNDED like k_jacobi_strip4o's (a partner is a z step away, ~2 us; 65 536 polls are ~10 ms) and
+// LOUD when it runs out: it raises this word, which fx_synchronize reads behind the device (strip3_fault_take) and returns as
+// FX_E_DEVICE instead of a hung device or a silently wrong pressure field (these loops span unbounded).
+__device__ unsigned g_strip3_fault;
+constexpr int kWaitSpins3 = 1 << 16;
+__device__ __noinline__ void strip3_raise_fault() { atomicOr(&g_strip3_fault, 1u); }
 __device__ __forceinline__ void lds_wait_ge(uint32_t lds_byte_addr, int v)
 {
-	while (lds_peek(lds_byte_addr) < v) __builtin_amdgcn_s_sleep(1);
+	for (int spins = 0; lds_peek(lds_byte_addr) < v; ++spins) {
+		if (__builtin_expect(spins > kWaitSpins3, 0)) { strip3_raise_fault(); break; }
+		__builtin_amdgcn_s_sleep(1);
+	}
+}
+// ... and the `volatile` form k_jacobi_strip3h keeps (see above)
+__device__ __forceinline__ void lds_wait_ge_volatile(const int* flag, int v)
+{
+	for (int spins = 0; *reinterpret_cast<const volatile int*>(flag) < v; ++spins) {
+		if (__builtin_expect(spins > kWaitSpins3, 0)) { strip3_raise_fault(); break; }
+		__builtin_amdgcn_s_sleep(1);
+	}
 }
 
 // counter and row in ONE LDS round trip: both reads are issued back to back (LDS operations of a wave execute in order, and the
@@ -132,9 +149,10 @@ __device__ __forceinline__ float4 lds_wait_read(uint32_t flag_byte_addr, int nee
 {
 	int f;
 	fx_q4 d;
-	for (;;) {
+	for (int spins = 0;; ++spins) {
 		asm volatile("ds_read_b32 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f), "=&v"(d) : "v"(flag_byte_addr), "v"(row_byte_addr) : "memory");
 		if (f >= need) break;
+		if (__builtin_expect(spins > kWaitSpins3, 0)) { strip3_raise_fault(); break; }
 		__builtin_amdgcn_s_sleep(1);
 	}
 	return make_float4(d.x, d.y, d.z, d.w);
@@ -308,7 +326,7 @@ __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 
 	   sees my counter at q knows I have read what it wrote two steps ago into the slot it reuses; a wave may run a step ahead */ \
 	float e1_[R3 + 4]; \
 	if (S1) { \
-		while (*reinterpret_cast<volatile int*>(xflag + (wave ^ 1)) < q - 1) __builtin_amdgcn_s_sleep(1); \
+		lds_wait_ge_volatile(xflag + (wave ^ 1), q - 1); \
 		asm volatile("" ::: "memory"); \
 		{ \
 			const float* xr_ = xbuf + (((q - 1) & 1) * WPG + (wave ^ 1)) * 16; \
@@ -362,7 +380,7 @@ __device__ __forceinline__ float4 relax4_h(float4 c, float4 U, float4 D, float4 
 	/* hand-over 2: the second-sweep cells (partner's plane q-3 for my sweep 3; mine of plane q-2), same order, their own counter */ \
 	float e2_[R3 + 2]; \
 	if (S2) { \
-		while (*reinterpret_cast<volatile int*>(xflag + WPG + (wave ^ 1)) < q - 1) __builtin_amdgcn_s_sleep(1); \
+		lds_wait_ge_volatile(xflag + WPG + (wave ^ 1), q - 1); \
 		asm volatile("" ::: "memory"); \
 		{ \
 			const float* xr_ = xbuf + (((q - 1) & 1) * WPG + (wave ^ 1)) * 16 + 8; \
@@ -686,6 +704,16 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip3c(const Geom g, const f
 // launch against k_jacobi_strip3c's 43.0 -- was measured in round 2 (profiles/archive/r03c_strip3z.txt) and removed in round 3.)
 
 }  // namespace
+
+// read-and-clear of the hand-over fault word on the current device (fx_synchronize, behind the device)
+hipError_t strip3_fault_take(unsigned* out)
+{
+	unsigned v = 0;
+	hipError_t e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_strip3_fault), sizeof v);
+	if (e == hipSuccess && v) { const unsigned zero = 0; e = hipMemcpyToSymbol(HIP_SYMBOL(g_strip3_fault), &zero, sizeof zero); }
+	*out = v;
+	return e;
+}
 
 bool jacobi_strip3_supported(const Geom& g)
 {

@@ -197,6 +197,13 @@ struct Frz4 {
 	uint32_t act;                       // bit m: own row m has a cell that still relaxes after the last level, in the current group of 8 planes
 };
 
+// A hand-over wait is BOUNDED (a neighbour is a z step away, ~2 us; 65 536 polls are ~10 ms: a protocol error must not hang the device)
+// and a wait that runs out is LOUD: it raises this word, which fx_synchronize reads behind the device (strip4_fault_take) and returns as
+// FX_E_DEVICE -- the pressure field of that launch is not to be trusted (ADVICE / VERDICT round 5: it used to continue silently).
+__device__ unsigned g_strip4_fault;
+constexpr int kWaitSpins4 = 1 << 16;
+__device__ __noinline__ void strip4_raise_fault() { atomicOr(&g_strip4_fault, 1u); }
+
 // counter and row in ONE LDS round trip (see k_jacobi_strip3c): a counter that is high enough vouches for the row read behind it
 __device__ __forceinline__ v4f lds_wait_read4(uint32_t flag_byte_addr, int need, uint32_t row_byte_addr)
 {
@@ -204,7 +211,8 @@ __device__ __forceinline__ v4f lds_wait_read4(uint32_t flag_byte_addr, int need,
 	v4f d;
 	for (int spins = 0;; ++spins) {
 		asm volatile("ds_read_b32 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f), "=&v"(d) : "v"(flag_byte_addr), "v"(row_byte_addr) : "memory");
-		if (f >= need || spins > (1 << 16)) break;                       // (bounded: a neighbour is a z step away, ~2 us; a protocol error must not hang the device)
+		if (f >= need) break;
+		if (__builtin_expect(spins > kWaitSpins4, 0)) { strip4_raise_fault(); break; }
 		__builtin_amdgcn_s_sleep(1);
 	}
 	return d;
@@ -1047,6 +1055,23 @@ constexpr int O_XROWS = 2 * 7 * 3 * 2;
 #endif
 static_assert((O_LDS_ROWS + O_XROWS) * 1024 + 128 <= 160 * 1024, "the octet's windows must fit the CU's LDS");
 
+// Where band `grp` of `ngroups` starts.  Bands lie top-down; the last one is shifted up to end at the last row (the rows it shares with its
+// neighbour are computed twice from the same inputs by the same arithmetic: both workgroups store the same bits).  An outer wave knows
+// a wall only as ITS OWN row (wall_top / wall_bot), and the three level-1 halo rows it recomputes beyond that row must be rows of the
+// field (the input row behind the last of them may be the clamped copy: that IS the wall's neighbour) -- a level-l row computed from
+// clamped loads behind the wall is not what the wall row's missing neighbour stands for.  So a band whose lower halo would reach beyond the
+// last row (the second-to-last band when Y % 14 is 1 or 2: Y = 128, 240, 30 ...) is shifted up too, until its halo ends at the last row;
+// the upper halo of a shifted band lies inside from Y = 17 on (octet_rows_supported).
+__device__ __host__ __forceinline__ int octet_band_y(int grp, int ngroups, int Y)
+{
+	if (grp == ngroups - 1) return Y - O_BAND;
+	const int yg = grp * O_BAND;
+	return yg + O_BAND + 3 > Y ? Y - O_BAND - 3 : yg;
+}
+// Y = 14: one band between both walls; from 17 on every shifted band keeps its three level-1 halo rows inside (15, 16: the last band's
+// upper halo would cross the first row)
+__host__ inline bool octet_rows_supported(int Y) { return Y == O_BAND || Y >= O_BAND + 3; }
+
 __global__ __launch_bounds__(512, 2) void k_jacobi_strip4o(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
 	float* __restrict__ p_out, int z_begin, int z_end, int zchunk, int ngroups, int nchunks, int remap)
 {
@@ -1067,7 +1092,7 @@ __global__ __launch_bounds__(512, 2) void k_jacobi_strip4o(const Geom g, const f
 	if (threadIdx.x < 24) xflag[threadIdx.x] = fill ? qs + 2 * ((int)threadIdx.x / 8 + 1) - 1 : qs - 1;
 	for (int i = (int)threadIdx.x; i < O_XROWS * 64; i += 512) xbuf[i] = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
 	__syncthreads();
-	const int yg = min(grp * O_BAND, g.Y - O_BAND);                     // (the last band is shifted up to end at the last row)
+	const int yg = octet_band_y(grp, ngroups, g.Y);                     // (the last band is shifted up to end at the last row)
 	const FrzArgs none{};
 #ifdef FX_O_ONLYMID
 	run4r<OctMid>(g, p_in, b, p_out, zb, ze, yg + 2 * wave, wave, lane, xbuf, xflag, none); return;   // (timing experiment: eight register-window waves in a ring; results are wrong)
@@ -1102,7 +1127,7 @@ __global__ __launch_bounds__(512, 2) void k_freeze_strip4o(const Geom g, const f
 	if (threadIdx.x < 24) xflag[threadIdx.x] = fill ? qs + 2 * ((int)threadIdx.x / 8 + 1) - 1 : qs - 1;
 	for (int i = (int)threadIdx.x; i < O_XROWS * 64; i += 512) xbuf[i] = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
 	__syncthreads();
-	const int yg = min(grp * O_BAND, g.Y - O_BAND);
+	const int yg = octet_band_y(grp, ngroups, g.Y);
 	if (wave == 0) run4<OctTop, true>(g, p_in, b, p_outA, zb, ze, yg, wave, lane, lds_all, xbuf, xflag, fa);
 	else if (wave == 7) run4<OctBot, true>(g, p_in, b, p_outA, zb, ze, yg + O_BAND - 1, wave, lane, lds_all + OctTop::LDS_ROWS * 64, xbuf, xflag, fa);
 	else run4r<OctMid, true>(g, p_in, b, p_outA, zb, ze, yg + 2 * wave - 1, wave, lane, xbuf, xflag, fa);
@@ -1142,11 +1167,22 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip4q(const Geom g, const f
 
 }  // namespace
 
+// read-and-clear of the hand-over fault word on the current device (fx_synchronize, behind the device)
+hipError_t strip4_fault_take(unsigned* out)
+{
+	unsigned v = 0;
+	hipError_t e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_strip4_fault), sizeof v);
+	if (e == hipSuccess && v) { const unsigned zero = 0; e = hipMemcpyToSymbol(HIP_SYMBOL(g_strip4_fault), &zero, sizeof zero); }
+	*out = v;
+	return e;
+}
+
 bool jacobi_strip4_supported(const Geom& g)
 {
-	// the octet takes any Y >= 14 (bands of 14 rows, the last one shifted); the quad (STRIP4_OCTET=0) whole bands of 16
+	// the octet takes Y = 14 and any Y >= 17 (bands of 14 rows, shifted where they or their halo would cross the last row: octet_band_y);
+	// the quad (STRIP4_OCTET=0) whole bands of 16
 	if (g.Zg <= 1 || g.X != 256) return false;
-	return FX_KNOB_INT("STRIP4_OCTET", 1) ? g.Y >= O_BAND : ((g.Y & 15) == 0 && g.Y >= 16);
+	return FX_KNOB_INT("STRIP4_OCTET", 1) ? octet_rows_supported(g.Y) : ((g.Y & 15) == 0 && g.Y >= 16);
 }
 
 hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b, float* p_out, int z_begin, int z_end, hipStream_t s)
@@ -1162,7 +1198,7 @@ hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b
 	if (zchunk < 8) zchunk = 8;
 	if (zchunk > nzp) zchunk = nzp;
 	nchunks = (nzp + zchunk - 1) / zchunk;
-	if (FX_KNOB_INT("STRIP4_OCTET", 1) && g.Y >= O_BAND) {     // the octet (two waves per SIMD) is the default; 0 = the quad
+	if (FX_KNOB_INT("STRIP4_OCTET", 1) && octet_rows_supported(g.Y)) {     // the octet (two waves per SIMD) is the default; 0 = the quad
 		const int bands = (g.Y + O_BAND - 1) / O_BAND;                  // 19 bands of 14 rows at Y = 256 (the last one shifted)
 		int nch = 256 / bands;                                          // one workgroup of eight waves per CU
 		if (nch < 1) nch = 1;
@@ -1178,7 +1214,7 @@ hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b
 
 bool jacobi_freeze_strip4_supported(const Geom& g)
 {
-	return g.nz == g.Zg && g.H == 0 && g.X == 256 && g.Y >= O_BAND && g.Zg >= 8 && (uint64_t)g.X * g.Y * (uint64_t)g.Zg < (1u << 30);
+	return g.nz == g.Zg && g.H == 0 && g.X == 256 && octet_rows_supported(g.Y) && g.Zg >= 8 && (uint64_t)g.X * g.Y * (uint64_t)g.Zg < (1u << 30);
 }
 
 // levels level_in + 1 .. level_in + 4 for every cell: p_in / m_in -> p_outA = p_outB, m_outA = m_outB; tiles that still relax get `tag`

@@ -95,7 +95,7 @@ def test_jacobi_sweep_counts(iters):
 @pytest.mark.parametrize("dims", [(256, 256, 200), (512, 512, 100), (256, 256, 193), (256, 256, 257), (512, 512, 97), (512, 512, 131)])
 def test_default_schedule_of_large_grids_is_bit_identical(dims):
     """grids large enough for the multi-sweep strip kernels: X = 512 runs N sweeps as threes + twos (+ a single): 4 = 2 + 2, 5 = 3 + 2,
-    7 = 3 + 2 + 2, ...; X = 256 as fours (k_jacobi_strip4q) with remainders 5 = 3 + 2, 6 = 3 + 3, 7 = 4 + 3; every count equals N launches
+    7 = 3 + 2 + 2, ...; X = 256 as fours (k_jacobi_strip4o) with remainders 5 = 3 + 2, 6 = 3 + 3, 7 = 4 + 3; every count equals N launches
     of one sweep bit for bit"""
     X, Y, Z = dims
     rng = np.random.default_rng(31)
@@ -210,6 +210,31 @@ def test_x256_four_sweeps_at_odd_depths_bit_exact(depth, kernel, knob):
     assert f.timing_read(True).jacobi_launches == 2
     q, _ = orc.jacobi(p, b, 8)
     assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
+
+
+@pytest.mark.parametrize("rows", [14, 15, 16, 17, 18, 19, 27, 28, 29, 30, 31, 44, 45, 58, 100, 128, 240, 254])
+def test_x256_four_sweeps_on_rows_that_do_not_tile_the_bands_bit_exact(rows):
+    """the octet's bands of 14 rows on row counts they do not tile.  Y % 14 = 1 or 2 (29, 30, 44, 58, 128, 240): the lower halo of the
+    second-to-last band would reach beyond the last row -- that band is shifted up like the last one (octet_band_y; round 5 computed
+    level-l rows behind the wall from clamped loads and let two workgroups store different bits to one address: ADVICE round 5).
+    Y = 15, 16 fit no placement (the last band's upper halo would cross the first row): jacobi_fuse = 4 is refused there and the default
+    schedule runs other kernels.  == oracle bit for bit, twice (a race between the two writers of a shared row would not repeat)"""
+    depth = 21
+    dims = (256, rows, depth)
+    _, _, p = rand_state(*dims, 51)
+    b = np.random.default_rng(52).uniform(-1, 1, (depth, rows, 256)).astype(f32)
+    q, _ = orc.jacobi(p, b, 8)
+    four = rows == 14 or rows >= 17
+    f = make(dims, jacobi_iters=8, jacobi_fuse=4 if four else 0)
+    for _ in range(2):
+        f.upload(fx.FIELD_PRESSURE, p)
+        f.upload(fx.FIELD_DIVERGENCE, b)
+        f.timing_enable(True); f.timing_read(True)
+        f.Jacobi(8)
+        f.Synchronize()
+        if four:
+            assert f.timing_read(True).jacobi_launches == 2
+        assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
 
 
 @pytest.mark.parametrize("kernel", ["octet", "quad"])
@@ -429,7 +454,7 @@ def test_x256_full_step_against_oracle(storage, address):
     """The headline grid itself (BASELINE configs[2], and configs[4] with fp16 storage): one whole step at 256^3 from a DEVELOPED state
     -- 48 steps of the plume plus a patch of fast random flow, so that k_advect_lds serves lanes from its LDS tile and lanes through its
     gather path -- stage by stage against the oracle on the same inputs: advection (k_advect_lds), divergence, 40 sweeps in the default
-    schedule (10 x k_jacobi_strip4q), projection; then fx_simulate as a whole against the staged run."""
+    schedule (10 x k_jacobi_strip4o, the octet), projection; then fx_simulate as a whole against the staged run."""
     dims = (256, 256, 256)
     X, Y, Z = dims
     half = storage == "fp16"
@@ -465,7 +490,7 @@ def test_x256_full_step_against_oracle(storage, address):
     f.Synchronize()
     t = f.timing_read(True)
     f.timing_enable(False)
-    assert t.jacobi_sweeps == 40 and t.jacobi_launches == 10 and t.jacobi_main_sweeps == 40      # 10 x 4 (k_jacobi_strip4q)
+    assert t.jacobi_sweeps == 40 and t.jacobi_launches == 10 and t.jacobi_main_sweeps == 40      # 10 x 4 (k_jacobi_strip4o)
     q, _ = orc.jacobi(p, b, 40)
     assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
     f.Project()

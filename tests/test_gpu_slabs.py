@@ -175,7 +175,7 @@ def test_uneven_slabs_and_fp16():
 @pytest.mark.parametrize("overlap", [1, 2])
 @pytest.mark.parametrize("dims", [(256, 256, 400), (512, 512, 260)])
 def test_thick_slabs_take_the_three_sweep_kernel(dims, overlap):
-    """slabs of >= 12.6 M cells at X = 256 run their serial rounds as 4 + 4 sweeps (k_jacobi_strip4q), slabs of >= 25 M at X = 512 as
+    """slabs of >= 12.6 M cells at X = 256 run their serial rounds as 4 + 4 sweeps (k_jacobi_strip4o), slabs of >= 25 M at X = 512 as
     3 + 3 + 2 (k_jacobi_strip3h), on the shrinking trapezoid ranges, halo planes included: bit-identical to one sweep per launch on the
     single domain"""
     ref = run_single(dims, 2, jacobi_iters=19, jacobi_fuse=1)
