@@ -229,7 +229,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=32)         # 32 warm-up + 100 timed steps
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5],
                     help="BASELINE.json config (1-based as listed there): 2 = 128^3/40, 3 = 256^3/40 (the default workload), "
                          "4 = 512^3/80 sweeps (on 8 ranks: 64-plane z-slabs), 5 = 256^3 fp16 storage; sets --grid/--iters/--storage")
@@ -258,8 +258,14 @@ def main():
     ap.add_argument("--peer-devices", action="store_true",
                     help="--loopback N --group peer: slab r lives on device r -- ONE process driving N GPUs, planes travelling by "
                          "hipMemcpyPeerAsync.  This is a measurement (n_gpus = N), unlike the one-GPU loop-back")
-    ap.add_argument("--no-preheat", action="store_true",
-                    help="skip the device wake-up in front of the warm-up steps (`device_preheat` in the line): the cold figure")
+    ap.add_argument("--preheat", action="store_true",
+                    help="run ~80 ms of the same step on a scratch context in front of the warm-up steps (`device_preheat` in the line).  OFF by "
+                         "default since round 6: `value` is the contract's protocol and nothing else -- W warm-up steps, K timed steps; the figure on "
+                         "a device that is already awake is reported beside it as `warm_device` (the same W + K steps on a second context)")
+    ap.add_argument("--no-preheat", action="store_true", help="(accepted for the round-5 tools; the default now)")
+    ap.add_argument("--no-warm-leg", action="store_true", help="skip the `warm_device` leg")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="N > 1: skip the single-domain replay that certifies the timed steps (`multi_rank_parity`); for profiler passes only")
     ap.add_argument("--no-peer-leg", action="store_true",
                     help="--gpus N > 1: do not time the in-process peer transport (a child process of rank 0, after the RCCL measurement) "
                          "beside the RCCL line")
@@ -406,7 +412,10 @@ def main():
 
     dt = 2.0 / GY                                 # FluidX12.cpp:266
 
+    step_log = []                                 # every frame index the run stepped with, in order: what the parity replay repeats
+
     def one_step(k):
+        step_log.append(k)
         if fluid is not None:
             fluid.UpdateFrame(dt, k % 3)
             fluid.Simulate(k % 3)
@@ -504,7 +513,7 @@ def main():
     # first; the contract's W warm-up steps and K timed steps follow on the fresh context, frames W .. W + K - 1 as before.  Reported
     # as `device_preheat`; --no-preheat gives the cold figure.
     preheat = None
-    if fluid is not None and not loop and not args.no_preheat:
+    if fluid is not None and not loop and args.preheat and not args.no_preheat:
         watch.arm("device wake-up", 2.0)
         import fluidx12_amd as fx_
         scratch = fx_.Fluid()
@@ -551,6 +560,101 @@ def main():
 
     elapsed = max_over_ranks(elapsed)
     watch.disarm()
+
+    # ---- N > 1: certify what was timed.  Every rank takes a device-side digest of its OWNED planes of velocity, colour and pressure
+    # (fx_field_digest: a sum over the elements of a mix of (stored bits, global position) -- independent of the decomposition); rank 0
+    # then replays the very same step sequence (schedule candidates, warm-up, timed steps) as ONE domain on its own GPU and takes the
+    # digests of each rank's planes there.  Equal digests = bit-identical fields.  A mismatch is named in the line and is exit code 4.
+    parity, parity_rc = None, 0
+    if N > 1:
+        if args.dry_run:
+            parity = {"result": "not checked (dry run: no GPU work)"}
+        elif args.no_parity:
+            parity = {"result": "not checked (--no-parity)"}
+        else:
+            from fluidx12_amd import capi as capi_p
+            FIELDS = (("velocity", capi_p.FIELD_VELOCITY), ("colour", capi_p.FIELD_COLOR), ("pressure", capi_p.FIELD_PRESSURE))
+            watch.arm("parity: digests of the owned planes")
+            fault = os.environ.get("FLUIDX_BENCH_FAULT", "")
+            if fault.startswith("corrupt:"):          # fault injection (tests): one value of one rank's pressure flips a bit behind the timed steps
+                import numpy as np
+                victim = int(fault.split(":")[1])
+                for r_, m_ in enumerate(members if loop else [fluid]):
+                    if (r_ if loop else rank) == victim:
+                        a_ = m_.download(capi_p.FIELD_PRESSURE)
+                        a_.view(np.uint32)[a_.shape[0] // 2, a_.shape[1] // 2, a_.shape[2] // 2] ^= np.uint32(1)
+                        m_.upload(capi_p.FIELD_PRESSURE, a_)
+            mine = [[m_.digest(f_) for _, f_ in FIELDS] for m_ in (members if loop else [fluid])]
+            if dist is not None:
+                box = [None] * N
+                dist.all_gather_object(box, mine[0])
+                got = box
+            else:
+                got = mine
+            t_par = time.perf_counter()
+            verdict = None
+            if rank == 0:
+                watch.arm("parity: single-domain replay of %d steps" % len(step_log), 2.0 + len(step_log) * N / 100.0)
+                import fluidx12_amd as fx_p
+                ref = fx_p.Fluid()
+                ok_ = ref.Init(1920, 1080, (GX, GY, GZ), storage=args.storage, jacobi_iters=args.iters, jacobi_mode=args.mode,
+                               advect_address=args.address, device=local_rank if not loop else -1)
+                if not ok_:
+                    verdict = "single-domain replay could not be created (status %d)" % ref.last_status
+                else:
+                    for k_ in step_log:
+                        ref.UpdateFrame(dt, k_ % 3)
+                        ref.Simulate(k_ % 3)
+                    ref.Synchronize()
+                    for r_ in range(N):
+                        z0r, nzr = slab_for_rank(GZ, r_, N)
+                        for (name_, f_), d_ in zip(FIELDS, got[r_]):
+                            if verdict is None and ref.digest(f_, z0r, nzr) != d_:
+                                verdict = "rank %d: %s of planes [%d, %d) differs from the single-domain replay" % (r_, name_, z0r, z0r + nzr)
+                    ref.Release()
+                    verdict = verdict or "bit-identical"
+            watch.disarm()
+            if dist is not None:
+                # the other ranks wait on the HOST (a key in the rendezvous store): in a device-side barrier they would spin on the GPUs
+                try:
+                    store_ = dist.distributed_c10d._get_default_store()
+                    if rank == 0:
+                        store_.set("fluidx_parity", verdict)
+                    else:
+                        import datetime
+                        store_.wait(["fluidx_parity"], datetime.timedelta(seconds=600.0))
+                        verdict = store_.get("fluidx_parity").decode()
+                except Exception as e_:
+                    box = [verdict]
+                    dist.broadcast_object_list(box, src=0)
+                    verdict = box[0]
+            parity = {"result": verdict, "fields": [n_ for n_, _ in FIELDS], "steps_replayed": len(step_log), "ranks": N,
+                      "replay_s": time.perf_counter() - t_par if rank == 0 else None,
+                      "how": "fx_field_digest of every rank's owned planes (128 bits over stored bits x global position) == the same planes of ONE "
+                             "domain stepped through the same %d frames on rank 0's GPU" % len(step_log)}
+            if verdict != "bit-identical":
+                parity_rc = 4
+
+    # ---- the same W + K steps once more on a second context (zero state), now that the device is awake: `warm_device`.  `value` above is
+    # the contract's protocol on whatever state the device was in when the process reached it (a GPU that has idled through library load
+    # and context creation runs its first ~40 ms of work 3-5 % slower: tools/step_time_profile.py); this is the other truth, beside it.
+    warm = None
+    if fluid is not None and N == 1 and not loop and not args.no_warm_leg and not args.dry_run:
+        import fluidx12_amd as fx_w
+        w_ = fx_w.Fluid()
+        if w_.Init(1920, 1080, (GX, GY, GZ), storage=args.storage, jacobi_iters=args.iters, jacobi_mode=args.mode, advect_address=args.address):
+            for k_ in range(args.warmup):
+                w_.UpdateFrame(dt, k_ % 3); w_.Simulate(k_ % 3)
+            w_.Synchronize()
+            t_w = time.perf_counter()
+            for k_ in range(args.steps):
+                w_.UpdateFrame(dt, (args.warmup + k_) % 3); w_.Simulate((args.warmup + k_) % 3)
+            w_.Synchronize()
+            el_w = time.perf_counter() - t_w
+            warm = {"value": float(GX) * GY * GZ * args.steps / el_w, "unit": "voxel-updates/s", "ms_per_step": el_w / max(args.steps, 1) * 1e3,
+                    "what": "the same %d warm-up + %d timed steps on a second context of the same grid (zero state), run right behind the timed region: "
+                            "the device is awake; no library marks in this leg" % (args.warmup, args.steps)}
+            w_.Release()
 
     roof = None
     timing = None
@@ -720,12 +824,16 @@ def main():
             fluid.timing_read(reset=True)
             t_dev = time.perf_counter()
             for k in range(DEV_STEPS):
+                fluid.timing_enable(k % 4 == 2)                         # marks on every fourth step, as in the timed region
                 one_step(frame_now + k)
             fluid.Synchronize()
             dev_s = (time.perf_counter() - t_dev) / DEV_STEPS
             t_dev_ = fluid.timing_read(reset=True)
+            fluid.timing_enable(False)
             developed = {"frames": [frame_now + 1, frame_now + DEV_STEPS], "ms_per_step": dev_s * 1e3, "value": float(GX) * GY * nz / dev_s,
-                         "unit": "voxel-updates/s"}
+                         "unit": "voxel-updates/s",
+                         "stage_ms_per_step": {k_: getattr(t_dev_, k_ + "_ms") / max(t_dev_.steps, 1) for k_ in ("advect", "divergence", "jacobi", "project")},
+                         "marked_steps": int(t_dev_.steps)}
             if t_dev_.freeze_solves:
                 developed["sweeps_executed_per_solve"] = t_dev_.freeze_sweeps / t_dev_.freeze_solves
                 developed["masked_strip_launches_per_solve"] = t_dev_.freeze_strip_launches / t_dev_.freeze_solves
@@ -886,6 +994,8 @@ def main():
             "scaling": args.scaling if N > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.storage == "fp32" else "f32 arithmetic / f16 field storage",
+            "value_cold": (voxels / elapsed if not args.dry_run else 0.0) if preheat is None else None,   # = `value` unless --preheat was asked for
+            "warm_device": warm,
             "device_preheat": preheat,
             "data": "synthetic" if not loop else ("synthetic; IN-PROCESS PEER GROUP: one process drives %d GPUs, a slab each" % loop) if args.peer_devices else
                     "synthetic; LOOP-BACK: %d slab ranks share ONE GPU (functional check of the multi-rank path, not a scaling measurement)" % loop,
@@ -937,6 +1047,16 @@ def main():
             out["developed_plume"] = developed
         if peer_leg is not None:
             out["peer_transport"] = peer_leg              # beside the RCCL figure in `value`, never instead of it
+        if parity is not None:
+            out["multi_rank_parity"] = parity["result"]
+            out["multi_rank_parity_detail"] = parity
+        if N > 1 and dist is not None and not args.dry_run:
+            try:
+                import torch
+                out["rccl"] = {"version": ".".join(str(v_) for v_ in torch.cuda.nccl.version()) if not args.shared_gpu else "mock (FLUIDX_RCCL_LIB)",
+                               "ranks_seen_by_torch_distributed": dist.get_world_size(), "backend": dist.get_backend()}
+            except Exception as e_:
+                out["rccl"] = {"error": repr(e_)}
         if N == 1 and not args.no_cpu_baseline and not args.dry_run:
             out["cpu_baseline"] = cpu_baseline(G, args.iters, args.cpu_budget, mode=int(args.mode == "faithful"), half=args.storage == "fp16",
                                                address=int(args.address == "mirror"))
@@ -947,6 +1067,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_rc:
+        sys.stderr.write("bench.py: multi-rank parity FAILED: %s\n" % parity["result"])
+        raise SystemExit(parity_rc)
 
 
 if __name__ == "__main__":

@@ -101,6 +101,29 @@ def build_lib(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, defs, sources=("fx_jacobi_strip4.hip",), outdir=None):
+    """A lab build of the library: `sources` recompiled with the extra `defs` (e.g. ["-DFX_S4_NOHAND"]: leave-one-out timing builds of the
+    four-sweep kernels, docs/LAB.md), every other object taken from the regular build; -> <outdir>/libfluidx_hip_<name>.so.  The tools
+    load it with FLUIDX_LIB_PATH=<that file> (fluidx12_amd/capi.py).  Built HERE (hipcc cross-compiles) so that it travels to the GPU
+    box with the snapshot; never what tests or bench.py measure."""
+    build_lib()
+    outdir = outdir or os.path.join(ROOT, "tools", "_variants")
+    vdir = os.path.join(OBJDIR, "variant_" + name)
+    os.makedirs(outdir, exist_ok=True)
+    os.makedirs(vdir, exist_ok=True)
+    objs = []
+    for s in SOURCES:
+        if s in sources:
+            obj = os.path.join(vdir, s + ".o")
+            subprocess.check_call([hipcc()] + FLAGS + EXTRA_FLAGS.get(s, []) + list(defs) + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj])
+        else:
+            obj = os.path.join(OBJDIR, s + ".o")
+        objs.append(obj)
+    lib = os.path.join(outdir, "libfluidx_hip_%s.so" % name)
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"])
+    return lib
+
+
 def ensure_built():
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     srcs = [os.path.join(CSRC, s) for s in SOURCES]

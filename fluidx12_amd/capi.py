@@ -18,7 +18,7 @@ JACOBI_FIXED, JACOBI_FAITHFUL = 0, 1
 ADDRESS_CLAMP, ADDRESS_MIRROR = 0, 1
 FLAG_JACOBI_FUSE_MASK, FLAG_NO_OVERLAP, FLAG_RENDER_ONLY = 0xF, 0x10, 0x20
 OPT_OVERLAP, OPT_JACOBI_ROUND, OPT_ADAPTIVE_HALO, OPT_COUNT_SAMPLES, OPT_RENDER_ACCEL = 1, 2, 3, 4, 5
-ABI_VERSION = 6                      # FX_ABI_VERSION of include/fluidx_hip.h
+ABI_VERSION = 7                      # FX_ABI_VERSION of include/fluidx_hip.h
 (FIELD_VELOCITY, FIELD_VELOCITY1, FIELD_COLOR, FIELD_COLOR_PREV, FIELD_PRESSURE, FIELD_DIVERGENCE,
  FIELD_LIGHTMAP, FIELD_CUBEMAP, FIELD_TARGET, FIELD_TARGET_FLOAT) = range(10)
 
@@ -66,6 +66,7 @@ SYMBOLS = {
     "fx_upload": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
     "fx_download": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
     "fx_field_bytes": (C.c_size_t, [_vp, C.c_int]),
+    "fx_field_digest": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
     "fx_checkpoint_save": (C.c_int, [_vp, C.c_char_p]),
     "fx_checkpoint_load": (C.c_int, [_vp, C.c_char_p]),
     "fx_advect": (C.c_int, [_vp, _vp]),
@@ -111,6 +112,8 @@ def load():
     except Exception:  # torch is plumbing, not a requirement
         pass
     path = _build.ensure_built()
+    if os.environ.get("FLUIDX_LIB_PATH"):          # a lab build of the library (build.build_variant): tools only -- tests and bench.py never set it
+        path = os.environ["FLUIDX_LIB_PATH"]
     if not os.path.exists(path):
         raise RuntimeError("libfluidx_hip.so is missing and could not be built")
     lib = C.CDLL(path, mode=C.RTLD_GLOBAL)

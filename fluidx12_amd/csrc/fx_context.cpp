@@ -380,6 +380,44 @@ size_t fx_field_bytes(fx_ctx* ctx, int field)
 	return b;
 }
 
+int fx_field_digest(fx_ctx* ctx, int field, uint32_t z_begin, uint32_t z_count, uint64_t out[2])
+{
+	if (!ctx || !out) return FX_E_INVALID;
+	size_t need = 0;
+	int rc = field_info(ctx, field, &need);
+	if (rc) return rc;
+	if (field > FX_FIELD_DIVERGENCE) return FX_E_INVALID;
+	const Geom& g = ctx->g;
+	if (!z_count) { z_begin = (uint32_t)g.z0; z_count = (uint32_t)g.nz; }
+	if ((int)z_begin < g.z0 || z_begin + z_count > (uint32_t)(g.z0 + g.nz)) return FX_E_INVALID;
+	DeviceGuard dg(ctx->device);
+	FX_HIP(hipDeviceSynchronize());
+	if ((rc = halo_fault_status(ctx))) return rc;
+	if ((rc = ensure_stage(ctx, 16))) return rc;
+	unsigned long long* acc = reinterpret_cast<unsigned long long*>(ctx->stage);
+	FX_HIP(hipMemsetAsync(acc, 0, 16, ctx->stream));
+	const size_t plane = g.plane(), cl = g.cells_local(), first = (size_t)g.lz((int)z_begin) * plane, n = (size_t)z_count * plane;
+	const size_t es = elem_size(ctx);
+	const unsigned long long gfirst = (unsigned long long)z_begin * plane, gcells = (unsigned long long)g.Zg * plane;
+	switch (field) {
+	case FX_FIELD_VELOCITY: case FX_FIELD_VELOCITY1: {
+		const char* src = (const char*)ctx->vel[field == FX_FIELD_VELOCITY1];
+		for (int a = 0; a < 3; ++a) FX_HIP(launch_digest(src + (a * cl + first) * es, n, (int)es, a * gcells + gfirst, acc, ctx->stream));
+		break;
+	}
+	case FX_FIELD_COLOR: case FX_FIELD_COLOR_PREV: {
+		const char* src = (const char*)ctx->col[field == FX_FIELD_COLOR ? ctx->frame_parity : 1 - ctx->frame_parity];
+		FX_HIP(launch_digest(src + first * 4 * es, 4 * n, (int)es, 4 * gfirst, acc, ctx->stream));
+		break;
+	}
+	case FX_FIELD_PRESSURE: FX_HIP(launch_digest(ctx->p[ctx->p_cur] + first, n, 4, gfirst, acc, ctx->stream)); break;
+	default: FX_HIP(launch_digest(ctx->b + first, n, 4, gfirst, acc, ctx->stream)); break;
+	}
+	FX_HIP(hipStreamSynchronize(ctx->stream));
+	FX_HIP(hipMemcpy(out, acc, 16, hipMemcpyDeviceToHost));
+	return FX_OK;
+}
+
 int fx_upload(fx_ctx* ctx, int field, const void* host, size_t bytes)
 {
 	if (!ctx || !host) return FX_E_INVALID;

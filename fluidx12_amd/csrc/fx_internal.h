@@ -129,6 +129,8 @@ bool jacobi_prefers_three(const Geom& g, int requested, int nzp);
 bool jacobi_prefers_four(const Geom& g, int requested, int nzp);
 // The LDS hand-overs of the strip kernels wait in bounded loops; a wait that runs out raises a device word (per translation unit) instead
 // of hanging the device or continuing silently.  Read-and-clear on the current device; fx_synchronize turns a raised word into FX_E_DEVICE.
+// fx_field_digest's kernel: two wrapping sums of 64-bit mixes of (stored bits, key0 + element index) over `count` elements, added to out[0..1]
+hipError_t launch_digest(const void* v, size_t count, int elem_bytes, unsigned long long key0, unsigned long long* out, hipStream_t s);
 hipError_t strip3_fault_take(unsigned* out);
 hipError_t strip4_fault_take(unsigned* out);
 // rec (optional, slab ranks): the step record of launch_face_need is produced by this launch when it can be (fp32 3-D kernel

@@ -124,7 +124,8 @@ __device__ __forceinline__ void lds_post(uint32_t lds_byte_addr, int v)
 // FX_E_DEVICE instead of a hung device or a silently wrong pressure field (these loops span unbounded).
 __device__ unsigned g_strip3_fault;
 constexpr int kWaitSpins3 = 1 << 16;
-__device__ __noinline__ void strip3_raise_fault() { atomicOr(&g_strip3_fault, 1u); }
+// (inline, and a plain atomic without a return value: a CALL in these kernels would cost the windows their registers)
+__device__ __forceinline__ void strip3_raise_fault() { (void)__hip_atomic_fetch_or(&g_strip3_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void lds_wait_ge(uint32_t lds_byte_addr, int v)
 {
 	for (int spins = 0; lds_peek(lds_byte_addr) < v; ++spins) {

@@ -37,6 +37,7 @@
 // Traffic: p and b are read once (+ 8 halo planes per chunk of 20) and the result written once per FOUR sweeps.
 #include "fx_internal.h"
 #include "fx_pk.h"
+#include <algorithm>
 #include <climits>
 #include <cstdlib>
 
@@ -51,9 +52,12 @@ constexpr int NRO = FX_STRIP4_OUTER_ROWS;   // rows of an outer wave
 constexpr int NRI = 8 - NRO;                // rows of an inner wave (a workgroup = 2 x (NRO + NRI) = 16 rows)
 
 // A: the wave recomputes a halo ABOVE its rows (the quad's top wave), W: below (the bottom wave).
-template <int NR_, bool A_, bool W_, int NW_ = 4> struct Role4 {
+// XS (X = 512, k_jacobi_strip4x): the wave holds HALF a row -- 1: the left half (its lane 63 looks across the cut at x = 256), 2: the right
+// half (its lane 0 looks at x = 255); 0: the wave is the row.
+template <int NR_, bool A_, bool W_, int NW_ = 4, int XS_ = 0> struct Role4 {
 	static constexpr int NR = NR_;
 	static constexpr int NW = NW_;                                            // waves per workgroup: NW - 1 inner boundaries, NW counters per level
+	static constexpr int XS = XS_;
 	static constexpr bool A = A_, W = W_;
 	static constexpr int NI = NR + (A ? 4 : 1) + (W ? 4 : 1);                 // input rows per plane; row i <-> y0 - (A ? 4 : 1) + i
 	static constexpr int N1 = NR + (A ? 3 : 0) + (W ? 3 : 0);                 // level-l rows; row j <-> y0 - (A ? 4 - l : 0) + j
@@ -89,6 +93,35 @@ __device__ __forceinline__ v4f relax4q(v4f c, v4f U, v4f D, v4f F, v4f Bk, v4f b
 	return v4f{ r.x, r.y, r.z, r.w };
 }
 
+// ... of a HALF-row wave (XS = 1 / 2, see Role4): the lane at the cut takes the partner's cell across it, E[HI], as the `old` operand of its
+// DPP shift -- built into the pair by the v_pk_mov_b32 that builds it anyway (no instruction more than relax4q)
+template <int XS, int HI>
+__device__ __forceinline__ v4f relax4qx(v4f c, v4f U, v4f D, v4f F, v4f Bk, v4f bb, fx_f2 E)
+{
+	const fx_f2 c01 = { c.x, c.y }, c23 = { c.z, c.w };
+	fx_f2 lx = XS == 2 ? pk_mov_sel<HI, 0>(E, c01) : pk_mov(c01, c01, 0);            // (edge | c.x, c.x)
+	const fx_f2 mid = pk_mov(c01, c23, 1);                                           // (c.y, c.z)
+	fx_f2 rx = XS == 1 ? pk_mov_sel<1, HI>(c23, E) : pk_mov(c23, c23, 2);            // (c.w, edge | c.w)
+	const float cx_ = c.x, cw_ = c.w, lx0_ = lx.x, rx1_ = rx.y;
+	lx.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, lx0_), __builtin_bit_cast(int, cw_), 0x138, 0xf, 0xf, false));
+	rx.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, rx1_), __builtin_bit_cast(int, cx_), 0x130, 0xf, 0xf, false));
+	const fx_f2 b01 = { bb.x, bb.y }, b23 = { bb.z, bb.w }, U01 = { U.x, U.y }, U23 = { U.z, U.w }, D01 = { D.x, D.y }, D23 = { D.z, D.w };
+	const fx_f2 F01 = { F.x, F.y }, F23 = { F.z, F.w }, B01 = { Bk.x, Bk.y }, B23 = { Bk.z, Bk.w };
+	fx_f2 s01 = (((((lx - b01) + mid) + U01) + D01) + F01) + B01;
+	fx_f2 s23 = (((((mid - b23) + rx) + U23) + D23) + F23) + B23;
+	const float inv = __uint_as_float(0x3e2aaaabu);
+	s01 *= inv; s23 *= inv;
+	return v4f{ s01.x, s01.y, s23.x, s23.y };
+}
+// row k of a level takes component k of the four edge cells that came in for it
+template <int XS, int K>
+__device__ __forceinline__ v4f relax4qe(v4f c, v4f U, v4f D, v4f F, v4f Bk, v4f bb, v4f EX)
+{
+	static_assert(K >= 0 && K < 4, "four edge cells per level");
+	const fx_f2 E = K < 2 ? fx_f2{ EX.x, EX.y } : fx_f2{ EX.z, EX.w };
+	return relax4qx<XS, K & 1>(c, U, D, F, Bk, bb, E);
+}
+
 __device__ __forceinline__ uint32_t opaque32q(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 // an output row.  FX_S4_SC1: as a write-through store (`sc0 sc1`: the line leaves the XCD's L2 instead of staying there dirty) --
 // a volatile store through a global-address-space pointer is how the compiler is told (it keeps counting the store in its vmcnt waits)
@@ -97,6 +130,8 @@ __device__ __forceinline__ void store_row4(char* base, uint32_t off, v4f v)
 {
 #ifdef FX_S4_SC1
 	*(volatile g_v4f*)(g_v4f*)(base + off) = v;
+#elif defined(FX_S4_NT)
+	__builtin_nontemporal_store(v, reinterpret_cast<v4f*>(base + off));   // (experiment: the output is not read again before the next launch)
 #else
 	*reinterpret_cast<v4f*>(base + off) = v;
 #endif
@@ -202,7 +237,8 @@ struct Frz4 {
 // FX_E_DEVICE -- the pressure field of that launch is not to be trusted (ADVICE / VERDICT round 5: it used to continue silently).
 __device__ unsigned g_strip4_fault;
 constexpr int kWaitSpins4 = 1 << 16;
-__device__ __noinline__ void strip4_raise_fault() { atomicOr(&g_strip4_fault, 1u); }
+// (inline, and a plain atomic without a return value: a CALL in these kernels would cost the windows their registers)
+__device__ __forceinline__ void strip4_raise_fault() { (void)__hip_atomic_fetch_or(&g_strip4_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // counter and row in ONE LDS round trip (see k_jacobi_strip3c): a counter that is high enough vouches for the row read behind it
 __device__ __forceinline__ v4f lds_wait_read4(uint32_t flag_byte_addr, int need, uint32_t row_byte_addr)
@@ -232,7 +268,16 @@ template <class R> struct Strip4 {
 	uint32_t xf0, xb0;                             // LDS byte addresses of the step counters and of the mailbox
 	int q, zb, ze, q_load_last, b_load_last, Zg, wave, lane;
 	bool wall_top, wall_bot;                       // the strip's first own row is y = 0 / its last own row is y = Y - 1
+	// half-row waves (R::XS): the cells across the cut.  Level 0 (the input) is fetched by the wave itself with the plane it prefetches --
+	// ONE load, lane i takes the cell across the cut of input row i -- and handed to a row's update by v_readlane; levels 1..3 travel like the
+	// edge ROWS: 16 bytes per wave, level and step parity in the LDS, written by the lane at the cut, read (a broadcast) by the partner
+	uint32_t eoff;                                 // byte offset of "my" input cell across the cut inside a plane
+	float E0;                                      // the input cells across the cut of the CENTRE plane q - 1 (fetched during step q - 1, a step behind the plane itself: one register)
+	v4f* xe;                                       // [step parity][wave][level 1..3] x 4 cells
+	uint32_t xe0;                                  // ... as an LDS byte address
 };
+template <int NW> __device__ __forceinline__ constexpr int xeslot(int par, int w, int lv) { return (par * NW + w) * 3 + lv; }
+__device__ __forceinline__ float lane_cell(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
 
 #define FXQ_LDS(st, slot, r) (st).lds[(slot) + (r) * 64]
 // The plane behind the last one of the field is a copy of the last (clamped neighbour): once per field and level.  Written as
@@ -249,7 +294,7 @@ template <class R> struct Strip4 {
 // LDS loads and only checked here: issued where it is needed, each hand-over is an exposed LDS round trip per neighbour -- six per step
 // for an inner wave, 12.5 us of a 58-us launch (measured by leaving the hand-overs out).  A row fetched before its owner had published
 // it (its counter says so) is fetched again by the waiting loop.
-template <class R> struct Mail4 { int fu, fd; v4f hu, hd; };
+template <class R> struct Mail4 { int fu, fd; v4f hu, hd; int fx; v4f ex; };
 
 template <class R, int L>
 __device__ __forceinline__ void mail_fetch4(const Strip4<R>& st, Mail4<R>& m)
@@ -268,22 +313,30 @@ __device__ __forceinline__ void mail_fetch4(const Strip4<R>& st, Mail4<R>& m)
 	// counter first, row behind it: a wave's LDS operations execute in order, so a counter that is high enough vouches for the row
 	if (!R::A) m.fu = __hip_atomic_load(flags + (L - 1) * R::NW + FX_WU(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	if (!R::W) m.fd = __hip_atomic_load(flags + (L - 1) * R::NW + FX_WD(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	if (R::XS) m.fx = __hip_atomic_load(flags + (L - 1) * R::NW + (w ^ 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // the partner: the other half of my rows
 	asm volatile("" ::: "memory");
 	__builtin_amdgcn_sched_barrier(0);
 	if (!R::A) m.hu = st.xbuf[xrow<R::NW>(pr, FX_WU(w), L - 1, 0) + st.lane];
 	if (!R::W) m.hd = st.xbuf[xrow<R::NW>(pr, w, L - 1, 1) + st.lane];
+	if (R::XS) m.ex = st.xe[xeslot<R::NW>(pr, w ^ 4, L - 1)];
 	asm volatile("" ::: "memory");
 	__builtin_amdgcn_sched_barrier(0);                                  // (the machine scheduler would otherwise sink the row loads to their use)
 }
 
-template <class R, int L>
-__device__ __forceinline__ void hand_over4(const Strip4<R>& st, Mail4<R>& m, const v4f mine_top, const v4f mine_bot, v4f& HU, v4f& HD)
+// (PN: the level's new plane, NL rows; its first and last row are the edge rows; EX: the partner's cells across the cut come back in it)
+template <class R, int L, int NL>
+__device__ __forceinline__ void hand_over4(const Strip4<R>& st, Mail4<R>& m, const v4f (&PN)[NL], v4f& HU, v4f& HD, v4f& EX)
 {
 #ifdef FX_S4_NOHAND
 	return;
 #endif
 	const int q = st.q, w = st.wave;
 	const int pr = (q - 1) & 1, pw = q & 1;
+	const v4f mine_top = PN[0], mine_bot = PN[NL - 1];
+	if (R::XS) {
+		if (__builtin_expect(m.fx < q - 1, 0)) m.ex = lds_wait_read4(st.xf0 + 4u * (uint32_t)((L - 1) * R::NW + (w ^ 4)), q - 1, st.xe0 + 16u * (uint32_t)xeslot<R::NW>(pr, w ^ 4, L - 1));
+		EX = m.ex;
+	}
 	if (!R::A) {
 		if (__builtin_expect(m.fu < q - 1, 0)) m.hu = lds_wait_read4(st.xf0 + 4u * (uint32_t)((L - 1) * R::NW + FX_WU(w)), q - 1, st.xb0 + 16u * (uint32_t)(xrow<R::NW>(pr, FX_WU(w), L - 1, 0) + st.lane));
 		HU = m.hu;
@@ -295,6 +348,15 @@ __device__ __forceinline__ void hand_over4(const Strip4<R>& st, Mail4<R>& m, con
 	asm volatile("" ::: "memory");
 	if (!R::A) st.xbuf[xrow<R::NW>(pw, FX_WU(w), L - 1, 1) + st.lane] = mine_top;
 	if (!R::W) st.xbuf[xrow<R::NW>(pw, w, L - 1, 0) + st.lane] = mine_bot;
+	if (R::XS) {
+		// my cells at the cut of the rows the NEXT sweep updates (rows UP .. of this level), for the partner's next step
+		constexpr int NN = NL - (R::A ? 1 : 0) - (R::W ? 1 : 0);
+		if (st.lane == (R::XS == 1 ? 63 : 0)) {
+			float* s_ = reinterpret_cast<float*>(st.xe + xeslot<R::NW>(pw, w, L - 1));
+#pragma unroll
+			for (int k = 0; k < NN; ++k) s_[k] = R::XS == 1 ? PN[k + R::UP].w : PN[k + R::UP].x;
+		}
+	}
 #ifndef FX_S4_BARRIER
 	if (st.lane == 0) lds_post4(st.xf0 + 4u * (uint32_t)((L - 1) * R::NW + w), q);        // LDS operations of a wave execute in order
 #endif
@@ -304,8 +366,9 @@ __device__ __forceinline__ void hand_over4(const Strip4<R>& st, Mail4<R>& m, con
 // (MK: the masked loop -- mctr = the nibbles of the centre plane in level-L indexing, mout = those of the new plane in level-(L+1) indexing)
 template <class R, int L, int NL, int NN, bool MK = false>
 __device__ __forceinline__ void relax_level4(const Strip4<R>& st, const v4f (&Pold)[NL], const v4f (&Pctr)[NL], const v4f (&Pnew)[NL],
-	const v4f (&Bq)[NN], v4f HU, v4f HD, v4f (&out)[NN], uint32_t mctr, uint32_t& mout)
+	const v4f (&Bq)[NN], v4f HU, v4f HD, v4f (&out)[NN], uint32_t mctr, uint32_t& mout, v4f EX = v4f{ 0.0f, 0.0f, 0.0f, 0.0f })
 {
+	static_assert(!(MK && R::XS), "the masked loop runs on whole-row waves");
 	uint32_t m_ = 0u;
 #pragma unroll
 	for (int kk = 0; kk < NN; ++kk) {
@@ -329,6 +392,14 @@ __device__ __forceinline__ void relax_level4(const Strip4<R>& st, const v4f (&Po
 #else
 			out[k] = relax4qf(c, u, d, Pold[jc], Pnew[jc], Bq[k], mctr, 4 * jc, m_);
 #endif
+		} else if (R::XS) {
+			// (k is a constant of the unrolled loop; the switch only names it for the template)
+			switch (k) {
+			case 0: out[k] = relax4qe<R::XS ? R::XS : 1, 0>(c, u, d, Pold[jc], Pnew[jc], Bq[k], EX); break;
+			case 1: out[k] = relax4qe<R::XS ? R::XS : 1, 1>(c, u, d, Pold[jc], Pnew[jc], Bq[k], EX); break;
+			case 2: out[k] = relax4qe<R::XS ? R::XS : 1, 2>(c, u, d, Pold[jc], Pnew[jc], Bq[k], EX); break;
+			default: out[k] = relax4qe<R::XS ? R::XS : 1, 3>(c, u, d, Pold[jc], Pnew[jc], Bq[k], EX); break;
+			}
 		} else
 			out[k] = relax4q(c, u, d, Pold[jc], Pnew[jc], Bq[k]);
 	}
@@ -441,6 +512,8 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 				for (int j = 0; j < N1; ++j) NM[j] = fz.pm[opaque32q(roff[j + 1] >> 4)];
 			}
 		}
+		// the cells across the cut of plane q, the next step's centre (past the last present plane E0 keeps plane zhi's)
+		if (R::XS && q <= st.q_load_last) st.E0 = *reinterpret_cast<const float*>(st.pp - st.plane_bytes + st.eoff);
 	};
 	if (EARLY) {
 #pragma unroll
@@ -455,6 +528,12 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 	if (q == 0) {                                                       // input plane -1 := plane 0, once (clamped front neighbour)
 #pragma unroll
 		for (int i = 0; i < NI; ++i) FXQ_LDS(st, st.s_ctr, i) = np(i);
+	}
+	// the centre plane's cells across the cut, rows of level 1 (row j's centre is input row j + 1): pairs for relax4qx
+	fx_f2 E1_[R::XS ? (N1 + 1) / 2 : 1];
+	if (R::XS) {
+#pragma unroll
+		for (int j = 0; j < N1; ++j) { const float e_ = lane_cell(st.E0, j + 1); if (j & 1) E1_[j >> 1].y = e_; else E1_[j >> 1].x = e_; }
 	}
 	if (S1) {
 		// (the new plane goes through a local first and into the window by unconditional stores: stores to different window slots in the two
@@ -492,6 +571,9 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 						uint32_t n_;
 						T_[j] = relax4qm(c_, u_, d_, f_, np(j + 1), nb(j), FXQ_NIB(fz.M0c, j), n_);
 						m1_ |= n_ << (4 * j);
+					} else if (R::XS) {
+						T_[j] = (j & 1) ? relax4qx<R::XS ? R::XS : 1, 1>(c_, u_, d_, f_, np(j + 1), nb(j), E1_[R::XS ? j >> 1 : 0])
+						                : relax4qx<R::XS ? R::XS : 1, 0>(c_, u_, d_, f_, np(j + 1), nb(j), E1_[R::XS ? j >> 1 : 0]);
 					} else
 						T_[j] = relax4q(c_, u_, d_, f_, np(j + 1), nb(j));
 					u_ = c_; c_ = d_;
@@ -550,14 +632,14 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 	st.pp += st.plane_bytes; st.pbq += st.plane_bytes;
 	if (MK) fz.pm += st.plane_bytes >> 4;
 	// hand-over 1, BEHIND the prefetch issue: a wait here must not delay the loads
-	v4f HU1 = zero, HD1 = zero;
-	if (S1) hand_over4<R, 1>(st, M1, P1[NEW][0], P1[NEW][N1 - 1], HU1, HD1);
+	v4f HU1 = zero, HD1 = zero, EX1 = zero;
+	if (S1) hand_over4<R, 1, N1>(st, M1, P1[NEW], HU1, HD1, EX1);
 	if (S2) mail_fetch4<R, 2>(st, M2);
 	// ---- sweep 2: level-2 plane q-2 -----------------------------------------------------------------------------------
 	if (S2) {
 		v4f T_[N2];
 		uint32_t m2_ = 0u;
-		relax_level4<R, 1, N1, N2, MK>(st, P1[OLD], P1[CTR], P1[NEW], B2_, HU1, HD1, T_, MK ? MW[0][CTR] : 0u, m2_);
+		relax_level4<R, 1, N1, N2, MK>(st, P1[OLD], P1[CTR], P1[NEW], B2_, HU1, HD1, T_, MK ? MW[0][CTR] : 0u, m2_, EX1);
 		if (MK && q - 2 >= st.zb && q - 2 < st.ze && (~(m2_ >> (4 * O2)) & OWN) != 0u) fz.rel |= 4u;
 		if (__builtin_expect(q - 2 == st.Zg, 0)) {
 			FXQ_RARE_BRANCH;
@@ -578,14 +660,14 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 	v4f B3_[N3];                                                     // b[q-3] (after the rotation: s_b4), rows of level 3
 #pragma unroll
 	for (int m = 0; m < N3; ++m) B3_[m] = FXQ_LDS(st, st.s_b4, m + UP);
-	v4f HU2 = zero, HD2 = zero;
-	if (S2) hand_over4<R, 2>(st, M2, P2[NEW][0], P2[NEW][N2 - 1], HU2, HD2);
+	v4f HU2 = zero, HD2 = zero, EX2 = zero;
+	if (S2) hand_over4<R, 2, N2>(st, M2, P2[NEW], HU2, HD2, EX2);
 	if (S3) mail_fetch4<R, 3>(st, M3);
 	// ---- sweep 3: level-3 plane q-3 -----------------------------------------------------------------------------------
 	if (S3) {
 		v4f T_[N3];
 		uint32_t m3_ = 0u;
-		relax_level4<R, 2, N2, N3, MK>(st, P2[OLD], P2[CTR], P2[NEW], B3_, HU2, HD2, T_, MK ? MW[1][CTR] : 0u, m3_);
+		relax_level4<R, 2, N2, N3, MK>(st, P2[OLD], P2[CTR], P2[NEW], B3_, HU2, HD2, T_, MK ? MW[1][CTR] : 0u, m3_, EX2);
 		if (MK && q - 3 >= st.zb && q - 3 < st.ze && (~(m3_ >> (4 * O3)) & OWN) != 0u) fz.rel |= 8u;
 		if (__builtin_expect(q - 3 == st.Zg, 0)) {
 			FXQ_RARE_BRANCH;
@@ -603,8 +685,8 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 			if (MK) MW[2][CTR] = m3_;
 		}
 	}
-	v4f HU3 = zero, HD3 = zero;
-	if (S3) hand_over4<R, 3>(st, M3, P3[NEW][0], P3[NEW][N3 - 1], HU3, HD3);
+	v4f HU3 = zero, HD3 = zero, EX3 = zero;
+	if (S3) hand_over4<R, 3, N3>(st, M3, P3[NEW], HU3, HD3, EX3);
 	// ---- sweep 4: output plane q-4 ------------------------------------------------------------------------------------
 	if (S4) {
 		// UNCONDITIONAL stores: behind a branch the compiler counts no store when it waits for the prefetched rows of the next step, and each
@@ -613,7 +695,7 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 		// wave to one address keep their order); no step of the loop lies above the chunk (q <= ze + 3).
 		v4f X_[NR];
 		uint32_t m4_ = 0u;
-		relax_level4<R, 3, N3, NR, MK>(st, P3[OLD], P3[CTR], P3[NEW], B4_, HU3, HD3, X_, MK ? MW[2][CTR] : 0u, m4_);
+		relax_level4<R, 3, N3, NR, MK>(st, P3[OLD], P3[CTR], P3[NEW], B4_, HU3, HD3, X_, MK ? MW[2][CTR] : 0u, m4_, EX3);
 		char* dst_ = q - 4 >= st.zb ? st.po : st.po_zb;
 #ifdef FX_S4_NOSTORE
 		if (q < -1000)                                                   // (experiment: the arithmetic stays, the stores never execute)
@@ -686,7 +768,7 @@ __device__ __forceinline__ void frz_end4(const FrzArgs& fa, const Frz4& fz, int 
 
 template <class R, bool MK = false>
 __device__ __forceinline__ void run4(const Geom& g, const float* __restrict__ p_in, const float* __restrict__ b, float* __restrict__ p_out,
-	int zb, int ze, int y0, int wave, int lane, v4f* lds_slice, v4f* xbuf, int* xflag, const FrzArgs& fa)
+	int zb, int ze, int y0, int wave, int lane, v4f* lds_slice, v4f* xbuf, int* xflag, const FrzArgs& fa, v4f* xe = nullptr)
 {
 	Strip4<R> st;
 	Frz4 fz;
@@ -709,8 +791,12 @@ __device__ __forceinline__ void run4(const Geom& g, const float* __restrict__ p_
 	st.xf0 = (uint32_t)(size_t)(__attribute__((address_space(3))) int*)xflag;
 	st.xb0 = (uint32_t)(size_t)(__attribute__((address_space(3))) v4f*)xbuf;
 	const int yb = y0 - (R::A ? 4 : 1);
+	constexpr uint32_t XCOL = R::XS == 2 ? 256u : 0u;                   // the first column of the wave's half of a row
 #pragma unroll
-	for (int i = 0; i < R::NI; ++i) roff[i] = ((uint32_t)min(max(yb + i, 0), g.Y - 1) * (uint32_t)g.X + 4u * (uint32_t)lane) * 4u;
+	for (int i = 0; i < R::NI; ++i) roff[i] = ((uint32_t)min(max(yb + i, 0), g.Y - 1) * (uint32_t)g.X + XCOL + 4u * (uint32_t)lane) * 4u;
+	st.xe = xe; st.xe0 = (uint32_t)(size_t)(__attribute__((address_space(3))) v4f*)xe;
+	st.eoff = ((uint32_t)min(max(yb + min(lane, R::NI - 1), 0), g.Y - 1) * (uint32_t)g.X + (R::XS == 2 ? 255u : 256u)) * 4u;
+	st.E0 = 0.0f;
 	st.s_ctr = 0; st.s_old = R::NI * 64;
 	st.s_b2 = 2 * R::NI * 64; st.s_b3 = st.s_b2 + (R::NW == 4 ? R::N2 * 64 : 0); st.s_b4 = st.s_b3 + R::N2 * 64;      // (lean waves: two b slots, s_b3 and s_b4)
 #pragma unroll
@@ -743,6 +829,8 @@ __device__ __forceinline__ void run4(const Geom& g, const float* __restrict__ p_
 		const char* bnext = reinterpret_cast<const char*>(b + (size_t)g.lz(min(max(q0, g.zlo), g.zhi)) * plane);
 #pragma unroll
 		for (int j = 0; j < R::N1; ++j) NBn[j] = *reinterpret_cast<const v4f*>(bnext + roff[j + 1]);
+		// the first step's centre plane q0 - 1, clamped into the planes present (q0 = 0: input plane -1 := plane 0)
+		if (R::XS) st.E0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p_in + (size_t)g.lz(min(max(q0 - 1, g.zlo), g.zhi)) * plane) + st.eoff);
 		if (fill) {                                                       // input planes q0 - 2 and q0 - 1 straight into their LDS slots
 			const char* pa = reinterpret_cast<const char*>(p_in + (size_t)g.lz(qs) * plane);
 			v4f A_[R::NI], B_[R::NI];
@@ -817,6 +905,11 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 #pragma unroll
 		for (int i = 0; i < NI; ++i) I[CTR][i] = I[NEW][i];
 	}
+	fx_f2 E1_[R::XS ? (NR + 1) / 2 : 1];                                 // the centre plane's cells across the cut (see step4)
+	if (R::XS) {
+#pragma unroll
+		for (int j = 0; j < NR; ++j) { const float e_ = lane_cell(st.E0, j + 1); if (j & 1) E1_[j >> 1].y = e_; else E1_[j >> 1].x = e_; }
+	}
 	if (S1) {
 		v4f T_[NR];
 		uint32_t m1_ = 0u;
@@ -836,6 +929,9 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 #else
 					T_[j] = relax4qf(I[CTR][j + 1], I[CTR][j], I[CTR][j + 2], I[OLD][j + 1], I[NEW][j + 1], NB[j], fz.M0c, 4 * j, m1_);
 #endif
+				} else if (R::XS) {
+					T_[j] = (j & 1) ? relax4qx<R::XS ? R::XS : 1, 1>(I[CTR][j + 1], I[CTR][j], I[CTR][j + 2], I[OLD][j + 1], I[NEW][j + 1], NB[j], E1_[R::XS ? j >> 1 : 0])
+					                : relax4qx<R::XS ? R::XS : 1, 0>(I[CTR][j + 1], I[CTR][j], I[CTR][j + 2], I[OLD][j + 1], I[NEW][j + 1], NB[j], E1_[R::XS ? j >> 1 : 0]);
 				} else
 					T_[j] = relax4q(I[CTR][j + 1], I[CTR][j], I[CTR][j + 2], I[OLD][j + 1], I[NEW][j + 1], NB[j]);
 			}
@@ -891,16 +987,17 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 #pragma unroll
 		for (int j = 0; j < NR; ++j) NB[j] = *reinterpret_cast<const v4f*>(st.pbq + opaque32q(roff[j + 1]));
 	}
+	if (R::XS && q <= st.q_load_last) st.E0 = *reinterpret_cast<const float*>(st.pp - st.plane_bytes + st.eoff);   // plane q's cells across the cut: the next step's centre
 	st.pp += st.plane_bytes; st.pbq += st.plane_bytes;
 	if (MK) fz.pm += st.plane_bytes >> 4;
-	v4f HU1 = zero, HD1 = zero;
-	if (S1) hand_over4<R, 1>(st, M1, P1[NEW][0], P1[NEW][NR - 1], HU1, HD1);
+	v4f HU1 = zero, HD1 = zero, EX1 = zero;
+	if (S1) hand_over4<R, 1, NR>(st, M1, P1[NEW], HU1, HD1, EX1);
 	if (S2) mail_fetch4<R, 2>(st, M2);
 	// ---- sweep 2 ----
 	if (S2) {
 		v4f T_[NR];
 		uint32_t m2_ = 0u;
-		relax_level4<R, 1, NR, NR, MK>(st, P1[OLD], P1[CTR], P1[NEW], B2_, HU1, HD1, T_, MK ? MW[0][CTR] : 0u, m2_);
+		relax_level4<R, 1, NR, NR, MK>(st, P1[OLD], P1[CTR], P1[NEW], B2_, HU1, HD1, T_, MK ? MW[0][CTR] : 0u, m2_, EX1);
 		if (MK && q - 2 >= st.zb && q - 2 < st.ze && (~m2_ & OWN) != 0u) fz.rel |= 4u;
 		if (__builtin_expect(q - 2 == st.Zg, 0)) {
 			FXQ_RARE_BRANCH;
@@ -918,14 +1015,14 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 			if (MK) MW[1][CTR] = m2_;
 		}
 	}
-	v4f HU2 = zero, HD2 = zero;
-	if (S2) hand_over4<R, 2>(st, M2, P2[NEW][0], P2[NEW][NR - 1], HU2, HD2);
+	v4f HU2 = zero, HD2 = zero, EX2 = zero;
+	if (S2) hand_over4<R, 2, NR>(st, M2, P2[NEW], HU2, HD2, EX2);
 	if (S3) mail_fetch4<R, 3>(st, M3);
 	// ---- sweep 3 ----
 	if (S3) {
 		v4f T_[NR];
 		uint32_t m3_ = 0u;
-		relax_level4<R, 2, NR, NR, MK>(st, P2[OLD], P2[CTR], P2[NEW], B3_, HU2, HD2, T_, MK ? MW[1][CTR] : 0u, m3_);
+		relax_level4<R, 2, NR, NR, MK>(st, P2[OLD], P2[CTR], P2[NEW], B3_, HU2, HD2, T_, MK ? MW[1][CTR] : 0u, m3_, EX2);
 		if (MK && q - 3 >= st.zb && q - 3 < st.ze && (~m3_ & OWN) != 0u) fz.rel |= 8u;
 		if (__builtin_expect(q - 3 == st.Zg, 0)) {
 			FXQ_RARE_BRANCH;
@@ -943,13 +1040,13 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 			if (MK) MW[2][CTR] = m3_;
 		}
 	}
-	v4f HU3 = zero, HD3 = zero;
-	if (S3) hand_over4<R, 3>(st, M3, P3[NEW][0], P3[NEW][NR - 1], HU3, HD3);
+	v4f HU3 = zero, HD3 = zero, EX3 = zero;
+	if (S3) hand_over4<R, 3, NR>(st, M3, P3[NEW], HU3, HD3, EX3);
 	// ---- sweep 4: the output ----
 	if (S4) {
 		v4f X_[NR];
 		uint32_t m4_ = 0u;
-		relax_level4<R, 3, NR, NR, MK>(st, P3[OLD], P3[CTR], P3[NEW], B4_, HU3, HD3, X_, MK ? MW[2][CTR] : 0u, m4_);
+		relax_level4<R, 3, NR, NR, MK>(st, P3[OLD], P3[CTR], P3[NEW], B4_, HU3, HD3, X_, MK ? MW[2][CTR] : 0u, m4_, EX3);
 		char* dst_ = q - 4 >= st.zb ? st.po : st.po_zb;
 #ifdef FX_S4_NOSTORE
 		if (q < -1000)
@@ -964,7 +1061,7 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 
 template <class R, bool MK = false>
 __device__ __forceinline__ void run4r(const Geom& g, const float* __restrict__ p_in, const float* __restrict__ b, float* __restrict__ p_out,
-	int zb, int ze, int y0, int wave, int lane, v4f* xbuf, int* xflag, const FrzArgs& fa)
+	int zb, int ze, int y0, int wave, int lane, v4f* xbuf, int* xflag, const FrzArgs& fa, v4f* xe = nullptr)
 {
 	Strip4<R> st;
 	Frz4 fz;
@@ -982,8 +1079,12 @@ __device__ __forceinline__ void run4r(const Geom& g, const float* __restrict__ p
 	st.xb0 = (uint32_t)(size_t)(__attribute__((address_space(3))) v4f*)xbuf;
 	st.s_ctr = st.s_old = st.s_b2 = st.s_b3 = st.s_b4 = 0;
 	const int yb = y0 - 1;
+	constexpr uint32_t XCOL = R::XS == 2 ? 256u : 0u;
 #pragma unroll
-	for (int i = 0; i < R::NI; ++i) roff[i] = ((uint32_t)min(max(yb + i, 0), g.Y - 1) * (uint32_t)g.X + 4u * (uint32_t)lane) * 4u;
+	for (int i = 0; i < R::NI; ++i) roff[i] = ((uint32_t)min(max(yb + i, 0), g.Y - 1) * (uint32_t)g.X + XCOL + 4u * (uint32_t)lane) * 4u;
+	st.xe = xe; st.xe0 = (uint32_t)(size_t)(__attribute__((address_space(3))) v4f*)xe;
+	st.eoff = ((uint32_t)min(max(yb + min(lane, R::NI - 1), 0), g.Y - 1) * (uint32_t)g.X + (R::XS == 2 ? 255u : 256u)) * 4u;
+	st.E0 = 0.0f;
 #pragma unroll
 	for (int k = 0; k < 3; ++k) {
 #pragma unroll
@@ -1004,6 +1105,8 @@ __device__ __forceinline__ void run4r(const Geom& g, const float* __restrict__ p
 		const char* bbase = reinterpret_cast<const char*>(b + (size_t)g.lz(min(max(q0 - 1, g.zlo), g.zhi)) * plane);
 #pragma unroll
 		for (int j = 0; j < R::NR; ++j) NB[j] = *reinterpret_cast<const v4f*>(bbase + roff[j + 1]);
+		// the first step's centre plane q0 - 1, clamped into the planes present (q0 = 0: input plane -1 := plane 0)
+		if (R::XS) st.E0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p_in + (size_t)g.lz(min(max(q0 - 1, g.zlo), g.zhi)) * plane) + st.eoff);
 		if (fill) {
 			const char* pa = reinterpret_cast<const char*>(p_in + (size_t)g.lz(qs) * plane);
 #pragma unroll
@@ -1133,6 +1236,143 @@ __global__ __launch_bounds__(512, 2) void k_freeze_strip4o(const Geom g, const f
 	else run4r<OctMid, true>(g, p_in, b, p_outA, zb, ze, yg + 2 * wave - 1, wave, lane, xbuf, xflag, fa);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// X = 512 (k_jacobi_strip4x): the octet's pipeline on HALF rows.  A wave is 64 lanes x 4 cells = 256 cells; a 512-cell row in one wave
+// would double every window (an outer wave's ten row updates per step -- the slowest wave of the step -- would become twenty), so the
+// workgroup's eight waves are 2 x-halves x 4 waves top-down (1 + 2 + 2 + 1 rows: a band of SIX rows), the x cut INSIDE the workgroup:
+//   * the input cells across the cut come with the plane a wave prefetches (one more load per step: lane i fetches row i's cell) and reach
+//     a row's update through v_readlane;
+//   * the cells of levels 1..3 travel like the edge rows -- the lane at the cut writes them into a 16-byte LDS slot per wave, level and step
+//     parity, the partner (the wave with the same rows in the other half) reads the slot as a broadcast, a sweep early, and checks the
+//     partner's step counter at the hand-over: the counter a wave posts per level now vouches for its edge rows AND its cut cells;
+//   * the partner's cell enters the update as the `old` operand of the DPP shift that brings every other lane its x neighbour, placed into
+//     the operand pair by the v_pk_mov_b32 that builds the pair anyway (relax4qx): no instruction more per update than at X = 256.
+// Waves w and w + 4 share a SIMD: the chain positions (left half top-down 0..3, right half 4..7) are dealt so that each SIMD gets one
+// outer wave (ten row updates per step) and one inner (eight).  LDS: 4 x 18 parked rows + 84 mailbox rows = 156 KiB.
+// Work: the launch's band-planes, ordered (z chunk, band, plane), are cut into ONE contiguous run per workgroup, so any band count fills the
+// chip's 256 CUs evenly -- 86 bands of six rows do not divide into 256 -- and a run that crosses into the next band becomes two pieces
+// (each pays its own fill).  The chunks are as long as a run (the last one shorter): the runs of a chunk then ARE its bands, neighbouring
+// bands walk the same planes at the same time on neighbouring CUs of one XCD, and the eight halo rows a six-row band reads beyond its
+// own come out of that XCD's L2 instead of the fabric (band-major runs: every band alone at its depth, 1.8 x the compulsory traffic).
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef Role4<1, true, false, 8, 1> XTopL;
+typedef Role4<2, false, false, 8, 1> XMidL;
+typedef Role4<1, false, true, 8, 1> XBotL;
+typedef Role4<1, true, false, 8, 2> XTopR;
+typedef Role4<2, false, false, 8, 2> XMidR;
+typedef Role4<1, false, true, 8, 2> XBotR;
+constexpr int X_BAND = 6;
+constexpr int X_OUTER_ROWS = XTopL::LDS_ROWS;                          // = XBotL's
+static_assert(XTopL::LDS_ROWS == XBotL::LDS_ROWS, "outer waves park alike");
+constexpr int X_LDS_ROWS = 4 * X_OUTER_ROWS;
+constexpr int X_XROWS = 2 * 7 * 3 * 2;                                 // (boundary 3, between the two halves' chains, is never used)
+static_assert((X_LDS_ROWS + X_XROWS) * 1024 + 2 * 8 * 3 * 16 + 128 <= 160 * 1024, "the half-row octet's windows must fit the CU's LDS");
+
+// where band `grp` starts: octet_band_y for bands of BAND rows
+__device__ __host__ __forceinline__ int band_y(int grp, int ngroups, int Y, int BAND)
+{
+	if (grp == ngroups - 1) return Y - BAND;
+	const int yg = grp * BAND;
+	return yg + BAND + 3 > Y ? Y - BAND - 3 : yg;
+}
+__host__ inline bool band_rows_supported(int Y, int BAND) { return Y == BAND || Y >= BAND + 3; }
+
+// The launch's band-planes in the order (z chunk, band, plane): `nch` chunks, chunk i = planes [zc[i], zc[i + 1]) of the launch's range.
+struct Runs4 { int bands, nzp, nch, nwg, minp; int zc[9]; };
+// position s of that order -> its band, its plane (relative to the range) and the planes left in its piece (a band's planes of one chunk)
+__device__ __forceinline__ void run_locate(const Runs4& r, int s, int& band, int& z, int& left)
+{
+	int i = 0;
+	while (i + 1 < r.nch && s >= r.bands * r.zc[i + 1]) ++i;
+	const int ci = r.zc[i + 1] - r.zc[i], q = s - r.bands * r.zc[i];
+	band = q / ci;
+	const int zo = q - band * ci;
+	z = r.zc[i] + zo; left = ci - zo;
+}
+// the first position of workgroup k's run: k T / nwg, moved to the piece boundary when it would leave fewer than `minp` planes of a piece
+__device__ __forceinline__ int run_cut(const Runs4& r, int k)
+{
+	const int T = r.bands * r.nzp;
+	if (k >= r.nwg) return T;
+	int s = (int)((long long)k * T / r.nwg), band, z, left;
+	run_locate(r, s, band, z, left);
+	int i = 0;
+	while (i + 1 < r.nch && z >= r.zc[i + 1]) ++i;
+	const int zo = z - r.zc[i];
+	if (zo < r.minp) s -= zo;
+	else if (left < r.minp) s += left;
+	return s;
+}
+
+__global__ __launch_bounds__(512, 2) void k_jacobi_strip4x(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
+	float* __restrict__ p_out, int z_begin, const Runs4 runs, int remap)
+{
+	__shared__ v4f lds_all[X_LDS_ROWS * 64];
+	__shared__ v4f xbuf[X_XROWS * 64];
+	__shared__ v4f xe[2 * 8 * 3];
+	__shared__ int xflag[24];
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int c = wave < 4 ? wave : 4 + ((wave ^ 1) & 3);              // chain position: 0 1 2 3 | 5 4 7 6 -- one outer wave per SIMD
+	int k = (int)blockIdx.x;
+	if (remap) {                                                        // XCD x walks the x-th contiguous eighth of the runs
+		const int qn = runs.nwg >> 3, r = runs.nwg & 7;
+		const int xcd = k & 7, j = k >> 3;
+		k = xcd * qn + min(xcd, r) + j;
+	}
+	// The pieces of a run are walked LAST FIRST: a run that crosses into the next band is [the tail of band b | the head of band b + 1], and
+	// with the head first every workgroup of a chunk walks UP through the planes from the chunk's first one at the same time -- neighbouring
+	// bands stay at the same depth (the halo rows come out of the L2) although the runs are a few planes longer than the chunk's pieces.
+	// (Tail first, each run starts 4 planes deeper into its band than its neighbour: 84 of the 256 workgroups of a 512^3 launch then shared nothing.)
+	// The list is made once, into the LDS: the walk below keeps nothing of the run arithmetic alive across a piece, whose windows take every
+	// register there is.
+	constexpr int MAXP = 8;
+	__shared__ int piece[MAXP][3];                                      // { first plane, planes, first row of the band }
+	__shared__ int npiece;
+	if (threadIdx.x == 0) {
+		const int t0 = run_cut(runs, k);
+		int t1 = run_cut(runs, k + 1), n = 0;
+		while (t0 < t1 && n < MAXP) {
+			int band, zoff, left;
+			run_locate(runs, t1 - 1, band, zoff, left);                   // the piece that ends the run
+			int pz0 = 0;
+			{ int i = 0; while (i + 1 < runs.nch && zoff >= runs.zc[i + 1]) ++i; pz0 = runs.zc[i]; }
+			// (the eighth piece of a run -- there is none in any shape the launcher makes -- would take all that is left of its band's chunk)
+			const int zfirst = n == MAXP - 1 ? pz0 : max(pz0, zoff - (t1 - 1 - t0));
+			piece[n][0] = z_begin + zfirst; piece[n][1] = zoff - zfirst + 1; piece[n][2] = band_y(band, runs.bands, g.Y, X_BAND);
+			t1 -= zoff - zfirst + 1;
+			++n;
+		}
+		npiece = n;
+	}
+	__syncthreads();
+	const FrzArgs none{};
+	const v4f zero = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+	for (int ip = 0; ip < __builtin_amdgcn_readfirstlane(npiece); ++ip) {
+		const int zb = __builtin_amdgcn_readfirstlane(piece[ip][0]), ze = zb + __builtin_amdgcn_readfirstlane(piece[ip][1]);
+		const int yg = __builtin_amdgcn_readfirstlane(piece[ip][2]);
+		const int qs = max(zb - 4, g.zlo);
+		const bool fill = qs == zb - 4;
+		// the lane id is made afresh for every piece (v_mbcnt; volatile: not hoisted): nothing per lane lives across a piece, whose windows
+		// take every register there is
+		int lane;
+		asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(lane));
+		const int tid = wave * 64 + lane;
+		__syncthreads();                                                // (the previous piece's mailbox reads are over)
+		if (tid < 24) xflag[tid] = fill ? qs + 2 * (tid / 8 + 1) - 1 : qs - 1;
+		for (int i = tid; i < X_XROWS * 64; i += 512) xbuf[i] = zero;
+		if (tid < 2 * 8 * 3) xe[tid] = zero;
+		__syncthreads();
+		switch (c) {
+		case 0: run4<XTopL>(g, p_in, b, p_out, zb, ze, yg, c, lane, lds_all, xbuf, xflag, none, xe); break;
+		case 1: case 2: run4r<XMidL>(g, p_in, b, p_out, zb, ze, yg + 2 * c - 1, c, lane, xbuf, xflag, none, xe); break;
+		case 3: run4<XBotL>(g, p_in, b, p_out, zb, ze, yg + X_BAND - 1, c, lane, lds_all + X_OUTER_ROWS * 64, xbuf, xflag, none, xe); break;
+		case 4: run4<XTopR>(g, p_in, b, p_out, zb, ze, yg, c, lane, lds_all + 2 * X_OUTER_ROWS * 64, xbuf, xflag, none, xe); break;
+		case 5: case 6: run4r<XMidR>(g, p_in, b, p_out, zb, ze, yg + 2 * (c - 4) - 1, c, lane, xbuf, xflag, none, xe); break;
+		default: run4<XBotR>(g, p_in, b, p_out, zb, ze, yg + X_BAND - 1, c, lane, lds_all + 3 * X_OUTER_ROWS * 64, xbuf, xflag, none, xe); break;
+		}
+	}
+}
+
 __global__ __launch_bounds__(256, 1) void k_jacobi_strip4q(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
 	float* __restrict__ p_out, int z_begin, int z_end, int zchunk, int ngroups, int nchunks, int remap)
 {
@@ -1180,7 +1420,8 @@ hipError_t strip4_fault_take(unsigned* out)
 bool jacobi_strip4_supported(const Geom& g)
 {
 	// the octet takes Y = 14 and any Y >= 17 (bands of 14 rows, shifted where they or their halo would cross the last row: octet_band_y);
-	// the quad (STRIP4_OCTET=0) whole bands of 16
+	// the quad (STRIP4_OCTET=0) whole bands of 16; X = 512: the half-row octet, bands of six rows
+	if (g.Zg > 1 && g.X == 512) return FX_KNOB_INT("STRIP4X", 1) && band_rows_supported(g.Y, X_BAND);
 	if (g.Zg <= 1 || g.X != 256) return false;
 	return FX_KNOB_INT("STRIP4_OCTET", 1) ? octet_rows_supported(g.Y) : ((g.Y & 15) == 0 && g.Y >= 16);
 }
@@ -1191,7 +1432,32 @@ hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b
 	if (!jacobi_strip4_supported(g)) return hipErrorNotSupported;
 	const int forced_chunk = FX_KNOB_INT("STRIP4_ZCHUNK", 0);
 	const int remap = FX_KNOB_INT("STRIP_REMAP", 1);
-	const int ngroups = g.Y / 16;
+	if (g.X == 512) {
+		// one run of band-planes per workgroup, one workgroup (156 KiB of LDS) per CU: 256 runs wherever a run is at least eight planes long
+		Runs4 r;
+		r.bands = (g.Y + X_BAND - 1) / X_BAND; r.nzp = z_end - z_begin;
+		const long long T = (long long)r.bands * r.nzp;
+		if (T >= ((long long)1 << 30)) return hipErrorNotSupported;
+		const int forced_wgs = FX_KNOB_INT("STRIP4X_WGS", 0);
+		r.nwg = forced_wgs > 0 ? forced_wgs : (int)std::min<long long>(256, std::max<long long>(1, T / 8));
+		r.minp = std::min(FX_KNOB_INT("STRIP4X_MINP", 8), std::max(r.nzp / 2, 1));
+		// chunks as long as a run (so that a chunk's runs are its bands), the last one shorter; a stub of a last chunk joins its neighbour;
+		// STRIP4X_ORDER=0: one chunk (band-major runs: every band alone at its depth)
+		// (where a run is shorter than 64 planes the pieces' fill outweighs the traffic saved -- everything is Infinity-Cache resident there:
+		// us per sweep band-major / chunked at 512 x 512 x D: D = 64 17.0 / 20.2, 128 31.1 / 32.7, 256 55.1 / 53.9, 512 100.2 / 96.4)
+		const int run = (int)((T + r.nwg - 1) / r.nwg);
+		const int order = FX_KNOB_INT("STRIP4X_ORDER", -1);
+		int C = (order < 0 ? run >= 64 : order != 0) ? std::min(std::max(run, 1), r.nzp) : r.nzp;
+		if ((r.nzp + C - 1) / C > 8) C = (r.nzp + 7) / 8;
+		r.nch = 0;
+		for (int z = 0; z < r.nzp; z += C) r.zc[r.nch++] = z;
+		if (r.nch > 1 && r.nzp - r.zc[r.nch - 1] < std::max(C / 3, r.minp)) --r.nch;
+		r.zc[r.nch] = r.nzp;
+		for (int i = r.nch + 1; i < 9; ++i) r.zc[i] = r.nzp;
+		hipLaunchKernelGGL(k_jacobi_strip4x, dim3(r.nwg), dim3(512), 0, s, g, p_in, b, p_out, z_begin, r, remap);
+		return hipGetLastError();
+	}
+	const int ngroups = std::max(g.Y / 16, 1);                          // (the quad's; Y = 14 runs the octet)
 	const int nzp = z_end - z_begin;
 	int nchunks = (256 + ngroups - 1) / ngroups;                        // 256 workgroups of four waves: one wave per SIMD
 	int zchunk = forced_chunk > 0 ? forced_chunk : (nzp + nchunks - 1) / nchunks;

@@ -12,7 +12,7 @@ const char* const kNames[] = {
 #endif
 	"FREEZE_DENSE_LEVELS", "FREEZE_DENSE_ONE", "FREEZE_FAST", "FREEZE_FUSE_DIV", "FREEZE_NT", "FREEZE_SHRINK", "FREEZE_STRIP4", "FREEZE_T", "FREEZE_WGS",
 	"JACOBI2D_TILE", "JACOBI_BLOCK", "JACOBI_BLOCKG", "JACOBI_PREFER3", "JACOBI_PREFER4", "JACOBI_T", "LIGHT_FILL", "LIGHT_FILL_DIRTY", "LIGHT_RAY_NT", "LIGHT_RAY_WGS", "PROJECT_V4", "RCCL_ONE_COMM", "ROW_VW",
-	"STRIP3H_PAIRS", "STRIP3_COOP", "STRIP3_NO512", "STRIP3_OFF", "STRIP3_ZCHUNK", "STRIP4_OCTET", "STRIP4_ZCHUNK", "STRIP_GENERIC", "STRIP_R", "STRIP_REMAP", "STRIP_WGS", "STRIP_WIDE",
+	"STRIP3H_PAIRS", "STRIP3_COOP", "STRIP3_NO512", "STRIP3_OFF", "STRIP3_ZCHUNK", "STRIP4X", "STRIP4X_MINP", "STRIP4X_ORDER", "STRIP4X_WGS", "STRIP4_OCTET", "STRIP4_ZCHUNK", "STRIP_GENERIC", "STRIP_R", "STRIP_REMAP", "STRIP_WGS", "STRIP_WIDE",
 	"STRIP_ZCHUNK", "VIEW_ORDER", "VIEW_WGS", "XCD_REMAP" };
 const int kCount = (int)(sizeof kNames / sizeof kNames[0]);
 struct Slot { bool set; char value[48]; };

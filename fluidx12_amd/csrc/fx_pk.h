@@ -19,6 +19,18 @@ __device__ __forceinline__ fx_f2 pk_mov(fx_f2 a, fx_f2 b, int sel)
 	return d;
 }
 
+// the general form: (a[SA], b[SB])
+template <int SA, int SB>
+__device__ __forceinline__ fx_f2 pk_mov_sel(fx_f2 a, fx_f2 b)
+{
+	fx_f2 d;
+	if (SA == 0 && SB == 0) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(d) : "v"(a), "v"(b));
+	else if (SA == 1 && SB == 0) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+	else if (SA == 1 && SB == 1) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(d) : "v"(a), "v"(b));
+	else asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+	return d;
+}
+
 // ((((((L - b) + R) + U) + D) + F) + B) * (1/6) on a float4 column of a row that IS the wave (X = 256): x neighbours by DPP
 // wave_shr:1 / wave_shl:1; the lanes without a source (0 / 63) are the clamped wall cells and keep the DPP's `old` operand.
 // left_own / right_own: that end of the wave's row is a wall (the lane keeps its own cell); otherwise it is the cut of a half-row

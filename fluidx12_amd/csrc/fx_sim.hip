@@ -13,6 +13,7 @@
 // Layout: velocity = 3 component planes (SoA), colour = interleaved rgba texels, pressure and
 // divergence = fp32 planes; x fastest, one wave64 = 64 consecutive x.  All memory-bound: no MFMA.
 #include "fx_internal.h"
+#include <algorithm>
 #include <cstdlib>
 #include <cstdio>
 
@@ -1006,6 +1007,7 @@ int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp)
 	const int forced = FX_KNOB_INT("JACOBI_T", 0);
 	if (jacobi_strip_supported(g) && jacobi_strip_wide(g)) {            // X = 512: one fused shape (two sweeps, wide strips)
 		const int want = requested > 0 ? requested : (forced > 0 ? forced : (strip_profitable(g, nzp) ? 2 : 1));
+		if (want >= 4 && jacobi_strip4_supported(g) && nzp >= 2) return 4;     // four sweeps: the half-row octet (k_jacobi_strip4x, fx_jacobi_strip4.hip)
 		return want >= 3 && jacobi_strip3_supported(g) ? 3 : (want >= 2 ? 2 : 1);
 	}
 	// rows that fit no strip / tile kernel (X no multiple of 4, or not 64 / 128 / 256 wide): the general block-per-wave kernel, two
@@ -1030,6 +1032,8 @@ bool jacobi_prefers_four(const Geom& g, int requested, int nzp)
 	const int forced = FX_KNOB_INT("JACOBI_T", 0);
 	const int prefer = FX_KNOB_INT("JACOBI_PREFER4", 1);
 	const bool octet = FX_KNOB_INT("STRIP4_OCTET", 1) != 0;
+	if (g.X == 512)                                                     // k_jacobi_strip4x: wherever the threes pay (jacobi_prefers_three)
+		return prefer && !requested && !forced && jacobi_strip4_supported(g) && (size_t)g.X * g.Y * (size_t)nzp >= ((size_t)1 << 24);
 	return prefer && !requested && !forced && jacobi_strip4_supported(g) && (size_t)g.X * g.Y * (size_t)nzp >= (octet ? (size_t)3 << 19 : (size_t)9 << 20);
 }
 
@@ -1055,6 +1059,7 @@ hipError_t launch_jacobi_fused(const Geom& g, const float* p_in, const float* b,
 {
 	if (z_end <= z_begin) return hipSuccess;
 	if (jacobi_strip_supported(g) && jacobi_strip_wide(g)) {
+		if (sweeps == 4) return launch_jacobi_strip4(g, p_in, b, p_out, z_begin, z_end, s);
 		if (sweeps == 3 && jacobi_strip3_supported(g)) return launch_jacobi_strip3(g, p_in, b, p_out, z_begin, z_end, s);
 		return sweeps == 2 ? launch_jacobi_strip(g, p_in, b, p_out, 2, z_begin, z_end, s) : hipErrorNotSupported;
 	}
@@ -1079,6 +1084,37 @@ hipError_t launch_jacobi_fused(const Geom& g, const float* p_in, const float* b,
 __global__ __launch_bounds__(256) void k_copy16(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n)
 {
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// fx_field_digest: out[0] += sum mix(bits, key0 + i), out[1] += sum mix'(...) over `count` elements of ES bytes each (splitmix64's
+// finaliser; the sums wrap: order-free, so atomics and any decomposition of the range give the same two words)
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x)
+{
+	x += 0x9E3779B97F4A7C15ull;
+	x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+	x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+	return x ^ (x >> 31);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_digest(const T* __restrict__ v, size_t count, unsigned long long key0, unsigned long long* __restrict__ out)
+{
+	unsigned long long a = 0, c = 0;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+		const unsigned long long h = mix64(((key0 + i) << 32) ^ ((key0 + i) >> 32) ^ ((unsigned long long)v[i] * 0xD6E8FEB86659FD93ull));
+		a += h;
+		c += mix64(h ^ 0xA5A5A5A55A5A5A5Aull);
+	}
+	for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); c += __shfl_down(c, o); }
+	if ((threadIdx.x & 63) == 0) { atomicAdd(out, a); atomicAdd(out + 1, c); }
+}
+
+hipError_t launch_digest(const void* v, size_t count, int elem_bytes, unsigned long long key0, unsigned long long* out, hipStream_t s)
+{
+	if (!count) return hipSuccess;
+	const unsigned grid = (unsigned)std::min<size_t>((count + 255) / 256, 4096);
+	if (elem_bytes == 4) hipLaunchKernelGGL(k_digest<uint32_t>, dim3(grid), dim3(256), 0, s, static_cast<const uint32_t*>(v), count, key0, out);
+	else hipLaunchKernelGGL(k_digest<uint16_t>, dim3(grid), dim3(256), 0, s, static_cast<const uint16_t*>(v), count, key0, out);
+	return hipGetLastError();
 }
 
 hipError_t launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t s)

@@ -231,6 +231,14 @@ class Fluid:
         capi.check(self._lib.fx_download(self._ctx, field, out.ctypes.data_as(C.c_void_p), out.nbytes), "download")
         return out
 
+    def digest(self, field, z_begin=0, z_count=0):
+        """128-bit device-side digest (an int) of global planes [z_begin, z_begin + z_count) of a simulation field -- equal between a
+        slab context and a single-domain context iff the planes agree bit for bit (fx_field_digest); z_count = 0: all owned planes"""
+        self._need()
+        out = (C.c_uint64 * 2)()
+        capi.check(self._lib.fx_field_digest(self._ctx, field, int(z_begin), int(z_count), out), "digest")
+        return (int(out[1]) << 64) | int(out[0])
+
     def upload(self, field, array):
         self._need()
         shape, dt = self._shape(field)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 6   /* 6: fx_comm_init_peer, fx_set_knob / fx_knob_name, FX_OPT_RENDER_ACCEL; the launcher switches no longer come from FLUIDX_* environment variables */
+#define FX_ABI_VERSION 7   /* 7: fx_field_digest; 6: fx_comm_init_peer, fx_set_knob / fx_knob_name, FX_OPT_RENDER_ACCEL, fx_timing.freeze_strip_launches; the launcher switches no longer come from FLUIDX_* environment variables */
 
 enum fx_status {
 	FX_OK = 0,
@@ -187,6 +187,14 @@ int fx_synchronize(fx_ctx* ctx);
 int fx_upload(fx_ctx* ctx, int field, const void* host, size_t bytes);
 int fx_download(fx_ctx* ctx, int field, void* host, size_t bytes);
 size_t fx_field_bytes(fx_ctx* ctx, int field);
+/* A 128-bit digest of global planes [z_begin, z_begin + z_count) of a simulation field (VELOCITY .. DIVERGENCE), computed ON THE DEVICE
+ * from the stored bits (fp16 storage: the fp16 bits) and each element's GLOBAL position: a sum over the elements of a 64-bit mix of
+ * (bits, global element index), twice with different seeds.  The sum does not depend on how the planes are spread over contexts, so
+ * a slab rank's digest of its owned planes equals the single-domain context's digest of the same planes if and only if (to 2^-128)
+ * the fields agree bit for bit -- what `bench.py --gpus N` certifies its timed steps with, without reading 0.5 GB per rank back.
+ * The planes must be owned by this context (FX_E_INVALID otherwise); z_count = 0 = all owned planes from z_begin = the first.
+ * Blocks like fx_download; FX_E_HALO while a halo fault is pending. */
+int fx_field_digest(fx_ctx* ctx, int field, uint32_t z_begin, uint32_t z_count, uint64_t out[2]);
 
 /* Checkpoint / resume (the reference keeps no state across runs).  One file holds what a later
  * fx_simulate depends on -- velocity[0], colour[parity], pressure (Fluid.cpp:360-384) -- for the WHOLE grid, dense fp32 in the

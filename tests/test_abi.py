@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(capi.SYMBOLS), "capi.SYMBOLS and include/fluidx_hip.h disagree"
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.fx_abi_version() == capi.ABI_VERSION == 6
+    assert lib.fx_abi_version() == capi.ABI_VERSION == 7
     assert lib.fx_error_string(-6).decode().startswith("advection")
 
 

@@ -16,7 +16,7 @@ def load_bench():
 
 def test_kernel_source_hash_names_every_profiled_kernel():
     from fluidx12_amd.build import kernel_source_hash
-    for k in ("k_jacobi_strip4o", "k_jacobi_strip4q", "k_jacobi_strip3c", "k_jacobi_strip3h", "k_jacobi_block2", "k_jacobi_blockg", "k_advect_lds", "k_divergence_v4",
+    for k in ("k_jacobi_strip4o", "k_jacobi_strip4x", "k_jacobi_strip4q", "k_jacobi_strip3c", "k_jacobi_strip3h", "k_jacobi_block2", "k_jacobi_blockg", "k_advect_lds", "k_divergence_v4",
               "k_project_v4", "k_freeze_dense", "k_freeze_tiles", "k_jacobi_strip2u", "k_raymarch_light", "k_raymarch_view"):
         h = kernel_source_hash(k)
         assert h and len(h) == 16, k
@@ -47,6 +47,18 @@ def test_stale_summary_is_flagged_and_not_used(tmp_path, monkeypatch):
     sq["kernels"][k]["source_hash"] = kernel_source_hash(k)
     (prof / "r09c_sq_counters.json").write_text(json.dumps(sq))
     assert b.limiter_note(k) == "issuing (r09c_sq_counters.json)"
+
+
+def test_bench_line_carries_both_truths_and_certifies_multi_rank_runs():
+    """VERDICT round 5, items 4 and 7 (source-level: no GPU here; the GPU tests assert the values): the line has `value_cold` and
+    `warm_device` beside `value`, the developed plume its own stage times, the default flags are SURVEY 8(d)'s 32 + 100, the device
+    wake-up is opt-in, and every N > 1 line carries `multi_rank_parity` with a non-zero exit code on a mismatch"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ('"value_cold"', '"warm_device"', '"stage_ms_per_step"', '"multi_rank_parity"', '"rccl"'):
+        assert key in src, key
+    assert 'add_argument("--warmup", type=int, default=32)' in src and 'add_argument("--steps", type=int, default=100)' in src
+    assert 'add_argument("--preheat", action="store_true"' in src and "args.preheat and not args.no_preheat" in src
+    assert "raise SystemExit(parity_rc)" in src
 
 
 def test_committed_summaries_of_the_headline_kernels_are_fresh():

@@ -33,6 +33,7 @@ def test_bench_two_ranks_gloo_dry_run():
     assert d["scaling"] == "weak" and d["unit"] == "voxel-updates/s" and d["higher_is_better"] is True
     assert d["config"]["parallelism"].startswith("z-slab x2")
     assert "cpu_baseline" not in d                        # rank 0 at N = 1 only
+    assert d["multi_rank_parity"].startswith("not checked (dry run")    # the key every N > 1 line carries; a GPU run replays the steps as one domain
 
 
 def test_slab_partition_covers_the_grid():

@@ -66,6 +66,26 @@ def test_bench_under_torchrun_shared_gpu(nranks, steps, mock_lib, tmp_path):
     assert [c["overlap"] for c in sc["candidates"]] == [0, 0, 1, 2, 2]          # the plainest schedule first
     assert "link_model" in sc and sc["exchange_calls_per_step"] > 0
     assert r.stderr.count("bench.py candidate: {") == 5                      # one line per candidate as it completes
+    # the line certifies what it timed: every rank's owned planes == the same planes of ONE domain stepped through the same frames
+    assert d["multi_rank_parity"] == "bit-identical" and d["multi_rank_parity_detail"]["ranks"] == nranks
+    assert d["multi_rank_parity_detail"]["steps_replayed"] == 5 * 4 + 1 + steps
+
+
+def test_bench_notices_a_corrupted_halo(mock_lib, tmp_path):
+    """bits of one halo message flip on their way to rank 1 (mock fault injection): the run still finishes and prints its line, but the
+    line names the rank and the field, and the exit code is 4"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", FLUIDX_RCCL_LIB=mock_lib, FXMOCK_DIR=str(tmp_path), FXMOCK_TIMEOUT_S="120",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", FXMOCK_CORRUPT="1:40")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "64", "--steps", "3", "--warmup", "1", "--shared-gpu"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    shutil.rmtree(tmp_path, ignore_errors=True)
+    assert "corrupted one byte" in r.stderr, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["multi_rank_parity"] != "bit-identical" and "differs from the single-domain replay" in d["multi_rank_parity"]
+    assert r.returncode != 0
 
 
 def test_mock_flags_a_byte_count_mismatch(mock_lib, tmp_path):

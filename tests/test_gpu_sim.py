@@ -94,18 +94,15 @@ def test_jacobi_sweep_counts(iters):
 
 @pytest.mark.parametrize("dims", [(256, 256, 200), (512, 512, 100), (256, 256, 193), (256, 256, 257), (512, 512, 97), (512, 512, 131)])
 def test_default_schedule_of_large_grids_is_bit_identical(dims):
-    """grids large enough for the multi-sweep strip kernels: X = 512 runs N sweeps as threes + twos (+ a single): 4 = 2 + 2, 5 = 3 + 2,
-    7 = 3 + 2 + 2, ...; X = 256 as fours (k_jacobi_strip4o) with remainders 5 = 3 + 2, 6 = 3 + 3, 7 = 4 + 3; every count equals N launches
-    of one sweep bit for bit"""
+    """grids large enough for the multi-sweep strip kernels run N sweeps as fours (X = 256: k_jacobi_strip4o, X = 512: k_jacobi_strip4x)
+    with remainders 5 = 3 + 2, 6 = 3 + 3, 7 = 4 + 3; every count equals N launches of one sweep bit for bit"""
     X, Y, Z = dims
     rng = np.random.default_rng(31)
     p = rng.standard_normal((Z, Y, X)).astype(f32)
     b = rng.uniform(-1, 1, (Z, Y, X)).astype(f32)
     ref = make(dims, jacobi_fuse=1)
     dut = make(dims)                                     # default schedule
-    expect = {1: (1, 1), 2: (1, 2), 3: (1, 3), 4: (2, 4), 5: (2, 5), 7: (3, 7), 8: (3, 8), 10: (4, 10)}
-    if X == 256:
-        expect = {1: (1, 1), 2: (1, 2), 3: (1, 3), 4: (1, 4), 5: (2, 5), 6: (2, 6), 7: (2, 7), 8: (2, 8), 10: (3, 10), 13: (4, 13)}
+    expect = {1: (1, 1), 2: (1, 2), 3: (1, 3), 4: (1, 4), 5: (2, 5), 6: (2, 6), 7: (2, 7), 8: (2, 8), 10: (3, 10), 13: (4, 13)}
     for iters, (launches, sweeps) in expect.items():
         for f in (ref, dut):
             f.upload(fx.FIELD_PRESSURE, p)
@@ -212,29 +209,111 @@ def test_x256_four_sweeps_at_odd_depths_bit_exact(depth, kernel, knob):
     assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
 
 
-@pytest.mark.parametrize("rows", [14, 15, 16, 17, 18, 19, 27, 28, 29, 30, 31, 44, 45, 58, 100, 128, 240, 254])
-def test_x256_four_sweeps_on_rows_that_do_not_tile_the_bands_bit_exact(rows):
-    """the octet's bands of 14 rows on row counts they do not tile.  Y % 14 = 1 or 2 (29, 30, 44, 58, 128, 240): the lower halo of the
-    second-to-last band would reach beyond the last row -- that band is shifted up like the last one (octet_band_y; round 5 computed
-    level-l rows behind the wall from clamped loads and let two workgroups store different bits to one address: ADVICE round 5).
-    Y = 15, 16 fit no placement (the last band's upper halo would cross the first row): jacobi_fuse = 4 is refused there and the default
-    schedule runs other kernels.  == oracle bit for bit, twice (a race between the two writers of a shared row would not repeat)"""
-    depth = 21
-    dims = (256, rows, depth)
-    _, _, p = rand_state(*dims, 51)
-    b = np.random.default_rng(52).uniform(-1, 1, (depth, rows, 256)).astype(f32)
+def strip4_direct(dims, p, b, launches=2):
+    """fx::launch_jacobi_strip4 called directly (the C++ launcher through its mangled name, device memory from torch): the C ABI only
+    takes square planes (grid_x == grid_y, Fluid.cpp:201), the kernels any row count -- what a slab or a future caller may hand them"""
+    import ctypes
+    import re
+    import subprocess
+    import torch
+    from fluidx12_amd import build, capi
+    capi.load()
+    out = subprocess.run(["nm", "-D", "--defined-only", build.LIB], capture_output=True, text=True, check=True).stdout
+    names = re.findall(r"\b(_ZN2fx20launch_jacobi_strip4E\w+)", out)
+    assert len(names) == 1, names
+    fn = getattr(ctypes.CDLL(build.LIB), names[0])
+    fn.restype = ctypes.c_int
+
+    class Geom(ctypes.Structure):                  # fx_internal.h struct Geom
+        _fields_ = [(n, ctypes.c_int) for n in ("X", "Y", "Zg", "z0", "nz", "H", "zlo", "zhi")]
+    X, Y, Z = dims
+    g = Geom(X, Y, Z, 0, Z, 0, 0, Z - 1)
+    tb = torch.from_numpy(b).to("cuda")
+    bufs = [torch.from_numpy(p).to("cuda"), torch.full((Z, Y, X), 7.0, dtype=torch.float32, device="cuda")]
+    vp = ctypes.c_void_p
+    for k in range(launches):
+        rc = fn(ctypes.byref(g), vp(bufs[k & 1].data_ptr()), vp(tb.data_ptr()), vp(bufs[(k + 1) & 1].data_ptr()), ctypes.c_int(0), ctypes.c_int(Z), vp(0))
+        if rc != 0:
+            return rc, None
+    torch.cuda.synchronize()
+    return 0, bufs[launches & 1].cpu().numpy()
+
+
+def explain(got, want):
+    bad = np.argwhere(got != want)
+    return (len(bad), bad[:5].tolist(), "x halves", np.unique(bad[:, 2] // 256).tolist(), "rows", np.unique(bad[:, 1])[:24].tolist(), "planes", np.unique(bad[:, 0])[:24].tolist())
+
+
+@pytest.mark.parametrize("dims", [(512, 512, 2), (512, 512, 5), (512, 512, 9), (512, 512, 21), (512, 512, 40)])
+def test_x512_four_sweeps_bit_exact(dims):
+    """X = 512, FOUR sweeps per launch (k_jacobi_strip4x: the octet's pipeline on half-row waves, the x cut inside the workgroup -- input
+    cells across it fetched with the plane, the cells of levels 1..3 through 16-byte LDS slots under the edge rows' counters): odd and tiny
+    depths (runs of unequal length, pieces that cross into the next band, fill and drain at both faces; 512 rows = 85 bands of six + a
+    shifted last band, and the band before it shifted as well: its halo would cross the last row), 8 = 4 + 4 sweeps; == oracle bit for
+    bit, twice (two writers of a shared row racing would not repeat)"""
+    X, Y, Z = dims
+    _, _, p = rand_state(X, Y, Z, 61)
+    b = np.random.default_rng(62).uniform(-1, 1, (Z, Y, X)).astype(f32)
     q, _ = orc.jacobi(p, b, 8)
-    four = rows == 14 or rows >= 17
-    f = make(dims, jacobi_iters=8, jacobi_fuse=4 if four else 0)
+    f = make(dims, jacobi_iters=8, jacobi_fuse=4)
     for _ in range(2):
         f.upload(fx.FIELD_PRESSURE, p)
         f.upload(fx.FIELD_DIVERGENCE, b)
         f.timing_enable(True); f.timing_read(True)
         f.Jacobi(8)
         f.Synchronize()
-        if four:
-            assert f.timing_read(True).jacobi_launches == 2
-        assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
+        assert f.timing_read(True).jacobi_launches == 2
+        got = f.download(fx.FIELD_PRESSURE)
+        assert np.array_equal(got, q), explain(got, q)
+
+
+@pytest.mark.parametrize("dims", [(512, 6, 21), (512, 9, 12), (512, 10, 12), (512, 11, 12), (512, 12, 12), (512, 13, 33), (512, 14, 12), (512, 20, 12),
+                                  (512, 31, 17), (512, 100, 50), (512, 256, 64), (512, 510, 11), (512, 511, 11), (512, 513, 11)])
+def test_x512_four_sweeps_on_any_row_count_bit_exact(dims):
+    """the half-row octet's bands of six rows on row counts they tile and do not tile (the launcher called directly: the C ABI takes square
+    planes only); Y = 7, 8 fit no placement and are refused"""
+    X, Y, Z = dims
+    _, _, p = rand_state(X, Y, Z, 65)
+    b = np.random.default_rng(66).uniform(-1, 1, (Z, Y, X)).astype(f32)
+    q, _ = orc.jacobi(p, b, 8)
+    for _ in range(2):
+        rc, got = strip4_direct(dims, p, b)
+        assert rc == 0
+        assert np.array_equal(got, q), explain(got, q)
+    assert strip4_direct((512, 7, 4), p[:4, :7].copy(), b[:4, :7].copy())[0] != 0
+
+
+@pytest.mark.parametrize("wgs", [1, 7, 64, 200, 256, 300])
+def test_x512_four_sweeps_any_number_of_runs(wgs, knob):
+    """the band-planes of a launch are cut into one contiguous run per workgroup; any number of runs gives the same bits"""
+    knob("STRIP4X_WGS", str(wgs))
+    dims = (512, 100, 30)
+    _, _, p = rand_state(*dims, 63)
+    b = np.random.default_rng(64).uniform(-1, 1, (30, 100, 512)).astype(f32)
+    q, _ = orc.jacobi(p, b, 4)
+    rc, got = strip4_direct(dims, p, b, launches=1)
+    assert rc == 0 and np.array_equal(got, q), explain(got, q)
+
+
+@pytest.mark.parametrize("rows", [14, 15, 16, 17, 18, 19, 27, 28, 29, 30, 31, 44, 45, 58, 100, 128, 240, 254])
+def test_x256_four_sweeps_on_rows_that_do_not_tile_the_bands_bit_exact(rows):
+    """the octet's bands of 14 rows on row counts they do not tile (the launcher called directly: the C ABI takes square planes only).
+    Y % 14 = 1 or 2 (29, 30, 44, 58, 128, 240): the lower halo of the second-to-last band would reach beyond the last row -- that band is
+    shifted up like the last one (octet_band_y; round 5 computed level-l rows behind the wall from clamped loads and let two workgroups
+    store different bits to one address: ADVICE round 5).  Y = 15, 16 fit no placement (the last band's upper halo would cross the first
+    row) and are refused.  == oracle bit for bit, twice (a race between the two writers of a shared row would not repeat)"""
+    depth = 21
+    dims = (256, rows, depth)
+    _, _, p = rand_state(*dims, 51)
+    b = np.random.default_rng(52).uniform(-1, 1, (depth, rows, 256)).astype(f32)
+    q, _ = orc.jacobi(p, b, 8)
+    for _ in range(2):
+        rc, got = strip4_direct(dims, p, b)
+        if rows in (15, 16):
+            assert rc != 0
+            return
+        assert rc == 0
+        assert np.array_equal(got, q), explain(got, q)
 
 
 @pytest.mark.parametrize("kernel", ["octet", "quad"])
@@ -433,7 +512,7 @@ def test_x512_full_step_against_oracle():
     f.Jacobi(80)
     f.Synchronize()
     t = f.timing_read(True)
-    assert t.jacobi_sweeps == 80 and t.jacobi_launches == 27 and t.jacobi_main_sweeps == 78      # 26 x 3 + 1 x 2
+    assert t.jacobi_sweeps == 80 and t.jacobi_launches == 20 and t.jacobi_main_sweeps == 80      # 20 x 4 (k_jacobi_strip4x)
     q, _ = orc.jacobi(p, b, 80)
     assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
     f.Project()

@@ -175,9 +175,8 @@ def test_uneven_slabs_and_fp16():
 @pytest.mark.parametrize("overlap", [1, 2])
 @pytest.mark.parametrize("dims", [(256, 256, 400), (512, 512, 260)])
 def test_thick_slabs_take_the_three_sweep_kernel(dims, overlap):
-    """slabs of >= 12.6 M cells at X = 256 run their serial rounds as 4 + 4 sweeps (k_jacobi_strip4o), slabs of >= 25 M at X = 512 as
-    3 + 3 + 2 (k_jacobi_strip3h), on the shrinking trapezoid ranges, halo planes included: bit-identical to one sweep per launch on the
-    single domain"""
+    """thick slabs run their serial rounds as 4 + 4 sweeps (X = 256: k_jacobi_strip4o from 1.5 M cells, X = 512: k_jacobi_strip4x from 16.8 M)
+    on the shrinking trapezoid ranges, halo planes included: bit-identical to one sweep per launch on the single domain"""
     ref = run_single(dims, 2, jacobi_iters=19, jacobi_fuse=1)
     fl = run_slabs(dims, 2, 2, jacobi_iters=19, halo_jacobi=8, halo_advect=8, overlap=overlap)
     fl[0].timing_enable(True)
@@ -186,10 +185,7 @@ def test_thick_slabs_take_the_three_sweep_kernel(dims, overlap):
     fl[0].Synchronize()
     t = fl[0].timing_read()
     if overlap == 1:
-        if dims[0] == 256:
-            assert t.jacobi_sweeps == 19 and t.jacobi_launches == 5 and t.jacobi_main_sweeps == 19  # 4+4, 4+4, 3 (no launch of a round is shorter than the one before it)
-        else:
-            assert t.jacobi_sweeps == 19 and t.jacobi_launches == 7 and t.jacobi_main_sweeps == 15  # 3+3+2, 3+3+2, 3
+        assert t.jacobi_sweeps == 19 and t.jacobi_launches == 5 and t.jacobi_main_sweeps == 19  # 4+4, 4+4, 3 (no launch of a round is shorter than the one before it)
     # overlap 2: the interior of every round runs as 2 + 3 + 3 beside the single-sweep face chains
     ref.UpdateFrame(f32(ref.default_time_step()), 2)
     ref.Simulate(2)
@@ -395,6 +391,14 @@ def test_bench_multi_rank_path_in_loopback():
     sched = d["config"]["schedule"]
     assert len(sched["candidates"]) == 5 and (sched["overlap"], sched["jacobi_round"]) in [(1, 8), (2, 8), (2, 4), (0, 8), (0, 4)]
     assert d["value"] > 0 and d["scaling"] == "weak"
+    # the line certifies its timed steps: each slab's owned planes == the same planes of ONE domain stepped through the same frames
+    assert d["multi_rank_parity"] == "bit-identical" and d["multi_rank_parity_detail"]["steps_replayed"] == 5 * 4 + 1 + 3
+    # ... and says so when they are not (fault injection: one bit of slab 1's pressure flips behind the timed steps): exit code 4
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--loopback", "2", "--grid", "64", "--iters", "8", "--steps", "3", "--warmup", "1",
+                          "--schedule", "0,8"], capture_output=True, text=True, timeout=300, cwd=root, env=dict(os.environ, FLUIDX_BENCH_FAULT="corrupt:1"))
+    assert bad.returncode == 4, (bad.returncode, bad.stderr[-1500:])
+    db = json.loads([l for l in bad.stdout.splitlines() if l.startswith("{")][-1])
+    assert db["multi_rank_parity"].startswith("rank 1: pressure of planes [64, 128) differs")
 
 
 @pytest.mark.parametrize("overlap", [3, 2, 0])
@@ -579,6 +583,7 @@ def test_bench_config4_in_loopback():
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["config"]["grid"] == [512, 512, 512] and d["config"]["jacobi_iters"] == 80
     assert "64 planes per rank" in d["config"]["parallelism"] and d["value"] > 0
+    assert d["multi_rank_parity"] == "bit-identical"          # eight slabs of 512 x 512 x 64 == the single 512^3 domain
 
 
 def test_bench_single_gpu_line_is_complete():
@@ -615,6 +620,11 @@ def test_bench_single_gpu_line_is_complete():
     # ... and the step is timed once more on the developed plume (frames 133-152), beside `value`
     dv = d["developed_plume"]
     assert dv["frames"] == [133, 152] and dv["ms_per_step"] > 0 and dv["value"] == pytest.approx(128 ** 3 / (dv["ms_per_step"] * 1e-3))
+    assert dv["marked_steps"] == 5 and all(dv["stage_ms_per_step"][k] > 0 for k in ("advect", "divergence", "jacobi", "project"))
+    # both truths: `value` is the contract's protocol and nothing else (no device wake-up in front of it: `value_cold` says it again),
+    # the same steps on a device that is awake are `warm_device`
+    assert d["device_preheat"] is None and d["value_cold"] == d["value"]
+    assert d["warm_device"]["value"] > 0 and d["warm_device"]["ms_per_step"] > 0
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
 
 
