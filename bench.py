@@ -137,6 +137,11 @@ def workload_grid(G, N, scaling):
         return (G, G, G), 0
     if scaling == "strong":
         return (G, G, G), (8 if G >= 512 else 0)      # 512^3: measured z reach 5.1 cells over 600 steps; 0 = the library default (6)
+    if scaling == "weak256":
+        # ONE kernel family over the whole table: G x G x (G N) for every N (the default table's N = 8 point is (2G)^3 -- other row length,
+        # other kernels: a kink there is the kernels', not the links').  Halo: the z reach grows with the depth (dt = 2 / Y, reach in cells
+        # ~ Z): 11.9 / 18.8 cells measured at N = 2 / 4 (tools/reach_probe.py), twice the N = 4 figure assumed at N = 8; FX_E_HALO if wrong.
+        return (G, G, G * N), {2: 16, 4: 22, 8: 44}.get(N, 6 * N + 2)
     table = {2: ((G, G, 2 * G), 16), 4: ((G, G, 4 * G), 22), 8: ((2 * G, 2 * G, 2 * G), 8)}
     return table.get(N, ((G, G, G * N), 6 * N + 2))
 
@@ -158,10 +163,12 @@ BASELINE_CONFIGS = {2: (128, 40, "fp32"), 3: (256, 40, "fp32"), 4: (512, 80, "fp
 
 
 def pressure_round(GX, nz_per_rank, iters):
-    """sweeps per pressure exchange.  Slab ranks thick enough for the three-sweep kernels (X = 256 from 12.6 M cells, X = 512 from
-    16.8 M -- a 64-plane rank of BASELINE configs[3]) take rounds of 9 = 3 + 3 + 3 instead of 8 = 3 + 3 + 2; everything else keeps
-    the library default of 8."""
+    """sweeps per pressure exchange: the library default of 8 = 4 + 4 sweeps (k_jacobi_strip4o / k_jacobi_strip4x).  With the four-sweep
+    kernels switched off (FLUIDX_JACOBI_PREFER4=0), slab ranks thick enough for the three-sweep kernels (X = 256 from 12.6 M cells,
+    X = 512 from 16.8 M -- a 64-plane rank of BASELINE configs[3]) take rounds of 9 = 3 + 3 + 3 instead of 8 = 3 + 3 + 2."""
     three = (GX == 256 and GX * GX * nz_per_rank >= 3 << 22) or (GX == 512 and GX * GX * nz_per_rank >= 1 << 24)
+    if os.environ.get("FLUIDX_JACOBI_PREFER4", "1") != "0":
+        return 8                                 # round 6: both row lengths have four-sweep kernels from these sizes on: 8 = 4 + 4 (9 would be 4 + 3 + 2)
     return 9 if (three and iters >= 9) else 8
 
 
@@ -242,7 +249,9 @@ def main():
     ap.add_argument("--address", default="clamp", choices=["clamp", "mirror"], help="advection sampler (FluidEZ = clamp, Fluid = mirror)")
     ap.add_argument("--reference-config", action="store_true",
                     help="the configuration the reference itself runs (Fluid.cpp:207-221, CSProject3D.hlsl:13): --mode faithful --iters 64 --storage fp16")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="how the grid grows with --gpus (N > 1)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong", "weak256"],
+                    help="how the grid grows with --gpus (N > 1): weak = 16.8 M voxels per GPU (N = 8: the 512^3 of BASELINE configs[3]); weak256 = the "
+                         "same on ONE kernel family, G x G x (G N) for every N; strong = the same G^3 for every N")
     ap.add_argument("--schedule", default="auto", help="N > 1: 'auto' times the slab schedules below for 3 steps each before the "
                     "warm-up and keeps the fastest, or 'OVERLAP,ROUND' (fx_set_option values) to pin one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -893,7 +902,7 @@ def main():
             sweeps_per_launch = main_sw / main_l
             names = {1: ["k_jacobi_generic"] if (args.mode == "faithful" or GX % 4 or GZ == 1) else ["k_jacobi_v4"],
                      2: (["k_jacobi_strip2h"] if GX == 512 else ["k_jacobi_block2"] if GX == 128 else ["k_jacobi_blockg"] if GX not in (64, 256) else []) + ["k_jacobi_strip2u", "k_jacobi_strip"],
-                     4: (["k_jacobi_strip4o"] if os.environ.get("FLUIDX_STRIP4_OCTET", "1") != "0" else []) + ["k_jacobi_strip4q"],
+                     4: ["k_jacobi_strip4x"] if GX == 512 else (["k_jacobi_strip4o"] if os.environ.get("FLUIDX_STRIP4_OCTET", "1") != "0" else []) + ["k_jacobi_strip4q"],
                      3: (["k_jacobi_strip3h"] if GX == 512 else ["k_jacobi_strip3c"] if (GX == 256 and GY % 8 == 0 and os.environ.get("FLUIDX_STRIP3_COOP", "1") != "0") else []) + ["k_jacobi_strip3", "k_jacobi_strip"]}
             cands = names.get(int(round(sweeps_per_launch)), ["k_jacobi_strip"]) if abs(sweeps_per_launch - round(sweeps_per_launch)) < 1e-9 else ["k_jacobi_strip"]
             tr = None
@@ -991,7 +1000,8 @@ def main():
             "n_gpus": N if (not loop or args.peer_devices) else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
             "higher_is_better": True,
-            "scaling": args.scaling if N > 1 else "weak",
+            "scaling": ("weak" if args.scaling == "weak256" else args.scaling) if N > 1 else "weak",
+            "scaling_table": args.scaling if N > 1 else None,
             "vs_baseline": None,
             "dtype": "f32" if args.storage == "fp32" else "f32 arithmetic / f16 field storage",
             "value_cold": (voxels / elapsed if not args.dry_run else 0.0) if preheat is None else None,   # = `value` unless --preheat was asked for

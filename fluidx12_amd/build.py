@@ -23,6 +23,11 @@ HEADERS = ["fx_internal.h", "fx_context.h", "fx_host.h", "fx_hostmath.h", "fx_pk
 # says fmaf(); everything else is separately rounded, like the oracle.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__"]
+# FLUIDX_BUILD_LAB=1: the lab build -- every A/B switch of the launchers (fx_knobs.cpp) and the superseded kernels kept as their baselines
+# (k_jacobi_strip4q ...).  The shipped library has ten switches and none of those kernels.
+LAB = os.environ.get("FLUIDX_BUILD_LAB", "0") == "1"
+if LAB:
+    FLAGS = FLAGS + ["-DFX_LAB"]
 
 
 # per-source additions.  The strip kernels run one wave per SIMD with ~300 registers: the machine scheduler's default

@@ -63,6 +63,7 @@ SYMBOLS = {
     "fx_render": (C.c_int, [_vp, _vp, C.c_uint8, C.c_uint8]),
     "fx_get_frame_info": (C.c_int, [_vp, C.POINTER(FrameInfo)]),
     "fx_synchronize": (C.c_int, [_vp]),
+    "fx_last_error": (C.c_char_p, [_vp]),
     "fx_upload": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
     "fx_download": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
     "fx_field_bytes": (C.c_size_t, [_vp, C.c_int]),
@@ -94,6 +95,12 @@ SYMBOLS = {
 }
 
 _lib = None
+# the launcher switches that exist in lab builds only (fx_knobs.cpp, -DFX_LAB)
+LAB_KNOBS = {"ADVECT_BLOCK", "ADVECT_FAST", "ADVECT_LDS_HALF", "ADVECT_TILE_ROWS", "ADVECT_ZCHUNK", "BLOCK_REMAP", "BLOCK_SHAPE", "DEBUG_NO_COPY",
+             "FREEZE_DENSE_LEVELS", "FREEZE_DENSE_ONE", "FREEZE_FAST", "FREEZE_FUSE_DIV", "FREEZE_NT", "FREEZE_SHRINK", "FREEZE_T", "FREEZE_WGS",
+             "JACOBI2D_TILE", "JACOBI_BLOCK", "JACOBI_BLOCKG", "LIGHT_FILL_DIRTY", "LIGHT_RAY_NT", "LIGHT_RAY_WGS", "PROJECT_V4", "ROW_VW",
+             "STRIP3H_PAIRS", "STRIP3_COOP", "STRIP3_NO512", "STRIP3_OFF", "STRIP3_ZCHUNK", "STRIP4X", "STRIP4X_MINP", "STRIP4X_ORDER", "STRIP4X_WGS",
+             "STRIP4_OCTET", "STRIP4_ZCHUNK", "STRIP_GENERIC", "STRIP_R", "STRIP_REMAP", "STRIP_WGS", "STRIP_WIDE", "STRIP_ZCHUNK", "VIEW_ORDER", "VIEW_WGS", "XCD_REMAP"}
 
 
 def lib_path():
@@ -129,10 +136,16 @@ def load():
     _lib = lib
     # the launcher switches (fx_set_knob) are process-wide values inside the library, which reads no environment for them; the tools'
     # habit of `FLUIDX_<NAME>=... python tools/...` is served here, once, by the harness
-    for name in knob_names():
+    offered = knob_names()
+    for name in offered:
         v = os.environ.get("FLUIDX_" + name)
         if v is not None:
             set_knob(name, v)
+    # ... and a tool that asks for a lab switch on the shipped library is told so instead of measuring the default twice
+    import sys
+    for k in os.environ:
+        if k.startswith("FLUIDX_") and k[7:] in LAB_KNOBS and k[7:] not in offered:
+            sys.stderr.write("fluidx12_amd: %s is a lab-build switch (FLUIDX_BUILD_LAB=1 python -m fluidx12_amd.build); this library ignores it\n" % k)
     return lib
 
 

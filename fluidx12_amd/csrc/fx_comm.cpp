@@ -273,7 +273,9 @@ struct RcclTransport : Transport {
 					if (comm2 && comm2 != comm) (void)api->CommAbort(comm2);
 					if (comm) (void)api->CommAbort(comm);
 				}
-				comm = comm2 = nullptr;                    // (aborted communicators are freed by ncclCommAbort: the destructor must not touch them)
+				// (aborted communicators are freed by ncclCommAbort: the destructor must not touch them.  A library without ncclCommAbort leaves
+				// a broken communicator behind: ncclCommDestroy on it can hang in its release path, so it is LEAKED rather than destroyed)
+				comm = comm2 = nullptr;
 			}
 		}
 		if (dead) { if (err) *err = dead_why; return FX_E_COMM; }
@@ -286,7 +288,8 @@ struct RcclTransport : Transport {
 		// -- through the closed connections -- its neighbours wait on it for ever
 		if (!dead) {
 			dead = true; dead_why = c->last_error + "; the communicators were aborted";
-			if (api->CommAbort) { if (comm2 && comm2 != comm) (void)api->CommAbort(comm2); if (comm) (void)api->CommAbort(comm); comm = comm2 = nullptr; }
+			if (api->CommAbort) { if (comm2 && comm2 != comm) (void)api->CommAbort(comm2); if (comm) (void)api->CommAbort(comm); }
+			comm = comm2 = nullptr;                        // (with or without ncclCommAbort: a broken communicator is never handed to ncclCommDestroy -- leaked rather than hung)
 		}
 		return FX_E_COMM;
 	}

@@ -304,8 +304,9 @@ static int wait_for_device(fx_ctx* c)
 	for (hipStream_t s : streams) {
 		if (!s) continue;
 		hipEvent_t e;
-		if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess || hipEventRecord(e, s) != hipSuccess) { rc = FX_E_DEVICE; break; }
-		evs.push_back(e);
+		if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rc = FX_E_DEVICE; break; }
+		evs.push_back(e);                                                   // (owned from here on: destroyed below whatever happens)
+		if (hipEventRecord(e, s) != hipSuccess) { rc = FX_E_DEVICE; break; }
 	}
 	for (size_t i = 0; i < evs.size() && rc == FX_OK;) {
 		const hipError_t q = hipEventQuery(evs[i]);
@@ -319,6 +320,8 @@ static int wait_for_device(fx_ctx* c)
 	if (rc == FX_OK && (rc = t->poll_error(&c->last_error)) == FX_OK && hipDeviceSynchronize() != hipSuccess) rc = FX_E_DEVICE;
 	return rc;
 }
+
+const char* fx_last_error(fx_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
 int fx_synchronize(fx_ctx* ctx)
 {
@@ -427,6 +430,10 @@ int fx_upload(fx_ctx* ctx, int field, const void* host, size_t bytes)
 	if (bytes != need) return FX_E_INVALID;
 	DeviceGuard dg(ctx->device);
 	FX_HIP(hipDeviceSynchronize());
+	// a state that comes from outside (a test's fields, a checkpoint): what the sparse solver had learnt about the OLD state's relaxing
+	// tiles -- how many masked strip launches a solve takes, a count still on its way -- starts over, so that the launch sequence is a
+	// function of (the uploaded state, the steps since) on every run
+	if (field <= FX_FIELD_DIVERGENCE) { ctx->fz_dense_n = 0; ctx->fz_active_pending = false; }
 	const size_t n = ctx->g.cells_owned(), off = (size_t)ctx->g.H * ctx->g.plane(), cl = ctx->g.cells_local();
 	const size_t es = elem_size(ctx);
 	switch (field) {

@@ -358,6 +358,9 @@ __device__ __forceinline__ void hand_over4(const Strip4<R>& st, Mail4<R>& m, con
 		}
 	}
 #ifndef FX_S4_BARRIER
+#ifdef FX_LAB_DROP_PUBLISH
+	if (L == 2 && w == 3) return;                                       // (fault injection, tests/test_gpu_faults.py: wave 3 never posts level 2 -- its neighbours' waits must run out LOUDLY)
+#endif
 	if (st.lane == 0) lds_post4(st.xf0 + 4u * (uint32_t)((L - 1) * R::NW + w), q);        // LDS operations of a wave execute in order
 #endif
 }
@@ -1336,12 +1339,13 @@ __global__ __launch_bounds__(512, 2) void k_jacobi_strip4x(const Geom g, const f
 			run_locate(runs, t1 - 1, band, zoff, left);                   // the piece that ends the run
 			int pz0 = 0;
 			{ int i = 0; while (i + 1 < runs.nch && zoff >= runs.zc[i + 1]) ++i; pz0 = runs.zc[i]; }
-			// (the eighth piece of a run -- there is none in any shape the launcher makes -- would take all that is left of its band's chunk)
-			const int zfirst = n == MAXP - 1 ? pz0 : max(pz0, zoff - (t1 - 1 - t0));
+			const int zfirst = max(pz0, zoff - (t1 - 1 - t0));
 			piece[n][0] = z_begin + zfirst; piece[n][1] = zoff - zfirst + 1; piece[n][2] = band_y(band, runs.bands, g.Y, X_BAND);
 			t1 -= zoff - zfirst + 1;
 			++n;
 		}
+		// (the launcher makes runs of at most seven pieces; planes left over here would be planes nobody sweeps: loud, like a hand-over that times out)
+		if (t0 < t1) strip4_raise_fault();
 		npiece = n;
 	}
 	__syncthreads();
@@ -1373,6 +1377,7 @@ __global__ __launch_bounds__(512, 2) void k_jacobi_strip4x(const Geom g, const f
 	}
 }
 
+#ifdef FX_LAB      // the quad (STRIP4_OCTET=0): superseded by the octet within round 5, kept as its A/B baseline in lab builds only
 __global__ __launch_bounds__(256, 1) void k_jacobi_strip4q(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
 	float* __restrict__ p_out, int z_begin, int z_end, int zchunk, int ngroups, int nchunks, int remap)
 {
@@ -1404,6 +1409,7 @@ __global__ __launch_bounds__(256, 1) void k_jacobi_strip4q(const Geom g, const f
 	else if (wave == 3) run4<RoleBot>(g, p_in, b, p_out, zb, ze, yg + NRO + 2 * NRI, wave, lane, lds_all + (RoleTop::LDS_ROWS + 2 * RoleMid::LDS_ROWS) * 64, xbuf, xflag, none);
 	else run4<RoleMid>(g, p_in, b, p_out, zb, ze, yg + NRO + (wave - 1) * NRI, wave, lane, lds_all + (RoleTop::LDS_ROWS + (wave - 1) * RoleMid::LDS_ROWS) * 64, xbuf, xflag, none);
 }
+#endif
 
 }  // namespace
 
@@ -1440,6 +1446,7 @@ hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b
 		if (T >= ((long long)1 << 30)) return hipErrorNotSupported;
 		const int forced_wgs = FX_KNOB_INT("STRIP4X_WGS", 0);
 		r.nwg = forced_wgs > 0 ? forced_wgs : (int)std::min<long long>(256, std::max<long long>(1, T / 8));
+		r.nwg = std::max(r.nwg, (r.bands + 5) / 6);                     // a run spans at most six bands (+ a head): at most seven pieces (the kernel lists eight)
 		r.minp = std::min(FX_KNOB_INT("STRIP4X_MINP", 8), std::max(r.nzp / 2, 1));
 		// chunks as long as a run (so that a chunk's runs are its bands), the last one shorter; a stub of a last chunk joins its neighbour;
 		// STRIP4X_ORDER=0: one chunk (band-major runs: every band alone at its depth)
@@ -1473,8 +1480,14 @@ hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b
 		if (zc > nzp) zc = nzp;
 		nch = (nzp + zc - 1) / zc;
 		hipLaunchKernelGGL(k_jacobi_strip4o, dim3(bands * nch), dim3(512), 0, s, g, p_in, b, p_out, z_begin, z_end, zc, bands, nch, remap);
-	} else
+	} else {
+#ifdef FX_LAB
 		hipLaunchKernelGGL(k_jacobi_strip4q, dim3(ngroups * nchunks), dim3(256), 0, s, g, p_in, b, p_out, z_begin, z_end, zchunk, ngroups, nchunks, remap);
+#else
+		(void)ngroups; (void)nchunks; (void)zchunk;
+		return hipErrorNotSupported;
+#endif
+	}
 	return hipGetLastError();
 }
 

@@ -4,16 +4,21 @@
 #include <string.h>
 
 namespace {
+// The switches a caller could need (which path serves a geometry; the transport's two options): what fx_knob_name enumerates in the
+// shipped library.  Everything else -- the A/B switches of the kernel launchers that docs/LAB.md measured with: chunk sizes, tile
+// orders, superseded kernels -- exists only in a lab build (-DFX_LAB: FLUIDX_BUILD_LAB=1 python -m fluidx12_amd.build); in the shipped
+// library a launcher that asks for one of those gets its default (knob_slot = -1) and fx_set_knob refuses the name.
 const char* const kNames[] = {
-	"ADVECT_ALPHA", "ADVECT_BLOCK", "ADVECT_DEFER", "ADVECT_FAST", "ADVECT_LDS", "ADVECT_LDS_HALF", "ADVECT_TILE_ROWS", "ADVECT_ZCHUNK",
-	"BLOCK_REMAP", "BLOCK_SHAPE", "COMM_PRIORITY",
+	"ADVECT_ALPHA", "ADVECT_DEFER", "ADVECT_LDS", "COMM_PRIORITY", "FREEZE_STRIP4", "JACOBI_PREFER3", "JACOBI_PREFER4", "JACOBI_T", "LIGHT_FILL", "RCCL_ONE_COMM",
 #ifdef FX_LAB
-	"DEBUG_NO_COPY",
-#endif
-	"FREEZE_DENSE_LEVELS", "FREEZE_DENSE_ONE", "FREEZE_FAST", "FREEZE_FUSE_DIV", "FREEZE_NT", "FREEZE_SHRINK", "FREEZE_STRIP4", "FREEZE_T", "FREEZE_WGS",
-	"JACOBI2D_TILE", "JACOBI_BLOCK", "JACOBI_BLOCKG", "JACOBI_PREFER3", "JACOBI_PREFER4", "JACOBI_T", "LIGHT_FILL", "LIGHT_FILL_DIRTY", "LIGHT_RAY_NT", "LIGHT_RAY_WGS", "PROJECT_V4", "RCCL_ONE_COMM", "ROW_VW",
+	"ADVECT_BLOCK", "ADVECT_FAST", "ADVECT_LDS_HALF", "ADVECT_TILE_ROWS", "ADVECT_ZCHUNK",
+	"BLOCK_REMAP", "BLOCK_SHAPE", "DEBUG_NO_COPY",
+	"FREEZE_DENSE_LEVELS", "FREEZE_DENSE_ONE", "FREEZE_FAST", "FREEZE_FUSE_DIV", "FREEZE_NT", "FREEZE_SHRINK", "FREEZE_T", "FREEZE_WGS",
+	"JACOBI2D_TILE", "JACOBI_BLOCK", "JACOBI_BLOCKG", "LIGHT_FILL_DIRTY", "LIGHT_RAY_NT", "LIGHT_RAY_WGS", "PROJECT_V4", "ROW_VW",
 	"STRIP3H_PAIRS", "STRIP3_COOP", "STRIP3_NO512", "STRIP3_OFF", "STRIP3_ZCHUNK", "STRIP4X", "STRIP4X_MINP", "STRIP4X_ORDER", "STRIP4X_WGS", "STRIP4_OCTET", "STRIP4_ZCHUNK", "STRIP_GENERIC", "STRIP_R", "STRIP_REMAP", "STRIP_WGS", "STRIP_WIDE",
-	"STRIP_ZCHUNK", "VIEW_ORDER", "VIEW_WGS", "XCD_REMAP" };
+	"STRIP_ZCHUNK", "VIEW_ORDER", "VIEW_WGS", "XCD_REMAP",
+#endif
+};
 const int kCount = (int)(sizeof kNames / sizeof kNames[0]);
 struct Slot { bool set; char value[48]; };
 Slot g_slots[kCount];

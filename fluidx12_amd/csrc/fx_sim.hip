@@ -1013,7 +1013,9 @@ int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp)
 	// rows that fit no strip / tile kernel (X no multiple of 4, or not 64 / 128 / 256 wide): the general block-per-wave kernel, two
 	// sweeps per launch (fx_jacobi_block.hip; 150^3, the reference's GI preset: 19.3 us per single-sweep launch before)
 	if (!tb_supported(g)) return jacobi_blockg_supported(g) && (!requested || requested == 2) && !forced && nzp >= 2 ? 2 : 1;   // (requested == 2: the slab rounds)
-	// X = 128: a 4 x 4-row block per wave, two sweeps (fx_jacobi_block.hip) -- the strips have too few waves there
+	// X = 128: a 4 x 4-row block per wave, two sweeps (fx_jacobi_block.hip) -- the strips have too few waves there.  (Round 6 built FOUR
+	// sweeps per launch on 8 x 8-row tiles, a workgroup each with the 16 x 16-row cone in its waves' registers and the planes handed over
+	// through the LDS: bit-exact, 24.9 us per launch against 2 x 6.8 -- eight barrier phases on one workgroup per CU; docs/LAB.md section 12.)
 	if (jacobi_block2_supported(g) && !requested && !forced) return nzp >= 2 ? 2 : 1;
 	// default: two sweeps per launch in the register-strip kernel (fx_jacobi_strip.hip) where the geometry allows it,
 	// else one sweep per launch

@@ -186,7 +186,16 @@ class Fluid:
     # ---- stages / access (no reference counterpart) ---------------------------------------------------
     def Synchronize(self):
         self._need()
-        capi.check(self._lib.fx_synchronize(self._ctx), "Synchronize")
+        rc = self._lib.fx_synchronize(self._ctx)
+        if rc != capi.FX_OK:                       # what the library had to say beyond the status (fx_last_error)
+            note = self.last_error
+            capi.check(rc, "Synchronize" + (" [%s]" % note if note else ""))
+
+    @property
+    def last_error(self):
+        self._need()
+        e = self._lib.fx_last_error(self._ctx)
+        return e.decode() if e else ""
 
     def Advect(self, stream=None):
         capi.check(self._lib.fx_advect(self._ctx, stream), "Advect")

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 7   /* 7: fx_field_digest; 6: fx_comm_init_peer, fx_set_knob / fx_knob_name, FX_OPT_RENDER_ACCEL, fx_timing.freeze_strip_launches; the launcher switches no longer come from FLUIDX_* environment variables */
+#define FX_ABI_VERSION 7   /* 7: fx_field_digest, fx_last_error; 6: fx_comm_init_peer, fx_set_knob / fx_knob_name, FX_OPT_RENDER_ACCEL, fx_timing.freeze_strip_launches; the launcher switches no longer come from FLUIDX_* environment variables */
 
 enum fx_status {
 	FX_OK = 0,
@@ -147,7 +147,12 @@ int fx_set_sh(fx_ctx* ctx, const float* coeffs27);
  * view/proj/eye may be NULL for a pure simulation context (no rendering state is updated). */
 int fx_update_frame(fx_ctx* ctx, float time_step, uint8_t frame_index,
 	const float view[16], const float proj[16], const float eye[3]);
-/* Fluid::Simulate (Fluid.cpp:348-410): enqueues advect + divergence + N sweeps + project */
+/* Fluid::Simulate (Fluid.cpp:348-410): enqueues advect + divergence + N sweeps + project.  Asynchronous like the reference's call, with one
+ * exception: with FX_JACOBI_FAITHFUL on a single 256-wide domain every fourth solve takes over a tile count that a launch two solves earlier
+ * left in host-visible memory and waits for THAT launch's event first (hipEventSynchronize; long past in practice) -- so the host runs at
+ * most about two steps ahead of the device there, and such a context must not be stepped inside a stream capture.  The wait is what makes
+ * the launch sequence a function of (the last uploaded state, the steps since) instead of when the host happened to look; fx_upload of a
+ * simulation field starts that adaptation over. */
 int fx_simulate(fx_ctx* ctx, void* stream, uint8_t frame_index);
 /* Fluid::Render (Fluid.cpp:412-446), all four flag combinations:
  *   flags & FX_RAY_MARCH_CUBEMAP   cube-map-space march (merged, or light volume + view pass with FX_SEPARATE_LIGHT_PASS):
@@ -182,6 +187,11 @@ int fx_get_frame_info(fx_ctx* ctx, fx_frame_info* out);
  * the host: that rank's read-back and checkpoints go on refusing until its fx_synchronize).  No rank runs on, or stores, fields that
  * differ from the single-domain run without having been told. */
 int fx_synchronize(fx_ctx* ctx);
+/* Also FX_E_DEVICE from fx_synchronize: a strip kernel's LDS hand-over wait ran out (a protocol error or a lost wave; the waits are bounded,
+ * ~10 ms) -- the pressure field that launch wrote is not the solver's; the report clears the fault.  fx_last_error: what the last failed
+ * call of this context had to say beyond its status (a HIP error string, which kernel family timed out, ...); "" if nothing; the pointer is
+ * valid until the context's next call. */
+const char* fx_last_error(fx_ctx* ctx);
 
 /* checkpoint / parity access (no reference counterpart; the reference cannot read fields back) */
 int fx_upload(fx_ctx* ctx, int field, const void* host, size_t bytes);

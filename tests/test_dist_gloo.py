@@ -72,3 +72,6 @@ def test_baseline_config_flags():
     assert "40 instead of 80" in bench.baseline_config_label(512, 512, 512, 40, "fp32", 8)
     assert bench.baseline_config_label(256, 256, 256, 40, "fp32", 1).startswith("BASELINE configs[2]")
     assert bench.workload_grid(512, 8, "strong") == ((512, 512, 512), 8)
+    # the default weak table changes row length at N = 8; weak256 keeps 256-wide rows for every N
+    assert bench.workload_grid(256, 8, "weak")[0] == (512, 512, 512) and bench.workload_grid(256, 8, "weak256")[0] == (256, 256, 2048)
+    assert bench.workload_grid(256, 4, "weak") == bench.workload_grid(256, 4, "weak256") == ((256, 256, 1024), 22)

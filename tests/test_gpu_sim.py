@@ -209,7 +209,7 @@ def test_x256_four_sweeps_at_odd_depths_bit_exact(depth, kernel, knob):
     assert np.array_equal(f.download(fx.FIELD_PRESSURE), q)
 
 
-def strip4_direct(dims, p, b, launches=2):
+def strip4_direct(dims, p, b, launches=2, zrange=None):
     """fx::launch_jacobi_strip4 called directly (the C++ launcher through its mangled name, device memory from torch): the C ABI only
     takes square planes (grid_x == grid_y, Fluid.cpp:201), the kernels any row count -- what a slab or a future caller may hand them"""
     import ctypes
@@ -231,8 +231,9 @@ def strip4_direct(dims, p, b, launches=2):
     tb = torch.from_numpy(b).to("cuda")
     bufs = [torch.from_numpy(p).to("cuda"), torch.full((Z, Y, X), 7.0, dtype=torch.float32, device="cuda")]
     vp = ctypes.c_void_p
+    z0, z1 = zrange or (0, Z)
     for k in range(launches):
-        rc = fn(ctypes.byref(g), vp(bufs[k & 1].data_ptr()), vp(tb.data_ptr()), vp(bufs[(k + 1) & 1].data_ptr()), ctypes.c_int(0), ctypes.c_int(Z), vp(0))
+        rc = fn(ctypes.byref(g), vp(bufs[k & 1].data_ptr()), vp(tb.data_ptr()), vp(bufs[(k + 1) & 1].data_ptr()), ctypes.c_int(z0), ctypes.c_int(z1), vp(0))
         if rc != 0:
             return rc, None
     torch.cuda.synchronize()
@@ -281,6 +282,22 @@ def test_x512_four_sweeps_on_any_row_count_bit_exact(dims):
         assert rc == 0
         assert np.array_equal(got, q), explain(got, q)
     assert strip4_direct((512, 7, 4), p[:4, :7].copy(), b[:4, :7].copy())[0] != 0
+
+
+@pytest.mark.parametrize("zrange", [(5, 6), (0, 1), (11, 12), (4, 6), (3, 11)])
+def test_x512_four_sweeps_on_a_range_of_planes(zrange):
+    """a launch over a few planes inside a deeper grid (what a slab rank's shrinking rounds hand the kernel): 86 bands x 1 plane are runs of
+    whole bands (at most seven pieces per run); the planes of the range == four sweeps of the oracle, the planes outside it untouched"""
+    dims = (512, 512, 12)
+    _, _, p = rand_state(*dims, 67)
+    b = np.random.default_rng(68).uniform(-1, 1, (12, 512, 512)).astype(f32)
+    q, _ = orc.jacobi(p, b, 4)
+    rc, got = strip4_direct(dims, p, b, launches=1, zrange=zrange)
+    assert rc == 0
+    z0, z1 = zrange
+    assert np.array_equal(got[z0:z1], q[z0:z1]), explain(got[z0:z1], q[z0:z1])
+    out = np.ones(12, bool); out[z0:z1] = False
+    assert np.all(got[out] == f32(7.0))
 
 
 @pytest.mark.parametrize("wgs", [1, 7, 64, 200, 256, 300])

@@ -113,8 +113,9 @@ def test_the_octet_kernel_fits_two_waves_per_simd(tmp_path):
                             int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)))
     octet = [v for k, v in seen.items() if "k_jacobi_strip4o" in k]
     quad = [v for k, v in seen.items() if "k_jacobi_strip4q" in k]
-    assert len(octet) == 1 and len(quad) == 1, list(seen)
+    assert len(octet) == 1 and len(quad) == (1 if b.LAB else 0), list(seen)       # the quad: lab builds only (-DFX_LAB)
     assert octet[0][0] <= 256 and octet[0][1] <= 160 * 1024 and octet[0][2] == 0, octet
     masked = [v for k, v in seen.items() if "k_freeze_strip4o" in k]          # the same octet with the freeze nibbles carried along
     assert len(masked) == 1 and masked[0][0] <= 256 and masked[0][1] <= 160 * 1024 and masked[0][2] == 0, masked
-    assert 256 < quad[0][0] <= 512 and quad[0][1] <= 160 * 1024 and quad[0][2] == 0, quad
+    if quad:
+        assert 256 < quad[0][0] <= 512 and quad[0][1] <= 160 * 1024 and quad[0][2] == 0, quad

@@ -29,6 +29,29 @@ import dxbc
 U32 = np.uint32
 F32 = np.float32
 
+# The OTHER choices the D3D11 functional spec allows an implementation (tools/dxbc_sensitivity.py switches them one at a time to bound
+# what the pinned choices above are worth; the goldens are made with every switch at its default):
+#   mad_fused      False: `mad` (and the multiply-add chain of dp2 / dp3 / dp4) rounds its product before the add
+#   rsq_ulps       n != 0: `rsq` returns the correctly rounded result moved by n units in the last place (the spec allows 1 ulp)
+#   exp_ulps       n != 0: the same for `exp`
+#   filter_bits    n > 0: sample_l's blend weights carry n fractional bits (fixed point, the spec's minimum is 8) instead of fp32
+ALT = {"mad_fused": True, "rsq_ulps": 0, "exp_ulps": 0, "filter_bits": 0}
+
+
+def _ulps(r, n):
+    r = r.astype(F32)
+    for _ in range(abs(int(n))):
+        r = np.nextafter(r, F32(np.inf) if n > 0 else F32(-np.inf)).astype(F32)
+    return r
+
+
+def mad32(a, b, c):
+    """`mad` as the implementation under test computes it"""
+    if ALT["mad_fused"]:
+        return fma32(a, b, c)
+    with np.errstate(all="ignore"):
+        return ((a.astype(F32) * b.astype(F32)).astype(F32) + c.astype(F32)).astype(F32)
+
 
 def f2u(a):
     return np.ascontiguousarray(a, dtype=F32).view(U32)
@@ -177,6 +200,9 @@ def sample_trilinear(tex, smp, u, v, w, off):
     tx, ty, tz = u * F32(X) - F32(0.5), v * F32(Y) - F32(0.5), w * F32(Z) - F32(0.5)
     flx, fly, flz = np.floor(tx), np.floor(ty), np.floor(tz)
     fx, fy, fz = (tx - flx).astype(F32), (ty - fly).astype(F32), (tz - flz).astype(F32)
+    if ALT["filter_bits"]:                      # fixed-point blend weights (round to nearest)
+        q = F32(2.0 ** ALT["filter_bits"])
+        fx, fy, fz = (np.floor(fx * q + F32(0.5)) / q).astype(F32), (np.floor(fy * q + F32(0.5)) / q).astype(F32), (np.floor(fz * q + F32(0.5)) / q).astype(F32)
     with np.errstate(invalid="ignore"):
         ix = np.nan_to_num(flx).astype(np.int64) + off[0]
         iy = np.nan_to_num(fly).astype(np.int64) + off[1]
@@ -626,13 +652,13 @@ class Machine:
             elif op == "DIV":
                 wf(F(1) / F(2))
             elif op == "MAD":
-                wf(fma32(F(1), F(2), F(3)))
+                wf(mad32(F(1), F(2), F(3)))
             elif op in ("DP2", "DP3", "DP4"):
                 n = int(op[2])
                 a, b = F(1), F(2)
                 acc = a[:, 0] * b[:, 0]
                 for k in range(1, n):
-                    acc = fma32(a[:, k], b[:, k], acc)
+                    acc = mad32(a[:, k], b[:, k], acc)
                 wf(np.repeat(acc[:, None], 4, 1))
             elif op == "MAX":
                 wf(np.fmax(F(1), F(2)))
@@ -641,9 +667,9 @@ class Machine:
             elif op == "SQRT":
                 wf(np.sqrt(F(1)))
             elif op == "RSQ":
-                wf((1.0 / np.sqrt(F(1).astype(np.float64))).astype(F32))
+                wf(_ulps((1.0 / np.sqrt(F(1).astype(np.float64))).astype(F32), ALT["rsq_ulps"]))
             elif op == "EXP":
-                wf(np.exp2(F(1).astype(np.float64)).astype(F32))
+                wf(_ulps(np.exp2(F(1).astype(np.float64)).astype(F32), ALT["exp_ulps"]))
             elif op == "LT":
                 wu(boolmask(F(1) < F(2)))
             elif op == "GE":
