@@ -285,6 +285,11 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="distributed plumbing only (no GPU work); used by the gloo CPU tests, never a measurement")
     args = ap.parse_args()
+    if args.gpus == 1 and "WORLD_SIZE" not in os.environ:
+        # the CPU baseline's OpenMP threads stay where they start (one per core): set before anything loads libgomp (60-107 M
+        # voxel-updates/s on one box with wandering threads)
+        os.environ.setdefault("OMP_PROC_BIND", "close")
+        os.environ.setdefault("OMP_PLACES", "cores")
     cg, ci, cs = BASELINE_CONFIGS.get(args.config, (256, 40, "fp32"))
     if args.reference_config:
         args.mode = "faithful"
@@ -720,7 +725,9 @@ def main():
             # `--steps 20 --warmup 5` line used to render a barely formed plume: 0.156 / 0.133 ms against 0.248 / 0.177 at frame 116).
             RENDER_FRAME = 132
             steps_done = args.warmup + args.steps
-            extra = max(0, RENDER_FRAME - steps_done)
+            # (at least one: the step that makes the rendered frame follows a render, so that its advection writes the render's alpha side volume
+            # -- what a frame loop does; the default 32 + 100 steps therefore render frame 133)
+            extra = max(1, RENDER_FRAME - steps_done)
             from fluidx12_amd import capi as capi_
             # A context that renders its frames has the advection of the NEXT step write the render's alpha side volume (one more 4-byte
             # store per voxel, fx_advect_lds.hip <ALPHA>; the timed steps above rendered nothing and did not pay for it).  The frame before

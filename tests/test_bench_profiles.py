@@ -64,6 +64,6 @@ def test_bench_line_carries_both_truths_and_certifies_multi_rank_runs():
 def test_committed_summaries_of_the_headline_kernels_are_fresh():
     """the summaries bench.py's default line cites must have been taken on the committed kernels"""
     b = load_bench()
-    for kernel, grid, iters, storage in (("k_jacobi_strip4o", 256, 40, "fp32"), ("k_jacobi_block2", 128, 40, "fp32")):
+    for kernel, grid, iters, storage in (("k_jacobi_strip4o", 256, 40, "fp32"), ("k_jacobi_block2", 128, 40, "fp32"), ("k_jacobi_strip4x", 512, 80, "fp32")):
         t = b.pmc_traffic(kernel, grid, iters, storage)
         assert t is not None and t[2] is False, (kernel, t)

@@ -8,17 +8,16 @@
 #                   summary stamped with the source hash of the kernel it was taken on
 #   render          kernel times + L2 / L1 hit rates of the render kernels at frame 132 (tools/render_pmc_summary.py), configs 3 and 5
 # Counter passes never share a run with a trace domain other than the kernel trace's own (this pool refuses such runs).
-TAG=${1:-r06}
+TAG=${1:-r10}
 cd "${GRAFT_REPO_ROOT:-.}" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/$TAG; if [ -z "$ONLY_RENDER" ]; then rm -rf $O; rm -f profiles/${TAG}_pmc_traffic_*.json profiles/${TAG}_sq_counters_*.json; fi; mkdir -p $O
 rm -f profiles/${TAG}_render_pmc_*.json
 prof() {  # tag, summary args, bench args...
   tag=$1; sargs=$2; shift 2
-  # (the counter passes without bench.py's device wake-up: their summaries divide dispatch counts by the steps profiled; the kernel
-  # trace with it: its per-launch averages are then taken on a device in the state the bench line's own averages are taken in)
-  B="python3 bench.py --no-cpu-baseline --no-render --no-developed --no-preheat $*"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$tag -o k -- python3 bench.py --no-cpu-baseline --no-render --no-developed $* > /dev/null 2>&1
+  # (every pass runs exactly --warmup + --steps steps on ONE context: the summaries divide dispatch counts by the steps profiled)
+  B="python3 bench.py --no-cpu-baseline --no-render --no-developed --no-warm-leg $*"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$tag -o k -- $B > /dev/null 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmcf_$tag -o f -- $B > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmcw_$tag -o w -- $B > /dev/null 2>&1
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --output-format csv -d $O/sq1_$tag -o p -- $B > /dev/null 2>&1
@@ -37,7 +36,7 @@ prof reference "--grid 256 --iters 64 --storage fp16 --mode faithful --steps-pro
 fi
 render() {  # tag, summary args, bench args...
   tag=$1; sargs=$2; shift 2
-  B="python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-developed --no-preheat $*"
+  B="python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-developed --no-warm-leg $*"
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/rkt_$tag -o k -- $B > /dev/null 2>&1
   rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/rl2_$tag -o p -- $B > /dev/null 2>&1
   rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum --output-format csv -d $O/rl1_$tag -o p -- $B > /dev/null 2>&1
