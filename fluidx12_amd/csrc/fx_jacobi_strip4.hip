@@ -58,6 +58,9 @@ template <int NR_, bool A_, bool W_, int NW_ = 4, int XS_ = 0> struct Role4 {
 	static constexpr int NR = NR_;
 	static constexpr int NW = NW_;                                            // waves per workgroup: NW - 1 inner boundaries, NW counters per level
 	static constexpr int XS = XS_;
+	// half-row waves: where the cut cells of levels 1..3 sit among the six a wave publishes per step (rows of the NEXT level: N2 + N3 + NR
+	// = 2 + 2 + 2 for an inner wave, 3 + 2 + 1 for an outer one; pairs stay register pairs: 0 1 2 | 3 | 4 5)
+	static constexpr int XO1 = 0, XO2 = (A_ || W_) ? 4 : 2, XO3 = (A_ || W_) ? 3 : 4;
 	static constexpr bool A = A_, W = W_;
 	static constexpr int NI = NR + (A ? 4 : 1) + (W ? 4 : 1);                 // input rows per plane; row i <-> y0 - (A ? 4 : 1) + i
 	static constexpr int N1 = NR + (A ? 3 : 0) + (W ? 3 : 0);                 // level-l rows; row j <-> y0 - (A ? 4 - l : 0) + j
@@ -113,13 +116,13 @@ __device__ __forceinline__ v4f relax4qx(v4f c, v4f U, v4f D, v4f F, v4f Bk, v4f 
 	s01 *= inv; s23 *= inv;
 	return v4f{ s01.x, s01.y, s23.x, s23.y };
 }
-// row k of a level takes component k of the four edge cells that came in for it
-template <int XS, int K>
-__device__ __forceinline__ v4f relax4qe(v4f c, v4f U, v4f D, v4f F, v4f Bk, v4f bb, v4f EX)
+// ... with the cell taken from the six (EA, EB) that came in from the partner for this step: component C
+template <int XS, int C>
+__device__ __forceinline__ v4f relax4qe(v4f c, v4f U, v4f D, v4f F, v4f Bk, v4f bb, v4f EA, fx_f2 EB)
 {
-	static_assert(K >= 0 && K < 4, "four edge cells per level");
-	const fx_f2 E = K < 2 ? fx_f2{ EX.x, EX.y } : fx_f2{ EX.z, EX.w };
-	return relax4qx<XS, K & 1>(c, U, D, F, Bk, bb, E);
+	static_assert(C >= 0 && C < 6, "six cut cells per step");
+	const fx_f2 E = C < 2 ? fx_f2{ EA.x, EA.y } : C < 4 ? fx_f2{ EA.z, EA.w } : EB;
+	return relax4qx<XS, C & 1>(c, U, D, F, Bk, bb, E);
 }
 
 __device__ __forceinline__ uint32_t opaque32q(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
@@ -273,10 +276,52 @@ template <class R> struct Strip4 {
 	// edge ROWS: 16 bytes per wave, level and step parity in the LDS, written by the lane at the cut, read (a broadcast) by the partner
 	uint32_t eoff;                                 // byte offset of "my" input cell across the cut inside a plane
 	float E0;                                      // the input cells across the cut of the CENTRE plane q - 1 (fetched during step q - 1, a step behind the plane itself: one register)
-	v4f* xe;                                       // [step parity][wave][level 1..3] x 4 cells
+	v4f* xe;                                       // [step parity][wave] x 8 cells (six used: Role4::XO1..3)
 	uint32_t xe0;                                  // ... as an LDS byte address
 };
-template <int NW> __device__ __forceinline__ constexpr int xeslot(int par, int w, int lv) { return (par * NW + w) * 3 + lv; }
+template <int NW> __device__ __forceinline__ constexpr int xeslot(int par, int w) { return (par * NW + w) * 2; }   // in v4f units: 32 bytes per slot
+
+// The cut cells of levels 1..3 travel ONCE per step (round 6, second half: per level -- a lane-masked write, a counter check and a slot read
+// each -- they cost an inner wave ~50 of its ~400 instructions per step and 7-11 % of the launch).  A wave publishes its six cells and its
+// step number behind sweep 4, under a hand-made exec mask (the lane at the cut only; control flow here is wave-uniform, exec is all ones);
+// the partner fetches slot and counter at the top of its next step and checks the counter in front of sweep 2.  The counter (xflag row 3)
+// vouches for the slot written in front of it (a wave's LDS operations execute in order); two slots by step parity: my counter at q - 1
+// says I have read what the partner wrote two steps ago.
+template <int XS>
+__device__ __forceinline__ void xe_publish(uint32_t slot_addr, uint32_t cnt_addr, int q, float v0, float v1, float v2, float v3, float v4, float v5)
+{
+	if (XS == 1)
+		asm volatile("s_bfm_b64 exec, 1, 63\n\tds_write2_b32 %0, %2, %3 offset1:1\n\tds_write2_b32 %0, %4, %5 offset0:2 offset1:3\n\tds_write2_b32 %0, %6, %7 offset0:4 offset1:5\n\t"
+			"ds_write_b32 %1, %8\n\ts_mov_b64 exec, -1" :: "v"(slot_addr), "v"(cnt_addr), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(q) : "memory");
+	else
+		asm volatile("s_mov_b64 exec, 1\n\tds_write2_b32 %0, %2, %3 offset1:1\n\tds_write2_b32 %0, %4, %5 offset0:2 offset1:3\n\tds_write2_b32 %0, %6, %7 offset0:4 offset1:5\n\t"
+			"ds_write_b32 %1, %8\n\ts_mov_b64 exec, -1" :: "v"(slot_addr), "v"(cnt_addr), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(q) : "memory");
+}
+struct XMail { int f; v4f a; fx_f2 b; };
+template <class R>
+__device__ __forceinline__ void xe_fetch(const Strip4<R>& st, XMail& x)
+{
+#ifdef FX_S4_NOXE
+	x.f = INT_MAX; return;                                              // (timing experiment: the cut's cells never travel; results are wrong)
+#endif
+	const int wp = st.wave ^ 4, pr = (st.q - 1) & 1;
+	x.f = __hip_atomic_load(reinterpret_cast<const int*>(st.xflag) + 3 * R::NW + wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	asm volatile("" ::: "memory");
+	__builtin_amdgcn_sched_barrier(0);
+	x.a = st.xe[xeslot<R::NW>(pr, wp)];
+	x.b = *reinterpret_cast<const fx_f2*>(st.xe + xeslot<R::NW>(pr, wp) + 1);
+	asm volatile("" ::: "memory");
+	__builtin_amdgcn_sched_barrier(0);
+}
+template <class R>
+__device__ __forceinline__ void xe_check(const Strip4<R>& st, XMail& x)
+{
+	if (__builtin_expect(x.f < st.q - 1, 0)) {                          // the partner has not published its step q - 1 yet
+		const int wp = st.wave ^ 4, pr = (st.q - 1) & 1;
+		x.a = lds_wait_read4(st.xf0 + 4u * (uint32_t)(3 * R::NW + wp), st.q - 1, st.xe0 + 16u * (uint32_t)xeslot<R::NW>(pr, wp));
+		x.b = *reinterpret_cast<const fx_f2*>(st.xe + xeslot<R::NW>(pr, wp) + 1);
+	}
+}
 __device__ __forceinline__ float lane_cell(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
 
 #define FXQ_LDS(st, slot, r) (st).lds[(slot) + (r) * 64]
@@ -294,7 +339,7 @@ __device__ __forceinline__ float lane_cell(float v, int lane) { return __builtin
 // LDS loads and only checked here: issued where it is needed, each hand-over is an exposed LDS round trip per neighbour -- six per step
 // for an inner wave, 12.5 us of a 58-us launch (measured by leaving the hand-overs out).  A row fetched before its owner had published
 // it (its counter says so) is fetched again by the waiting loop.
-template <class R> struct Mail4 { int fu, fd; v4f hu, hd; int fx; v4f ex; };
+template <class R> struct Mail4 { int fu, fd; v4f hu, hd; };
 
 template <class R, int L>
 __device__ __forceinline__ void mail_fetch4(const Strip4<R>& st, Mail4<R>& m)
@@ -313,19 +358,17 @@ __device__ __forceinline__ void mail_fetch4(const Strip4<R>& st, Mail4<R>& m)
 	// counter first, row behind it: a wave's LDS operations execute in order, so a counter that is high enough vouches for the row
 	if (!R::A) m.fu = __hip_atomic_load(flags + (L - 1) * R::NW + FX_WU(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	if (!R::W) m.fd = __hip_atomic_load(flags + (L - 1) * R::NW + FX_WD(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-	if (R::XS) m.fx = __hip_atomic_load(flags + (L - 1) * R::NW + (w ^ 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // the partner: the other half of my rows
 	asm volatile("" ::: "memory");
 	__builtin_amdgcn_sched_barrier(0);
 	if (!R::A) m.hu = st.xbuf[xrow<R::NW>(pr, FX_WU(w), L - 1, 0) + st.lane];
 	if (!R::W) m.hd = st.xbuf[xrow<R::NW>(pr, w, L - 1, 1) + st.lane];
-	if (R::XS) m.ex = st.xe[xeslot<R::NW>(pr, w ^ 4, L - 1)];
 	asm volatile("" ::: "memory");
 	__builtin_amdgcn_sched_barrier(0);                                  // (the machine scheduler would otherwise sink the row loads to their use)
 }
 
-// (PN: the level's new plane, NL rows; its first and last row are the edge rows; EX: the partner's cells across the cut come back in it)
+// (PN: the level's new plane, NL rows; its first and last row are the edge rows)
 template <class R, int L, int NL>
-__device__ __forceinline__ void hand_over4(const Strip4<R>& st, Mail4<R>& m, const v4f (&PN)[NL], v4f& HU, v4f& HD, v4f& EX)
+__device__ __forceinline__ void hand_over4(const Strip4<R>& st, Mail4<R>& m, const v4f (&PN)[NL], v4f& HU, v4f& HD)
 {
 #ifdef FX_S4_NOHAND
 	return;
@@ -333,10 +376,6 @@ __device__ __forceinline__ void hand_over4(const Strip4<R>& st, Mail4<R>& m, con
 	const int q = st.q, w = st.wave;
 	const int pr = (q - 1) & 1, pw = q & 1;
 	const v4f mine_top = PN[0], mine_bot = PN[NL - 1];
-	if (R::XS) {
-		if (__builtin_expect(m.fx < q - 1, 0)) m.ex = lds_wait_read4(st.xf0 + 4u * (uint32_t)((L - 1) * R::NW + (w ^ 4)), q - 1, st.xe0 + 16u * (uint32_t)xeslot<R::NW>(pr, w ^ 4, L - 1));
-		EX = m.ex;
-	}
 	if (!R::A) {
 		if (__builtin_expect(m.fu < q - 1, 0)) m.hu = lds_wait_read4(st.xf0 + 4u * (uint32_t)((L - 1) * R::NW + FX_WU(w)), q - 1, st.xb0 + 16u * (uint32_t)(xrow<R::NW>(pr, FX_WU(w), L - 1, 0) + st.lane));
 		HU = m.hu;
@@ -348,15 +387,6 @@ __device__ __forceinline__ void hand_over4(const Strip4<R>& st, Mail4<R>& m, con
 	asm volatile("" ::: "memory");
 	if (!R::A) st.xbuf[xrow<R::NW>(pw, FX_WU(w), L - 1, 1) + st.lane] = mine_top;
 	if (!R::W) st.xbuf[xrow<R::NW>(pw, w, L - 1, 0) + st.lane] = mine_bot;
-	if (R::XS) {
-		// my cells at the cut of the rows the NEXT sweep updates (rows UP .. of this level), for the partner's next step
-		constexpr int NN = NL - (R::A ? 1 : 0) - (R::W ? 1 : 0);
-		if (st.lane == (R::XS == 1 ? 63 : 0)) {
-			float* s_ = reinterpret_cast<float*>(st.xe + xeslot<R::NW>(pw, w, L - 1));
-#pragma unroll
-			for (int k = 0; k < NN; ++k) s_[k] = R::XS == 1 ? PN[k + R::UP].w : PN[k + R::UP].x;
-		}
-	}
 #ifndef FX_S4_BARRIER
 #ifdef FX_LAB_DROP_PUBLISH
 	if (L == 2 && w == 3) return;                                       // (fault injection, tests/test_gpu_faults.py: wave 3 never posts level 2 -- its neighbours' waits must run out LOUDLY)
@@ -369,8 +399,9 @@ __device__ __forceinline__ void hand_over4(const Strip4<R>& st, Mail4<R>& m, con
 // (MK: the masked loop -- mctr = the nibbles of the centre plane in level-L indexing, mout = those of the new plane in level-(L+1) indexing)
 template <class R, int L, int NL, int NN, bool MK = false>
 __device__ __forceinline__ void relax_level4(const Strip4<R>& st, const v4f (&Pold)[NL], const v4f (&Pctr)[NL], const v4f (&Pnew)[NL],
-	const v4f (&Bq)[NN], v4f HU, v4f HD, v4f (&out)[NN], uint32_t mctr, uint32_t& mout, v4f EX = v4f{ 0.0f, 0.0f, 0.0f, 0.0f })
+	const v4f (&Bq)[NN], v4f HU, v4f HD, v4f (&out)[NN], uint32_t mctr, uint32_t& mout, const XMail* xm = nullptr)
 {
+	constexpr int EOFF = L == 1 ? R::XO1 : L == 2 ? R::XO2 : R::XO3;     // where this level's cut cells sit among the partner's six
 	static_assert(!(MK && R::XS), "the masked loop runs on whole-row waves");
 	uint32_t m_ = 0u;
 #pragma unroll
@@ -398,10 +429,9 @@ __device__ __forceinline__ void relax_level4(const Strip4<R>& st, const v4f (&Po
 		} else if (R::XS) {
 			// (k is a constant of the unrolled loop; the switch only names it for the template)
 			switch (k) {
-			case 0: out[k] = relax4qe<R::XS ? R::XS : 1, 0>(c, u, d, Pold[jc], Pnew[jc], Bq[k], EX); break;
-			case 1: out[k] = relax4qe<R::XS ? R::XS : 1, 1>(c, u, d, Pold[jc], Pnew[jc], Bq[k], EX); break;
-			case 2: out[k] = relax4qe<R::XS ? R::XS : 1, 2>(c, u, d, Pold[jc], Pnew[jc], Bq[k], EX); break;
-			default: out[k] = relax4qe<R::XS ? R::XS : 1, 3>(c, u, d, Pold[jc], Pnew[jc], Bq[k], EX); break;
+			case 0: out[k] = relax4qe<R::XS ? R::XS : 1, (EOFF + 0) % 6>(c, u, d, Pold[jc], Pnew[jc], Bq[k], xm->a, xm->b); break;
+			case 1: out[k] = relax4qe<R::XS ? R::XS : 1, (EOFF + 1) % 6>(c, u, d, Pold[jc], Pnew[jc], Bq[k], xm->a, xm->b); break;
+			default: out[k] = relax4qe<R::XS ? R::XS : 1, (EOFF + 2) % 6>(c, u, d, Pold[jc], Pnew[jc], Bq[k], xm->a, xm->b); break;
 			}
 		} else
 			out[k] = relax4q(c, u, d, Pold[jc], Pnew[jc], Bq[k]);
@@ -479,6 +509,8 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 	if (S1) mail_fetch4<R, 1>(st, M1);
+	XMail xm; xm.f = INT_MIN; xm.a = zero; xm.b = fx_f2{ 0.0f, 0.0f };
+	if (R::XS && S2) xe_fetch<R>(st, xm);
 	// EARLY (the quad): the plane and the b rows that arrived go into their own registers and the NEXT prefetch is issued at once, a whole
 	// step ahead of its use; b is fetched two steps ahead into NBn (L - b opens every cell's sum).  LEAN (the octet's outer waves, two waves
 	// per SIMD: every register counts, the other wave of the SIMD covers the waits): no copies, no second b buffer, the prefetch goes out
@@ -635,14 +667,15 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 	st.pp += st.plane_bytes; st.pbq += st.plane_bytes;
 	if (MK) fz.pm += st.plane_bytes >> 4;
 	// hand-over 1, BEHIND the prefetch issue: a wait here must not delay the loads
-	v4f HU1 = zero, HD1 = zero, EX1 = zero;
-	if (S1) hand_over4<R, 1, N1>(st, M1, P1[NEW], HU1, HD1, EX1);
+	v4f HU1 = zero, HD1 = zero;
+	if (S1) hand_over4<R, 1, N1>(st, M1, P1[NEW], HU1, HD1);
+	if (R::XS && S2) xe_check<R>(st, xm);
 	if (S2) mail_fetch4<R, 2>(st, M2);
 	// ---- sweep 2: level-2 plane q-2 -----------------------------------------------------------------------------------
 	if (S2) {
 		v4f T_[N2];
 		uint32_t m2_ = 0u;
-		relax_level4<R, 1, N1, N2, MK>(st, P1[OLD], P1[CTR], P1[NEW], B2_, HU1, HD1, T_, MK ? MW[0][CTR] : 0u, m2_, EX1);
+		relax_level4<R, 1, N1, N2, MK>(st, P1[OLD], P1[CTR], P1[NEW], B2_, HU1, HD1, T_, MK ? MW[0][CTR] : 0u, m2_, &xm);
 		if (MK && q - 2 >= st.zb && q - 2 < st.ze && (~(m2_ >> (4 * O2)) & OWN) != 0u) fz.rel |= 4u;
 		if (__builtin_expect(q - 2 == st.Zg, 0)) {
 			FXQ_RARE_BRANCH;
@@ -663,14 +696,14 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 	v4f B3_[N3];                                                     // b[q-3] (after the rotation: s_b4), rows of level 3
 #pragma unroll
 	for (int m = 0; m < N3; ++m) B3_[m] = FXQ_LDS(st, st.s_b4, m + UP);
-	v4f HU2 = zero, HD2 = zero, EX2 = zero;
-	if (S2) hand_over4<R, 2, N2>(st, M2, P2[NEW], HU2, HD2, EX2);
+	v4f HU2 = zero, HD2 = zero;
+	if (S2) hand_over4<R, 2, N2>(st, M2, P2[NEW], HU2, HD2);
 	if (S3) mail_fetch4<R, 3>(st, M3);
 	// ---- sweep 3: level-3 plane q-3 -----------------------------------------------------------------------------------
 	if (S3) {
 		v4f T_[N3];
 		uint32_t m3_ = 0u;
-		relax_level4<R, 2, N2, N3, MK>(st, P2[OLD], P2[CTR], P2[NEW], B3_, HU2, HD2, T_, MK ? MW[1][CTR] : 0u, m3_, EX2);
+		relax_level4<R, 2, N2, N3, MK>(st, P2[OLD], P2[CTR], P2[NEW], B3_, HU2, HD2, T_, MK ? MW[1][CTR] : 0u, m3_, &xm);
 		if (MK && q - 3 >= st.zb && q - 3 < st.ze && (~(m3_ >> (4 * O3)) & OWN) != 0u) fz.rel |= 8u;
 		if (__builtin_expect(q - 3 == st.Zg, 0)) {
 			FXQ_RARE_BRANCH;
@@ -688,8 +721,8 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 			if (MK) MW[2][CTR] = m3_;
 		}
 	}
-	v4f HU3 = zero, HD3 = zero, EX3 = zero;
-	if (S3) hand_over4<R, 3, N3>(st, M3, P3[NEW], HU3, HD3, EX3);
+	v4f HU3 = zero, HD3 = zero;
+	if (S3) hand_over4<R, 3, N3>(st, M3, P3[NEW], HU3, HD3);
 	// ---- sweep 4: output plane q-4 ------------------------------------------------------------------------------------
 	if (S4) {
 		// UNCONDITIONAL stores: behind a branch the compiler counts no store when it waits for the prefetched rows of the next step, and each
@@ -698,7 +731,7 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 		// wave to one address keep their order); no step of the loop lies above the chunk (q <= ze + 3).
 		v4f X_[NR];
 		uint32_t m4_ = 0u;
-		relax_level4<R, 3, N3, NR, MK>(st, P3[OLD], P3[CTR], P3[NEW], B4_, HU3, HD3, X_, MK ? MW[2][CTR] : 0u, m4_, EX3);
+		relax_level4<R, 3, N3, NR, MK>(st, P3[OLD], P3[CTR], P3[NEW], B4_, HU3, HD3, X_, MK ? MW[2][CTR] : 0u, m4_, &xm);
 		char* dst_ = q - 4 >= st.zb ? st.po : st.po_zb;
 #ifdef FX_S4_NOSTORE
 		if (q < -1000)                                                   // (experiment: the arithmetic stays, the stores never execute)
@@ -707,6 +740,18 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 		for (int m = 0; m < NR; ++m) store_row4(dst_, opaque32q(roff[m + (R::A ? 4 : 1)]), X_[m]);
 		if (MK) frz_out4<R>(st, fz, dst_, X_, m4_, roff);
 	}
+#ifndef FX_S4_NOXE
+	if (R::XS) {                                                        // my cut cells of this step's new planes (levels 1..3), for the partner's next step
+		float v_[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+		for (int k = 0; k < N2; ++k) v_[R::XO1 + k] = R::XS == 1 ? P1[NEW][k + UP].w : P1[NEW][k + UP].x;
+#pragma unroll
+		for (int k = 0; k < N3; ++k) v_[R::XO2 + k] = R::XS == 1 ? P2[NEW][k + UP].w : P2[NEW][k + UP].x;
+#pragma unroll
+		for (int k = 0; k < NR; ++k) v_[R::XO3 + k] = R::XS == 1 ? P3[NEW][k + UP].w : P3[NEW][k + UP].x;
+		xe_publish<R::XS ? R::XS : 1>(st.xe0 + 16u * (uint32_t)xeslot<R::NW>(q & 1, st.wave), st.xf0 + 4u * (uint32_t)(3 * R::NW + st.wave), q, v_[0], v_[1], v_[2], v_[3], v_[4], v_[5]);
+	}
+#endif
 	st.po += st.plane_bytes;
 	++st.q;
 }
@@ -902,6 +947,8 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 	Mail4<R> M1, M2, M3;
 	M1.fu = M1.fd = M2.fu = M2.fd = M3.fu = M3.fd = INT_MIN; M1.hu = M1.hd = M2.hu = M2.hd = M3.hu = M3.hd = zero;
 	if (S1) mail_fetch4<R, 1>(st, M1);
+	XMail xm; xm.f = INT_MIN; xm.a = zero; xm.b = fx_f2{ 0.0f, 0.0f };
+	if (R::XS && S2) xe_fetch<R>(st, xm);
 	// ---- sweep 1: level-1 plane q-1 from input planes q-2 (OLD), q-1 (CTR), q (NEW: arrived) and b[q-1] (NB) ----
 	if (__builtin_expect(q == 0, 0)) {                                  // input plane -1 := plane 0, once
 		FXQ_RARE_BRANCH;
@@ -993,14 +1040,15 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 	if (R::XS && q <= st.q_load_last) st.E0 = *reinterpret_cast<const float*>(st.pp - st.plane_bytes + st.eoff);   // plane q's cells across the cut: the next step's centre
 	st.pp += st.plane_bytes; st.pbq += st.plane_bytes;
 	if (MK) fz.pm += st.plane_bytes >> 4;
-	v4f HU1 = zero, HD1 = zero, EX1 = zero;
-	if (S1) hand_over4<R, 1, NR>(st, M1, P1[NEW], HU1, HD1, EX1);
+	v4f HU1 = zero, HD1 = zero;
+	if (S1) hand_over4<R, 1, NR>(st, M1, P1[NEW], HU1, HD1);
+	if (R::XS && S2) xe_check<R>(st, xm);
 	if (S2) mail_fetch4<R, 2>(st, M2);
 	// ---- sweep 2 ----
 	if (S2) {
 		v4f T_[NR];
 		uint32_t m2_ = 0u;
-		relax_level4<R, 1, NR, NR, MK>(st, P1[OLD], P1[CTR], P1[NEW], B2_, HU1, HD1, T_, MK ? MW[0][CTR] : 0u, m2_, EX1);
+		relax_level4<R, 1, NR, NR, MK>(st, P1[OLD], P1[CTR], P1[NEW], B2_, HU1, HD1, T_, MK ? MW[0][CTR] : 0u, m2_, &xm);
 		if (MK && q - 2 >= st.zb && q - 2 < st.ze && (~m2_ & OWN) != 0u) fz.rel |= 4u;
 		if (__builtin_expect(q - 2 == st.Zg, 0)) {
 			FXQ_RARE_BRANCH;
@@ -1018,14 +1066,14 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 			if (MK) MW[1][CTR] = m2_;
 		}
 	}
-	v4f HU2 = zero, HD2 = zero, EX2 = zero;
-	if (S2) hand_over4<R, 2, NR>(st, M2, P2[NEW], HU2, HD2, EX2);
+	v4f HU2 = zero, HD2 = zero;
+	if (S2) hand_over4<R, 2, NR>(st, M2, P2[NEW], HU2, HD2);
 	if (S3) mail_fetch4<R, 3>(st, M3);
 	// ---- sweep 3 ----
 	if (S3) {
 		v4f T_[NR];
 		uint32_t m3_ = 0u;
-		relax_level4<R, 2, NR, NR, MK>(st, P2[OLD], P2[CTR], P2[NEW], B3_, HU2, HD2, T_, MK ? MW[1][CTR] : 0u, m3_, EX2);
+		relax_level4<R, 2, NR, NR, MK>(st, P2[OLD], P2[CTR], P2[NEW], B3_, HU2, HD2, T_, MK ? MW[1][CTR] : 0u, m3_, &xm);
 		if (MK && q - 3 >= st.zb && q - 3 < st.ze && (~m3_ & OWN) != 0u) fz.rel |= 8u;
 		if (__builtin_expect(q - 3 == st.Zg, 0)) {
 			FXQ_RARE_BRANCH;
@@ -1043,13 +1091,13 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 			if (MK) MW[2][CTR] = m3_;
 		}
 	}
-	v4f HU3 = zero, HD3 = zero, EX3 = zero;
-	if (S3) hand_over4<R, 3, NR>(st, M3, P3[NEW], HU3, HD3, EX3);
+	v4f HU3 = zero, HD3 = zero;
+	if (S3) hand_over4<R, 3, NR>(st, M3, P3[NEW], HU3, HD3);
 	// ---- sweep 4: the output ----
 	if (S4) {
 		v4f X_[NR];
 		uint32_t m4_ = 0u;
-		relax_level4<R, 3, NR, NR, MK>(st, P3[OLD], P3[CTR], P3[NEW], B4_, HU3, HD3, X_, MK ? MW[2][CTR] : 0u, m4_, EX3);
+		relax_level4<R, 3, NR, NR, MK>(st, P3[OLD], P3[CTR], P3[NEW], B4_, HU3, HD3, X_, MK ? MW[2][CTR] : 0u, m4_, &xm);
 		char* dst_ = q - 4 >= st.zb ? st.po : st.po_zb;
 #ifdef FX_S4_NOSTORE
 		if (q < -1000)
@@ -1058,6 +1106,18 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 		for (int m = 0; m < NR; ++m) store_row4(dst_, opaque32q(roff[m + 1]), X_[m]);
 		if (MK) frz_out4<R>(st, fz, dst_, X_, m4_, roff);
 	}
+#ifndef FX_S4_NOXE
+	if (R::XS) {                                                        // my cut cells of this step's new planes (levels 1..3), for the partner's next step
+		float v_[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+		for (int k = 0; k < NR; ++k) {
+			v_[R::XO1 + k] = R::XS == 1 ? P1[NEW][k].w : P1[NEW][k].x;
+			v_[R::XO2 + k] = R::XS == 1 ? P2[NEW][k].w : P2[NEW][k].x;
+			v_[R::XO3 + k] = R::XS == 1 ? P3[NEW][k].w : P3[NEW][k].x;
+		}
+		xe_publish<R::XS ? R::XS : 1>(st.xe0 + 16u * (uint32_t)xeslot<R::NW>(q & 1, st.wave), st.xf0 + 4u * (uint32_t)(3 * R::NW + st.wave), q, v_[0], v_[1], v_[2], v_[3], v_[4], v_[5]);
+	}
+#endif
 	st.po += st.plane_bytes;
 	++st.q;
 }
@@ -1269,7 +1329,7 @@ constexpr int X_OUTER_ROWS = XTopL::LDS_ROWS;                          // = XBot
 static_assert(XTopL::LDS_ROWS == XBotL::LDS_ROWS, "outer waves park alike");
 constexpr int X_LDS_ROWS = 4 * X_OUTER_ROWS;
 constexpr int X_XROWS = 2 * 7 * 3 * 2;                                 // (boundary 3, between the two halves' chains, is never used)
-static_assert((X_LDS_ROWS + X_XROWS) * 1024 + 2 * 8 * 3 * 16 + 128 <= 160 * 1024, "the half-row octet's windows must fit the CU's LDS");
+static_assert((X_LDS_ROWS + X_XROWS) * 1024 + 2 * 8 * 2 * 16 + 256 <= 160 * 1024, "the half-row octet's windows must fit the CU's LDS");
 
 // where band `grp` starts: octet_band_y for bands of BAND rows
 __device__ __host__ __forceinline__ int band_y(int grp, int ngroups, int Y, int BAND)
@@ -1293,6 +1353,9 @@ __device__ __forceinline__ void run_locate(const Runs4& r, int s, int& band, int
 	z = r.zc[i] + zo; left = ci - zo;
 }
 // the first position of workgroup k's run: k T / nwg, moved to the piece boundary when it would leave fewer than `minp` planes of a piece
+// the first position of workgroup k's run: k T / nwg, moved to the piece boundary when it would leave fewer than `minp` planes of a piece.
+// (Cuts placed under a step budget per run -- a piece costs its planes + its fill -- were built and measured level with these at every
+// depth: the fill steps of a piece are cheaper than its full steps by about what the model charges for them.)
 __device__ __forceinline__ int run_cut(const Runs4& r, int k)
 {
 	const int T = r.bands * r.nzp;
@@ -1312,8 +1375,8 @@ __global__ __launch_bounds__(512, 2) void k_jacobi_strip4x(const Geom g, const f
 {
 	__shared__ v4f lds_all[X_LDS_ROWS * 64];
 	__shared__ v4f xbuf[X_XROWS * 64];
-	__shared__ v4f xe[2 * 8 * 3];
-	__shared__ int xflag[24];
+	__shared__ v4f xe[2 * 8 * 2];                                       // the cut cells: [step parity][wave] x 32 bytes
+	__shared__ int xflag[32];                                          // [level 1..3][wave] as in the octet + [3][wave]: the last step whose cut cells the wave has published
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	const int c = wave < 4 ? wave : 4 + ((wave ^ 1) & 3);              // chain position: 0 1 2 3 | 5 4 7 6 -- one outer wave per SIMD
 	int k = (int)blockIdx.x;
@@ -1363,8 +1426,9 @@ __global__ __launch_bounds__(512, 2) void k_jacobi_strip4x(const Geom g, const f
 		const int tid = wave * 64 + lane;
 		__syncthreads();                                                // (the previous piece's mailbox reads are over)
 		if (tid < 24) xflag[tid] = fill ? qs + 2 * (tid / 8 + 1) - 1 : qs - 1;
+		else if (tid < 32) xflag[tid] = (fill ? qs + 2 : qs) - 1;          // the step in front of the walk's first one: its (never written) cells feed only sweeps whose planes are not kept
 		for (int i = tid; i < X_XROWS * 64; i += 512) xbuf[i] = zero;
-		if (tid < 2 * 8 * 3) xe[tid] = zero;
+		if (tid < 2 * 8 * 2) xe[tid] = zero;
 		__syncthreads();
 		switch (c) {
 		case 0: run4<XTopL>(g, p_in, b, p_out, zb, ze, yg, c, lane, lds_all, xbuf, xflag, none, xe); break;

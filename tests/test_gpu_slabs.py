@@ -69,6 +69,43 @@ def test_slabs_equal_single_domain(nranks, iters, hj, overlap):
     assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
 
 
+@pytest.mark.parametrize("storage", ["fp32", "fp16"])
+def test_field_digest_is_independent_of_the_decomposition_and_sees_one_bit(storage):
+    """fx_field_digest (what `bench.py --gpus N` certifies its timed steps with): the digest of a range of planes is the same whether
+    one context owns them or three slabs do (each digests the part it owns: the words add), differs between fields, ranges and
+    storages, refuses planes a context does not own, and changes when ONE bit of one element changes"""
+    dims = (64, 64, 48)
+    ref = run_single(dims, 5, jacobi_iters=8, storage=storage)
+    fl = run_slabs(dims, 5, 3, jacobi_iters=8, halo_jacobi=4, halo_advect=6, storage=storage)
+    M = (1 << 128) - 1
+
+    def add(a, b):                                   # the two 64-bit words wrap separately
+        return (((a >> 64) + (b >> 64)) & ((1 << 64) - 1)) << 64 | ((a + b) & ((1 << 64) - 1))
+    seen = set()
+    for field in (fx.FIELD_VELOCITY, fx.FIELD_VELOCITY1, fx.FIELD_COLOR, fx.FIELD_PRESSURE, fx.FIELD_DIVERGENCE):
+        whole = ref.digest(field)
+        assert 0 < whole <= M and whole not in seen
+        seen.add(whole)
+        parts = 0
+        for r, f in enumerate(fl):
+            z0, nz = r * 16, 16
+            d = f.digest(field)                                          # all owned planes
+            assert d == f.digest(field, z0, nz) == ref.digest(field, z0, nz)
+            parts = add(parts, d)
+        assert parts == whole
+        assert ref.digest(field, 3, 7) != ref.digest(field, 3, 8)
+    with pytest.raises(fx.FluidxError):
+        fl[1].digest(fx.FIELD_PRESSURE, 0, 16)                          # planes of rank 0
+    p = ref.download(fx.FIELD_PRESSURE)
+    before = ref.digest(fx.FIELD_PRESSURE)
+    p.view(np.uint32)[20, 31, 17] ^= np.uint32(1)
+    ref.upload(fx.FIELD_PRESSURE, p)
+    after = ref.digest(fx.FIELD_PRESSURE)
+    assert after != before
+    assert ref.digest(fx.FIELD_PRESSURE, 0, 16) == fl[0].digest(fx.FIELD_PRESSURE)          # the planes below the flipped bit: untouched
+    assert ref.digest(fx.FIELD_PRESSURE, 21, 27) == add(fl[1].digest(fx.FIELD_PRESSURE, 21, 11), fl[2].digest(fx.FIELD_PRESSURE))
+
+
 @pytest.mark.parametrize("overlap", [True, False])
 @pytest.mark.parametrize("fuse,iters", [(2, 12), (4, 12), (2, 11), (3, 13)])
 def test_slabs_with_temporal_blocking(fuse, iters, overlap):
