@@ -54,8 +54,9 @@ constexpr int NRI = 8 - NRO;                // rows of an inner wave (a workgrou
 // A: the wave recomputes a halo ABOVE its rows (the quad's top wave), W: below (the bottom wave).
 // XS (X = 512, k_jacobi_strip4x): the wave holds HALF a row -- 1: the left half (its lane 63 looks across the cut at x = 256), 2: the right
 // half (its lane 0 looks at x = 255); 0: the wave is the row.
-template <int NR_, bool A_, bool W_, int NW_ = 4, int XS_ = 0> struct Role4 {
+template <int NR_, bool A_, bool W_, int NW_ = 4, int XS_ = 0, bool NT_ = false> struct Role4 {
 	static constexpr int NR = NR_;
+	static constexpr bool NT = NT_;                                           // the output rows as non-temporal stores (store_row4nt)
 	static constexpr int NW = NW_;                                            // waves per workgroup: NW - 1 inner boundaries, NW counters per level
 	static constexpr int XS = XS_;
 	// half-row waves: where the cut cells of levels 1..3 sit among the six a wave publishes per step (rows of the NEXT level: N2 + N3 + NR
@@ -138,6 +139,14 @@ __device__ __forceinline__ void store_row4(char* base, uint32_t off, v4f v)
 #else
 	*reinterpret_cast<v4f*>(base + off) = v;
 #endif
+}
+// ... as a non-temporal store (Role4::NT, compile-time: behind a run-time flag the launch lost 4-7 %): fields beyond the Infinity Cache
+// (p + b of 512^3 are 1 GiB) are not read again before the next launch, and lines that do not stay behind leave the L2 to the halo rows the
+// bands share -- k_jacobi_strip4x at 512^3: 343.6 -> 335 us per launch in the bench, 96.2 -> 94.4 in the sweep micro-benchmark; on fields
+// that fit (512 x 512 x 64: +4 %; 256^3: worse, round 5) the plain store
+__device__ __forceinline__ void store_row4nt(char* base, uint32_t off, v4f v)
+{
+	__builtin_nontemporal_store(v, reinterpret_cast<v4f*>(base + off));
 }
 
 // ---- the reference's own loop (k_freeze_strip4o; CSPoisson.hlsli:8-26: a cell leaves the loop for good once a sweep changes it by less
@@ -737,7 +746,7 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 		if (q < -1000)                                                   // (experiment: the arithmetic stays, the stores never execute)
 #endif
 #pragma unroll
-		for (int m = 0; m < NR; ++m) store_row4(dst_, opaque32q(roff[m + (R::A ? 4 : 1)]), X_[m]);
+		for (int m = 0; m < NR; ++m) { if (R::NT) store_row4nt(dst_, opaque32q(roff[m + (R::A ? 4 : 1)]), X_[m]); else store_row4(dst_, opaque32q(roff[m + (R::A ? 4 : 1)]), X_[m]); }
 		if (MK) frz_out4<R>(st, fz, dst_, X_, m4_, roff);
 	}
 #ifndef FX_S4_NOXE
@@ -1103,7 +1112,7 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 		if (q < -1000)
 #endif
 #pragma unroll
-		for (int m = 0; m < NR; ++m) store_row4(dst_, opaque32q(roff[m + 1]), X_[m]);
+		for (int m = 0; m < NR; ++m) { if (R::NT) store_row4nt(dst_, opaque32q(roff[m + 1]), X_[m]); else store_row4(dst_, opaque32q(roff[m + 1]), X_[m]); }
 		if (MK) frz_out4<R>(st, fz, dst_, X_, m4_, roff);
 	}
 #ifndef FX_S4_NOXE
@@ -1319,11 +1328,7 @@ __global__ __launch_bounds__(512, 2) void k_freeze_strip4o(const Geom g, const f
 // own come out of that XCD's L2 instead of the fabric (band-major runs: every band alone at its depth, 1.8 x the compulsory traffic).
 // ---------------------------------------------------------------------------------------------------------------------------
 typedef Role4<1, true, false, 8, 1> XTopL;
-typedef Role4<2, false, false, 8, 1> XMidL;
 typedef Role4<1, false, true, 8, 1> XBotL;
-typedef Role4<1, true, false, 8, 2> XTopR;
-typedef Role4<2, false, false, 8, 2> XMidR;
-typedef Role4<1, false, true, 8, 2> XBotR;
 constexpr int X_BAND = 6;
 constexpr int X_OUTER_ROWS = XTopL::LDS_ROWS;                          // = XBotL's
 static_assert(XTopL::LDS_ROWS == XBotL::LDS_ROWS, "outer waves park alike");
@@ -1370,9 +1375,17 @@ __device__ __forceinline__ int run_cut(const Runs4& r, int k)
 	return s;
 }
 
+// NT: the output as non-temporal stores (fields beyond the Infinity Cache: store_row4nt)
+template <bool NT>
 __global__ __launch_bounds__(512, 2) void k_jacobi_strip4x(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
 	float* __restrict__ p_out, int z_begin, const Runs4 runs, int remap)
 {
+	typedef Role4<1, true, false, 8, 1, NT> XTopL;
+	typedef Role4<2, false, false, 8, 1, NT> XMidL;
+	typedef Role4<1, false, true, 8, 1, NT> XBotL;
+	typedef Role4<1, true, false, 8, 2, NT> XTopR;
+	typedef Role4<2, false, false, 8, 2, NT> XMidR;
+	typedef Role4<1, false, true, 8, 2, NT> XBotR;
 	__shared__ v4f lds_all[X_LDS_ROWS * 64];
 	__shared__ v4f xbuf[X_XROWS * 64];
 	__shared__ v4f xe[2 * 8 * 2];                                       // the cut cells: [step parity][wave] x 32 bytes
@@ -1525,7 +1538,11 @@ hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b
 		if (r.nch > 1 && r.nzp - r.zc[r.nch - 1] < std::max(C / 3, r.minp)) --r.nch;
 		r.zc[r.nch] = r.nzp;
 		for (int i = r.nch + 1; i < 9; ++i) r.zc[i] = r.nzp;
-		hipLaunchKernelGGL(k_jacobi_strip4x, dim3(r.nwg), dim3(512), 0, s, g, p_in, b, p_out, z_begin, r, remap);
+		// p + b beyond the Infinity Cache (320 MiB at 40 M cells): the output as non-temporal stores
+		if (g.cells_local() >= ((size_t)40 << 20) && FX_KNOB_INT("STRIP4X_NT", 1))
+			hipLaunchKernelGGL(k_jacobi_strip4x<true>, dim3(r.nwg), dim3(512), 0, s, g, p_in, b, p_out, z_begin, r, remap);
+		else
+			hipLaunchKernelGGL(k_jacobi_strip4x<false>, dim3(r.nwg), dim3(512), 0, s, g, p_in, b, p_out, z_begin, r, remap);
 		return hipGetLastError();
 	}
 	const int ngroups = std::max(g.Y / 16, 1);                          // (the quad's; Y = 14 runs the octet)

@@ -284,6 +284,22 @@ def test_x512_four_sweeps_on_any_row_count_bit_exact(dims):
     assert strip4_direct((512, 7, 4), p[:4, :7].copy(), b[:4, :7].copy())[0] != 0
 
 
+def test_x512_four_sweeps_beyond_the_infinity_cache_bit_exact():
+    """from 40 M cells (p + b no longer fit the Infinity Cache) k_jacobi_strip4x<NT> writes its output with non-temporal stores:
+    512 x 512 x 160 (42 M cells), 8 = 4 + 4 sweeps == oracle bit for bit"""
+    dims = (512, 512, 160)
+    rng = np.random.default_rng(69)
+    p = rng.standard_normal((160, 512, 512)).astype(f32)
+    b = rng.uniform(-1, 1, (160, 512, 512)).astype(f32)
+    q, _ = orc.jacobi(p, b, 8)
+    f = make(dims, jacobi_iters=8, jacobi_fuse=4)
+    f.upload(fx.FIELD_PRESSURE, p)
+    f.upload(fx.FIELD_DIVERGENCE, b)
+    f.Jacobi(8)
+    got = f.download(fx.FIELD_PRESSURE)
+    assert np.array_equal(got, q), explain(got, q)
+
+
 @pytest.mark.parametrize("zrange", [(5, 6), (0, 1), (11, 12), (4, 6), (3, 11)])
 def test_x512_four_sweeps_on_a_range_of_planes(zrange):
     """a launch over a few planes inside a deeper grid (what a slab rank's shrinking rounds hand the kernel): 86 bands x 1 plane are runs of
