@@ -134,6 +134,32 @@ def test_cube_resolve_vs_reference_binary(name):
     assert np.mean(d > 1e-4) < 2e-3 and np.median(d) < 2e-5
 
 
+@pytest.mark.parametrize("name", ["rendered16", "random8"])
+def test_cube_resolve_vs_the_rasterised_resolve_as_shipped(name):
+    """k_resolve_cube against the picture the reference's executable DRAWS (VSCube.cso + PSCube.cso through D3D11's rasteriser rules:
+    tests/golden/dxbc_raster.npz, tools/make_raster_golden.py): the same pixels up to the silhouette flips of the library's own fp32
+    frame constants, colours within half an 8-bit step"""
+    RAS = np.load(os.path.join(GOLD, "dxbc_raster.npz"))
+    W, H, vw, vh = (int(v) for v in RES["params"])
+    cube = RES["cube_" + name]
+    N = cube.shape[1]
+    f = fx.Fluid()
+    assert f.Init(W, H, (N, N, N))
+    view, proj, eye = fx.default_camera(vw, vh)
+    f.UpdateFrame(0.0, 0, view, proj, eye)
+    f.upload(fx.FIELD_CUBEMAP, cube)
+    f.ClearRenderTarget()
+    f.RenderCube(0)
+    f.Synchronize()
+    got = f.download(fx.FIELD_TARGET_FLOAT)
+    drawn = ~RAS["discard_" + name]
+    cov = got[..., 3] > 0
+    assert np.mean(cov != drawn) < 2e-3
+    both = cov & drawn
+    d = np.abs(got[both] - RAS["target_" + name][both])
+    assert np.mean(d.max(axis=-1) > 1 / 510) < 2e-3 and d.max() < 1 / 255
+
+
 @pytest.mark.parametrize("has_sh", [0, 1])
 def test_direct_ray_cast_vs_reference_binaries(has_sh):
     """k_raycast_direct against PSRayCastV.cso / PSRayCast.cso (row f-2); own frame constants as in the resolve test"""

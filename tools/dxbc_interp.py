@@ -437,6 +437,9 @@ class Machine:
             cb = self.cbs[o.indices[0]]
             i = self._index(o.indices[1])
             val = cb[i] if isinstance(i, np.ndarray) else np.broadcast_to(cb[i], (self.N, 4))
+        elif t == "icb":                                  # immediate constant buffer (the CUSTOMDATA block of class 3)
+            i = self._index(o.indices[-1])
+            val = self.icb[i] if isinstance(i, np.ndarray) else np.broadcast_to(self.icb[i], (self.N, 4))
         elif t in self.v:
             val = self.v[t]
         elif t == "v":                                    # pixel-shader input register
@@ -686,6 +689,8 @@ class Machine:
                 wu((R(O[1]).astype(np.int64) + R(O[2]).view(np.int32).astype(np.int64)) & 0xFFFFFFFF)
             elif op == "ISHL":
                 wu((R(O[1]).astype(np.uint64) << (R(O[2]) & 31).astype(np.uint64)) & 0xFFFFFFFF)
+            elif op == "USHR":
+                wu((R(O[1]).astype(np.uint64) >> (R(O[2]) & 31).astype(np.uint64)) & 0xFFFFFFFF)
             elif op == "IMAD":
                 a, b, c = (R(O[k]).view(np.int32).astype(np.int64) for k in (1, 2, 3))
                 wu((a * b + c) & 0xFFFFFFFF)
@@ -819,6 +824,23 @@ class PixelMachine(Machine):
                 self.x[int(idx)] = np.zeros((self.N, int(size), 4), U32)
         self.gsm = {}
         self.executed = 0
+
+
+class VertexMachine(PixelMachine):
+    """vs_5_0: one lane per vertex; `inputs` = {register index: uint32[N][4]} (SV_VertexID, SV_InstanceID ... as the input assembler
+    hands them over: raw bits), outputs in self.outputs[index].  Immediate constant buffers (icb) come from the shader's CUSTOMDATA."""
+
+    def __init__(self, blob, inputs, resources, cbs, samplers=None):
+        super().__init__(blob, {k: np.zeros((len(v), 4), F32) for k, v in inputs.items()}, resources, cbs, samplers)
+        self.inputs = {k: np.ascontiguousarray(v, U32) for k, v in inputs.items()}
+        for i in self.ins:
+            if i.op == "CUSTOMDATA" and (i.ctrl & 0x1FFFFF) == 3:
+                self.icb = np.array(i.raw, U32).reshape(-1, 4)
+
+
+def run_vertex_shader(path, inputs, cbs, **kw):
+    m = VertexMachine(open(path, "rb").read(), inputs, {}, cbs)
+    return m.run(**kw)
 
 
 def run_pixel_shader(path, inputs, resources, cbs, samplers=None, **kw):
