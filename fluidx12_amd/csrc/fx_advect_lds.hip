@@ -76,60 +76,63 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // LDS offsets are wave-uniform (SGPRs).  Inline assembly on purpose: through the builtin the compiler knows the LDS is being
 // written and puts `s_waitcnt vmcnt(0)` in front of the next ds_read -- every tap read of plane z would then wait for plane
 // z + 2, which has the whole iteration to land.  The workgroup barrier (after an explicit vmcnt(0)) is what orders the ring.
+// Addresses: a wave-uniform base per field (SGPR pair: the field + the plane's offset, made by scalar adds per plane) + a 32-bit byte
+// offset per lane that never changes (the lane's cell inside a plane) -- `global_load_lds_* v_offset, s[base:base+1]`.  (Round 6; as
+// 64-bit addresses per lane every plane cost eight v_lshl_add_u64 and their moves, and the kernel is bound by what it issues.)
 template <int VEL_BYTES>
-__device__ __forceinline__ void stage64(const void* col, const void* v0, const void* v1, const void* v2, uint32_t lds_col, uint32_t lds_vel)
+__device__ __forceinline__ void stage64(const void* col, const void* v0, const void* v1, const void* v2, uint32_t off_col, uint32_t off_vel, uint32_t lds_col, uint32_t lds_vel)
 {
 	uint32_t keep;
 	lds_col = __builtin_amdgcn_readfirstlane(lds_col);     // wave-uniform by construction; pins the operands to SGPRs for the "s" constraints
 	lds_vel = __builtin_amdgcn_readfirstlane(lds_vel);
 	asm volatile(
 		"s_mov_b32 %0, m0\n\t"
-		"s_mov_b32 m0, %5\n\t"
+		"s_mov_b32 m0, %7\n\t"
 		"s_nop 0\n\t"
-		"global_load_lds_dwordx4 %1, off\n\t"
-		"s_mov_b32 m0, %6\n\t"
+		"global_load_lds_dwordx4 %5, %1\n\t"
+		"s_mov_b32 m0, %8\n\t"
 		"s_nop 0\n\t"
-		"global_load_lds_dword %2, off\n\t"
-		"s_add_u32 m0, m0, %7\n\t"
+		"global_load_lds_dword %6, %2\n\t"
+		"s_add_u32 m0, m0, %9\n\t"
 		"s_nop 0\n\t"
-		"global_load_lds_dword %3, off\n\t"
-		"s_add_u32 m0, m0, %7\n\t"
+		"global_load_lds_dword %6, %3\n\t"
+		"s_add_u32 m0, m0, %9\n\t"
 		"s_nop 0\n\t"
-		"global_load_lds_dword %4, off\n\t"
+		"global_load_lds_dword %6, %4\n\t"
 		"s_mov_b32 m0, %0"
 		: "=&s"(keep)
-		: "v"(col), "v"(v0), "v"(v1), "v"(v2), "s"(lds_col), "s"(lds_vel), "n"(VEL_BYTES)
+		: "s"(col), "s"(v0), "s"(v1), "s"(v2), "v"(off_col), "v"(off_vel), "s"(lds_col), "s"(lds_vel), "n"(VEL_BYTES)
 		: "scc");                                              // s_add_u32 writes SCC: the compiler must not keep a compare live across the statement
 }
 
 // fp16 storage: colour texel = 8 bytes -> its two dwords to two LDS planes NCELL * 4 bytes apart; a velocity half -> a dword per lane
 template <int VEL_BYTES>
-__device__ __forceinline__ void stage64h(const void* col, const void* v0, const void* v1, const void* v2, uint32_t lds_col, uint32_t lds_vel)
+__device__ __forceinline__ void stage64h(const void* col, const void* v0, const void* v1, const void* v2, uint32_t off_col, uint32_t off_vel, uint32_t lds_col, uint32_t lds_vel)
 {
 	uint32_t keep;
 	lds_col = __builtin_amdgcn_readfirstlane(lds_col);
 	lds_vel = __builtin_amdgcn_readfirstlane(lds_vel);
-	const void* col_hi = static_cast<const char*>(col) + 4;      // (an instruction offset would shift the LDS address too)
+	const uint32_t off_col_hi = off_col + 4u;                     // (an instruction offset would shift the LDS address too)
 	asm volatile(
 		"s_mov_b32 %0, m0\n\t"
-		"s_mov_b32 m0, %6\n\t"
+		"s_mov_b32 m0, %8\n\t"
 		"s_nop 0\n\t"
-		"global_load_lds_dword %1, off\n\t"
-		"s_add_u32 m0, m0, %8\n\t"
+		"global_load_lds_dword %5, %1\n\t"
+		"s_add_u32 m0, m0, %10\n\t"
 		"s_nop 0\n\t"
-		"global_load_lds_dword %2, off\n\t"
-		"s_mov_b32 m0, %7\n\t"
+		"global_load_lds_dword %6, %1\n\t"
+		"s_mov_b32 m0, %9\n\t"
 		"s_nop 0\n\t"
-		"global_load_lds_ushort %3, off\n\t"
-		"s_add_u32 m0, m0, %8\n\t"
+		"global_load_lds_ushort %7, %2\n\t"
+		"s_add_u32 m0, m0, %10\n\t"
 		"s_nop 0\n\t"
-		"global_load_lds_ushort %4, off\n\t"
-		"s_add_u32 m0, m0, %8\n\t"
+		"global_load_lds_ushort %7, %3\n\t"
+		"s_add_u32 m0, m0, %10\n\t"
 		"s_nop 0\n\t"
-		"global_load_lds_ushort %5, off\n\t"
+		"global_load_lds_ushort %7, %4\n\t"
 		"s_mov_b32 m0, %0"
 		: "=&s"(keep)
-		: "v"(col), "v"(col_hi), "v"(v0), "v"(v1), "v"(v2), "s"(lds_col), "s"(lds_vel), "n"(VEL_BYTES)
+		: "s"(col), "s"(v0), "s"(v1), "s"(v2), "v"(off_col), "v"(off_col_hi), "v"(off_vel), "s"(lds_col), "s"(lds_vel), "n"(VEL_BYTES)
 		: "scc");
 }
 
@@ -213,22 +216,23 @@ __device__ __forceinline__ void advect_finish(const SimParams& sp, float (&u)[3]
 			c[3] = saturatef(fmaf(bdt, 40.0f, c[3]));
 		}
 	}
+	// the stores: uniform bases + 32-bit byte offsets (`global_store v_offset, v_data, s[base]`; the launcher keeps 16 x cells below 2^32)
+	char* vo = static_cast<char*>(vel_out);
+	char* co = static_cast<char*>(col_out);
 	if (HALF) {
-		h16* vo = static_cast<h16*>(vel_out);
-		vo[id] = to_h16(u[0] * atten);
-		vo[(size_t)stride + id] = to_h16(u[1] * atten);
-		vo[2 * (size_t)stride + id] = to_h16(u[2] * atten);
+		*reinterpret_cast<h16*>(vo + id * 2u) = to_h16(u[0] * atten);
+		*reinterpret_cast<h16*>(vo + (stride + id) * 2u) = to_h16(u[1] * atten);
+		*reinterpret_cast<h16*>(vo + (2u * stride + id) * 2u) = to_h16(u[2] * atten);
 		h16x4 hc;
 		hc.x = to_h16(c[0] * atten); hc.y = to_h16(c[1] * atten); hc.z = to_h16(c[2] * atten); hc.w = to_h16(c[3] * atten);
-		static_cast<h16x4*>(col_out)[id] = hc;
-		if (ALPHA) alpha_out[id] = (float)hc.w;
+		*reinterpret_cast<h16x4*>(co + id * 8u) = hc;
+		if (ALPHA) *reinterpret_cast<float*>(reinterpret_cast<char*>(alpha_out) + id * 4u) = (float)hc.w;
 	} else {
-		float* vo = static_cast<float*>(vel_out);
-		vo[id] = u[0] * atten;
-		vo[(size_t)stride + id] = u[1] * atten;
-		vo[2 * (size_t)stride + id] = u[2] * atten;
-		static_cast<float4*>(col_out)[id] = make_float4(c[0] * atten, c[1] * atten, c[2] * atten, c[3] * atten);
-		if (ALPHA) alpha_out[id] = c[3] * atten;
+		*reinterpret_cast<float*>(vo + id * 4u) = u[0] * atten;
+		*reinterpret_cast<float*>(vo + (stride + id) * 4u) = u[1] * atten;
+		*reinterpret_cast<float*>(vo + (2u * stride + id) * 4u) = u[2] * atten;
+		*reinterpret_cast<float4*>(co + id * 16u) = make_float4(c[0] * atten, c[1] * atten, c[2] * atten, c[3] * atten);
+		if (ALPHA) *reinterpret_cast<float*>(reinterpret_cast<char*>(alpha_out) + id * 4u) = c[3] * atten;
 	}
 }
 
@@ -291,22 +295,16 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
 	const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds;
 	auto fill = [&](int zq) {
 		const int za = min(max(addr_tap(zq, g.Zg, sp.address), g.zlo), g.zhi);   // voxels that would need a plane this slab lacks take the flagged path
-		const uint32_t pz = planes<P2>((uint32_t)g.lz(za), lgP, g);
+		const size_t pz = planes<P2>((uint32_t)g.lz(za), lgP, g);                  // wave-uniform: the plane's offset goes into the bases
 		const uint32_t slot = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(((zq + 4) & 3) * SLOT_BYTES));
-		{
-			const size_t cell = pz + src_a;
-			if (HALF) stage64h<VEL_BYTES>(reinterpret_cast<const char*>(col_in) + cell * CS, v0 + cell * ES, v1 + cell * ES, v2 + cell * ES,
-				slot + (uint32_t)wave * (64 * 4), slot + COL_BYTES + (uint32_t)wave * (64 * 4));
-			else stage64<VEL_BYTES>(reinterpret_cast<const char*>(col_in) + cell * CS, v0 + cell * ES, v1 + cell * ES, v2 + cell * ES,
-				slot + (uint32_t)wave * (64 * 16), slot + COL_BYTES + (uint32_t)wave * (64 * 4));
-		}
+		const char* bc = reinterpret_cast<const char*>(col_in) + pz * CS;
+		const char *b0 = v0 + pz * ES, *b1 = v1 + pz * ES, *b2 = v2 + pz * ES;
+		if (HALF) stage64h<VEL_BYTES>(bc, b0, b1, b2, src_a * CS, src_a * ES, slot + (uint32_t)wave * (64 * 4), slot + COL_BYTES + (uint32_t)wave * (64 * 4));
+		else stage64<VEL_BYTES>(bc, b0, b1, b2, src_a * CS, src_a * ES, slot + (uint32_t)wave * (64 * 16), slot + COL_BYTES + (uint32_t)wave * (64 * 4));
 		if (wave_has_b) {
 			if (has_b) {
-				const size_t cell = pz + src_b;
-				if (HALF) stage64h<VEL_BYTES>(reinterpret_cast<const char*>(col_in) + cell * CS, v0 + cell * ES, v1 + cell * ES, v2 + cell * ES,
-					slot + (NT + (uint32_t)wave * 64) * 4, slot + COL_BYTES + (NT + (uint32_t)wave * 64) * 4);
-				else stage64<VEL_BYTES>(reinterpret_cast<const char*>(col_in) + cell * CS, v0 + cell * ES, v1 + cell * ES, v2 + cell * ES,
-					slot + (NT + (uint32_t)wave * 64) * 16, slot + COL_BYTES + (NT + (uint32_t)wave * 64) * 4);
+				if (HALF) stage64h<VEL_BYTES>(bc, b0, b1, b2, src_b * CS, src_b * ES, slot + (NT + (uint32_t)wave * 64) * 4, slot + COL_BYTES + (NT + (uint32_t)wave * 64) * 4);
+				else stage64<VEL_BYTES>(bc, b0, b1, b2, src_b * CS, src_b * ES, slot + (NT + (uint32_t)wave * 64) * 16, slot + COL_BYTES + (NT + (uint32_t)wave * 64) * 4);
 			}
 		}
 	};

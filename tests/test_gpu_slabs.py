@@ -656,7 +656,7 @@ def test_bench_single_gpu_line_is_complete():
     assert 0 < rn["bound"]["light_pass"]["frac_of_hbm_peak"] < 1 and 0 < rn["bound"]["view_pass"]["frac_of_hbm_peak"] < 1
     # ... and the step is timed once more on the developed plume (frames 133-152), beside `value`
     dv = d["developed_plume"]
-    assert dv["frames"] == [133, 152] and dv["ms_per_step"] > 0 and dv["value"] == pytest.approx(128 ** 3 / (dv["ms_per_step"] * 1e-3))
+    assert dv["frames"] == [133, 152] and dv["settling_steps_behind_the_render_leg"] == 40 and dv["ms_per_step"] > 0 and dv["value"] == pytest.approx(128 ** 3 / (dv["ms_per_step"] * 1e-3))
     assert dv["marked_steps"] == 5 and all(dv["stage_ms_per_step"][k] > 0 for k in ("advect", "divergence", "jacobi", "project"))
     # both truths: `value` is the contract's protocol and nothing else (no device wake-up in front of it: `value_cold` says it again),
     # the same steps on a device that is awake are `warm_device`
