@@ -285,11 +285,9 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="distributed plumbing only (no GPU work); used by the gloo CPU tests, never a measurement")
     args = ap.parse_args()
-    if args.gpus == 1 and "WORLD_SIZE" not in os.environ:
-        # the CPU baseline's OpenMP threads stay where they start (one per core): set before anything loads libgomp (60-107 M
-        # voxel-updates/s on one box with wandering threads)
-        os.environ.setdefault("OMP_PROC_BIND", "close")
-        os.environ.setdefault("OMP_PLACES", "cores")
+    # (the CPU baseline's OpenMP threads are left to the scheduler: pinned with OMP_PROC_BIND=close / OMP_PLACES=cores the same sample ran at
+    # 15.8 instead of 56 M voxel-updates/s on the box of round 6 -- the visible CPUs of a container are not its cores; unpinned the three
+    # timings of a run agree to 3 %)
     cg, ci, cs = BASELINE_CONFIGS.get(args.config, (256, 40, "fp32"))
     if args.reference_config:
         args.mode = "faithful"
