@@ -1,7 +1,9 @@
-// fx_jacobi_strip4.hip -- FOUR lock-step Jacobi sweeps per launch (X = 256): k_jacobi_strip3c's streaming register / LDS windows with the
-// waves of a workgroup sharing a band of rows, every inner boundary an LDS mailbox.  Two kernels:
-//   k_jacobi_strip4o  (the default) EIGHT waves per workgroup, two per SIMD, over a band of 14 rows (1 + 2 + 2 + 2 + 2 + 2 + 2 + 1);
-//   k_jacobi_strip4q  (STRIP4_OCTET=0) four waves, one per SIMD, over a band of 16 rows (3 + 5 + 5 + 3).
+// fx_jacobi_strip4.hip -- FOUR lock-step Jacobi sweeps per launch (X = 256 and X = 512): k_jacobi_strip3c's streaming register / LDS
+// windows with the waves of a workgroup sharing a band of rows, every inner boundary an LDS mailbox.  The kernels:
+//   k_jacobi_strip4o      X = 256: EIGHT waves per workgroup, two per SIMD, over a band of 14 rows (1 + 2 + 2 + 2 + 2 + 2 + 2 + 1);
+//   k_jacobi_strip4x<NT>  X = 512 (round 6): the same octet on HALF-row waves -- 2 x-halves x (1 + 2 + 2 + 1 rows), a band of six, the x cut inside
+//                         the workgroup; a launch's band-planes cut into one run per CU; NT: non-temporal output stores (fields beyond the cache);
+//   k_jacobi_strip4q      (lab builds, STRIP4_OCTET=0) four waves, one per SIMD, over a band of 16 rows (3 + 5 + 5 + 3): the octet's predecessor;
 // and the octet once more as k_freeze_strip4o: four levels of the reference's OWN loop (a cell leaves it for good once a sweep changes it by
 // less than 1e-3) for every cell, the freeze nibbles carried along the windows -- the masked strip launch of the sparse solver
 // (fx_schedule.cpp jacobi_freeze; k_freeze_strip3 of fx_jacobi_stripm.hip is the three-level, one-wave-per-SIMD predecessor).
