@@ -56,8 +56,11 @@ constexpr int NRI = 8 - NRO;                // rows of an inner wave (a workgrou
 // A: the wave recomputes a halo ABOVE its rows (the quad's top wave), W: below (the bottom wave).
 // XS (X = 512, k_jacobi_strip4x): the wave holds HALF a row -- 1: the left half (its lane 63 looks across the cut at x = 256), 2: the right
 // half (its lane 0 looks at x = 255); 0: the wave is the row.
-template <int NR_, bool A_, bool W_, int NW_ = 4, int XS_ = 0, bool NT_ = false> struct Role4 {
+// XT (any X >= 256, k_jacobi_strip4t): the wave holds 256 cells of a LONGER row, an x tile with its own recomputed halo -- one lane (four
+// cells, four sweeps) at every side that is no wall; those lanes compute along and store nothing (Strip4::keep).
+template <int NR_, bool A_, bool W_, int NW_ = 4, int XS_ = 0, bool NT_ = false, bool XT_ = false> struct Role4 {
 	static constexpr int NR = NR_;
+	static constexpr bool XT = XT_;
 	static constexpr bool NT = NT_;                                           // the output rows as non-temporal stores (store_row4nt)
 	static constexpr int NW = NW_;                                            // waves per workgroup: NW - 1 inner boundaries, NW counters per level
 	static constexpr int XS = XS_;
@@ -282,6 +285,7 @@ template <class R> struct Strip4 {
 	uint32_t xf0, xb0;                             // LDS byte addresses of the step counters and of the mailbox
 	int q, zb, ze, q_load_last, b_load_last, Zg, wave, lane;
 	bool wall_top, wall_bot;                       // the strip's first own row is y = 0 / its last own row is y = Y - 1
+	bool keep;                                     // x tiles (R::XT): this lane's four cells are the tile's to store (not its x halo)
 	// half-row waves (R::XS): the cells across the cut.  Level 0 (the input) is fetched by the wave itself with the plane it prefetches --
 	// ONE load, lane i takes the cell across the cut of input row i -- and handed to a row's update by v_readlane; levels 1..3 travel like the
 	// edge ROWS: 16 bytes per wave, level and step parity in the LDS, written by the lane at the cut, read (a broadcast) by the partner
@@ -747,8 +751,10 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 #ifdef FX_S4_NOSTORE
 		if (q < -1000)                                                   // (experiment: the arithmetic stays, the stores never execute)
 #endif
+		if (!R::XT || st.keep) {
 #pragma unroll
-		for (int m = 0; m < NR; ++m) { if (R::NT) store_row4nt(dst_, opaque32q(roff[m + (R::A ? 4 : 1)]), X_[m]); else store_row4(dst_, opaque32q(roff[m + (R::A ? 4 : 1)]), X_[m]); }
+			for (int m = 0; m < NR; ++m) { if (R::NT) store_row4nt(dst_, opaque32q(roff[m + (R::A ? 4 : 1)]), X_[m]); else store_row4(dst_, opaque32q(roff[m + (R::A ? 4 : 1)]), X_[m]); }
+		}
 		if (MK) frz_out4<R>(st, fz, dst_, X_, m4_, roff);
 	}
 #ifndef FX_S4_NOXE
@@ -779,8 +785,10 @@ __device__ __forceinline__ void head_stores4(const Strip4<R>& st, const Frz4& fz
 #ifndef FX_S4_NOHEADSTORES
 	constexpr int RB = R::A ? 4 : 1;
 	const v4f zero = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+	if (!R::XT || st.keep) {
 #pragma unroll
-	for (int m = 0; m < R::NR; ++m) store_row4(st.po_zb, opaque32q(roff[m + RB]), zero);
+		for (int m = 0; m < R::NR; ++m) store_row4(st.po_zb, opaque32q(roff[m + RB]), zero);
+	}
 	if (MK) {
 		const ptrdiff_t mo_ = (st.po_zb - fz.outA) >> 4;
 #pragma unroll
@@ -827,7 +835,7 @@ __device__ __forceinline__ void frz_end4(const FrzArgs& fa, const Frz4& fz, int 
 
 template <class R, bool MK = false>
 __device__ __forceinline__ void run4(const Geom& g, const float* __restrict__ p_in, const float* __restrict__ b, float* __restrict__ p_out,
-	int zb, int ze, int y0, int wave, int lane, v4f* lds_slice, v4f* xbuf, int* xflag, const FrzArgs& fa, v4f* xe = nullptr)
+	int zb, int ze, int y0, int wave, int lane, v4f* lds_slice, v4f* xbuf, int* xflag, const FrzArgs& fa, v4f* xe = nullptr, int x0 = 0, bool keep = true)
 {
 	Strip4<R> st;
 	Frz4 fz;
@@ -850,7 +858,8 @@ __device__ __forceinline__ void run4(const Geom& g, const float* __restrict__ p_
 	st.xf0 = (uint32_t)(size_t)(__attribute__((address_space(3))) int*)xflag;
 	st.xb0 = (uint32_t)(size_t)(__attribute__((address_space(3))) v4f*)xbuf;
 	const int yb = y0 - (R::A ? 4 : 1);
-	constexpr uint32_t XCOL = R::XS == 2 ? 256u : 0u;                   // the first column of the wave's half of a row
+	const uint32_t XCOL = R::XT ? (uint32_t)x0 : R::XS == 2 ? 256u : 0u;   // the first column of the wave's half of a row / of its x tile
+	st.keep = keep;
 #pragma unroll
 	for (int i = 0; i < R::NI; ++i) roff[i] = ((uint32_t)min(max(yb + i, 0), g.Y - 1) * (uint32_t)g.X + XCOL + 4u * (uint32_t)lane) * 4u;
 	st.xe = xe; st.xe0 = (uint32_t)(size_t)(__attribute__((address_space(3))) v4f*)xe;
@@ -1113,8 +1122,10 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 #ifdef FX_S4_NOSTORE
 		if (q < -1000)
 #endif
+		if (!R::XT || st.keep) {
 #pragma unroll
-		for (int m = 0; m < NR; ++m) { if (R::NT) store_row4nt(dst_, opaque32q(roff[m + 1]), X_[m]); else store_row4(dst_, opaque32q(roff[m + 1]), X_[m]); }
+			for (int m = 0; m < NR; ++m) { if (R::NT) store_row4nt(dst_, opaque32q(roff[m + 1]), X_[m]); else store_row4(dst_, opaque32q(roff[m + 1]), X_[m]); }
+		}
 		if (MK) frz_out4<R>(st, fz, dst_, X_, m4_, roff);
 	}
 #ifndef FX_S4_NOXE
@@ -1135,7 +1146,7 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 
 template <class R, bool MK = false>
 __device__ __forceinline__ void run4r(const Geom& g, const float* __restrict__ p_in, const float* __restrict__ b, float* __restrict__ p_out,
-	int zb, int ze, int y0, int wave, int lane, v4f* xbuf, int* xflag, const FrzArgs& fa, v4f* xe = nullptr)
+	int zb, int ze, int y0, int wave, int lane, v4f* xbuf, int* xflag, const FrzArgs& fa, v4f* xe = nullptr, int x0 = 0, bool keep = true)
 {
 	Strip4<R> st;
 	Frz4 fz;
@@ -1153,7 +1164,8 @@ __device__ __forceinline__ void run4r(const Geom& g, const float* __restrict__ p
 	st.xb0 = (uint32_t)(size_t)(__attribute__((address_space(3))) v4f*)xbuf;
 	st.s_ctr = st.s_old = st.s_b2 = st.s_b3 = st.s_b4 = 0;
 	const int yb = y0 - 1;
-	constexpr uint32_t XCOL = R::XS == 2 ? 256u : 0u;
+	const uint32_t XCOL = R::XT ? (uint32_t)x0 : R::XS == 2 ? 256u : 0u;
+	st.keep = keep;
 #pragma unroll
 	for (int i = 0; i < R::NI; ++i) roff[i] = ((uint32_t)min(max(yb + i, 0), g.Y - 1) * (uint32_t)g.X + XCOL + 4u * (uint32_t)lane) * 4u;
 	st.xe = xe; st.xe0 = (uint32_t)(size_t)(__attribute__((address_space(3))) v4f*)xe;
@@ -1456,6 +1468,79 @@ __global__ __launch_bounds__(512, 2) void k_jacobi_strip4x(const Geom g, const f
 	}
 }
 
+// Any other row length from 256 cells on (X % 4 == 0; k_jacobi_strip4t): the octet of X = 256 on X TILES.  A wave still holds 256 consecutive cells
+// of a row; where a tile's side is no wall its outermost lane is the tile's own x halo -- four cells for four sweeps, recomputed like the rows
+// above and below a band: after sweep s the s cells next to the side are not the field's, after four exactly that lane's, which computes
+// along and stores nothing (the wall clamp it applies at its outer cell is part of what is thrown away).  Tiles lie 248 cells apart, the last
+// one ends at the row's end and keeps what its neighbour does not: 1 + ceil((X - 256) / 248) tiles.  Nothing crosses between the tiles of a
+// row inside a launch, so a (tile, band) pair is a "band" of k_jacobi_strip4x's run arithmetic -- the launch's (tile, band)-planes in
+// (z chunk, band, tile, plane) order, one contiguous run per workgroup, pieces walked last first (neighbouring tiles and bands at the same
+// depth on neighbouring CUs: the halo lanes and rows come out of the XCD's L2).
+__device__ __host__ __forceinline__ int xtiles(int X) { return 1 + (X - 256 + 247) / 248; }
+template <bool NT>
+__global__ __launch_bounds__(512, 2) void k_jacobi_strip4t(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
+	float* __restrict__ p_out, int z_begin, const Runs4 runs, int ntx, int remap)
+{
+	typedef Role4<1, true, false, 8, 0, NT, true> TTop;
+	typedef Role4<2, false, false, 8, 0, NT, true> TMid;
+	typedef Role4<1, false, true, 8, 0, NT, true> TBot;
+	__shared__ v4f lds_all[O_LDS_ROWS * 64];
+	__shared__ v4f xbuf[O_XROWS * 64];
+	__shared__ int xflag[24];
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	int k = (int)blockIdx.x;
+	if (remap) {
+		const int qn = runs.nwg >> 3, r = runs.nwg & 7;
+		const int xcd = k & 7, j = k >> 3;
+		k = xcd * qn + min(xcd, r) + j;
+	}
+	constexpr int MAXP = 8;
+	__shared__ int piece[MAXP][3];                                      // { first plane, planes, (tile, band) }
+	__shared__ int npiece;
+	if (threadIdx.x == 0) {
+		const int t0 = run_cut(runs, k);
+		int t1 = run_cut(runs, k + 1), n = 0;
+		while (t0 < t1 && n < MAXP) {
+			int band, zoff, left;
+			run_locate(runs, t1 - 1, band, zoff, left);
+			int pz0 = 0;
+			{ int i = 0; while (i + 1 < runs.nch && zoff >= runs.zc[i + 1]) ++i; pz0 = runs.zc[i]; }
+			const int zfirst = max(pz0, zoff - (t1 - 1 - t0));
+			piece[n][0] = z_begin + zfirst; piece[n][1] = zoff - zfirst + 1; piece[n][2] = band;
+			t1 -= zoff - zfirst + 1;
+			++n;
+		}
+		if (t0 < t1) strip4_raise_fault();
+		npiece = n;
+	}
+	__syncthreads();
+	const FrzArgs none{};
+	const v4f zero = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+	const int nby = runs.bands / ntx;
+	for (int ip = 0; ip < __builtin_amdgcn_readfirstlane(npiece); ++ip) {
+		const int zb = __builtin_amdgcn_readfirstlane(piece[ip][0]), ze = zb + __builtin_amdgcn_readfirstlane(piece[ip][1]);
+		const int tb = __builtin_amdgcn_readfirstlane(piece[ip][2]);
+		const int tx = tb % ntx, yg = octet_band_y(tb / ntx, nby, g.Y);
+		// the tile's first column, and the lanes whose cells it keeps: from where its left neighbour stops (a wall: from the first) to its
+		// last lane but one (a wall: the last)
+		const int x0 = tx == ntx - 1 ? g.X - 256 : 248 * tx;
+		const int keep_lo = tx == 0 ? 0 : (248 * (tx - 1) + 252 - x0) >> 2, keep_hi = tx == ntx - 1 ? 63 : 62;
+		const int qs = max(zb - 4, g.zlo);
+		const bool fill = qs == zb - 4;
+		int lane;
+		asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(lane));
+		const int tid = wave * 64 + lane;
+		const bool keep = lane >= keep_lo && lane <= keep_hi;
+		__syncthreads();                                                // (the previous piece's mailbox reads are over)
+		if (tid < 24) xflag[tid] = fill ? qs + 2 * (tid / 8 + 1) - 1 : qs - 1;
+		for (int i = tid; i < O_XROWS * 64; i += 512) xbuf[i] = zero;
+		__syncthreads();
+		if (wave == 0) run4<TTop>(g, p_in, b, p_out, zb, ze, yg, wave, lane, lds_all, xbuf, xflag, none, nullptr, x0, keep);
+		else if (wave == 7) run4<TBot>(g, p_in, b, p_out, zb, ze, yg + O_BAND - 1, wave, lane, lds_all + TTop::LDS_ROWS * 64, xbuf, xflag, none, nullptr, x0, keep);
+		else run4r<TMid>(g, p_in, b, p_out, zb, ze, yg + 2 * wave - 1, wave, lane, xbuf, xflag, none, nullptr, x0, keep);
+	}
+}
+
 #ifdef FX_LAB      // the quad (STRIP4_OCTET=0): superseded by the octet within round 5, kept as its A/B baseline in lab builds only
 __global__ __launch_bounds__(256, 1) void k_jacobi_strip4q(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
 	float* __restrict__ p_out, int z_begin, int z_end, int zchunk, int ngroups, int nchunks, int remap)
@@ -1507,6 +1592,8 @@ bool jacobi_strip4_supported(const Geom& g)
 	// the octet takes Y = 14 and any Y >= 17 (bands of 14 rows, shifted where they or their halo would cross the last row: octet_band_y);
 	// the quad (STRIP4_OCTET=0) whole bands of 16; X = 512: the half-row octet, bands of six rows
 	if (g.Zg > 1 && g.X == 512) return FX_KNOB_INT("STRIP4X", 1) && band_rows_supported(g.Y, X_BAND);
+	// any other row of whole quads from 256 cells on: the octet on x tiles (k_jacobi_strip4t); a plane's byte offsets are 32-bit
+	if (g.Zg > 1 && g.X > 256 && (g.X & 3) == 0) return FX_KNOB_INT("STRIP4T", 1) && octet_rows_supported(g.Y) && (uint64_t)g.X * (uint64_t)g.Y < ((uint64_t)1 << 30);
 	if (g.Zg <= 1 || g.X != 256) return false;
 	return FX_KNOB_INT("STRIP4_OCTET", 1) ? octet_rows_supported(g.Y) : ((g.Y & 15) == 0 && g.Y >= 16);
 }
@@ -1517,10 +1604,12 @@ hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b
 	if (!jacobi_strip4_supported(g)) return hipErrorNotSupported;
 	const int forced_chunk = FX_KNOB_INT("STRIP4_ZCHUNK", 0);
 	const int remap = FX_KNOB_INT("STRIP_REMAP", 1);
-	if (g.X == 512) {
+	if (g.X != 256) {
 		// one run of band-planes per workgroup, one workgroup (156 KiB of LDS) per CU: 256 runs wherever a run is at least eight planes long
+		const bool tiled = g.X != 512;                                  // k_jacobi_strip4t: a "band" is an x tile of a band of 14 rows
+		const int ntx = tiled ? xtiles(g.X) : 1;
 		Runs4 r;
-		r.bands = (g.Y + X_BAND - 1) / X_BAND; r.nzp = z_end - z_begin;
+		r.bands = tiled ? ntx * ((g.Y + O_BAND - 1) / O_BAND) : (g.Y + X_BAND - 1) / X_BAND; r.nzp = z_end - z_begin;
 		const long long T = (long long)r.bands * r.nzp;
 		if (T >= ((long long)1 << 30)) return hipErrorNotSupported;
 		const int forced_wgs = FX_KNOB_INT("STRIP4X_WGS", 0);
@@ -1541,6 +1630,13 @@ hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b
 		r.zc[r.nch] = r.nzp;
 		for (int i = r.nch + 1; i < 9; ++i) r.zc[i] = r.nzp;
 		// p + b beyond the Infinity Cache (320 MiB at 40 M cells): the output as non-temporal stores
+		if (tiled) {
+			if (g.cells_local() >= ((size_t)40 << 20) && FX_KNOB_INT("STRIP4X_NT", 1))
+				hipLaunchKernelGGL(k_jacobi_strip4t<true>, dim3(r.nwg), dim3(512), 0, s, g, p_in, b, p_out, z_begin, r, ntx, remap);
+			else
+				hipLaunchKernelGGL(k_jacobi_strip4t<false>, dim3(r.nwg), dim3(512), 0, s, g, p_in, b, p_out, z_begin, r, ntx, remap);
+			return hipGetLastError();
+		}
 		if (g.cells_local() >= ((size_t)40 << 20) && FX_KNOB_INT("STRIP4X_NT", 1))
 			hipLaunchKernelGGL(k_jacobi_strip4x<true>, dim3(r.nwg), dim3(512), 0, s, g, p_in, b, p_out, z_begin, r, remap);
 		else

@@ -312,6 +312,15 @@ static int jacobi_launch(fx_ctx* ctx, hipStream_t s, int src, int t, Range r, Sc
 	return FX_OK;
 }
 
+// a launch of `t` sweeps the geometry has a kernel for: threes exist for X = 256 / 512 only, twos wherever a fused kernel serves the rows
+static int legal_sweeps(const fx_ctx* c, int t)
+{
+	if (c->frozen || takes_2d_tiles(c)) return t;
+	if (t == 3 && !jacobi_strip3_supported(c->g)) t = 2;
+	if (t == 2 && jacobi_fused_max_sweeps(c->g, 2, c->g.nz) < 2) t = 1;
+	return t;
+}
+
 static int fused_sweeps(const fx_ctx* c)
 {
 	if (takes_2d_tiles(c)) return jacobi2d_max_sweeps(c->g);
@@ -329,7 +338,9 @@ static int jacobi_round(fx_ctx* ctx, hipStream_t s, int count, ScopedMark* mk)
 		if (!ctx->frozen && !takes_2d_tiles(ctx) && jacobi_prefers_three(ctx->g, (int)(ctx->desc.flags & FX_FLAG_JACOBI_FUSE_MASK), ctx->g.nz))
 			t = left == 4 ? 2 : std::min(left, 3);           // threes, and a remainder of 4 as 2 + 2 rather than 3 + 1
 		if (!ctx->frozen && !takes_2d_tiles(ctx) && jacobi_prefers_four(ctx->g, (int)(ctx->desc.flags & FX_FLAG_JACOBI_FUSE_MASK), ctx->g.nz))
-			t = left >= 7 || left == 4 ? 4 : std::min(left, 3);   // fours; a remainder of 5 / 6 as 3 + 2 / 3 + 3
+			t = jacobi_strip3_supported(ctx->g) ? (left >= 7 || left == 4 ? 4 : std::min(left, 3))   // fours; a remainder of 5 / 6 as 3 + 2 / 3 + 3
+				: std::min(left, 4);                                    // (x tiles: no threes -- 4 + 2, 4 + 1)
+		t = legal_sweeps(ctx, t);
 		if (mk && mk->kind == MK_JACOBI && mk->launches && t * mk->launches < mk->sweeps) mk->split(MK_JACOBI_TAIL);   // shorter launches from here on
 		const int rc = jacobi_launch(ctx, s, ctx->p_cur, t, grown(ctx, multi_rank(ctx) ? left - t : 0), mk);
 		if (rc) return rc;
@@ -575,7 +586,12 @@ static int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t 
 	uint32_t done = 0;
 	while (done < iters) {
 		const int cnt = (int)std::min<uint32_t>(k, iters - done);
-		const int m = (cnt + t - 1) / t, t_first = cnt - (m - 1) * t;
+		// the interior's launches: the remainder first, then whole t's -- each one a launch the geometry has a kernel for (the same list on
+		// every member: X and Y are the chain's)
+		std::vector<int> parts;
+		for (int left = cnt - (cnt / t) * t; left > 0;) { const int p = legal_sweeps(lead, left); parts.push_back(p); left -= p; }
+		for (int j = 0; j < cnt / t; ++j) parts.push_back(t);
+		const int m = (int)parts.size();
 		const int src = lead->p_cur, fin = src ^ (m & 1);
 		int fbuf = 0;                                      // which scratch buffer holds the chain's last level (set below)
 		// ---- face stream: the chain (needs the previous round's interior + face copy, and its exchange)
@@ -611,7 +627,7 @@ static int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t 
 			const Range o = owned(mctx);
 			int lvl = 0, cur = src;
 			for (int j = 0; j < m; ++j) {
-				const int tj = j == 0 ? t_first : t;
+				const int tj = parts[j];
 				lvl += tj;
 				const int rem = cnt - lvl;
 				const Range in{ has_lower(mctx) ? o.lo + k - rem : o.lo, has_upper(mctx) ? o.hi - k + rem : o.hi };

@@ -1010,6 +1010,9 @@ int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp)
 		if (want >= 4 && jacobi_strip4_supported(g) && nzp >= 2) return 4;     // four sweeps: the half-row octet (k_jacobi_strip4x, fx_jacobi_strip4.hip)
 		return want >= 3 && jacobi_strip3_supported(g) ? 3 : (want >= 2 ? 2 : 1);
 	}
+	// any other row of whole quads longer than 256 cells: FOUR sweeps on x tiles of the octet (k_jacobi_strip4t, fx_jacobi_strip4.hip) where
+	// asked for or preferred (jacobi_prefers_four); remainders through the paths below
+	if (!tb_supported(g) && (requested >= 4 || (!requested && forced >= 4)) && jacobi_strip4_supported(g) && nzp >= 2) return 4;
 	// rows that fit no strip / tile kernel (X no multiple of 4, or not 64 / 128 / 256 wide): the general block-per-wave kernel, two
 	// sweeps per launch (fx_jacobi_block.hip; 150^3, the reference's GI preset: 19.3 us per single-sweep launch before)
 	if (!tb_supported(g)) return jacobi_blockg_supported(g) && (!requested || requested == 2) && !forced && nzp >= 2 ? 2 : 1;   // (requested == 2: the slab rounds)
@@ -1029,6 +1032,7 @@ int jacobi_fused_max_sweeps(const Geom& g, int requested, int nzp)
 // 32 6.2 / 7.7 / 6.9 / 5.2, 64 9.6 / 8.1 / 7.3 / 5.6, 96 - / - / 7.7 / 6.1, 128 8.8 (threes) / 7.1, 192 11.3 / 9.6, 256 14.0 / 12.1, 400 23.3 / 19.0;
 // with the quad kernel (STRIP4_OCTET=0) from 144 planes.  JACOBI_PREFER4=0 keeps the threes; an explicit jacobi_fuse / JACOBI_T request is
 // always honoured as given.
+static size_t jacobi_tiled_four_from() { return (size_t)FX_KNOB_INT("STRIP4T_FROM", 1 << 20); }
 bool jacobi_prefers_four(const Geom& g, int requested, int nzp)
 {
 	const int forced = FX_KNOB_INT("JACOBI_T", 0);
@@ -1036,6 +1040,8 @@ bool jacobi_prefers_four(const Geom& g, int requested, int nzp)
 	const bool octet = FX_KNOB_INT("STRIP4_OCTET", 1) != 0;
 	if (g.X == 512)                                                     // k_jacobi_strip4x: wherever the threes pay (jacobi_prefers_three)
 		return prefer && !requested && !forced && jacobi_strip4_supported(g) && (size_t)g.X * g.Y * (size_t)nzp >= ((size_t)1 << 24);
+	if (g.X != 256)                                                     // k_jacobi_strip4t (x tiles of the octet): see the table at jacobi_tiled_four_from
+		return prefer && !requested && !forced && jacobi_strip4_supported(g) && (size_t)g.X * g.Y * (size_t)nzp >= jacobi_tiled_four_from();
 	return prefer && !requested && !forced && jacobi_strip4_supported(g) && (size_t)g.X * g.Y * (size_t)nzp >= (octet ? (size_t)3 << 19 : (size_t)9 << 20);
 }
 
@@ -1065,7 +1071,10 @@ hipError_t launch_jacobi_fused(const Geom& g, const float* p_in, const float* b,
 		if (sweeps == 3 && jacobi_strip3_supported(g)) return launch_jacobi_strip3(g, p_in, b, p_out, z_begin, z_end, s);
 		return sweeps == 2 ? launch_jacobi_strip(g, p_in, b, p_out, 2, z_begin, z_end, s) : hipErrorNotSupported;
 	}
-	if (!tb_supported(g)) return sweeps == 2 && jacobi_blockg_supported(g) ? launch_jacobi_blockg(g, p_in, b, p_out, z_begin, z_end, s) : hipErrorNotSupported;
+	if (!tb_supported(g)) {
+		if (sweeps == 4) return launch_jacobi_strip4(g, p_in, b, p_out, z_begin, z_end, s);       // k_jacobi_strip4t
+		return sweeps == 2 && jacobi_blockg_supported(g) ? launch_jacobi_blockg(g, p_in, b, p_out, z_begin, z_end, s) : hipErrorNotSupported;
+	}
 	switch (sweeps) {
 	case 2:
 		if (jacobi_block2_supported(g)) return launch_jacobi_block2(g, p_in, b, p_out, z_begin, z_end, s);

@@ -328,6 +328,38 @@ def test_x512_four_sweeps_any_number_of_runs(wgs, knob):
     assert rc == 0 and np.array_equal(got, q), explain(got, q)
 
 
+@pytest.mark.parametrize("dims", [(260, 17, 9), (264, 30, 12), (320, 20, 21), (384, 45, 12), (500, 14, 12), (504, 33, 7), (508, 18, 5), (516, 29, 12),
+                                  (752, 17, 6), (756, 40, 9), (1000, 19, 6), (1024, 31, 10), (2048, 17, 5)])
+def test_any_row_length_four_sweeps_bit_exact(dims):
+    """rows longer than 256 cells that are neither 256 nor 512 ("any other row length falls to the generic paths"):
+    k_jacobi_strip4t, the octet on x tiles of 256 cells 248 apart -- a tile's outermost lane on a side that is no wall is its own recomputed
+    halo and stores nothing.  Tile counts 2..9, last tiles that keep 2 to 62 lanes, row counts that do and do not tile the bands, odd depths;
+    8 = 4 + 4 sweeps == oracle bit for bit, twice (two writers of one cell racing would not repeat).  The launcher directly: any Y."""
+    X, Y, Z = dims
+    _, _, p = rand_state(X, Y, Z, 71)
+    b = np.random.default_rng(72).uniform(-1, 1, (Z, Y, X)).astype(f32)
+    q, _ = orc.jacobi(p, b, 8)
+    for _ in range(2):
+        rc, got = strip4_direct(dims, p, b)
+        assert rc == 0
+        assert np.array_equal(got, q), explain(got, q)
+
+
+@pytest.mark.parametrize("zrange", [(5, 6), (0, 1), (11, 12), (3, 11)])
+def test_any_row_length_four_sweeps_on_a_range_of_planes(zrange):
+    """... over a few planes inside a deeper grid: the planes of the range == four sweeps of the oracle, the others untouched"""
+    dims = (384, 40, 12)
+    _, _, p = rand_state(*dims, 73)
+    b = np.random.default_rng(74).uniform(-1, 1, (12, 40, 384)).astype(f32)
+    q, _ = orc.jacobi(p, b, 4)
+    rc, got = strip4_direct(dims, p, b, launches=1, zrange=zrange)
+    assert rc == 0
+    z0, z1 = zrange
+    assert np.array_equal(got[z0:z1], q[z0:z1]), explain(got[z0:z1], q[z0:z1])
+    out = np.ones(12, bool); out[z0:z1] = False
+    assert np.all(got[out] == f32(7.0))
+
+
 @pytest.mark.parametrize("rows", [14, 15, 16, 17, 18, 19, 27, 28, 29, 30, 31, 44, 45, 58, 100, 128, 240, 254])
 def test_x256_four_sweeps_on_rows_that_do_not_tile_the_bands_bit_exact(rows):
     """the octet's bands of 14 rows on row counts they do not tile (the launcher called directly: the C ABI takes square planes only).
@@ -514,6 +546,46 @@ def test_errors_and_call_order():
         f.UpdateFrame(0.1, 3)                                      # frameIndex < FrameCount
     with pytest.raises(ValueError):
         f.upload(fx.FIELD_PRESSURE, np.zeros((4, 4, 4), f32))
+
+
+@pytest.mark.parametrize("dims,iters,launches", [((384, 384, 40), 40, 10), ((320, 320, 24), 23, 8), ((264, 264, 30), 6, 3)])
+def test_any_row_length_full_step_against_oracle(dims, iters, launches):
+    """a grid whose rows are neither 256 nor 512 cells through one whole step, stage by stage against the oracle: the default schedule takes
+    FOUR sweeps per launch on x tiles of the octet (k_jacobi_strip4t; 23 sweeps = 5 x 4 + 1 + 1 + 1: these rows have no three- or
+    two-sweep kernel), advection / divergence / projection their general kernels; then fx_simulate as a whole against the staged run"""
+    X, Y, Z = dims
+    rng = np.random.default_rng(384)
+    vel = (rng.random((3, Z, Y, X), dtype=f32) - f32(0.5)) * f32(4.0)
+    col = rng.random((Z, Y, X, 4), dtype=f32)
+    p = rng.standard_normal((Z, Y, X)).astype(f32)
+    f = make(dims, jacobi_iters=iters)
+    dt = f32(f.default_time_step())
+    f.upload(fx.FIELD_VELOCITY, vel); f.upload(fx.FIELD_COLOR, col); f.upload(fx.FIELD_PRESSURE, p)
+    f.UpdateFrame(dt, 0)
+    f.Advect()
+    gv, gc = f.download(fx.FIELD_VELOCITY1), f.download(fx.FIELD_COLOR)
+    vo, co = orc.advect(vel, col, dt)
+    assert rel_l2(gv, vo) < 1e-6 and rel_l2(gc, co) < 1e-6
+    f.Divergence()
+    b = orc.divergence(gv)
+    assert np.array_equal(f.download(fx.FIELD_DIVERGENCE), b)
+    f.timing_enable(True); f.timing_read(True)
+    f.Jacobi(iters)
+    f.Synchronize()
+    t = f.timing_read(True)
+    assert t.jacobi_sweeps == iters and t.jacobi_launches == launches, (t.jacobi_sweeps, t.jacobi_launches)
+    q, _ = orc.jacobi(p, b, iters)
+    got = f.download(fx.FIELD_PRESSURE)
+    assert np.array_equal(got, q), explain(got, q)
+    f.Project()
+    want = orc.project(gv, q)
+    assert np.array_equal(f.download(fx.FIELD_VELOCITY), want)
+    g = make(dims, jacobi_iters=iters)
+    g.upload(fx.FIELD_VELOCITY, vel); g.upload(fx.FIELD_COLOR, col); g.upload(fx.FIELD_PRESSURE, p)
+    g.UpdateFrame(dt, 0)
+    g.Simulate(0)
+    g.Synchronize()
+    assert np.array_equal(g.download(fx.FIELD_VELOCITY), want) and np.array_equal(g.download(fx.FIELD_COLOR), gc)
 
 
 # ---- full BASELINE sizes: size-independent properties --------------------------------------------------

@@ -963,6 +963,28 @@ def test_peer_group_across_two_devices():
     assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
 
 
+@pytest.mark.parametrize("hj,iters,overlap", [(9, 23, 1), (7, 16, 2), (5, 11, 0), (9, 20, 2), (8, 40, 2), (8, 23, 2)])
+def test_slabs_of_any_row_length_take_the_tiled_four_sweep_kernel(hj, iters, overlap):
+    """k_jacobi_strip4t (rows of 320 cells: two x tiles) on the trapezoid ranges of slab ranks: three slabs of 320 x 320 x 120, rounds of
+    9 / 7 / 5 / 8 sweeps as 1 + 4 + 4, 1 + 1 + 1 + 4, 1 + 4, 4 + 4 (these rows have no three- or two-sweep kernel: the schedule composes a
+    round from launches that exist); bit-identical to one sweep per launch on the single domain"""
+    dims = (320, 320, 120)
+    ref = run_single(dims, 2, jacobi_iters=iters, jacobi_fuse=1)
+    fl = run_slabs(dims, 2, 3, jacobi_iters=iters, halo_jacobi=hj, halo_advect=8, overlap=overlap)
+    fl[0].timing_enable(True); fl[0].timing_read(True)
+    fl[0].UpdateFrame(f32(fl[0].default_time_step()), 2)
+    fl[0].Simulate(2)
+    fl[0].Synchronize()
+    t = fl[0].timing_read()
+    assert t.jacobi_launches < t.jacobi_sweeps                       # fused launches took part
+    ref.UpdateFrame(f32(ref.default_time_step()), 2)
+    ref.Simulate(2)
+    ref.Synchronize()
+    assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
+    assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
+    assert np.abs(ref.download(fx.FIELD_PRESSURE)).max() > 0
+
+
 @pytest.mark.parametrize("kernel", ["octet", "quad"])
 @pytest.mark.parametrize("hj,iters,overlap", [(9, 23, 1), (7, 16, 1), (5, 11, 0), (9, 20, 2)])
 def test_four_sweep_kernel_on_uneven_slab_ranges(hj, iters, overlap, kernel, knob):
