@@ -1614,6 +1614,23 @@ hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b
 		if (T >= ((long long)1 << 30)) return hipErrorNotSupported;
 		const int forced_wgs = FX_KNOB_INT("STRIP4X_WGS", 0);
 		r.nwg = forced_wgs > 0 ? forced_wgs : (int)std::min<long long>(256, std::max<long long>(1, T / 8));
+		// More bands than CUs (rows of 1024 cells: 5 tiles x 74 bands): runs of 1.45 bands start at any depth, and no two neighbouring bands
+		// walk the same planes at the same time -- every halo row comes from memory.  There a workgroup takes ONE piece (a band's planes of
+		// one z chunk), more workgroups than CUs: an XCD's 32 CUs start 32 neighbouring bands at the chunk's first plane and walk up
+		// together, the next 32 follow as they finish.  1..4 chunks, pieces of STRIP4T_PIECES = 64 planes or more: the count that fills the
+		// rounds of 256 best, a piece charged twelve planes of fill; kept to runs where no count fills 85 %.  us per sweep, runs / pieces:
+		// 1024^3 1005-1071 / 758-822 (370 bands x 2 chunks = 740 workgroups, 2.9 rounds), 1024 x 1024 x 512 521 / 423, x 256 243 / 193,
+		// x 128 120 / 106 (two chunks of 64; one of 128: 121), x 64 59.0 / 62.8 (runs stay); 2048 x 2048 x 128 497 / 388.
+		const int piece_min = FX_KNOB_INT("STRIP4T_PIECES", 64);
+		if (forced_wgs <= 0 && r.bands > 256 && piece_min > 0) {
+			int best = 0; double best_score = 0.0;
+			for (int n = 1; n <= 4 && r.nzp / n >= piece_min; ++n) {
+				const long long P = (long long)r.bands * n;
+				const double occ = (double)P / (double)(((P + 255) / 256) * 256), C = (double)r.nzp / n, score = occ * C / (C + 12.0);
+				if (occ >= 0.85 && score > best_score + 1e-9) { best_score = score; best = n; }
+			}
+			if (best) r.nwg = r.bands * best;
+		}
 		r.nwg = std::max(r.nwg, (r.bands + 5) / 6);                     // a run spans at most six bands (+ a head): at most seven pieces (the kernel lists eight)
 		r.minp = std::min(FX_KNOB_INT("STRIP4X_MINP", 8), std::max(r.nzp / 2, 1));
 		// chunks as long as a run (so that a chunk's runs are its bands), the last one shorter; a stub of a last chunk joins its neighbour;

@@ -16,7 +16,7 @@ def load_bench():
 
 def test_kernel_source_hash_names_every_profiled_kernel():
     from fluidx12_amd.build import kernel_source_hash
-    for k in ("k_jacobi_strip4o", "k_jacobi_strip4x", "k_jacobi_strip4q", "k_jacobi_strip3c", "k_jacobi_strip3h", "k_jacobi_block2", "k_jacobi_blockg", "k_advect_lds", "k_divergence_v4",
+    for k in ("k_jacobi_strip4o", "k_jacobi_strip4x", "k_jacobi_strip4t", "k_jacobi_strip4q", "k_jacobi_strip3c", "k_jacobi_strip3h", "k_jacobi_block2", "k_jacobi_blockg", "k_advect_lds", "k_divergence_v4",
               "k_project_v4", "k_freeze_dense", "k_freeze_tiles", "k_jacobi_strip2u", "k_raymarch_light", "k_raymarch_view"):
         h = kernel_source_hash(k)
         assert h and len(h) == 16, k
@@ -64,6 +64,6 @@ def test_bench_line_carries_both_truths_and_certifies_multi_rank_runs():
 def test_committed_summaries_of_the_headline_kernels_are_fresh():
     """the summaries bench.py's default line cites must have been taken on the committed kernels"""
     b = load_bench()
-    for kernel, grid, iters, storage in (("k_jacobi_strip4o", 256, 40, "fp32"), ("k_jacobi_block2", 128, 40, "fp32"), ("k_jacobi_strip4x", 512, 80, "fp32")):
+    for kernel, grid, iters, storage in (("k_jacobi_strip4o", 256, 40, "fp32"), ("k_jacobi_block2", 128, 40, "fp32"), ("k_jacobi_strip4x", 512, 80, "fp32"), ("k_jacobi_strip4t", 384, 40, "fp32")):
         t = b.pmc_traffic(kernel, grid, iters, storage)
         assert t is not None and t[2] is False, (kernel, t)

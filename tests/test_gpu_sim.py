@@ -2,6 +2,8 @@
 identical inputs.  Bar: velocity/colour within 1e-4 rel-L2 of the oracle (north_star); in practice the
 kernels that contain no transcendental (divergence, Jacobi, projection) are asserted BIT-EXACT and
 advection (one exp2 per voxel inside the impulse ball) to 1e-6."""
+import os
+
 import numpy as np
 import pytest
 
@@ -218,10 +220,11 @@ def strip4_direct(dims, p, b, launches=2, zrange=None):
     import torch
     from fluidx12_amd import build, capi
     capi.load()
-    out = subprocess.run(["nm", "-D", "--defined-only", build.LIB], capture_output=True, text=True, check=True).stdout
+    path = os.environ.get("FLUIDX_LIB_PATH") or build.LIB       # (the library capi loaded: a lab build's switches live in ITS launchers)
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
     names = re.findall(r"\b(_ZN2fx20launch_jacobi_strip4E\w+)", out)
     assert len(names) == 1, names
-    fn = getattr(ctypes.CDLL(build.LIB), names[0])
+    fn = getattr(ctypes.CDLL(path), names[0])
     fn.restype = ctypes.c_int
 
     class Geom(ctypes.Structure):                  # fx_internal.h struct Geom
@@ -343,6 +346,32 @@ def test_any_row_length_four_sweeps_bit_exact(dims):
         rc, got = strip4_direct(dims, p, b)
         assert rc == 0
         assert np.array_equal(got, q), explain(got, q)
+
+
+@pytest.mark.parametrize("dims,piece_min", [((4096, 406, 10), 8), ((4096, 406, 21), 5), ((1024, 1246, 9), 4), ((2048, 700, 13), 3)])
+def test_any_row_length_one_piece_per_workgroup(dims, piece_min, knob):
+    """more (tile, band) pairs than CUs: the launcher hands every workgroup one piece (a band's planes of one z chunk) instead of a run --
+    493 / 445 / 450 bands, one to four chunks, depths the chunks do not divide (the cuts then fall a few planes beside the piece boundaries:
+    any cut gives the same bits); STRIP4T_PIECES (lab builds) lowers the 64 planes a piece must have so that the case fits a test"""
+    knob("STRIP4T_PIECES", str(piece_min))
+    X, Y, Z = dims
+    _, _, p = rand_state(X, Y, Z, 75)
+    b = np.random.default_rng(76).uniform(-1, 1, (Z, Y, X)).astype(f32)
+    q, _ = orc.jacobi(p, b, 4)
+    rc, got = strip4_direct(dims, p, b, launches=1)
+    assert rc == 0 and np.array_equal(got, q), explain(got, q)
+
+
+def test_any_row_length_one_piece_per_workgroup_at_full_depth():
+    """... with the shipped thresholds: 1024 x 1246 x 64 (5 tiles x 89 bands = 445 pieces of 64 planes, 1.7 rounds of 256), four sweeps ==
+    oracle bit for bit"""
+    dims = (1024, 1246, 64)
+    rng = np.random.default_rng(77)
+    p = rng.standard_normal((64, 1246, 1024)).astype(f32)
+    b = rng.uniform(-1, 1, (64, 1246, 1024)).astype(f32)
+    q, _ = orc.jacobi(p, b, 4)
+    rc, got = strip4_direct(dims, p, b, launches=1)
+    assert rc == 0 and np.array_equal(got, q), explain(got, q)
 
 
 @pytest.mark.parametrize("zrange", [(5, 6), (0, 1), (11, 12), (3, 11)])

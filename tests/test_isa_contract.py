@@ -69,24 +69,26 @@ def test_no_scratch_in_the_hot_kernels(tmp_path):
                            ("fx_render_accel.hip", "k_direct_march"), ("fx_jacobi_strip4.hip", "k_jacobi_strip4"), ("fx_jacobi_strip4.hip", "k_freeze_strip4"), ("fx_jacobi_strip3.hip", "k_jacobi_strip3c")):
         text = "\n".join(device_isa(source, tmp_path))
         for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
-            if prefix in m.group(1) and "k_jacobi_strip4x" not in m.group(1):      # (the half-row octet: its own test below)
+            if prefix in m.group(1) and "k_jacobi_strip4x" not in m.group(1) and "k_jacobi_strip4t" not in m.group(1):      # (the half-row and the tiled octet: their own test below)
                 assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", m.group(2)), m.group(1)
 
 
-def test_the_half_row_octet_keeps_its_hot_loops_free_of_scratch(tmp_path):
-    """k_jacobi_strip4x (X = 512) carries four role bodies at 256 registers each; the allocator parks a few values of their PROLOGUES in
-    scratch (< 256 bytes).  What must hold: two waves per SIMD (<= 256 registers), the LDS under 160 KiB, and no scratch instruction inside
-    any of the steady-state loops (three z steps each: 3 or 6 output rows stored per trip)"""
+@pytest.mark.parametrize("kernel,loops", [("k_jacobi_strip4x", 6), ("k_jacobi_strip4t", 3)])
+def test_the_half_row_and_the_tiled_octet_keep_their_hot_loops_free_of_scratch(tmp_path, kernel, loops):
+    """k_jacobi_strip4x (X = 512) carries four role bodies at 256 registers each, k_jacobi_strip4t (any other X > 256) three inside a loop
+    over the pieces of a run; the allocator parks a few values of their PROLOGUES in scratch (< 256 bytes).  What must hold: two waves per
+    SIMD (<= 256 registers), the LDS under 160 KiB, and no scratch instruction inside any of the steady-state loops (three z steps each: 3
+    or 6 output rows stored per trip)"""
     lines = device_isa("fx_jacobi_strip4.hip", tmp_path)
     text = "\n".join(lines)
-    m = [m for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S) if "k_jacobi_strip4x" in m.group(1)]
+    m = [m for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S) if kernel in m.group(1)]
     assert len(m) == 2                                               # <NT = false / true>: plain and non-temporal output stores
     for mm in m:
         body = mm.group(2)
         assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1)) <= 256
         assert int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", body).group(1)) <= 160 * 1024
         assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)) <= 256
-    ks = kernels(lines, "k_jacobi_strip4x")
+    ks = kernels(lines, kernel)
     assert len(ks) == 2
     for code in ks.values():
         labels = {mm.group(1): i for i, ln in enumerate(code) for mm in [re.match(r"^(\.LBB\d+_\d+):", ln)] if mm}
@@ -98,6 +100,6 @@ def test_the_half_row_octet_keeps_its_hot_loops_free_of_scratch(tmp_path):
                 stores = sum(1 for x in seg if x.startswith("global_store_dwordx4"))
                 if stores in (3, 6) and 900 < len(seg) < 1800:
                     hot.append(seg)
-        assert len(hot) >= 6, len(hot)                               # (each of the six role bodies' loops, seen through one or more back edges)
+        assert len(hot) >= loops, len(hot)                           # (each of the role bodies' loops, seen through one or more back edges)
         for seg in hot:
             assert not [x for x in seg if x.startswith("scratch_")]

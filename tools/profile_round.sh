@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root):  tools/profile_round.sh <tag>          e.g.  gpurun -- 'tools/profile_round.sh r06'
 # The measurement set of one round, into gpurun_out/<tag>/ (copy what is to be judged into profiles/<tag>_*):
-#   bench lines     default (config 3), the driver's --steps 20 --warmup 5, configs 2 / 4 / 5, 150^3, the reference's own configuration
+#   bench lines     default (config 3), the driver's --steps 20 --warmup 5, configs 2 / 4 / 5, 150^3, 384^3, 1024^3, the reference's own configuration
 #                   (256^3, 128^3, 150^3), in-process slab groups (shared and peer, N = 2 / 4; config 4 on 8 slabs)
 #   per workload    rocprofv3 --kernel-trace --stats, HBM-side traffic (--pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
 #                   MI355X_MICROARCH.md prescribes: tools/pmc_summary.py) and SQ issue / wait counters (tools/sq_summary.py), every
@@ -32,6 +32,7 @@ prof 256 "--grid 256 --iters 40 --storage fp32" --steps 4 --warmup 1 --config 3
 prof 128 "--grid 128 --iters 40 --storage fp32" --steps 4 --warmup 1 --config 2
 prof 512_80 "--grid 512 --iters 80 --storage fp32" --steps 4 --warmup 1 --config 4
 prof 150 "--grid 150 --iters 40 --storage fp32" --steps 4 --warmup 1 --grid 150
+prof 384 "--grid 384 --iters 40 --storage fp32" --steps 4 --warmup 1 --grid 384
 prof reference "--grid 256 --iters 64 --storage fp16 --mode faithful --steps-profiled 44" --steps 4 --warmup 40 --reference-config
 fi
 render() {  # tag, summary args, bench args...
@@ -57,6 +58,8 @@ python bench.py --config 2 --steps 100 --warmup 16 --no-cpu-baseline > $O/bench_
 python bench.py --config 4 --steps 10 --warmup 3 --no-cpu-baseline --no-render > $O/bench_512_80.json 2>> $O/bench.err
 python bench.py --config 5 --no-cpu-baseline > $O/bench_fp16.json 2>> $O/bench.err
 python bench.py --grid 150 --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_150.json 2>> $O/bench.err
+python bench.py --grid 384 --steps 30 --warmup 10 --no-cpu-baseline --no-render > $O/bench_384.json 2>> $O/bench.err
+python bench.py --grid 1024 --steps 4 --warmup 2 --no-cpu-baseline --no-render --no-developed --no-warm-leg > $O/bench_1024.json 2>> $O/bench.err
 python bench.py --reference-config > $O/bench_reference.json 2>> $O/bench.err
 python bench.py --reference-config --grid 128 --no-cpu-baseline > $O/bench_reference_128.json 2>> $O/bench.err
 python bench.py --reference-config --grid 150 --no-cpu-baseline > $O/bench_reference_150.json 2>> $O/bench.err
