@@ -154,6 +154,18 @@ __device__ __forceinline__ void store_row4nt(char* base, uint32_t off, v4f v)
 	__builtin_nontemporal_store(v, reinterpret_cast<v4f*>(base + off));
 }
 
+// ... of an x tile (Role4::XT): the lanes that are the tile's own x halo store nothing.  Not a branch around the stores (the compiler pulls
+// the last sweep's arithmetic into it and splits the step into blocks: X = 256 through the tiled kernel 9 % behind the octet) but an offset
+// the hardware refuses: the plane as a buffer resource of 2 GiB - 1 bytes, a halo lane's offset beyond it -- the lane's write is dropped.
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ void store_row4xt(char* base, uint32_t off, bool keep, v4f v)
+{
+	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+	const uint32_t o = keep ? off : 0xfffffff0u;
+	__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rs, (int)o, 0, NT ? 2 : 0);
+}
+
 // ---- the reference's own loop (k_freeze_strip4o; CSPoisson.hlsli:8-26: a cell leaves the loop for good once a sweep changes it by less
 // than 1e-3): relax4m of fx_jacobi_stripm.hip on native vectors -- relax4_pairs' sum, kept for the freeze test; nib = the quad's frozen
 // bits on entry, returned updated; a cell frozen on entry keeps its value
@@ -751,9 +763,11 @@ __device__ __forceinline__ void step4(Strip4<R>& st, v4f (&P1)[3][R::N1], v4f (&
 #ifdef FX_S4_NOSTORE
 		if (q < -1000)                                                   // (experiment: the arithmetic stays, the stores never execute)
 #endif
-		if (!R::XT || st.keep) {
 #pragma unroll
-			for (int m = 0; m < NR; ++m) { if (R::NT) store_row4nt(dst_, opaque32q(roff[m + (R::A ? 4 : 1)]), X_[m]); else store_row4(dst_, opaque32q(roff[m + (R::A ? 4 : 1)]), X_[m]); }
+		for (int m = 0; m < NR; ++m) {
+			if (R::XT) store_row4xt<R::NT>(dst_, opaque32q(roff[m + (R::A ? 4 : 1)]), st.keep, X_[m]);
+			else if (R::NT) store_row4nt(dst_, opaque32q(roff[m + (R::A ? 4 : 1)]), X_[m]);
+			else store_row4(dst_, opaque32q(roff[m + (R::A ? 4 : 1)]), X_[m]);
 		}
 		if (MK) frz_out4<R>(st, fz, dst_, X_, m4_, roff);
 	}
@@ -785,9 +799,10 @@ __device__ __forceinline__ void head_stores4(const Strip4<R>& st, const Frz4& fz
 #ifndef FX_S4_NOHEADSTORES
 	constexpr int RB = R::A ? 4 : 1;
 	const v4f zero = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
-	if (!R::XT || st.keep) {
 #pragma unroll
-		for (int m = 0; m < R::NR; ++m) store_row4(st.po_zb, opaque32q(roff[m + RB]), zero);
+	for (int m = 0; m < R::NR; ++m) {
+		if (R::XT) store_row4xt<false>(st.po_zb, opaque32q(roff[m + RB]), st.keep, zero);
+		else store_row4(st.po_zb, opaque32q(roff[m + RB]), zero);
 	}
 	if (MK) {
 		const ptrdiff_t mo_ = (st.po_zb - fz.outA) >> 4;
@@ -1122,9 +1137,11 @@ __device__ __forceinline__ void step4r(Strip4<R>& st, v4f (&I)[3][R::NI], v4f (&
 #ifdef FX_S4_NOSTORE
 		if (q < -1000)
 #endif
-		if (!R::XT || st.keep) {
 #pragma unroll
-			for (int m = 0; m < NR; ++m) { if (R::NT) store_row4nt(dst_, opaque32q(roff[m + 1]), X_[m]); else store_row4(dst_, opaque32q(roff[m + 1]), X_[m]); }
+		for (int m = 0; m < NR; ++m) {
+			if (R::XT) store_row4xt<R::NT>(dst_, opaque32q(roff[m + 1]), st.keep, X_[m]);
+			else if (R::NT) store_row4nt(dst_, opaque32q(roff[m + 1]), X_[m]);
+			else store_row4(dst_, opaque32q(roff[m + 1]), X_[m]);
 		}
 		if (MK) frz_out4<R>(st, fz, dst_, X_, m4_, roff);
 	}
@@ -1360,7 +1377,9 @@ __device__ __host__ __forceinline__ int band_y(int grp, int ngroups, int Y, int 
 __host__ inline bool band_rows_supported(int Y, int BAND) { return Y == BAND || Y >= BAND + 3; }
 
 // The launch's band-planes in the order (z chunk, band, plane): `nch` chunks, chunk i = planes [zc[i], zc[i + 1]) of the launch's range.
-struct Runs4 { int bands, nzp, nch, nwg, minp; int zc[9]; };
+// exact: workgroup k takes piece k (band k % bands of chunk k / bands) and nothing else -- nwg = bands x nch, any number of them.
+constexpr int RUNS4_MAXCH = 32;
+struct Runs4 { int bands, nzp, nch, nwg, minp, exact; int zc[RUNS4_MAXCH + 1]; };
 // position s of that order -> its band, its plane (relative to the range) and the planes left in its piece (a band's planes of one chunk)
 __device__ __forceinline__ void run_locate(const Runs4& r, int s, int& band, int& z, int& left)
 {
@@ -1379,6 +1398,7 @@ __device__ __forceinline__ int run_cut(const Runs4& r, int k)
 {
 	const int T = r.bands * r.nzp;
 	if (k >= r.nwg) return T;
+	if (r.exact) { const int i = k / r.bands; return r.bands * r.zc[i] + (k - i * r.bands) * (r.zc[i + 1] - r.zc[i]); }
 	int s = (int)((long long)k * T / r.nwg), band, z, left;
 	run_locate(r, s, band, z, left);
 	int i = 0;
@@ -1592,8 +1612,8 @@ bool jacobi_strip4_supported(const Geom& g)
 	// the octet takes Y = 14 and any Y >= 17 (bands of 14 rows, shifted where they or their halo would cross the last row: octet_band_y);
 	// the quad (STRIP4_OCTET=0) whole bands of 16; X = 512: the half-row octet, bands of six rows
 	if (g.Zg > 1 && g.X == 512) return FX_KNOB_INT("STRIP4X", 1) && band_rows_supported(g.Y, X_BAND);
-	// any other row of whole quads from 256 cells on: the octet on x tiles (k_jacobi_strip4t); a plane's byte offsets are 32-bit
-	if (g.Zg > 1 && g.X > 256 && (g.X & 3) == 0) return FX_KNOB_INT("STRIP4T", 1) && octet_rows_supported(g.Y) && (uint64_t)g.X * (uint64_t)g.Y < ((uint64_t)1 << 30);
+	// any other row of whole quads from 256 cells on: the octet on x tiles (k_jacobi_strip4t); a plane's byte offsets stay below the 2 GiB of the buffer resource its output rows are stored through
+	if (g.Zg > 1 && g.X > 256 && (g.X & 3) == 0) return FX_KNOB_INT("STRIP4T", 1) && octet_rows_supported(g.Y) && (uint64_t)g.X * (uint64_t)g.Y < ((uint64_t)1 << 29);
 	if (g.Zg <= 1 || g.X != 256) return false;
 	return FX_KNOB_INT("STRIP4_OCTET", 1) ? octet_rows_supported(g.Y) : ((g.Y & 15) == 0 && g.Y >= 16);
 }
@@ -1604,7 +1624,7 @@ hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b
 	if (!jacobi_strip4_supported(g)) return hipErrorNotSupported;
 	const int forced_chunk = FX_KNOB_INT("STRIP4_ZCHUNK", 0);
 	const int remap = FX_KNOB_INT("STRIP_REMAP", 1);
-	if (g.X != 256) {
+	if (g.X != 256 || FX_KNOB_INT("STRIP4T_256", 0)) {              // (STRIP4T_256, lab builds: X = 256 as ONE tile of k_jacobi_strip4t -- the octet with runs instead of a grid of chunks)
 		// one run of band-planes per workgroup, one workgroup (156 KiB of LDS) per CU: 256 runs wherever a run is at least eight planes long
 		const bool tiled = g.X != 512;                                  // k_jacobi_strip4t: a "band" is an x tile of a band of 14 rows
 		const int ntx = tiled ? xtiles(g.X) : 1;
@@ -1621,16 +1641,33 @@ hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b
 		// rounds of 256 best, a piece charged twelve planes of fill; kept to runs where no count fills 85 %.  us per sweep, runs / pieces:
 		// 1024^3 1005-1071 / 758-822 (370 bands x 2 chunks = 740 workgroups, 2.9 rounds), 1024 x 1024 x 512 521 / 423, x 256 243 / 193,
 		// x 128 120 / 106 (two chunks of 64; one of 128: 121), x 64 59.0 / 62.8 (runs stay); 2048 x 2048 x 128 497 / 388.
+		int exact_nch = 0;                                              // > 0: one piece per workgroup, this many z chunks
 		const int piece_min = FX_KNOB_INT("STRIP4T_PIECES", 64);
 		if (forced_wgs <= 0 && r.bands > 256 && piece_min > 0) {
-			int best = 0; double best_score = 0.0;
+			double best_score = 0.0;
 			for (int n = 1; n <= 4 && r.nzp / n >= piece_min; ++n) {
 				const long long P = (long long)r.bands * n;
 				const double occ = (double)P / (double)(((P + 255) / 256) * 256), C = (double)r.nzp / n, score = occ * C / (C + 12.0);
-				if (occ >= 0.85 && score > best_score + 1e-9) { best_score = score; best = n; }
+				if (occ >= 0.85 && score > best_score + 1e-9) { best_score = score; exact_nch = n; }
 			}
-			if (best) r.nwg = r.bands * best;
 		}
+		// Short runs (below 64 planes: grids the Infinity Cache holds) on tiles: the octet's own grid -- 256 / bands z chunks of eight planes
+		// or more, workgroup k = (chunk k / bands, band k % bands): whole pieces, and neighbouring workgroups are neighbouring bands at one
+		// depth.  (X = 256 through this kernel, STRIP4T_256: runs 15.0 us per sweep, this grid ..., k_jacobi_strip4o 11.3.)
+		if (forced_wgs <= 0 && tiled && !exact_nch && r.bands <= 256 && T / 256 < 64 && FX_KNOB_INT("STRIP4T_GRID", 1)) {
+			const int n = std::min(std::max(256 / r.bands, 1), RUNS4_MAXCH);
+			const int zc = std::min(std::max((r.nzp + n - 1) / n, 8), r.nzp), nch = (r.nzp + zc - 1) / zc;
+			if (r.bands * nch >= 205) exact_nch = nch;                     // (at least 80 % of the CUs: 640 x 640 x 64 -- 138 bands, one chunk -- runs 23.4, this grid 29.9)
+		}
+		r.exact = 0;
+		if (exact_nch) {
+			const int C = (r.nzp + exact_nch - 1) / exact_nch;
+			r.nch = 0;
+			for (int z = 0; z < r.nzp; z += C) r.zc[r.nch++] = z;
+			for (int i = r.nch; i <= RUNS4_MAXCH; ++i) r.zc[i] = r.nzp;
+			r.nwg = r.bands * r.nch; r.exact = 1;
+			r.minp = 1;
+		} else {
 		r.nwg = std::max(r.nwg, (r.bands + 5) / 6);                     // a run spans at most six bands (+ a head): at most seven pieces (the kernel lists eight)
 		r.minp = std::min(FX_KNOB_INT("STRIP4X_MINP", 8), std::max(r.nzp / 2, 1));
 		// chunks as long as a run (so that a chunk's runs are its bands), the last one shorter; a stub of a last chunk joins its neighbour;
@@ -1645,7 +1682,8 @@ hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b
 		for (int z = 0; z < r.nzp; z += C) r.zc[r.nch++] = z;
 		if (r.nch > 1 && r.nzp - r.zc[r.nch - 1] < std::max(C / 3, r.minp)) --r.nch;
 		r.zc[r.nch] = r.nzp;
-		for (int i = r.nch + 1; i < 9; ++i) r.zc[i] = r.nzp;
+		for (int i = r.nch + 1; i <= RUNS4_MAXCH; ++i) r.zc[i] = r.nzp;
+		}
 		// p + b beyond the Infinity Cache (320 MiB at 40 M cells): the output as non-temporal stores
 		if (tiled) {
 			if (g.cells_local() >= ((size_t)40 << 20) && FX_KNOB_INT("STRIP4X_NT", 1))

@@ -97,7 +97,7 @@ def test_the_half_row_and_the_tiled_octet_keep_their_hot_loops_free_of_scratch(t
             mm = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", ln)
             if mm and mm.group(1) in labels and labels[mm.group(1)] < i:
                 seg = [x for x in code[labels[mm.group(1)]:i + 1] if x and not x.startswith((".", ";"))]
-                stores = sum(1 for x in seg if x.startswith("global_store_dwordx4"))
+                stores = sum(1 for x in seg if x.startswith(("global_store_dwordx4", "buffer_store_dwordx4")))
                 if stores in (3, 6) and 900 < len(seg) < 1800:
                     hot.append(seg)
         assert len(hot) >= loops, len(hot)                           # (each of the role bodies' loops, seen through one or more back edges)
