@@ -1626,7 +1626,11 @@ hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b
 	const int remap = FX_KNOB_INT("STRIP_REMAP", 1);
 	if (g.X != 256 || FX_KNOB_INT("STRIP4T_256", 0)) {              // (STRIP4T_256, lab builds: X = 256 as ONE tile of k_jacobi_strip4t -- the octet with runs instead of a grid of chunks)
 		// one run of band-planes per workgroup, one workgroup (156 KiB of LDS) per CU: 256 runs wherever a run is at least eight planes long
-		const bool tiled = g.X != 512;                                  // k_jacobi_strip4t: a "band" is an x tile of a band of 14 rows
+		const bool tiled = g.X != 512 || (octet_rows_supported(g.Y) && (z_end - z_begin) <= FX_KNOB_INT("STRIP4T_512", 96));
+		// k_jacobi_strip4t: a "band" is an x tile of a band of 14 rows.  X = 512 over a thin range of planes (a slab rank's face zones and
+		// shrinking rounds) as THREE x tiles: 768 cells computed for 512, but whole pieces on the octet's grid instead of runs of 1.3 six-row
+		// bands -- us per sweep k_jacobi_strip4x / tiles at 512 x 512 x D: 16 7.1 / 6.1, 32 11.0 / 9.6, 64 16.4 / 15.7, 96 22.9 / 22.4,
+		// 128 29.1 / 29.4, 256 51.0 / 54.4
 		const int ntx = tiled ? xtiles(g.X) : 1;
 		Runs4 r;
 		r.bands = tiled ? ntx * ((g.Y + O_BAND - 1) / O_BAND) : (g.Y + X_BAND - 1) / X_BAND; r.nzp = z_end - z_begin;
