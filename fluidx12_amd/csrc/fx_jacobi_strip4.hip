@@ -1655,12 +1655,12 @@ hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b
 				if (occ >= 0.85 && score > best_score + 1e-9) { best_score = score; exact_nch = n; }
 			}
 		}
-		// Short runs (below 64 planes: grids the Infinity Cache holds) on tiles: the octet's own grid -- 256 / bands z chunks of eight planes
+		// Short runs (below 64 planes: grids the Infinity Cache holds) on tiles: the octet's own grid -- 256 / bands z chunks of four planes
 		// or more, workgroup k = (chunk k / bands, band k % bands): whole pieces, and neighbouring workgroups are neighbouring bands at one
 		// depth.  (X = 256 through this kernel, STRIP4T_256: runs 15.0 us per sweep, this grid ..., k_jacobi_strip4o 11.3.)
 		if (forced_wgs <= 0 && tiled && !exact_nch && r.bands <= 256 && T / 256 < 64 && FX_KNOB_INT("STRIP4T_GRID", 1)) {
 			const int n = std::min(std::max(256 / r.bands, 1), RUNS4_MAXCH);
-			const int zc = std::min(std::max((r.nzp + n - 1) / n, 8), r.nzp), nch = (r.nzp + zc - 1) / zc;
+			const int zc = std::min(std::max((r.nzp + n - 1) / n, 4), r.nzp), nch = (r.nzp + zc - 1) / zc;
 			if (r.bands * nch >= 205) exact_nch = nch;                     // (at least 80 % of the CUs: 640 x 640 x 64 -- 138 bands, one chunk -- runs 23.4, this grid 29.9)
 		}
 		r.exact = 0;
@@ -1714,7 +1714,11 @@ hipError_t launch_jacobi_strip4(const Geom& g, const float* p_in, const float* b
 		int nch = 256 / bands;                                          // one workgroup of eight waves per CU
 		if (nch < 1) nch = 1;
 		int zc = forced_chunk > 0 ? forced_chunk : (nzp + nch - 1) / nch;
-		if (zc < 8) zc = 8;
+		// (chunks of four planes or more -- a forced chunk is taken as given.  The floor was eight until round 6: thin ranges left CUs idle --
+		// us per sweep at 256 x 256 x D, floor 8 / 4: D = 16 4.72 / 3.97 (38 / 76 workgroups), 32 4.93 / 3.96, 64 5.24 / 5.02 (chunks of five); from 96 alike.
+		// Chunks of two or three planes: level or worse, and more workgroups than CUs much worse -- 64 planes in chunks of four: 7.2)
+		const int zfloor = FX_KNOB_INT("STRIP4_ZFLOOR", 4);
+		if (zc < zfloor && forced_chunk <= 0) zc = zfloor;
 		if (zc > nzp) zc = nzp;
 		nch = (nzp + zc - 1) / zc;
 		hipLaunchKernelGGL(k_jacobi_strip4o, dim3(bands * nch), dim3(512), 0, s, g, p_in, b, p_out, z_begin, z_end, zc, bands, nch, remap);

@@ -1038,11 +1038,15 @@ bool jacobi_prefers_four(const Geom& g, int requested, int nzp)
 	const int forced = FX_KNOB_INT("JACOBI_T", 0);
 	const int prefer = FX_KNOB_INT("JACOBI_PREFER4", 1);
 	const bool octet = FX_KNOB_INT("STRIP4_OCTET", 1) != 0;
-	if (g.X == 512)                                                     // k_jacobi_strip4x: wherever the threes pay (jacobi_prefers_three)
-		return prefer && !requested && !forced && jacobi_strip4_supported(g) && (size_t)g.X * g.Y * (size_t)nzp >= ((size_t)1 << 24);
+	if (g.X == 512)                                                     // k_jacobi_strip4x from 96 planes; below, three x tiles of the octet (k_jacobi_strip4t) from SIX planes --
+		// us per sweep at 512 x 512 x D, the round-5 schedule (ones below 16 planes, twos) / fours: 4 6.9 / 9.6, 6 7.0 / 4.9, 8 7.7 / 4.9, 12 10.1 / 5.5,
+		// 16 10.2 / 6.3, 32 12.2 / 9.3, 48 15.8 / 12.3 (rows the octet's bands cannot be placed on, Y = 15, 16: from 64 planes, k_jacobi_strip4x)
+		return prefer && !requested && !forced && jacobi_strip4_supported(g) && (size_t)g.X * g.Y * (size_t)nzp >= (g.Y >= 17 ? (size_t)3 << 19 : (size_t)1 << 24);
 	if (g.X != 256)                                                     // k_jacobi_strip4t (x tiles of the octet): see the table at jacobi_tiled_four_from
 		return prefer && !requested && !forced && jacobi_strip4_supported(g) && (size_t)g.X * g.Y * (size_t)nzp >= jacobi_tiled_four_from();
-	return prefer && !requested && !forced && jacobi_strip4_supported(g) && (size_t)g.X * g.Y * (size_t)nzp >= (octet ? (size_t)3 << 19 : (size_t)9 << 20);
+	return prefer && !requested && !forced && jacobi_strip4_supported(g) && (size_t)g.X * g.Y * (size_t)nzp >= (octet ? (size_t)3 << 17 : (size_t)9 << 20);
+	// (the octet from SIX planes of 256 x 256 since its z chunks may be four planes short -- round 6, us per sweep in ones / fours: D = 6 3.88 / 3.33,
+	// 8 4.30 / 3.48, 12 4.79 / 3.90, 16 5.33 / 3.96, 20 5.58 / 3.87; with chunks of eight or more the fours started at 24 planes)
 }
 
 // Default schedule of the serial rounds (single domain, and slab ranks thick enough): THREE sweeps per launch (k_jacobi_strip3) where that kernel exists and the grid is large
