@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 3000 python -m pytest tests -m gpu -q --timeout=900 -x 2>&1 | grep -E "passed|failed|Error|error" | tail -5
-python bench.py --config 4 --loopback 8 --group shared --steps 6 --warmup 2 --no-cpu-baseline --no-render --no-developed 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('loopback8 config4', d['ms_per_step'], d['stage_ms_per_step'], d.get('multi_rank_parity'), d['config']['schedule']['overlap'], d['config']['schedule']['jacobi_round'])"
+export FLUIDX_LIB_PATH=tools/_variants/libfluidx_hip_lab.so
+for g in 384 264 320; do echo "== long run $g"; timeout 1200 python tools/long_run_parity.py $g 200 fp32 2>&1 | tail -3 | cut -c1-160; done
+echo "== long run 256"; timeout 1200 python tools/long_run_parity.py 256 300 fp32 2>&1 | tail -3 | cut -c1-160
+echo "== long run 384 fp16"; timeout 1200 python tools/long_run_parity.py 384 100 fp16 2>&1 | tail -2 | cut -c1-160
