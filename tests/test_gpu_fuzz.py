@@ -34,9 +34,28 @@ def draw_single(seed):
                 scale=float(rng.choice([0.2, 1.0, 3.0])), rng=rng)
 
 
+def draw_wide(seed):
+    """rows of 256 cells and more, a few planes deep: the four-sweep band kernels on thin ranges (k_jacobi_strip4o from six planes,
+    k_jacobi_strip4t's x tiles -- 512 cells as three of them below 96 planes --, chunks of four planes, remainders in threes, twos, ones)"""
+    rng = np.random.default_rng(9000 + seed)
+    S = int(rng.choice([256, 256, 260, 264, 288, 320, 384, 512, 512, 516]))
+    Z = int(rng.integers(2, 25))
+    return dict(dims=(S, S, Z), storage=str(rng.choice(["fp32", "fp16"])), address=str(rng.choice(["clamp", "mirror"])),
+                mode=str(rng.choice(["fixed", "fixed", "faithful"])), iters=int(rng.integers(1, 18)), fuse=int(rng.choice([0, 0, 1, 2, 3, 4])),
+                scale=float(rng.choice([0.2, 1.0, 3.0])), rng=rng)
+
+
+@pytest.mark.parametrize("seed", range(SOAK // 8 or 10))
+def test_random_wide_step_matches_oracle(seed):
+    check_random_step(draw_wide(seed))
+
+
 @pytest.mark.parametrize("seed", range(SOAK or 24))
 def test_random_step_matches_oracle(seed):
-    c = draw_single(seed)
+    check_random_step(draw_single(seed))
+
+
+def check_random_step(c):
     X, Y, Z = c["dims"]
     rng = c["rng"]
     half = c["storage"] == "fp16"
@@ -101,9 +120,33 @@ def draw_slabs(seed):
                 rnd=int(rng.integers(1, hj + 1)), steps=int(rng.integers(2, 5)))
 
 
+def draw_wide_slabs(seed):
+    """... on rows of 256 cells and more: thin slabs whose rounds run the four-sweep band kernels on shrinking ranges of a few planes"""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(2, 4))
+    hj = int(rng.integers(1, 9))
+    ha = int(rng.integers(6, 11))
+    H = max(hj, ha)
+    sizes = [H + int(rng.integers(0, 12)) for _ in range(n)]
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    S = int(rng.choice([256, 264, 320, 512]))
+    return dict(dims=(S, S, int(cuts[-1])), slabs=[(int(cuts[i]), int(sizes[i])) for i in range(n)], hj=hj, ha=ha,
+                storage=str(rng.choice(["fp32", "fp16"])), mode=str(rng.choice(["fixed", "fixed", "fixed", "faithful"])),
+                iters=int(rng.integers(2, 21)), fuse=int(rng.choice([0, 0, 1, 2, 3, 4])), overlap=int(rng.integers(0, 4)),
+                rnd=int(rng.integers(1, hj + 1)), steps=int(rng.integers(2, 4)))
+
+
+@pytest.mark.parametrize("seed", range(SOAK // 8 or 10))
+def test_random_wide_slab_decomposition_is_bit_identical(seed):
+    check_random_slabs(draw_wide_slabs(seed))
+
+
 @pytest.mark.parametrize("seed", range(SOAK or 24))
 def test_random_slab_decomposition_is_bit_identical(seed):
-    c = draw_slabs(seed)
+    check_random_slabs(draw_slabs(seed))
+
+
+def check_random_slabs(c):
     kw = dict(storage=c["storage"], jacobi_mode=c["mode"], jacobi_iters=c["iters"])
     ref = fx.Fluid()
     assert ref.Init(800, 800, c["dims"], jacobi_fuse=1, **kw), (c, ref.last_status)
