@@ -36,7 +36,11 @@ int exchange_items(fx_ctx* c, int which_set, int k, int pidx, ExchItem out[4])
 		out[0] = ExchItem{ (char*)c->b, plane * 4, 1, k, nullptr };
 		return 1;
 	case EX_PRESSURE:
-		out[0] = ExchItem{ (char*)c->p[pidx & 1], plane * 4, 1, k, nullptr };
+		// the member's OWN current buffer: the members of an in-process group may have taken different numbers of launches for the
+		// same sweeps (a 12-plane slab runs fours where its 8-plane neighbour runs ones), so the lead's index is not theirs.
+		// (A rank of an RCCL chain is its own lead: pidx == c->p_cur there.  Found by the wide-row slab fuzz of round 6.)
+		(void)pidx;
+		out[0] = ExchItem{ (char*)c->p[c->p_cur & 1], plane * 4, 1, k, nullptr };
 		if (!c->frozen) return 1;
 		out[1] = ExchItem{ (char*)c->frozen, plane, 1, k, nullptr };      // the neighbour's freeze state travels with its pressure
 		return 2;

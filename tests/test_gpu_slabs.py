@@ -231,6 +231,38 @@ def test_thick_slabs_take_the_three_sweep_kernel(dims, overlap):
     assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
 
 
+@pytest.mark.parametrize("dims,slabs,hj,ha,iters,rnd", [((320, 320, 20), [(0, 12), (12, 8)], 6, 7, 11, 4), ((256, 256, 14), [(0, 9), (9, 5)], 4, 5, 8, 4),
+                                                    ((512, 512, 13), [(0, 8), (8, 5)], 5, 5, 10, 5), ((264, 264, 26), [(0, 17), (17, 9)], 7, 7, 19, 4)])
+def test_neighbours_that_take_different_launches_for_the_same_sweeps(dims, slabs, hj, ha, iters, rnd):
+    """the serial schedule lets every member of a group compose a round from the launches ITS slab prefers: 12 planes of 320 x 320 run
+    fours where the 8-plane neighbour runs single sweeps, and the two end a round in different pressure buffers.  The pressure exchange
+    takes every member's own current buffer (it took the lead's index for all of them: found by the wide-row slab fuzz of round 6 --
+    in-process groups only, a rank of an RCCL chain is its own lead); bit-identical to the single domain"""
+    ref = fx.Fluid()
+    assert ref.Init(800, 800, dims, jacobi_iters=iters, jacobi_fuse=1)
+    fl = []
+    for z0, nz in slabs:
+        f = fx.Fluid()
+        assert f.Init(800, 800, dims, slab=(z0, nz), halo_advect=ha, halo_jacobi=hj, jacobi_iters=iters), f.last_status
+        fl.append(f)
+    fx.comm_init_local(fl)
+    from fluidx12_amd import capi
+    for f in fl:
+        f.set_option(capi.OPT_OVERLAP, 0)
+        f.set_option(capi.OPT_JACOBI_ROUND, rnd)
+    fl[0].timing_enable(True); fl[1].timing_enable(True)
+    dt = f32(ref.default_time_step())
+    for k in range(3):
+        ref.UpdateFrame(dt, k % 3); ref.Simulate(k % 3)
+        fl[0].UpdateFrame(dt, k % 3); fl[0].Simulate(k % 3)
+    ref.Synchronize(); fl[0].Synchronize()
+    launches = [f.timing_read().jacobi_launches for f in fl]
+    assert launches[0] != launches[1], launches                      # the case this test is about
+    assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
+    assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
+    assert np.abs(ref.download(fx.FIELD_PRESSURE)).max() > 0
+
+
 def test_halo_overflow_is_reported():
     """a back-trace that leaves the exchanged halo must be reported, not silently clamped"""
     dims = (32, 32, 32)
