@@ -1,3 +1,4 @@
+"""the wide-row slab fuzz of tests/test_gpu_fuzz.py over 500 seeds, every failing configuration printed in full (pytest abbreviates them)"""
 import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np
