@@ -39,10 +39,25 @@ def draw_wide(seed):
     k_jacobi_strip4t's x tiles -- 512 cells as three of them below 96 planes --, chunks of four planes, remainders in threes, twos, ones)"""
     rng = np.random.default_rng(9000 + seed)
     S = int(rng.choice([256, 256, 260, 264, 288, 320, 384, 512, 512, 516]))
-    Z = int(rng.integers(2, 25))
+    Z = 1 if rng.random() < 0.12 else int(rng.integers(2, 25))
     return dict(dims=(S, S, Z), storage=str(rng.choice(["fp32", "fp16"])), address=str(rng.choice(["clamp", "mirror"])),
                 mode=str(rng.choice(["fixed", "fixed", "faithful"])), iters=int(rng.integers(1, 18)), fuse=int(rng.choice([0, 0, 1, 2, 3, 4])),
                 scale=float(rng.choice([0.2, 1.0, 3.0])), rng=rng)
+
+
+def draw_deep(seed):
+    """... and 40 to 110 planes deep: where the launchers change their minds (X = 512 as three tiles up to 96 planes, runs or the octet's
+    grid of whole pieces by the planes per CU, z chunks by the depth)"""
+    rng = np.random.default_rng(11000 + seed)
+    S = int(rng.choice([256, 264, 320, 384, 512]))
+    Z = int(rng.integers(40, 111))
+    return dict(dims=(S, S, Z), storage="fp32", address=str(rng.choice(["clamp", "mirror"])), mode="fixed", iters=int(rng.integers(4, 10)),
+                fuse=int(rng.choice([0, 0, 0, 4])), scale=float(rng.choice([0.2, 1.0])), rng=rng)
+
+
+@pytest.mark.parametrize("seed", range(SOAK // 40 or 6))
+def test_random_deep_wide_step_matches_oracle(seed):
+    check_random_step(draw_deep(seed))
 
 
 @pytest.mark.parametrize("seed", range(SOAK // 8 or 10))
