@@ -55,7 +55,7 @@ int exchange_items(fx_ctx* c, int which_set, int k, int pidx, ExchItem out[4])
 		out[1] = ExchItem{ (char*)c->fz_x_m, (size_t)((c->g.X + 3) / 4) * c->g.Y, 1, k, nullptr };
 		return 2;
 	case EX_PRESSURE_FACE:
-		out[0] = ExchItem{ (char*)c->p_face[(pidx >> 1) & 1], plane * 4, 1, k, (char*)c->p[pidx & 1] };
+		out[0] = ExchItem{ (char*)c->p_face[(pidx >> 1) & 1], plane * 4, 1, k, (char*)c->p[(c->p_cur ^ pidx) & 1] };   // bit 0: relative to the member's current buffer
 		return 1;
 	}
 	return 0;

@@ -592,7 +592,11 @@ static int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t 
 		for (int left = cnt - (cnt / t) * t; left > 0;) { const int p = legal_sweeps(lead, left); parts.push_back(p); left -= p; }
 		for (int j = 0; j < cnt / t; ++j) parts.push_back(t);
 		const int m = (int)parts.size();
-		const int src = lead->p_cur, fin = src ^ (m & 1);
+		// (every member from ITS OWN current buffer: members that ran serial rounds before -- the schedule is an option at run time -- may
+		// hold their pressure in different buffers; SRC / FIN below are per member)
+		const int flip = m & 1;
+#define FX_SRC(c_) ((c_)->p_cur)
+#define FX_FIN(c_) ((c_)->p_cur ^ flip)
 		int fbuf = 0;                                      // which scratch buffer holds the chain's last level (set below)
 		// ---- face stream: the chain (needs the previous round's interior + face copy, and its exchange)
 		FX_LANES(FX_HIP(hipStreamWaitEvent(L.lane->face, L.lane->ev_int, 0)); if (in_flight) FX_HIP(hipStreamWaitEvent(L.lane->face, L.lane->ev_done, 0)););
@@ -606,7 +610,7 @@ static int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t 
 					if (!has_lower(mctx) && !has_upper(mctx)) continue;
 					DeviceGuard dg(mctx->device);
 					const Range o = owned(mctx);
-					const float* in = grp_i == 0 ? mctx->p[src] : mctx->p_face[grp_i & 1];
+					const float* in = grp_i == 0 ? mctx->p[FX_SRC(mctx)] : mctx->p_face[grp_i & 1];
 					const Range lo{ o.lo - rem, has_lower(mctx) ? o.lo + k + rem : o.lo - rem };
 					const Range hi{ has_upper(mctx) ? o.hi - k - rem : o.hi + rem, o.hi + rem };
 					FX_HIP(launch_jacobi_sweep2(mctx->g, in, mctx->b, mctx->p_face[ob], nullptr, lo.lo, lo.hi, hi.lo, hi.hi, grp->lane_of(mctx).face));
@@ -617,7 +621,7 @@ static int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t 
 		}
 		// ---- comm stream: the k final planes of the chain travel, the neighbour's land in the halo of p[fin]
 		FX_LANES(FX_HIP(hipEventRecord(L.lane->ev_ready, L.lane->face)); FX_HIP(hipStreamWaitEvent(L.lane->comm, L.lane->ev_ready, 0)););
-		const ExchSpec pspec{ EX_PRESSURE_FACE, k, (fbuf << 1) | fin };
+		const ExchSpec pspec{ EX_PRESSURE_FACE, k, (fbuf << 1) | flip };      // (bit 0: the receiving buffer relative to the member's current one)
 		if ((rc = do_exchange(lead, M, &pspec, 1, ON_COMM, s))) return rc;
 		if ((rc = comm_mark_done(lead, M, s))) return rc;
 		in_flight = true;
@@ -625,7 +629,7 @@ static int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t 
 		for (fx_ctx* mctx : M) {
 			ScopedMark mk(mctx, CS(mctx, s), MK_JACOBI);
 			const Range o = owned(mctx);
-			int lvl = 0, cur = src;
+			int lvl = 0, cur = FX_SRC(mctx);
 			for (int j = 0; j < m; ++j) {
 				const int tj = parts[j];
 				lvl += tj;
@@ -646,16 +650,18 @@ static int jacobi_overlapped(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t 
 			const size_t pl = mctx->g.plane(), kb = (size_t)k * pl * 4;
 			const Range o = owned(mctx);
 			if (has_lower(mctx))
-				FX_HIP(launch_copy_bytes(mctx->p[fin] + (size_t)mctx->g.lz(o.lo) * pl, mctx->p_face[fbuf] + (size_t)mctx->g.lz(o.lo) * pl, kb, CS(mctx, s)));
+				FX_HIP(launch_copy_bytes(mctx->p[FX_FIN(mctx)] + (size_t)mctx->g.lz(o.lo) * pl, mctx->p_face[fbuf] + (size_t)mctx->g.lz(o.lo) * pl, kb, CS(mctx, s)));
 			if (has_upper(mctx))
-				FX_HIP(launch_copy_bytes(mctx->p[fin] + (size_t)mctx->g.lz(o.hi - k) * pl, mctx->p_face[fbuf] + (size_t)mctx->g.lz(o.hi - k) * pl, kb, CS(mctx, s)));
-			mctx->p_cur = fin;
+				FX_HIP(launch_copy_bytes(mctx->p[FX_FIN(mctx)] + (size_t)mctx->g.lz(o.hi - k) * pl, mctx->p_face[fbuf] + (size_t)mctx->g.lz(o.hi - k) * pl, kb, CS(mctx, s)));
+			mctx->p_cur = FX_FIN(mctx);
 		}
 		FX_LANES(FX_HIP(hipEventRecord(L.lane->ev_int, L.compute)););
 		done += cnt;
 	}
 	if (in_flight) rc = comm_join(lead, M, s);
 	return rc;
+#undef FX_SRC
+#undef FX_FIN
 }
 
 int jacobi_all(fx_ctx* lead, std::vector<fx_ctx*>& M, hipStream_t s, uint32_t iters)

@@ -263,6 +263,36 @@ def test_neighbours_that_take_different_launches_for_the_same_sweeps(dims, slabs
     assert np.abs(ref.download(fx.FIELD_PRESSURE)).max() > 0
 
 
+def test_switching_to_the_overlapped_schedule_after_the_members_buffers_diverged():
+    """... and when a step ends with the members' pressures in different buffers (12 sweeps in rounds of 4: three launches of four on the
+    12-plane slab, twelve single sweeps on its 8-plane neighbour), the overlapped schedule -- an option at run time -- starts every
+    member's round from ITS buffer (it took the lead's for all)"""
+    dims, slabs = (320, 320, 20), [(0, 12), (12, 8)]
+    ref = fx.Fluid()
+    assert ref.Init(800, 800, dims, jacobi_iters=12, jacobi_fuse=1)
+    fl = []
+    for z0, nz in slabs:
+        f = fx.Fluid()
+        assert f.Init(800, 800, dims, slab=(z0, nz), halo_advect=7, halo_jacobi=6, jacobi_iters=12), f.last_status
+        fl.append(f)
+    fx.comm_init_local(fl)
+    from fluidx12_amd import capi
+    dt = f32(ref.default_time_step())
+    k = 0
+    for overlap, rnd, steps in ((0, 4, 1), (2, 2, 2), (0, 4, 1), (3, 2, 2)):
+        for f in fl:
+            f.set_option(capi.OPT_OVERLAP, overlap)
+            f.set_option(capi.OPT_JACOBI_ROUND, rnd)
+        for _ in range(steps):
+            ref.UpdateFrame(dt, k % 3); ref.Simulate(k % 3)
+            fl[0].UpdateFrame(dt, k % 3); fl[0].Simulate(k % 3)
+            k += 1
+        ref.Synchronize(); fl[0].Synchronize()
+        assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE)), (overlap, rnd)
+    assert np.array_equal(gather(fl, fx.FIELD_VELOCITY, 1), ref.download(fx.FIELD_VELOCITY))
+    assert np.abs(ref.download(fx.FIELD_PRESSURE)).max() > 0
+
+
 def test_halo_overflow_is_reported():
     """a back-trace that leaves the exchanged halo must be reported, not silently clamped"""
     dims = (32, 32, 32)
