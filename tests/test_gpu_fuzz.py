@@ -175,7 +175,13 @@ def check_random_slabs(c):
         f.set_option(capi.OPT_OVERLAP, c["overlap"])
         f.set_option(capi.OPT_JACOBI_ROUND, c["rnd"])
     dt = f32(ref.default_time_step())
+    rng2 = np.random.default_rng(c["hj"] * 131 + c["iters"] * 17 + c["dims"][2])
     for k in range(c["steps"]):
+        if k and rng2.random() < 0.5:                      # the schedule is an option at run time: whatever the steps before left behind must serve the next one
+            o2, r2 = int(rng2.integers(0, 4)), int(rng2.integers(1, c["hj"] + 1))
+            for f in fl:
+                f.set_option(capi.OPT_OVERLAP, o2)
+                f.set_option(capi.OPT_JACOBI_ROUND, r2)
         ref.UpdateFrame(dt, k % 3)
         ref.Simulate(k % 3)
         fl[0].UpdateFrame(dt, k % 3)
