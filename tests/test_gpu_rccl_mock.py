@@ -40,7 +40,9 @@ def launch(nranks, script_args, mock_lib, tmp_path, timeout=600):
 
 
 @pytest.mark.parametrize("nranks,dims,halo_j,storage", [(2, "64x64x64", 8, "fp32"), (3, "64x64x96", 4, "fp32"),
-                                                       (4, "64x64x128", 8, "fp16")])
+                                                       (4, "64x64x128", 8, "fp16"),
+                                                       # rows the four-sweep band kernels serve, thin slabs: x tiles, the octet's short z chunks, 512 as three tiles
+                                                       (2, "320x320x40", 8, "fp32"), (3, "256x256x48", 5, "fp32"), (2, "512x512x34", 6, "fp32")])
 def test_rank_processes_match_single_domain(nranks, dims, halo_j, storage, mock_lib, tmp_path):
     r, leftovers = launch(nranks, [os.path.join(ROOT, "tests", "mp_slab_worker.py"), dims, "6", "16", str(halo_j), storage],
                           mock_lib, tmp_path)
