@@ -920,7 +920,7 @@ def main():
             sweeps_per_launch = main_sw / main_l
             names = {1: ["k_jacobi_generic"] if (args.mode == "faithful" or GX % 4 or GZ == 1) else ["k_jacobi_v4"],
                      2: (["k_jacobi_strip2h"] if GX == 512 else ["k_jacobi_block2"] if GX == 128 else ["k_jacobi_blockg"] if GX not in (64, 256) else []) + ["k_jacobi_strip2u", "k_jacobi_strip"],
-                     4: ["k_jacobi_strip4x"] if GX == 512 else ["k_jacobi_strip4t"] if GX > 256 else (["k_jacobi_strip4o"] if os.environ.get("FLUIDX_STRIP4_OCTET", "1") != "0" else []) + ["k_jacobi_strip4q"],
+                     4: ["k_jacobi_strip4x"] if GX == 512 else ["k_jacobi_strip4t"] if GX != 256 else (["k_jacobi_strip4o"] if os.environ.get("FLUIDX_STRIP4_OCTET", "1") != "0" else []) + ["k_jacobi_strip4q"],
                      3: (["k_jacobi_strip3h"] if GX == 512 else ["k_jacobi_strip3c"] if (GX == 256 and GY % 8 == 0 and os.environ.get("FLUIDX_STRIP3_COOP", "1") != "0") else []) + ["k_jacobi_strip3", "k_jacobi_strip"]}
             cands = names.get(int(round(sweeps_per_launch)), ["k_jacobi_strip"]) if abs(sweeps_per_launch - round(sweeps_per_launch)) < 1e-9 else ["k_jacobi_strip"]
             tr = None

@@ -1496,7 +1496,10 @@ __global__ __launch_bounds__(512, 2) void k_jacobi_strip4x(const Geom g, const f
 // row inside a launch, so a (tile, band) pair is a "band" of k_jacobi_strip4x's run arithmetic -- the launch's (tile, band)-planes in
 // (z chunk, band, tile, plane) order, one contiguous run per workgroup, pieces walked last first (neighbouring tiles and bands at the same
 // depth on neighbouring CUs: the halo lanes and rows come out of the XCD's L2).
-__device__ __host__ __forceinline__ int xtiles(int X) { return 1 + (X - 256 + 247) / 248; }
+// Rows SHORTER than 256 cells (whole quads) are one tile whose upper lanes are switched off for the whole walk: with EXEC clear a lane
+// loads, computes and stores nothing, and the DPP shift that brings a lane its right-hand neighbour finds no source at the row's last
+// lane and leaves the `old` operand -- the lane's own cell -- in place, exactly as at lane 63 of a full row: the wall costs nothing.
+__device__ __host__ __forceinline__ int xtiles(int X) { return X <= 256 ? 1 : 1 + (X - 256 + 247) / 248; }
 template <bool NT>
 __global__ __launch_bounds__(512, 2) void k_jacobi_strip4t(const Geom g, const float* __restrict__ p_in, const float* __restrict__ b,
 	float* __restrict__ p_out, int z_begin, const Runs4 runs, int ntx, int remap)
@@ -1543,7 +1546,8 @@ __global__ __launch_bounds__(512, 2) void k_jacobi_strip4t(const Geom g, const f
 		const int tx = tb % ntx, yg = octet_band_y(tb / ntx, nby, g.Y);
 		// the tile's first column, and the lanes whose cells it keeps: from where its left neighbour stops (a wall: from the first) to its
 		// last lane but one (a wall: the last)
-		const int x0 = tx == ntx - 1 ? g.X - 256 : 248 * tx;
+		const int x0 = tx == ntx - 1 ? max(g.X - 256, 0) : 248 * tx;
+		const int nl = min(g.X >> 2, 64);                               // lanes that hold cells (all 64 from 256 cells on)
 		const int keep_lo = tx == 0 ? 0 : (248 * (tx - 1) + 252 - x0) >> 2, keep_hi = tx == ntx - 1 ? 63 : 62;
 		const int qs = max(zb - 4, g.zlo);
 		const bool fill = qs == zb - 4;
@@ -1555,9 +1559,11 @@ __global__ __launch_bounds__(512, 2) void k_jacobi_strip4t(const Geom g, const f
 		if (tid < 24) xflag[tid] = fill ? qs + 2 * (tid / 8 + 1) - 1 : qs - 1;
 		for (int i = tid; i < O_XROWS * 64; i += 512) xbuf[i] = zero;
 		__syncthreads();
-		if (wave == 0) run4<TTop>(g, p_in, b, p_out, zb, ze, yg, wave, lane, lds_all, xbuf, xflag, none, nullptr, x0, keep);
-		else if (wave == 7) run4<TBot>(g, p_in, b, p_out, zb, ze, yg + O_BAND - 1, wave, lane, lds_all + TTop::LDS_ROWS * 64, xbuf, xflag, none, nullptr, x0, keep);
-		else run4r<TMid>(g, p_in, b, p_out, zb, ze, yg + 2 * wave - 1, wave, lane, xbuf, xflag, none, nullptr, x0, keep);
+		if (lane < nl) {                                                // (no barrier inside: the waves of a piece meet through the LDS counters)
+			if (wave == 0) run4<TTop>(g, p_in, b, p_out, zb, ze, yg, wave, lane, lds_all, xbuf, xflag, none, nullptr, x0, keep);
+			else if (wave == 7) run4<TBot>(g, p_in, b, p_out, zb, ze, yg + O_BAND - 1, wave, lane, lds_all + TTop::LDS_ROWS * 64, xbuf, xflag, none, nullptr, x0, keep);
+			else run4r<TMid>(g, p_in, b, p_out, zb, ze, yg + 2 * wave - 1, wave, lane, xbuf, xflag, none, nullptr, x0, keep);
+		}
 	}
 }
 
@@ -1613,7 +1619,7 @@ bool jacobi_strip4_supported(const Geom& g)
 	// the quad (STRIP4_OCTET=0) whole bands of 16; X = 512: the half-row octet, bands of six rows
 	if (g.Zg > 1 && g.X == 512) return FX_KNOB_INT("STRIP4X", 1) && band_rows_supported(g.Y, X_BAND);
 	// any other row of whole quads from 256 cells on: the octet on x tiles (k_jacobi_strip4t); a plane's byte offsets stay below the 2 GiB of the buffer resource its output rows are stored through
-	if (g.Zg > 1 && g.X > 256 && (g.X & 3) == 0) return FX_KNOB_INT("STRIP4T", 1) && octet_rows_supported(g.Y) && (uint64_t)g.X * (uint64_t)g.Y < ((uint64_t)1 << 29);
+	if (g.Zg > 1 && (g.X > 256 || (g.X >= 68 && g.X < 256 && g.X != 128)) && (g.X & 3) == 0) return FX_KNOB_INT("STRIP4T", 1) && octet_rows_supported(g.Y) && (uint64_t)g.X * (uint64_t)g.Y < ((uint64_t)1 << 29);
 	if (g.Zg <= 1 || g.X != 256) return false;
 	return FX_KNOB_INT("STRIP4_OCTET", 1) ? octet_rows_supported(g.Y) : ((g.Y & 15) == 0 && g.Y >= 16);
 }

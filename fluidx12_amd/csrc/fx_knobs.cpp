@@ -15,7 +15,7 @@ const char* const kNames[] = {
 	"BLOCK_REMAP", "BLOCK_SHAPE", "DEBUG_NO_COPY",
 	"FREEZE_DENSE_LEVELS", "FREEZE_DENSE_ONE", "FREEZE_FAST", "FREEZE_FUSE_DIV", "FREEZE_NT", "FREEZE_SHRINK", "FREEZE_T", "FREEZE_WGS",
 	"JACOBI2D_TILE", "JACOBI_BLOCK", "JACOBI_BLOCKG", "LIGHT_FILL_DIRTY", "LIGHT_RAY_NT", "LIGHT_RAY_WGS", "PROJECT_V4", "ROW_VW",
-	"STRIP3H_PAIRS", "STRIP3_COOP", "STRIP3_NO512", "STRIP3_OFF", "STRIP3_ZCHUNK", "STRIP4T", "STRIP4T_256", "STRIP4T_512", "STRIP4T_FROM", "STRIP4T_GRID", "STRIP4T_PIECES", "STRIP4X", "STRIP4X_MINP", "STRIP4X_NT", "STRIP4X_ORDER", "STRIP4X_WGS", "STRIP4_OCTET", "STRIP4_ZCHUNK", "STRIP4_ZFLOOR", "STRIP_GENERIC", "STRIP_R", "STRIP_REMAP", "STRIP_WGS", "STRIP_WIDE",
+	"STRIP3H_PAIRS", "STRIP3_COOP", "STRIP3_NO512", "STRIP3_OFF", "STRIP3_ZCHUNK", "STRIP4T", "STRIP4T_256", "STRIP4T_512", "STRIP4T_FROM", "STRIP4T_GRID", "STRIP4T_NARROW", "STRIP4T_NARROW_FROM", "STRIP4T_PIECES", "STRIP4X", "STRIP4X_MINP", "STRIP4X_NT", "STRIP4X_ORDER", "STRIP4X_WGS", "STRIP4_OCTET", "STRIP4_ZCHUNK", "STRIP4_ZFLOOR", "STRIP_GENERIC", "STRIP_R", "STRIP_REMAP", "STRIP_WGS", "STRIP_WIDE",
 	"STRIP_ZCHUNK", "VIEW_ORDER", "VIEW_WGS", "XCD_REMAP",
 #endif
 };

@@ -1043,7 +1043,12 @@ bool jacobi_prefers_four(const Geom& g, int requested, int nzp)
 		// 16 10.2 / 6.3, 32 12.2 / 9.3, 48 15.8 / 12.3 (rows the octet's bands cannot be placed on, Y = 15, 16: from 64 planes, k_jacobi_strip4x)
 		return prefer && !requested && !forced && jacobi_strip4_supported(g) && (size_t)g.X * g.Y * (size_t)nzp >= (g.Y >= 17 ? (size_t)3 << 19 : (size_t)1 << 24);
 	if (g.X != 256)                                                     // k_jacobi_strip4t (x tiles of the octet): see the table at jacobi_tiled_four_from
-		return prefer && !requested && !forced && jacobi_strip4_supported(g) && (size_t)g.X * g.Y * (size_t)nzp >= jacobi_tiled_four_from();
+		// (rows below 256 cells: a tile with its upper lanes switched off -- from 160 cells a row and 3.1 M cells; us per sweep, the block kernel's twos /
+		// fours: 132^3 4.9 / 5.5, 160^3 7.7 / 6.2, 192^3 9.8 / 7.7, 224^3 15.2 / 9.6, 252^3 20.3 / 11.8; 192 x 192 x 48 4.0 / 5.5,
+		// x 80 5.2 / 5.3, x 100 6.5 / 5.8; 224 x 224 x 48 4.1 / 5.6, x 64 5.8 / 5.2; 240 x 240 x 48 4.6 / 5.0, x 64 6.2 / 5.4; 160 x 160 x 100 5.1 / 5.3, x 128 6.1 / 5.9)
+		return prefer && !requested && !forced && jacobi_strip4_supported(g) &&
+			(g.X > 256 ? (size_t)g.X * g.Y * (size_t)nzp >= jacobi_tiled_four_from()
+			           : g.X >= FX_KNOB_INT("STRIP4T_NARROW", 160) && (size_t)g.X * g.Y * (size_t)nzp >= (size_t)FX_KNOB_INT("STRIP4T_NARROW_FROM", 3 << 20));
 	return prefer && !requested && !forced && jacobi_strip4_supported(g) && (size_t)g.X * g.Y * (size_t)nzp >= (octet ? (size_t)3 << 17 : (size_t)9 << 20);
 	// (the octet from SIX planes of 256 x 256 since its z chunks may be four planes short -- round 6, us per sweep in ones / fours: D = 6 3.88 / 3.33,
 	// 8 4.30 / 3.48, 12 4.79 / 3.90, 16 5.33 / 3.96, 20 5.58 / 3.87; with chunks of eight or more the fours started at 24 planes)

@@ -331,6 +331,21 @@ def test_x512_four_sweeps_any_number_of_runs(wgs, knob):
     assert rc == 0 and np.array_equal(got, q), explain(got, q)
 
 
+@pytest.mark.parametrize("dims", [(68, 17, 9), (100, 30, 12), (132, 20, 8), (160, 45, 12), (192, 33, 21), (200, 14, 12), (224, 29, 7), (252, 18, 5)])
+def test_rows_shorter_than_256_cells_four_sweeps_bit_exact(dims):
+    """rows of 68..252 cells (whole quads) as ONE tile of k_jacobi_strip4t with its upper lanes switched off for the whole walk: the
+    row's last lane finds no source for its right-hand neighbour and keeps its own cell -- the wall -- as lane 63 of a full row does;
+    8 = 4 + 4 sweeps == oracle bit for bit, twice.  The launcher directly: any Y."""
+    X, Y, Z = dims
+    _, _, p = rand_state(X, Y, Z, 81)
+    b = np.random.default_rng(82).uniform(-1, 1, (Z, Y, X)).astype(f32)
+    q, _ = orc.jacobi(p, b, 8)
+    for _ in range(2):
+        rc, got = strip4_direct(dims, p, b)
+        assert rc == 0
+        assert np.array_equal(got, q), explain(got, q)
+
+
 @pytest.mark.parametrize("dims", [(260, 17, 9), (264, 30, 12), (320, 20, 21), (384, 45, 12), (500, 14, 12), (504, 33, 7), (508, 18, 5), (516, 29, 12),
                                   (752, 17, 6), (756, 40, 9), (1000, 19, 6), (1024, 31, 10), (2048, 17, 5)])
 def test_any_row_length_four_sweeps_bit_exact(dims):
@@ -577,11 +592,11 @@ def test_errors_and_call_order():
         f.upload(fx.FIELD_PRESSURE, np.zeros((4, 4, 4), f32))
 
 
-@pytest.mark.parametrize("dims,iters,launches", [((384, 384, 40), 40, 10), ((320, 320, 24), 23, 8), ((264, 264, 30), 6, 3)])
+@pytest.mark.parametrize("dims,iters,launches", [((384, 384, 40), 40, 10), ((320, 320, 24), 23, 8), ((264, 264, 30), 6, 3), ((192, 192, 96), 40, 10), ((252, 252, 56), 9, 3)])
 def test_any_row_length_full_step_against_oracle(dims, iters, launches):
     """a grid whose rows are neither 256 nor 512 cells through one whole step, stage by stage against the oracle: the default schedule takes
     FOUR sweeps per launch on x tiles of the octet (k_jacobi_strip4t; 23 sweeps = 5 x 4 + 1 + 1 + 1: these rows have no three- or
-    two-sweep kernel), advection / divergence / projection their general kernels; then fx_simulate as a whole against the staged run"""
+    two-sweep kernel; rows of 192 / 252 cells: one tile with its upper lanes switched off, from 3.1 M cells, 9 sweeps = 4 + 4 + 1), advection / divergence / projection their general kernels; then fx_simulate as a whole against the staged run"""
     X, Y, Z = dims
     rng = np.random.default_rng(384)
     vel = (rng.random((3, Z, Y, X), dtype=f32) - f32(0.5)) * f32(4.0)

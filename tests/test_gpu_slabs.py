@@ -1025,12 +1025,13 @@ def test_peer_group_across_two_devices():
     assert np.array_equal(gather(fl, fx.FIELD_PRESSURE, 0), ref.download(fx.FIELD_PRESSURE))
 
 
+@pytest.mark.parametrize("dims", [(320, 320, 120), (224, 224, 210)])
 @pytest.mark.parametrize("hj,iters,overlap", [(9, 23, 1), (7, 16, 2), (5, 11, 0), (9, 20, 2), (8, 40, 2), (8, 23, 2)])
-def test_slabs_of_any_row_length_take_the_tiled_four_sweep_kernel(hj, iters, overlap):
+def test_slabs_of_any_row_length_take_the_tiled_four_sweep_kernel(hj, iters, overlap, dims):
     """k_jacobi_strip4t (rows of 320 cells: two x tiles) on the trapezoid ranges of slab ranks: three slabs of 320 x 320 x 120, rounds of
     9 / 7 / 5 / 8 sweeps as 1 + 4 + 4, 1 + 1 + 1 + 4, 1 + 4, 4 + 4 (these rows have no three- or two-sweep kernel: the schedule composes a
-    round from launches that exist); bit-identical to one sweep per launch on the single domain"""
-    dims = (320, 320, 120)
+    round from launches that exist); 224 x 224 x 210: rows below 256 cells -- one tile, its upper lanes switched off; bit-identical to one
+    sweep per launch on the single domain"""
     ref = run_single(dims, 2, jacobi_iters=iters, jacobi_fuse=1)
     fl = run_slabs(dims, 2, 3, jacobi_iters=iters, halo_jacobi=hj, halo_advect=8, overlap=overlap)
     fl[0].timing_enable(True); fl[0].timing_read(True)
