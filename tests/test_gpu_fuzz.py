@@ -49,7 +49,7 @@ def draw_deep(seed):
     """... and 40 to 110 planes deep: where the launchers change their minds (X = 512 as three tiles up to 96 planes, runs or the octet's
     grid of whole pieces by the planes per CU, z chunks by the depth)"""
     rng = np.random.default_rng(11000 + seed)
-    S = int(rng.choice([256, 264, 320, 384, 512]))
+    S = int(rng.choice([192, 224, 252, 256, 264, 320, 384, 512]))              # (192..252: one tile with its upper lanes off, from 3.1 M cells)
     Z = int(rng.integers(40, 111))
     return dict(dims=(S, S, Z), storage="fp32", address=str(rng.choice(["clamp", "mirror"])), mode="fixed", iters=int(rng.integers(4, 10)),
                 fuse=int(rng.choice([0, 0, 0, 4])), scale=float(rng.choice([0.2, 1.0])), rng=rng)
